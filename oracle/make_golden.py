@@ -1,0 +1,148 @@
+"""Generate the committed fixtures under tests/golden/ (BUILD-CONTAINER ONLY: reads /root/reference).
+
+Two kinds of fixture, both pure data (inputs + expected outputs):
+
+1. ``ref_test_drt_fit_eis.npz`` -- the known-answer vectors the reference's own test holds
+   (/root/reference/tests/test_drt_fit.py:6-134: 71 frequencies, 71 noisy impedances, expected x / R_inf /
+   inductance / z_sigma_tot / q_vector).  Extracted by parsing the literals out of that file's AST; these
+   numbers were produced by the reference author with the REAL cvxopt, so they pin the oracle's coneqp
+   restatement independently of anything in this repository.
+
+2. ``refrun_*.npz`` -- outputs of the reference itself (hybdrt imported read-only from /root/reference
+   through oracle/refshim, whose only arithmetic substitution is cvxopt.solvers.qp -> oracle/coneqp.py)
+   on seeded synthetic inputs: lookup tables, Z'/Z'' matrices (interp and trapz), penalty matrices, vmm,
+   every QP (P, q, h, x, iterations), per-iteration hyper-parameter history, final fit parameters.
+
+Run:  python -m oracle.make_golden      (from the repo root)
+"""
+import ast
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+OUT = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference"
+
+
+def extract_reference_test_vectors():
+    src = open(os.path.join(REF, "tests", "test_drt_fit.py")).read()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "test_drt_fit_eis")
+    env = {"np": np}
+    for node in fn.body:
+        if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) and \
+                node.targets[0].id in ("freq", "z_noisy", "expected_result"):
+            code = compile(ast.Module(body=[node], type_ignores=[]), "<golden>", "exec")
+            exec(code, env)
+    exp = env["expected_result"]
+    np.savez(os.path.join(OUT, "ref_test_drt_fit_eis.npz"),
+             freq=env["freq"], z=env["z_noisy"], x=exp["x"], R_inf=exp["R_inf"],
+             inductance=exp["inductance"], C_inv=exp["C_inv"], z_sigma_tot=exp["z_sigma_tot"],
+             vz_offset_eps=exp["vz_offset_eps"], q_vector=exp["q_vector"])
+    return env["freq"], env["z_noisy"]
+
+
+def _boot_reference():
+    sys.path.insert(0, os.path.join(HERE, "refshim"))
+    import oracle_boot  # noqa: F401
+    import cvxopt
+    from hybdrt.models import DRT
+    return DRT, cvxopt
+
+
+def _quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def run_case(DRT, cvxopt, name, freq, z, ctor_kw, fit_kw, save_mats=True, save_qps=True, row_stride=1):
+    log = []
+    cvxopt.solvers.options["_oracle_log"] = log
+    with _quiet():
+        drt = DRT(**ctor_kw)
+        drt.fit_eis(freq, z, **fit_kw)
+    cvxopt.solvers.options["_oracle_log"] = None
+    fp, qp = drt.fit_parameters, drt.qphb_params
+    out = dict(freq=freq, z=z, basis_tau=drt.basis_tau, tau_epsilon=drt.tau_epsilon,
+               x=fp["x"], R_inf=fp["R_inf"], inductance=fp["inductance"], z_sigma_tot=fp["z_sigma_tot"],
+               q_vector=fp["q_vector"], x_scaled=np.array(list(drt.cvx_result["x"])),
+               coefficient_scale=drt.coefficient_scale,
+               est_weights=qp["est_weights"], weights=qp["true_weights"], rho_vector=qp["rho_vector"],
+               s_vectors=np.array(qp["s_vectors"]), xmx_norms=qp["xmx_norms"],
+               x_overfit=qp["x_overfit_eis"], qp_iterations=np.array([l["iterations"] for l in log]),
+               outer_iterations=len(drt.qphb_history),
+               hist_x=np.array([h["x"] for h in drt.qphb_history]),
+               hist_rho=np.array([h["rho_vector"] for h in drt.qphb_history]),
+               hist_weights=np.array([h["weights"] for h in drt.qphb_history]),
+               nonneg=fit_kw.get("nonneg", True))
+    if save_mats:
+        lk = drt.interpolate_lookups
+        if lk["z_real"] is not None:
+            out.update(lut_log_wt_re=lk["z_real"][0], lut_z_re=lk["z_real"][1],
+                       lut_log_wt_im=lk["z_imag"][0], lut_z_im=lk["z_imag"][1])
+        zm = drt.fit_matrices["impedance"]
+        out.update(zm_re=zm.real[::row_stride], zm_im=zm.imag[::row_stride], row_stride=row_stride,
+                   m0=drt.fit_matrices["m0"][::row_stride], m1=drt.fit_matrices["m1"][::row_stride],
+                   m2=drt.fit_matrices["m2"][::row_stride], vmm=qp["vmm"][::row_stride],
+                   rm=qp["rm"][::row_stride], rv=qp["rv"])
+    if save_qps:
+        for i, l in enumerate(log):
+            out[f"qp{i}_P"] = l["P"]; out[f"qp{i}_q"] = l["q"]; out[f"qp{i}_h"] = l["h"]
+            out[f"qp{i}_x"] = l["x"]; out[f"qp{i}_pcost"] = l["pcost"]
+        out["p_matrix"] = fp["p_matrix"]
+    np.savez_compressed(os.path.join(OUT, f"refrun_{name}.npz"), **out)
+    print(f"{name}: outer={out['outer_iterations']} qp_iters={out['qp_iterations'].tolist()}")
+
+
+def run_trapz_matrices(name, freq, tau, eps):
+    sys.path.insert(0, os.path.join(HERE, "refshim"))
+    import oracle_boot  # noqa: F401
+    from hybdrt.matrices import mat1d
+    out = dict(freq=freq, tau=tau, eps=eps)
+    for part in ("real", "imag"):
+        out[f"A_{part}"] = mat1d.construct_impedance_matrix(freq, part, tau=tau, epsilon=eps,
+                                                            integrate_method="trapz")
+    np.savez_compressed(os.path.join(OUT, f"refrun_{name}.npz"), **out)
+    print(f"{name}: trapz matrices {out['A_real'].shape}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, REPO)
+    from hipdrt import synth
+
+    freq_g, z_g = extract_reference_test_vectors()
+    DRT, cvxopt = _boot_reference()
+
+    default = dict(fit_inductance=True, fit_capacitance=False, fit_dop=False, fit_ohmic=True)
+    # (1) the reference's own test inputs, with all intermediates
+    run_case(DRT, cvxopt, "golden71x91", freq_g, z_g, default, {})
+    # (2) same inputs, DRT coefficients allowed negative (h = 1e5 branch of make_h_constraint)
+    run_case(DRT, cvxopt, "golden71x91_neg", freq_g, z_g, default, dict(nonneg=False), save_mats=False)
+    # (3) C1 variant: 71 freqs x fixed 121-point tau grid, 2-ZARC seed 0
+    c1 = synth.config_c1()
+    run_case(DRT, cvxopt, "c1_71x121", c1["freq"], synth.zarc2_spectrum(c1["freq"], 0),
+             dict(default, fixed_basis_tau=c1["tau"]), {})
+    # (4) C2: 256 x 512, seeds 0..2 (matrices sub-sampled, no per-QP P's: size)
+    c2 = synth.config_c2()
+    for seed in range(3):
+        run_case(DRT, cvxopt, f"c2_256x512_s{seed}", c2["freq"], synth.zarc2_spectrum(c2["freq"], seed),
+                 dict(default, fixed_basis_tau=c2["tau"]), {}, save_mats=(seed == 0), save_qps=False,
+                 row_stride=16)
+    # (5) batch members (jittered) of the C3/C4 workload, first 4
+    for b in range(4):
+        run_case(DRT, cvxopt, f"c3_member{b}", c2["freq"], synth.zarc2_spectrum(c2["freq"], b, jitter=True),
+                 dict(default, fixed_basis_tau=c2["tau"]), {}, save_mats=False, save_qps=False)
+    # (6) trapz-mode matrices: non-Toeplitz 32 x 64 and Toeplitz 71 x 91
+    run_trapz_matrices("trapz_32x64", np.logspace(4, 0, 32), np.logspace(-6, 1, 64),
+                       1 / np.mean(np.diff(np.log(np.logspace(-6, 1, 64)))))
+    from oracle.drt_oracle import get_basis_tau, get_epsilon_from_ppd
+    run_trapz_matrices("trapz_71x91_toeplitz", freq_g, get_basis_tau(freq_g), get_epsilon_from_ppd(10))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""Pin the oracle (CPU restatement, oracle/) against (1) the reference's own known-answer test vectors and
+(2) outputs of the reference itself captured in the build container (tests/golden/refrun_*.npz).
+CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import drt_oracle as orc
+from oracle.coneqp import coneqp_boxlow
+
+from conftest import GOLDEN
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def test_reference_known_answer_test():
+    """Mirror of /root/reference/tests/test_drt_fit.py: same inputs, same np.allclose criterion."""
+    g = load("ref_test_drt_fit_eis.npz")
+    drt = orc.OracleDRT(fit_inductance=True, fit_ohmic=True)
+    hypers = dict(rp_scale=14, derivative_weights=np.array([1.5, 1.0, 0.5]), sigma_ds=np.array([1, 1000, 1000]),
+                  l1_lambda_0=0, l2_lambda_0=142, s_alpha=np.array([5, 10, 25]),
+                  rho_alpha=np.array([0.15, 0.2, 0.25]), iw_alpha=None, iw_beta=None, s_0=np.ones(3),
+                  rho_0=np.ones(3), outlier_p=None)
+    fp = drt.fit_eis(g["freq"], g["z"], **hypers)
+    for key in ("x", "R_inf", "inductance", "C_inv", "z_sigma_tot", "vz_offset_eps", "q_vector"):
+        assert np.allclose(g[key], fp[key]), key
+    assert fp["v_sigma_tot"] is None and fp["v_sigma_res"] is None
+
+
+def test_lookup_and_matrices_vs_reference_run():
+    g = load("refrun_golden71x91.npz")
+    eps = float(g["tau_epsilon"])
+    assert eps == orc.get_epsilon_from_ppd(10)
+    (lre, zre), (lim, zim) = orc.generate_impedance_lookup(eps)
+    for a, b in ((lre, g["lut_log_wt_re"]), (zre, g["lut_z_re"]), (lim, g["lut_log_wt_im"]), (zim, g["lut_z_im"])):
+        np.testing.assert_array_equal(a, b)
+    tau = orc.get_basis_tau(g["freq"])
+    np.testing.assert_array_equal(tau, g["basis_tau"])
+    assert orc.impedance_matrix_is_toeplitz(g["freq"], tau)
+    zr = orc.construct_impedance_matrix(g["freq"], "real", tau, eps, "interp", interpolate_grids=(lre, zre))
+    zi = orc.construct_impedance_matrix(g["freq"], "imag", tau, eps, "interp", interpolate_grids=(lim, zim))
+    np.testing.assert_array_equal(zr, g["zm_re"])
+    np.testing.assert_array_equal(zi, g["zm_im"])
+    for k in range(3):
+        m = orc.construct_integrated_derivative_matrix(np.log(tau), k, eps)
+        np.testing.assert_array_equal(m, g[f"m{k}"])
+    np.testing.assert_array_equal(orc.construct_eis_var_matrix(g["freq"]), g["vmm"])
+
+
+def test_trapz_matrices_vs_reference_run():
+    for name in ("refrun_trapz_32x64.npz", "refrun_trapz_71x91_toeplitz.npz"):
+        g = load(name)
+        for part in ("real", "imag"):
+            a = orc.construct_impedance_matrix(g["freq"], part, g["tau"], float(g["eps"]), "trapz")
+            np.testing.assert_array_equal(a, g[f"A_{part}"])
+
+
+@pytest.mark.parametrize("name", ["refrun_golden71x91.npz", "refrun_golden71x91_neg.npz", "refrun_c1_71x121.npz"])
+def test_every_qp_vs_reference_run(name):
+    g = load(name)
+    for i in range(len(g["qp_iterations"])):
+        res = coneqp_boxlow(g[f"qp{i}_P"], g[f"qp{i}_q"], g[f"qp{i}_h"])
+        assert res["iterations"] == g["qp_iterations"][i]
+        np.testing.assert_array_equal(res["x"], g[f"qp{i}_x"])
+
+
+def _fit(g, structure="fast"):
+    fixed = None
+    if len(g["basis_tau"]) != len(orc.get_basis_tau(g["freq"])):
+        fixed = g["basis_tau"]
+    drt = orc.OracleDRT(fixed_basis_tau=fixed)
+    drt.fit_eis(g["freq"], g["z"], nonneg=bool(g["nonneg"]), keep_history=True, structure=structure)
+    return drt
+
+
+@pytest.mark.parametrize("name", ["refrun_golden71x91.npz", "refrun_golden71x91_neg.npz", "refrun_c1_71x121.npz",
+                                  "refrun_c2_256x512_s2.npz", "refrun_c3_member2.npz"])
+def test_full_fit_trajectory_vs_reference_run(name):
+    g = load(name)
+    drt = _fit(g)
+    assert [q["iterations"] for q in drt.qp_log] == g["qp_iterations"].tolist()
+    assert len(drt.qphb_history) == int(g["outer_iterations"])
+    tol = dict(rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(np.array([h["x"] for h in drt.qphb_history]), g["hist_x"], **tol)
+    np.testing.assert_allclose(np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], **tol)
+    np.testing.assert_allclose(np.array([h["weights"] for h in drt.qphb_history]), g["hist_weights"], **tol)
+    fp, qp = drt.fit_parameters, drt.qphb_params
+    for key in ("x", "R_inf", "inductance", "z_sigma_tot", "q_vector"):
+        np.testing.assert_allclose(fp[key], g[key], **tol)
+    np.testing.assert_allclose(qp["est_weights"], g["est_weights"], **tol)
+    np.testing.assert_allclose(np.array(qp["s_vectors"]), g["s_vectors"], **tol)
+    np.testing.assert_allclose(qp["xmx_norms"], g["xmx_norms"], **tol)
+    if "p_matrix" in g:
+        np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-7, atol=1e-9)
+
+
+def test_reference_structure_equals_fast():
+    g = load("refrun_golden71x91.npz")
+    a = _fit(g, "fast").fit_parameters
+    b = _fit(g, "reference").fit_parameters
+    np.testing.assert_allclose(a["x"], b["x"], rtol=1e-10, atol=1e-14)

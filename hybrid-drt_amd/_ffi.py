@@ -1,0 +1,368 @@
+"""ctypes binding of libhipdrt.so (C-ABI declared in include/hipdrt.h).  numpy in, numpy out.
+
+There is deliberately no CPU fallback: if the shared library is missing, or no gfx950 device is visible,
+every compute entry point raises ``HipDrtError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhipdrt.so")
+
+MODE_INTERP, MODE_TRAPZ = 0, 1
+QP_OPTIMAL, QP_MAXITER, QP_SINGULAR_LATE, QP_SINGULAR = 0, 1, 2, -1
+
+
+class HipDrtError(RuntimeError):
+    pass
+
+
+class QpOpts(C.Structure):
+    _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("feastol", C.c_double), ("maxiters", C.c_int)]
+
+
+class FitOpts(C.Structure):
+    _fields_ = [
+        ("rp_scale", C.c_double), ("derivative_weights", C.c_double * 3), ("sigma_ds", C.c_double * 3),
+        ("l1_lambda_0", C.c_double), ("l2_lambda_0", C.c_double), ("s_alpha", C.c_double * 3),
+        ("s_0", C.c_double * 3), ("rho_alpha", C.c_double * 3), ("rho_0", C.c_double * 3),
+        ("iw_l1_lambda_0", C.c_double), ("iw_l2_lambda_0", C.c_double),
+        ("ohmic_penalty", C.c_double), ("inductance_penalty", C.c_double), ("inductance_scale", C.c_double),
+        ("eis_vmm_epsilon", C.c_double), ("eis_reim_cor", C.c_double), ("xtol", C.c_double),
+        ("max_iter", C.c_int), ("nonneg", C.c_int), ("scale_data", C.c_int), ("fit_ohmic", C.c_int),
+        ("fit_inductance", C.c_int), ("eis_error_uniform", C.c_int), ("qp", QpOpts),
+    ]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> argtypes (all return int unless listed in _RESTYPES).  Mirrors include/hipdrt.h one-to-one;
+# tests/test_cabi_symbols.py checks the header and this table against the built library.
+SIGNATURES = {
+    "hipdrt_create": [C.c_int, C.POINTER(_vp)],
+    "hipdrt_destroy": [_vp],
+    "hipdrt_last_error": [],
+    "hipdrt_stream": [_vp],
+    "hipdrt_synchronize": [_vp],
+    "hipdrt_device_info": [_vp, C.c_char_p, C.c_int, _ip, C.POINTER(C.c_longlong)],
+    "hipdrt_impedance_lookup": [_vp, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, _dp],
+    "hipdrt_impedance_matrix": [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
+                                C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp],
+    "hipdrt_impedance_matrix_dev": [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
+                                    C.c_int, _dp, _dp, _dp, _dp, C.c_int, _vp, _vp, C.c_int, C.POINTER(C.c_float)],
+    "hipdrt_penalty_matrices": [_vp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp],
+    "hipdrt_eis_var_matrix": [_vp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp],
+    "hipdrt_qp_batch": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.POINTER(QpOpts), _dp, _ip, _dp, _ip],
+    "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
+    "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
+    "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                           _dp, _dp, _dp, _dp, C.POINTER(FitOpts), C.c_int, C.POINTER(_vp)],
+    "hipdrt_plan_destroy": [_vp],
+    "hipdrt_plan_dims": [_vp, _ip, _ip, _ip],
+    "hipdrt_plan_get": [_vp, C.c_char_p, _dp, C.c_longlong],
+    "hipdrt_plan_set_lookup": [_vp, _dp, _dp],
+    "hipdrt_plan_upload": [_vp, C.c_int, _dp, _dp],
+    "hipdrt_plan_fit": [_vp],
+    "hipdrt_plan_download": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip],
+    "hipdrt_plan_get_p_matrix": [_vp, C.c_int, _dp],
+    "hipdrt_plan_record_history": [_vp, C.c_int],
+    "hipdrt_plan_get_history": [_vp, _dp, _dp, _dp, _ip, C.c_int, _ip],
+    "hipdrt_plan_timings": [_vp, C.POINTER(C.c_float), _ip],
+    "hipdrt_fit_eis_batch": [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int,
+                             C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(FitOpts), _dp, _dp, _dp, _dp,
+                             _dp, _dp, _dp, _dp, _ip, _ip],
+}
+_RESTYPES = {"hipdrt_last_error": C.c_char_p, "hipdrt_stream": C.c_void_p, "hipdrt_default_fit_opts": None}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libhipdrt.so and attach the prototypes (no device is touched)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipDrtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                                  f"g.build()'` (hipdrt has no CPU fallback)")
+            lib = C.CDLL(LIB_PATH)
+            for name, argtypes in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.argtypes = argtypes
+                fn.restype = _RESTYPES.get(name, C.c_int)
+            _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HipDrtError(f"hipdrt error {rc}: {load_library().hipdrt_last_error().decode()}")
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def default_fit_opts() -> FitOpts:
+    o = FitOpts()
+    load_library().hipdrt_default_fit_opts(C.byref(o))
+    return o
+
+
+class Context:
+    """One hipdrt_ctx (device + stream)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = _vp()
+        _check(self._lib.hipdrt_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hipdrt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return self._lib.hipdrt_stream(self._h)
+
+    def synchronize(self):
+        _check(self._lib.hipdrt_synchronize(self._h))
+
+    def device_info(self):
+        buf = C.create_string_buffer(64)
+        ncu = C.c_int()
+        hbm = C.c_longlong()
+        _check(self._lib.hipdrt_device_info(self._h, buf, 64, C.byref(ncu), C.byref(hbm)))
+        return dict(arch=buf.value.decode(), num_cu=ncu.value, hbm_bytes=hbm.value)
+
+    # ---- L1 ------------------------------------------------------------------------------------------
+    def impedance_lookup(self, epsilon, wt_re, wt_im, ny=1000):
+        wt_re, wt_im = _f64(wt_re), _f64(wt_im)
+        z_re, z_im = np.empty_like(wt_re), np.empty_like(wt_im)
+        _check(self._lib.hipdrt_impedance_lookup(self._h, float(epsilon), wt_re.size, int(ny), _p(wt_re), _p(wt_im),
+                                                 _p(z_re), _p(z_im)))
+        return z_re, z_im
+
+    def impedance_matrix(self, freq, tau, epsilon, mode=MODE_INTERP, toeplitz=False, lookups=None, ny=1000):
+        freq, tau = _f64(freq), _f64(tau)
+        batched = freq.ndim == 2
+        B = freq.shape[0] if batched else 1
+        nf = freq.shape[-1]
+        if lookups is not None:
+            (lre, zre), (lim, zim) = lookups
+            lre, zre, lim, zim = _f64(lre), _f64(zre), _f64(lim), _f64(zim)
+            ng = lre.size
+        else:
+            lre = zre = lim = zim = None
+            ng = 0
+        a_re = np.empty((B, nf, tau.size))
+        a_im = np.empty((B, nf, tau.size))
+        _check(self._lib.hipdrt_impedance_matrix(self._h, B, int(batched), _p(freq), nf, _p(tau), tau.size, int(mode),
+                                                 int(bool(toeplitz)), float(epsilon), ng, _p(lre), _p(zre), _p(lim),
+                                                 _p(zim), int(ny), _p(a_re), _p(a_im)))
+        if not batched:
+            return a_re[0], a_im[0]
+        return a_re, a_im
+
+    def impedance_matrix_timed(self, freq, tau, epsilon, dev_re, dev_im, mode=MODE_INTERP, toeplitz=False,
+                               lookups=None, ny=1000, repeat=1):
+        """Device-resident build (dev_re/dev_im: integer device pointers); returns elapsed ms of `repeat` launches."""
+        freq, tau = _f64(freq), _f64(tau)
+        batched = freq.ndim == 2
+        B = freq.shape[0] if batched else 1
+        nf = freq.shape[-1]
+        (lre, zre), (lim, zim) = lookups if lookups is not None else ((None, None), (None, None))
+        arrs = [None if a is None else _f64(a) for a in (lre, zre, lim, zim)]
+        ng = 0 if arrs[0] is None else arrs[0].size
+        ms = C.c_float()
+        _check(self._lib.hipdrt_impedance_matrix_dev(self._h, B, int(batched), _p(freq), nf, _p(tau), tau.size,
+                                                     int(mode), int(bool(toeplitz)), float(epsilon), ng, _p(arrs[0]),
+                                                     _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), int(ny), _vp(dev_re),
+                                                     _vp(dev_im), int(repeat), C.byref(ms)))
+        return ms.value
+
+    def penalty_matrices(self, ln_tau, epsilon, toeplitz):
+        ln_tau = _f64(ln_tau)
+        n = ln_tau.size
+        out = [np.empty((n, n)) for _ in range(3)]
+        _check(self._lib.hipdrt_penalty_matrices(self._h, _p(ln_tau), n, float(epsilon), int(bool(toeplitz)),
+                                                 _p(out[0]), _p(out[1]), _p(out[2])))
+        return out
+
+    def eis_var_matrix(self, freq, vmm_epsilon=0.25, reim_cor=0.25, uniform=False):
+        freq = _f64(freq)
+        vmm = np.empty((2 * freq.size, 2 * freq.size))
+        _check(self._lib.hipdrt_eis_var_matrix(self._h, _p(freq), freq.size, float(vmm_epsilon), float(reim_cor),
+                                               int(bool(uniform)), _p(vmm)))
+        return vmm
+
+    # ---- L2 ------------------------------------------------------------------------------------------
+    def qp_batch(self, P, q, h, opts: QpOpts | None = None):
+        P, q, h = _f64(P), _f64(q), _f64(h)
+        if q.ndim == 1:
+            q = q[None, :]
+        B, n = q.shape
+        p_batched = P.ndim == 3
+        h_batched = h.ndim == 2
+        x = np.empty((B, n))
+        iters = np.empty(B, dtype=np.int32)
+        pcost = np.empty(B)
+        status = np.empty(B, dtype=np.int32)
+        _check(self._lib.hipdrt_qp_batch(self._h, B, n, int(p_batched), _p(P), _p(q), int(h_batched), _p(h),
+                                         C.byref(opts) if opts is not None else None, _p(x), _pi(iters), _p(pcost),
+                                         _pi(status)))
+        return dict(x=x, iterations=iters, pcost=pcost, status=status)
+
+    def weighted_gram(self, A, w, b, l2=None, l1=None):
+        A, w, b = _f64(A), _f64(w), _f64(b)
+        if w.ndim == 1:
+            w, b = w[None, :], b[None, :]
+        B, m = w.shape
+        n = A.shape[1]
+        l2a = None if l2 is None else _f64(l2)
+        l1a = None if l1 is None else _f64(l1)
+        P = np.empty((B, n, n))
+        q = np.empty((B, n))
+        _check(self._lib.hipdrt_weighted_gram(self._h, B, m, n, _p(A), _p(w), _p(b),
+                                              int(l2a is not None and l2a.ndim == 3), _p(l2a), _p(l1a), _p(P), _p(q)))
+        return P, q
+
+
+class Plan:
+    """hipdrt_plan: shared matrices + work space for `capacity` spectra on one frequency / tau grid."""
+
+    def __init__(self, ctx: Context, freq, tau, epsilon, wt_re=None, wt_im=None, mode=MODE_INTERP,
+                 toeplitz_a=False, toeplitz_m=False, opts: FitOpts | None = None, capacity=1, ny=1000):
+        self._lib = load_library()
+        self.ctx = ctx
+        freq, tau = _f64(freq), _f64(tau)
+        self.freq, self.tau = freq, tau
+        if mode == MODE_INTERP:
+            wt_re, wt_im = _f64(wt_re), _f64(wt_im)
+            lre, lim = np.log(wt_re), np.log(wt_im)
+            ng = wt_re.size
+        else:
+            wt_re = wt_im = lre = lim = None
+            ng = 0
+        self.log_wt_re, self.log_wt_im = lre, lim
+        self.opts = opts if opts is not None else default_fit_opts()
+        h = _vp()
+        _check(self._lib.hipdrt_plan_create(ctx._h, _p(freq), freq.size, _p(tau), tau.size, float(epsilon), int(mode),
+                                            int(bool(toeplitz_a)), int(bool(toeplitz_m)), ng, int(ny), _p(wt_re),
+                                            _p(wt_im), _p(lre), _p(lim), C.byref(self.opts), int(capacity),
+                                            C.byref(h)))
+        self._h = h
+        n, m, ns = C.c_int(), C.c_int(), C.c_int()
+        _check(self._lib.hipdrt_plan_dims(self._h, C.byref(n), C.byref(m), C.byref(ns)))
+        self.n, self.m, self.ns = n.value, m.value, ns.value
+        self.nf, self.ntau, self.ngrid = freq.size, tau.size, ng
+        self.capacity = int(capacity)
+        self.B = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hipdrt_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get(self, which):
+        shapes = {"lut_z_re": (self.ngrid,), "lut_z_im": (self.ngrid,), "a_re": (self.nf, self.ntau),
+                  "a_im": (self.nf, self.ntau), "rm": (self.m, self.n), "m0": (self.n, self.n),
+                  "m1": (self.n, self.n), "m2": (self.n, self.n), "vmm": (self.m, self.m), "h": (self.n,)}
+        out = np.empty(shapes[which])
+        _check(self._lib.hipdrt_plan_get(self._h, which.encode(), _p(out), out.size))
+        return out
+
+    def set_lookup(self, z_re, z_im):
+        z_re, z_im = _f64(z_re), _f64(z_im)
+        _check(self._lib.hipdrt_plan_set_lookup(self._h, _p(z_re), _p(z_im)))
+
+    def upload(self, z):
+        z = np.asarray(z)
+        if z.ndim == 1:
+            z = z[None, :]
+        z_re, z_im = _f64(z.real), _f64(z.imag)
+        _check(self._lib.hipdrt_plan_upload(self._h, z.shape[0], _p(z_re), _p(z_im)))
+        self.B = z.shape[0]
+
+    def fit(self):
+        _check(self._lib.hipdrt_plan_fit(self._h))
+
+    def record_history(self, b):
+        _check(self._lib.hipdrt_plan_record_history(self._h, int(b)))
+
+    def download(self, s_vectors=False):
+        B, n, m = self.B, self.n, self.m
+        out = dict(x=np.empty((B, n)), fit_x=np.empty((B, self.ntau)), R_inf=np.empty(B), inductance=np.empty(B),
+                   weights=np.empty((B, m)), coefficient_scale=np.empty(B), rho=np.empty((B, 3)),
+                   q_vector=np.empty((B, n)), outer_iters=np.empty(B, dtype=np.int32),
+                   qp_iters_total=np.empty(B, dtype=np.int32), status=np.empty(B, dtype=np.int32))
+        sv = np.empty((B, 3, n)) if s_vectors else None
+        _check(self._lib.hipdrt_plan_download(self._h, _p(out["x"]), _p(out["fit_x"]), _p(out["R_inf"]),
+                                              _p(out["inductance"]), _p(out["weights"]), _p(out["coefficient_scale"]),
+                                              _p(out["rho"]), _p(sv), _p(out["q_vector"]), _pi(out["outer_iters"]),
+                                              _pi(out["qp_iters_total"]), _pi(out["status"])))
+        if s_vectors:
+            out["s_vectors"] = sv
+        return out
+
+    def p_matrix(self, b):
+        out = np.empty((self.n, self.n))
+        _check(self._lib.hipdrt_plan_get_p_matrix(self._h, int(b), _p(out)))
+        return out
+
+    def history(self):
+        cap = int(self.opts.max_iter)
+        hx, hr, hw = np.empty((cap, self.n)), np.empty((cap, 3)), np.empty((cap, self.m))
+        qi = np.empty(cap + 1, dtype=np.int32)
+        rows = C.c_int()
+        _check(self._lib.hipdrt_plan_get_history(self._h, _p(hx), _p(hr), _p(hw), _pi(qi), cap, C.byref(rows)))
+        r = rows.value
+        return dict(x=hx[:r], rho=hr[:r], weights=hw[:r], qp_iterations=qi[:r + 1])
+
+    def timings(self):
+        t = (C.c_float * 5)()
+        l = (C.c_int * 5)()
+        _check(self._lib.hipdrt_plan_timings(self._h, t, l))
+        names = ("total", "gram", "qp", "hyper", "other")
+        return {k: float(t[i]) for i, k in enumerate(names)}, {k: int(l[i]) for i, k in enumerate(names)}
+
+
+_default_ctx = {}
+
+
+def get_context(device: int = 0) -> Context:
+    """Process-wide context per device (created on first use)."""
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

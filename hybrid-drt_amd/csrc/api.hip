@@ -1,0 +1,707 @@
+// C-ABI of libhipdrt.so (include/hipdrt.h): context, stand-alone operators, and the plan that runs
+// DRT._qphb_fit_core (hybdrt/models/drt1d.py:102-1104, EIS branch) for a batch of spectra on the device.
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "common.hpp"
+
+namespace hipdrt {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace hipdrt
+
+using namespace hipdrt;
+
+// ---------------------------------------------------------------------------------------------------------
+struct hipdrt_plan {
+    hipdrt_ctx* ctx = nullptr;
+    int nf = 0, ntau = 0, n = 0, m = 0, ns = 0, ngrid = 0, ny = 0, mode = 0, toeplitz_a = 0, toeplitz_m = 0;
+    int idx_rinf = -1, idx_induc = -1;
+    int ldrm = 0, ldm = 0, ldp = 0, ldl = 0;
+    int capacity = 0, B = 0;
+    double eps = 0;
+    hipdrt_fit_opts opts{};
+    // shared
+    DevBuf freq, tau, ln_tau, wt_re, wt_im, lut6, a_re, a_im, cr, rm, mk[3], vmm, h, l1;
+    // per spectrum
+    DevBuf z_re, z_im, rv, w, est_w, x, x_in, q, s, rho, xmx, coef_scale, var_floor;
+    DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
+    DevBuf P, L, Ptmp;
+    // history
+    int hist_b = -1, hist_cap = 0;
+    DevBuf hist_x, hist_w, hist_rho, hist_qp, hist_rows;
+    // timings of the last fit
+    float t_ms[5] = {0, 0, 0, 0, 0};
+    int launches[5] = {0, 0, 0, 0, 0};
+
+    FitState state() const {
+        FitState st{};
+        st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm;
+        st.opts = opts;
+        st.rm = rm.d(); st.vmm = vmm.d();
+        for (int k = 0; k < 3; ++k) st.mk[k] = mk[k].d();
+        st.z_re = z_re.d(); st.z_im = z_im.d();
+        st.rv = rv.d(); st.w = w.d(); st.est_w = est_w.d();
+        st.x = x.d(); st.x_in = x_in.d(); st.s = s.d(); st.rho = rho.d(); st.xmx = xmx.d();
+        st.coef_scale = coef_scale.d(); st.var_floor = var_floor.d();
+        st.active = active.i(); st.outer_iters = outer_iters.i(); st.fit_status = fit_status.i();
+        st.qp_iters_total = qp_iters_total.i(); st.qp_status = qp_status.i(); st.qp_iters = qp_iters.i();
+        st.n_active = n_active.i();
+        st.hist_b = hist_b; st.hist_cap = hist_cap;
+        st.hist_x = hist_x.d(); st.hist_w = hist_w.d(); st.hist_rho = hist_rho.d();
+        st.hist_qp = hist_qp.i(); st.hist_rows = hist_rows.i();
+        return st;
+    }
+};
+
+static int upload(DevBuf& buf, const void* src, size_t bytes, hipStream_t st) {
+    HIPDRT_CHECK(buf.alloc(bytes));
+    if (src) HIPDRT_CHECK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+#define LAUNCH_OK() HIPDRT_CHECK(hipGetLastError())
+
+extern "C" {
+
+const char* hipdrt_last_error(void) { return g_err.c_str(); }
+
+int hipdrt_create(int device, hipdrt_ctx** out) {
+    HIPDRT_REQUIRE(out != nullptr, "out is NULL");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device visible (libhipdrt has no CPU fallback)");
+        return HIPDRT_E_NODEVICE;
+    }
+    HIPDRT_REQUIRE(device >= 0 && device < count, "device index out of range");
+    HIPDRT_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPDRT_CHECK(hipGetDeviceProperties(&prop, device));
+    std::string arch = prop.gcnArchName;
+    if (arch.rfind("gfx950", 0) != 0) {
+        set_error("device " + std::to_string(device) + " is " + arch + "; libhipdrt is built for gfx950 only");
+        return HIPDRT_E_NODEVICE;
+    }
+    auto* c = new hipdrt_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    c->hbm_bytes = prop.totalGlobalMem;
+    c->arch = arch.substr(0, arch.find(':'));
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; set_error(hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    *out = c;
+    return HIPDRT_OK;
+}
+
+int hipdrt_destroy(hipdrt_ctx* ctx) {
+    if (!ctx) return HIPDRT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return HIPDRT_OK;
+}
+
+void* hipdrt_stream(hipdrt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int hipdrt_synchronize(hipdrt_ctx* ctx) {
+    HIPDRT_REQUIRE(ctx, "ctx is NULL");
+    HIPDRT_CHECK(hipStreamSynchronize(ctx->stream));
+    return HIPDRT_OK;
+}
+
+int hipdrt_device_info(hipdrt_ctx* ctx, char* arch, int arch_len, int* num_cu, long long* hbm_bytes) {
+    HIPDRT_REQUIRE(ctx, "ctx is NULL");
+    if (arch && arch_len > 0) { std::strncpy(arch, ctx->arch.c_str(), arch_len - 1); arch[arch_len - 1] = 0; }
+    if (num_cu) *num_cu = ctx->num_cu;
+    if (hbm_bytes) *hbm_bytes = (long long)ctx->hbm_bytes;
+    return HIPDRT_OK;
+}
+
+// ---- stand-alone operators --------------------------------------------------------------------------------
+
+int hipdrt_impedance_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, const double* wt_re,
+                            const double* wt_im, double* z_re, double* z_im) {
+    HIPDRT_REQUIRE(ctx && wt_re && wt_im && z_re && z_im, "NULL pointer");
+    HIPDRT_REQUIRE(ngrid >= 2 && ny >= 2 && ny <= 6000, "ngrid >= 2, 2 <= ny <= 6000");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dwr, dwi, dzr, dzi;
+    const size_t gb = (size_t)ngrid * sizeof(double);
+    TRY(upload(dwr, wt_re, gb, st)); TRY(upload(dwi, wt_im, gb, st));
+    HIPDRT_CHECK(dzr.alloc(gb)); HIPDRT_CHECK(dzi.alloc(gb));
+    launch_lookup(st, epsilon, ngrid, ny, dwr.d(), dwi.d(), dzr.d(), dzi.d());
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(z_re, dzr.p, gb, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(z_im, dzi.p, gb, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+// lut6 = {log_wt_re, z_re, slope_re, log_wt_im, z_im, slope_im}
+static int build_lut6(hipStream_t st, DevBuf& lut6, int ngrid, const double* log_wt_re, const double* z_re,
+                      const double* log_wt_im, const double* z_im, bool z_on_device) {
+    const size_t gb = (size_t)ngrid * sizeof(double);
+    if (!lut6.p) HIPDRT_CHECK(lut6.alloc(6 * gb));
+    double* base = lut6.d();
+    const hipMemcpyKind zk = z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIPDRT_CHECK(hipMemcpyAsync(base, log_wt_re, gb, hipMemcpyHostToDevice, st));
+    HIPDRT_CHECK(hipMemcpyAsync(base + 3 * (size_t)ngrid, log_wt_im, gb, hipMemcpyHostToDevice, st));
+    if (z_re) HIPDRT_CHECK(hipMemcpyAsync(base + ngrid, z_re, gb, zk, st));
+    if (z_im) HIPDRT_CHECK(hipMemcpyAsync(base + 4 * (size_t)ngrid, z_im, gb, zk, st));
+    launch_lookup_slopes(st, ngrid, base, base + ngrid, base + 2 * (size_t)ngrid);
+    launch_lookup_slopes(st, ngrid, base + 3 * (size_t)ngrid, base + 4 * (size_t)ngrid, base + 5 * (size_t)ngrid);
+    LAUNCH_OK();
+    return 0;
+}
+
+static int impedance_matrix_common(hipdrt_ctx* ctx, int B, int freq_batched, const double* freq, int nf,
+                                   const double* tau, int ntau, int mode, int toeplitz, double epsilon, int ngrid,
+                                   const double* log_wt_re, const double* z_re, const double* log_wt_im,
+                                   const double* z_im, int ny, double* a_re_dev, double* a_im_dev, int repeat,
+                                   float* elapsed_ms) {
+    HIPDRT_REQUIRE(ctx && freq && tau && a_re_dev && a_im_dev, "NULL pointer");
+    HIPDRT_REQUIRE(B >= 1 && nf >= 1 && ntau >= 1, "B, nf, ntau >= 1");
+    HIPDRT_REQUIRE(mode == HIPDRT_MODE_INTERP || mode == HIPDRT_MODE_TRAPZ, "mode");
+    HIPDRT_REQUIRE(!(toeplitz && freq_batched), "Toeplitz shortcut needs one shared frequency grid");
+    if (mode == HIPDRT_MODE_INTERP)
+        HIPDRT_REQUIRE(log_wt_re && z_re && log_wt_im && z_im && ngrid >= 2 && ngrid <= 3400,
+                       "interp needs lookups with 2 <= ngrid <= 3400");
+    else HIPDRT_REQUIRE(ny >= 2 && ny <= 6000, "2 <= ny <= 6000");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dfreq, dtau, lut6, cr;
+    TRY(upload(dfreq, freq, (size_t)(freq_batched ? B : 1) * nf * sizeof(double), st));
+    TRY(upload(dtau, tau, (size_t)ntau * sizeof(double), st));
+    if (mode == HIPDRT_MODE_INTERP) TRY(build_lut6(st, lut6, ngrid, log_wt_re, z_re, log_wt_im, z_im, false));
+    HIPDRT_CHECK(cr.alloc(2 * (size_t)(nf + ntau) * sizeof(double)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (elapsed_ms) { HIPDRT_CHECK(hipEventCreate(&e0)); HIPDRT_CHECK(hipEventCreate(&e1)); HIPDRT_CHECK(hipEventRecord(e0, st)); }
+    for (int r = 0; r < (repeat < 1 ? 1 : repeat); ++r)
+        launch_impedance_matrix(st, B, freq_batched, dfreq.d(), nf, dtau.d(), ntau, mode, toeplitz, epsilon, ngrid,
+                                lut6.d(), ny, a_re_dev, a_im_dev, cr.d());
+    LAUNCH_OK();
+    if (elapsed_ms) { HIPDRT_CHECK(hipEventRecord(e1, st)); }
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    if (elapsed_ms) {
+        HIPDRT_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    return HIPDRT_OK;
+}
+
+int hipdrt_impedance_matrix_dev(hipdrt_ctx* ctx, int B, int freq_batched, const double* freq, int nf,
+                                const double* tau, int ntau, int mode, int toeplitz, double epsilon, int ngrid,
+                                const double* log_wt_re, const double* z_re, const double* log_wt_im,
+                                const double* z_im, int ny, void* a_re_dev, void* a_im_dev, int repeat,
+                                float* elapsed_ms) {
+    return impedance_matrix_common(ctx, B, freq_batched, freq, nf, tau, ntau, mode, toeplitz, epsilon, ngrid,
+                                   log_wt_re, z_re, log_wt_im, z_im, ny, (double*)a_re_dev, (double*)a_im_dev, repeat,
+                                   elapsed_ms);
+}
+
+int hipdrt_impedance_matrix(hipdrt_ctx* ctx, int B, int freq_batched, const double* freq, int nf, const double* tau,
+                            int ntau, int mode, int toeplitz, double epsilon, int ngrid, const double* log_wt_re,
+                            const double* z_re, const double* log_wt_im, const double* z_im, int ny, double* a_re,
+                            double* a_im) {
+    HIPDRT_REQUIRE(ctx && a_re && a_im, "NULL pointer");
+    HIPDRT_REQUIRE(B >= 1 && nf >= 1 && ntau >= 1, "B, nf, ntau >= 1");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    DevBuf dre, dim;
+    const size_t bytes = (size_t)B * nf * ntau * sizeof(double);
+    HIPDRT_CHECK(dre.alloc(bytes)); HIPDRT_CHECK(dim.alloc(bytes));
+    TRY(impedance_matrix_common(ctx, B, freq_batched, freq, nf, tau, ntau, mode, toeplitz, epsilon, ngrid, log_wt_re,
+                                z_re, log_wt_im, z_im, ny, dre.d(), dim.d(), 1, nullptr));
+    HIPDRT_CHECK(hipMemcpy(a_re, dre.p, bytes, hipMemcpyDeviceToHost));
+    HIPDRT_CHECK(hipMemcpy(a_im, dim.p, bytes, hipMemcpyDeviceToHost));
+    return HIPDRT_OK;
+}
+
+int hipdrt_penalty_matrices(hipdrt_ctx* ctx, const double* ln_tau, int n, double epsilon, int toeplitz, double* m0,
+                            double* m1, double* m2) {
+    HIPDRT_REQUIRE(ctx && ln_tau && m0 && m1 && m2, "NULL pointer");
+    HIPDRT_REQUIRE(n >= 1, "n >= 1");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dl, d0, d1, d2;
+    const size_t bytes = (size_t)n * n * sizeof(double);
+    TRY(upload(dl, ln_tau, (size_t)n * sizeof(double), st));
+    HIPDRT_CHECK(d0.alloc(bytes)); HIPDRT_CHECK(d1.alloc(bytes)); HIPDRT_CHECK(d2.alloc(bytes));
+    launch_penalty(st, dl.d(), n, epsilon, toeplitz, d0.d(), d1.d(), d2.d(), n, 0);
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(m0, d0.p, bytes, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(m1, d1.p, bytes, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(m2, d2.p, bytes, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+int hipdrt_eis_var_matrix(hipdrt_ctx* ctx, const double* freq, int nf, double vmm_epsilon, double reim_cor,
+                          int uniform, double* vmm) {
+    HIPDRT_REQUIRE(ctx && freq && vmm, "NULL pointer");
+    HIPDRT_REQUIRE(nf >= 1, "nf >= 1");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf df, dv;
+    const size_t bytes = (size_t)4 * nf * nf * sizeof(double);
+    TRY(upload(df, freq, (size_t)nf * sizeof(double), st));
+    HIPDRT_CHECK(dv.alloc(bytes));
+    launch_eis_vmm(st, df.d(), nf, vmm_epsilon, reim_cor, uniform, dv.d());
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(vmm, dv.p, bytes, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+static hipdrt_qp_opts default_qp_opts() { return hipdrt_qp_opts{1e-7, 1e-6, 1e-7, 100}; }
+
+int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* P, const double* q, int h_batched,
+                    const double* h, const hipdrt_qp_opts* opts, double* x, int* iters, double* pcost, int* status) {
+    HIPDRT_REQUIRE(ctx && P && q && h && x && status, "NULL pointer");
+    HIPDRT_REQUIRE(B >= 1 && n >= 1 && n <= 2048, "B >= 1, 1 <= n <= 2048");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dP, dq, dh, dL, dx, dit, dpc, dst;
+    const int ldl = (int)qp_scratch_ld(n);
+    TRY(upload(dP, P, (size_t)(p_batched ? B : 1) * n * n * sizeof(double), st));
+    TRY(upload(dq, q, (size_t)B * n * sizeof(double), st));
+    TRY(upload(dh, h, (size_t)(h_batched ? B : 1) * n * sizeof(double), st));
+    HIPDRT_CHECK(dL.alloc((size_t)B * n * ldl * sizeof(double)));
+    HIPDRT_CHECK(dx.alloc((size_t)B * n * sizeof(double)));
+    HIPDRT_CHECK(dit.alloc((size_t)B * sizeof(int)));
+    HIPDRT_CHECK(dpc.alloc((size_t)B * sizeof(double)));
+    HIPDRT_CHECK(dst.alloc((size_t)B * sizeof(int)));
+    QpArgs a{};
+    a.B = B; a.n = n; a.P = dP.d(); a.p_stride = p_batched ? (long long)n * n : 0; a.ldp = n;
+    a.q = dq.d(); a.h = dh.d(); a.h_stride = h_batched ? n : 0;
+    a.L = dL.d(); a.ldl = ldl; a.l_stride = (long long)n * ldl;
+    a.x = dx.d(); a.iters = dit.i(); a.pcost = dpc.d(); a.status = dst.i();
+    a.active = nullptr; a.iters_accum = nullptr;
+    a.opts = opts ? *opts : default_qp_opts();
+    TRY(launch_qp(st, a));
+    HIPDRT_CHECK(hipMemcpyAsync(x, dx.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (iters) HIPDRT_CHECK(hipMemcpyAsync(iters, dit.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (pcost) HIPDRT_CHECK(hipMemcpyAsync(pcost, dpc.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(status, dst.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+int hipdrt_weighted_gram(hipdrt_ctx* ctx, int B, int m, int n, const double* A, const double* w, const double* b,
+                         int l2_batched, const double* l2, const double* l1, double* P, double* q) {
+    HIPDRT_REQUIRE(ctx && A && w && b && P && q, "NULL pointer");
+    HIPDRT_REQUIRE(B >= 1 && m >= 1 && n >= 1, "B, m, n >= 1");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dA, dw, db, dl2, dl1, dP, dq;
+    TRY(upload(dA, A, (size_t)m * n * sizeof(double), st));
+    TRY(upload(dw, w, (size_t)B * m * sizeof(double), st));
+    TRY(upload(db, b, (size_t)B * m * sizeof(double), st));
+    if (l2) TRY(upload(dl2, l2, (size_t)(l2_batched ? B : 1) * n * n * sizeof(double), st));
+    if (l1) TRY(upload(dl1, l1, (size_t)n * sizeof(double), st));
+    HIPDRT_CHECK(dP.alloc((size_t)B * n * n * sizeof(double)));
+    HIPDRT_CHECK(dq.alloc((size_t)B * n * sizeof(double)));
+    launch_weighted_gram(st, B, m, n, dA.d(), n, dw.d(), db.d(), l2 ? dl2.d() : nullptr,
+                         l2_batched ? (long long)n * n : 0, n, l1 ? dl1.d() : nullptr, dP.d(), n, (long long)n * n,
+                         dq.d(), nullptr);
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(P, dP.p, (size_t)B * n * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(q, dq.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+// ---- plan ---------------------------------------------------------------------------------------------------
+
+void hipdrt_default_fit_opts(hipdrt_fit_opts* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->rp_scale = 14;
+    const double dw[3] = {1.5, 1.0, 0.5}, sd[3] = {1, 1000, 1000}, sa[3] = {5, 10, 25}, ra[3] = {0.15, 0.2, 0.25};
+    for (int k = 0; k < 3; ++k) {
+        o->derivative_weights[k] = dw[k]; o->sigma_ds[k] = sd[k]; o->s_alpha[k] = sa[k]; o->s_0[k] = 1.0;
+        o->rho_alpha[k] = ra[k]; o->rho_0[k] = 1.0;
+    }
+    o->l1_lambda_0 = 0; o->l2_lambda_0 = 142;
+    o->iw_l1_lambda_0 = 1e-4; o->iw_l2_lambda_0 = 1e-4;
+    o->ohmic_penalty = 1e-6; o->inductance_penalty = 1e-6; o->inductance_scale = 1e-5;
+    o->eis_vmm_epsilon = 0.25; o->eis_reim_cor = 0.25;
+    o->xtol = 1e-2; o->max_iter = 50; o->nonneg = 1; o->scale_data = 1; o->fit_ohmic = 1; o->fit_inductance = 1;
+    o->eis_error_uniform = 0;
+    o->qp = default_qp_opts();
+}
+
+static int plan_build_matrices(hipdrt_plan* p, bool build_lookup) {
+    hipStream_t st = p->ctx->stream;
+    const size_t gb = (size_t)p->ngrid * sizeof(double);
+    if (p->mode == HIPDRT_MODE_INTERP && build_lookup) {
+        double* base = p->lut6.d();
+        launch_lookup(st, p->eps, p->ngrid, p->ny, p->wt_re.d(), p->wt_im.d(), base + p->ngrid, base + 4 * (size_t)p->ngrid);
+        LAUNCH_OK();
+    }
+    if (p->mode == HIPDRT_MODE_INTERP) {
+        double* base = p->lut6.d();
+        launch_lookup_slopes(st, p->ngrid, base, base + p->ngrid, base + 2 * (size_t)p->ngrid);
+        launch_lookup_slopes(st, p->ngrid, base + 3 * (size_t)p->ngrid, base + 4 * (size_t)p->ngrid, base + 5 * (size_t)p->ngrid);
+    }
+    (void)gb;
+    launch_impedance_matrix(st, 1, 0, p->freq.d(), p->nf, p->tau.d(), p->ntau, p->mode, p->toeplitz_a, p->eps, p->ngrid,
+                            p->lut6.d(), p->ny, p->a_re.d(), p->a_im.d(), p->cr.d());
+    LAUNCH_OK();
+    FitState fs = p->state();
+    launch_assemble_rm(st, fs, p->a_re.d(), p->a_im.d(), p->freq.d(), p->rm.d(), p->idx_rinf, p->idx_induc);
+    LAUNCH_OK();
+    return 0;
+}
+
+int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double* tau, int ntau, double epsilon,
+                       int mode, int toeplitz_a, int toeplitz_m, int ngrid, int ny, const double* wt_re,
+                       const double* wt_im, const double* log_wt_re, const double* log_wt_im,
+                       const hipdrt_fit_opts* opts, int capacity, hipdrt_plan** out) {
+    HIPDRT_REQUIRE(ctx && freq && tau && out, "NULL pointer");
+    HIPDRT_REQUIRE(nf >= 2 && ntau >= 2 && capacity >= 1, "nf, ntau >= 2, capacity >= 1");
+    HIPDRT_REQUIRE(mode == HIPDRT_MODE_INTERP || mode == HIPDRT_MODE_TRAPZ, "mode");
+    if (mode == HIPDRT_MODE_INTERP)
+        HIPDRT_REQUIRE(wt_re && wt_im && log_wt_re && log_wt_im && ngrid >= 2 && ngrid <= 3400, "interp lookups");
+    HIPDRT_REQUIRE(ny >= 2 && ny <= 6000, "2 <= ny <= 6000");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<hipdrt_plan> p(new hipdrt_plan());
+    p->ctx = ctx;
+    if (opts) p->opts = *opts; else hipdrt_default_fit_opts(&p->opts);
+    p->nf = nf; p->ntau = ntau; p->eps = epsilon; p->mode = mode; p->ngrid = ngrid; p->ny = ny;
+    p->toeplitz_a = toeplitz_a; p->toeplitz_m = toeplitz_m; p->capacity = capacity;
+    // special parameters in registration order (drt1d.py:383-388): R_inf, then inductance
+    int ns = 0;
+    if (p->opts.fit_ohmic) p->idx_rinf = ns++;
+    if (p->opts.fit_inductance) p->idx_induc = ns++;
+    p->ns = ns; p->n = ns + ntau; p->m = 2 * nf;
+    const int n = p->n, m = p->m;
+    HIPDRT_REQUIRE(n <= 2048, "ns + ntau <= 2048");
+    p->ldrm = round_up(n, 2); p->ldm = round_up(n, 2); p->ldp = round_up(n, 2); p->ldl = (int)qp_scratch_ld(n);
+
+    std::vector<double> ln_tau(ntau);
+    for (int i = 0; i < ntau; ++i) ln_tau[i] = std::log(tau[i]);
+    TRY(upload(p->freq, freq, (size_t)nf * sizeof(double), st));
+    TRY(upload(p->tau, tau, (size_t)ntau * sizeof(double), st));
+    const size_t gb = (size_t)(ngrid > 0 ? ngrid : 1) * sizeof(double);
+    if (mode == HIPDRT_MODE_INTERP) {
+        TRY(upload(p->wt_re, wt_re, gb, st)); TRY(upload(p->wt_im, wt_im, gb, st));
+        HIPDRT_CHECK(p->lut6.alloc(6 * gb));
+        HIPDRT_CHECK(hipMemcpyAsync(p->lut6.d(), log_wt_re, gb, hipMemcpyHostToDevice, st));
+        HIPDRT_CHECK(hipMemcpyAsync(p->lut6.d() + 3 * (size_t)ngrid, log_wt_im, gb, hipMemcpyHostToDevice, st));
+    }
+    HIPDRT_CHECK(p->a_re.alloc((size_t)nf * ntau * sizeof(double)));
+    HIPDRT_CHECK(p->a_im.alloc((size_t)nf * ntau * sizeof(double)));
+    HIPDRT_CHECK(p->cr.alloc(2 * (size_t)(nf + ntau) * sizeof(double)));
+    HIPDRT_CHECK(p->rm.alloc((size_t)m * p->ldrm * sizeof(double)));
+    HIPDRT_CHECK(hipMemsetAsync(p->rm.p, 0, p->rm.bytes, st));
+    for (int k = 0; k < 3; ++k) {
+        HIPDRT_CHECK(p->mk[k].alloc((size_t)n * p->ldm * sizeof(double)));
+        HIPDRT_CHECK(hipMemsetAsync(p->mk[k].p, 0, p->mk[k].bytes, st));
+    }
+    HIPDRT_CHECK(p->vmm.alloc((size_t)m * m * sizeof(double)));
+    HIPDRT_CHECK(p->h.alloc((size_t)n * sizeof(double)));
+    // l1_lambda_vector: 0 on specials, l1_lambda_0 on DRT coefficients (drt1d.py:552-553)
+    std::vector<double> l1(n, 0.0);
+    for (int i = ns; i < n; ++i) l1[i] = p->opts.l1_lambda_0;
+    TRY(upload(p->l1, l1.data(), (size_t)n * sizeof(double), st));
+    // ln(tau) on the host: np.log(self.basis_tau) (drt1d.py:5694)
+    TRY(upload(p->ln_tau, ln_tau.data(), (size_t)ntau * sizeof(double), st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));   // host vectors above go out of scope
+
+    // per-spectrum buffers
+    const size_t cap = (size_t)capacity;
+    HIPDRT_CHECK(p->z_re.alloc(cap * nf * sizeof(double))); HIPDRT_CHECK(p->z_im.alloc(cap * nf * sizeof(double)));
+    HIPDRT_CHECK(p->rv.alloc(cap * m * sizeof(double))); HIPDRT_CHECK(p->w.alloc(cap * m * sizeof(double)));
+    HIPDRT_CHECK(p->est_w.alloc(cap * m * sizeof(double)));
+    HIPDRT_CHECK(p->x.alloc(cap * n * sizeof(double))); HIPDRT_CHECK(p->x_in.alloc(cap * n * sizeof(double)));
+    HIPDRT_CHECK(p->q.alloc(cap * n * sizeof(double)));
+    HIPDRT_CHECK(p->s.alloc(cap * 3 * n * sizeof(double)));
+    HIPDRT_CHECK(p->rho.alloc(cap * 3 * sizeof(double))); HIPDRT_CHECK(p->xmx.alloc(cap * 3 * sizeof(double)));
+    HIPDRT_CHECK(p->coef_scale.alloc(cap * sizeof(double))); HIPDRT_CHECK(p->var_floor.alloc(cap * sizeof(double)));
+    HIPDRT_CHECK(p->pcost.alloc(cap * sizeof(double)));
+    for (DevBuf* ib : {&p->active, &p->outer_iters, &p->fit_status, &p->qp_iters_total, &p->qp_status, &p->qp_iters})
+        HIPDRT_CHECK(ib->alloc(cap * sizeof(int)));
+    HIPDRT_CHECK(p->n_active.alloc(sizeof(int)));
+    HIPDRT_CHECK(p->P.alloc(cap * n * p->ldp * sizeof(double)));
+    HIPDRT_CHECK(p->L.alloc(cap * n * p->ldl * sizeof(double)));
+    HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
+    HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
+
+    // shared matrices on the device
+    TRY(plan_build_matrices(p.get(), true));
+    launch_penalty(st, p->ln_tau.d(), ntau, epsilon, toeplitz_m, p->mk[0].d(), p->mk[1].d(), p->mk[2].d(), p->ldm, ns);
+    launch_special_penalty(st, p->mk[0].d(), p->mk[1].d(), p->mk[2].d(), p->ldm, p->idx_rinf, p->idx_induc,
+                           p->opts.ohmic_penalty, p->opts.inductance_penalty);
+    launch_eis_vmm(st, p->freq.d(), nf, p->opts.eis_vmm_epsilon, p->opts.eis_reim_cor, p->opts.eis_error_uniform,
+                   p->vmm.d());
+    launch_make_h(st, p->h.d(), n, ns, p->opts.nonneg);
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    *out = p.release();
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_destroy(hipdrt_plan* plan) {
+    if (plan) { (void)hipSetDevice(plan->ctx->device); delete plan; }
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_dims(hipdrt_plan* plan, int* n, int* m, int* ns) {
+    HIPDRT_REQUIRE(plan, "plan is NULL");
+    if (n) *n = plan->n;
+    if (m) *m = plan->m;
+    if (ns) *ns = plan->ns;
+    return HIPDRT_OK;
+}
+
+static int copy_strided(double* out, const double* dev, int rows, int cols, int ld, hipStream_t st) {
+    HIPDRT_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), dev, (size_t)ld * sizeof(double),
+                                  (size_t)cols * sizeof(double), rows, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long count) {
+    HIPDRT_REQUIRE(p && which && out, "NULL pointer");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const std::string w = which;
+    const double* src = nullptr; int rows = 0, cols = 0, ld = 0;
+    if (w == "lut_z_re") { src = p->lut6.d() + p->ngrid; rows = 1; cols = ld = p->ngrid; }
+    else if (w == "lut_z_im") { src = p->lut6.d() + 4 * (size_t)p->ngrid; rows = 1; cols = ld = p->ngrid; }
+    else if (w == "a_re") { src = p->a_re.d(); rows = p->nf; cols = ld = p->ntau; }
+    else if (w == "a_im") { src = p->a_im.d(); rows = p->nf; cols = ld = p->ntau; }
+    else if (w == "rm") { src = p->rm.d(); rows = p->m; cols = p->n; ld = p->ldrm; }
+    else if (w == "m0" || w == "m1" || w == "m2") { src = p->mk[w[1] - '0'].d(); rows = cols = p->n; ld = p->ldm; }
+    else if (w == "vmm") { src = p->vmm.d(); rows = cols = ld = p->m; }
+    else if (w == "h") { src = p->h.d(); rows = 1; cols = ld = p->n; }
+    else { set_error("unknown matrix name: " + w); return HIPDRT_E_INVALID; }
+    HIPDRT_REQUIRE(src != nullptr, "matrix not available in this mode");
+    HIPDRT_REQUIRE(count == (long long)rows * cols, "count does not match the matrix size");
+    return copy_strided(out, src, rows, cols, ld, st);
+}
+
+int hipdrt_plan_set_lookup(hipdrt_plan* p, const double* z_re, const double* z_im) {
+    HIPDRT_REQUIRE(p && z_re && z_im, "NULL pointer");
+    HIPDRT_REQUIRE(p->mode == HIPDRT_MODE_INTERP, "plan is not in interp mode");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const size_t gb = (size_t)p->ngrid * sizeof(double);
+    HIPDRT_CHECK(hipMemcpyAsync(p->lut6.d() + p->ngrid, z_re, gb, hipMemcpyHostToDevice, st));
+    HIPDRT_CHECK(hipMemcpyAsync(p->lut6.d() + 4 * (size_t)p->ngrid, z_im, gb, hipMemcpyHostToDevice, st));
+    TRY(plan_build_matrices(p, false));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_upload(hipdrt_plan* p, int B, const double* z_re, const double* z_im) {
+    HIPDRT_REQUIRE(p && z_re && z_im, "NULL pointer");
+    HIPDRT_REQUIRE(B >= 1 && B <= p->capacity, "1 <= B <= capacity");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const size_t bytes = (size_t)B * p->nf * sizeof(double);
+    HIPDRT_CHECK(hipMemcpyAsync(p->z_re.p, z_re, bytes, hipMemcpyHostToDevice, st));
+    HIPDRT_CHECK(hipMemcpyAsync(p->z_im.p, z_im, bytes, hipMemcpyHostToDevice, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    p->B = B;
+    return HIPDRT_OK;
+}
+
+namespace {
+struct PhaseTimer {
+    hipStream_t st;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cat;
+    explicit PhaseTimer(hipStream_t s) : st(s) {}
+    ~PhaseTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+    void mark(int category) {   // closes the previous phase, opens `category` (-1 = end)
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, st);
+        ev.push_back(e);
+        cat.push_back(category);
+    }
+    void collect(float* t_ms, int* launches) {
+        for (int i = 0; i < 5; ++i) { t_ms[i] = 0; launches[i] = 0; }
+        for (size_t i = 0; i + 1 < ev.size(); ++i) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess && cat[i] >= 1 && cat[i] <= 4) {
+                t_ms[cat[i]] += ms; launches[cat[i]] += 1;
+            }
+        }
+        if (ev.size() >= 2) { float ms = 0; (void)hipEventElapsedTime(&ms, ev.front(), ev.back()); t_ms[0] = ms; launches[0] = 1; }
+    }
+};
+}  // namespace
+
+int hipdrt_plan_fit(hipdrt_plan* p) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_REQUIRE(p->B >= 1, "no spectra staged (call hipdrt_plan_upload)");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const int B = p->B, n = p->n, m = p->m;
+    FitState fs = p->state();
+    PhaseTimer tm(st);
+    tm.mark(4);
+    if (p->hist_b >= 0) HIPDRT_CHECK(hipMemsetAsync(p->hist_rows.p, 0, sizeof(int), st));
+    launch_prep(st, fs, B);
+    LAUNCH_OK();
+
+    GramL2 g{};
+    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1;
+    for (int k = 0; k < 3; ++k) g.mk[k] = p->mk[k].d();
+    g.s = p->s.d(); g.rho = p->rho.d();
+
+    QpArgs qa{};
+    qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
+    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)n * p->ldl;
+    qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
+    qa.iters_accum = p->qp_iters_total.i(); qa.opts = p->opts.qp;
+
+    // ---- initialize_weights (qphb.py:1609-1681): one un-weighted, weakly penalised QP; P is the same for
+    //      every spectrum (weights = 1, s = s_0, rho = rho_0), only q differs -------------------------------
+    tm.mark(1);
+    for (int k = 0; k < 3; ++k) g.dfac[k] = p->opts.iw_l2_lambda_0 * p->opts.derivative_weights[k];
+    launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d(), g, p->P.d(), p->ldp, 0, nullptr);
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), nullptr, p->opts.iw_l1_lambda_0, p->q.d(), nullptr);
+    LAUNCH_OK();
+    tm.mark(2);
+    qa.P = p->P.d(); qa.p_stride = 0; qa.active = nullptr;
+    TRY(launch_qp(st, qa));
+    tm.mark(3);
+    TRY(launch_init_weights(st, fs, B));
+    LAUNCH_OK();
+
+    // ---- outer loop (drt1d.py:877-988) ----------------------------------------------------------------------
+    for (int k = 0; k < 3; ++k) g.dfac[k] = p->opts.l2_lambda_0 * p->opts.derivative_weights[k];
+    qa.p_stride = (long long)n * p->ldp; qa.active = p->active.i();
+    int it = 0;
+    for (; it < p->opts.max_iter; ++it) {
+        tm.mark(1);
+        HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
+        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, p->P.d(), p->ldp, (long long)n * p->ldp, p->active.i());
+        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i());
+        LAUNCH_OK();
+        tm.mark(2);
+        TRY(launch_qp(st, qa));
+        tm.mark(3);
+        TRY(launch_hyper(st, fs, B, it));
+        LAUNCH_OK();
+        int n_active = 0;
+        HIPDRT_CHECK(hipMemcpyAsync(&n_active, p->n_active.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPDRT_CHECK(hipStreamSynchronize(st));
+        if (n_active == 0) break;
+    }
+    // ---- calculate_pq's q with the final weights (qphb.py:1154-1183) ---------------------------------------
+    tm.mark(4);
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr);
+    LAUNCH_OK();
+    tm.mark(-1);
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    tm.collect(p->t_ms, p->launches);
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_timings(hipdrt_plan* p, float* t, int* launches) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    if (t) std::memcpy(t, p->t_ms, sizeof(p->t_ms));
+    if (launches) std::memcpy(launches, p->launches, sizeof(p->launches));
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_download(hipdrt_plan* p, double* x, double* fit_x, double* r_inf, double* induc, double* weights,
+                         double* coef_scale, double* rho, double* s_vectors, double* q_vector, int* outer_iters,
+                         int* qp_iters_total, int* status) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_REQUIRE(p->B >= 1, "nothing fitted");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    const int B = p->B, n = p->n, m = p->m, ns = p->ns, ntau = p->ntau;
+    std::vector<double> hx((size_t)B * n), hcs(B);
+    HIPDRT_CHECK(hipMemcpy(hx.data(), p->x.p, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPDRT_CHECK(hipMemcpy(hcs.data(), p->coef_scale.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost));
+    if (x) std::memcpy(x, hx.data(), hx.size() * sizeof(double));
+    if (coef_scale) std::memcpy(coef_scale, hcs.data(), (size_t)B * sizeof(double));
+    // extract_qphb_parameters (drt1d.py:6228-6289)
+    for (int b = 0; b < B; ++b) {
+        const double cs = hcs[b];
+        const double* xb = hx.data() + (size_t)b * n;
+        if (fit_x) for (int i = 0; i < ntau; ++i) fit_x[(size_t)b * ntau + i] = xb[ns + i] * cs;
+        if (r_inf) r_inf[b] = p->idx_rinf >= 0 ? xb[p->idx_rinf] * cs : 0.0;
+        if (induc) induc[b] = p->idx_induc >= 0 ? xb[p->idx_induc] * (cs * p->opts.inductance_scale) : 0.0;
+    }
+    if (weights) HIPDRT_CHECK(hipMemcpy(weights, p->w.p, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost));
+    if (rho) HIPDRT_CHECK(hipMemcpy(rho, p->rho.p, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (s_vectors) HIPDRT_CHECK(hipMemcpy(s_vectors, p->s.p, (size_t)B * 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (q_vector) HIPDRT_CHECK(hipMemcpy(q_vector, p->q.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (outer_iters) HIPDRT_CHECK(hipMemcpy(outer_iters, p->outer_iters.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    if (qp_iters_total) HIPDRT_CHECK(hipMemcpy(qp_iters_total, p->qp_iters_total.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    if (status) HIPDRT_CHECK(hipMemcpy(status, p->fit_status.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
+    HIPDRT_REQUIRE(p && out, "NULL pointer");
+    HIPDRT_REQUIRE(b >= 0 && b < p->B, "spectrum index out of range");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const int n = p->n, m = p->m;
+    GramL2 g{};
+    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1;
+    for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = p->opts.l2_lambda_0 * p->opts.derivative_weights[k]; }
+    g.s = p->s.d() + (size_t)b * 3 * n; g.rho = p->rho.d() + (size_t)b * 3;
+    launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d() + (size_t)b * m, g, p->Ptmp.d(), p->ldp, 0, nullptr);
+    LAUNCH_OK();
+    return copy_strided(out, p->Ptmp.d(), n, n, p->ldp, st);
+}
+
+int hipdrt_plan_record_history(hipdrt_plan* p, int b) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    p->hist_b = b;
+    if (b >= 0 && p->hist_cap == 0) {
+        p->hist_cap = p->opts.max_iter;
+        HIPDRT_CHECK(p->hist_x.alloc((size_t)p->hist_cap * p->n * sizeof(double)));
+        HIPDRT_CHECK(p->hist_w.alloc((size_t)p->hist_cap * p->m * sizeof(double)));
+        HIPDRT_CHECK(p->hist_rho.alloc((size_t)p->hist_cap * 3 * sizeof(double)));
+        HIPDRT_CHECK(p->hist_qp.alloc((size_t)(p->hist_cap + 1) * sizeof(int)));
+    }
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_get_history(hipdrt_plan* p, double* hist_x, double* hist_rho, double* hist_w, int* qp_iters,
+                            int max_rows, int* rows) {
+    HIPDRT_REQUIRE(p && rows, "NULL pointer");
+    HIPDRT_REQUIRE(p->hist_b >= 0 && p->hist_cap > 0, "history recording was not enabled");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    int r = 0;
+    HIPDRT_CHECK(hipMemcpy(&r, p->hist_rows.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (r > max_rows) r = max_rows;
+    *rows = r;
+    if (hist_x) HIPDRT_CHECK(hipMemcpy(hist_x, p->hist_x.p, (size_t)r * p->n * sizeof(double), hipMemcpyDeviceToHost));
+    if (hist_w) HIPDRT_CHECK(hipMemcpy(hist_w, p->hist_w.p, (size_t)r * p->m * sizeof(double), hipMemcpyDeviceToHost));
+    if (hist_rho) HIPDRT_CHECK(hipMemcpy(hist_rho, p->hist_rho.p, (size_t)r * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (qp_iters) HIPDRT_CHECK(hipMemcpy(qp_iters, p->hist_qp.p, (size_t)(r + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    return HIPDRT_OK;
+}
+
+int hipdrt_fit_eis_batch(hipdrt_ctx* ctx, int B, const double* freq, int nf, const double* z_re, const double* z_im,
+                         const double* tau, int ntau, double epsilon, int mode, int toeplitz_a, int toeplitz_m,
+                         int ngrid, int ny, const double* wt_re, const double* wt_im, const double* log_wt_re,
+                         const double* log_wt_im, const hipdrt_fit_opts* opts, double* x, double* fit_x, double* r_inf,
+                         double* induc, double* weights, double* coef_scale, double* rho, double* q_vector,
+                         int* outer_iters, int* status) {
+    hipdrt_plan* p = nullptr;
+    TRY(hipdrt_plan_create(ctx, freq, nf, tau, ntau, epsilon, mode, toeplitz_a, toeplitz_m, ngrid, ny, wt_re, wt_im,
+                           log_wt_re, log_wt_im, opts, B, &p));
+    int rc = hipdrt_plan_upload(p, B, z_re, z_im);
+    if (!rc) rc = hipdrt_plan_fit(p);
+    if (!rc) rc = hipdrt_plan_download(p, x, fit_x, r_inf, induc, weights, coef_scale, rho, nullptr, q_vector,
+                                       outer_iters, nullptr, status);
+    hipdrt_plan_destroy(p);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+// Internal declarations shared by the HIP translation units of libhipdrt.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/hipdrt.h"
+
+namespace hipdrt {
+
+void set_error(const std::string& msg);
+
+#define HIPDRT_CHECK(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            hipdrt::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" +       \
+                              __FILE__ + ":" + std::to_string(__LINE__) + ")");                \
+            return HIPDRT_E_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+#define HIPDRT_REQUIRE(cond, msg)                                                              \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            hipdrt::set_error(std::string("invalid argument: ") + msg);                        \
+            return HIPDRT_E_INVALID;                                                           \
+        }                                                                                      \
+    } while (0)
+
+// RAII device buffer (freed on destruction; the ctx/plan own these)
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 8;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+    double* d() const { return static_cast<double*>(p); }
+    int* i() const { return static_cast<int*>(p); }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace hipdrt
+
+struct hipdrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 0;
+    size_t hbm_bytes = 0;
+    std::string arch;
+};
+
+// ---- launchers implemented in the .hip files (all asynchronous on `st`) ---------------------------------
+namespace hipdrt {
+
+// matrices.hip
+void launch_lookup(hipStream_t st, double eps, int ngrid, int ny, const double* wt_re, const double* wt_im,
+                   double* z_re, double* z_im);
+void launch_lookup_slopes(hipStream_t st, int ngrid, const double* xp, const double* fp, double* slopes);
+// lut = {log_wt_re, z_re, slope_re, log_wt_im, z_im, slope_im} each [ngrid], device
+void launch_impedance_matrix(hipStream_t st, int B, int freq_batched, const double* freq, int nf, const double* tau,
+                             int ntau, int mode, int toeplitz, double eps, int ngrid, const double* lut6, int ny,
+                             double* a_re, double* a_im, double* cr_scratch);
+void launch_penalty(hipStream_t st, const double* ln_tau, int n, double eps, int toeplitz, double* m0, double* m1,
+                    double* m2, int ld, int pad);
+void launch_eis_vmm(hipStream_t st, const double* freq, int nf, double vmm_eps, double reim_cor, int uniform,
+                    double* vmm);
+
+// gram.hip
+struct GramL2 {
+    // explicit L2 (stand-alone API) ...
+    const double* l2;
+    long long l2_stride;
+    int ldl2;
+    // ... or hyper-parameter form (fit loop)
+    const double* mk[3];   // padded penalty matrices [n][ldm]
+    int ldm;
+    const double* s;       // [B][3][n]
+    const double* rho;     // [B][3]
+    double dfac[3];        // l2_lambda_0 * derivative_weight[k]   (0 => order skipped)
+    int ns;
+    int use_rho;
+};
+void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const GramL2& g,
+                    double* P, int ldp, long long p_stride, const int* active);
+void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,
+                 const double* l1, double l1_scalar, double* q, const int* active);
+void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w,
+                          const double* b, const double* l2, long long l2_stride, int ldl2, const double* l1,
+                          double* P, int ldp, long long p_stride, double* q, const int* active);
+
+// hyper.hip: device-resident state of a batched fit (passed by value to the kernels)
+struct FitState {
+    int nf, m, n, ns, ldrm, ldm;
+    hipdrt_fit_opts opts;
+    // shared (plan) matrices
+    const double* rm;      // [m][ldrm]  stacked [Re; Im] response matrix incl. special columns
+    const double* vmm;     // [m][m]
+    const double* mk[3];   // [n][ldm]   padded penalty matrices
+    // per-spectrum
+    const double *z_re, *z_im;   // [B][nf]
+    double *rv, *w, *est_w;      // [B][m]
+    double *x, *x_in;            // [B][n]
+    double* s;                   // [B][3][n]
+    double *rho, *xmx;           // [B][3]
+    double *coef_scale, *var_floor;   // [B]
+    int *active, *outer_iters, *fit_status, *qp_iters_total, *qp_status, *qp_iters;   // [B]
+    int* n_active;               // [1]
+    // optional history of one spectrum
+    int hist_b, hist_cap;
+    double *hist_x, *hist_w, *hist_rho;
+    int *hist_qp, *hist_rows;
+};
+size_t hyper_lds_bytes(int n, int m, int ns);
+int launch_prep(hipStream_t s, const FitState& st, int B);
+int launch_init_weights(hipStream_t s, const FitState& st, int B);
+int launch_hyper(hipStream_t s, const FitState& st, int B, int it);
+void launch_assemble_rm(hipStream_t s, const FitState& st, const double* a_re, const double* a_im, const double* freq,
+                        double* rm, int idx_rinf, int idx_induc);
+void launch_special_penalty(hipStream_t s, double* m0, double* m1, double* m2, int ld, int idx_rinf, int idx_induc,
+                            double pen_r, double pen_l);
+void launch_make_h(hipStream_t s, double* h, int n, int ns, int nonneg);
+
+// qp.hip
+struct QpArgs {
+    int B, n;
+    const double* P;      // [B or 1][n][ldp]
+    long long p_stride;   // 0 if shared
+    int ldp;
+    const double* q;      // [B][n]
+    const double* h;      // [B or 1][n]
+    long long h_stride;
+    double* L;            // scratch [B][n_pad][ldl]
+    int ldl;
+    long long l_stride;
+    double* x;            // [B][n] out
+    int* iters;           // [B] out (may be null)
+    double* pcost;        // [B] out (may be null)
+    int* status;          // [B] out
+    const int* active;    // [B] or null: skip problems with active[b]==0
+    int* iters_accum;     // [B] or null: += iterations
+    hipdrt_qp_opts opts;
+};
+int launch_qp(hipStream_t st, const QpArgs& a);
+size_t qp_scratch_ld(int n);
+
+}  // namespace hipdrt

@@ -1,0 +1,173 @@
+// Weighted normal equations of qphb.solve_convex_opt (hybdrt/models/qphb.py:465-466) and the L2 assembly of
+// qphb.calculate_qp_l2_matrix (qphb.py:53-120), batched over spectra that share one response matrix A:
+//
+//     P_b = (W_b A)' (W_b A) + L2_b ,   L2_b = sum_k S_bk^1/2 (M_k o scale_bk) S_bk^1/2
+//     q_b = -(W_b A)' (W_b y_b) + l1
+//
+// FP64 only.  The contraction runs on v_mfma_f64_16x16x4_f64: a 256-thread workgroup
+// (4 wavefronts as 2x2) owns a 64x64 tile of the lower triangle of P_b, stages 16-row slabs of A (already
+// multiplied by w_b) through LDS and mirrors the tile into the upper triangle on store.  The reference forms
+// L2 with two dense n^3 products per derivative order; here it is the O(n^2) elementwise epilogue of the tile.
+#include "common.hpp"
+
+namespace hipdrt {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+static constexpr int GT = 64;        // tile edge
+static constexpr int GK = 16;        // K slab
+static constexpr int GLD = 80;       // LDS row stride in doubles (k-rows land 32 banks apart: conflict-free b64 reads)
+
+
+__global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* __restrict__ A, int lda,
+                                                   const double* __restrict__ w, GramL2 g, double* __restrict__ P,
+                                                   int ldp, long long p_stride, const int* __restrict__ active,
+                                                   int ntile) {
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    // decode lower-triangular tile index -> (ti >= tj)
+    int t = blockIdx.x, ti = 0;
+    while (t >= ti + 1) { t -= ti + 1; ++ti; }
+    const int tj = t;
+    const int i0 = ti * GT, j0 = tj * GT;
+    const bool diag = (ti == tj);
+
+    __shared__ double sI[GK * GLD];
+    __shared__ double sJ[GK * GLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;     // wave's 32x32 sub-tile
+    const double* wb = w + (size_t)b * m;
+
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // staging map: thread -> (k = tid/16, 4 consecutive columns)
+    const int sk = tid >> 4, sc = (tid & 15) * 4;
+    for (int k0 = 0; k0 < m; k0 += GK) {
+        const int k = k0 + sk;
+        double wk = 0.0;
+        if (k < m) wk = wb[k];
+        double vi[4] = {0, 0, 0, 0}, vj[4] = {0, 0, 0, 0};
+        if (k < m) {
+            const double* row = A + (size_t)k * lda;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = i0 + sc + e, cj = j0 + sc + e;
+                if (ci < n) vi[e] = wk * row[ci];
+                if (!diag && cj < n) vj[e] = wk * row[cj];
+            }
+        }
+        __syncthreads();   // previous slab fully consumed
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sI[sk * GLD + sc + e] = vi[e];
+            if (!diag) sJ[sk * GLD + sc + e] = vj[e];
+        }
+        __syncthreads();
+        const double* sj = diag ? sI : sJ;
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 4) {
+            const int kr = kk + (lane >> 4);
+            double a0 = sI[kr * GLD + wi + (lane & 15)];
+            double a1 = sI[kr * GLD + wi + 16 + (lane & 15)];
+            double b0 = sj[kr * GLD + wj + (lane & 15)];
+            double b1 = sj[kr * GLD + wj + 16 + (lane & 15)];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // epilogue: + L2, store lower tile and its mirror.  C/D map of v_mfma_f64_16x16x4: col = lane&15,
+    // row = (lane>>4) + 4*reg.
+    double* Pb = P + (size_t)b * p_stride;
+    const double* sb = g.s ? g.s + (size_t)b * 3 * n : nullptr;
+    double fac[3] = {0, 0, 0};
+    if (g.s) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fac[k] = g.dfac[k] * (g.use_rho ? g.rho[(size_t)b * 3 + k] : 1.0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi + a * 16 + (lane >> 4) + 4 * r;
+                const int j = j0 + wj + c * 16 + (lane & 15);
+                if (i >= n || j >= n) continue;
+                if (diag && j > i) continue;          // upper part of a diagonal tile comes from the mirror
+                double v = acc[a][c][r];
+                if (g.s) {
+                    double l2 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (g.dfac[k] > 0.0) {
+                            double mv = g.mk[k][(size_t)i * g.ldm + j];
+                            if (i >= g.ns && j >= g.ns) mv *= fac[k];
+                            l2 += (sqrt(sb[k * n + i]) * mv) * sqrt(sb[k * n + j]);
+                        }
+                    }
+                    v += l2;
+                } else if (g.l2) {
+                    v += g.l2[(size_t)b * g.l2_stride + (size_t)i * g.ldl2 + j];
+                }
+                Pb[(size_t)i * ldp + j] = v;
+                if (i != j) Pb[(size_t)j * ldp + i] = v;
+            }
+}
+
+// q_b[i] = -sum_k (w_k A_ki)(w_k y_k) + l1_i ; grid (ceil(n/256), B)
+__global__ __launch_bounds__(256) void qvec_kernel(int m, int n, const double* __restrict__ A, int lda,
+                                                   const double* __restrict__ w, const double* __restrict__ y,
+                                                   const double* __restrict__ l1, double l1_scalar,
+                                                   double* __restrict__ q, const int* __restrict__ active) {
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    __shared__ double sw[256], swy[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double* wb = w + (size_t)b * m;
+    const double* yb = y + (size_t)b * m;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < m; k0 += 256) {
+        __syncthreads();
+        const int kk = k0 + threadIdx.x;
+        if (kk < m) { const double wk = wb[kk]; sw[threadIdx.x] = wk; swy[threadIdx.x] = wk * yb[kk]; }
+        __syncthreads();
+        const int lim = (m - k0) < 256 ? (m - k0) : 256;
+        if (i < n) {
+            for (int k = 0; k < lim; ++k) acc += (sw[k] * A[(size_t)(k0 + k) * lda + i]) * swy[k];
+        }
+    }
+    if (i < n) q[(size_t)b * n + i] = -acc + (l1 ? l1[i] : l1_scalar);
+}
+
+void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const GramL2& g,
+                    double* P, int ldp, long long p_stride, const int* active) {
+    const int nt = (n + GT - 1) / GT;
+    const int ntile = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(gram_kernel, dim3(ntile, B), dim3(256), 0, st, m, n, A, lda, w, g, P, ldp, p_stride, active,
+                       ntile);
+}
+
+void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,
+                 const double* l1, double l1_scalar, double* q, const int* active) {
+    hipLaunchKernelGGL(qvec_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, m, n, A, lda, w, y, l1, l1_scalar, q,
+                       active);
+}
+
+void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w,
+                          const double* b, const double* l2, long long l2_stride, int ldl2, const double* l1,
+                          double* P, int ldp, long long p_stride, double* q, const int* active) {
+    GramL2 g{};
+    g.l2 = l2; g.l2_stride = l2_stride; g.ldl2 = ldl2; g.s = nullptr;
+    launch_gram_l2(st, B, m, n, A, lda, w, g, P, ldp, p_stride, active);
+    launch_qvec(st, B, m, n, A, lda, w, b, l1, 0.0, q, active);
+}
+
+}  // namespace hipdrt

@@ -1,0 +1,402 @@
+// Per-spectrum pieces of the QPHB outer loop that are not the QP itself (one 512-thread workgroup per spectrum):
+//
+//   prep_kernel       DRTBase.scale_data / pp.estimate_rp (EIS branch)   hybdrt/models/drtbase.py:439-514,
+//                     preprocessing.py:828-841; state initialisation     drt1d.py:542-566, 612
+//   weights_kernel    qphb.estimate_weights                               hybdrt/models/qphb.py:1545-1594
+//   hyper_kernel      the s_k / rho_k updates of qphb.iterate_qphb (qphb.py:718-816) = solve_s (320-356) +
+//                     solve_rho (385-405), the xmx_norms freeze (drt1d.py:946-951), estimate_weights and the
+//                     convergence rule (qphb.py:597-603, 969-970)
+//
+// The reference codes solve_s / calculate_qp_l2_matrix as dense n^3 diagonal products; algebraically they are
+// row sums of elementwise products, done here as one wavefront per matrix row (coalesced row reads of the shared
+// penalty / response / variance matrices, which stay L2/Infinity-Cache resident across the batch).
+#include "common.hpp"
+
+namespace hipdrt {
+
+static constexpr int HT = 512;
+static constexpr int HNW = HT / 64;
+
+__device__ __forceinline__ double hw_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double hw_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double hw_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// block-wide reductions over HT threads; red = LDS [HNW]; two syncs so `red` is immediately reusable
+__device__ __forceinline__ double blk_sum(double v, double* red) {
+    v = hw_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < HNW; ++w) t += red[w];
+    return t;
+}
+__device__ __forceinline__ double blk_max(double v, double* red) {
+    v = hw_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < HNW; ++w) t = fmax(t, red[w]);
+    return t;
+}
+__device__ __forceinline__ double blk_min(double v, double* red) {
+    v = hw_min(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < HNW; ++w) t = fmin(t, red[w]);
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prep: scaling + state init.  grid = B
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HT) void prep_kernel(FitState st) {
+    __shared__ double red[HNW];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nf = st.nf, m = st.m, n = st.n;
+    const double* zr = st.z_re + (size_t)b * nf;
+    const double* zi = st.z_im + (size_t)b * nf;
+    double mx = -INFINITY, mn = INFINITY;
+    for (int i = tid; i < nf; i += HT) { mx = fmax(mx, zr[i]); mn = fmin(mn, zr[i]); }
+    mx = blk_max(mx, red);
+    mn = blk_min(mn, red);
+    double cs = 1.0;
+    if (st.opts.scale_data) cs = (mx - mn) / st.opts.rp_scale;     // rp_est / rp_scale
+    double* rv = st.rv + (size_t)b * m;
+    double s1 = 0.0;
+    for (int i = tid; i < m; i += HT) {
+        const double v = (i < nf ? zr[i] : zi[i - nf]) / cs;
+        rv[i] = v;
+        s1 += v;
+    }
+    const double mean = blk_sum(s1, red) / (double)m;
+    double s2 = 0.0;
+    for (int i = tid; i < m; i += HT) { const double dv = rv[i] - mean; s2 += dv * dv; }
+    const double var = blk_sum(s2, red) / (double)m;                 // np.var
+    for (int i = tid; i < m; i += HT) st.w[(size_t)b * m + i] = 1.0;  // unweighted initial-weights QP
+    for (int k = 0; k < 3; ++k)
+        for (int i = tid; i < n; i += HT) st.s[((size_t)b * 3 + k) * n + i] = st.opts.s_0[k];
+    for (int i = tid; i < n; i += HT) { st.x[(size_t)b * n + i] = 1e-6; st.x_in[(size_t)b * n + i] = 1e-6; }
+    if (tid == 0) {
+        st.coef_scale[b] = cs;
+        st.var_floor[b] = var * 1e-7;
+        for (int k = 0; k < 3; ++k) { st.rho[(size_t)b * 3 + k] = st.opts.rho_0[k]; st.xmx[(size_t)b * 3 + k] = 1.0; }
+        st.active[b] = 1;
+        st.outer_iters[b] = 0;
+        st.fit_status[b] = 1;
+        st.qp_iters_total[b] = 0;
+    }
+}
+
+// y[i] = sum_j M[i][j] * v[j] for the rows owned by this wavefront; v in LDS; result to LDS out
+__device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld, int nrow, int ncol,
+                                            const double* __restrict__ v, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = wv; i < nrow; i += HNW) {
+        const double* row = M + (size_t)i * ld;
+        double s = 0.0;
+        for (int j = lane; j < ncol; j += 64) s += row[j] * v[j];
+        s = hw_sum(s);
+        if (lane == 0) out[i] = s;
+    }
+}
+
+// estimate_weights for spectrum b: xs = LDS x[n]; tmp = LDS [m]; result written to w_out[m] (global)
+__device__ void estimate_weights_dev(const FitState& st, int b, const double* xs, double* tmp, double* tmp2,
+                                     const double* est_w, double* w_out) {
+    const int m = st.m, n = st.n, tid = threadIdx.x;
+    const double* rv = st.rv + (size_t)b * m;
+    rows_matvec(st.rm, st.ldrm, m, n, xs, tmp);        // rm @ x
+    __syncthreads();
+    for (int i = tid; i < m; i += HT) { const double r = tmp[i] - rv[i]; tmp[i] = r * r; }
+    __syncthreads();
+    rows_matvec(st.vmm, m, m, m, tmp, tmp2);           // vmm @ resid**2
+    __syncthreads();
+    const double vf = st.var_floor[b];
+    for (int i = tid; i < m; i += HT) {
+        double sh = tmp2[i];
+        if (sh < vf) sh = vf;
+        double wh = 1.0 / sqrt(sh);                      // s_hat ** -0.5
+        if (est_w) {
+            const double ew = est_w[i];
+            const double fc = wh / (wh + ew);
+            const double fe = 1.0 - fc;
+            wh = fc * wh + fe * ew;
+        }
+        w_out[i] = fmax(wh, 1e-10);
+    }
+    __syncthreads();
+}
+
+// after the initial-weights QP: est_weights = estimate_weights(x_overfit, est_weights=None); weights = est
+__global__ __launch_bounds__(HT) void init_weights_kernel(FitState st) {
+    extern __shared__ double sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, n = st.n, m = st.m;
+    double* xs = sm;
+    double* tmp = xs + n;
+    double* tmp2 = tmp + m;
+    if (st.qp_status[b] < 0) {
+        if (tid == 0) { st.active[b] = 0; st.fit_status[b] = -1; }
+        return;
+    }
+    for (int i = tid; i < n; i += HT) xs[i] = st.x[(size_t)b * n + i];
+    __syncthreads();
+    estimate_weights_dev(st, b, xs, tmp, tmp2, nullptr, st.est_w + (size_t)b * m);
+    for (int i = tid; i < m; i += HT) st.w[(size_t)b * m + i] = st.est_w[(size_t)b * m + i];
+    // the outer loop starts from x = 1e-6 (drt1d.py:612), not from x_overfit
+    for (int i = tid; i < n; i += HT) st.x[(size_t)b * n + i] = 1e-6;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// hyper-parameter update + weights + convergence for one outer iteration.  grid = B
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
+    extern __shared__ double sm[];
+    __shared__ double red[HNW];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!st.active[b]) return;
+    const int n = st.n, m = st.m, ns = st.ns, nd = n - ns;
+    double* xs = sm;              // [n]   new x
+    double* bsum = xs + n;        // [nd]  off-diagonal row sums of gamma @ diag(sqrt s)
+    double* gdia = bsum + nd;     // [nd]  diag(gamma)
+    double* sq = gdia + nd;       // [nd]  sqrt(s_k)
+    double* xh = sq + nd;         // [nd]  sign(x) sqrt|x|
+    double* tmp = xh + nd;        // [max(m, nd)]
+    const int tl = m > nd ? m : nd;
+    double* tmp2 = tmp + tl;      // [max(m, nd)]
+
+    if (st.qp_status[b] < 0) {    // QP broke down at its start point: cvxopt raises, DRTMD flags the observation
+        if (tid == 0) { st.active[b] = 0; st.fit_status[b] = -1; st.outer_iters[b] = it + 1; }
+        return;
+    }
+    double* xg = st.x + (size_t)b * n;
+    for (int i = tid; i < n; i += HT) xs[i] = xg[i];
+    __syncthreads();
+    const double* xd = xs + ns;
+    for (int i = tid; i < nd; i += HT) {
+        const double v = xd[i];
+        const double sg = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
+        xh[i] = sg * sqrt(fabs(v));
+    }
+    __syncthreads();
+
+    for (int k = 0; k < 3; ++k) {
+        if (!(st.opts.derivative_weights[k] > 0.0)) continue;
+        double* sk = st.s + ((size_t)b * 3 + k) * n + ns;
+        const double* Mk = st.mk[k] + (size_t)ns * st.ldm + ns;
+        const double* M1 = st.mk[1] + (size_t)ns * st.ldm + ns;
+        const double alpha = st.opts.s_alpha[k];
+        const double beta = (alpha - 1.0) / st.opts.s_0[k];
+        const double sig2 = 2.0 * st.opts.sigma_ds[k] * st.opts.sigma_ds[k];
+        for (int i = tid; i < nd; i += HT) sq[i] = sqrt(sk[i]);
+        __syncthreads();
+        // gamma = X M X + G/(2 sigma^2) + beta I ; gu = gamma @ diag(sqrt s), zero diagonal
+        double gmax = 0.0;
+        for (int i = wv; i < nd; i += HNW) {
+            const double* row = Mk + (size_t)i * st.ldm;
+            const double* row1 = M1 + (size_t)i * st.ldm;
+            const double xi = xd[i], xhi = xh[i];
+            double sacc = 0.0, mxx = 0.0, dg = 0.0;
+            for (int j = lane; j < nd; j += 64) {
+                double g = (xi * row[j]) * xd[j];
+                if (k == 0) g += ((xhi * row1[j]) * xh[j]) / sig2;
+                if (j == i) dg = g + beta;
+                else {
+                    const double gu = g * sq[j];
+                    sacc += gu;
+                    mxx = fmax(mxx, fabs(gu));
+                }
+            }
+            sacc = hw_sum(sacc);
+            mxx = hw_max(mxx);
+            dg = hw_sum(dg);      // exactly one lane holds the diagonal entry
+            gmax = fmax(gmax, mxx);
+            if (lane == 0) { bsum[i] = sacc; gdia[i] = dg; }
+        }
+        gmax = blk_max(gmax, red);   // also orders bsum/gdia writes before the reads below
+        for (int i = tid; i < nd; i += HT) {
+            const double gd = gdia[i];
+            double sh;
+            if (gmax > 1e-10) {
+                const double bb = bsum[i];
+                const double sgn = (bb > 0.0) ? 1.0 : ((bb < 0.0) ? -1.0 : 0.0);
+                const double u = (-bb + sgn * sqrt(bb * bb + 4.0 * gd * (alpha - 1.0))) / (2.0 * gd);
+                sh = u * u;
+            } else {
+                sh = (alpha - 1.0) / gd;
+            }
+            if (sh != sh) sh = 1.0;          // s_hat[isnan] = 1
+            if (sh <= 0.0) sh = 1e-15;       // caller's floor (qphb.py:780)
+            sk[i] = sh;
+            tmp[i] = sqrt(sh) * xd[i];       // v = S^1/2 x for solve_rho
+        }
+        __syncthreads();
+        rows_matvec(Mk, st.ldm, nd, nd, tmp, tmp2);
+        __syncthreads();
+        double part = 0.0;
+        for (int i = tid; i < nd; i += HT) part += tmp[i] * tmp2[i];
+        const double xsmsx = blk_sum(part, red);
+        if (tid == 0) {
+            const double ra = st.opts.rho_alpha[k];
+            const double rb = ra / st.opts.rho_0[k];
+            st.rho[(size_t)b * 3 + k] = ra / (xsmsx / st.xmx[(size_t)b * 3 + k] + rb);
+        }
+        __syncthreads();
+    }
+
+    if (it == 0) {   // xmx_norms frozen after the first iteration (drt1d.py:946-951)
+        for (int k = 0; k < 3; ++k) {
+            const double* Mk = st.mk[k] + (size_t)ns * st.ldm + ns;
+            rows_matvec(Mk, st.ldm, nd, nd, xd, tmp2);
+            __syncthreads();
+            double part = 0.0;
+            for (int i = tid; i < nd; i += HT) part += xd[i] * tmp2[i];
+            const double v = blk_sum(part, red);
+            if (tid == 0) st.xmx[(size_t)b * 3 + k] = v;
+            __syncthreads();
+        }
+    }
+
+    // weights
+    double* wg = st.w + (size_t)b * m;
+    estimate_weights_dev(st, b, xs, tmp, tmp2, st.est_w + (size_t)b * m, wg);
+
+    // convergence (qphb.py:597-603, 969-970)
+    double* xin = st.x_in + (size_t)b * n;
+    double mrel = 0.0, mabs = 0.0, sx = 0.0;
+    for (int i = tid; i < n; i += HT) {
+        const double xi0 = xin[i];
+        const double dlt = xs[i] - xi0;
+        mrel = fmax(mrel, fabs(dlt / (xi0 + 1e-15)));
+        mabs = fmax(mabs, fabs(dlt));
+        sx += xi0;
+    }
+    mrel = blk_max(mrel, red);
+    mabs = blk_max(mabs, red);
+    sx = blk_sum(sx, red);
+    const double atol = sx / (double)n * 1e-3;
+    const bool conv = (mrel <= st.opts.xtol) || (mabs <= atol);
+    for (int i = tid; i < n; i += HT) xin[i] = xs[i];
+    if (st.hist_b == b && it < st.hist_cap) {
+        for (int i = tid; i < n; i += HT) st.hist_x[(size_t)it * n + i] = xs[i];
+        for (int i = tid; i < m; i += HT) st.hist_w[(size_t)it * m + i] = wg[i];
+        if (tid < 3) st.hist_rho[(size_t)it * 3 + tid] = st.rho[(size_t)b * 3 + tid];
+        if (tid == 0) { st.hist_qp[it + 1] = st.qp_iters[b]; st.hist_rows[0] = it + 1; }
+    }
+    if (tid == 0) {
+        st.outer_iters[b] = it + 1;
+        if (conv) { st.active[b] = 0; st.fit_status[b] = 0; }
+        else if (it + 1 >= st.opts.max_iter) { st.active[b] = 0; st.fit_status[b] = 1; }
+        if (!conv && it + 1 < st.opts.max_iter) atomicAdd(st.n_active, 1);
+    }
+}
+
+__global__ void record_init_qp_kernel(FitState st) {
+    if (st.hist_b >= 0 && threadIdx.x == 0) st.hist_qp[0] = st.qp_iters[st.hist_b];
+}
+
+// specials: diagonal penalties of the padded M_k (drt1d.py:5880-5896) and the special columns of the stacked
+// response matrix rm = [Re; Im] (drt1d.py:5825-5857)
+__global__ void assemble_rm_kernel(FitState st, const double* __restrict__ a_re, const double* __restrict__ a_im,
+                                   const double* __restrict__ freq, double* __restrict__ rm, int idx_rinf,
+                                   int idx_induc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;   // column of rm
+    const int i = blockIdx.y;                              // row in [0, 2nf)
+    const int n = st.n, nf = st.nf, ns = st.ns, ntau = n - ns;
+    if (j >= n) return;
+    const bool im = i >= nf;
+    const int r = im ? i - nf : i;
+    double v;
+    if (j >= ns) v = im ? a_im[(size_t)r * ntau + (j - ns)] : a_re[(size_t)r * ntau + (j - ns)];
+    else if (j == idx_rinf) v = im ? 0.0 : 1.0;
+    else if (j == idx_induc) v = im ? (2.0 * 3.141592653589793 * freq[r]) * st.opts.inductance_scale : 0.0;
+    else v = 0.0;
+    rm[(size_t)i * st.ldrm + j] = v;
+}
+
+__global__ void special_penalty_kernel(double* m0, double* m1, double* m2, int ld, int idx_rinf, int idx_induc,
+                                       double pen_r, double pen_l) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double* ms[3] = {m0, m1, m2};
+        for (int k = 0; k < 3; ++k) {
+            if (idx_rinf >= 0) ms[k][(size_t)idx_rinf * ld + idx_rinf] = pen_r;
+            if (idx_induc >= 0) ms[k][(size_t)idx_induc * ld + idx_induc] = pen_l;
+        }
+    }
+}
+
+__global__ void make_h_kernel(double* h, int n, int ns, int nonneg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // make_h_constraint (qphb.py:521-557): R_inf / inductance are always non-negative specials
+    h[i] = (nonneg || i < ns) ? 0.0 : 1e5;
+}
+
+size_t hyper_lds_bytes(int n, int m, int ns) {
+    const int nd = n - ns;
+    const int tl = m > nd ? m : nd;
+    return ((size_t)n + 4 * (size_t)nd + 2 * (size_t)tl) * sizeof(double);
+}
+
+int launch_prep(hipStream_t s, const FitState& st, int B) {
+    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(HT), 0, s, st);
+    return 0;
+}
+
+static int set_lds(const void* f, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    return 0;
+}
+
+int launch_init_weights(hipStream_t s, const FitState& st, int B) {
+    const size_t lds = ((size_t)st.n + 2 * (size_t)st.m) * sizeof(double);
+    if (int rc = set_lds(reinterpret_cast<const void*>(init_weights_kernel), lds)) return rc;
+    hipLaunchKernelGGL(init_weights_kernel, dim3(B), dim3(HT), lds, s, st);
+    hipLaunchKernelGGL(record_init_qp_kernel, dim3(1), dim3(64), 0, s, st);
+    return 0;
+}
+
+int launch_hyper(hipStream_t s, const FitState& st, int B, int it) {
+    const size_t lds = hyper_lds_bytes(st.n, st.m, st.ns);
+    if (int rc = set_lds(reinterpret_cast<const void*>(hyper_kernel), lds)) return rc;
+    hipLaunchKernelGGL(hyper_kernel, dim3(B), dim3(HT), lds, s, st, it);
+    return 0;
+}
+
+void launch_assemble_rm(hipStream_t s, const FitState& st, const double* a_re, const double* a_im, const double* freq,
+                        double* rm, int idx_rinf, int idx_induc) {
+    hipLaunchKernelGGL(assemble_rm_kernel, dim3((st.n + 255) / 256, st.m), dim3(256), 0, s, st, a_re, a_im, freq, rm,
+                       idx_rinf, idx_induc);
+}
+
+void launch_special_penalty(hipStream_t s, double* m0, double* m1, double* m2, int ld, int idx_rinf, int idx_induc,
+                            double pen_r, double pen_l) {
+    hipLaunchKernelGGL(special_penalty_kernel, dim3(1), dim3(64), 0, s, m0, m1, m2, ld, idx_rinf, idx_induc, pen_r,
+                       pen_l);
+}
+
+void launch_make_h(hipStream_t s, double* h, int n, int ns, int nonneg) {
+    hipLaunchKernelGGL(make_h_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h, n, ns, nonneg);
+}
+
+}  // namespace hipdrt

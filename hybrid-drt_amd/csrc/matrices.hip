@@ -1,0 +1,361 @@
+// Kernel-matrix builders for gfx950 (compiled with -ffp-contract=off so that the interpolation
+// arithmetic rounds exactly like numpy's un-fused slope*(x-xp[j])+fp[j]).
+//
+//  lookup_kernel          basis.generate_impedance_lookup        hybdrt/matrices/basis.py:648-669
+//  impedance_*_kernel     mat1d.construct_impedance_matrix        hybdrt/matrices/mat1d.py:212-374
+//  penalty_kernel         mat1d.construct_integrated_derivative_matrix  mat1d.py:125-209, basis.py:382-395
+//  eis_vmm_kernel         mat1d.construct_eis_var_matrix          mat1d.py:493-515
+//
+// Layout: every matrix row-major float64.  The interp build is HBM-write bound (2*nf*ntau*8 B per
+// frequency grid); the lookup tables (3 arrays x 2 parts x ngrid x 8 B = 96 kB at ngrid=2000) are staged
+// once per workgroup into LDS, each thread produces two adjacent tau columns of both parts and stores them
+// as 16-byte vectors, so a wavefront writes 1 KiB contiguous per store instruction.
+#include "common.hpp"
+
+namespace hipdrt {
+
+
+// ---------------------------------------------------------------------------------------------------------
+// integrands (basis.py:93-95, 565-570) evaluated for one y; lw = log(w*t), wt = w*t
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void integrand(double phi, double ey, double y, double lw, double w, double t,
+                                          double& fre, double& fim) {
+    const double den = 1.0 + exp(2.0 * (y + lw));
+    fre = phi / den;
+    fim = (((-phi) * ey) * w) * t / den;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// One wavefront integrates one (w, t) pair with the ny-point trapezoid rule of np.trapezoid:
+// sum_j d_j * (f_{j+1} + f_j) / 2 on y = linspace(-20, 20, ny).  ys/phis/eys are LDS tables [ny].
+__device__ __forceinline__ void trapz_pair(const double* ys, const double* phis, const double* eys, int ny,
+                                           double w, double t, int lane, double& zre, double& zim) {
+    const double lw = log(w * t);
+    double sre = 0.0, sim = 0.0;
+    for (int j = lane; j < ny - 1; j += 64) {
+        double f0r, f0i, f1r, f1i;
+        integrand(phis[j], eys[j], ys[j], lw, w, t, f0r, f0i);
+        integrand(phis[j + 1], eys[j + 1], ys[j + 1], lw, w, t, f1r, f1i);
+        const double d = ys[j + 1] - ys[j];
+        sre += d * (f1r + f0r) / 2.0;
+        sim += d * (f1i + f0i) / 2.0;
+    }
+    zre = wave_sum(sre);
+    zim = wave_sum(sim);
+}
+
+__device__ __forceinline__ void fill_y_tables(double* ys, double* phis, double* eys, int ny, double eps) {
+    const double step = 40.0 / (double)(ny - 1);   // np.linspace(-20, 20, ny)
+    for (int j = threadIdx.x; j < ny; j += blockDim.x) {
+        double y = (double)j * step + (-20.0);
+        if (j == ny - 1) y = 20.0;
+        ys[j] = y;
+        const double ey2 = eps * y;
+        phis[j] = exp(-(ey2 * ey2));
+        eys[j] = exp(y);
+    }
+}
+
+// grid: ceil(2*ngrid / 4) blocks of 256 threads; wave g handles table entry g (re for g < ngrid, else im)
+__global__ __launch_bounds__(256) void lookup_kernel(double eps, int ngrid, int ny, const double* __restrict__ wt_re,
+                                                     const double* __restrict__ wt_im, double* __restrict__ z_re,
+                                                     double* __restrict__ z_im) {
+    extern __shared__ double sm[];
+    double* ys = sm;
+    double* phis = sm + ny;
+    double* eys = sm + 2 * ny;
+    fill_y_tables(ys, phis, eys, ny, eps);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= 2 * ngrid) return;
+    const bool im = g >= ngrid;
+    const int i = im ? g - ngrid : g;
+    const double wt = im ? wt_im[i] : wt_re[i];
+    double zr, zi;
+    trapz_pair(ys, phis, eys, ny, wt, 1.0, lane, zr, zi);
+    if (lane == 0) {
+        if (im) z_im[i] = zi; else z_re[i] = zr;
+    }
+}
+
+__global__ void slopes_kernel(int ngrid, const double* __restrict__ xp, const double* __restrict__ fp,
+                              double* __restrict__ slopes) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < ngrid - 1) slopes[j] = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    else if (j == ngrid - 1) slopes[j] = 0.0;
+}
+
+// np.interp(x, xp, fp) with numpy's semantics (end clamping, exact-knot shortcut, un-fused evaluation).
+// xp is log(logspace(..)), i.e. uniform to ~1e-15, so the bin is found arithmetically and then verified
+// against the true knots (result identical to numpy's binary search).
+__device__ __forceinline__ double np_interp(double x, const double* xp, const double* fp, const double* sl,
+                                            int ng, double x0, double inv_dx) {
+    if (x > xp[ng - 1]) return fp[ng - 1];
+    if (x < xp[0]) return fp[0];
+    int j = (int)((x - x0) * inv_dx);
+    j = j < 0 ? 0 : (j > ng - 1 ? ng - 1 : j);
+    while (j > 0 && xp[j] > x) --j;
+    while (j < ng - 1 && xp[j + 1] <= x) ++j;
+    if (j == ng - 1) return fp[j];
+    const double xj = xp[j];
+    if (xj == x) return fp[j];
+    return sl[j] * (x - xj) + fp[j];
+}
+
+struct LutView {
+    const double *xr, *fr, *sr, *xi, *fi, *si;
+};
+
+__device__ __forceinline__ LutView stage_lut(double* sm, const double* __restrict__ lut6, int ng) {
+    for (int i = threadIdx.x; i < 6 * ng; i += blockDim.x) sm[i] = lut6[i];
+    __syncthreads();
+    return LutView{sm, sm + ng, sm + 2 * ng, sm + 3 * ng, sm + 4 * ng, sm + 5 * ng};
+}
+
+// INTERP, general (non-Toeplitz) build.  grid = (ceil(ntau/2/TPB), rows_per_block groups, B).
+// Each block stages the tables once and walks `rows_per_block` frequency rows.
+__global__ __launch_bounds__(1024) void impedance_interp_kernel(
+    int freq_batched, const double* __restrict__ freq, int nf, const double* __restrict__ tau, int ntau, int ng,
+    const double* __restrict__ lut6, int rows_per_block, double* __restrict__ a_re, double* __restrict__ a_im) {
+    extern __shared__ double sm[];
+    const LutView L = stage_lut(sm, lut6, ng);
+    const double x0r = L.xr[0], idr = (double)(ng - 1) / (L.xr[ng - 1] - L.xr[0]);
+    const double x0i = L.xi[0], idi = (double)(ng - 1) / (L.xi[ng - 1] - L.xi[0]);
+    const int b = blockIdx.z;
+    const double* fr = freq + (freq_batched ? (size_t)b * nf : 0);
+    const int row0 = blockIdx.y * rows_per_block;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (c >= ntau) return;
+    const bool two = (c + 1 < ntau);
+    const double t0 = tau[c], t1 = two ? tau[c + 1] : 0.0;
+    for (int r = row0; r < row0 + rows_per_block && r < nf; ++r) {
+        const double w = fr[r] * 2.0 * 3.141592653589793;   // frequencies * 2 * np.pi
+        const double xa = log(w * t0);
+        double re0 = np_interp(xa, L.xr, L.fr, L.sr, ng, x0r, idr);
+        double im0 = np_interp(xa, L.xi, L.fi, L.si, ng, x0i, idi);
+        const size_t o = ((size_t)b * nf + r) * ntau + c;
+        if (two) {
+            const double xb = log(w * t1);
+            double re1 = np_interp(xb, L.xr, L.fr, L.sr, ng, x0r, idr);
+            double im1 = np_interp(xb, L.xi, L.fi, L.si, ng, x0i, idi);
+            if ((ntau & 1) == 0) {
+                *reinterpret_cast<double2*>(a_re + o) = make_double2(re0, re1);
+                *reinterpret_cast<double2*>(a_im + o) = make_double2(im0, im1);
+            } else {
+                a_re[o] = re0; a_re[o + 1] = re1;
+                a_im[o] = im0; a_im[o + 1] = im1;
+            }
+        } else {
+            a_re[o] = re0;
+            a_im[o] = im0;
+        }
+    }
+}
+
+// first column c[nf] (omega_n * tau_0) and first row r[ntau] (omega_0 * tau_m) of the Toeplitz shortcut
+// (mat1d.py:353-360).  cr = {c_re[nf], r_re[ntau], c_im[nf], r_im[ntau]}.
+// INTERP: one thread per entry; TRAPZ: one wavefront per entry.
+__global__ void toeplitz_cr_interp_kernel(const double* __restrict__ freq, int nf, const double* __restrict__ tau,
+                                          int ntau, int ng, const double* __restrict__ lut6, double* __restrict__ cr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf + ntau) return;
+    const double* xr = lut6; const double* fr = lut6 + ng; const double* sr = lut6 + 2 * ng;
+    const double* xi = lut6 + 3 * ng; const double* fi = lut6 + 4 * ng; const double* si = lut6 + 5 * ng;
+    const double idr = (double)(ng - 1) / (xr[ng - 1] - xr[0]);
+    const double idi = (double)(ng - 1) / (xi[ng - 1] - xi[0]);
+    double w, t;
+    if (i < nf) { w = freq[i] * 2.0 * 3.141592653589793; t = tau[0]; }
+    else { w = freq[0] * 2.0 * 3.141592653589793; t = tau[i - nf]; }
+    const double x = log(w * t);
+    cr[i] = np_interp(x, xr, fr, sr, ng, xr[0], idr);
+    cr[nf + ntau + i] = np_interp(x, xi, fi, si, ng, xi[0], idi);
+}
+
+__global__ __launch_bounds__(256) void toeplitz_cr_trapz_kernel(const double* __restrict__ freq, int nf,
+                                                                const double* __restrict__ tau, int ntau, double eps,
+                                                                int ny, double* __restrict__ cr) {
+    extern __shared__ double sm[];
+    double* ys = sm; double* phis = sm + ny; double* eys = sm + 2 * ny;
+    fill_y_tables(ys, phis, eys, ny, eps);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nf + ntau) return;
+    double w, t;
+    if (i < nf) { w = freq[i] * 2.0 * 3.141592653589793; t = tau[0]; }
+    else { w = freq[0] * 2.0 * 3.141592653589793; t = tau[i - nf]; }
+    double zr, zi;
+    trapz_pair(ys, phis, eys, ny, w, t, lane, zr, zi);
+    if (lane == 0) { cr[i] = zr; cr[nf + ntau + i] = zi; }
+}
+
+// scipy.linalg.toeplitz(c, r): A[i][j] = c[i-j] (i >= j) else r[j-i]
+__global__ void toeplitz_fill_kernel(int B, int nf, int ntau, const double* __restrict__ cr, double* __restrict__ a_re,
+                                     double* __restrict__ a_im) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= ntau) return;
+    const double* c_re = cr; const double* r_re = cr + nf;
+    const double* c_im = cr + nf + ntau; const double* r_im = c_im + nf;
+    const double vr = (i >= j) ? c_re[i - j] : r_re[j - i];
+    const double vi = (i >= j) ? c_im[i - j] : r_im[j - i];
+    for (int b = blockIdx.z; b < B; b += gridDim.z) {
+        const size_t o = ((size_t)b * nf + i) * ntau + j;
+        a_re[o] = vr;
+        a_im[o] = vi;
+    }
+}
+
+// TRAPZ, general: one wavefront per matrix entry, 4 entries per 256-thread block along tau.
+__global__ __launch_bounds__(256) void impedance_trapz_kernel(int freq_batched, const double* __restrict__ freq, int nf,
+                                                              const double* __restrict__ tau, int ntau, double eps, int ny,
+                                                              double* __restrict__ a_re, double* __restrict__ a_im) {
+    extern __shared__ double sm[];
+    double* ys = sm; double* phis = sm + ny; double* eys = sm + 2 * ny;
+    fill_y_tables(ys, phis, eys, ny, eps);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int r = blockIdx.y, b = blockIdx.z;
+    const double* fr = freq + (freq_batched ? (size_t)b * nf : 0);
+    const double w = fr[r] * 2.0 * 3.141592653589793;
+    // each block covers 16 consecutive tau columns
+    for (int k = 0; k < 4; ++k) {
+        const int c = blockIdx.x * 16 + k * 4 + wv;
+        if (c >= ntau) continue;
+        double zr, zi;
+        trapz_pair(ys, phis, eys, ny, w, tau[c], lane, zr, zi);
+        if (lane == 0) {
+            const size_t o = ((size_t)b * nf + r) * ntau + c;
+            a_re[o] = zr;
+            a_im[o] = zi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// penalty matrices: orders 0..2 in one pass.  out matrices have leading dimension ld and the DRT block
+// starts at (pad, pad) (pad = number of special parameters in the plan; 0 for the stand-alone API).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void penalty_funcs(double x_n, double x_m, double eps, double& f0, double& f1, double& f2) {
+    const double a = eps * (x_m - x_n);
+    const double a2 = a * a;
+    const double e = exp(-(a2 / 2.0));
+    const double rpi = sqrt(3.141592653589793 / 2.0);
+    f0 = rpi * (1.0 / eps) * e;
+    f1 = (-rpi) * eps * (-1.0 + a2) * e;
+    f2 = rpi * (eps * eps * eps) * (3.0 - 6.0 * a2 + a2 * a2) * e;
+}
+
+__global__ void penalty_kernel(const double* __restrict__ ln_tau, int n, double eps, int toeplitz,
+                               double* __restrict__ m0, double* __restrict__ m1, double* __restrict__ m2, int ld,
+                               int pad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n) return;
+    double f0, f1, f2;
+    if (toeplitz) {
+        const int dd = i > j ? i - j : j - i;
+        penalty_funcs(ln_tau[dd], ln_tau[0], eps, f0, f1, f2);   // c[d] = func(x_d, x_0)
+    } else {
+        penalty_funcs(ln_tau[i], ln_tau[j], eps, f0, f1, f2);
+    }
+    const size_t o = (size_t)(i + pad) * ld + (j + pad);
+    m0[o] = f0;
+    m1[o] = f1;
+    m2[o] = f2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// EIS variance-estimation matrix: one 256-thread block per row of the (2nf x 2nf) matrix
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eis_vmm_kernel(const double* __restrict__ freq, int nf, double ve, double cor,
+                                                      int uniform, double* __restrict__ vmm) {
+    __shared__ double red[4];
+    const int i = blockIdx.x;          // row in [0, 2nf)
+    const int ih = i >= nf ? i - nf : i;
+    const int m = 2 * nf;
+    const double lfi = log(freq[ih]);
+    double s = 0.0;
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        const int jh = j >= nf ? j - nf : j;
+        double v = 1.0;
+        if (!uniform) {
+            const double dd = ve * (lfi - log(freq[jh]));
+            v = exp(-(dd * dd));
+        }
+        if ((i >= nf) != (j >= nf)) v = v * cor;
+        vmm[(size_t)i * m + j] = v;
+        s += v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int j = threadIdx.x; j < m; j += blockDim.x) vmm[(size_t)i * m + j] /= tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+void launch_lookup(hipStream_t st, double eps, int ngrid, int ny, const double* wt_re, const double* wt_im,
+                   double* z_re, double* z_im) {
+    const int blocks = (2 * ngrid + 3) / 4;
+    hipLaunchKernelGGL(lookup_kernel, dim3(blocks), dim3(256), 3 * ny * sizeof(double), st, eps, ngrid, ny, wt_re,
+                       wt_im, z_re, z_im);
+}
+
+void launch_lookup_slopes(hipStream_t st, int ngrid, const double* xp, const double* fp, double* slopes) {
+    hipLaunchKernelGGL(slopes_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, st, ngrid, xp, fp, slopes);
+}
+
+void launch_impedance_matrix(hipStream_t st, int B, int freq_batched, const double* freq, int nf, const double* tau,
+                             int ntau, int mode, int toeplitz, double eps, int ngrid, const double* lut6, int ny,
+                             double* a_re, double* a_im, double* cr_scratch) {
+    if (toeplitz) {
+        const int tot = nf + ntau;
+        if (mode == HIPDRT_MODE_INTERP)
+            hipLaunchKernelGGL(toeplitz_cr_interp_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, freq, nf, tau, ntau,
+                               ngrid, lut6, cr_scratch);
+        else
+            hipLaunchKernelGGL(toeplitz_cr_trapz_kernel, dim3((tot + 3) / 4), dim3(256), 3 * ny * sizeof(double), st,
+                               freq, nf, tau, ntau, eps, ny, cr_scratch);
+        const int zb = B < 64 ? B : 64;
+        hipLaunchKernelGGL(toeplitz_fill_kernel, dim3((ntau + 255) / 256, nf, zb), dim3(256), 0, st, B, nf, ntau,
+                           cr_scratch, a_re, a_im);
+        return;
+    }
+    if (mode == HIPDRT_MODE_INTERP) {
+        // one block covers up to 2048 tau columns; rows_per_block amortises the 96 kB table staging
+        int threads = (ntau + 1) / 2;
+        threads = threads > 1024 ? 1024 : ((threads + 63) / 64 * 64);
+        const int bx = ((ntau + 1) / 2 + threads - 1) / threads;
+        int rpb = 16;
+        if ((long long)B * nf < 4096) rpb = 4;
+        const int by = (nf + rpb - 1) / rpb;
+        hipLaunchKernelGGL(impedance_interp_kernel, dim3(bx, by, B), dim3(threads), 6 * (size_t)ngrid * sizeof(double),
+                           st, freq_batched, freq, nf, tau, ntau, ngrid, lut6, rpb, a_re, a_im);
+    } else {
+        hipLaunchKernelGGL(impedance_trapz_kernel, dim3((ntau + 15) / 16, nf, B), dim3(256), 3 * ny * sizeof(double),
+                           st, freq_batched, freq, nf, tau, ntau, eps, ny, a_re, a_im);
+    }
+}
+
+void launch_penalty(hipStream_t st, const double* ln_tau, int n, double eps, int toeplitz, double* m0, double* m1,
+                    double* m2, int ld, int pad) {
+    hipLaunchKernelGGL(penalty_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, ln_tau, n, eps, toeplitz, m0, m1,
+                       m2, ld, pad);
+}
+
+void launch_eis_vmm(hipStream_t st, const double* freq, int nf, double vmm_eps, double reim_cor, int uniform,
+                    double* vmm) {
+    hipLaunchKernelGGL(eis_vmm_kernel, dim3(2 * nf), dim3(256), 0, st, freq, nf, vmm_eps, reim_cor, uniform, vmm);
+}
+
+}  // namespace hipdrt

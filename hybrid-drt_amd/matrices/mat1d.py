@@ -1,0 +1,107 @@
+"""Drop-in for the hot-path builders of hybdrt/matrices/mat1d.py (same names, argument meaning and error
+behaviour); the arithmetic runs in libhipdrt.so."""
+import numpy as np
+
+from .. import _ffi
+from ..utils.array import is_log_uniform, is_uniform, rel_round
+
+
+def impedance_matrix_is_toeplitz(frequencies, tau, frequency_precision=10):
+    """The reference's Toeplitz decision (hybdrt/matrices/mat1d.py:229-295): f log-uniform and tau equal to
+    1/omega, or one a contiguous run of the other with tau log-uniform.  Pure host logic."""
+    omega = np.asarray(frequencies) * 2 * np.pi
+    tau = np.asarray(tau)
+    rnd = lambda v: rel_round(v, frequency_precision)
+    tau_eq_omega = len(tau) == len(omega) and np.array_equal(rnd(tau), rnd(1 / omega))
+    subset = False
+    match = rnd(1 / omega[0]) == rnd(tau)
+    if np.sum(match) == 1:
+        start = int(np.where(match)[0][0])
+        seg = tau[start:start + len(omega)]
+        subset = len(seg) == len(omega) and np.array_equal(rnd(seg), rnd(1 / omega))
+    elif np.sum(match) > 1:
+        raise Exception('Repeated tau values')
+    if not subset:
+        match = rnd(1 / omega) == rnd(tau[0])
+        if np.sum(match) == 1:
+            start = int(np.where(match)[0][0])
+            seg = omega[start:start + len(tau)]
+            subset = len(seg) == len(tau) and np.array_equal(rnd(seg), rnd(1 / tau))
+        elif np.sum(match) > 1:
+            raise Exception('Repeated omega values')
+    if is_log_uniform(frequencies):
+        return bool(tau_eq_omega or (subset and is_log_uniform(tau)))
+    return False
+
+
+def construct_impedance_matrices(frequencies, tau, epsilon, integrate_method='trapz', integrate_points=1000,
+                                 interpolate_grids=None, frequency_precision=10, device=0):
+    """Both parts in one device pass.  ``interpolate_grids`` = ((log_wt_re, z_re), (log_wt_im, z_im)).
+    ``frequencies`` may be (B, nf) for a batched build (then never Toeplitz)."""
+    frequencies = np.asarray(frequencies, dtype=float)
+    tau = np.asarray(tau, dtype=float)
+    if integrate_method == 'interp':
+        if interpolate_grids is None:
+            raise ValueError("interpolate_grids must be provided to use integrate_method 'interp'")
+        mode = _ffi.MODE_INTERP
+    elif integrate_method == 'trapz':
+        mode = _ffi.MODE_TRAPZ
+    else:
+        raise NotImplementedError("integrate_method 'quad' is not on the hot path")
+    tpl = frequencies.ndim == 1 and impedance_matrix_is_toeplitz(frequencies, tau, frequency_precision)
+    return _ffi.get_context(device).impedance_matrix(frequencies, tau, epsilon, mode=mode, toeplitz=tpl,
+                                                     lookups=interpolate_grids, ny=integrate_points)
+
+
+def construct_impedance_matrix(frequencies, part, tau=None, basis_type='gaussian', epsilon=1, frequency_precision=10,
+                               integrate_method='trapz', integrate_points=1000, zga_params=None,
+                               interpolate_grids=None, device=0):
+    """mat1d.construct_impedance_matrix (hybdrt/matrices/mat1d.py:212-374).  ``interpolate_grids`` is the
+    (log_wt_grid, z_grid) pair of the requested part, as in the reference."""
+    if basis_type != 'gaussian':
+        raise NotImplementedError("only the default gaussian basis is on the hot path")
+    if part not in ('real', 'imag'):
+        raise ValueError(f'Invalid part {part}. Options: real, imag')
+    frequencies = np.asarray(frequencies, dtype=float)
+    if tau is None:
+        tau = 1 / (frequencies * 2 * np.pi)
+    grids = None
+    if integrate_method == 'interp':
+        if interpolate_grids is None:
+            raise ValueError("interpolate_grids must be provided to use integrate_method 'interp'")
+        # the device kernel always produces both parts; feed the given table on both sides and keep one
+        grids = (interpolate_grids, interpolate_grids)
+    a_re, a_im = construct_impedance_matrices(frequencies, tau, epsilon, integrate_method, integrate_points, grids,
+                                              frequency_precision, device)
+    if integrate_method == 'interp':
+        return a_re      # both outputs interpolate the table that was passed in
+    return a_re if part == 'real' else a_im
+
+
+def construct_integrated_derivative_matrix(basis_grid, basis_type='gaussian', order=1, epsilon=1, zga_params=None,
+                                           integration_limits=None, device=0):
+    """mat1d.construct_integrated_derivative_matrix (hybdrt/matrices/mat1d.py:125-209), orders 0-2."""
+    if basis_type != 'gaussian' or integration_limits is not None:
+        raise NotImplementedError("only the gaussian basis with infinite limits is on the hot path")
+    if order not in (0, 1, 2):
+        raise ValueError(f'Invalid order {order}. Order must be between 0 and 2')
+    basis_grid = np.asarray(basis_grid, dtype=float)
+    mats = _ffi.get_context(device).penalty_matrices(basis_grid, epsilon, is_uniform(basis_grid))
+    return mats[order]
+
+
+def construct_inductance_impedance_vector(frequencies):
+    """mat1d.py:446-447."""
+    return 1j * 2 * np.pi * frequencies
+
+
+def construct_capacitance_impedance_vector(frequencies):
+    """mat1d.py:450-451."""
+    return 1 / (1j * 2 * np.pi * frequencies)
+
+
+def construct_eis_var_matrix(frequencies, vmm_epsilon, reim_cor, error_structure, device=0):
+    """mat1d.construct_eis_var_matrix (hybdrt/matrices/mat1d.py:493-515)."""
+    if error_structure not in (None, 'uniform'):
+        raise ValueError(f'Invalid error_structure {error_structure}')
+    return _ffi.get_context(device).eis_var_matrix(frequencies, vmm_epsilon, reim_cor, error_structure == 'uniform')

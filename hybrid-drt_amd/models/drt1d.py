@@ -1,0 +1,202 @@
+"""Drop-in for the EIS fit path of hybdrt.models.DRT (hybdrt/models/drt1d.py + drtbase.py).
+
+``DRT(**ctor).fit_eis(frequencies, z, **hypers)`` leaves ``fit_parameters``, ``qphb_params``,
+``qphb_history`` populated like the reference; ``fit_eis_batch`` is the batched form the reference runs as a
+serial loop in DRTMD.fit_observations (hybdrt/mapping/drtmd.py:303-319).  All arithmetic -- lookup tables,
+Z'/Z'' and penalty matrices, the QPHB loop -- runs in libhipdrt.so on one MI355X; this module only decides
+grids and options and rescales results (host logic mirrored from the reference, cited per method)."""
+import warnings
+
+import numpy as np
+
+from .. import _ffi, preprocessing as pp
+from ..matrices import mat1d
+from ..utils.array import is_uniform
+from . import qphb
+
+_FIT_KW_DEFAULTS = dict(  # DRT._qphb_fit_core keyword defaults (drt1d.py:102-137) that the device loop honours
+    nonneg=True, scale_data=True, ohmic_penalty=1e-6, inductance_penalty=1e-6, inductance_scale=1e-5,
+    penalty_type='integral', eis_error_structure=None, eis_vmm_epsilon=0.25, eis_reim_cor=0.25,
+    iw_l1_lambda_0=1e-4, iw_l2_lambda_0=1e-4, eff_hp=True, weight_factor=1, xtol=1e-2, max_iter=50)
+
+
+class DRT:
+    def __init__(self, fixed_basis_tau=None, tau_supergrid=None, tau_basis_type='gaussian', tau_epsilon=None,
+                 basis_tau_ppd=10, extend_basis_decades=1, interpolate_integrals=True, fit_dop=False,
+                 fit_inductance=True, fit_ohmic=True, fit_capacitance=False, frequency_precision=10,
+                 print_diagnostics=False, warn=True, device=0):
+        """DRTBase.__init__ (hybdrt/models/drtbase.py:21-159): epsilon rule and the lookup tables."""
+        if tau_basis_type != 'gaussian':
+            raise NotImplementedError("only the default gaussian basis is on the hot path")
+        if fit_dop or fit_capacitance:
+            raise NotImplementedError("fit_dop / fit_capacitance are later scope rows (SURVEY.md 8)")
+        if fixed_basis_tau is not None and tau_supergrid is not None:
+            warnings.warn('If fixed_basis_tau is provided, tau_supergrid will be ignored')
+        self.fixed_basis_tau = None if fixed_basis_tau is None else np.asarray(fixed_basis_tau, dtype=float)
+        self.tau_supergrid = None if tau_supergrid is None else np.asarray(tau_supergrid, dtype=float)
+        self.tau_basis_type = tau_basis_type
+        self.tau_epsilon = tau_epsilon
+        self.extend_basis_decades = extend_basis_decades
+        self.fit_inductance, self.fit_ohmic, self.fit_capacitance, self.fit_dop = fit_inductance, fit_ohmic, False, False
+        self.frequency_precision = frequency_precision
+        self.print_diagnostics, self.warn = print_diagnostics, warn
+        self.device = device
+        if self.tau_epsilon is None:
+            if self.fixed_basis_tau is not None:
+                self.tau_epsilon = 1 / np.mean(np.diff(np.log(self.fixed_basis_tau)))
+            elif self.tau_supergrid is not None:
+                self.tau_epsilon = 1 / np.mean(np.diff(np.log(self.tau_supergrid)))
+            elif basis_tau_ppd is not None:
+                self.tau_epsilon = pp.get_epsilon_from_ppd(basis_tau_ppd)
+        self.integrate_method = 'interp' if interpolate_integrals else 'trapz'
+        # lookup abscissae (basis.py:653-657); the ordinates are produced on the device inside the plan
+        self._wt_re = np.logspace(-2.7, 2.7, 2000)
+        self._wt_im = np.logspace(-5.4, 5.4, 2000)
+        self._plan = None
+        self._plan_key = None
+        self.basis_tau = None
+        self.special_qp_params = {}
+        self.fit_parameters = None
+        self.qphb_params = None
+        self.qphb_history = None
+        self.cvx_result = None
+        self.fit_kwargs = None
+        self.fit_type = None
+        self.coefficient_scale = 1.0
+        self.impedance_scale = 1.0
+        self.inductance_scale = None
+        self.f_fit = []
+
+    # ---- plan management (the counterpart of the reference's matrix recalc cache, drtbase.py:1008-1032) ----
+    @property
+    def interpolate_lookups(self):
+        if self._plan is None or self.integrate_method != 'interp':
+            return {'z_real': None, 'z_imag': None}
+        p = self._plan
+        return {'z_real': (p.log_wt_re, p.get('lut_z_re')), 'z_imag': (p.log_wt_im, p.get('lut_z_im'))}
+
+    def _special_params(self):
+        """drt1d.py:375-408 / drtbase.py:538-547 for an EIS fit."""
+        sp = {}
+        if self.fit_ohmic:
+            sp['R_inf'] = {'index': len(sp), 'nonneg': True, 'size': 1}
+        if self.fit_inductance:
+            sp['inductance'] = {'index': len(sp), 'nonneg': True, 'size': 1}
+        return sp
+
+    def _get_plan(self, frequencies, opts, capacity):
+        if self.fixed_basis_tau is not None:
+            basis_tau = self.fixed_basis_tau
+        else:
+            basis_tau = pp.get_basis_tau(frequencies, None, None, tau_grid=self.tau_supergrid,
+                                         extend_decades=self.extend_basis_decades)
+        if self.tau_epsilon is None:
+            self.tau_epsilon = 1 / np.mean(np.diff(np.log(basis_tau)))
+        key = (np.asarray(frequencies).tobytes(), basis_tau.tobytes(), float(self.tau_epsilon), bytes(opts))
+        if self._plan is not None and self._plan_key == key and self._plan.capacity >= capacity:
+            return self._plan
+        if self._plan is not None:
+            self._plan.close()
+        mode = _ffi.MODE_INTERP if self.integrate_method == 'interp' else _ffi.MODE_TRAPZ
+        tpl_a = mat1d.impedance_matrix_is_toeplitz(frequencies, basis_tau, self.frequency_precision)
+        tpl_m = is_uniform(np.log(basis_tau))
+        self._plan = _ffi.Plan(_ffi.get_context(self.device), frequencies, basis_tau, self.tau_epsilon,
+                               wt_re=self._wt_re, wt_im=self._wt_im, mode=mode, toeplitz_a=tpl_a, toeplitz_m=tpl_m,
+                               opts=opts, capacity=capacity)
+        self._plan_key = key
+        self.basis_tau = basis_tau
+        return self._plan
+
+    def _make_opts(self, fit_kw):
+        kw = dict(_FIT_KW_DEFAULTS)
+        hypers = qphb.get_default_hypers(True, False, 'gaussian')
+        for key, val in fit_kw.items():
+            if key in kw:
+                kw[key] = val
+            elif key in hypers:
+                hypers[key] = val
+            else:
+                raise ValueError(f'Invalid keyword argument {key}')     # drt1d.py:415-419
+        if kw['penalty_type'] != 'integral':
+            raise NotImplementedError("penalty_type 'discrete' is deprecated in the reference and not built")
+        if not kw['eff_hp'] or kw['weight_factor'] != 1:
+            raise NotImplementedError("only eff_hp=True, weight_factor=1 (the defaults) are built")
+        if hypers['outlier_p'] is not None or hypers['iw_alpha'] is not None or hypers['iw_beta'] is not None:
+            raise NotImplementedError("outlier_p / iw_alpha / iw_beta are optional branches not built yet")
+        if kw['eis_error_structure'] not in (None, 'uniform'):
+            raise ValueError(f"Invalid eis_error_structure {kw['eis_error_structure']}")
+        o = _ffi.default_fit_opts()
+        o.rp_scale = float(hypers['rp_scale'])
+        for name in ('derivative_weights', 'sigma_ds', 's_alpha', 's_0', 'rho_alpha', 'rho_0'):
+            vals = np.broadcast_to(np.asarray(hypers[name], dtype=float), (3,))
+            for k in range(3):
+                getattr(o, name)[k] = float(vals[k])
+        o.l1_lambda_0, o.l2_lambda_0 = float(hypers['l1_lambda_0']), float(hypers['l2_lambda_0'])
+        o.iw_l1_lambda_0, o.iw_l2_lambda_0 = float(kw['iw_l1_lambda_0']), float(kw['iw_l2_lambda_0'])
+        o.ohmic_penalty, o.inductance_penalty = float(kw['ohmic_penalty']), float(kw['inductance_penalty'])
+        o.inductance_scale = float(kw['inductance_scale'])
+        o.eis_vmm_epsilon, o.eis_reim_cor = float(kw['eis_vmm_epsilon']), float(kw['eis_reim_cor'])
+        o.xtol, o.max_iter = float(kw['xtol']), int(kw['max_iter'])
+        o.nonneg, o.scale_data = int(bool(kw['nonneg'])), int(bool(kw['scale_data']))
+        o.fit_ohmic, o.fit_inductance = int(self.fit_ohmic), int(self.fit_inductance)
+        o.eis_error_uniform = int(kw['eis_error_structure'] == 'uniform')
+        return o, hypers, kw
+
+    # ---- the fits ------------------------------------------------------------------------------------------
+    def fit_eis(self, frequencies, z, **kw):
+        """DRT.fit_eis (drt1d.py:1215-1241) -> _qphb_fit_core (102-1104) for one spectrum."""
+        frequencies = np.asarray(frequencies, dtype=float)
+        z = np.asarray(z, dtype=complex)
+        if len(frequencies) != len(z):
+            raise ValueError('Length of frequencies and z must be equal')    # utils/validation.check_eis_data
+        res = self._fit(frequencies, z[None, :], kw, history_of=0)
+        b = 0
+        fp = {'x': res['fit_x'][b], 'R_inf': res['R_inf'][b] if self.fit_ohmic else 0,
+              'inductance': res['inductance'][b] if self.fit_inductance else 0, 'C_inv': 0,
+              'v_sigma_tot': None, 'v_sigma_res': None, 'z_sigma_tot': res['z_sigma_tot'][b], 'vz_offset_eps': 1,
+              'p_matrix': self._plan.p_matrix(b), 'q_vector': res['q_vector'][b]}
+        if res['status'][b] < 0:
+            raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")          # cvxopt's error at the QP start point
+        if res['status'][b] == 1 and self.warn:
+            warnings.warn(f"Solution did not converge within {self.fit_kwargs['max_iter']} iterations. "
+                          f"This is usually not an issue.")
+        self.fit_parameters = fp
+        self.coefficient_scale = self.impedance_scale = float(res['coefficient_scale'][b])
+        hist = self._plan.history()
+        self.qphb_history = [{'x': hist['x'][i], 'rho_vector': hist['rho'][i], 'weights': hist['weights'][i]}
+                             for i in range(len(hist['x']))]
+        self.qphb_params = {'weights': res['weights'][b], 'true_weights': res['weights'][b],
+                            'rho_vector': res['rho'][b], 's_vectors': list(res['s_vectors'][b]),
+                            'p_matrix': fp['p_matrix'], 'q_vector': fp['q_vector'], 'rm': self._plan.get('rm'),
+                            'vmm': self._plan.get('vmm'), 'num_eis': len(frequencies), 'num_chrono': 0,
+                            'qp_iterations': hist['qp_iterations'], 'outer_iterations': int(res['outer_iters'][b])}
+        self.cvx_result = {'x': res['x'][b]}
+        self.fit_type = 'qphb_eis'
+        return fp
+
+    def fit_eis_batch(self, frequencies, z_batch, **kw):
+        """B spectra on one frequency grid, fitted concurrently (the reference's DRTMD loop calls
+        _qphb_fit_core once per observation, mapping/drtmd.py:245-319).  Returns a dict of arrays."""
+        frequencies = np.asarray(frequencies, dtype=float)
+        z_batch = np.asarray(z_batch, dtype=complex)
+        if z_batch.ndim != 2 or z_batch.shape[1] != len(frequencies):
+            raise ValueError('z_batch must have shape (B, len(frequencies))')
+        return self._fit(frequencies, z_batch, kw, history_of=-1)
+
+    def _fit(self, frequencies, z_batch, kw, history_of):
+        opts, hypers, fkw = self._make_opts(kw)
+        plan = self._get_plan(frequencies, opts, z_batch.shape[0])
+        self.special_qp_params = self._special_params()
+        self.inductance_scale = fkw['inductance_scale']
+        self.fit_kwargs = dict(hypers, **fkw)
+        self.f_fit = frequencies
+        plan.record_history(history_of)
+        plan.upload(z_batch)
+        plan.fit()
+        res = plan.download(s_vectors=True)
+        nf = len(frequencies)
+        sigma = 1.0 / res['weights']
+        res['z_sigma_tot'] = (sigma[:, :nf] + 1j * sigma[:, nf:]) * res['coefficient_scale'][:, None]
+        res['basis_tau'] = self.basis_tau
+        res['timings_ms'], res['launches'] = plan.timings()
+        return res

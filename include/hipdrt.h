@@ -1,0 +1,199 @@
+/* hipdrt.h -- C-ABI of libhipdrt.so, the MI355X (gfx950) implementation of hybrid-drt's hot path.
+ *
+ * The reference (jdhuang-csm/hybrid-drt) is pure Python; it has no FFI of its own.  The entry points below
+ * are what a ctypes binding for the hot path replaces, each citing the reference interface it stands for
+ * (paths relative to the reference root).  Conventions:
+ *   - plain C: opaque handles, pointers and sizes only; no C++/torch types;
+ *   - every array is row-major contiguous float64 (int32 for counters/status) unless stated otherwise;
+ *   - "host" pointers are caller-owned host memory, the library does the H2D/D2H copies;
+ *     "_dev" entry points take device pointers and neither copy nor synchronise more than documented;
+ *   - every function returns 0 on success, <0 on error (HIPDRT_E_*); hipdrt_last_error() gives the text;
+ *     nothing throws, nothing falls back to the CPU: without a gfx950 device hipdrt_create fails;
+ *   - one hipdrt_ctx per (process, device); a ctx is not re-entrant, distinct ctxs are independent.
+ */
+#ifndef HIPDRT_H
+#define HIPDRT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPDRT_OK 0
+#define HIPDRT_E_INVALID (-1)   /* bad argument                                         */
+#define HIPDRT_E_HIP (-2)       /* HIP runtime error (text in hipdrt_last_error)         */
+#define HIPDRT_E_NODEVICE (-3)  /* no usable gfx950 device                              */
+#define HIPDRT_E_NUMERIC (-4)   /* numerical breakdown for the whole call               */
+
+/* per-problem status codes written to status[] arrays */
+#define HIPDRT_QP_OPTIMAL 0     /* coneqp stopping test met                                        */
+#define HIPDRT_QP_MAXITER 1     /* maxiters reached (cvxopt status 'unknown')                      */
+#define HIPDRT_QP_SINGULAR_LATE 2 /* Cholesky breakdown after iteration 0: cvxopt returns current x */
+#define HIPDRT_QP_SINGULAR (-1) /* breakdown at the start point: cvxopt raises ValueError          */
+
+#define HIPDRT_MODE_INTERP 0    /* integrate_method='interp' (drtbase.py:155)  */
+#define HIPDRT_MODE_TRAPZ 1     /* integrate_method='trapz'  (drtbase.py:159)  */
+
+typedef struct hipdrt_ctx hipdrt_ctx;
+typedef struct hipdrt_plan hipdrt_plan;
+
+/* ---- context -------------------------------------------------------------------------------------- */
+int hipdrt_create(int device, hipdrt_ctx** out);
+int hipdrt_destroy(hipdrt_ctx* ctx);
+const char* hipdrt_last_error(void);
+/* HIP stream the ctx launches on (so callers can record events / order other work): returns hipStream_t */
+void* hipdrt_stream(hipdrt_ctx* ctx);
+int hipdrt_synchronize(hipdrt_ctx* ctx);
+/* name of the device architecture, e.g. "gfx950" */
+int hipdrt_device_info(hipdrt_ctx* ctx, char* arch, int arch_len, int* num_cu, long long* hbm_bytes);
+
+/* ---- L1 kernel matrices --------------------------------------------------------------------------- */
+
+/* basis.generate_impedance_lookup (hybdrt/matrices/basis.py:648-669), Gaussian basis.
+ * in : wt_re[ngrid], wt_im[ngrid]  the omega*tau abscissae (np.logspace(-2.7,2.7,ngrid) / (-5.4,5.4))
+ * out: z_re[ngrid], z_im[ngrid]    ny-point trapezoid integrals over y = linspace(-20,20,ny)          */
+int hipdrt_impedance_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny,
+                            const double* wt_re, const double* wt_im, double* z_re, double* z_im);
+
+/* mat1d.construct_impedance_matrix (hybdrt/matrices/mat1d.py:212-374), both parts in one call,
+ * batched over B frequency grids.
+ * freq[B or 1][nf] (freq_batched selects), tau[ntau]; mode INTERP uses the lookups (log_wt_*, z_* of
+ * length ngrid, np.interp semantics incl. end clamping); mode TRAPZ integrates ny points.
+ * toeplitz != 0 reproduces the reference's Toeplitz shortcut (mat1d.py:353-360): first column/row are
+ * evaluated and scattered (the caller decides with the reference's rule, it requires B-independent grids).
+ * out: a_re[B][nf][ntau], a_im[B][nf][ntau]                                                          */
+int hipdrt_impedance_matrix(hipdrt_ctx* ctx, int B, int freq_batched, const double* freq, int nf,
+                            const double* tau, int ntau, int mode, int toeplitz, double epsilon,
+                            int ngrid, const double* log_wt_re, const double* z_re,
+                            const double* log_wt_im, const double* z_im, int ny,
+                            double* a_re, double* a_im);
+/* same, outputs stay on the device (a_re_dev/a_im_dev are device pointers); used by bench.py to time the
+ * build with HIP events without the D2H copy.  elapsed_ms (may be NULL) = kernel time over `repeat` launches */
+int hipdrt_impedance_matrix_dev(hipdrt_ctx* ctx, int B, int freq_batched, const double* freq, int nf,
+                                const double* tau, int ntau, int mode, int toeplitz, double epsilon,
+                                int ngrid, const double* log_wt_re, const double* z_re,
+                                const double* log_wt_im, const double* z_im, int ny,
+                                void* a_re_dev, void* a_im_dev, int repeat, float* elapsed_ms);
+
+/* mat1d.construct_integrated_derivative_matrix (hybdrt/matrices/mat1d.py:125-209), orders 0,1,2 of the
+ * Gaussian basis (closed forms basis.py:382-395).  toeplitz != 0: first column scattered (mat1d.py:158-168).
+ * out: m0, m1, m2 each [n][n]                                                                        */
+int hipdrt_penalty_matrices(hipdrt_ctx* ctx, const double* ln_tau, int n, double epsilon, int toeplitz,
+                            double* m0, double* m1, double* m2);
+
+/* mat1d.construct_eis_var_matrix (hybdrt/matrices/mat1d.py:493-515): out vmm[2nf][2nf], rows normalised.
+ * uniform != 0 is error_structure='uniform'.                                                         */
+int hipdrt_eis_var_matrix(hipdrt_ctx* ctx, const double* freq, int nf, double vmm_epsilon, double reim_cor,
+                          int uniform, double* vmm);
+
+/* ---- L2 QP ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    double abstol, reltol, feastol; /* cvxopt.solvers.options defaults 1e-7, 1e-6, 1e-7 */
+    int maxiters;                   /* 100 */
+} hipdrt_qp_opts;
+
+/* cvxopt.solvers.qp(P, q, G=-I, h) as called from qphb.solve_convex_opt (hybdrt/models/qphb.py:512-519):
+ * B independent problems min 1/2 x'Px + q'x s.t. -x <= h, solved with coneqp's trajectory.
+ * P[B or 1][n][n] (p_batched selects; only the lower triangle is read), q[B][n], h[B or 1][n].
+ * out: x[B][n], iters[B], pcost[B] ('primal objective'), status[B]                                    */
+int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* P, const double* q,
+                    int h_batched, const double* h, const hipdrt_qp_opts* opts,
+                    double* x, int* iters, double* pcost, int* status);
+
+/* P = (W A)'(W A) + L2, q = -(W A)'(W b) + l1 of qphb.solve_convex_opt (qphb.py:465-466) for B weight
+ * vectors over one shared A[m][n]:  w[B][m], b[B][m], l2[B or 1][n][n], l1[n] -> P[B][n][n], q[B][n]   */
+int hipdrt_weighted_gram(hipdrt_ctx* ctx, int B, int m, int n, const double* A, const double* w,
+                         const double* b, int l2_batched, const double* l2, const double* l1,
+                         double* P, double* q);
+
+/* ---- L3/L4 batched fit ------------------------------------------------------------------------------ */
+
+typedef struct {
+    /* qphb.get_default_hypers (hybdrt/models/qphb.py:208-255), eff_hp=True */
+    double rp_scale;                 /* 14 */
+    double derivative_weights[3];    /* 1.5, 1.0, 0.5 */
+    double sigma_ds[3];              /* 1, 1000, 1000 */
+    double l1_lambda_0;              /* 0 */
+    double l2_lambda_0;              /* 142 */
+    double s_alpha[3];               /* 5, 10, 25 */
+    double s_0[3];                   /* 1, 1, 1 */
+    double rho_alpha[3];             /* 0.15, 0.2, 0.25 */
+    double rho_0[3];                 /* 1, 1, 1 */
+    /* DRT._qphb_fit_core keyword defaults (hybdrt/models/drt1d.py:102-137) */
+    double iw_l1_lambda_0, iw_l2_lambda_0;   /* 1e-4, 1e-4 */
+    double ohmic_penalty, inductance_penalty; /* 1e-6, 1e-6 */
+    double inductance_scale;         /* 1e-5 */
+    double eis_vmm_epsilon, eis_reim_cor;    /* 0.25, 0.25 */
+    double xtol;                     /* 1e-2 */
+    int max_iter;                    /* 50 */
+    int nonneg;                      /* 1 */
+    int scale_data;                  /* 1 */
+    int fit_ohmic, fit_inductance;   /* 1, 1 */
+    int eis_error_uniform;           /* 0 (eis_error_structure=None) */
+    hipdrt_qp_opts qp;
+} hipdrt_fit_opts;
+
+void hipdrt_default_fit_opts(hipdrt_fit_opts* o);
+
+/* A plan = everything that does not depend on the measured impedances: lookups (DRTBase.__init__,
+ * hybdrt/models/drtbase.py:138-156), Z'/Z'' (DRT._prep_impedance_fit_matrix, drt1d.py:5625-5657), penalty
+ * matrices (_prep_penalty_matrices, 5673-5734), the stacked [Re;Im] response matrix and padded M_k
+ * (_format_qp_matrices, 5736-5963), the variance-estimation matrix (drt1d.py:622-636), all built on the
+ * device, plus work space for `capacity` spectra.  All spectra of a plan share freq[nf] and tau[ntau]
+ * (the DRTMD case: mapping/drtmd.py:245-319 with one DRT instance and its recalc cache).
+ * toeplitz_a / toeplitz_m carry the reference's Toeplitz decisions (host logic); wt_* are the lookup
+ * abscissae and log_wt_* = np.log(wt_*) (both computed by the caller exactly as basis.py:655-669 does). */
+int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double* tau, int ntau,
+                       double epsilon, int mode, int toeplitz_a, int toeplitz_m, int ngrid, int ny,
+                       const double* wt_re, const double* wt_im, const double* log_wt_re,
+                       const double* log_wt_im, const hipdrt_fit_opts* opts, int capacity,
+                       hipdrt_plan** out);
+int hipdrt_plan_destroy(hipdrt_plan* plan);
+/* dimensions: n = ns + ntau unknowns, m = 2 nf rows, ns special parameters */
+int hipdrt_plan_dims(hipdrt_plan* plan, int* n, int* m, int* ns);
+/* copy a shared matrix of the plan back to the host: which = "lut_z_re","lut_z_im" [ngrid],
+ * "a_re","a_im" [nf][ntau], "rm" [m][n], "m0","m1","m2" [n][n] (padded), "vmm" [m][m]                  */
+int hipdrt_plan_get(hipdrt_plan* plan, const char* which, double* out, long long count);
+/* replace the plan's lookup tables with externally supplied ones (multi-GPU: rank 0 builds them, RCCL
+ * broadcasts, the other ranks install them) and rebuild the dependent matrices            */
+int hipdrt_plan_set_lookup(hipdrt_plan* plan, const double* z_re, const double* z_im);
+
+/* stage B <= capacity spectra (z_re[B][nf], z_im[B][nf], host) into the plan's device buffers */
+int hipdrt_plan_upload(hipdrt_plan* plan, int B, const double* z_re, const double* z_im);
+/* DRT._qphb_fit_core (drt1d.py:102-1104) for the staged spectra, entirely on the device: scale_data,
+ * initialize_weights (qphb.py:1609-1681), the iterate_qphb loop (qphb.py:606-972) with per-spectrum
+ * convergence masks, calculate_pq's q (qphb.py:1154-1183).  Asynchronous on the ctx stream except for one
+ * 4-byte "all converged" read-back per outer iteration.                                                */
+int hipdrt_plan_fit(hipdrt_plan* plan);
+/* results for the B staged spectra (any pointer may be NULL):
+ * x[B][n] QP solution in scaled units, fit_x[B][ntau] / r_inf[B] / induc[B] rescaled like
+ * extract_qphb_parameters (drt1d.py:6228-6289), weights[B][m] (1/sigma, scaled units),
+ * coef_scale[B], rho[B][3], s_vectors[B][3][n], q_vector[B][n], outer_iters[B], qp_iters_total[B],
+ * status[B] (0 converged, 1 max_iter reached, <0 failed)                                              */
+int hipdrt_plan_download(hipdrt_plan* plan, double* x, double* fit_x, double* r_inf, double* induc,
+                         double* weights, double* coef_scale, double* rho, double* s_vectors,
+                         double* q_vector, int* outer_iters, int* qp_iters_total, int* status);
+/* final P (calculate_pq) of spectrum b: p[n][n] */
+int hipdrt_plan_get_p_matrix(hipdrt_plan* plan, int b, double* p);
+/* per-outer-iteration history of spectrum b recorded when record_history was enabled before the fit:
+ * hist_x[iters][n], hist_rho[iters][3], hist_w[iters][m], qp_iters[iters+1]                            */
+int hipdrt_plan_record_history(hipdrt_plan* plan, int b_or_minus1);
+int hipdrt_plan_get_history(hipdrt_plan* plan, double* hist_x, double* hist_rho, double* hist_w,
+                            int* qp_iters, int max_rows, int* rows);
+/* kernel-time breakdown of the last hipdrt_plan_fit in ms (HIP events on the ctx stream):
+ * t[0]=total, t[1]=gram, t[2]=qp, t[3]=hyper, t[4]=setup/other; launches[5] same order                 */
+int hipdrt_plan_timings(hipdrt_plan* plan, float* t, int* launches);
+
+/* one-shot convenience: create plan, upload, fit, download, destroy */
+int hipdrt_fit_eis_batch(hipdrt_ctx* ctx, int B, const double* freq, int nf, const double* z_re,
+                         const double* z_im, const double* tau, int ntau, double epsilon, int mode,
+                         int toeplitz_a, int toeplitz_m, int ngrid, int ny, const double* wt_re,
+                         const double* wt_im, const double* log_wt_re, const double* log_wt_im,
+                         const hipdrt_fit_opts* opts, double* x, double* fit_x,
+                         double* r_inf, double* induc, double* weights, double* coef_scale, double* rho,
+                         double* q_vector, int* outer_iters, int* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPDRT_H */

@@ -1,0 +1,173 @@
+"""GPU parity of the device-resident QPHB fit (DRT.fit_eis / fit_eis_batch through the C-ABI).
+
+Tolerance (BASELINE.json north_star): recovered DRT coefficients within 1e-7 relative of the
+oracle / reference-run fixtures (relative to the spectrum's peak coefficient; entries of a converged interior
+point are all > 0), identical outer-iteration and IPM-iteration counts, and the reference's own
+np.allclose(rtol=1e-5, atol=1e-8) on its known-answer test."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+X_RTOL = 1e-7
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def close_to_peak(a, ref, tol=X_RTOL):
+    np.testing.assert_allclose(a, ref, rtol=100 * tol, atol=tol * np.abs(ref).max())
+
+
+def test_reference_known_answer_test_on_gpu():
+    """Mirror of /root/reference/tests/test_drt_fit.py with hipdrt.models.DRT in place of hybdrt.models.DRT."""
+    from hipdrt.models import DRT
+    g = load("ref_test_drt_fit_eis.npz")
+    drt = DRT(fit_inductance=True, fit_capacitance=False, fit_dop=False, fit_ohmic=True)
+    hypers = dict(rp_scale=14, derivative_weights=np.array([1.5, 1.0, 0.5]), sigma_ds=np.array([1, 1000, 1000]),
+                  l1_lambda_0=0, l2_lambda_0=142, s_alpha=np.array([5, 10, 25]),
+                  rho_alpha=np.array([0.15, 0.2, 0.25]), iw_alpha=None, iw_beta=None, s_0=np.ones(3),
+                  rho_0=np.ones(3), outlier_p=None)
+    drt.fit_eis(g["freq"], g["z"], **hypers)
+    for key in ("x", "R_inf", "inductance", "C_inv", "z_sigma_tot", "vz_offset_eps", "q_vector"):
+        assert np.allclose(g[key], drt.fit_parameters[key]), key
+    assert drt.fit_parameters["v_sigma_tot"] is None and drt.fit_parameters["v_sigma_res"] is None
+    assert len(drt.basis_tau) == 91
+    with pytest.raises(ValueError):
+        drt.fit_eis(g["freq"], g["z"], not_a_hyper=1)
+
+
+@pytest.mark.parametrize("name", ["refrun_golden71x91.npz", "refrun_golden71x91_neg.npz", "refrun_c1_71x121.npz",
+                                  "refrun_c2_256x512_s0.npz", "refrun_c2_256x512_s1.npz", "refrun_c2_256x512_s2.npz"])
+def test_fit_trajectory_vs_reference_run(name):
+    from hipdrt.models import DRT
+    from oracle import drt_oracle as orc
+    g = load(name)
+    fixed = None if len(g["basis_tau"]) == len(orc.get_basis_tau(g["freq"])) else g["basis_tau"]
+    drt = DRT(fixed_basis_tau=fixed)
+    fp = drt.fit_eis(g["freq"], g["z"], nonneg=bool(g["nonneg"]))
+    qp = drt.qphb_params
+    assert qp["outer_iterations"] == int(g["outer_iterations"])
+    assert qp["qp_iterations"].tolist() == g["qp_iterations"].tolist()
+    hx = np.array([h["x"] for h in drt.qphb_history])
+    close_to_peak(hx, g["hist_x"])
+    np.testing.assert_allclose(np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], rtol=1e-6)
+    np.testing.assert_allclose(np.array([h["weights"] for h in drt.qphb_history]), g["hist_weights"], rtol=1e-6)
+    close_to_peak(fp["x"], g["x"])
+    np.testing.assert_allclose(fp["R_inf"], g["R_inf"], rtol=1e-7)
+    np.testing.assert_allclose(fp["inductance"], g["inductance"], rtol=1e-6, atol=1e-7 * abs(float(g["R_inf"])) * 1e-5)
+    np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
+    np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-7 * np.abs(g["q_vector"]).max())
+    np.testing.assert_allclose(np.array(qp["s_vectors"]), g["s_vectors"], rtol=1e-5, atol=1e-12)
+    if "p_matrix" in g:
+        np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-7 * np.abs(g["p_matrix"]).max())
+
+
+def test_plan_matrices_vs_reference_run():
+    from hipdrt.models import DRT
+    g = load("refrun_golden71x91.npz")
+    drt = DRT()
+    drt.fit_eis(g["freq"], g["z"])
+    p = drt._plan
+    np.testing.assert_allclose(p.get("rm"), g["rm"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(p.get("vmm"), g["vmm"], rtol=1e-12)
+    for k in range(3):
+        mk = p.get(f"m{k}")
+        np.testing.assert_allclose(mk[2:, 2:], g[f"m{k}"], rtol=1e-12, atol=1e-300)
+        assert mk[0, 0] == 1e-6 and mk[1, 1] == 1e-6 and not mk[:2, 2:].any()
+    lk = drt.interpolate_lookups
+    np.testing.assert_allclose(lk["z_real"][1], g["lut_z_re"], rtol=1e-12)
+
+
+def test_batch_members_vs_reference_run_and_batch_invariance():
+    """First 4 members of the C3/C4 workload inside one batch == reference run; and a spectrum fitted alone is
+    bit-identical to the same spectrum fitted inside a batch (workgroups are independent)."""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    c2 = synth.config_c2()
+    z = synth.zarc2_batch(c2["freq"], 6)
+    drt = DRT(fixed_basis_tau=c2["tau"])
+    res = drt.fit_eis_batch(c2["freq"], z)
+    assert res["status"].tolist() == [0] * 6
+    for b in range(4):
+        g = load(f"refrun_c3_member{b}.npz")
+        np.testing.assert_array_equal(g["z"], z[b])
+        assert res["outer_iters"][b] == int(g["outer_iterations"])
+        assert res["qp_iters_total"][b] == int(g["qp_iterations"].sum())
+        close_to_peak(res["fit_x"][b], g["x"])
+        np.testing.assert_allclose(res["R_inf"][b], g["R_inf"], rtol=1e-7)
+        np.testing.assert_allclose(res["z_sigma_tot"][b], g["z_sigma_tot"], rtol=1e-6)
+    single = drt.fit_eis_batch(c2["freq"], z[3:4])
+    np.testing.assert_array_equal(single["x"][0], res["x"][3])
+    np.testing.assert_array_equal(single["weights"][0], res["weights"][3])
+
+
+def test_batch_vs_oracle_and_supergrid_scatter():
+    """16 jittered spectra on the golden frequency grid through the DRTMD-style driver vs the oracle loop."""
+    from hipdrt import synth
+    from hipdrt.mapping import fit_observations
+    from hipdrt.models import DRT
+    from oracle import drt_oracle as orc
+    freq = np.logspace(6, -1, 71)
+    z = synth.zarc2_batch(freq, 16, first_seed=100)
+    supergrid = np.logspace(-9, 3, 121)
+    drt = DRT(tau_supergrid=supergrid)
+    obs_x, obs_special, res = fit_observations(drt, freq, z, tau_supergrid=supergrid)
+    assert len(res["basis_tau"]) == 92 and obs_x.shape == (16, 121)     # supergrid rule: slice [12:104]
+    np.testing.assert_array_equal(res["basis_tau"], supergrid[12:104])
+    ref = orc.fit_eis_batch(freq, z, fixed_basis_tau=supergrid[12:104])
+    for b in range(16):
+        assert res["outer_iters"][b] == ref[b]["outer_iterations"]
+        close_to_peak(obs_x[b, 12:104], ref[b]["x"])
+        np.testing.assert_allclose(obs_special["R_inf"][b], ref[b]["R_inf"], rtol=1e-7)
+    assert not obs_x[:, :12].any() and not obs_x[:, 104:].any()
+
+
+def test_edge_cases():
+    from hipdrt.models import DRT
+    freq = np.logspace(5, 0, 12)
+    from hipdrt import synth
+    z = synth.zarc2_spectrum(freq, 1)
+    drt = DRT()
+    with pytest.raises(ValueError):
+        drt.fit_eis(freq, z[:-1])                      # ragged input
+    with pytest.raises(ValueError):
+        drt.fit_eis_batch(freq, np.zeros((0,)))        # empty batch
+    fp = drt.fit_eis(freq, z)                          # tiny problem (12 x 71) still runs
+    assert np.all(np.isfinite(fp["x"])) and np.all(fp["x"] > 0)
+    fp2 = DRT(fit_inductance=False).fit_eis(freq, z)   # one special parameter only
+    assert fp2["inductance"] == 0 and np.all(np.isfinite(fp2["x"]))
+    with pytest.raises(NotImplementedError):
+        DRT(fit_dop=True)
+
+
+@pytest.mark.timeout(900)
+def test_full_size_batch_properties():
+    """BASELINE configs[2] size (1024 spectra, 256 x 512): size-independent properties -- every fit converges
+    with a strictly interior solution, a re-run is bit-identical (fixed reduction orders), x satisfies the
+    reference's convergence rule, and q_vector is consistent with the returned weights (checked in numpy)."""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    c2 = synth.config_c2()
+    B = 1024
+    z = synth.zarc2_batch(c2["freq"], B)
+    drt = DRT(fixed_basis_tau=c2["tau"])
+    res = drt.fit_eis_batch(c2["freq"], z)
+    assert (res["status"] == 0).all()
+    assert (res["x"] > 0).all() and np.isfinite(res["x"]).all()
+    assert res["outer_iters"].min() >= 2 and res["outer_iters"].max() <= 50
+    res2 = drt.fit_eis_batch(c2["freq"], z)
+    np.testing.assert_array_equal(res["x"], res2["x"])
+    rm = drt._plan.get("rm")
+    cs = res["coefficient_scale"]
+    np.testing.assert_allclose(cs, (z.real.max(1) - z.real.min(1)) / 14, rtol=1e-15)
+    for b in (0, 511, 1023):
+        rv = np.concatenate([z[b].real, z[b].imag]) / cs[b]
+        w = res["weights"][b]
+        np.testing.assert_allclose(res["q_vector"][b], -(w[:, None] * rm).T @ (w * rv), rtol=1e-10,
+                                   atol=1e-10 * np.abs(res["q_vector"][b]).max())

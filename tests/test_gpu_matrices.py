@@ -1,0 +1,137 @@
+"""GPU parity of the kernel-matrix builders (through the C-ABI) against the oracle and the committed
+reference-run fixtures.  Floating-point tolerance: 1e-12 relative (+1e-300 abs) -- the kernels evaluate the
+same formulas; only libm (exp/log) and summation order differ from numpy."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from hipdrt import _ffi
+    return _ffi.get_context(0)
+
+
+def test_device_is_gfx950(ctx):
+    info = ctx.device_info()
+    assert info["arch"] == "gfx950" and info["num_cu"] > 0
+
+
+@pytest.mark.parametrize("eps", [4.342944819032518, 22.19])
+def test_impedance_lookup(ctx, eps):
+    from hipdrt.matrices import basis
+    from oracle import drt_oracle as orc
+    (lre, zre), (lim, zim) = basis.generate_impedance_lookup('gaussian', eps, 2000)
+    (olre, ozre), (olim, ozim) = orc.generate_impedance_lookup(eps, 2000)
+    np.testing.assert_array_equal(lre, olre)
+    np.testing.assert_array_equal(lim, olim)
+    np.testing.assert_allclose(zre, ozre, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(zim, ozim, rtol=RTOL, atol=1e-300)
+
+
+def test_lookup_vs_reference_fixture(ctx):
+    g = load("refrun_golden71x91.npz")
+    zre, zim = ctx.impedance_lookup(float(g["tau_epsilon"]), np.exp(g["lut_log_wt_re"]) * 0 + np.logspace(-2.7, 2.7, 2000),
+                                    np.logspace(-5.4, 5.4, 2000))
+    np.testing.assert_allclose(zre, g["lut_z_re"], rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(zim, g["lut_z_im"], rtol=RTOL, atol=1e-300)
+
+
+def test_impedance_interp_toeplitz_vs_reference_fixture(ctx):
+    from hipdrt.matrices import mat1d
+    g = load("refrun_golden71x91.npz")
+    grids = ((g["lut_log_wt_re"], g["lut_z_re"]), (g["lut_log_wt_im"], g["lut_z_im"]))
+    assert mat1d.impedance_matrix_is_toeplitz(g["freq"], g["basis_tau"])
+    a_re, a_im = mat1d.construct_impedance_matrices(g["freq"], g["basis_tau"], float(g["tau_epsilon"]), 'interp',
+                                                    interpolate_grids=grids)
+    np.testing.assert_allclose(a_re, g["zm_re"], rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(a_im, g["zm_im"], rtol=RTOL, atol=1e-300)
+    # single-part signature of the reference
+    one = mat1d.construct_impedance_matrix(g["freq"], 'imag', tau=g["basis_tau"], epsilon=float(g["tau_epsilon"]),
+                                           integrate_method='interp', interpolate_grids=grids[1])
+    np.testing.assert_array_equal(one, a_im)
+
+
+def test_impedance_interp_general_256x512(ctx):
+    """Non-Toeplitz build at the C2 size incl. the clamped region (48 % of Z' entries)."""
+    from hipdrt import synth
+    from hipdrt.matrices import mat1d
+    from oracle import drt_oracle as orc
+    c2 = synth.config_c2()
+    eps = orc.epsilon_from_tau(c2["tau"])
+    grids = orc.generate_impedance_lookup(eps)
+    assert not mat1d.impedance_matrix_is_toeplitz(c2["freq"], c2["tau"])
+    a_re, a_im = mat1d.construct_impedance_matrices(c2["freq"], c2["tau"], eps, 'interp', interpolate_grids=grids)
+    o_re = orc.construct_impedance_matrix(c2["freq"], 'real', c2["tau"], eps, 'interp', interpolate_grids=grids[0])
+    o_im = orc.construct_impedance_matrix(c2["freq"], 'imag', c2["tau"], eps, 'interp', interpolate_grids=grids[1])
+    np.testing.assert_allclose(a_re, o_re, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(a_im, o_im, rtol=RTOL, atol=1e-300)
+    assert np.mean(a_re == o_re) > 0.45          # the clamped entries are copies of the table ends: bit-exact
+    g = load("refrun_c2_256x512_s0.npz")
+    stride = int(g["row_stride"])
+    np.testing.assert_allclose(a_re[::stride], g["zm_re"], rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(a_im[::stride], g["zm_im"], rtol=RTOL, atol=1e-300)
+
+
+def test_impedance_interp_batched_frequency_grids(ctx):
+    """Per-spectrum frequency grids (ragged-in-value, odd tau count exercises the scalar-store path)."""
+    from hipdrt.matrices import mat1d
+    from oracle import drt_oracle as orc
+    rng = np.random.default_rng(5)
+    tau = np.logspace(-7, 2, 101)
+    eps = orc.epsilon_from_tau(tau)
+    grids = orc.generate_impedance_lookup(eps)
+    freq = np.sort(10 ** rng.uniform(-2, 6.5, size=(3, 37)), axis=1)[:, ::-1].copy()
+    a_re, a_im = mat1d.construct_impedance_matrices(freq, tau, eps, 'interp', interpolate_grids=grids)
+    assert a_re.shape == (3, 37, 101)
+    for b in range(3):
+        o_re = orc.construct_impedance_matrix(freq[b], 'real', tau, eps, 'interp', interpolate_grids=grids[0])
+        o_im = orc.construct_impedance_matrix(freq[b], 'imag', tau, eps, 'interp', interpolate_grids=grids[1])
+        np.testing.assert_allclose(a_re[b], o_re, rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(a_im[b], o_im, rtol=RTOL, atol=1e-300)
+
+
+@pytest.mark.parametrize("name", ["refrun_trapz_32x64.npz", "refrun_trapz_71x91_toeplitz.npz"])
+def test_impedance_trapz_vs_reference_fixture(ctx, name):
+    from hipdrt.matrices import mat1d
+    g = load(name)
+    for part in ("real", "imag"):
+        a = mat1d.construct_impedance_matrix(g["freq"], part, tau=g["tau"], epsilon=float(g["eps"]),
+                                             integrate_method='trapz')
+        np.testing.assert_allclose(a, g[f"A_{part}"], rtol=1e-11, atol=1e-300)
+
+
+def test_penalty_matrices(ctx):
+    from hipdrt.matrices import mat1d
+    from oracle import drt_oracle as orc
+    g = load("refrun_golden71x91.npz")
+    ln_tau = np.log(g["basis_tau"])
+    for k in range(3):
+        m = mat1d.construct_integrated_derivative_matrix(ln_tau, order=k, epsilon=float(g["tau_epsilon"]))
+        np.testing.assert_allclose(m, g[f"m{k}"], rtol=RTOL, atol=1e-300)
+    grid = np.sort(np.random.default_rng(1).uniform(-10, 3, 57))     # non-uniform grid: full evaluation
+    for k in range(3):
+        m = mat1d.construct_integrated_derivative_matrix(grid, order=k, epsilon=3.0)
+        np.testing.assert_allclose(m, orc.construct_integrated_derivative_matrix(grid, k, 3.0), rtol=RTOL, atol=1e-300)
+    with pytest.raises(ValueError):
+        mat1d.construct_integrated_derivative_matrix(grid, order=3, epsilon=3.0)
+
+
+def test_eis_var_matrix(ctx):
+    from hipdrt.matrices import mat1d
+    from oracle import drt_oracle as orc
+    g = load("refrun_golden71x91.npz")
+    np.testing.assert_allclose(mat1d.construct_eis_var_matrix(g["freq"], 0.25, 0.25, None), g["vmm"], rtol=RTOL)
+    np.testing.assert_allclose(mat1d.construct_eis_var_matrix(g["freq"], 0.25, 0.25, 'uniform'),
+                               orc.construct_eis_var_matrix(g["freq"], 0.25, 0.25, 'uniform'), rtol=RTOL)

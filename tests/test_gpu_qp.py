@@ -1,0 +1,128 @@
+"""GPU parity of the weighted normal equations and the batched coneqp kernel against the oracle and the QPs
+captured from the reference run (P, q, h -> x, iterations)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from hipdrt import _ffi
+    return _ffi.get_context(0)
+
+
+@pytest.mark.parametrize("m,n", [(7, 5), (64, 64), (142, 93), (512, 514), (100, 131)])
+def test_weighted_gram_layout_and_values(ctx, m, n):
+    """Asymmetric integer-valued operands: exact in FP64, catches any swapped MFMA fragment / C-D map."""
+    rng = np.random.default_rng(m * 1000 + n)
+    A = rng.integers(-4, 5, size=(m, n)).astype(float)
+    w = rng.integers(1, 4, size=(3, m)).astype(float)
+    b = rng.integers(-3, 4, size=(3, m)).astype(float)
+    l2 = rng.integers(-2, 3, size=(n, n)).astype(float)
+    l2 = l2 + l2.T
+    l1 = rng.integers(0, 3, size=n).astype(float)
+    P, q = ctx.weighted_gram(A, w, b, l2=l2, l1=l1)
+    for i in range(3):
+        wa = w[i][:, None] * A
+        np.testing.assert_array_equal(P[i], wa.T @ wa + l2)
+        np.testing.assert_array_equal(q[i], -wa.T @ (w[i] * b[i]) + l1)
+
+
+def test_weighted_gram_float_vs_numpy(ctx):
+    g = load("refrun_golden71x91.npz")
+    rm, rv = g["rm"], g["rv"]
+    w = np.stack([g["est_weights"], g["weights"]])
+    P, q = ctx.weighted_gram(rm, w, np.stack([rv, rv]))
+    for i in range(2):
+        wa = w[i][:, None] * rm
+        np.testing.assert_allclose(P[i], wa.T @ wa, rtol=1e-13, atol=1e-13 * np.abs(wa.T @ wa).max())
+        np.testing.assert_allclose(q[i], -wa.T @ (w[i] * rv), rtol=1e-12, atol=1e-12 * np.abs(q[i]).max())
+
+
+@pytest.mark.parametrize("name", ["refrun_golden71x91.npz", "refrun_golden71x91_neg.npz", "refrun_c1_71x121.npz"])
+def test_qp_vs_reference_run(ctx, name):
+    """Every QP of the reference trajectories: same iteration count, x within 1e-7 relative of the peak."""
+    g = load(name)
+    nqp = len(g["qp_iterations"])
+    P = np.stack([g[f"qp{i}_P"] for i in range(nqp)])
+    q = np.stack([g[f"qp{i}_q"] for i in range(nqp)])
+    h = np.stack([g[f"qp{i}_h"] for i in range(nqp)])
+    res = ctx.qp_batch(P, q, h)
+    assert res["status"].tolist() == [0] * nqp
+    assert res["iterations"].tolist() == g["qp_iterations"].tolist()
+    for i in range(nqp):
+        ref = g[f"qp{i}_x"]
+        np.testing.assert_allclose(res["x"][i], ref, rtol=1e-6, atol=1e-7 * np.abs(ref).max())
+        assert abs(res["pcost"][i] - float(g[f"qp{i}_pcost"])) <= 1e-9 * abs(float(g[f"qp{i}_pcost"]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 31, 32, 33, 64, 100, 257, 514, 600])
+def test_qp_random_spd_vs_oracle(ctx, n):
+    from oracle.coneqp import coneqp_boxlow
+    rng = np.random.default_rng(n)
+    B = 3
+    Ps, qs, hs = [], [], []
+    for b in range(B):
+        M = rng.standard_normal((n + 3, n))
+        Ps.append(M.T @ M + 0.1 * np.eye(n))
+        qs.append(rng.standard_normal(n) * 3)
+        hs.append(np.where(rng.random(n) < 0.8, 0.0, 1000.0))
+    res = ctx.qp_batch(np.stack(Ps), np.stack(qs), np.stack(hs))
+    for b in range(B):
+        ref = coneqp_boxlow(Ps[b], qs[b], hs[b])
+        assert res["iterations"][b] == ref["iterations"]
+        np.testing.assert_allclose(res["x"][b], ref["x"], rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ref["x"]).max()))
+
+
+def test_qp_shared_p_and_h(ctx):
+    from oracle.coneqp import coneqp_boxlow
+    rng = np.random.default_rng(0)
+    n = 40
+    M = rng.standard_normal((60, n))
+    P = M.T @ M
+    q = rng.standard_normal((5, n))
+    h = np.zeros(n)
+    res = ctx.qp_batch(P, q, h)
+    for b in range(5):
+        ref = coneqp_boxlow(P, q[b], h)
+        assert res["iterations"][b] == ref["iterations"]
+        np.testing.assert_allclose(res["x"][b], ref["x"], rtol=1e-8, atol=1e-10)
+
+
+def test_qp_singular_start_point_reports_status(ctx):
+    """cvxopt raises ValueError when P + G'G is not positive definite at the start point; the batch API reports
+    it per problem and the solve_convex_opt mirror raises."""
+    from hipdrt.models import qphb
+    n = 6
+    P = -2.0 * np.eye(n)
+    res = ctx.qp_batch(np.stack([P, np.eye(n)]), np.zeros((2, n)) - 1.0, np.zeros(n))
+    assert res["status"][0] == -1 and res["status"][1] == 0
+    with pytest.raises(ValueError):
+        qphb.solve_convex_opt(np.zeros(3), np.zeros((3, n)), P, 0.0, True, {})
+
+
+def test_solve_convex_opt_mirror(ctx):
+    """Same call the reference makes at qphb.py:673 (first outer iteration of the golden case)."""
+    from hipdrt.models import qphb
+    from oracle import drt_oracle as orc
+    g = load("refrun_golden71x91.npz")
+    rm, rv, w = g["rm"], g["rv"], g["est_weights"]
+    special = {'R_inf': {'index': 0, 'nonneg': True, 'size': 1}, 'inductance': {'index': 1, 'nonneg': True, 'size': 1}}
+    pen = []
+    for k in range(3):
+        mk = np.zeros((93, 93)); mk[0, 0] = mk[1, 1] = 1e-6; mk[2:, 2:] = g[f"m{k}"]; pen.append(mk)
+    l2 = orc.calculate_qp_l2_matrix(orc.get_default_hypers(), np.ones(3), pen, [np.ones(93)] * 3, 2)
+    l1 = np.zeros(93)
+    out = qphb.solve_convex_opt(w * rv, w[:, None] * rm, l2, l1, True, special)
+    ref = g["qp1_x"]
+    assert out['iterations'] == int(g["qp_iterations"][1]) and out['status'] == 'optimal'
+    np.testing.assert_allclose(np.array(list(out['x'])), ref, rtol=1e-6, atol=1e-7 * np.abs(ref).max())

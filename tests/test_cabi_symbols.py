@@ -1,0 +1,64 @@
+"""CPU: libhipdrt.so loads, exports every symbol include/hipdrt.h declares, the ctypes table matches the
+header, and compute entry points fail loudly (no CPU fallback) when no GPU is visible."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "hipdrt.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(hipdrt_[a-z0-9_]+)\s*\(", txt))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(ROOT, "hybrid-drt_amd", "libhipdrt.so")):
+        g.build()
+    from hipdrt import _ffi
+    return _ffi.load_library()
+
+
+def test_header_and_binding_agree(lib):
+    from hipdrt import _ffi
+    declared = header_functions()
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layout_matches_defaults(lib):
+    from hipdrt import _ffi
+    o = _ffi.default_fit_opts()
+    assert o.rp_scale == 14 and list(o.derivative_weights) == [1.5, 1.0, 0.5] and o.l2_lambda_0 == 142
+    assert list(o.s_alpha) == [5, 10, 25] and list(o.rho_alpha) == [0.15, 0.2, 0.25]
+    assert o.iw_l1_lambda_0 == 1e-4 and o.inductance_scale == 1e-5 and o.xtol == 1e-2 and o.max_iter == 50
+    assert o.nonneg == 1 and o.fit_ohmic == 1 and o.fit_inductance == 1
+    assert (o.qp.abstol, o.qp.reltol, o.qp.feastol, o.qp.maxiters) == (1e-7, 1e-6, 1e-7, 100)
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU visible: the failure path is for GPU-less hosts")
+    from hipdrt import _ffi
+    with pytest.raises(_ffi.HipDrtError, match="no HIP device"):
+        _ffi.Context(0)
+    from hipdrt.models import DRT
+    import numpy as np
+    with pytest.raises(_ffi.HipDrtError):
+        DRT().fit_eis(np.logspace(3, 0, 10), np.ones(10) + 0j)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "hybrid-drt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(dirpath, f)
+                assert "oracle/" not in src and "oracle." not in src, os.path.join(dirpath, f)

@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhipdrt.so")
+LIB_PATH = os.environ.get("HIPDRT_LIB", os.path.join(_HERE, "libhipdrt.so"))
 
 MODE_INTERP, MODE_TRAPZ = 0, 1
 QP_OPTIMAL, QP_MAXITER, QP_SINGULAR_LATE, QP_SINGULAR = 0, 1, 2, -1
@@ -60,6 +60,7 @@ SIGNATURES = {
     "hipdrt_penalty_matrices": [_vp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp],
     "hipdrt_eis_var_matrix": [_vp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp],
     "hipdrt_qp_batch": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.POINTER(QpOpts), _dp, _ip, _dp, _ip],
+    "hipdrt_qp_profile": [_vp, C.POINTER(C.c_ulonglong), C.c_int, C.c_int],
     "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -237,6 +238,11 @@ class Context:
                                          C.byref(opts) if opts is not None else None, _p(x), _pi(iters), _p(pcost),
                                          _pi(status)))
         return dict(x=x, iterations=iters, pcost=pcost, status=status)
+
+    def qp_profile(self, reset=True):
+        buf = (C.c_ulonglong * 16)()
+        _check(self._lib.hipdrt_qp_profile(self._h, buf, 16, int(reset)))
+        return [int(v) for v in buf]
 
     def weighted_gram(self, A, w, b, l2=None, l1=None):
         A, w, b = _f64(A), _f64(w), _f64(b)

@@ -264,7 +264,13 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     hipStream_t st = ctx->stream;
     DevBuf dP, dq, dh, dL, dx, dit, dpc, dst;
     const int ldl = (int)qp_scratch_ld(n);
-    TRY(upload(dP, P, (size_t)(p_batched ? B : 1) * n * n * sizeof(double), st));
+    // device copy of P with an even leading dimension (16-byte row-pair loads in the kernels), pad column zeroed
+    const int ldp = round_up(n, 2);
+    const size_t nmat = (size_t)(p_batched ? B : 1);
+    HIPDRT_CHECK(dP.alloc(nmat * n * ldp * sizeof(double)));
+    if (ldp != n) HIPDRT_CHECK(hipMemsetAsync(dP.p, 0, dP.bytes, st));
+    HIPDRT_CHECK(hipMemcpy2DAsync(dP.p, (size_t)ldp * sizeof(double), P, (size_t)n * sizeof(double),
+                                  (size_t)n * sizeof(double), nmat * n, hipMemcpyHostToDevice, st));
     TRY(upload(dq, q, (size_t)B * n * sizeof(double), st));
     TRY(upload(dh, h, (size_t)(h_batched ? B : 1) * n * sizeof(double), st));
     HIPDRT_CHECK(dL.alloc((size_t)B * n * ldl * sizeof(double)));
@@ -273,7 +279,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     HIPDRT_CHECK(dpc.alloc((size_t)B * sizeof(double)));
     HIPDRT_CHECK(dst.alloc((size_t)B * sizeof(int)));
     QpArgs a{};
-    a.B = B; a.n = n; a.P = dP.d(); a.p_stride = p_batched ? (long long)n * n : 0; a.ldp = n;
+    a.B = B; a.n = n; a.P = dP.d(); a.p_stride = p_batched ? (long long)n * ldp : 0; a.ldp = ldp;
     a.q = dq.d(); a.h = dh.d(); a.h_stride = h_batched ? n : 0;
     a.L = dL.d(); a.ldl = ldl; a.l_stride = (long long)n * ldl;
     a.x = dx.d(); a.iters = dit.i(); a.pcost = dpc.d(); a.status = dst.i();
@@ -286,6 +292,13 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     HIPDRT_CHECK(hipMemcpyAsync(status, dst.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
+}
+
+int hipdrt_qp_profile(hipdrt_ctx* ctx, unsigned long long* cycles, int n, int reset) {
+    HIPDRT_REQUIRE(ctx && cycles, "NULL pointer");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipStreamSynchronize(ctx->stream));
+    return qp_profile_read(cycles, n, reset) < 0 ? HIPDRT_E_HIP : HIPDRT_OK;
 }
 
 int hipdrt_weighted_gram(hipdrt_ctx* ctx, int B, int m, int n, const double* A, const double* w, const double* b,

@@ -20,80 +20,12 @@
 //   * P x: one wavefront per row, coalesced, shuffle-reduced.
 // LDS: panel (PR x 33 doubles) + L11 (32 x 33) + two length-n vectors  ~= 77 kB at PR = 224, so two
 // workgroups share a CU and one's sequential phases overlap the other's MFMA phases.
-#include "common.hpp"
+#include <cstdlib>
+
+#include "qp_common.hpp"
+#include "qp_resident.hpp"
 
 namespace hipdrt {
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-static constexpr int NB = 32;     // Cholesky block
-static constexpr int PLD = 33;    // LDS panel row stride (doubles): odd => conflict-free row-per-lane access
-
-__device__ __forceinline__ double bcast_lane(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
-template <int NW>
-struct Reducer {
-    double* buf;   // LDS [4][NW][4]
-    int slot;
-    __device__ Reducer(double* b) : buf(b), slot(0) {}
-    // sums up to 4 values at once; every thread gets the totals
-    template <int N>
-    __device__ __forceinline__ void sum(double (&v)[N]) {
-        static_assert(N <= 4, "");
-        double* s = buf + (slot & 3) * NW * 4;
-        ++slot;
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = wsum(v[i]);
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) s[(threadIdx.x >> 6) * 4 + i] = v[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) t += s[w * 4 + i];
-            v[i] = t;
-        }
-    }
-    template <int N>
-    __device__ __forceinline__ void max(double (&v)[N]) {
-        static_assert(N <= 4, "");
-        double* s = buf + (slot & 3) * NW * 4;
-        ++slot;
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = wmax(v[i]);
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) s[(threadIdx.x >> 6) * 4 + i] = v[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double t = s[i];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) t = fmax(t, s[w * 4 + i]);
-            v[i] = t;
-        }
-    }
-};
 
 struct QpSmem {
     double* panel;   // [PR][PLD]
@@ -142,7 +74,7 @@ __device__ __forceinline__ bool factor_diag_block(double* __restrict__ panel, do
 // PR = panel rows per pass (multiple of 16, <= NW*MAXT*16).  Returns false on breakdown (uniform).
 // ---------------------------------------------------------------------------------------------------------
 template <int THREADS, int MAXT>
-__device__ bool chol_factor(const double* __restrict__ P, int ldp, double* __restrict__ L, int ldl, int n, int PR,
+__device__ __forceinline__ bool chol_factor(const double* __restrict__ P, int ldp, double* __restrict__ L, int ldl, int n, int PR,
                             const QpSmem& sm) {
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -159,6 +91,7 @@ __device__ bool chol_factor(const double* __restrict__ P, int ldp, double* __res
             const int cr = (R - c0) < pr ? (R - c0) : pr;      // valid rows in this pass
             const int ntile = (cr + 15) >> 4;
             const int rowbase = j0 + c0;
+            PROF_DECL
             // ---- (1) C = P - L[rows,:j0] L[blk,:j0]' on MFMA -------------------------------------------
             v4d acc[MAXT][2];
 #pragma unroll
@@ -198,6 +131,7 @@ __device__ bool chol_factor(const double* __restrict__ P, int ldp, double* __res
                     }
                 }
             }
+            PROF(0);
             // C/D map of v_mfma_f64_16x16x4: col = lane&15, row = (lane>>4) + 4*reg
 #pragma unroll
             for (int u = 0; u < MAXT; ++u) {
@@ -223,6 +157,7 @@ __device__ bool chol_factor(const double* __restrict__ P, int ldp, double* __res
                 }
             }
             __syncthreads();
+            PROF(1);
             // ---- (2) diagonal block ---------------------------------------------------------------------
             if (c0 == 0) {
                 if (wv == 0) {
@@ -233,6 +168,7 @@ __device__ bool chol_factor(const double* __restrict__ P, int ldp, double* __res
                 __syncthreads();
                 if (sm.flag[0]) return false;
             }
+            PROF(2);
             // ---- (3) panel rows: X L11' = C, one thread per row -----------------------------------------
             {
                 const int rstart = (c0 == 0) ? NB : 0;
@@ -261,12 +197,14 @@ __device__ bool chol_factor(const double* __restrict__ P, int ldp, double* __res
                 }
             }
             __syncthreads();
+            PROF(3);
             // ---- (4) coalesced write-back of the pass (32 columns = 256 B per row) ---------------------
             for (int e = tid; e < cr * NB; e += THREADS) {
                 const int r = e >> 5, c = e & 31;
                 if (c < nv) L[(size_t)(rowbase + r) * ldl + j0 + c] = sm.panel[r * PLD + c];
             }
             __syncthreads();
+            PROF(4);
         }
     }
     return true;
@@ -276,11 +214,12 @@ __device__ bool chol_factor(const double* __restrict__ P, int ldp, double* __res
 // vec := S^-1 vec  with S = L L'
 // ---------------------------------------------------------------------------------------------------------
 template <int THREADS>
-__device__ void chol_solve(const double* __restrict__ L, int ldl, int n, const QpSmem& sm) {
+__device__ __forceinline__ void chol_solve(const double* __restrict__ L, int ldl, int n, const QpSmem& sm) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nblk = (n + NB - 1) / NB;
     double* vec = sm.vec;
     // ---- forward: L y = b ---------------------------------------------------------------------------------
+    PROF_DECL
     for (int jb = 0; jb < nblk; ++jb) {
         const int j0 = jb * NB;
         const int nv = (n - j0) < NB ? (n - j0) : NB;
@@ -305,6 +244,7 @@ __device__ void chol_solve(const double* __restrict__ L, int ldl, int n, const Q
             if (lane < nv) vec[j0 + lane] = bb;
         }
         __syncthreads();
+        PROF(5);
         for (int row = j0 + NB + tid; row < n; row += THREADS) {
             const double* lp = L + (size_t)row * ldl + j0;
             double t = vec[row];
@@ -317,6 +257,7 @@ __device__ void chol_solve(const double* __restrict__ L, int ldl, int n, const Q
             vec[row] = t;
         }
         __syncthreads();
+        PROF(6);
     }
     // ---- backward: L' x = y -------------------------------------------------------------------------------
     for (int jb = nblk - 1; jb >= 0; --jb) {
@@ -343,6 +284,7 @@ __device__ void chol_solve(const double* __restrict__ L, int ldl, int n, const Q
             if (lane < nv) vec[j0 + lane] = yy;
         }
         __syncthreads();
+        PROF(7);
         for (int col = tid; col < j0; col += THREADS) {
             double t = vec[col];
 #pragma unroll 8
@@ -352,12 +294,13 @@ __device__ void chol_solve(const double* __restrict__ L, int ldl, int n, const Q
             vec[col] = t;
         }
         __syncthreads();
+        PROF(8);
     }
 }
 
 // out[i] = sum_j P[i][j] * vec[j]   (P symmetric, full storage); one wavefront per row
 template <int THREADS>
-__device__ void matvec_P(const double* __restrict__ P, int ldp, int n, const double* __restrict__ xin,
+__device__ __forceinline__ void matvec_P(const double* __restrict__ P, int ldp, int n, const double* __restrict__ xin,
                          double* __restrict__ out) {
     constexpr int NW = THREADS / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -371,223 +314,50 @@ __device__ void matvec_P(const double* __restrict__ P, int ldp, int n, const dou
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// the solver
+// multi-pass kernel: any n <= 2048 (panel of PR rows cycled through LDS, L11 copy, strided solves)
 // ---------------------------------------------------------------------------------------------------------
+template <int THREADS, int MAXT>
+struct OpsMultipass {
+    const double* P; int ldp; double* L; int ldl; int n; int PR; QpSmem sm;
+    __device__ __forceinline__ bool factor() { return chol_factor<THREADS, MAXT>(P, ldp, L, ldl, n, PR, sm); }
+    __device__ __forceinline__ void solve() { chol_solve<THREADS>(L, ldl, n, sm); }
+    __device__ __forceinline__ void matvec() { matvec_P<THREADS>(P, ldp, n, sm.vec, sm.dvec); }
+};
+
 template <int THREADS, int MAXT, int EPT>
 __global__ __launch_bounds__(THREADS) void qp_kernel(QpArgs a, int PR) {
     constexpr int NW = THREADS / 64;
     const int b = blockIdx.x;
     if (a.active && !a.active[b]) return;
-    const int n = a.n, tid = threadIdx.x;
-    const double* P = a.P + (size_t)b * a.p_stride;
-    const double* qg = a.q + (size_t)b * n;
-    const double* hg = a.h + (size_t)b * a.h_stride;
-    double* L = a.L + (size_t)b * a.l_stride;
-    const int ldp = a.ldp, ldl = a.ldl;
-
+    const int n = a.n;
     extern __shared__ double smem[];
-    QpSmem sm;
-    sm.panel = smem;
-    sm.l11 = sm.panel + (size_t)PR * PLD;
-    sm.vec = sm.l11 + NB * PLD;
-    sm.dvec = sm.vec + n;
-    sm.red = sm.dvec + n;
-    sm.flag = reinterpret_cast<int*>(sm.red + 4 * NW * 4);
-    Reducer<NW> red(sm.red);
-
-    double x[EPT], z[EPT], s[EPT], d[EPT], di[EPT], lm[EPT], qv[EPT], hv[EPT];
-#define FOR_E for (int e = 0, i = tid; e < EPT; ++e, i += THREADS)
-#define VALID (i < n)
-#pragma unroll
-    FOR_E { qv[e] = VALID ? qg[i] : 0.0; hv[e] = VALID ? hg[i] : 0.0; x[e] = z[e] = 0.0; s[e] = lm[e] = 1.0; d[e] = di[e] = 1.0; }
-
-    double nq[2] = {0.0, 0.0};
-#pragma unroll
-    FOR_E { nq[0] += qv[e] * qv[e]; nq[1] += hv[e] * hv[e]; }
-    red.sum(nq);
-    const double resx0 = fmax(1.0, sqrt(nq[0]));
-    const double resz0 = fmax(1.0, sqrt(nq[1]));
-
-    int status = HIPDRT_QP_MAXITER, iters = 0;
-    double pcost = 0.0;
-    bool done = false;
-
-    // ---- start point: W = I ---------------------------------------------------------------------------------
-#pragma unroll
-    FOR_E if (VALID) { sm.dvec[i] = 1.0; sm.vec[i] = -qv[e] - hv[e]; }
-    __syncthreads();
-    if (!chol_factor<THREADS, MAXT>(P, ldp, L, ldl, n, PR, sm)) {
-        status = HIPDRT_QP_SINGULAR;
-        done = true;
-    } else {
-        chol_solve<THREADS>(L, ldl, n, sm);
-        double st[2] = {0.0, 0.0}, mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-        FOR_E {
-            if (VALID) {
-                x[e] = sm.vec[i];
-                z[e] = -x[e] - hv[e];
-                s[e] = -z[e];
-                st[0] += s[e] * s[e]; st[1] += z[e] * z[e];
-                mx[0] = fmax(mx[0], -s[e]); mx[1] = fmax(mx[1], -z[e]);
-            }
-        }
-        red.sum(st);
-        red.max(mx);
-        const double nrms = sqrt(st[0]), nrmz = sqrt(st[1]);
-        if (mx[0] >= -1e-8 * fmax(nrms, 1.0)) {
-#pragma unroll
-            FOR_E s[e] += 1.0 + mx[0];
-        }
-        if (mx[1] >= -1e-8 * fmax(nrmz, 1.0)) {
-#pragma unroll
-            FOR_E z[e] += 1.0 + mx[1];
-        }
-    }
-    double gp[1] = {0.0};
-#pragma unroll
-    FOR_E if (VALID) gp[0] += s[e] * z[e];
-    red.sum(gp);
-    double gap = gp[0];
-
-    double rx[EPT], rz[EPT];
-    while (!done) {
-        // ---- residuals, costs, stopping test -------------------------------------------------------------
-        __syncthreads();
-#pragma unroll
-        FOR_E if (VALID) sm.vec[i] = x[e];
-        __syncthreads();
-        matvec_P<THREADS>(P, ldp, n, sm.vec, sm.dvec);
-        __syncthreads();
-        double t4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        FOR_E {
-            rx[e] = rz[e] = 0.0;
-            if (VALID) {
-                double r = sm.dvec[i] + qv[e];          // P x + q
-                t4[0] += x[e] * r;                      // x'(Px+q)
-                t4[1] += x[e] * qv[e];                  // x'q
-                r -= z[e];                              // + G'z
-                rx[e] = r;
-                t4[2] += r * r;
-                const double rzz = s[e] - hv[e] - x[e]; // s + Gx - h
-                rz[e] = rzz;
-                t4[3] += rzz * rzz;
-            }
-        }
-        red.sum(t4);
-        double zr[1] = {0.0};
-#pragma unroll
-        FOR_E if (VALID) zr[0] += z[e] * rz[e];
-        red.sum(zr);
-        const double f0 = 0.5 * (t4[0] + t4[1]);
-        const double resx = sqrt(t4[2]), resz = sqrt(t4[3]);
-        pcost = f0;
-        const double dcost = f0 + zr[0] - gap;
-        bool has_rel = false;
-        double relgap = 0.0;
-        if (pcost < 0.0) { relgap = gap / -pcost; has_rel = true; }
-        else if (dcost > 0.0) { relgap = gap / dcost; has_rel = true; }
-        const double pres = resz / resz0, dres = resx / resx0;
-        const bool conv = pres <= a.opts.feastol && dres <= a.opts.feastol &&
-                          (gap <= a.opts.abstol || (has_rel && relgap <= a.opts.reltol));
-        if (conv) { status = HIPDRT_QP_OPTIMAL; break; }
-        if (iters == a.opts.maxiters) { status = HIPDRT_QP_MAXITER; break; }
-
-        // ---- scaling --------------------------------------------------------------------------------------
-        if (iters == 0) {
-#pragma unroll
-            FOR_E if (VALID) { d[e] = sqrt(s[e] / z[e]); di[e] = 1.0 / d[e]; lm[e] = sqrt(s[e] * z[e]); }
-        }
-        __syncthreads();
-#pragma unroll
-        FOR_E if (VALID) sm.dvec[i] = di[e] * di[e];
-        __syncthreads();
-        if (!chol_factor<THREADS, MAXT>(P, ldp, L, ldl, n, PR, sm)) {
-            status = (iters == 0) ? HIPDRT_QP_SINGULAR : HIPDRT_QP_SINGULAR_LATE;
-            break;
-        }
-
-        const double mu = gap / (double)n;
-        double sigma = 0.0, step = 1.0;
-        double dx[EPT], ds[EPT], dz[EPT], ws3[EPT];
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-            double zz[EPT], sv[EPT];
-#pragma unroll
-            FOR_E {
-                if (VALID) {
-                    double t = (pc == 1) ? (-ws3[e] - lm[e] * lm[e]) : (-(lm[e] * lm[e]));
-                    t += sigma * mu;
-                    sv[e] = t / lm[e];
-                    const double bz = -rz[e] - d[e] * sv[e];
-                    zz[e] = bz * di[e];
-                    sm.vec[i] = -rx[e] - di[e] * zz[e];
-                }
-            }
-            __syncthreads();
-            chol_solve<THREADS>(L, ldl, n, sm);
-            double dd[1] = {0.0}, mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-            FOR_E {
-                if (VALID) {
-                    dx[e] = sm.vec[i];
-                    dz[e] = -di[e] * dx[e] - zz[e];
-                    ds[e] = sv[e] - dz[e];
-                    dd[0] += ds[e] * dz[e];
-                    if (pc == 0) ws3[e] = ds[e] * dz[e];
-                    ds[e] /= lm[e];
-                    dz[e] /= lm[e];
-                    mx[0] = fmax(mx[0], -ds[e]);
-                    mx[1] = fmax(mx[1], -dz[e]);
-                }
-            }
-            red.sum(dd);
-            red.max(mx);
-            const double t = fmax(0.0, fmax(mx[0], mx[1]));
-            if (t == 0.0) step = 1.0;
-            else if (pc == 0) step = fmin(1.0, 1.0 / t);
-            else step = fmin(1.0, 0.99 / t);
-            if (pc == 0) {
-                const double sg = fmin(1.0, fmax(0.0, 1.0 - step + dd[0] / gap * (step * step)));
-                sigma = sg * sg * sg;
-            }
-        }
-        // ---- update ---------------------------------------------------------------------------------------
-        double g2[1] = {0.0};
-#pragma unroll
-        FOR_E {
-            if (VALID) {
-                x[e] += step * dx[e];
-                const double dss = (1.0 + step * ds[e]) * lm[e];
-                const double dzz = (1.0 + step * dz[e]) * lm[e];
-                const double sqs = sqrt(dss), sqz = sqrt(dzz);
-                d[e] = d[e] * sqs / sqz;
-                di[e] = 1.0 / d[e];
-                lm[e] = sqs * sqz;
-                s[e] = lm[e] * d[e];
-                z[e] = lm[e] * di[e];
-                g2[0] += lm[e] * lm[e];
-            }
-        }
-        red.sum(g2);
-        gap = g2[0];
-        ++iters;
-    }
-
-#pragma unroll
-    FOR_E if (VALID) a.x[(size_t)b * n + i] = x[e];
-    if (tid == 0) {
-        if (a.iters) a.iters[b] = iters;
-        if (a.pcost) a.pcost[b] = pcost;
-        a.status[b] = status;
-        if (a.iters_accum) a.iters_accum[b] += iters;
-    }
-#undef FOR_E
-#undef VALID
+    OpsMultipass<THREADS, MAXT> ops;
+    ops.P = a.P + (size_t)b * a.p_stride; ops.ldp = a.ldp;
+    ops.L = a.L + (size_t)b * a.l_stride; ops.ldl = a.ldl; ops.n = n; ops.PR = PR;
+    ops.sm.panel = smem;
+    ops.sm.l11 = ops.sm.panel + (size_t)PR * PLD;
+    ops.sm.vec = ops.sm.l11 + NB * PLD;
+    ops.sm.dvec = ops.sm.vec + n;
+    ops.sm.red = ops.sm.dvec + n;
+    ops.sm.flag = reinterpret_cast<int*>(ops.sm.red + 4 * NW * 4);
+    IpmSmem is{ops.sm.vec, ops.sm.dvec, ops.sm.red};
+    ipm_solve<THREADS, EPT>(a, b, ops, is);
 }
 
 size_t qp_scratch_ld(int n) { return (size_t)round_up(n, 16); }
+
+int qp_profile_read(unsigned long long* out, int n, int reset) {
+#ifdef HIPDRT_QP_PROFILE
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_qp_prof), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 16; ++i) out[i] = h[i];
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qp_prof), z, sizeof(z)); }
+    return 1;
+#else
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    return 0;
+#endif
+}
 
 static constexpr int QP_THREADS = 512;
 static constexpr int QP_MAXT = 2;
@@ -604,8 +374,21 @@ static int launch_qp_ept(hipStream_t st, const QpArgs& a, int PR, size_t lds) {
     return HIPDRT_OK;
 }
 
+static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
+    const int NP = round_up(a.n, 32);
+    const size_t lds = resident_lds_bytes(NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_resident),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(qp resident): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    hipLaunchKernelGGL(qp_kernel_resident, dim3(a.B), dim3(RT), lds, st, a, NP);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("qp launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    return HIPDRT_OK;
+}
+
 int launch_qp(hipStream_t st, const QpArgs& a) {
     const int n = a.n;
+    if (n <= RNP_MAX && !getenv("HIPDRT_QP_MULTIPASS")) return launch_qp_resident(st, a);
     constexpr int NW = QP_THREADS / 64;
     // panel rows: as many as keep two workgroups per CU (<= 80 kB each), at most NW*MAXT*16
     const size_t fixed = ((size_t)NB * PLD + 2 * (size_t)n + 4 * NW * 4) * sizeof(double) + 64;

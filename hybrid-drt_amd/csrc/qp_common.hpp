@@ -1,0 +1,315 @@
+// Shared pieces of the batched coneqp kernels: wave helpers, fixed-order block reductions and the interior-point
+// driver itself (cvxopt coneprog.coneqp for one 'l' cone with G = -I; restated for tests in the repository's CPU
+// checker).  The driver is templated on an Ops policy that provides the three linear-algebra
+// services: factor S = P + diag(dvec), solve S vec = vec in place, and out = P * vec.
+#pragma once
+#include "common.hpp"
+
+namespace hipdrt {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#ifdef HIPDRT_QP_PROFILE
+__device__ unsigned long long g_qp_prof[16];
+#define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime();
+#define PROF(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
+    atomicAdd(&g_qp_prof[slot], _n - _pt); _pt = _n; } else { _pt = 0; } } while (0)
+#else
+#define PROF_DECL
+#define PROF(slot)
+#endif
+
+static constexpr int NB = 32;     // Cholesky block
+static constexpr int PLD = 33;    // LDS panel row stride (doubles): odd => conflict-free row-per-lane access
+
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+template <int NW>
+struct Reducer {
+    double* buf;   // LDS [4][NW][4]
+    int slot;
+    __device__ Reducer(double* b) : buf(b), slot(0) {}
+    // sums up to 4 values at once; every thread gets the totals
+    template <int N>
+    __device__ __forceinline__ void sum(double (&v)[N]) {
+        static_assert(N <= 4, "");
+        double* s = buf + (slot & 3) * NW * 4;
+        ++slot;
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = wsum(v[i]);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) s[(threadIdx.x >> 6) * 4 + i] = v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += s[w * 4 + i];
+            v[i] = t;
+        }
+    }
+    template <int N>
+    __device__ __forceinline__ void max(double (&v)[N]) {
+        static_assert(N <= 4, "");
+        double* s = buf + (slot & 3) * NW * 4;
+        ++slot;
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = wmax(v[i]);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) s[(threadIdx.x >> 6) * 4 + i] = v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double t = s[i];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) t = fmax(t, s[w * 4 + i]);
+            v[i] = t;
+        }
+    }
+};
+
+
+// LDS vectors every Ops policy provides
+struct IpmSmem {
+    double* vec;     // [n]  rhs / solution of the KKT solve; x for the mat-vec
+    double* dvec;    // [n]  diagonal shift d^-2 for the factorisation; P x result
+    double* red;     // [4][NW][4]
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// The interior-point iteration.  O(n) vectors live in registers, element i owned by thread i % THREADS.
+// ---------------------------------------------------------------------------------------------------------
+template <int THREADS, int EPT, class Ops>
+__device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, const IpmSmem& sm) {
+    constexpr int NW = THREADS / 64;
+    const int n = a.n, tid = threadIdx.x;
+    const double* qg = a.q + (size_t)b * n;
+    const double* hg = a.h + (size_t)b * a.h_stride;
+    Reducer<NW> red(sm.red);
+
+    double x[EPT], z[EPT], s[EPT], d[EPT], di[EPT], lm[EPT], qv[EPT], hv[EPT];
+#define FOR_E for (int e = 0, i = tid; e < EPT; ++e, i += THREADS)
+#define VALID (i < n)
+#pragma unroll
+    FOR_E { qv[e] = VALID ? qg[i] : 0.0; hv[e] = VALID ? hg[i] : 0.0; x[e] = z[e] = 0.0; s[e] = lm[e] = 1.0; d[e] = di[e] = 1.0; }
+
+    double nq[2] = {0.0, 0.0};
+#pragma unroll
+    FOR_E { nq[0] += qv[e] * qv[e]; nq[1] += hv[e] * hv[e]; }
+    red.sum(nq);
+    const double resx0 = fmax(1.0, sqrt(nq[0]));
+    const double resz0 = fmax(1.0, sqrt(nq[1]));
+
+    PROF_DECL
+    int status = HIPDRT_QP_MAXITER, iters = 0;
+    double pcost = 0.0, gap = 0.0;
+    double rx[EPT], rz[EPT];
+#pragma unroll
+    FOR_E { rx[e] = 0.0; rz[e] = 0.0; }
+
+    // One loop body serves the start point (W = I, one KKT solve) and every Mehrotra iteration (two KKT solves)
+    // so that factor(), solve() and matvec() are each inlined exactly once.
+    bool start = true;
+    for (;;) {
+        if (!start) {
+            // ---- residuals, costs, stopping test ----------------------------------------------------------
+            __syncthreads();
+#pragma unroll
+            FOR_E if (VALID) sm.vec[i] = x[e];
+            __syncthreads();
+            { PROF_DECL
+            ops.matvec();
+            __syncthreads();
+            PROF(9); }
+            double t4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            FOR_E {
+                rx[e] = rz[e] = 0.0;
+                if (VALID) {
+                    double r = sm.dvec[i] + qv[e];          // P x + q
+                    t4[0] += x[e] * r;                      // x'(Px+q)
+                    t4[1] += x[e] * qv[e];                  // x'q
+                    r -= z[e];                              // + G'z
+                    rx[e] = r;
+                    t4[2] += r * r;
+                    const double rzz = s[e] - hv[e] - x[e]; // s + Gx - h
+                    rz[e] = rzz;
+                    t4[3] += rzz * rzz;
+                }
+            }
+            red.sum(t4);
+            double zr[1] = {0.0};
+#pragma unroll
+            FOR_E if (VALID) zr[0] += z[e] * rz[e];
+            red.sum(zr);
+            const double f0 = 0.5 * (t4[0] + t4[1]);
+            const double resx = sqrt(t4[2]), resz = sqrt(t4[3]);
+            pcost = f0;
+            const double dcost = f0 + zr[0] - gap;
+            bool has_rel = false;
+            double relgap = 0.0;
+            if (pcost < 0.0) { relgap = gap / -pcost; has_rel = true; }
+            else if (dcost > 0.0) { relgap = gap / dcost; has_rel = true; }
+            const double pres = resz / resz0, dres = resx / resx0;
+            const bool conv = pres <= a.opts.feastol && dres <= a.opts.feastol &&
+                              (gap <= a.opts.abstol || (has_rel && relgap <= a.opts.reltol));
+            if (conv) { status = HIPDRT_QP_OPTIMAL; break; }
+            if (iters == a.opts.maxiters) { status = HIPDRT_QP_MAXITER; break; }
+            if (iters == 0) {
+#pragma unroll
+                FOR_E if (VALID) { d[e] = sqrt(s[e] / z[e]); di[e] = 1.0 / d[e]; lm[e] = sqrt(s[e] * z[e]); }
+            }
+        }
+        // ---- factor S = P + diag(di^2)  (di = 1 at the start point) --------------------------------------
+        __syncthreads();
+#pragma unroll
+        FOR_E if (VALID) sm.dvec[i] = di[e] * di[e];
+        __syncthreads();
+        if (!ops.factor()) {
+            status = (start || iters == 0) ? HIPDRT_QP_SINGULAR : HIPDRT_QP_SINGULAR_LATE;
+            break;
+        }
+
+        const double mu = gap / (double)n;
+        double sigma = 0.0, step = 1.0;
+        double dx[EPT], ds[EPT], dz[EPT], ws3[EPT];
+#pragma unroll
+        FOR_E { dx[e] = ds[e] = dz[e] = ws3[e] = 0.0; }
+        const int nsolve = start ? 1 : 2;
+#pragma nounroll
+        for (int pc = 0; pc < nsolve; ++pc) {
+            double zz[EPT], sv[EPT];
+#pragma unroll
+            FOR_E {
+                zz[e] = sv[e] = 0.0;
+                if (VALID) {
+                    if (start) {
+                        sm.vec[i] = -qv[e] - hv[e];           // bx + Gs' bz with bx = -q, bz = h
+                    } else {
+                        double t = (pc == 1) ? (-ws3[e] - lm[e] * lm[e]) : (-(lm[e] * lm[e]));
+                        t += sigma * mu;
+                        sv[e] = t / lm[e];
+                        const double bz = -rz[e] - d[e] * sv[e];
+                        zz[e] = bz * di[e];
+                        sm.vec[i] = -rx[e] - di[e] * zz[e];
+                    }
+                }
+            }
+            __syncthreads();
+            ops.solve();
+            if (start) {
+                double st[2] = {0.0, 0.0}, mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+                FOR_E {
+                    if (VALID) {
+                        x[e] = sm.vec[i];
+                        z[e] = -x[e] - hv[e];
+                        s[e] = -z[e];
+                        st[0] += s[e] * s[e]; st[1] += z[e] * z[e];
+                        mx[0] = fmax(mx[0], -s[e]); mx[1] = fmax(mx[1], -z[e]);
+                    }
+                }
+                red.sum(st);
+                red.max(mx);
+                const double nrms = sqrt(st[0]), nrmz = sqrt(st[1]);
+                if (mx[0] >= -1e-8 * fmax(nrms, 1.0)) {
+#pragma unroll
+                    FOR_E s[e] += 1.0 + mx[0];
+                }
+                if (mx[1] >= -1e-8 * fmax(nrmz, 1.0)) {
+#pragma unroll
+                    FOR_E z[e] += 1.0 + mx[1];
+                }
+                double gp[1] = {0.0};
+#pragma unroll
+                FOR_E if (VALID) gp[0] += s[e] * z[e];
+                red.sum(gp);
+                gap = gp[0];
+            } else {
+                double dd[1] = {0.0}, mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+                FOR_E {
+                    if (VALID) {
+                        dx[e] = sm.vec[i];
+                        dz[e] = -di[e] * dx[e] - zz[e];
+                        ds[e] = sv[e] - dz[e];
+                        dd[0] += ds[e] * dz[e];
+                        if (pc == 0) ws3[e] = ds[e] * dz[e];
+                        ds[e] /= lm[e];
+                        dz[e] /= lm[e];
+                        mx[0] = fmax(mx[0], -ds[e]);
+                        mx[1] = fmax(mx[1], -dz[e]);
+                    }
+                }
+                red.sum(dd);
+                red.max(mx);
+                const double t = fmax(0.0, fmax(mx[0], mx[1]));
+                if (t == 0.0) step = 1.0;
+                else if (pc == 0) step = fmin(1.0, 1.0 / t);
+                else step = fmin(1.0, 0.99 / t);
+                if (pc == 0) {
+                    const double sg = fmin(1.0, fmax(0.0, 1.0 - step + dd[0] / gap * (step * step)));
+                    sigma = sg * sg * sg;
+                }
+            }
+        }
+        if (start) { start = false; continue; }
+        // ---- update ---------------------------------------------------------------------------------------
+        double g2[1] = {0.0};
+#pragma unroll
+        FOR_E {
+            if (VALID) {
+                x[e] += step * dx[e];
+                const double dss = (1.0 + step * ds[e]) * lm[e];
+                const double dzz = (1.0 + step * dz[e]) * lm[e];
+                const double sqs = sqrt(dss), sqz = sqrt(dzz);
+                d[e] = d[e] * sqs / sqz;
+                di[e] = 1.0 / d[e];
+                lm[e] = sqs * sqz;
+                s[e] = lm[e] * d[e];
+                z[e] = lm[e] * di[e];
+                g2[0] += lm[e] * lm[e];
+            }
+        }
+        red.sum(g2);
+        gap = g2[0];
+        ++iters;
+    }
+
+    PROF(10);
+#pragma unroll
+    FOR_E if (VALID) a.x[(size_t)b * n + i] = x[e];
+    if (tid == 0) {
+#ifdef HIPDRT_QP_PROFILE
+        if (b == 0) atomicAdd(&g_qp_prof[11], (unsigned long long)(iters + 1));
+#endif
+        if (a.iters) a.iters[b] = iters;
+        if (a.pcost) a.pcost[b] = pcost;
+        a.status[b] = status;
+        if (a.iters_accum) a.iters_accum[b] += iters;
+    }
+#undef FOR_E
+#undef VALID
+}
+
+}  // namespace hipdrt

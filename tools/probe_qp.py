@@ -1,0 +1,39 @@
+"""Diagnostic: time hipdrt_qp_batch on B copies of a C2-sized QP and (with HIPDRT_LIB=.../libhipdrt_prof.so)
+print the in-kernel phase breakdown of workgroup 0."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from hipdrt import synth, _ffi
+from oracle import drt_oracle as orc
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+c2 = synth.config_c2()
+d = orc.OracleDRT(fixed_basis_tau=c2["tau"])
+m = d.prepare(c2["freq"])
+z = synth.zarc2_spectrum(c2["freq"], 0)
+cs = (z.real.max() - z.real.min()) / 14
+rv = np.concatenate([z.real, z.imag]) / cs
+hyp = orc.get_default_hypers()
+l2 = orc.calculate_qp_l2_matrix(hyp, np.ones(3), m["pen"], [np.ones(514)] * 3, 2)
+w = np.full(512, 50.0)
+wa = w[:, None] * m["rzm"]
+P = wa.T @ wa + l2
+q = -wa.T @ (w * rv)
+h = np.zeros(514)
+ctx = _ffi.get_context(0)
+qs = np.tile(q, (B, 1))
+Ps = np.tile(P, (B, 1, 1))
+for rep in range(3):
+    ctx.qp_profile(reset=True)
+    t = time.time(); res = ctx.qp_batch(Ps, qs, h); dt = time.time() - t
+    prof = ctx.qp_profile(reset=True)
+    it = int(res["iterations"][0])
+    print(f"B={B} iters={it} wall {dt*1e3:.1f} ms (incl. H2D of {Ps.nbytes/1e6:.0f} MB)")
+names = ["gemm", "panel_store", "diag", "trsm", "writeback", "fwd_diag", "fwd_upd", "bwd_diag", "bwd_upd", "matvec", "total"]
+if prof[10]:
+    tot = prof[10]
+    print("in-kernel ticks of WG0:", {n: prof[i] for i, n in enumerate(names)}, "factorizations:", prof[11])
+    print("shares:", {n: round(prof[i] / tot, 3) for i, n in enumerate(names)})
+from oracle.coneqp import coneqp_boxlow
+r = coneqp_boxlow(P, q, h)
+print("oracle iters", r["iterations"], "max rel err", np.max(np.abs(res["x"][0] - r["x"])) / np.abs(r["x"]).max())

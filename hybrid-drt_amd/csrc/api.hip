@@ -273,7 +273,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
                                   (size_t)n * sizeof(double), nmat * n, hipMemcpyHostToDevice, st));
     TRY(upload(dq, q, (size_t)B * n * sizeof(double), st));
     TRY(upload(dh, h, (size_t)(h_batched ? B : 1) * n * sizeof(double), st));
-    HIPDRT_CHECK(dL.alloc((size_t)B * n * ldl * sizeof(double)));
+    HIPDRT_CHECK(dL.alloc((size_t)B * qp_scratch_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(dx.alloc((size_t)B * n * sizeof(double)));
     HIPDRT_CHECK(dit.alloc((size_t)B * sizeof(int)));
     HIPDRT_CHECK(dpc.alloc((size_t)B * sizeof(double)));
@@ -281,7 +281,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     QpArgs a{};
     a.B = B; a.n = n; a.P = dP.d(); a.p_stride = p_batched ? (long long)n * ldp : 0; a.ldp = ldp;
     a.q = dq.d(); a.h = dh.d(); a.h_stride = h_batched ? n : 0;
-    a.L = dL.d(); a.ldl = ldl; a.l_stride = (long long)n * ldl;
+    a.L = dL.d(); a.ldl = ldl; a.l_stride = (long long)qp_scratch_doubles(n);
     a.x = dx.d(); a.iters = dit.i(); a.pcost = dpc.d(); a.status = dst.i();
     a.active = nullptr; a.iters_accum = nullptr;
     a.opts = opts ? *opts : default_qp_opts();
@@ -439,7 +439,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
         HIPDRT_CHECK(ib->alloc(cap * sizeof(int)));
     HIPDRT_CHECK(p->n_active.alloc(sizeof(int)));
     HIPDRT_CHECK(p->P.alloc(cap * n * p->ldp * sizeof(double)));
-    HIPDRT_CHECK(p->L.alloc(cap * n * p->ldl * sizeof(double)));
+    HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
     HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
 
@@ -570,7 +570,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
 
     QpArgs qa{};
     qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
-    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)n * p->ldl;
+    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n);
     qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
     qa.iters_accum = p->qp_iters_total.i(); qa.opts = p->opts.qp;
 

@@ -161,6 +161,7 @@ struct QpArgs {
 };
 int launch_qp(hipStream_t st, const QpArgs& a);
 size_t qp_scratch_ld(int n);
+size_t qp_scratch_doubles(int n);
 int qp_profile_read(unsigned long long* out, int n, int reset);
 
 }  // namespace hipdrt

@@ -346,6 +346,13 @@ __global__ __launch_bounds__(THREADS) void qp_kernel(QpArgs a, int PR) {
 
 size_t qp_scratch_ld(int n) { return (size_t)round_up(n, 16); }
 
+// doubles of factor scratch per problem (covers both the row-major multipass and the tile-packed resident layout)
+size_t qp_scratch_doubles(int n) {
+    size_t d = (size_t)n * qp_scratch_ld(n);
+    if (n <= RNP_MAX) { const size_t r = resident_l_doubles(n); if (r > d) d = r; }
+    return d;
+}
+
 int qp_profile_read(unsigned long long* out, int n, int reset) {
 #ifdef HIPDRT_QP_PROFILE
     unsigned long long h[16];

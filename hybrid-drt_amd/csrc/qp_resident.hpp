@@ -1,21 +1,24 @@
 // Linear-algebra services of the coneqp kernel for n <= 528 unknowns (C1-C4 sizes: n = 93 ... 514), built around
 // memory-level parallelism: one 1024-thread workgroup (16 wavefronts) per problem, one per CU.
 //
+//  * The Cholesky factor L lives in HBM in a TILE-PACKED layout: 16x16 tiles, each one contiguous 2 KB block,
+//    tiles of one tile-row adjacent ([tile_row][k_chunk][16][16]).  An MFMA operand fragment (16 rows x 16 k),
+//    a block-column panel of a tile-row (2 adjacent tiles) and a block-row of finished columns are all
+//    contiguous byte ranges, so every phase reads and writes long coalesced runs (1 KB per wave instruction)
+//    instead of 128-byte row segments 4 KB apart.
 //  * LDS array U[NP][33] (NP = n rounded up to 32): while block column j of the left-looking Cholesky is
 //    processed it is the panel for rows >= 32 j; rows of already finished block columns keep their 32x32 diagonal
-//    block L_jj there.  After the factorisation all diagonal blocks are LDS resident, so the triangular solves
-//    never fetch them from HBM, and their reciprocal diagonals sit in the pad column U[i][32].
-//  * Block column j in ONE pass: every wavefront owns up to 3 row tiles (16 rows x 32 cols, two MFMA
+//    block L_jj there, with 1/L_ii in the pad column U[i][32].  After the factorisation all diagonal blocks are
+//    LDS resident, so the triangular solves never fetch them from HBM.
+//  * Block column j in ONE pass: every wavefront owns up to 2 row tiles (16 rows x 32 cols, two MFMA
 //    accumulators each) initialised with -(P + diag) and accumulating +L L' over the finished columns with
-//    v_mfma_f64_16x16x4_f64; operands come straight from L in HBM/L2 as 128-byte row segments; 4 wavefronts
-//    per SIMD hide the load latency.
+//    v_mfma_f64_16x16x4_f64; operand slabs are double buffered in registers (the next 16-deep slab is in flight
+//    while the current one is multiplied).
 //  * Diagonal block: wavefront 0, lane = row, rows in registers, column broadcast through a 32-double LDS
-//    buffer (one ds_write + b128 broadcast reads per step) instead of v_readlane chains.
-//  * Panel rows (X L11' = C): thread per row, right-looking substitution (independent FMAs per step, reciprocal
-//    pivots) against the LDS-resident L11.
-//  * Solves: per 32-block a register/LDS substitution by wavefront 0, then the rank-32 update with fully
-//    coalesced reads of L: forward = 4 rows per wave instruction + 16-lane shuffle reduction, backward = thread
-//    per column with 32 independent loads.
+//    buffer, reciprocal pivots from rsqrt.
+//  * Panel rows (X L11' = C): thread per row, right-looking substitution against the LDS-resident L11.
+//  * Solves: per 32-block a substitution by wavefront 0; wavefronts 1..15 apply the rank-32 updates from
+//    operands that were fetched (contiguous tiles) before the diagonal solve started.
 //  * P x: two rows x 5 column chunks of 16-byte loads in flight per lane.
 #pragma once
 #include "qp_common.hpp"
@@ -26,27 +29,24 @@ static constexpr int RT = 1024;          // threads
 static constexpr int RNW = RT / 64;      // 16 wavefronts
 static constexpr int RMAXT = 2;          // row tiles per wavefront for block columns j >= 1 (<= 31 tiles)
 static constexpr int RNP_MAX = 528;
+static constexpr int TSZ = 256;          // doubles per 16x16 tile
 
 struct ResSmem {
     double* U;       // [NP][PLD]
-    double* vec;     // [NP]
-    double* dvec;    // [NP]
+    double* vec;     // [NP + 32]
+    double* dvec;    // [NP + 32]
     double* colbuf;  // [64]
     double* red;     // [4][RNW][4]
     int* flag;       // [4]
 };
 
-// reduction over the 16 lanes of a DPP row (lanes sharing lane>>4)
-__device__ __forceinline__ double row16_sum(double v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-}
-
 struct OpsResident {
-    const double* P; int ldp; double* L; int ldl; int n; ResSmem sm;
+    const double* P; int ldp; double* L; int nch; int n; ResSmem sm;   // nch = tiles per tile-row (NP/16)
+
+    // tile (t, c) starts at ((t*nch + c) * TSZ) doubles; returned in double2 units
+    __device__ __forceinline__ const double2* tile2(int t, int c) const {
+        return reinterpret_cast<const double2*>(L) + (size_t)((t * nch + c) * (TSZ / 2));
+    }
 
     // -----------------------------------------------------------------------------------------------------
     __device__ __forceinline__ bool factor() {
@@ -58,6 +58,7 @@ struct OpsResident {
             const int nv = (n - j0) < NB ? (n - j0) : NB;
             const int R = n - j0;
             const int ntile = (R + 15) >> 4;
+            const int tb = j0 >> 4;                 // first tile-row of the block
             PROF_DECL
             // ---- (1) tiles: acc = -(P + diag) + L[rows,:j0] L[blk,:j0]' -----------------------------------
             if (j0 == 0) {
@@ -96,30 +97,25 @@ struct OpsResident {
                         }
                 }
                 if (wv < ntile) {
-                    int brow0 = j0 + li;       if (brow0 > n - 1) brow0 = n - 1;
-                    int brow1 = j0 + 16 + li;  if (brow1 > n - 1) brow1 = n - 1;
-                    const double* pb0 = L + (size_t)brow0 * ldl + 4 * kq;
-                    const double* pb1 = L + (size_t)brow1 * ldl + 4 * kq;
-                    const double* pa[RMAXT];
+                    // fragment of lane (i = lane&15, kq = lane>>4): doubles [i][4kq .. 4kq+3] of a 16x16 tile
+                    // = double2 index i*8 + 2kq (+1)
+                    const int fo = li * 8 + 2 * kq;
+                    const double2* pb0 = tile2(tb, 0) + fo;
+                    const double2* pb1 = tile2(tb + 1 < nch ? tb + 1 : tb, 0) + fo;
+                    const double2* pa[RMAXT];
 #pragma unroll
                     for (int u = 0; u < RMAXT; ++u) {
-                        int ar = j0 + (wv + u * RNW) * 16 + li;
-                        if (ar > n - 1) ar = n - 1;
-                        pa[u] = L + (size_t)ar * ldl + 4 * kq;
+                        int t = tb + wv + u * RNW;
+                        if (t > nch - 1) t = nch - 1;
+                        pa[u] = tile2(t, 0) + fo;
                     }
-                    // ping-pong prefetch: the next 16-deep operand slab is in flight while the current one is
-                    // multiplied (j0 is a multiple of 32, so slabs come in pairs)
                     struct Slab { double2 b0a, b0b, b1a, b1b, aa[RMAXT], ab[RMAXT]; };
-                    auto load = [&](Slab& s_, int k0) {
-                        s_.b0a = *reinterpret_cast<const double2*>(pb0 + k0);
-                        s_.b0b = *reinterpret_cast<const double2*>(pb0 + k0 + 2);
-                        s_.b1a = *reinterpret_cast<const double2*>(pb1 + k0);
-                        s_.b1b = *reinterpret_cast<const double2*>(pb1 + k0 + 2);
+                    auto load = [&](Slab& s_, int c) {          // c = k-chunk index (16 columns)
+                        const int o = c * (TSZ / 2);
+                        s_.b0a = pb0[o]; s_.b0b = pb0[o + 1];
+                        s_.b1a = pb1[o]; s_.b1b = pb1[o + 1];
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) {
-                            s_.aa[u] = *reinterpret_cast<const double2*>(pa[u] + k0);
-                            s_.ab[u] = *reinterpret_cast<const double2*>(pa[u] + k0 + 2);
-                        }
+                        for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = pa[u][o]; s_.ab[u] = pa[u][o + 1]; }
                     };
                     auto mult = [&](const Slab& s_) {
 #pragma unroll
@@ -136,12 +132,14 @@ struct OpsResident {
                             }
                         }
                     };
+                    // ping-pong prefetch over the 2*jb finished 16-column chunks (always an even count)
                     Slab sa, sb;
+                    const int nc = 2 * jb;
                     load(sa, 0);
-                    for (int k0 = 0; k0 < j0; k0 += 32) {
-                        load(sb, k0 + 16);
+                    for (int c = 0; c < nc; c += 2) {
+                        load(sb, c + 1);
                         mult(sa);
-                        if (k0 + 32 < j0) load(sa, k0 + 32);
+                        if (c + 2 < nc) load(sa, c + 2);
                         mult(sb);
                     }
                 }
@@ -186,7 +184,7 @@ struct OpsResident {
                         const double lrc = (r == c) ? ljj : a[c] * rinv;       // L_rc
                         const double lrs = lrc * rinv;                         // L_rc / L_cc
                         a[c] = lrc;
-                        if (lane == c) U[(size_t)(j0 + c) * PLD + NB] = rinv;  // reciprocal pivot lives in the pad column
+                        if (lane == c) Ub[c * PLD + NB] = rinv;                // reciprocal pivot -> pad column
 #pragma unroll
                         for (int k = c + 1; k < NB; ++k) a[k] -= lrs * cv[k];  // a_rk -= L_rc * L_kc
                     }
@@ -213,7 +211,7 @@ struct OpsResident {
 #pragma unroll
                     for (int c = 0; c < NB; ++c) {
                         if (c < nv) {
-                            const double xc = v[c] * U[(size_t)(j0 + c) * PLD + NB];
+                            const double xc = v[c] * Ub[c * PLD + NB];
                             v[c] = xc;
 #pragma unroll
                             for (int k = c + 1; k < NB; ++k) v[k] -= xc * Ub[k * PLD + c];
@@ -225,13 +223,14 @@ struct OpsResident {
             }
             __syncthreads();
             PROF(3);
-            // ---- (4) coalesced write-back: 16 x 16-byte pieces per row ---------------------------------------
-            for (int e = tid; e < R * 16; e += RT) {
-                const int r = e >> 4, p2 = (e & 15) * 2;
-                const double* src = U + (size_t)(j0 + r) * PLD + p2;
-                double* dst = L + (size_t)(j0 + r) * ldl + j0 + p2;
-                if (p2 + 1 < nv) *reinterpret_cast<double2*>(dst) = make_double2(src[0], src[1]);
-                else if (p2 < nv) dst[0] = src[0];
+            // ---- (4) write-back: per tile-row 2 adjacent tiles = 4 KB contiguous ---------------------------
+            // e -> (tile t, chunk ch, row i, 16-byte piece pc)
+            for (int e = tid; e < ntile * 256; e += RT) {
+                const int pc = e & 7, i = (e >> 3) & 15, ch = (e >> 7) & 1, t = e >> 8;
+                const double* src = U + (size_t)(j0 + t * 16 + i) * PLD + ch * 16 + 2 * pc;
+                double2* dst = reinterpret_cast<double2*>(L) +
+                               (size_t)(((tb + t) * nch + 2 * jb + ch) * (TSZ / 2) + i * 8 + pc);
+                *dst = make_double2(src[0], src[1]);
             }
             __syncthreads();
             PROF(4);
@@ -241,30 +240,36 @@ struct OpsResident {
 
     // -----------------------------------------------------------------------------------------------------
     // vec := S^-1 vec.  Wavefront 0 solves the 32x32 diagonal systems (L_jj and 1/L_ii are LDS resident);
-    // wavefronts 1..15 apply the rank-32 updates.  The update operands (rows/columns of L in HBM) do not
-    // depend on the running solution, so they are fetched BEFORE the diagonal solve of the same block and
-    // are in flight while wavefront 0 substitutes.
+    // wavefronts 1..15 apply the rank-32 updates.  The update operands (tiles of L in HBM) do not depend on the
+    // running solution, so they are fetched BEFORE the diagonal solve of the same block and are in flight while
+    // wavefront 0 substitutes.
+    //   tile load map: instruction q of a 2 KB tile covers double2 index q*64 + lane  ->  row i = q*8 + lane/8,
+    //   columns 2*(lane%8), +1.
     __device__ __forceinline__ void solve() {
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
         const int nblk = (n + NB - 1) / NB;
         double* vec = sm.vec;
         const double* U = sm.U;
         constexpr int UW = RNW - 1;                 // updater wavefronts
+        const int l8 = lane & 7, g8 = lane >> 3;
         PROF_DECL
         // ---- forward: L y = b -----------------------------------------------------------------------------
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
             const int nv = (n - j0) < NB ? (n - j0) : NB;
-            const int rows_below = n - (j0 + NB);
-            const int li = lane & 15, rq = lane >> 4;
-            constexpr int FG = 9;                     // 4-row groups per updater wavefront: 15*9*4 = 540 rows
-            double2 lv[FG];
-            if (wv > 0 && rows_below > 0) {
+            const int tb = j0 >> 4;
+            const int tbelow = ((n + 15) >> 4) - (tb + 2);     // row tiles below the block
+            constexpr int FT = 3;                               // tiles per updater wavefront (15*3 = 45 >= 31)
+            double2 lv[FT][4];                                  // [tile][chunk*2 + half]
+            if (wv > 0 && tbelow > 0) {
 #pragma unroll
-                for (int u = 0; u < FG; ++u) {
-                    int row = j0 + NB + ((wv - 1) + u * UW) * 4 + rq;
-                    if (row > n - 1) row = n - 1;
-                    lv[u] = *reinterpret_cast<const double2*>(L + (size_t)row * ldl + j0 + 2 * li);
+                for (int u = 0; u < FT; ++u) {
+                    const int tt = (wv - 1) + u * UW;
+                    if (tt < tbelow) {
+                        const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;   // chunks 2jb, 2jb+1 are adjacent
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) lv[u][q] = p[q * 64];
+                    }
                 }
             }
             if (wv == 0) {
@@ -288,14 +293,28 @@ struct OpsResident {
             }
             __syncthreads();
             PROF(5);
-            if (wv > 0 && rows_below > 0) {
-                const double y0 = vec[j0 + 2 * li], y1 = vec[j0 + 2 * li + 1];
+            if (wv > 0 && tbelow > 0) {
+                // lane holds columns 2*l8, 2*l8+1 of chunk 0 (q = 0,1) and of chunk 1 (q = 2,3)
+                const double y00 = vec[j0 + 2 * l8], y01 = vec[j0 + 2 * l8 + 1];
+                const double y10 = vec[j0 + 16 + 2 * l8], y11 = vec[j0 + 16 + 2 * l8 + 1];
 #pragma unroll
-                for (int u = 0; u < FG; ++u) {
-                    const int row = j0 + NB + ((wv - 1) + u * UW) * 4 + rq;
-                    double pv = lv[u].x * y0 + lv[u].y * y1;
-                    pv = row16_sum(pv);
-                    if (li == 0 && row < n) vec[row] -= pv;
+                for (int u = 0; u < FT; ++u) {
+                    const int tt = (wv - 1) + u * UW;
+                    if (tt < tbelow) {
+                        // rows g8 (q even) and 8 + g8 (q odd) of the tile
+                        double pA = lv[u][0].x * y00 + lv[u][0].y * y01 + lv[u][2].x * y10 + lv[u][2].y * y11;
+                        double pB = lv[u][1].x * y00 + lv[u][1].y * y01 + lv[u][3].x * y10 + lv[u][3].y * y11;
+#pragma unroll
+                        for (int off = 1; off < 8; off <<= 1) {
+                            pA += __shfl_xor(pA, off, 64);
+                            pB += __shfl_xor(pB, off, 64);
+                        }
+                        if (l8 == 0) {
+                            const int row = (tb + 2 + tt) * 16 + g8;
+                            if (row < n) vec[row] -= pA;
+                            if (row + 8 < n) vec[row + 8] -= pB;
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -305,12 +324,22 @@ struct OpsResident {
         for (int jb = nblk - 1; jb >= 0; --jb) {
             const int j0 = jb * NB;
             const int nv = (n - j0) < NB ? (n - j0) : NB;
-            const int col = tid - 64;                 // updater thread -> column
-            double lvb[NB];
-            if (wv > 0 && col < j0) {
-                const double* lp = L + (size_t)j0 * ldl + col;
+            const int tb = j0 >> 4;
+            const int nc = 2 * jb;                              // 16-column chunks left of the block
+            const bool two = (tb + 1) * 16 < n;                 // second tile-row of the block holds valid rows
+            constexpr int BC = 3;                               // chunks per updater wavefront (15*3 = 45 >= 32)
+            double2 lb[BC][4];                                  // [chunk][tile*2 + half]
+            if (wv > 0) {
 #pragma unroll
-                for (int r = 0; r < NB; ++r) lvb[r] = (r < nv) ? lp[(size_t)r * ldl] : 0.0;
+                for (int u = 0; u < BC; ++u) {
+                    const int c = (wv - 1) + u * UW;
+                    if (c < nc) {
+                        const double2* p0 = tile2(tb, c) + lane;
+                        const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
+                        lb[u][0] = p0[0]; lb[u][1] = p0[64];
+                        lb[u][2] = p1[0]; lb[u][3] = p1[64];
+                    }
+                }
             }
             if (wv == 0) {
                 const int c = lane & 31;     // lane = column c of the block: needs L[j0+r][j0+c], r >= c
@@ -332,14 +361,27 @@ struct OpsResident {
             }
             __syncthreads();
             PROF(7);
-            if (wv > 0 && col < j0) {
-                double t0 = 0.0, t1 = 0.0;
+            if (wv > 0 && nc > 0) {
+                // x of the block: rows g8, 8+g8 of tile tb and of tile tb+1 (zero padding beyond n)
+                const double x0 = vec[j0 + g8], x1 = vec[j0 + 8 + g8];
+                const double x2 = two ? vec[j0 + 16 + g8] : 0.0, x3 = two ? vec[j0 + 24 + g8] : 0.0;
 #pragma unroll
-                for (int r = 0; r < NB; r += 2) {
-                    t0 += lvb[r] * vec[j0 + r];          // vec beyond n is zero padding
-                    t1 += lvb[r + 1] * vec[j0 + r + 1];
+                for (int u = 0; u < BC; ++u) {
+                    const int c = (wv - 1) + u * UW;
+                    if (c < nc) {
+                        double s0 = lb[u][0].x * x0 + lb[u][1].x * x1 + lb[u][2].x * x2 + lb[u][3].x * x3;   // col 2*l8
+                        double s1 = lb[u][0].y * x0 + lb[u][1].y * x1 + lb[u][2].y * x2 + lb[u][3].y * x3;   // col 2*l8+1
+#pragma unroll
+                        for (int off = 8; off < 64; off <<= 1) {
+                            s0 += __shfl_xor(s0, off, 64);
+                            s1 += __shfl_xor(s1, off, 64);
+                        }
+                        if (g8 == 0) {
+                            vec[c * 16 + 2 * l8] -= s0;
+                            vec[c * 16 + 2 * l8 + 1] -= s1;
+                        }
+                    }
                 }
-                vec[col] -= (t0 + t1);
             }
             __syncthreads();
             PROF(8);
@@ -390,15 +432,15 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
     extern __shared__ double smem[];
     OpsResident ops;
     ops.P = a.P + (size_t)b * a.p_stride; ops.ldp = a.ldp;
-    ops.L = a.L + (size_t)b * a.l_stride; ops.ldl = a.ldl; ops.n = a.n;
+    ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.sm.U = smem;
     ops.sm.vec = ops.sm.U + (size_t)NP * PLD;
     ops.sm.dvec = ops.sm.vec + NP + 32;
     ops.sm.colbuf = ops.sm.dvec + NP + 32;
     ops.sm.red = ops.sm.colbuf + 64;
     ops.sm.flag = reinterpret_cast<int*>(ops.sm.red + 4 * RNW * 4);
-    // zero U (rows >= n are read, never used) and the padding of vec (read by the backward update of the
-    // last, partial block)
+    // zero U (rows >= n are read, never used) and the padding of vec (read by the updates of the last,
+    // partial block)
     for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
     for (int i = threadIdx.x; i < NP + 32; i += RT) ops.sm.vec[i] = 0.0;
     __syncthreads();
@@ -408,6 +450,12 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
 
 static size_t resident_lds_bytes(int NP) {
     return ((size_t)NP * PLD + 2 * (size_t)(NP + 32) + 64 + 4 * RNW * 4) * sizeof(double) + 64;
+}
+
+// scratch doubles per problem for the tile-packed factor: (NP/16)^2 tiles of 256 doubles
+static size_t resident_l_doubles(int n) {
+    const size_t nt = (size_t)round_up(n, 32) / 16;
+    return nt * nt * TSZ;
 }
 
 }  // namespace hipdrt

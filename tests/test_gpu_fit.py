@@ -158,9 +158,19 @@ def test_full_size_batch_properties():
     z = synth.zarc2_batch(c2["freq"], B)
     drt = DRT(fixed_basis_tau=c2["tau"])
     res = drt.fit_eis_batch(c2["freq"], z)
-    assert (res["status"] == 0).all()
+    # status 1 = max_iter reached without meeting xtol: the reference warns "Solution did not converge within
+    # 50 iterations. This is usually not an issue." (drt1d.py:985-986) and keeps the last iterate
+    assert np.isin(res["status"], (0, 1)).all() and (res["status"] == 0).mean() > 0.85
+    assert (res["outer_iters"][res["status"] == 1] == 50).all()
     assert (res["x"] > 0).all() and np.isfinite(res["x"]).all()
     assert res["outer_iters"].min() >= 2 and res["outer_iters"].max() <= 50
+    # one spectrum that exhausts max_iter must do so in the oracle too, with the same iterate
+    from oracle import drt_oracle as orc
+    bad = int(np.where(res["status"] == 1)[0][0])
+    odrt = orc.OracleDRT(fixed_basis_tau=c2["tau"])
+    ofp = odrt.fit_eis(c2["freq"], z[bad])
+    assert not odrt.qphb_params["converged"] and odrt.qphb_params["outer_iterations"] == 50
+    close_to_peak(res["fit_x"][bad], ofp["x"])
     res2 = drt.fit_eis_batch(c2["freq"], z)
     np.testing.assert_array_equal(res["x"], res2["x"])
     rm = drt._plan.get("rm")

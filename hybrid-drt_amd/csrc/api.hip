@@ -27,7 +27,7 @@ struct hipdrt_plan {
     // per spectrum
     DevBuf z_re, z_im, rv, w, est_w, x, x_in, q, s, rho, xmx, coef_scale, var_floor;
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
-    DevBuf P, L, Ptmp;
+    DevBuf P, L, Ptmp, qpstate;
     // history
     int hist_b = -1, hist_cap = 0;
     DevBuf hist_x, hist_w, hist_rho, hist_qp, hist_rows;
@@ -175,7 +175,7 @@ static int impedance_matrix_common(hipdrt_ctx* ctx, int B, int freq_batched, con
     TRY(upload(dfreq, freq, (size_t)(freq_batched ? B : 1) * nf * sizeof(double), st));
     TRY(upload(dtau, tau, (size_t)ntau * sizeof(double), st));
     if (mode == HIPDRT_MODE_INTERP) TRY(build_lut6(st, lut6, ngrid, log_wt_re, z_re, log_wt_im, z_im, false));
-    HIPDRT_CHECK(cr.alloc(2 * (size_t)(nf + ntau) * sizeof(double)));
+    HIPDRT_CHECK(cr.alloc(((size_t)(freq_batched ? B : 1) * nf + 2 * (size_t)(nf + ntau)) * sizeof(double)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (elapsed_ms) { HIPDRT_CHECK(hipEventCreate(&e0)); HIPDRT_CHECK(hipEventCreate(&e1)); HIPDRT_CHECK(hipEventRecord(e0, st)); }
     for (int r = 0; r < (repeat < 1 ? 1 : repeat); ++r)
@@ -262,7 +262,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     HIPDRT_REQUIRE(B >= 1 && n >= 1 && n <= 2048, "B >= 1, 1 <= n <= 2048");
     HIPDRT_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevBuf dP, dq, dh, dL, dx, dit, dpc, dst;
+    DevBuf dP, dq, dh, dL, dx, dit, dpc, dst, dstate;
     const int ldl = (int)qp_scratch_ld(n);
     // device copy of P with an even leading dimension (16-byte row-pair loads in the kernels), pad column zeroed
     const int ldp = round_up(n, 2);
@@ -284,6 +284,8 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     a.L = dL.d(); a.ldl = ldl; a.l_stride = (long long)qp_scratch_doubles(n);
     a.x = dx.d(); a.iters = dit.i(); a.pcost = dpc.d(); a.status = dst.i();
     a.active = nullptr; a.iters_accum = nullptr;
+    HIPDRT_CHECK(dstate.alloc((size_t)B * qp_state_doubles(n) * sizeof(double)));
+    a.state = dstate.d(); a.state_ld = qp_state_ld(n); a.state_stride = (long long)qp_state_doubles(n);
     a.opts = opts ? *opts : default_qp_opts();
     TRY(launch_qp(st, a));
     HIPDRT_CHECK(hipMemcpyAsync(x, dx.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -441,6 +443,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     HIPDRT_CHECK(p->P.alloc(cap * n * p->ldp * sizeof(double)));
     HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
+    HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
 
     // shared matrices on the device
@@ -573,6 +576,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n);
     qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
     qa.iters_accum = p->qp_iters_total.i(); qa.opts = p->opts.qp;
+    qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);
 
     // ---- initialize_weights (qphb.py:1609-1681): one un-weighted, weakly penalised QP; P is the same for
     //      every spectrum (weights = 1, s = s_0, rho = rho_0), only q differs -------------------------------

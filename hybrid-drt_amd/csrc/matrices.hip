@@ -113,47 +113,67 @@ struct LutView {
 };
 
 __device__ __forceinline__ LutView stage_lut(double* sm, const double* __restrict__ lut6, int ng) {
-    for (int i = threadIdx.x; i < 6 * ng; i += blockDim.x) sm[i] = lut6[i];
+    if ((ng & 1) == 0) {
+        const double2* src = reinterpret_cast<const double2*>(lut6);
+        double2* dst = reinterpret_cast<double2*>(sm);
+        for (int i = threadIdx.x; i < 3 * ng; i += blockDim.x) dst[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < 6 * ng; i += blockDim.x) sm[i] = lut6[i];
+    }
     __syncthreads();
     return LutView{sm, sm + ng, sm + 2 * ng, sm + 3 * ng, sm + 4 * ng, sm + 5 * ng};
 }
 
-// INTERP, general (non-Toeplitz) build.  grid = (ceil(ntau/2/TPB), rows_per_block groups, B).
-// Each block stages the tables once and walks `rows_per_block` frequency rows.
+// ln(2 pi f) per (grid, frequency) and ln(tau): the general build evaluates ln(omega tau) as their sum (one add
+// per entry instead of one FP64 log; differs from log(omega*tau) by <= 2 ulp of the abscissa, i.e. ~1e-16
+// relative in the interpolated value, and not at all in the clamped regions).
+__global__ void log_grid_kernel(int count_f, const double* __restrict__ freq, int ntau, const double* __restrict__ tau,
+                                double* __restrict__ lw, double* __restrict__ lt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count_f) lw[i] = log(freq[i] * 2.0 * 3.141592653589793);
+    if (i < ntau) lt[i] = log(tau[i]);
+}
+
+// INTERP, general (non-Toeplitz) build.  grid = (row chunks, B), 1024 threads: the 96 kB of tables are staged
+// once per workgroup and amortised over `rows_per_block` rows; thread (tr, tc) walks rows tr, tr+RP, ... and owns
+// two adjacent tau columns, so a wavefront stores 1 KiB contiguous per matrix per row.
 __global__ __launch_bounds__(1024) void impedance_interp_kernel(
-    int freq_batched, const double* __restrict__ freq, int nf, const double* __restrict__ tau, int ntau, int ng,
-    const double* __restrict__ lut6, int rows_per_block, double* __restrict__ a_re, double* __restrict__ a_im) {
+    int freq_batched, const double* __restrict__ lw, int nf, const double* __restrict__ lt, int ntau, int ng,
+    const double* __restrict__ lut6, int rows_per_block, int tpr, double* __restrict__ a_re,
+    double* __restrict__ a_im) {
     extern __shared__ double sm[];
     const LutView L = stage_lut(sm, lut6, ng);
     const double x0r = L.xr[0], idr = (double)(ng - 1) / (L.xr[ng - 1] - L.xr[0]);
     const double x0i = L.xi[0], idi = (double)(ng - 1) / (L.xi[ng - 1] - L.xi[0]);
-    const int b = blockIdx.z;
-    const double* fr = freq + (freq_batched ? (size_t)b * nf : 0);
-    const int row0 = blockIdx.y * rows_per_block;
-    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (c >= ntau) return;
-    const bool two = (c + 1 < ntau);
-    const double t0 = tau[c], t1 = two ? tau[c + 1] : 0.0;
-    for (int r = row0; r < row0 + rows_per_block && r < nf; ++r) {
-        const double w = fr[r] * 2.0 * 3.141592653589793;   // frequencies * 2 * np.pi
-        const double xa = log(w * t0);
-        double re0 = np_interp(xa, L.xr, L.fr, L.sr, ng, x0r, idr);
-        double im0 = np_interp(xa, L.xi, L.fi, L.si, ng, x0i, idi);
-        const size_t o = ((size_t)b * nf + r) * ntau + c;
-        if (two) {
-            const double xb = log(w * t1);
-            double re1 = np_interp(xb, L.xr, L.fr, L.sr, ng, x0r, idr);
-            double im1 = np_interp(xb, L.xi, L.fi, L.si, ng, x0i, idi);
-            if ((ntau & 1) == 0) {
-                *reinterpret_cast<double2*>(a_re + o) = make_double2(re0, re1);
-                *reinterpret_cast<double2*>(a_im + o) = make_double2(im0, im1);
+    const int b = blockIdx.y;
+    const double* lwb = lw + (freq_batched ? (size_t)b * nf : 0);
+    const int row0 = blockIdx.x * rows_per_block;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr, rp = blockDim.x / tpr;
+    const bool even = (ntau & 1) == 0;
+    for (int c = 2 * tc; c < ntau; c += 2 * tpr) {
+        const bool two = (c + 1 < ntau);
+        const double t0 = lt[c], t1 = two ? lt[c + 1] : 0.0;
+        for (int r = row0 + tr; r < row0 + rows_per_block && r < nf; r += rp) {
+            const double w = lwb[r];
+            const double xa = w + t0;
+            const double re0 = np_interp(xa, L.xr, L.fr, L.sr, ng, x0r, idr);
+            const double im0 = np_interp(xa, L.xi, L.fi, L.si, ng, x0i, idi);
+            const size_t o = ((size_t)b * nf + r) * ntau + c;
+            if (two) {
+                const double xb = w + t1;
+                const double re1 = np_interp(xb, L.xr, L.fr, L.sr, ng, x0r, idr);
+                const double im1 = np_interp(xb, L.xi, L.fi, L.si, ng, x0i, idi);
+                if (even) {
+                    *reinterpret_cast<double2*>(a_re + o) = make_double2(re0, re1);
+                    *reinterpret_cast<double2*>(a_im + o) = make_double2(im0, im1);
+                } else {
+                    a_re[o] = re0; a_re[o + 1] = re1;
+                    a_im[o] = im0; a_im[o + 1] = im1;
+                }
             } else {
-                a_re[o] = re0; a_re[o + 1] = re1;
-                a_im[o] = im0; a_im[o + 1] = im1;
+                a_re[o] = re0;
+                a_im[o] = im0;
             }
-        } else {
-            a_re[o] = re0;
-            a_im[o] = im0;
         }
     }
 }
@@ -332,15 +352,20 @@ void launch_impedance_matrix(hipStream_t st, int B, int freq_batched, const doub
         return;
     }
     if (mode == HIPDRT_MODE_INTERP) {
-        // one block covers up to 2048 tau columns; rows_per_block amortises the 96 kB table staging
-        int threads = (ntau + 1) / 2;
-        threads = threads > 1024 ? 1024 : ((threads + 63) / 64 * 64);
-        const int bx = ((ntau + 1) / 2 + threads - 1) / threads;
-        int rpb = 16;
-        if ((long long)B * nf < 4096) rpb = 4;
-        const int by = (nf + rpb - 1) / rpb;
-        hipLaunchKernelGGL(impedance_interp_kernel, dim3(bx, by, B), dim3(threads), 6 * (size_t)ngrid * sizeof(double),
-                           st, freq_batched, freq, nf, tau, ntau, ngrid, lut6, rpb, a_re, a_im);
+        // cr_scratch doubles as storage for ln(omega) [B*nf] and ln(tau) [ntau] (sized by the caller)
+        double* lw = cr_scratch;
+        const int count_f = (freq_batched ? B : 1) * nf;
+        double* lt = cr_scratch + count_f;
+        const int cnt = count_f > ntau ? count_f : ntau;
+        hipLaunchKernelGGL(log_grid_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, count_f, freq, ntau, tau, lw, lt);
+        int tpr = ((ntau + 1) / 2 + 63) / 64 * 64;           // threads per row (two columns each)
+        if (tpr > 1024) tpr = 1024;
+        while (1024 % tpr) tpr += 64;                         // 64,128,256,512,1024
+        int rpb = 256;
+        while (rpb > 4 && (long long)B * ((nf + rpb - 1) / rpb) < 1024) rpb /= 2;   // enough workgroups for 256 CUs
+        const int bx = (nf + rpb - 1) / rpb;
+        hipLaunchKernelGGL(impedance_interp_kernel, dim3(bx, B), dim3(1024), 6 * (size_t)ngrid * sizeof(double), st,
+                           freq_batched, lw, nf, lt, ntau, ngrid, lut6, rpb, tpr, a_re, a_im);
     } else {
         hipLaunchKernelGGL(impedance_trapz_kernel, dim3((ntau + 15) / 16, nf, B), dim3(256), 3 * ny * sizeof(double),
                            st, freq_batched, freq, nf, tau, ntau, eps, ny, a_re, a_im);

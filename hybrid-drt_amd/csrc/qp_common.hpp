@@ -107,15 +107,24 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     const double* hg = a.h + (size_t)b * a.h_stride;
     Reducer<NW> red(sm.red);
 
-    double x[EPT], z[EPT], s[EPT], d[EPT], di[EPT], lm[EPT], qv[EPT], hv[EPT];
-#define FOR_E for (int e = 0, i = tid; e < EPT; ++e, i += THREADS)
+    // The O(n) iterates live in a per-problem global scratch (L1/L2 resident, 16 vectors), element i touched
+    // only by its owner thread, so no synchronisation is needed for them; keeping them out of registers leaves
+    // the 128-VGPR budget of the 1024-thread kernel to the factorisation / solve phases (fewer spills there).
+    double* const S_ = a.state + (size_t)b * a.state_stride;
+    const int sld = a.state_ld;
+#define SV(k) (S_ + (size_t)(k) * sld)
+    double* const x = SV(0); double* const z = SV(1); double* const s = SV(2); double* const d = SV(3);
+    double* const di = SV(4); double* const lm = SV(5); double* const qv = SV(6); double* const hv = SV(7);
+    double* const rx = SV(8); double* const rz = SV(9); double* const dx = SV(10); double* const ds = SV(11);
+    double* const dz = SV(12); double* const ws3 = SV(13); double* const zz = SV(14); double* const sv = SV(15);
+#define FOR_E for (int e_ = 0, i = tid; e_ < EPT; ++e_, i += THREADS)
 #define VALID (i < n)
 #pragma unroll
-    FOR_E { qv[e] = VALID ? qg[i] : 0.0; hv[e] = VALID ? hg[i] : 0.0; x[e] = z[e] = 0.0; s[e] = lm[e] = 1.0; d[e] = di[e] = 1.0; }
+    FOR_E if (VALID) { qv[i] = qg[i]; hv[i] = hg[i]; x[i] = z[i] = 0.0; s[i] = lm[i] = 1.0; d[i] = di[i] = 1.0; }
 
     double nq[2] = {0.0, 0.0};
 #pragma unroll
-    FOR_E { nq[0] += qv[e] * qv[e]; nq[1] += hv[e] * hv[e]; }
+    FOR_E if (VALID) { nq[0] += qv[i] * qv[i]; nq[1] += hv[i] * hv[i]; }
     red.sum(nq);
     const double resx0 = fmax(1.0, sqrt(nq[0]));
     const double resz0 = fmax(1.0, sqrt(nq[1]));
@@ -123,9 +132,6 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     PROF_DECL
     int status = HIPDRT_QP_MAXITER, iters = 0;
     double pcost = 0.0, gap = 0.0;
-    double rx[EPT], rz[EPT];
-#pragma unroll
-    FOR_E { rx[e] = 0.0; rz[e] = 0.0; }
 
     // One loop body serves the start point (W = I, one KKT solve) and every Mehrotra iteration (two KKT solves)
     // so that factor(), solve() and matvec() are each inlined exactly once.
@@ -135,7 +141,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             // ---- residuals, costs, stopping test ----------------------------------------------------------
             __syncthreads();
 #pragma unroll
-            FOR_E if (VALID) sm.vec[i] = x[e];
+            FOR_E if (VALID) sm.vec[i] = x[i];
             __syncthreads();
             { PROF_DECL
             ops.matvec();
@@ -144,23 +150,22 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             double t4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             FOR_E {
-                rx[e] = rz[e] = 0.0;
                 if (VALID) {
-                    double r = sm.dvec[i] + qv[e];          // P x + q
-                    t4[0] += x[e] * r;                      // x'(Px+q)
-                    t4[1] += x[e] * qv[e];                  // x'q
-                    r -= z[e];                              // + G'z
-                    rx[e] = r;
+                    double r = sm.dvec[i] + qv[i];          // P x + q
+                    t4[0] += x[i] * r;                      // x'(Px+q)
+                    t4[1] += x[i] * qv[i];                  // x'q
+                    r -= z[i];                              // + G'z
+                    rx[i] = r;
                     t4[2] += r * r;
-                    const double rzz = s[e] - hv[e] - x[e]; // s + Gx - h
-                    rz[e] = rzz;
+                    const double rzz = s[i] - hv[i] - x[i]; // s + Gx - h
+                    rz[i] = rzz;
                     t4[3] += rzz * rzz;
                 }
             }
             red.sum(t4);
             double zr[1] = {0.0};
 #pragma unroll
-            FOR_E if (VALID) zr[0] += z[e] * rz[e];
+            FOR_E if (VALID) zr[0] += z[i] * rz[i];
             red.sum(zr);
             const double f0 = 0.5 * (t4[0] + t4[1]);
             const double resx = sqrt(t4[2]), resz = sqrt(t4[3]);
@@ -177,13 +182,13 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             if (iters == a.opts.maxiters) { status = HIPDRT_QP_MAXITER; break; }
             if (iters == 0) {
 #pragma unroll
-                FOR_E if (VALID) { d[e] = sqrt(s[e] / z[e]); di[e] = 1.0 / d[e]; lm[e] = sqrt(s[e] * z[e]); }
+                FOR_E if (VALID) { d[i] = sqrt(s[i] / z[i]); di[i] = 1.0 / d[i]; lm[i] = sqrt(s[i] * z[i]); }
             }
         }
         // ---- factor S = P + diag(di^2)  (di = 1 at the start point) --------------------------------------
         __syncthreads();
 #pragma unroll
-        FOR_E if (VALID) sm.dvec[i] = di[e] * di[e];
+        FOR_E if (VALID) sm.dvec[i] = di[i] * di[i];
         __syncthreads();
         if (!ops.factor()) {
             status = (start || iters == 0) ? HIPDRT_QP_SINGULAR : HIPDRT_QP_SINGULAR_LATE;
@@ -192,26 +197,21 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 
         const double mu = gap / (double)n;
         double sigma = 0.0, step = 1.0;
-        double dx[EPT], ds[EPT], dz[EPT], ws3[EPT];
-#pragma unroll
-        FOR_E { dx[e] = ds[e] = dz[e] = ws3[e] = 0.0; }
         const int nsolve = start ? 1 : 2;
 #pragma nounroll
         for (int pc = 0; pc < nsolve; ++pc) {
-            double zz[EPT], sv[EPT];
 #pragma unroll
             FOR_E {
-                zz[e] = sv[e] = 0.0;
                 if (VALID) {
                     if (start) {
-                        sm.vec[i] = -qv[e] - hv[e];           // bx + Gs' bz with bx = -q, bz = h
+                        sm.vec[i] = -qv[i] - hv[i];           // bx + Gs' bz with bx = -q, bz = h
                     } else {
-                        double t = (pc == 1) ? (-ws3[e] - lm[e] * lm[e]) : (-(lm[e] * lm[e]));
+                        double t = (pc == 1) ? (-ws3[i] - lm[i] * lm[i]) : (-(lm[i] * lm[i]));
                         t += sigma * mu;
-                        sv[e] = t / lm[e];
-                        const double bz = -rz[e] - d[e] * sv[e];
-                        zz[e] = bz * di[e];
-                        sm.vec[i] = -rx[e] - di[e] * zz[e];
+                        sv[i] = t / lm[i];
+                        const double bz = -rz[i] - d[i] * sv[i];
+                        zz[i] = bz * di[i];
+                        sm.vec[i] = -rx[i] - di[i] * zz[i];
                     }
                 }
             }
@@ -222,11 +222,11 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
                 FOR_E {
                     if (VALID) {
-                        x[e] = sm.vec[i];
-                        z[e] = -x[e] - hv[e];
-                        s[e] = -z[e];
-                        st[0] += s[e] * s[e]; st[1] += z[e] * z[e];
-                        mx[0] = fmax(mx[0], -s[e]); mx[1] = fmax(mx[1], -z[e]);
+                        x[i] = sm.vec[i];
+                        z[i] = -x[i] - hv[i];
+                        s[i] = -z[i];
+                        st[0] += s[i] * s[i]; st[1] += z[i] * z[i];
+                        mx[0] = fmax(mx[0], -s[i]); mx[1] = fmax(mx[1], -z[i]);
                     }
                 }
                 red.sum(st);
@@ -234,15 +234,15 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 const double nrms = sqrt(st[0]), nrmz = sqrt(st[1]);
                 if (mx[0] >= -1e-8 * fmax(nrms, 1.0)) {
 #pragma unroll
-                    FOR_E s[e] += 1.0 + mx[0];
+                    FOR_E if (VALID) s[i] += 1.0 + mx[0];
                 }
                 if (mx[1] >= -1e-8 * fmax(nrmz, 1.0)) {
 #pragma unroll
-                    FOR_E z[e] += 1.0 + mx[1];
+                    FOR_E if (VALID) z[i] += 1.0 + mx[1];
                 }
                 double gp[1] = {0.0};
 #pragma unroll
-                FOR_E if (VALID) gp[0] += s[e] * z[e];
+                FOR_E if (VALID) gp[0] += s[i] * z[i];
                 red.sum(gp);
                 gap = gp[0];
             } else {
@@ -250,15 +250,15 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
                 FOR_E {
                     if (VALID) {
-                        dx[e] = sm.vec[i];
-                        dz[e] = -di[e] * dx[e] - zz[e];
-                        ds[e] = sv[e] - dz[e];
-                        dd[0] += ds[e] * dz[e];
-                        if (pc == 0) ws3[e] = ds[e] * dz[e];
-                        ds[e] /= lm[e];
-                        dz[e] /= lm[e];
-                        mx[0] = fmax(mx[0], -ds[e]);
-                        mx[1] = fmax(mx[1], -dz[e]);
+                        dx[i] = sm.vec[i];
+                        dz[i] = -di[i] * dx[i] - zz[i];
+                        ds[i] = sv[i] - dz[i];
+                        dd[0] += ds[i] * dz[i];
+                        if (pc == 0) ws3[i] = ds[i] * dz[i];
+                        ds[i] /= lm[i];
+                        dz[i] /= lm[i];
+                        mx[0] = fmax(mx[0], -ds[i]);
+                        mx[1] = fmax(mx[1], -dz[i]);
                     }
                 }
                 red.sum(dd);
@@ -279,16 +279,16 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
         FOR_E {
             if (VALID) {
-                x[e] += step * dx[e];
-                const double dss = (1.0 + step * ds[e]) * lm[e];
-                const double dzz = (1.0 + step * dz[e]) * lm[e];
+                x[i] += step * dx[i];
+                const double dss = (1.0 + step * ds[i]) * lm[i];
+                const double dzz = (1.0 + step * dz[i]) * lm[i];
                 const double sqs = sqrt(dss), sqz = sqrt(dzz);
-                d[e] = d[e] * sqs / sqz;
-                di[e] = 1.0 / d[e];
-                lm[e] = sqs * sqz;
-                s[e] = lm[e] * d[e];
-                z[e] = lm[e] * di[e];
-                g2[0] += lm[e] * lm[e];
+                d[i] = d[i] * sqs / sqz;
+                di[i] = 1.0 / d[i];
+                lm[i] = sqs * sqz;
+                s[i] = lm[i] * d[i];
+                z[i] = lm[i] * di[i];
+                g2[0] += lm[i] * lm[i];
             }
         }
         red.sum(g2);
@@ -298,7 +298,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 
     PROF(10);
 #pragma unroll
-    FOR_E if (VALID) a.x[(size_t)b * n + i] = x[e];
+    FOR_E if (VALID) a.x[(size_t)b * n + i] = x[i];
     if (tid == 0) {
 #ifdef HIPDRT_QP_PROFILE
         if (b == 0) atomicAdd(&g_qp_prof[11], (unsigned long long)(iters + 1));
@@ -310,6 +310,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     }
 #undef FOR_E
 #undef VALID
+#undef SV
 }
 
 }  // namespace hipdrt

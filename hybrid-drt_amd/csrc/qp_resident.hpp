@@ -1,8 +1,9 @@
 // Linear-algebra services of the coneqp kernel for n <= 528 unknowns (C1-C4 sizes: n = 93 ... 514), built around
 // memory-level parallelism: one 1024-thread workgroup (16 wavefronts) per problem, one per CU.
 //
-//  * The Cholesky factor L lives in HBM in a TILE-PACKED layout: 16x16 tiles, each one contiguous 2 KB block,
-//    tiles of one tile-row adjacent ([tile_row][k_chunk][16][16]).  An MFMA operand fragment (16 rows x 16 k),
+//  * The Cholesky factor L lives in HBM in a TILE-PACKED layout: 16x16 tiles, each one contiguous 2 KB block
+//    stored as [k-half][row][8 doubles] so that a wavefront's MFMA fragment load covers one contiguous 1 KB,
+//    tiles of one tile-row adjacent ([tile_row][k_chunk][2][16][8]).  An MFMA operand fragment (16 rows x 16 k),
 //    a block-column panel of a tile-row (2 adjacent tiles) and a block-row of finished columns are all
 //    contiguous byte ranges, so every phase reads and writes long coalesced runs (1 KB per wave instruction)
 //    instead of 128-byte row segments 4 KB apart.
@@ -97,9 +98,11 @@ struct OpsResident {
                         }
                 }
                 if (wv < ntile) {
-                    // fragment of lane (i = lane&15, kq = lane>>4): doubles [i][4kq .. 4kq+3] of a 16x16 tile
-                    // = double2 index i*8 + 2kq (+1)
-                    const int fo = li * 8 + 2 * kq;
+                    // Tile-internal layout [k-half h][row i][8 doubles]: lane (i = lane&15, kq = lane>>4) takes the
+                    // double2 at h*64 + i*4 + kq, i.e. k = 8h + 2kq, +1 -- each wave instruction covers one
+                    // contiguous 1 KB (full 128-byte lines; the half-line pattern of a row-major tile halves the
+                    // per-CU load throughput).  A and B use the same k assignment, so the MFMA sums are complete.
+                    const int fo = li * 4 + kq;
                     const double2* pb0 = tile2(tb, 0) + fo;
                     const double2* pb1 = tile2(tb + 1 < nch ? tb + 1 : tb, 0) + fo;
                     const double2* pa[RMAXT];
@@ -112,10 +115,10 @@ struct OpsResident {
                     struct Slab { double2 b0a, b0b, b1a, b1b, aa[RMAXT], ab[RMAXT]; };
                     auto load = [&](Slab& s_, int c) {          // c = k-chunk index (16 columns)
                         const int o = c * (TSZ / 2);
-                        s_.b0a = pb0[o]; s_.b0b = pb0[o + 1];
-                        s_.b1a = pb1[o]; s_.b1b = pb1[o + 1];
+                        s_.b0a = pb0[o]; s_.b0b = pb0[o + 64];
+                        s_.b1a = pb1[o]; s_.b1b = pb1[o + 64];
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = pa[u][o]; s_.ab[u] = pa[u][o + 1]; }
+                        for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = pa[u][o]; s_.ab[u] = pa[u][o + 64]; }
                     };
                     auto mult = [&](const Slab& s_) {
 #pragma unroll
@@ -224,12 +227,12 @@ struct OpsResident {
             __syncthreads();
             PROF(3);
             // ---- (4) write-back: per tile-row 2 adjacent tiles = 4 KB contiguous ---------------------------
-            // e -> (tile t, chunk ch, row i, 16-byte piece pc)
+            // e -> (tile t, chunk ch, half h, row i, 16-byte piece p): consecutive threads write consecutive 16 B
             for (int e = tid; e < ntile * 256; e += RT) {
-                const int pc = e & 7, i = (e >> 3) & 15, ch = (e >> 7) & 1, t = e >> 8;
-                const double* src = U + (size_t)(j0 + t * 16 + i) * PLD + ch * 16 + 2 * pc;
+                const int pc = e & 3, i = (e >> 2) & 15, h = (e >> 6) & 1, ch = (e >> 7) & 1, t = e >> 8;
+                const double* src = U + (size_t)(j0 + t * 16 + i) * PLD + ch * 16 + 8 * h + 2 * pc;
                 double2* dst = reinterpret_cast<double2*>(L) +
-                               (size_t)(((tb + t) * nch + 2 * jb + ch) * (TSZ / 2) + i * 8 + pc);
+                               (size_t)(((tb + t) * nch + 2 * jb + ch) * (TSZ / 2) + h * 64 + i * 4 + pc);
                 *dst = make_double2(src[0], src[1]);
             }
             __syncthreads();
@@ -243,15 +246,15 @@ struct OpsResident {
     // wavefronts 1..15 apply the rank-32 updates.  The update operands (tiles of L in HBM) do not depend on the
     // running solution, so they are fetched BEFORE the diagonal solve of the same block and are in flight while
     // wavefront 0 substitutes.
-    //   tile load map: instruction q of a 2 KB tile covers double2 index q*64 + lane  ->  row i = q*8 + lane/8,
-    //   columns 2*(lane%8), +1.
+    //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane  ->  row i = lane/4,
+    //   columns 8h + 2*(lane%4), +1.
     __device__ __forceinline__ void solve() {
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
         const int nblk = (n + NB - 1) / NB;
         double* vec = sm.vec;
         const double* U = sm.U;
         constexpr int UW = RNW - 1;                 // updater wavefronts
-        const int l8 = lane & 7, g8 = lane >> 3;
+        const int l4 = lane & 3, g4 = lane >> 2;
         PROF_DECL
         // ---- forward: L y = b -----------------------------------------------------------------------------
         for (int jb = 0; jb < nblk; ++jb) {
@@ -275,44 +278,40 @@ struct OpsResident {
             if (wv == 0) {
                 const int r = lane & 31;
                 const double* Ub = U + (size_t)(j0 + r) * PLD;
+                // minimal dependency chain per step: mul, broadcast, fma.  Entries with c >= r are zeroed at load
+                // time, so bb stops changing after step r-1 and y_r = bb * rinv falls out at the end.
                 double lr[NB];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) lr[c] = Ub[c];
+                for (int c = 0; c < NB; ++c) lr[c] = (c < r) ? Ub[c] : 0.0;
                 const bool rv_ = (j0 + r) < n;
                 double bb = rv_ ? vec[j0 + r] : 0.0;
                 const double rinv = rv_ ? Ub[NB] : 0.0;
 #pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    if (c < nv) {
-                        const double yc = bcast_lane(bb * rinv, c);
-                        if (r > c) bb -= lr[c] * yc;
-                        else if (r == c) bb = yc;
-                    }
+                for (int c = 0; c < NB - 1; ++c) {
+                    const double yc = bcast_lane(bb * rinv, c);
+                    bb -= lr[c] * yc;
                 }
-                if (lane < nv) vec[j0 + lane] = bb;
+                if (lane < nv) vec[j0 + lane] = bb * rinv;
             }
             __syncthreads();
             PROF(5);
             if (wv > 0 && tbelow > 0) {
-                // lane holds columns 2*l8, 2*l8+1 of chunk 0 (q = 0,1) and of chunk 1 (q = 2,3)
-                const double y00 = vec[j0 + 2 * l8], y01 = vec[j0 + 2 * l8 + 1];
-                const double y10 = vec[j0 + 16 + 2 * l8], y11 = vec[j0 + 16 + 2 * l8 + 1];
+                // q = 2*chunk + half: lane holds columns 16*chunk + 8*half + 2*l4, +1 of tile row g4
+                double ya[4], yb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ya[q] = vec[j0 + 8 * q + 2 * l4]; yb[q] = vec[j0 + 8 * q + 2 * l4 + 1]; }
 #pragma unroll
                 for (int u = 0; u < FT; ++u) {
                     const int tt = (wv - 1) + u * UW;
                     if (tt < tbelow) {
-                        // rows g8 (q even) and 8 + g8 (q odd) of the tile
-                        double pA = lv[u][0].x * y00 + lv[u][0].y * y01 + lv[u][2].x * y10 + lv[u][2].y * y11;
-                        double pB = lv[u][1].x * y00 + lv[u][1].y * y01 + lv[u][3].x * y10 + lv[u][3].y * y11;
+                        double pv = 0.0;
 #pragma unroll
-                        for (int off = 1; off < 8; off <<= 1) {
-                            pA += __shfl_xor(pA, off, 64);
-                            pB += __shfl_xor(pB, off, 64);
-                        }
-                        if (l8 == 0) {
-                            const int row = (tb + 2 + tt) * 16 + g8;
-                            if (row < n) vec[row] -= pA;
-                            if (row + 8 < n) vec[row + 8] -= pB;
+                        for (int q = 0; q < 4; ++q) pv += lv[u][q].x * ya[q] + lv[u][q].y * yb[q];
+                        pv += __shfl_xor(pv, 1, 64);
+                        pv += __shfl_xor(pv, 2, 64);
+                        if (l4 == 0) {
+                            const int row = (tb + 2 + tt) * 16 + g4;
+                            if (row < n) vec[row] -= pv;
                         }
                     }
                 }
@@ -345,40 +344,40 @@ struct OpsResident {
                 const int c = lane & 31;     // lane = column c of the block: needs L[j0+r][j0+c], r >= c
                 double lc[NB];
 #pragma unroll
-                for (int r = 0; r < NB; ++r) lc[r] = U[(size_t)(j0 + r) * PLD + c];
+                for (int r = 0; r < NB; ++r) lc[r] = (r > c && r < nv) ? U[(size_t)(j0 + r) * PLD + c] : 0.0;
                 const bool cv_ = (j0 + c) < n;
                 double yy = cv_ ? vec[j0 + c] : 0.0;
                 const double rinv = cv_ ? U[(size_t)(j0 + c) * PLD + NB] : 0.0;
 #pragma unroll
-                for (int r = NB - 1; r >= 0; --r) {
-                    if (r < nv) {
-                        const double xr = bcast_lane(yy * rinv, r);
-                        if (c < r) yy -= lc[r] * xr;
-                        else if (c == r) yy = xr;
-                    }
+                for (int r = NB - 1; r > 0; --r) {
+                    const double xr = bcast_lane(yy * rinv, r);    // lanes >= nv carry yy = 0, rinv = 0
+                    yy -= lc[r] * xr;
                 }
-                if (lane < nv) vec[j0 + lane] = yy;
+                if (lane < nv) vec[j0 + lane] = yy * rinv;
             }
             __syncthreads();
             PROF(7);
             if (wv > 0 && nc > 0) {
-                // x of the block: rows g8, 8+g8 of tile tb and of tile tb+1 (zero padding beyond n)
-                const double x0 = vec[j0 + g8], x1 = vec[j0 + 8 + g8];
-                const double x2 = two ? vec[j0 + 16 + g8] : 0.0, x3 = two ? vec[j0 + 24 + g8] : 0.0;
+                // x of the block: row g4 of tile tb and of tile tb+1 (zero padding beyond n)
+                const double x0 = vec[j0 + g4];
+                const double x1 = two ? vec[j0 + 16 + g4] : 0.0;
 #pragma unroll
                 for (int u = 0; u < BC; ++u) {
                     const int c = (wv - 1) + u * UW;
                     if (c < nc) {
-                        double s0 = lb[u][0].x * x0 + lb[u][1].x * x1 + lb[u][2].x * x2 + lb[u][3].x * x3;   // col 2*l8
-                        double s1 = lb[u][0].y * x0 + lb[u][1].y * x1 + lb[u][2].y * x2 + lb[u][3].y * x3;   // col 2*l8+1
+                        // lb[u][0..1] = tile tb halves 0,1 ; lb[u][2..3] = tile tb+1 halves 0,1
+                        double s0 = lb[u][0].x * x0 + lb[u][2].x * x1;     // column 16c + 2*l4
+                        double s1 = lb[u][0].y * x0 + lb[u][2].y * x1;     // column 16c + 2*l4 + 1
+                        double s2 = lb[u][1].x * x0 + lb[u][3].x * x1;     // column 16c + 8 + 2*l4
+                        double s3 = lb[u][1].y * x0 + lb[u][3].y * x1;     // column 16c + 8 + 2*l4 + 1
 #pragma unroll
-                        for (int off = 8; off < 64; off <<= 1) {
-                            s0 += __shfl_xor(s0, off, 64);
-                            s1 += __shfl_xor(s1, off, 64);
+                        for (int off = 4; off < 64; off <<= 1) {
+                            s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64);
+                            s2 += __shfl_xor(s2, off, 64); s3 += __shfl_xor(s3, off, 64);
                         }
-                        if (g8 == 0) {
-                            vec[c * 16 + 2 * l8] -= s0;
-                            vec[c * 16 + 2 * l8 + 1] -= s1;
+                        if (g4 == 0) {
+                            vec[c * 16 + 2 * l4] -= s0;     vec[c * 16 + 2 * l4 + 1] -= s1;
+                            vec[c * 16 + 8 + 2 * l4] -= s2; vec[c * 16 + 8 + 2 * l4 + 1] -= s3;
                         }
                     }
                 }

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(RT) void gemm_phase(const double* __restrict__ Lall
         v4d acc[RMAXT][2];
         for (int u = 0; u < RMAXT; ++u) { acc[u][0] = (v4d){0,0,0,0}; acc[u][1] = (v4d){0,0,0,0}; }
         if (wv < ntile) {
-            const int fo = li * 8 + 2 * kq;
+            const int fo = (VAR == 8) ? lane : li * 8 + 2 * kq;
+            const int o2 = (VAR == 8) ? 64 : 1;     // second half of the fragment
             auto tile2 = [&](int t, int c) { return reinterpret_cast<const double2*>(L) + (size_t)((t * NCH + c) * (TSZ / 2)); };
             const double2* pb0 = tile2(tb, 0) + fo;
             const double2* pb1 = tile2(tb + 1 < NCH ? tb + 1 : tb, 0) + fo;
@@ -38,8 +39,8 @@ __global__ __launch_bounds__(RT) void gemm_phase(const double* __restrict__ Lall
                     s_.b0a = s_.b0b = s_.b1a = s_.b1b = make_double2(1.0 + c, 2.0 + lane);
                     for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = make_double2(3.0, c); s_.ab[u] = make_double2(lane, 4.0); }
                 } else {
-                    s_.b0a = pb0[o]; s_.b0b = pb0[o + 1]; s_.b1a = pb1[o]; s_.b1b = pb1[o + 1];
-                    for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = pa[u][o]; s_.ab[u] = pa[u][o + 1]; }
+                    s_.b0a = pb0[o]; s_.b0b = pb0[o + o2]; s_.b1a = pb1[o]; s_.b1b = pb1[o + o2];
+                    for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = pa[u][o]; s_.ab[u] = pa[u][o + o2]; }
                 }
             };
             auto mult = [&](const Slab& s_) {
@@ -195,6 +196,7 @@ int main() {
         run<2>(L, out, nwg, "V2 loads only (no mfma)");
         run<3>(L, out, nwg, "V3 A loads + mfma (B const)");
         run<4>(L, out, nwg, "V4 B loads + mfma (A const)");
+        run<8>(L, out, nwg, "V8 contiguous 1KB loads");
         run_ldsb<1>(L, out, nwg, "V5 LDS-B, 16 k per barrier");
         run_ldsb<2>(L, out, nwg, "V6 LDS-B, 32 k per barrier");
         run_ldsb<4>(L, out, nwg, "V7 LDS-B, 64 k per barrier");

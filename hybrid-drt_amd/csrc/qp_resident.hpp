@@ -162,69 +162,106 @@ struct OpsResident {
             }
             __syncthreads();
             PROF(1);
-            // ---- (2) diagonal block, in place in U rows j0..j0+31 -------------------------------------------
-            if (wv == 0) {
-                const int r = lane & 31;
-                double* Ub = U + (size_t)j0 * PLD;
-                double a[NB];
+            // ---- (2)+(3) 32-wide panel in two 16-wide halves (halves the sequential diagonal work and the
+            //      substitution work per panel row; the rank-16 coupling between the halves runs on MFMA) -------
+            // half h: wavefront 0 factors the 16x16 diagonal block D_h in place (lane = row, column broadcast via
+            // LDS, rsqrt pivots) -- for h = 0 the lanes 16..31 carry the rows of the lower-left block L21 along;
+            // then every panel row (thread per row) is substituted against D_h.
+            bool failed = false;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                const int c0 = 16 * h;                               // first column of the half
+                const int nvh = nv - c0 < 16 ? nv - c0 : 16;          // valid columns in this half (may be <= 0)
+                if (nvh <= 0) break;
+                if (wv == 0) {
+                    const int r = lane & 31;                          // row j0 + c0 + r  (h = 1: only r < 16 matter)
+                    double* Ub = U + (size_t)(j0 + c0) * PLD + c0;    // D_h origin
+                    double a[16];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) a[c] = Ub[r * PLD + c];
-                bool ok = true;
-                double* cb = sm.colbuf;
+                    for (int c = 0; c < 16; ++c) a[c] = Ub[r * PLD + c];
+                    bool ok = true;
+                    double* cb = sm.colbuf;
 #pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    if (c < nv) {
-                        double* col = cb + (c & 1) * 32;
-                        if (lane < 32) col[r] = a[c];                         // column c before scaling
-                        __builtin_amdgcn_wave_barrier();
-                        double cv[NB];
+                    for (int c = 0; c < 16; ++c) {
+                        if (c < nvh) {
+                            double* col = cb + (c & 1) * 32;
+                            if (lane < 32) col[r] = a[c];
+                            __builtin_amdgcn_wave_barrier();
+                            const double piv = col[c];
+                            if (!(piv > 0.0)) ok = false;
+                            const double rinv = rsqrt(piv);            // 1 / L_cc
+                            const double ljj = piv * rinv;             // L_cc
+                            const double lrc = (r == c) ? ljj : a[c] * rinv;
+                            const double lrs = lrc * rinv;
+                            a[c] = lrc;
+                            if (lane == c) U[(size_t)(j0 + c0 + c) * PLD + NB] = rinv;   // reciprocal pivot -> pad column
 #pragma unroll
-                        for (int k = c; k < NB; ++k) cv[k] = col[k];           // broadcast reads, issued together
-                        const double piv = cv[c];
-                        if (!(piv > 0.0)) ok = false;
-                        const double rinv = rsqrt(piv);                        // 1 / L_cc
-                        const double ljj = piv * rinv;                         // L_cc
-                        const double lrc = (r == c) ? ljj : a[c] * rinv;       // L_rc
-                        const double lrs = lrc * rinv;                         // L_rc / L_cc
-                        a[c] = lrc;
-                        if (lane == c) Ub[c * PLD + NB] = rinv;                // reciprocal pivot -> pad column
-#pragma unroll
-                        for (int k = c + 1; k < NB; ++k) a[k] -= lrs * cv[k];  // a_rk -= L_rc * L_kc
-                    }
-                }
-                if (lane < 32) {
-#pragma unroll
-                    for (int c = 0; c < NB; ++c) Ub[r * PLD + c] = (c <= r) ? a[c] : 0.0;
-                }
-                const unsigned long long bad = __ballot(!ok);
-                if (lane == 0) sm.flag[0] = bad ? 1 : 0;
-            }
-            __syncthreads();
-            if (sm.flag[0]) return false;
-            PROF(2);
-            // ---- (3) panel rows: X L11' = C, thread per row, right-looking ------------------------------------
-            {
-                const int rr = j0 + NB + tid;
-                if (rr < n) {
-                    double v[NB];
-                    double* prow = U + (size_t)rr * PLD;
-                    const double* Ub = U + (size_t)j0 * PLD;
-#pragma unroll
-                    for (int c = 0; c < NB; ++c) v[c] = prow[c];
-#pragma unroll
-                    for (int c = 0; c < NB; ++c) {
-                        if (c < nv) {
-                            const double xc = v[c] * Ub[c * PLD + NB];
-                            v[c] = xc;
-#pragma unroll
-                            for (int k = c + 1; k < NB; ++k) v[k] -= xc * Ub[k * PLD + c];
+                            for (int k = c + 1; k < 16; ++k) a[k] -= lrs * col[k];
                         }
                     }
+                    const int rows_here = (h == 0) ? 32 : 16;
+                    if (lane < rows_here) {
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) prow[c] = v[c];
+                        for (int c = 0; c < 16; ++c) Ub[r * PLD + c] = (c <= r) ? a[c] : 0.0;
+                    } else if (h == 1 && lane < 32) {
+                        // upper-right 16x16 of the diagonal block: zero (never referenced, kept clean)
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) U[(size_t)(j0 + (lane - 16)) * PLD + 16 + c] = 0.0;
+                    }
+                    const unsigned long long bad = __ballot(!ok);
+                    if (lane == 0) sm.flag[0] = bad ? 1 : 0;
+                }
+                __syncthreads();
+                if (sm.flag[0]) { failed = true; break; }
+                if (h == 0) PROF(2);
+                // panel rows below the diagonal block: x = v D_h^-T, right-looking, reciprocal pivots
+                {
+                    const int rr = j0 + NB + tid;
+                    if (rr < n) {
+                        double v[16];
+                        double* prow = U + (size_t)rr * PLD + c0;
+                        const double* Ub = U + (size_t)(j0 + c0) * PLD + c0;
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) v[c] = prow[c];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            if (c < nvh) {
+                                const double xc = v[c] * U[(size_t)(j0 + c0 + c) * PLD + NB];
+                                v[c] = xc;
+#pragma unroll
+                                for (int k = c + 1; k < 16; ++k) v[k] -= xc * Ub[k * PLD + c];
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) prow[c] = v[c];
+                    }
+                }
+                __syncthreads();
+                if (h == 0 && nv > 16) {
+                    // rank-16 coupling on MFMA: C[:, 16:32] -= X[:, 0:16] * L21' for every row >= j0+16
+                    // (tile 0 = the lower half of the diagonal block itself); operands straight from the LDS panel
+                    const int li = lane & 15, kq = lane >> 4;
+                    const int nt3 = (n - (j0 + 16) + 15) >> 4;
+                    const double* Bp = U + (size_t)(j0 + 16 + li) * PLD + 4 * kq;
+                    const double b0 = Bp[0], b1 = Bp[1], b2 = Bp[2], b3 = Bp[3];
+                    for (int t = wv; t < nt3; t += RNW) {
+                        const int row0 = j0 + 16 + 16 * t;
+                        const double* Ap = U + (size_t)(row0 + li) * PLD + 4 * kq;
+                        double* Cp = U + (size_t)(row0 + kq) * PLD + 16 + li;
+                        v4d acc;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) acc[rg] = Cp[(size_t)(4 * rg) * PLD];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[0], b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[1], b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[2], b2, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[3], b3, acc, 0, 0, 0);
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) Cp[(size_t)(4 * rg) * PLD] = acc[rg];
+                    }
+                    __syncthreads();
                 }
             }
-            __syncthreads();
+            if (failed) return false;
             PROF(3);
             // ---- (4) write-back: per tile-row 2 adjacent tiles = 4 KB contiguous ---------------------------
             // e -> (tile t, chunk ch, half h, row i, 16-byte piece p): consecutive threads write consecutive 16 B

@@ -62,17 +62,30 @@ struct OpsResident {
             const int tb = j0 >> 4;                 // first tile-row of the block
             PROF_DECL
             // ---- (1) tiles: acc = -(P + diag) + L[rows,:j0] L[blk,:j0]' -----------------------------------
-            if (j0 == 0) {
-                // first block column: nothing to subtract, the panel is P + diag itself
-                for (int e = tid; e < n * NB; e += RT) {
-                    const int r = e >> 5, c = e & 31;
-                    double v = 0.0;
-                    if (c < n) {
-                        v = (r >= c) ? P[(size_t)r * ldp + c] : P[(size_t)c * ldp + r];
-                        if (r == c) v += sm.dvec[r];
+            // panel <- P + diag with coalesced 16-byte loads (16 lanes per 256-byte row segment, 4 rows = 1 KB per
+            // wave instruction; the accumulator-shaped 8-byte gather used before cost ~45 % of the GEMM phase).
+            // Inside the diagonal block the upper part is taken from the lower triangle (only P's lower triangle is
+            // ever read there).
+            for (int e = tid; e < ntile * 256; e += RT) {
+                const int rr = e >> 4, pc = (e & 15) * 2;
+                const int r = j0 + rr, cc = j0 + pc;
+                double2 v = make_double2(0.0, 0.0);
+                if (r < n) {
+                    if (cc + 1 <= r || rr >= NB) {
+                        if (cc + 1 < n) v = *reinterpret_cast<const double2*>(P + (size_t)r * ldp + cc);
+                        else if (cc < n) v.x = P[(size_t)r * ldp + cc];
+                    } else {
+                        if (cc < n) v.x = (r >= cc) ? P[(size_t)r * ldp + cc] : P[(size_t)cc * ldp + r];
+                        if (cc + 1 < n) v.y = (r >= cc + 1) ? P[(size_t)r * ldp + cc + 1] : P[(size_t)(cc + 1) * ldp + r];
                     }
-                    U[r * PLD + c] = v;
+                    if (r == cc) v.x += sm.dvec[r];
+                    if (r == cc + 1) v.y += sm.dvec[r];
                 }
+                U[r * PLD + pc] = v.x;
+                U[r * PLD + pc + 1] = v.y;
+            }
+            __syncthreads();
+            if (j0 == 0) {
                 PROF(0);
             } else {
                 v4d acc[RMAXT][2];
@@ -83,19 +96,8 @@ struct OpsResident {
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            double v = 0.0;
-                            if (t < ntile) {
-                                const int row = j0 + t * 16 + kq + 4 * rg;
-                                const int col = j0 + ct * 16 + li;
-                                if (row < n && col < n) {
-                                    const int pr_ = row > col ? row : col, pc_ = row > col ? col : row;
-                                    v = -P[(size_t)pr_ * ldp + pc_];
-                                    if (row == col) v -= sm.dvec[row];
-                                }
-                            }
-                            acc[u][ct][rg] = v;
-                        }
+                        for (int rg = 0; rg < 4; ++rg)
+                            acc[u][ct][rg] = (t < ntile) ? -U[(j0 + t * 16 + kq + 4 * rg) * PLD + ct * 16 + li] : 0.0;
                 }
                 if (wv < ntile) {
                     // Tile-internal layout [k-half h][row i][8 doubles]: lane (i = lane&15, kq = lane>>4) takes the

@@ -26,9 +26,9 @@
 
 namespace hipdrt {
 
-static constexpr int RT = 1024;          // threads
+static constexpr int RT = 512;           // threads
 static constexpr int RNW = RT / 64;      // 16 wavefronts
-static constexpr int RMAXT = 2;          // row tiles per wavefront for block columns j >= 1 (<= 31 tiles)
+static constexpr int RMAXT = 32 / RNW;   // row tiles per wavefront for block columns j >= 1 (<= 31 tiles)
 static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
 
@@ -218,8 +218,7 @@ struct OpsResident {
                 if (h == 0) PROF(2);
                 // panel rows below the diagonal block: x = v D_h^-T, right-looking, reciprocal pivots
                 {
-                    const int rr = j0 + NB + tid;
-                    if (rr < n) {
+                    for (int rr = j0 + NB + tid; rr < n; rr += RT) {
                         double v[16];
                         double* prow = U + (size_t)rr * PLD + c0;
                         const double* Ub = U + (size_t)(j0 + c0) * PLD + c0;
@@ -301,7 +300,7 @@ struct OpsResident {
             const int nv = (n - j0) < NB ? (n - j0) : NB;
             const int tb = j0 >> 4;
             const int tbelow = ((n + 15) >> 4) - (tb + 2);     // row tiles below the block
-            constexpr int FT = 3;                               // tiles per updater wavefront (15*3 = 45 >= 31)
+            constexpr int FT = (31 + UW - 1) / UW;              // tiles per updater wavefront
             double2 lv[FT][4];                                  // [tile][chunk*2 + half]
             if (wv > 0 && tbelow > 0) {
 #pragma unroll
@@ -365,7 +364,7 @@ struct OpsResident {
             const int tb = j0 >> 4;
             const int nc = 2 * jb;                              // 16-column chunks left of the block
             const bool two = (tb + 1) * 16 < n;                 // second tile-row of the block holds valid rows
-            constexpr int BC = 3;                               // chunks per updater wavefront (15*3 = 45 >= 32)
+            constexpr int BC = (32 + UW - 1) / UW;              // chunks per updater wavefront
             double2 lb[BC][4];                                  // [chunk][tile*2 + half]
             if (wv > 0) {
 #pragma unroll
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
     for (int i = threadIdx.x; i < NP + 32; i += RT) ops.sm.vec[i] = 0.0;
     __syncthreads();
     IpmSmem is{ops.sm.vec, ops.sm.dvec, ops.sm.red};
-    ipm_solve<RT, 1>(a, b, ops, is);
+    ipm_solve<RT, (RNP_MAX + RT - 1) / RT>(a, b, ops, is);
 }
 
 static size_t resident_lds_bytes(int NP) {

@@ -27,7 +27,7 @@ struct hipdrt_plan {
     // per spectrum
     DevBuf z_re, z_im, rv, w, est_w, x, x_in, q, s, rho, xmx, coef_scale, var_floor;
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
-    DevBuf P, L, Ptmp, qpstate;
+    DevBuf P, L, Ptmp, qpstate, Ppk;
     // history
     int hist_b = -1, hist_cap = 0;
     DevBuf hist_x, hist_w, hist_rho, hist_qp, hist_rows;
@@ -262,7 +262,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     HIPDRT_REQUIRE(B >= 1 && n >= 1 && n <= 2048, "B >= 1, 1 <= n <= 2048");
     HIPDRT_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevBuf dP, dq, dh, dL, dx, dit, dpc, dst, dstate;
+    DevBuf dP, dq, dh, dL, dx, dit, dpc, dst, dstate, dPpk;
     const int ldl = (int)qp_scratch_ld(n);
     // device copy of P with an even leading dimension (16-byte row-pair loads in the kernels), pad column zeroed
     const int ldp = round_up(n, 2);
@@ -284,6 +284,9 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     a.L = dL.d(); a.ldl = ldl; a.l_stride = (long long)qp_scratch_doubles(n);
     a.x = dx.d(); a.iters = dit.i(); a.pcost = dpc.d(); a.status = dst.i();
     a.active = nullptr; a.iters_accum = nullptr;
+    HIPDRT_CHECK(dPpk.alloc(nmat * qp_ppk_doubles(n) * sizeof(double)));
+    launch_pack_p(st, (int)nmat, n, dP.d(), ldp, (long long)n * ldp, dPpk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
+    a.Ppk = dPpk.d(); a.ppk_stride = p_batched ? (long long)qp_ppk_doubles(n) : 0; a.nchp = qp_nchp(n);
     HIPDRT_CHECK(dstate.alloc((size_t)B * qp_state_doubles(n) * sizeof(double)));
     a.state = dstate.d(); a.state_ld = qp_state_ld(n); a.state_stride = (long long)qp_state_doubles(n);
     a.opts = opts ? *opts : default_qp_opts();
@@ -444,6 +447,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
     HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
+    HIPDRT_CHECK(p->Ppk.alloc(cap * qp_ppk_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
 
     // shared matrices on the device
@@ -582,11 +586,12 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     //      every spectrum (weights = 1, s = s_0, rho = rho_0), only q differs -------------------------------
     tm.mark(1);
     for (int k = 0; k < 3; ++k) g.dfac[k] = p->opts.iw_l2_lambda_0 * p->opts.derivative_weights[k];
-    launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d(), g, p->P.d(), p->ldp, 0, nullptr);
+    launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d(), g, p->P.d(), p->ldp, 0, nullptr, p->Ppk.d(), 0, qp_nchp(n));
     launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), nullptr, p->opts.iw_l1_lambda_0, p->q.d(), nullptr);
     LAUNCH_OK();
     tm.mark(2);
     qa.P = p->P.d(); qa.p_stride = 0; qa.active = nullptr;
+    qa.Ppk = p->Ppk.d(); qa.ppk_stride = 0; qa.nchp = qp_nchp(n);
     TRY(launch_qp(st, qa));
     tm.mark(3);
     TRY(launch_init_weights(st, fs, B));
@@ -595,11 +600,13 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     // ---- outer loop (drt1d.py:877-988) ----------------------------------------------------------------------
     for (int k = 0; k < 3; ++k) g.dfac[k] = p->opts.l2_lambda_0 * p->opts.derivative_weights[k];
     qa.p_stride = (long long)n * p->ldp; qa.active = p->active.i();
+    qa.ppk_stride = (long long)qp_ppk_doubles(n);
     int it = 0;
     for (; it < p->opts.max_iter; ++it) {
         tm.mark(1);
         HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
-        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, p->P.d(), p->ldp, (long long)n * p->ldp, p->active.i());
+        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, p->P.d(), p->ldp, (long long)n * p->ldp, p->active.i(),
+                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
         launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i());
         LAUNCH_OK();
         tm.mark(2);

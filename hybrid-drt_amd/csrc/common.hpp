@@ -100,7 +100,13 @@ struct GramL2 {
     int use_rho;
 };
 void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const GramL2& g,
-                    double* P, int ldp, long long p_stride, const int* active);
+                    double* P, int ldp, long long p_stride, const int* active, double* Ppk = nullptr,
+                    long long ppk_stride = 0, int nchp = 0);
+// row-major symmetric P -> accumulator-native lower tiles
+void launch_pack_p(hipStream_t st, int B, int n, const double* P, int ldp, long long p_stride, double* Ppk,
+                   long long ppk_stride, int nchp);
+inline int qp_nchp(int n) { return round_up(n, 32) / 16; }
+inline size_t qp_ppk_doubles(int n) { return (size_t)qp_nchp(n) * qp_nchp(n) * 256; }
 void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,
                  const double* l1, double l1_scalar, double* q, const int* active);
 void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w,
@@ -145,6 +151,9 @@ struct QpArgs {
     const double* P;      // [B or 1][n][ldp]
     long long p_stride;   // 0 if shared
     int ldp;
+    const double* Ppk;    // optional [B or 1][nchp][nchp][256]: P in accumulator-native 16x16 tiles (lower tiles)
+    long long ppk_stride; // 0 if shared
+    int nchp;
     const double* q;      // [B][n]
     const double* h;      // [B or 1][n]
     long long h_stride;

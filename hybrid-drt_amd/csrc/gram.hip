@@ -22,7 +22,7 @@ static constexpr int GLD = 80;       // LDS row stride in doubles (k-rows land 3
 __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* __restrict__ A, int lda,
                                                    const double* __restrict__ w, GramL2 g, double* __restrict__ P,
                                                    int ldp, long long p_stride, const int* __restrict__ active,
-                                                   int ntile) {
+                                                   int ntile, double* __restrict__ Ppk, long long ppk_stride, int nchp) {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     // decode lower-triangular tile index -> (ti >= tj)
@@ -92,34 +92,71 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
 #pragma unroll
         for (int k = 0; k < 3; ++k) fac[k] = g.dfac[k] * (g.use_rho ? g.rho[(size_t)b * 3 + k] : 1.0);
     }
+    double* Pk = Ppk ? Ppk + (size_t)b * ppk_stride : nullptr;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
+            double vals[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + wi + a * 16 + (lane >> 4) + 4 * r;
                 const int j = j0 + wj + c * 16 + (lane & 15);
-                if (i >= n || j >= n) continue;
-                if (diag && j > i) continue;          // upper part of a diagonal tile comes from the mirror
-                double v = acc[a][c][r];
-                if (g.s) {
-                    double l2 = 0.0;
+                double v = 0.0;
+                if (i < n && j < n) {
+                    v = acc[a][c][r];
+                    if (g.s) {
+                        double l2 = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        if (g.dfac[k] > 0.0) {
-                            double mv = g.mk[k][(size_t)i * g.ldm + j];
-                            if (i >= g.ns && j >= g.ns) mv *= fac[k];
-                            l2 += (sqrt(sb[k * n + i]) * mv) * sqrt(sb[k * n + j]);
+                        for (int k = 0; k < 3; ++k) {
+                            if (g.dfac[k] > 0.0) {
+                                double mv = g.mk[k][(size_t)i * g.ldm + j];
+                                if (i >= g.ns && j >= g.ns) mv *= fac[k];
+                                l2 += (sqrt(sb[k * n + i]) * mv) * sqrt(sb[k * n + j]);
+                            }
                         }
+                        v += l2;
+                    } else if (g.l2) {
+                        v += g.l2[(size_t)b * g.l2_stride + (size_t)i * g.ldl2 + j];
                     }
-                    v += l2;
-                } else if (g.l2) {
-                    v += g.l2[(size_t)b * g.l2_stride + (size_t)i * g.ldl2 + j];
+                    if (!(diag && j > i)) {            // upper part of a diagonal tile comes from the mirror
+                        Pb[(size_t)i * ldp + j] = v;
+                        if (i != j) Pb[(size_t)j * ldp + i] = v;
+                    }
                 }
-                Pb[(size_t)i * ldp + j] = v;
-                if (i != j) Pb[(size_t)j * ldp + i] = v;
+                vals[r] = v;
             }
+            // second copy for the Cholesky: the 16x16 tile exactly as an MFMA accumulator holds it
+            // ([reg pair][lane][2]), two 16-byte stores per lane, 2 KB contiguous per tile
+            if (Pk) {
+                const int tr = ((i0 + wi) >> 4) + a, tc = ((j0 + wj) >> 4) + c;
+                if (tr < nchp && tc < nchp && tr >= tc) {
+                    double2* tile = reinterpret_cast<double2*>(Pk + ((size_t)tr * nchp + tc) * 256);
+                    tile[lane] = make_double2(vals[0], vals[1]);
+                    tile[64 + lane] = make_double2(vals[2], vals[3]);
+                }
+            }
+        }
+}
+
+// row-major symmetric P -> accumulator-native lower tiles; one wavefront per tile, grid (tiles, B)
+__global__ __launch_bounds__(64) void pack_p_kernel(int n, const double* __restrict__ P, int ldp, long long p_stride,
+                                                    double* __restrict__ Ppk, long long ppk_stride, int nchp) {
+    int t = blockIdx.x, tr = 0;
+    while (t >= tr + 1) { t -= tr + 1; ++tr; }
+    const int tc = t, b = blockIdx.y, lane = threadIdx.x;
+    const double* Pb = P + (size_t)b * p_stride;
+    double vals[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = tr * 16 + (lane >> 4) + 4 * r, j = tc * 16 + (lane & 15);
+        double v = 0.0;
+        if (i < n && j < n) v = (i >= j) ? Pb[(size_t)i * ldp + j] : Pb[(size_t)j * ldp + i];   // lower triangle only
+        vals[r] = v;
+    }
+    double2* tile = reinterpret_cast<double2*>(Ppk + (size_t)b * ppk_stride + ((size_t)tr * nchp + tc) * 256);
+    tile[lane] = make_double2(vals[0], vals[1]);
+    tile[64 + lane] = make_double2(vals[2], vals[3]);
 }
 
 // q_b[i] = -sum_k (w_k A_ki)(w_k y_k) + l1_i ; grid (ceil(n/256), B)
@@ -147,12 +184,20 @@ __global__ __launch_bounds__(256) void qvec_kernel(int m, int n, const double* _
     if (i < n) q[(size_t)b * n + i] = -acc + (l1 ? l1[i] : l1_scalar);
 }
 
+void launch_pack_p(hipStream_t st, int B, int n, const double* P, int ldp, long long p_stride, double* Ppk,
+                   long long ppk_stride, int nchp) {
+    const int nt = (n + 15) / 16;
+    hipLaunchKernelGGL(pack_p_kernel, dim3(nt * (nt + 1) / 2, B), dim3(64), 0, st, n, P, ldp, p_stride, Ppk, ppk_stride,
+                       nchp);
+}
+
 void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const GramL2& g,
-                    double* P, int ldp, long long p_stride, const int* active) {
+                    double* P, int ldp, long long p_stride, const int* active, double* Ppk, long long ppk_stride,
+                    int nchp) {
     const int nt = (n + GT - 1) / GT;
     const int ntile = nt * (nt + 1) / 2;
     hipLaunchKernelGGL(gram_kernel, dim3(ntile, B), dim3(256), 0, st, m, n, A, lda, w, g, P, ldp, p_stride, active,
-                       ntile);
+                       ntile, Ppk, ppk_stride, nchp);
 }
 
 void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,

@@ -43,6 +43,7 @@ struct ResSmem {
 
 struct OpsResident {
     const double* P; int ldp; double* L; int nch; int n; ResSmem sm;   // nch = tiles per tile-row (NP/16)
+    const double* Ppk; int nchp;                                       // optional accumulator-native copy of P
 
     // tile (t, c) starts at ((t*nch + c) * TSZ) doubles; returned in double2 units
     __device__ __forceinline__ const double2* tile2(int t, int c) const {
@@ -66,6 +67,8 @@ struct OpsResident {
             // wave instruction; the accumulator-shaped 8-byte gather used before cost ~45 % of the GEMM phase).
             // Inside the diagonal block the upper part is taken from the lower triangle (only P's lower triangle is
             // ever read there).
+            const bool packed = (Ppk != nullptr) && j0 > 0;
+            if (!packed)
             for (int e = tid; e < ntile * 256; e += RT) {
                 const int rr = e >> 4, pc = (e & 15) * 2;
                 const int r = j0 + rr, cc = j0 + pc;
@@ -84,20 +87,45 @@ struct OpsResident {
                 U[r * PLD + pc] = v.x;
                 U[r * PLD + pc + 1] = v.y;
             }
-            __syncthreads();
+            if (!packed) __syncthreads();
             if (j0 == 0) {
                 PROF(0);
             } else {
                 v4d acc[RMAXT][2];
                 const int li = lane & 15, kq = lane >> 4;
+                if (packed) {
+                    // accumulators straight from the accumulator-native copy of P the Gram kernel wrote: two
+                    // contiguous 1 KB loads per 16x16 tile, no LDS hop, no extra barrier
 #pragma unroll
-                for (int u = 0; u < RMAXT; ++u) {
-                    const int t = wv + u * RNW;
+                    for (int u = 0; u < RMAXT; ++u) {
+                        const int t = wv + u * RNW;
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
+                        for (int ct = 0; ct < 2; ++ct) {
+                            v4d a_ = (v4d){0, 0, 0, 0};
+                            const int T = tb + t, Cc = 2 * jb + ct;
+                            if (t < ntile && T >= Cc) {
+                                const double2* tile = reinterpret_cast<const double2*>(Ppk + ((size_t)T * nchp + Cc) * 256);
+                                const double2 d0 = tile[lane], d1 = tile[64 + lane];
+                                a_ = (v4d){-d0.x, -d0.y, -d1.x, -d1.y};
+                                if (T == Cc) {
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg)
-                            acc[u][ct][rg] = (t < ntile) ? -U[(j0 + t * 16 + kq + 4 * rg) * PLD + ct * 16 + li] : 0.0;
+                                    for (int rg = 0; rg < 4; ++rg)
+                                        if (kq + 4 * rg == li) a_[rg] -= sm.dvec[T * 16 + li];
+                                }
+                            }
+                            acc[u][ct] = a_;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RMAXT; ++u) {
+                        const int t = wv + u * RNW;
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg)
+                                acc[u][ct][rg] = (t < ntile) ? -U[(j0 + t * 16 + kq + 4 * rg) * PLD + ct * 16 + li] : 0.0;
+                    }
                 }
                 if (wv < ntile) {
                     // Tile-internal layout [k-half h][row i][8 doubles]: lane (i = lane&15, kq = lane>>4) takes the
@@ -470,6 +498,7 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
     OpsResident ops;
     ops.P = a.P + (size_t)b * a.p_stride; ops.ldp = a.ldp;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
+    ops.Ppk = a.Ppk ? a.Ppk + (size_t)b * a.ppk_stride : nullptr; ops.nchp = a.nchp;
     ops.sm.U = smem;
     ops.sm.vec = ops.sm.U + (size_t)NP * PLD;
     ops.sm.dvec = ops.sm.vec + NP + 32;

@@ -45,8 +45,20 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[a][c] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    // staging map: thread -> (k = tid/16, 4 consecutive columns)
+    // staging map: thread -> (k = tid/16, 4 consecutive columns), fetched as two 16-byte loads when the
+    // leading dimension and n are even (always true for the plan's matrices)
     const int sk = tid >> 4, sc = (tid & 15) * 4;
+    const bool vec2 = ((lda | n) & 1) == 0;
+    // sqrt(s_k) of the tile's rows / columns once per workgroup (the L2 epilogue needs them per element)
+    __shared__ double sqI[3][GT], sqJ[3][GT];
+    if (g.s) {
+        const double* sb_ = g.s + (size_t)b * 3 * n;
+        for (int e = tid; e < 3 * GT; e += 256) {
+            const int k = e / GT, c = e % GT;
+            sqI[k][c] = (i0 + c < n) ? sqrt(sb_[k * n + i0 + c]) : 0.0;
+            sqJ[k][c] = (j0 + c < n) ? sqrt(sb_[k * n + j0 + c]) : 0.0;
+        }
+    }
     for (int k0 = 0; k0 < m; k0 += GK) {
         const int k = k0 + sk;
         double wk = 0.0;
@@ -54,18 +66,28 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
         double vi[4] = {0, 0, 0, 0}, vj[4] = {0, 0, 0, 0};
         if (k < m) {
             const double* row = A + (size_t)k * lda;
+            if (vec2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ci = i0 + sc + e, cj = j0 + sc + e;
-                if (ci < n) vi[e] = wk * row[ci];
-                if (!diag && cj < n) vj[e] = wk * row[cj];
+                for (int e = 0; e < 4; e += 2) {
+                    const int ci = i0 + sc + e, cj = j0 + sc + e;
+                    if (ci < n) { const double2 t = *reinterpret_cast<const double2*>(row + ci); vi[e] = wk * t.x; vi[e + 1] = wk * t.y; }
+                    if (!diag && cj < n) { const double2 t = *reinterpret_cast<const double2*>(row + cj); vj[e] = wk * t.x; vj[e + 1] = wk * t.y; }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = i0 + sc + e, cj = j0 + sc + e;
+                    if (ci < n) vi[e] = wk * row[ci];
+                    if (!diag && cj < n) vj[e] = wk * row[cj];
+                }
             }
         }
         __syncthreads();   // previous slab fully consumed
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sI[sk * GLD + sc + e] = vi[e];
-            if (!diag) sJ[sk * GLD + sc + e] = vj[e];
+        *reinterpret_cast<double2*>(&sI[sk * GLD + sc]) = make_double2(vi[0], vi[1]);
+        *reinterpret_cast<double2*>(&sI[sk * GLD + sc + 2]) = make_double2(vi[2], vi[3]);
+        if (!diag) {
+            *reinterpret_cast<double2*>(&sJ[sk * GLD + sc]) = make_double2(vj[0], vj[1]);
+            *reinterpret_cast<double2*>(&sJ[sk * GLD + sc + 2]) = make_double2(vj[2], vj[3]);
         }
         __syncthreads();
         const double* sj = diag ? sI : sJ;
@@ -86,7 +108,6 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
     // epilogue: + L2, store lower tile and its mirror.  C/D map of v_mfma_f64_16x16x4: col = lane&15,
     // row = (lane>>4) + 4*reg.
     double* Pb = P + (size_t)b * p_stride;
-    const double* sb = g.s ? g.s + (size_t)b * 3 * n : nullptr;
     double fac[3] = {0, 0, 0};
     if (g.s) {
 #pragma unroll
@@ -112,7 +133,7 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
                             if (g.dfac[k] > 0.0) {
                                 double mv = g.mk[k][(size_t)i * g.ldm + j];
                                 if (i >= g.ns && j >= g.ns) mv *= fac[k];
-                                l2 += (sqrt(sb[k * n + i]) * mv) * sqrt(sb[k * n + j]);
+                                l2 += (sqI[k][i - i0] * mv) * sqJ[k][j - j0];
                             }
                         }
                         v += l2;

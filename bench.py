@@ -63,9 +63,12 @@ def cpu_baseline(freq, tau, z, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="spectra per GPU per step")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="batches kept in flight per GPU (each on its own plan + HIP stream); steps are dealt "
+                         "round-robin to them, so the low-occupancy tail of one step overlaps the next step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix-build", action="store_true")
     args = ap.parse_args()
@@ -88,32 +91,64 @@ def main():
     B = args.batch
     z = synth.zarc2_batch(freq, B, first_seed=rank * B)
 
-    drt = DRT(fixed_basis_tau=tau, device=local)
-    plan = drt.stage_batch(freq, z)                       # lookups + matrices built, spectra resident in HBM
+    import threading
+    from hipdrt import _ffi
+    nfl = max(1, min(args.inflight, max(args.steps, 1)))
+    # one DRT + plan + HIP stream per in-flight batch; all hold the same resident inputs (a step = one full fit
+    # of `B` spectra; which plan runs it does not change the work)
+    drts = [DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local)) for _ in range(nfl)]
+    plans = [d.stage_batch(freq, z) for d in drts]         # lookups + matrices built, spectra resident in HBM
+    drt, plan = drts[0], plans[0]
     if world > 1:                                         # rank 0's tables -> everyone (one RCCL broadcast)
         zr, zi = hd.broadcast_arrays([plan.get("lut_z_re"), plan.get("lut_z_im")], src=0)
-        plan.set_lookup(zr, zi)
+        for p_ in plans:
+            p_.set_lookup(zr, zi)
 
-    for _ in range(args.warmup):
-        drt.fit_staged()
+    for d in drts:
+        for _ in range(args.warmup):
+            d.fit_staged()
 
-    qp_ms = qp_launch = 0.0
-    phase = {"gram": 0.0, "qp": 0.0, "hyper": 0.0}
-    hd.barrier()
-    torch.cuda.synchronize()
-    plan.ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        drt.fit_staged()                                  # returns after the ctx stream has drained
-        tms, launches = plan.timings()
-        qp_ms += tms["qp"]
-        qp_launch += launches["qp"]
-        for k in phase:
-            phase[k] += tms[k]
-    plan.ctx.synchronize()
-    torch.cuda.synchronize()
-    hd.barrier()
-    elapsed = hd.max_over_ranks(time.perf_counter() - t0)
+    stats = [dict(qp_ms=0.0, qp_launch=0, phase={"gram": 0.0, "qp": 0.0, "hyper": 0.0}) for _ in range(nfl)]
+
+    def worker(i, nsteps):
+        for _ in range(nsteps):
+            drts[i].fit_staged()                          # returns after the plan's stream has drained
+            tms, launches = plans[i].timings()
+            stats[i]["qp_ms"] += tms["qp"]
+            stats[i]["qp_launch"] += launches["qp"]
+            for k in stats[i]["phase"]:
+                stats[i]["phase"][k] += tms[k]
+
+    def timed(nfl_used):
+        share = [args.steps // nfl_used + (1 if i < args.steps % nfl_used else 0) for i in range(nfl_used)]
+        hd.barrier()
+        torch.cuda.synchronize()
+        for p_ in plans:
+            p_.ctx.synchronize()
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=worker, args=(i, share[i])) for i in range(nfl_used)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for p_ in plans:
+            p_.ctx.synchronize()
+        torch.cuda.synchronize()
+        hd.barrier()
+        return hd.max_over_ranks(time.perf_counter() - t0)
+
+    elapsed = timed(nfl)
+    qp_ms = sum(s_["qp_ms"] for s_ in stats)
+    qp_launch = sum(s_["qp_launch"] for s_ in stats)
+    phase = {k: sum(s_["phase"][k] for s_ in stats) for k in ("gram", "qp", "hyper")}
+    # the same K steps strictly one after the other (one batch in flight), for reference
+    single_elapsed = None
+    if nfl > 1:
+        for s_ in stats:
+            s_.update(qp_ms=0.0, qp_launch=0, phase={"gram": 0.0, "qp": 0.0, "hyper": 0.0})
+        single_elapsed = timed(1)
+        qp_ms, qp_launch = stats[0]["qp_ms"], stats[0]["qp_launch"]      # roofline from the un-overlapped launches
+        phase = dict(stats[0]["phase"])
 
     res = drt.collect_staged()
     n = plan.n
@@ -144,6 +179,7 @@ def main():
                                    f"(DRT.fit_eis defaults, interp lookups)",
                        "batch_per_gpu": B, "nf": 256, "ntau": 512, "n_unknowns": n,
                        "sharding": f"{world} rank(s) x {B} independent spectra, no data-path collective",
+                       "batches_in_flight_per_gpu": nfl,
                        "converged_fraction": float((res["status"] == 0).mean()),
                        "mean_outer_iterations": float(res["outer_iters"].mean()),
                        "mean_ipm_iterations_per_fit": float(res["qp_iters_total"].mean())},
@@ -153,6 +189,9 @@ def main():
                          "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches_per_step": launches_step},
             "phase_ms_per_step": {k: v / args.steps for k, v in phase.items()},
+            "single_stream": None if single_elapsed is None else {
+                "value": world * B * args.steps / single_elapsed, "ms_per_step": single_elapsed / args.steps * 1e3,
+                "note": "same K steps with one batch in flight; roofline / phase timings are taken from this run"},
         }
         if not args.no_matrix_build:
             # secondary roofline (north_star): batched Z'/Z'' build with per-spectrum frequency grids

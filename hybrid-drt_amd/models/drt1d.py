@@ -24,7 +24,7 @@ class DRT:
     def __init__(self, fixed_basis_tau=None, tau_supergrid=None, tau_basis_type='gaussian', tau_epsilon=None,
                  basis_tau_ppd=10, extend_basis_decades=1, interpolate_integrals=True, fit_dop=False,
                  fit_inductance=True, fit_ohmic=True, fit_capacitance=False, frequency_precision=10,
-                 print_diagnostics=False, warn=True, device=0):
+                 print_diagnostics=False, warn=True, device=0, context=None):
         """DRTBase.__init__ (hybdrt/models/drtbase.py:21-159): epsilon rule and the lookup tables."""
         if tau_basis_type != 'gaussian':
             raise NotImplementedError("only the default gaussian basis is on the hot path")
@@ -41,6 +41,8 @@ class DRT:
         self.frequency_precision = frequency_precision
         self.print_diagnostics, self.warn = print_diagnostics, warn
         self.device = device
+        self._context = context          # optional private hipdrt context (own HIP stream): lets several
+                                         # DRT instances keep batches in flight concurrently on one GPU
         if self.tau_epsilon is None:
             if self.fixed_basis_tau is not None:
                 self.tau_epsilon = 1 / np.mean(np.diff(np.log(self.fixed_basis_tau)))
@@ -100,7 +102,8 @@ class DRT:
         mode = _ffi.MODE_INTERP if self.integrate_method == 'interp' else _ffi.MODE_TRAPZ
         tpl_a = mat1d.impedance_matrix_is_toeplitz(frequencies, basis_tau, self.frequency_precision)
         tpl_m = is_uniform(np.log(basis_tau))
-        self._plan = _ffi.Plan(_ffi.get_context(self.device), frequencies, basis_tau, self.tau_epsilon,
+        ctx = self._context if self._context is not None else _ffi.get_context(self.device)
+        self._plan = _ffi.Plan(ctx, frequencies, basis_tau, self.tau_epsilon,
                                wt_re=self._wt_re, wt_im=self._wt_im, mode=mode, toeplitz_a=tpl_a, toeplitz_m=tpl_m,
                                opts=opts, capacity=capacity)
         self._plan_key = key

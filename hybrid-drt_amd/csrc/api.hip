@@ -37,7 +37,7 @@ struct hipdrt_plan {
 
     FitState state() const {
         FitState st{};
-        st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm;
+        st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm; st.toeplitz_m = toeplitz_m;
         st.opts = opts;
         st.rm = rm.d(); st.vmm = vmm.d();
         for (int k = 0; k < 3; ++k) st.mk[k] = mk[k].d();

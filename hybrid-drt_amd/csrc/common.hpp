@@ -116,6 +116,7 @@ void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, 
 // hyper.hip: device-resident state of a batched fit (passed by value to the kernels)
 struct FitState {
     int nf, m, n, ns, ldrm, ldm;
+    int toeplitz_m;        // penalty blocks are symmetric Toeplitz (uniform ln-tau grid): first column suffices
     hipdrt_fit_opts opts;
     // shared (plan) matrices
     const double* rm;      // [m][ldrm]  stacked [Re; Im] response matrix incl. special columns

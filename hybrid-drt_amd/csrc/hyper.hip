@@ -119,6 +119,18 @@ __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld
     }
 }
 
+// same for a symmetric Toeplitz matrix given by its first column c (LDS): y[i] = sum_j c[|i-j|] v[j]
+__device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, int nd, const double* __restrict__ v,
+                                                double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = wv; i < nd; i += HNW) {
+        double s = 0.0;
+        for (int j = lane; j < nd; j += 64) { const int dd = i > j ? i - j : j - i; s += c[dd] * v[j]; }
+        s = hw_sum(s);
+        if (lane == 0) out[i] = s;
+    }
+}
+
 // estimate_weights for spectrum b: xs = LDS x[n]; tmp = LDS [m]; result written to w_out[m] (global)
 __device__ void estimate_weights_dev(const FitState& st, int b, const double* xs, double* tmp, double* tmp2,
                                      const double* est_w, double* w_out) {
@@ -182,6 +194,14 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
     double* tmp = xh + nd;        // [max(m, nd)]
     const int tl = m > nd ? m : nd;
     double* tmp2 = tmp + tl;      // [max(m, nd)]
+    double* ctp = tmp2 + tl;      // [3][nd] first columns of the Toeplitz penalty blocks (uniform ln-tau grids)
+    const bool tpl = st.toeplitz_m != 0;
+    if (tpl) {
+        for (int e = tid; e < 3 * nd; e += HT) {
+            const int k = e / nd, dd = e % nd;
+            ctp[e] = st.mk[k][(size_t)ns * st.ldm + ns + dd];
+        }
+    }
 
     if (st.qp_status[b] < 0) {    // QP broke down at its start point: cvxopt raises, DRTMD flags the observation
         if (tid == 0) { st.active[b] = 0; st.fit_status[b] = -1; st.outer_iters[b] = it + 1; }
@@ -216,8 +236,10 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             const double xi = xd[i], xhi = xh[i];
             double sacc = 0.0, mxx = 0.0, dg = 0.0;
             for (int j = lane; j < nd; j += 64) {
-                double g = (xi * row[j]) * xd[j];
-                if (k == 0) g += ((xhi * row1[j]) * xh[j]) / sig2;
+                const int dd = i > j ? i - j : j - i;
+                const double mij = tpl ? ctp[k * nd + dd] : row[j];
+                double g = (xi * mij) * xd[j];
+                if (k == 0) g += ((xhi * (tpl ? ctp[nd + dd] : row1[j])) * xh[j]) / sig2;
                 if (j == i) dg = g + beta;
                 else {
                     const double gu = g * sq[j];
@@ -249,7 +271,8 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             tmp[i] = sqrt(sh) * xd[i];       // v = S^1/2 x for solve_rho
         }
         __syncthreads();
-        rows_matvec(Mk, st.ldm, nd, nd, tmp, tmp2);
+        if (tpl) toeplitz_matvec(ctp + k * nd, nd, tmp, tmp2);
+        else rows_matvec(Mk, st.ldm, nd, nd, tmp, tmp2);
         __syncthreads();
         double part = 0.0;
         for (int i = tid; i < nd; i += HT) part += tmp[i] * tmp2[i];
@@ -265,7 +288,8 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
     if (it == 0) {   // xmx_norms frozen after the first iteration (drt1d.py:946-951)
         for (int k = 0; k < 3; ++k) {
             const double* Mk = st.mk[k] + (size_t)ns * st.ldm + ns;
-            rows_matvec(Mk, st.ldm, nd, nd, xd, tmp2);
+            if (tpl) toeplitz_matvec(ctp + k * nd, nd, xd, tmp2);
+            else rows_matvec(Mk, st.ldm, nd, nd, xd, tmp2);
             __syncthreads();
             double part = 0.0;
             for (int i = tid; i < nd; i += HT) part += xd[i] * tmp2[i];
@@ -353,7 +377,7 @@ __global__ void make_h_kernel(double* h, int n, int ns, int nonneg) {
 size_t hyper_lds_bytes(int n, int m, int ns) {
     const int nd = n - ns;
     const int tl = m > nd ? m : nd;
-    return ((size_t)n + 4 * (size_t)nd + 2 * (size_t)tl) * sizeof(double);
+    return ((size_t)n + 4 * (size_t)nd + 2 * (size_t)tl + 3 * (size_t)nd) * sizeof(double);
 }
 
 int launch_prep(hipStream_t s, const FitState& st, int B) {

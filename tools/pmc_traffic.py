@@ -1,0 +1,53 @@
+"""Fold two rocprofv3 counter passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate runs, as
+MI355X_MICROARCH.md's HBM section prescribes) into profiles/qp_traffic.json: HBM bytes per launch of the dominant
+kernel.  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts half of the bytes moved by 16-byte-per-lane
+streaming reads (the guide's correction), and every global load in the QP kernel is 16 B/lane, so fetch is doubled.
+
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [kernel substring]
+"""
+import csv
+import json
+import os
+import sys
+
+
+def fold(path, counter, kernel):
+    total, launches = 0.0, 0
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                total += float(row["Counter_Value"])
+                launches += 1
+    return total, launches
+
+
+def main():
+    fetch_csv, write_csv = sys.argv[1], sys.argv[2]
+    kernel = sys.argv[3] if len(sys.argv) > 3 else "qp_kernel_resident"
+    fetch_kb, nf = fold(fetch_csv, "FETCH_SIZE", kernel)
+    write_kb, nw = fold(write_csv, "WRITE_SIZE", kernel)
+    if nf == 0 or nw == 0:
+        raise SystemExit("kernel %r not found in the counter files" % kernel)
+    fetch_raw = fetch_kb * 1024.0 / nf
+    write_b = write_kb * 1024.0 / nw
+    out = {
+        "kernel": kernel,
+        "launches": nf,
+        "fetch_size_kb_sum": fetch_kb,
+        "write_size_kb_sum": write_kb,
+        "fetch_bytes_per_launch_raw": fetch_raw,
+        "fetch_bytes_per_launch_x2": 2.0 * fetch_raw,
+        "write_bytes_per_launch": write_b,
+        "hbm_bytes_per_launch": 2.0 * fetch_raw + write_b,
+        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 "
+                "--warmup 0 --inflight 1 --no-cpu-baseline` (1024 spectra per launch); FETCH_SIZE doubled per "
+                "MI355X_MICROARCH.md (gfx950 reports half of 16-B/lane streaming reads; the kernel's loads are all "
+                "16 B/lane); WRITE_SIZE taken as is; KB -> bytes x1024.",
+    }
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "qp_traffic.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -98,15 +98,17 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
             double a1 = sI[kr * GLD + wi + 16 + (lane & 15)];
             double b0 = sj[kr * GLD + wj + (lane & 15)];
             double b1 = sj[kr * GLD + wj + 16 + (lane & 15)];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            // operands swapped: the accumulators hold the TRANSPOSED 16x16 sub-tiles (lane&15 = row, (lane>>4)+4*reg
+            // = column), which is the register image the Cholesky kernel wants for its packed copy
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
         }
     }
 
-    // epilogue: + L2, store lower tile and its mirror.  C/D map of v_mfma_f64_16x16x4: col = lane&15,
-    // row = (lane>>4) + 4*reg.
+    // epilogue: + L2, store lower tile and its mirror.  With the swapped operands the accumulator of lane l, register
+    // r is element (row = l&15, column = (l>>4) + 4r) of the sub-tile.
     double* Pb = P + (size_t)b * p_stride;
     double fac[3] = {0, 0, 0};
     if (g.s) {
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
             double vals[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = i0 + wi + a * 16 + (lane >> 4) + 4 * r;
-                const int j = j0 + wj + c * 16 + (lane & 15);
+                const int i = i0 + wi + a * 16 + (lane & 15);
+                const int j = j0 + wj + c * 16 + (lane >> 4) + 4 * r;
                 double v = 0.0;
                 if (i < n && j < n) {
                     v = acc[a][c][r];
@@ -147,20 +149,21 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
                 }
                 vals[r] = v;
             }
-            // second copy for the Cholesky: the 16x16 tile exactly as an MFMA accumulator holds it
-            // ([reg pair][lane][2]), two 16-byte stores per lane, 2 KB contiguous per tile
+            // second copy for the Cholesky in the factor's tile layout (qp_resident.hpp): double2 h*64 + i*4 + q holds
+            // columns q + 8h, q + 8h + 4 of row i -- two 16-byte stores per lane, 2 KB contiguous per tile
             if (Pk) {
                 const int tr = ((i0 + wi) >> 4) + a, tc = ((j0 + wj) >> 4) + c;
                 if (tr < nchp && tc < nchp && tr >= tc) {
                     double2* tile = reinterpret_cast<double2*>(Pk + ((size_t)tr * nchp + tc) * 256);
-                    tile[lane] = make_double2(vals[0], vals[1]);
-                    tile[64 + lane] = make_double2(vals[2], vals[3]);
+                    const int fo = (lane & 15) * 4 + (lane >> 4);
+                    tile[fo] = make_double2(vals[0], vals[1]);
+                    tile[64 + fo] = make_double2(vals[2], vals[3]);
                 }
             }
         }
 }
 
-// row-major symmetric P -> accumulator-native lower tiles; one wavefront per tile, grid (tiles, B)
+// row-major symmetric P -> lower tiles in the factor's tile layout; one wavefront per tile, grid (tiles, B)
 __global__ __launch_bounds__(64) void pack_p_kernel(int n, const double* __restrict__ P, int ldp, long long p_stride,
                                                     double* __restrict__ Ppk, long long ppk_stride, int nchp) {
     int t = blockIdx.x, tr = 0;
@@ -170,14 +173,15 @@ __global__ __launch_bounds__(64) void pack_p_kernel(int n, const double* __restr
     double vals[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int i = tr * 16 + (lane >> 4) + 4 * r, j = tc * 16 + (lane & 15);
+        const int i = tr * 16 + (lane & 15), j = tc * 16 + (lane >> 4) + 4 * r;
         double v = 0.0;
         if (i < n && j < n) v = (i >= j) ? Pb[(size_t)i * ldp + j] : Pb[(size_t)j * ldp + i];   // lower triangle only
         vals[r] = v;
     }
     double2* tile = reinterpret_cast<double2*>(Ppk + (size_t)b * ppk_stride + ((size_t)tr * nchp + tc) * 256);
-    tile[lane] = make_double2(vals[0], vals[1]);
-    tile[64 + lane] = make_double2(vals[2], vals[3]);
+    const int fo = (lane & 15) * 4 + (lane >> 4);
+    tile[fo] = make_double2(vals[0], vals[1]);
+    tile[64 + fo] = make_double2(vals[2], vals[3]);
 }
 
 // q_b[i] = -sum_k (w_k A_ki)(w_k y_k) + l1_i ; grid (ceil(n/256), B)

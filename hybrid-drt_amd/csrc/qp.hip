@@ -383,6 +383,7 @@ static int launch_qp_ept(hipStream_t st, const QpArgs& a, int PR, size_t lds) {
 
 static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
     const int NP = round_up(a.n, 32);
+    if (!a.Ppk) { set_error("qp resident: packed copy of P missing"); return HIPDRT_E_INVALID; }
     const size_t lds = resident_lds_bytes(NP);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_resident),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -22,6 +22,13 @@ __device__ unsigned long long g_qp_prof[16];
 static constexpr int NB = 32;     // Cholesky block
 static constexpr int PLD = 33;    // LDS panel row stride (doubles): odd => conflict-free row-per-lane access
 
+// the value unchanged, but opaque to the optimiser: address arithmetic derived from it is redone where it is used
+// instead of being hoisted to the top of the kernel and kept (or spilled) across every phase
+__device__ __forceinline__ unsigned opaque_u32(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -102,7 +109,9 @@ struct IpmSmem {
 template <int THREADS, int EPT, class Ops>
 __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, const IpmSmem& sm) {
     constexpr int NW = THREADS / 64;
-    const int n = a.n, tid = threadIdx.x;
+    const int n = a.n;
+    const unsigned tid = threadIdx.x;      // unsigned indices: SGPR base + 32-bit VGPR offset addressing, no per-vector
+                                           // 64-bit address registers kept alive across the whole kernel
     const double* qg = a.q + (size_t)b * n;
     const double* hg = a.h + (size_t)b * a.h_stride;
     Reducer<NW> red(sm.red);
@@ -117,8 +126,8 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     double* const di = SV(4); double* const lm = SV(5); double* const qv = SV(6); double* const hv = SV(7);
     double* const rx = SV(8); double* const rz = SV(9); double* const dx = SV(10); double* const ds = SV(11);
     double* const dz = SV(12); double* const ws3 = SV(13); double* const zz = SV(14); double* const sv = SV(15);
-#define FOR_E for (int e_ = 0, i = tid; e_ < EPT; ++e_, i += THREADS)
-#define VALID (i < n)
+#define FOR_E for (unsigned e_ = 0, i = opaque_u32(tid); e_ < (unsigned)EPT; ++e_, i += THREADS)
+#define VALID (i < (unsigned)n)
 #pragma unroll
     FOR_E if (VALID) { qv[i] = qg[i]; hv[i] = hg[i]; x[i] = z[i] = 0.0; s[i] = lm[i] = 1.0; d[i] = di[i] = 1.0; }
 

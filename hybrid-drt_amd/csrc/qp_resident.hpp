@@ -1,322 +1,352 @@
-// Linear-algebra services of the coneqp kernel for n <= 528 unknowns (C1-C4 sizes: n = 93 ... 514), built around
-// memory-level parallelism: one 1024-thread workgroup (16 wavefronts) per problem, one per CU.
+// Linear-algebra services of the coneqp kernel for n <= 528 unknowns (C1-C4 sizes: n = 93 ... 514): one
+// 512-thread workgroup (8 wavefronts) per problem, one per CU.
 //
-//  * The Cholesky factor L lives in HBM in a TILE-PACKED layout: 16x16 tiles, each one contiguous 2 KB block
-//    stored as [k-half][row][8 doubles] so that a wavefront's MFMA fragment load covers one contiguous 1 KB,
-//    tiles of one tile-row adjacent ([tile_row][k_chunk][2][16][8]).  An MFMA operand fragment (16 rows x 16 k),
-//    a block-column panel of a tile-row (2 adjacent tiles) and a block-row of finished columns are all
-//    contiguous byte ranges, so every phase reads and writes long coalesced runs (1 KB per wave instruction)
-//    instead of 128-byte row segments 4 KB apart.
-//  * LDS array U[NP][33] (NP = n rounded up to 32): while block column j of the left-looking Cholesky is
-//    processed it is the panel for rows >= 32 j; rows of already finished block columns keep their 32x32 diagonal
-//    block L_jj there, with 1/L_ii in the pad column U[i][32].  After the factorisation all diagonal blocks are
-//    LDS resident, so the triangular solves never fetch them from HBM.
-//  * Block column j in ONE pass: every wavefront owns up to 2 row tiles (16 rows x 32 cols, two MFMA
-//    accumulators each) initialised with -(P + diag) and accumulating +L L' over the finished columns with
-//    v_mfma_f64_16x16x4_f64; operand slabs are double buffered in registers (the next 16-deep slab is in flight
-//    while the current one is multiplied).
-//  * Diagonal block: wavefront 0, lane = row, rows in registers, column broadcast through a 32-double LDS
-//    buffer, reciprocal pivots from rsqrt.
-//  * Panel rows (X L11' = C): thread per row, right-looking substitution against the LDS-resident L11.
-//  * Solves: per 32-block a substitution by wavefront 0; wavefronts 1..15 apply the rank-32 updates from
-//    operands that were fetched (contiguous tiles) before the diagonal solve started.
-//  * P x: two rows x 5 column chunks of 16-byte loads in flight per lane.
+//  * The Cholesky factor L lives in HBM in a TILE-PACKED layout: 16x16 tiles, each one contiguous 2 KB block,
+//    tiles of one tile-row adjacent ([tile_row][k_chunk][256]).  Inside a tile the double2 with index
+//    h*64 + i*4 + q (h = k-half, i = row, q = 0..3) holds columns q + 8h and q + 8h + 4 of row i.  With lane
+//    (i = lane&15, q = lane>>4) reading that double2, a wavefront's MFMA operand load covers one contiguous 1 KB
+//    (full 128-byte lines), and it is also exactly the register image in which the factorisation produces a tile
+//    (below), so tiles are stored with two 16-byte-per-lane instructions and no shuffle.  The accumulator-native
+//    copy of P (Ppk, written by the Gram kernel) uses the same tile layout.
+//  * Left-looking blocked Cholesky, block 32.  Every wavefront owns up to 4 tile rows x 2 tile columns of the block
+//    column and accumulates the TRANSPOSED tiles  accT = -(S - L L')'  with v_mfma_f64_16x16x4_f64 (operand slabs
+//    ping-pong prefetched in registers).  In that register image a tile is directly the B operand of the next
+//    MFMA, so the triangular solve against the diagonal block runs on the matrix pipe from registers:
+//        X1' = W1 C1' ,  C2' -= L21 X1' ,  X2' = W2 C2'      (W = inverse of a 16x16 diagonal Cholesky block)
+//    -- no LDS panel, no thread-per-row substitution.
+//  * Wavefront 0 owns only the two tile rows of the diagonal block: it finishes its (shorter) rank-k update
+//    first and factors / inverts the two 16x16 diagonal blocks (lane = row, column broadcast through LDS, rsqrt
+//    pivots; inverse by lane = column substitution) while the other wavefronts are still multiplying.
+//  * LDS array U[NP][33] keeps, for every finished block, the INVERSE of its 32x32 diagonal Cholesky block
+//    [[W1, 0], [-W2 L21 W1, W2]], so the triangular solves do one 32x32 mat-vec per block instead of a 32-step
+//    substitution chain and never fetch diagonal blocks from HBM (the diagonal-block tiles of L are not even
+//    written to HBM).
+//  * Solves: per 32-block the mat-vec by wavefront 0; wavefronts 1..7 apply the rank-32 updates from operands
+//    that were fetched (contiguous tiles) before the diagonal step started.
+//  * P x: two rows x 5 column chunks of 16-byte loads per lane, next row pair in flight while reducing.
 #pragma once
 #include "qp_common.hpp"
 
 namespace hipdrt {
 
 static constexpr int RT = 512;           // threads
-static constexpr int RNW = RT / 64;      // 16 wavefronts
-static constexpr int RMAXT = 32 / RNW;   // row tiles per wavefront for block columns j >= 1 (<= 31 tiles)
+static constexpr int RNW = RT / 64;      // 8 wavefronts
+static constexpr int RMAXT = 4;          // tile rows per wavefront and pass
+static constexpr int ROW_PER_PASS = (RNW - 1) * RMAXT;   // off-diagonal tile rows handled per pass
 static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
+static constexpr int DLD = 17;           // row stride of the 16x16 LDS scratch blocks
 
 struct ResSmem {
-    double* U;       // [NP][PLD]
+    double* U;       // [NP][PLD]   inverse diagonal blocks
     double* vec;     // [NP + 32]
     double* dvec;    // [NP + 32]
     double* colbuf;  // [64]
     double* red;     // [4][RNW][4]
+    double* t21;     // [16][DLD]   L21 of the current block
+    double* dsc;     // [16][DLD]   diagonal block being factored
     int* flag;       // [4]
 };
 
 struct OpsResident {
     const double* P; int ldp; double* L; int nch; int n; ResSmem sm;   // nch = tiles per tile-row (NP/16)
-    const double* Ppk; int nchp;                                       // optional accumulator-native copy of P
+    const double* Ppk; int nchp;                                       // P in L's tile layout (lower tiles)
 
     // tile (t, c) starts at ((t*nch + c) * TSZ) doubles; returned in double2 units
     __device__ __forceinline__ const double2* tile2(int t, int c) const {
         return reinterpret_cast<const double2*>(L) + (size_t)((t * nch + c) * (TSZ / 2));
     }
 
+    // lane id recomputed on the spot (two VALU instructions) instead of carried in a register across the kernel
+    static __device__ __forceinline__ int fresh_lane() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    }
+
+    // Wavefront 0: W = inverse of the Cholesky factor of the 16x16 block D (given as at = -D' in accumulator layout)
+    // -> U[(r0+i)*PLD + c0 + j].  Register-only Gauss-Jordan on [D | I]: lane r holds row r of D and of W, the pivot,
+    // the column of multipliers and the finished row of W travel by v_readlane -- no LDS round trip and no barrier on
+    // the dependency chain (pivot -> rsqrt -> multiplier -> next pivot).  Only the lower triangle of D is referenced.
+    __device__ __forceinline__ bool cholinv16(const v4d& at, int r0, int c0) const {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        double* D = sm.dsc;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) D[li * DLD + kq + 4 * rg] = -at[rg];
+        __builtin_amdgcn_wave_barrier();
+        const int r = li;
+        double a[16], w[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { a[c] = D[r * DLD + c]; w[c] = (c == r) ? 1.0 : 0.0; }
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const double piv = bcast_lane(a[c], c);
+            if (!(piv > 0.0)) ok = false;
+            const double rinv = rsqrt(piv);              // 1 / L_cc
+            const double lrc = a[c] * rinv;              // L_rc for r >= c
+            const double lm = (r > c) ? lrc : 0.0;       // row operation  row_r -= L_rc * row_c  below the pivot only
+            const double sc = (r == c) ? rinv : 1.0;     // the pivot row itself is scaled
+#pragma unroll
+            for (int j = 0; j <= c; ++j) {
+                const double wcj = bcast_lane(w[j], c) * rinv;
+                w[j] = w[j] * sc - lm * wcj;
+                asm volatile("" : "+v"(w[j]));           // pinned: see below
+            }
+            // the updates are pinned here (opaque use): left to itself the optimiser sinks them to their first use and
+            // keeps every broadcast value alive, which spills -- and a scratch reload queues behind the other
+            // wavefronts' operand traffic
+#pragma unroll
+            for (int k = c + 1; k < 16; ++k) {
+                const double lkc = bcast_lane(lrc, k);
+                a[k] -= lrc * lkc;
+                asm volatile("" : "+v"(a[k]));
+            }
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sm.U[(size_t)(r0 + r) * PLD + c0 + j] = (j <= r) ? w[j] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        return ok;
+    }
+
+    // accumulator image of -(S tile (T, Cc))': lane (li, kq) register rg <-> row li, column kq + 4 rg
+    __device__ __forceinline__ v4d init_tile(int T, int Cc, int ntr, int fo, int li, int kq) const {
+        v4d a_ = (v4d){0, 0, 0, 0};
+        if (T < ntr) {
+            const double2* tile = reinterpret_cast<const double2*>(Ppk + ((size_t)T * nchp + Cc) * 256);
+            const double2 d0 = tile[fo], d1 = tile[64 + fo];
+            a_ = (v4d){-d0.x, -d0.y, -d1.x, -d1.y};
+        }
+        if (T == Cc) {
+            // diagonal shift; identity beyond n
+            const int row = T * 16 + li;
+            const double dg = row < n ? sm.dvec[row] : 1.0;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                if (kq + 4 * rg == li) a_[rg] -= dg;
+        }
+        return a_;
+    }
+
     // -----------------------------------------------------------------------------------------------------
     __device__ __forceinline__ bool factor() {
-        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;              // this lane's double2 inside a 1 KB half tile
         const int nblk = (n + NB - 1) / NB;
+        const int ntr = (n + 15) >> 4;           // tile rows that hold valid rows
         double* U = sm.U;
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
-            const int nv = (n - j0) < NB ? (n - j0) : NB;
-            const int R = n - j0;
-            const int ntile = (R + 15) >> 4;
             const int tb = j0 >> 4;                 // first tile-row of the block
+            const bool two = (tb + 1) < ntr;        // the block's second tile row holds valid rows
+            const int nc = 2 * jb;                  // finished 16-column chunks
             PROF_DECL
-            // ---- (1) tiles: acc = -(P + diag) + L[rows,:j0] L[blk,:j0]' -----------------------------------
-            // panel <- P + diag with coalesced 16-byte loads (16 lanes per 256-byte row segment, 4 rows = 1 KB per
-            // wave instruction; the accumulator-shaped 8-byte gather used before cost ~45 % of the GEMM phase).
-            // Inside the diagonal block the upper part is taken from the lower triangle (only P's lower triangle is
-            // ever read there).
-            const bool packed = (Ppk != nullptr) && j0 > 0;
-            if (!packed)
-            for (int e = tid; e < ntile * 256; e += RT) {
-                const int rr = e >> 4, pc = (e & 15) * 2;
-                const int r = j0 + rr, cc = j0 + pc;
-                double2 v = make_double2(0.0, 0.0);
-                if (r < n) {
-                    if (cc + 1 <= r || rr >= NB) {
-                        if (cc + 1 < n) v = *reinterpret_cast<const double2*>(P + (size_t)r * ldp + cc);
-                        else if (cc < n) v.x = P[(size_t)r * ldp + cc];
-                    } else {
-                        if (cc < n) v.x = (r >= cc) ? P[(size_t)r * ldp + cc] : P[(size_t)cc * ldp + r];
-                        if (cc + 1 < n) v.y = (r >= cc + 1) ? P[(size_t)r * ldp + cc + 1] : P[(size_t)(cc + 1) * ldp + r];
+            if (wv == 0) {
+                // ======== wavefront 0: the diagonal block ======================================================
+                // Only its two tile rows, whose tiles are A and B operand at once (4 KB per 16-column chunk), four
+                // chunks in flight; the factorisation of the block then overlaps the other wavefronts' multiplication.
+                v4d d11 = init_tile(tb, tb, ntr, fo, li, kq);
+                v4d d21 = init_tile(tb + 1, tb, ntr, fo, li, kq);
+                v4d d22 = init_tile(tb + 1, tb + 1, ntr, fo, li, kq);
+                if (jb > 0) {
+                    const double2* p0 = tile2(tb, 0) + fo;
+                    const double2* p1 = tile2(two ? tb + 1 : tb, 0) + fo;
+                    struct Frag { double2 f0a, f0b, f1a, f1b; };
+                    auto loadf = [&](Frag& f_, int c) {
+                        const int o = c * (TSZ / 2);
+                        f_.f0a = p0[o]; f_.f0b = p0[o + 64];
+                        f_.f1a = p1[o]; f_.f1b = p1[o + 64];
+                    };
+                    auto multf = [&](const Frag& f_) {
+                        d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0a.x, f_.f0a.x, d11, 0, 0, 0);
+                        d21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0a.x, f_.f1a.x, d21, 0, 0, 0);
+                        d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f1a.x, f_.f1a.x, d22, 0, 0, 0);
+                        d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0a.y, f_.f0a.y, d11, 0, 0, 0);
+                        d21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0a.y, f_.f1a.y, d21, 0, 0, 0);
+                        d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f1a.y, f_.f1a.y, d22, 0, 0, 0);
+                        d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0b.x, f_.f0b.x, d11, 0, 0, 0);
+                        d21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0b.x, f_.f1b.x, d21, 0, 0, 0);
+                        d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f1b.x, f_.f1b.x, d22, 0, 0, 0);
+                        d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0b.y, f_.f0b.y, d11, 0, 0, 0);
+                        d21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0b.y, f_.f1b.y, d21, 0, 0, 0);
+                        d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f1b.y, f_.f1b.y, d22, 0, 0, 0);
+                    };
+                    constexpr int PD = 4;
+                    Frag fb[PD];
+                    const v4d keep22 = d22;
+#pragma unroll
+                    for (int k = 0; k < PD; ++k) if (k < nc) loadf(fb[k], k);
+                    for (int c = 0; c < nc; c += PD) {
+#pragma unroll
+                        for (int k = 0; k < PD; ++k) {
+                            if (c + k < nc) {
+                                multf(fb[k]);
+                                if (c + k + PD < nc) loadf(fb[k], c + k + PD);
+                            }
+                        }
                     }
-                    if (r == cc) v.x += sm.dvec[r];
-                    if (r == cc + 1) v.y += sm.dvec[r];
+                    if (!two) { d21 = (v4d){0, 0, 0, 0}; d22 = keep22; }   // stand-in operand: padding stays identity
                 }
-                U[r * PLD + pc] = v.x;
-                U[r * PLD + pc + 1] = v.y;
-            }
-            if (!packed) __syncthreads();
-            if (j0 == 0) {
                 PROF(0);
+                bool ok = cholinv16(d11, j0, 0);
+                PROF(12);
+                // L21' = W1 * C21'  (d21 = -C21', operand -W1)
+                v4d x21 = (v4d){0, 0, 0, 0};
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    x21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + li) * PLD + 4 * s_ + kq], d21[s_], x21, 0, 0, 0);
+                // lane (li, kq) holds L21[li][kq + 4 rg]
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) sm.t21[li * DLD + kq + 4 * rg] = x21[rg];
+                __builtin_amdgcn_wave_barrier();
+                // -D2' += L21 * L21'
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq], x21[s_], d22, 0, 0, 0);
+                PROF(14);
+                ok = cholinv16(d22, j0 + 16, 16) && ok;
+                PROF(15);
+                if (lane == 0) sm.flag[0] = ok ? 0 : 1;
+                PROF(2);
+                __syncthreads();                                    // (A) W1, L21, W2 published
+                PROF(1);
+                if (sm.flag[0]) return false;
+                // lower-left block of the inverse for the solves: W21 = -W2 (L21 W1)
+                v4d y = (v4d){0, 0, 0, 0};
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    y = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq],
+                                                             U[(size_t)(j0 + 4 * s_ + kq) * PLD + li], y, 0, 0, 0);
+                v4d w21 = (v4d){0, 0, 0, 0};
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq], y[s_], w21, 0, 0, 0);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
+                PROF(3);
             } else {
-                v4d acc[RMAXT][2];
-                const int li = lane & 15, kq = lane >> 4;
-                if (packed) {
-                    // accumulators straight from the accumulator-native copy of P the Gram kernel wrote: two
-                    // contiguous 1 KB loads per 16x16 tile, no LDS hop, no extra barrier
+                // ======== wavefronts 1..7: the rows below the diagonal block ==================================
+                const int nothers = ntr - (tb + 2);
+                const int npass = nothers > ROW_PER_PASS ? (nothers + ROW_PER_PASS - 1) / ROW_PER_PASS : 1;
+#pragma unroll 1
+                for (int ps = 0; ps < npass; ++ps) {
+                    int T[RMAXT];
+                    bool act[RMAXT];
 #pragma unroll
                     for (int u = 0; u < RMAXT; ++u) {
-                        const int t = wv + u * RNW;
+                        T[u] = tb + 2 + (wv - 1) + u * (RNW - 1) + ps * ROW_PER_PASS;
+                        act[u] = T[u] < ntr;
+                    }
+                    // ---- (1) accT = -(S' tile) + sum_c L(Cc, c) L(T, c)' --------------------------------------
+                    v4d acc[RMAXT][2];
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            v4d a_ = (v4d){0, 0, 0, 0};
-                            const int T = tb + t, Cc = 2 * jb + ct;
-                            if (t < ntile && T >= Cc) {
-                                const double2* tile = reinterpret_cast<const double2*>(Ppk + ((size_t)T * nchp + Cc) * 256);
-                                const double2 d0 = tile[lane], d1 = tile[64 + lane];
-                                a_ = (v4d){-d0.x, -d0.y, -d1.x, -d1.y};
-                                if (T == Cc) {
+                    for (int u = 0; u < RMAXT; ++u)
 #pragma unroll
-                                    for (int rg = 0; rg < 4; ++rg)
-                                        if (kq + 4 * rg == li) a_[rg] -= sm.dvec[T * 16 + li];
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                    if (jb > 0 && act[0]) {
+                        const double2* pb0 = tile2(tb, 0) + fo;
+                        const double2* pb1 = tile2(tb + 1, 0) + fo;     // rows below exist => the block is complete
+                        const double2* pa[RMAXT];
+#pragma unroll
+                        for (int u = 0; u < RMAXT; ++u) pa[u] = tile2(act[u] ? T[u] : tb, 0) + fo;
+                        struct Slab { double2 b0a, b0b, b1a, b1b, aa[RMAXT], ab[RMAXT]; };
+                        auto load = [&](Slab& s_, int c) {          // c = k-chunk index (16 columns)
+                            const int o = c * (TSZ / 2);
+                            s_.b0a = pb0[o]; s_.b0b = pb0[o + 64];
+                            s_.b1a = pb1[o]; s_.b1b = pb1[o + 64];
+#pragma unroll
+                            for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = pa[u][o]; s_.ab[u] = pa[u][o + 64]; }
+                        };
+                        auto mult = [&](const Slab& s_) {
+#pragma unroll
+                            for (int u = 0; u < RMAXT; ++u) {
+                                if (act[u]) {
+                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0a.x, s_.aa[u].x, acc[u][0], 0, 0, 0);
+                                    acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1a.x, s_.aa[u].x, acc[u][1], 0, 0, 0);
+                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0a.y, s_.aa[u].y, acc[u][0], 0, 0, 0);
+                                    acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1a.y, s_.aa[u].y, acc[u][1], 0, 0, 0);
+                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0b.x, s_.ab[u].x, acc[u][0], 0, 0, 0);
+                                    acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1b.x, s_.ab[u].x, acc[u][1], 0, 0, 0);
+                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0b.y, s_.ab[u].y, acc[u][0], 0, 0, 0);
+                                    acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1b.y, s_.ab[u].y, acc[u][1], 0, 0, 0);
                                 }
                             }
-                            acc[u][ct] = a_;
+                        };
+                        // ping-pong prefetch over the 2*jb finished 16-column chunks (always an even count)
+                        Slab sa, sb;
+                        load(sa, 0);
+                        for (int c = 0; c < nc; c += 2) {
+                            load(sb, c + 1);
+                            mult(sa);
+                            if (c + 2 < nc) load(sa, c + 2);
+                            mult(sb);
                         }
                     }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < RMAXT; ++u) {
-                        const int t = wv + u * RNW;
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                            for (int rg = 0; rg < 4; ++rg)
-                                acc[u][ct][rg] = (t < ntile) ? -U[(j0 + t * 16 + kq + 4 * rg) * PLD + ct * 16 + li] : 0.0;
+                    if (ps == 0) {
+                        __syncthreads();                            // (A) W1, L21, W2 published by wavefront 0
+                        if (sm.flag[0]) return false;
                     }
-                }
-                if (wv < ntile) {
-                    // Tile-internal layout [k-half h][row i][8 doubles]: lane (i = lane&15, kq = lane>>4) takes the
-                    // double2 at h*64 + i*4 + kq, i.e. k = 8h + 2kq, +1 -- each wave instruction covers one
-                    // contiguous 1 KB (full 128-byte lines; the half-line pattern of a row-major tile halves the
-                    // per-CU load throughput).  A and B use the same k assignment, so the MFMA sums are complete.
-                    const int fo = li * 4 + kq;
-                    const double2* pb0 = tile2(tb, 0) + fo;
-                    const double2* pb1 = tile2(tb + 1 < nch ? tb + 1 : tb, 0) + fo;
-                    const double2* pa[RMAXT];
+                    // ---- (3) X1' = W1 C1', C2' -= L21 X1', X2' = W2 C2' on the matrix pipe, from registers -----
+                    if (act[0]) {
+                        double wn1[4], l21[4], wn2[4];
 #pragma unroll
-                    for (int u = 0; u < RMAXT; ++u) {
-                        int t = tb + wv + u * RNW;
-                        if (t > nch - 1) t = nch - 1;
-                        pa[u] = tile2(t, 0) + fo;
-                    }
-                    struct Slab { double2 b0a, b0b, b1a, b1b, aa[RMAXT], ab[RMAXT]; };
-                    auto load = [&](Slab& s_, int c) {          // c = k-chunk index (16 columns)
-                        const int o = c * (TSZ / 2);
-                        s_.b0a = pb0[o]; s_.b0b = pb0[o + 64];
-                        s_.b1a = pb1[o]; s_.b1b = pb1[o + 64];
+                        for (int s_ = 0; s_ < 4; ++s_) {
+                            wn1[s_] = -U[(size_t)(j0 + li) * PLD + 4 * s_ + kq];
+                            l21[s_] = sm.t21[li * DLD + 4 * s_ + kq];
+                            wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
+                        }
+                        v4d x1[RMAXT], x2[RMAXT];
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = pa[u][o]; s_.ab[u] = pa[u][o + 64]; }
-                    };
-                    auto mult = [&](const Slab& s_) {
+                        for (int u = 0; u < RMAXT; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RMAXT; ++u)
+                                x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RMAXT; ++u)
+                                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RMAXT; ++u)
+                                x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
+                        // ---- (4) tiles straight from registers: two contiguous 1 KB stores per tile ------------
 #pragma unroll
                         for (int u = 0; u < RMAXT; ++u) {
-                            if (wv + u * RNW < ntile) {
-                                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.aa[u].x, s_.b0a.x, acc[u][0], 0, 0, 0);
-                                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.aa[u].x, s_.b1a.x, acc[u][1], 0, 0, 0);
-                                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.aa[u].y, s_.b0a.y, acc[u][0], 0, 0, 0);
-                                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.aa[u].y, s_.b1a.y, acc[u][1], 0, 0, 0);
-                                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.ab[u].x, s_.b0b.x, acc[u][0], 0, 0, 0);
-                                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.ab[u].x, s_.b1b.x, acc[u][1], 0, 0, 0);
-                                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.ab[u].y, s_.b0b.y, acc[u][0], 0, 0, 0);
-                                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.ab[u].y, s_.b1b.y, acc[u][1], 0, 0, 0);
+                            if (act[u]) {
+                                double2* d0 = const_cast<double2*>(tile2(T[u], 2 * jb)) + fo;
+                                d0[0] = make_double2(x1[u][0], x1[u][1]);
+                                d0[64] = make_double2(x1[u][2], x1[u][3]);
+                                d0[128] = make_double2(x2[u][0], x2[u][1]);
+                                d0[192] = make_double2(x2[u][2], x2[u][3]);
                             }
                         }
-                    };
-                    // ping-pong prefetch over the 2*jb finished 16-column chunks (always an even count)
-                    Slab sa, sb;
-                    const int nc = 2 * jb;
-                    load(sa, 0);
-                    for (int c = 0; c < nc; c += 2) {
-                        load(sb, c + 1);
-                        mult(sa);
-                        if (c + 2 < nc) load(sa, c + 2);
-                        mult(sb);
-                    }
-                }
-                PROF(0);
-                // C/D map of v_mfma_f64_16x16x4: col = lane&15, row = (lane>>4) + 4*reg
-#pragma unroll
-                for (int u = 0; u < RMAXT; ++u) {
-                    const int t = wv + u * RNW;
-                    if (t < ntile) {
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                            for (int rg = 0; rg < 4; ++rg)
-                                U[(j0 + t * 16 + kq + 4 * rg) * PLD + ct * 16 + li] = -acc[u][ct][rg];
                     }
                 }
             }
-            __syncthreads();
-            PROF(1);
-            // ---- (2)+(3) 32-wide panel in two 16-wide halves (halves the sequential diagonal work and the
-            //      substitution work per panel row; the rank-16 coupling between the halves runs on MFMA) -------
-            // half h: wavefront 0 factors the 16x16 diagonal block D_h in place (lane = row, column broadcast via
-            // LDS, rsqrt pivots) -- for h = 0 the lanes 16..31 carry the rows of the lower-left block L21 along;
-            // then every panel row (thread per row) is substituted against D_h.
-            bool failed = false;
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                const int c0 = 16 * h;                               // first column of the half
-                const int nvh = nv - c0 < 16 ? nv - c0 : 16;          // valid columns in this half (may be <= 0)
-                if (nvh <= 0) break;
-                if (wv == 0) {
-                    const int r = lane & 31;                          // row j0 + c0 + r  (h = 1: only r < 16 matter)
-                    double* Ub = U + (size_t)(j0 + c0) * PLD + c0;    // D_h origin
-                    double a[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) a[c] = Ub[r * PLD + c];
-                    bool ok = true;
-                    double* cb = sm.colbuf;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        if (c < nvh) {
-                            double* col = cb + (c & 1) * 32;
-                            if (lane < 32) col[r] = a[c];
-                            __builtin_amdgcn_wave_barrier();
-                            const double piv = col[c];
-                            if (!(piv > 0.0)) ok = false;
-                            const double rinv = rsqrt(piv);            // 1 / L_cc
-                            const double ljj = piv * rinv;             // L_cc
-                            const double lrc = (r == c) ? ljj : a[c] * rinv;
-                            const double lrs = lrc * rinv;
-                            a[c] = lrc;
-                            if (lane == c) U[(size_t)(j0 + c0 + c) * PLD + NB] = rinv;   // reciprocal pivot -> pad column
-#pragma unroll
-                            for (int k = c + 1; k < 16; ++k) a[k] -= lrs * col[k];
-                        }
-                    }
-                    const int rows_here = (h == 0) ? 32 : 16;
-                    if (lane < rows_here) {
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) Ub[r * PLD + c] = (c <= r) ? a[c] : 0.0;
-                    } else if (h == 1 && lane < 32) {
-                        // upper-right 16x16 of the diagonal block: zero (never referenced, kept clean)
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) U[(size_t)(j0 + (lane - 16)) * PLD + 16 + c] = 0.0;
-                    }
-                    const unsigned long long bad = __ballot(!ok);
-                    if (lane == 0) sm.flag[0] = bad ? 1 : 0;
-                }
-                __syncthreads();
-                if (sm.flag[0]) { failed = true; break; }
-                if (h == 0) PROF(2);
-                // panel rows below the diagonal block: x = v D_h^-T, right-looking, reciprocal pivots
-                {
-                    for (int rr = j0 + NB + tid; rr < n; rr += RT) {
-                        double v[16];
-                        double* prow = U + (size_t)rr * PLD + c0;
-                        const double* Ub = U + (size_t)(j0 + c0) * PLD + c0;
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) v[c] = prow[c];
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) {
-                            if (c < nvh) {
-                                const double xc = v[c] * U[(size_t)(j0 + c0 + c) * PLD + NB];
-                                v[c] = xc;
-#pragma unroll
-                                for (int k = c + 1; k < 16; ++k) v[k] -= xc * Ub[k * PLD + c];
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) prow[c] = v[c];
-                    }
-                }
-                __syncthreads();
-                if (h == 0 && nv > 16) {
-                    // rank-16 coupling on MFMA: C[:, 16:32] -= X[:, 0:16] * L21' for every row >= j0+16
-                    // (tile 0 = the lower half of the diagonal block itself); operands straight from the LDS panel
-                    const int li = lane & 15, kq = lane >> 4;
-                    const int nt3 = (n - (j0 + 16) + 15) >> 4;
-                    const double* Bp = U + (size_t)(j0 + 16 + li) * PLD + 4 * kq;
-                    const double b0 = Bp[0], b1 = Bp[1], b2 = Bp[2], b3 = Bp[3];
-                    for (int t = wv; t < nt3; t += RNW) {
-                        const int row0 = j0 + 16 + 16 * t;
-                        const double* Ap = U + (size_t)(row0 + li) * PLD + 4 * kq;
-                        double* Cp = U + (size_t)(row0 + kq) * PLD + 16 + li;
-                        v4d acc;
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) acc[rg] = Cp[(size_t)(4 * rg) * PLD];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[0], b0, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[1], b1, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[2], b2, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[3], b3, acc, 0, 0, 0);
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) Cp[(size_t)(4 * rg) * PLD] = acc[rg];
-                    }
-                    __syncthreads();
-                }
-            }
-            if (failed) return false;
-            PROF(3);
-            // ---- (4) write-back: per tile-row 2 adjacent tiles = 4 KB contiguous ---------------------------
-            // e -> (tile t, chunk ch, half h, row i, 16-byte piece p): consecutive threads write consecutive 16 B
-            for (int e = tid; e < ntile * 256; e += RT) {
-                const int pc = e & 3, i = (e >> 2) & 15, h = (e >> 6) & 1, ch = (e >> 7) & 1, t = e >> 8;
-                const double* src = U + (size_t)(j0 + t * 16 + i) * PLD + ch * 16 + 8 * h + 2 * pc;
-                double2* dst = reinterpret_cast<double2*>(L) +
-                               (size_t)(((tb + t) * nch + 2 * jb + ch) * (TSZ / 2) + h * 64 + i * 4 + pc);
-                *dst = make_double2(src[0], src[1]);
-            }
-            __syncthreads();
+            __syncthreads();                                        // (B) block column visible to everyone
             PROF(4);
         }
         return true;
     }
 
     // -----------------------------------------------------------------------------------------------------
-    // vec := S^-1 vec.  Wavefront 0 solves the 32x32 diagonal systems (L_jj and 1/L_ii are LDS resident);
-    // wavefronts 1..15 apply the rank-32 updates.  The update operands (tiles of L in HBM) do not depend on the
-    // running solution, so they are fetched BEFORE the diagonal solve of the same block and are in flight while
-    // wavefront 0 substitutes.
+    // vec := S^-1 vec.  Wavefront 0 multiplies by the inverse 32x32 diagonal blocks (LDS resident); wavefronts
+    // 1..7 apply the rank-32 updates.  The update operands (tiles of L in HBM) do not depend on the running
+    // solution, so they are fetched BEFORE the diagonal step of the same block and are in flight meanwhile.
     //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane  ->  row i = lane/4,
-    //   columns 8h + 2*(lane%4), +1.
+    //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
     __device__ __forceinline__ void solve() {
-        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int nblk = (n + NB - 1) / NB;
+        const int ntr = (n + 15) >> 4;
         double* vec = sm.vec;
         const double* U = sm.U;
         constexpr int UW = RNW - 1;                 // updater wavefronts
@@ -325,9 +355,8 @@ struct OpsResident {
         // ---- forward: L y = b -----------------------------------------------------------------------------
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
-            const int nv = (n - j0) < NB ? (n - j0) : NB;
             const int tb = j0 >> 4;
-            const int tbelow = ((n + 15) >> 4) - (tb + 2);     // row tiles below the block
+            const int tbelow = ntr - (tb + 2);                  // row tiles below the block
             constexpr int FT = (31 + UW - 1) / UW;              // tiles per updater wavefront
             double2 lv[FT][4];                                  // [tile][chunk*2 + half]
             if (wv > 0 && tbelow > 0) {
@@ -342,30 +371,28 @@ struct OpsResident {
                 }
             }
             if (wv == 0) {
+                // y = M b with M = inverse of the block's Cholesky factor (upper-right 16x16 of M is zero)
                 const int r = lane & 31;
-                const double* Ub = U + (size_t)(j0 + r) * PLD;
-                // minimal dependency chain per step: mul, broadcast, fma.  Entries with c >= r are zeroed at load
-                // time, so bb stops changing after step r-1 and y_r = bb * rinv falls out at the end.
-                double lr[NB];
+                const double* Mr = U + (size_t)(j0 + r) * PLD;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-                for (int c = 0; c < NB; ++c) lr[c] = (c < r) ? Ub[c] : 0.0;
-                const bool rv_ = (j0 + r) < n;
-                double bb = rv_ ? vec[j0 + r] : 0.0;
-                const double rinv = rv_ ? Ub[NB] : 0.0;
-#pragma unroll
-                for (int c = 0; c < NB - 1; ++c) {
-                    const double yc = bcast_lane(bb * rinv, c);
-                    bb -= lr[c] * yc;
+                for (int c = 0; c < NB; c += 4) {
+                    s0 += Mr[c] * vec[j0 + c];
+                    s1 += Mr[c + 1] * vec[j0 + c + 1];
+                    s2 += Mr[c + 2] * vec[j0 + c + 2];
+                    s3 += Mr[c + 3] * vec[j0 + c + 3];
                 }
-                if (lane < nv) vec[j0 + lane] = bb * rinv;
+                const double y = (s0 + s1) + (s2 + s3);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < NB) vec[j0 + lane] = y;
             }
             __syncthreads();
             PROF(5);
             if (wv > 0 && tbelow > 0) {
-                // q = 2*chunk + half: lane holds columns 16*chunk + 8*half + 2*l4, +1 of tile row g4
+                // q = 2*chunk + half: lane holds columns 8q + l4 and 8q + l4 + 4 of tile row g4
                 double ya[4], yb[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ya[q] = vec[j0 + 8 * q + 2 * l4]; yb[q] = vec[j0 + 8 * q + 2 * l4 + 1]; }
+                for (int q = 0; q < 4; ++q) { ya[q] = vec[j0 + 8 * q + l4]; yb[q] = vec[j0 + 8 * q + l4 + 4]; }
 #pragma unroll
                 for (int u = 0; u < FT; ++u) {
                     const int tt = (wv - 1) + u * UW;
@@ -388,10 +415,9 @@ struct OpsResident {
         // ---- backward: L' x = y ---------------------------------------------------------------------------
         for (int jb = nblk - 1; jb >= 0; --jb) {
             const int j0 = jb * NB;
-            const int nv = (n - j0) < NB ? (n - j0) : NB;
             const int tb = j0 >> 4;
             const int nc = 2 * jb;                              // 16-column chunks left of the block
-            const bool two = (tb + 1) * 16 < n;                 // second tile-row of the block holds valid rows
+            const bool two = (tb + 1) < ntr;                    // second tile-row of the block holds valid rows
             constexpr int BC = (32 + UW - 1) / UW;              // chunks per updater wavefront
             double2 lb[BC][4];                                  // [chunk][tile*2 + half]
             if (wv > 0) {
@@ -407,19 +433,20 @@ struct OpsResident {
                 }
             }
             if (wv == 0) {
-                const int c = lane & 31;     // lane = column c of the block: needs L[j0+r][j0+c], r >= c
-                double lc[NB];
+                // x = M' y : lane = column c of M
+                const int c = lane & 31;
+                const double* Mc = U + (size_t)j0 * PLD + c;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-                for (int r = 0; r < NB; ++r) lc[r] = (r > c && r < nv) ? U[(size_t)(j0 + r) * PLD + c] : 0.0;
-                const bool cv_ = (j0 + c) < n;
-                double yy = cv_ ? vec[j0 + c] : 0.0;
-                const double rinv = cv_ ? U[(size_t)(j0 + c) * PLD + NB] : 0.0;
-#pragma unroll
-                for (int r = NB - 1; r > 0; --r) {
-                    const double xr = bcast_lane(yy * rinv, r);    // lanes >= nv carry yy = 0, rinv = 0
-                    yy -= lc[r] * xr;
+                for (int r = 0; r < NB; r += 4) {
+                    s0 += Mc[(size_t)r * PLD] * vec[j0 + r];
+                    s1 += Mc[(size_t)(r + 1) * PLD] * vec[j0 + r + 1];
+                    s2 += Mc[(size_t)(r + 2) * PLD] * vec[j0 + r + 2];
+                    s3 += Mc[(size_t)(r + 3) * PLD] * vec[j0 + r + 3];
                 }
-                if (lane < nv) vec[j0 + lane] = yy * rinv;
+                const double xv = (s0 + s1) + (s2 + s3);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < NB) vec[j0 + lane] = xv;
             }
             __syncthreads();
             PROF(7);
@@ -432,18 +459,18 @@ struct OpsResident {
                     const int c = (wv - 1) + u * UW;
                     if (c < nc) {
                         // lb[u][0..1] = tile tb halves 0,1 ; lb[u][2..3] = tile tb+1 halves 0,1
-                        double s0 = lb[u][0].x * x0 + lb[u][2].x * x1;     // column 16c + 2*l4
-                        double s1 = lb[u][0].y * x0 + lb[u][2].y * x1;     // column 16c + 2*l4 + 1
-                        double s2 = lb[u][1].x * x0 + lb[u][3].x * x1;     // column 16c + 8 + 2*l4
-                        double s3 = lb[u][1].y * x0 + lb[u][3].y * x1;     // column 16c + 8 + 2*l4 + 1
+                        double s0 = lb[u][0].x * x0 + lb[u][2].x * x1;     // column 16c + l4
+                        double s1 = lb[u][0].y * x0 + lb[u][2].y * x1;     // column 16c + l4 + 4
+                        double s2 = lb[u][1].x * x0 + lb[u][3].x * x1;     // column 16c + 8 + l4
+                        double s3 = lb[u][1].y * x0 + lb[u][3].y * x1;     // column 16c + 12 + l4
 #pragma unroll
                         for (int off = 4; off < 64; off <<= 1) {
                             s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64);
                             s2 += __shfl_xor(s2, off, 64); s3 += __shfl_xor(s3, off, 64);
                         }
                         if (g4 == 0) {
-                            vec[c * 16 + 2 * l4] -= s0;     vec[c * 16 + 2 * l4 + 1] -= s1;
-                            vec[c * 16 + 8 + 2 * l4] -= s2; vec[c * 16 + 8 + 2 * l4 + 1] -= s3;
+                            vec[c * 16 + l4] -= s0;     vec[c * 16 + l4 + 4] -= s1;
+                            vec[c * 16 + 8 + l4] -= s2; vec[c * 16 + 12 + l4] -= s3;
                         }
                     }
                 }
@@ -454,39 +481,52 @@ struct OpsResident {
     }
 
     // -----------------------------------------------------------------------------------------------------
-    // dvec = P * vec ; rows in pairs per wavefront, 16-byte loads, up to 5 column chunks of 128
+    // dvec = P * vec ; rows in pairs per wavefront, 16-byte loads, up to 5 column chunks of 128; the next row pair
+    // is in flight while the current one is reduced
     __device__ __forceinline__ void matvec() {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const double* xin = sm.vec;
         double* out = sm.dvec;
         const int c0 = 2 * lane;
         double2 xv[5];
+        int co[5];
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
             const int c = c0 + 128 * t;
             xv[t] = make_double2(c < n ? xin[c] : 0.0, c + 1 < n ? xin[c + 1] : 0.0);
+            co[t] = (c + 1 >= ldp) ? 0 : c;                   // clamp (value is multiplied by xv = 0)
         }
-        for (int i0 = 2 * wv; i0 < n; i0 += 2 * RNW) {
+        struct Rows { double2 a0[5], a1[5]; };
+        auto load = [&](Rows& r_, int i0) {
             const int i1 = (i0 + 1 < n) ? i0 + 1 : i0;
             const double* r0 = P + (size_t)i0 * ldp;
             const double* r1 = P + (size_t)i1 * ldp;
-            double2 a0[5], a1[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                int c = c0 + 128 * t;
-                if (c + 1 >= ldp) c = 0;                       // clamp (value is multiplied by xv = 0)
-                a0[t] = *reinterpret_cast<const double2*>(r0 + c);
-                a1[t] = *reinterpret_cast<const double2*>(r1 + c);
+                r_.a0[t] = *reinterpret_cast<const double2*>(r0 + co[t]);
+                r_.a1[t] = *reinterpret_cast<const double2*>(r1 + co[t]);
             }
+        };
+        auto reduce = [&](const Rows& r_, int i0) {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                s0 += a0[t].x * xv[t].x + a0[t].y * xv[t].y;
-                s1 += a1[t].x * xv[t].x + a1[t].y * xv[t].y;
+                s0 += r_.a0[t].x * xv[t].x + r_.a0[t].y * xv[t].y;
+                s1 += r_.a1[t].x * xv[t].x + r_.a1[t].y * xv[t].y;
             }
             s0 = wsum(s0);
             s1 = wsum(s1);
             if (lane == 0) { out[i0] = s0; if (i0 + 1 < n) out[i0 + 1] = s1; }
+        };
+        constexpr int STEP = 2 * RNW;
+        Rows ra, rb;
+        int i0 = 2 * wv;
+        if (i0 < n) load(ra, i0);
+        for (; i0 < n; i0 += 2 * STEP) {
+            if (i0 + STEP < n) load(rb, i0 + STEP);
+            reduce(ra, i0);
+            if (i0 + 2 * STEP < n) load(ra, i0 + 2 * STEP);
+            if (i0 + STEP < n) reduce(rb, i0 + STEP);
         }
     }
 };
@@ -499,14 +539,18 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
     ops.P = a.P + (size_t)b * a.p_stride; ops.ldp = a.ldp;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk ? a.Ppk + (size_t)b * a.ppk_stride : nullptr; ops.nchp = a.nchp;
-    ops.sm.U = smem;
-    ops.sm.vec = ops.sm.U + (size_t)NP * PLD;
-    ops.sm.dvec = ops.sm.vec + NP + 32;
-    ops.sm.colbuf = ops.sm.dvec + NP + 32;
+    // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
+    constexpr int VEC = RNP_MAX + 16 + 32;                 // NP <= 544
+    ops.sm.colbuf = smem;
     ops.sm.red = ops.sm.colbuf + 64;
-    ops.sm.flag = reinterpret_cast<int*>(ops.sm.red + 4 * RNW * 4);
-    // zero U (rows >= n are read, never used) and the padding of vec (read by the updates of the last,
-    // partial block)
+    ops.sm.t21 = ops.sm.red + 4 * RNW * 4;
+    ops.sm.dsc = ops.sm.t21 + 16 * DLD;
+    ops.sm.flag = reinterpret_cast<int*>(ops.sm.dsc + 16 * DLD);
+    ops.sm.vec = ops.sm.dsc + 16 * DLD + 8;
+    ops.sm.dvec = ops.sm.vec + VEC;
+    ops.sm.U = ops.sm.dvec + VEC;
+    // zero U (the upper-right quarter of every inverse block stays zero) and the padding of vec (read by the
+    // updates of the last, partial block)
     for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
     for (int i = threadIdx.x; i < NP + 32; i += RT) ops.sm.vec[i] = 0.0;
     __syncthreads();
@@ -515,7 +559,7 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
 }
 
 static size_t resident_lds_bytes(int NP) {
-    return ((size_t)NP * PLD + 2 * (size_t)(NP + 32) + 64 + 4 * RNW * 4) * sizeof(double) + 64;
+    return ((size_t)NP * PLD + 2 * (size_t)(RNP_MAX + 16 + 32) + 64 + 4 * RNW * 4 + 2 * 16 * DLD + 8) * sizeof(double);
 }
 
 // scratch doubles per problem for the tile-packed factor: (NP/16)^2 tiles of 256 doubles

@@ -33,7 +33,7 @@ names = ["gemm", "panel_store", "diag", "trsm", "writeback", "fwd_diag", "fwd_up
 if prof[10]:
     tot = prof[10]
     print("in-kernel ticks of WG0:", {n: prof[i] for i, n in enumerate(names)}, "factorizations:", prof[11])
-    print("acc-init (P loads):", prof[12]); print("shares:", {n: round(prof[i] / tot, 3) for i, n in enumerate(names)})
+    print("chain: chol1", prof[12], "inv1", prof[13], "l21+d2", prof[14], "chol2", prof[15]); print("shares:", {n: round(prof[i] / tot, 3) for i, n in enumerate(names)})
 from oracle.coneqp import coneqp_boxlow
 r = coneqp_boxlow(P, q, h)
 print("oracle iters", r["iterations"], "max rel err", np.max(np.abs(res["x"][0] - r["x"])) / np.abs(r["x"]).max())

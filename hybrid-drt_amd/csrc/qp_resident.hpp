@@ -45,6 +45,7 @@ struct ResSmem {
     double* red;     // [4][RNW][4]
     double* t21;     // [16][DLD]   L21 of the current block
     double* dsc;     // [16][DLD]   diagonal block being factored
+    double* img;     // [2][64][4]  register images of -D21', -D22' of the next diagonal block
     int* flag;       // [4]
 };
 
@@ -68,12 +69,20 @@ struct OpsResident {
     // -> U[(r0+i)*PLD + c0 + j].  Register-only Gauss-Jordan on [D | I]: lane r holds row r of D and of W, the pivot,
     // the column of multipliers and the finished row of W travel by v_readlane -- no LDS round trip and no barrier on
     // the dependency chain (pivot -> rsqrt -> multiplier -> next pivot).  Only the lower triangle of D is referenced.
-    __device__ __forceinline__ bool cholinv16(const v4d& at, int r0, int c0) const {
+    // at = -D' (accumulator layout) -> D row-major in the LDS scratch block
+    __device__ __forceinline__ void stage_dsc(const v4d& at) const {
         const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
-        double* D = sm.dsc;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) D[li * DLD + kq + 4 * rg] = -at[rg];
+        for (int rg = 0; rg < 4; ++rg) sm.dsc[li * DLD + kq + 4 * rg] = -at[rg];
+    }
+    __device__ __forceinline__ bool cholinv16(const v4d& at, int r0, int c0) const {
+        stage_dsc(at);
         __builtin_amdgcn_wave_barrier();
+        return cholinv16_dsc(r0, c0);
+    }
+    __device__ __forceinline__ bool cholinv16_dsc(int r0, int c0) const {
+        const int lane = fresh_lane(), li = lane & 15;
+        const double* D = sm.dsc;
         const int r = li;
         double a[16], w[16];
 #pragma unroll
@@ -131,6 +140,7 @@ struct OpsResident {
     }
 
     // -----------------------------------------------------------------------------------------------------
+    // operand fragments of a tile held in its register image (rg <-> column kq + 4 rg): k-half h = (x[2h], x[2h+1])
     __device__ __forceinline__ bool factor() {
         const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int li = lane & 15, kq = lane >> 4;
@@ -138,62 +148,34 @@ struct OpsResident {
         const int nblk = (n + NB - 1) / NB;
         const int ntr = (n + 15) >> 4;           // tile rows that hold valid rows
         double* U = sm.U;
+        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);        // register images of -D21', -D22' of the next block
+        v4d* const img22 = img21 + 64;
+        // Roles.  Wavefront 0: factor + invert the diagonal block (no global traffic at all).  Wavefront 1: the two tile
+        // rows of the NEXT diagonal block -- their panel tiles in this block column plus, one column ahead, the rank-k
+        // update of the next diagonal block, which it hands to wavefront 0 through LDS.  Wavefronts 2..7: all rows below.
+        // So the sequential diagonal work of column j+1 overlaps everybody else's rank-k update of column j+1.
+        if (wv == 1) {
+            // prologue: diagonal block of column 0 straight from P
+            const v4d d11 = init_tile(0, 0, ntr, fo, li, kq);
+            const v4d d21 = init_tile(1, 0, ntr, fo, li, kq);
+            const v4d d22 = init_tile(1, 1, ntr, fo, li, kq);
+            stage_dsc(d11);
+            img21[lane] = d21;
+            img22[lane] = d22;
+        }
+        __syncthreads();
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
             const int tb = j0 >> 4;                 // first tile-row of the block
-            const bool two = (tb + 1) < ntr;        // the block's second tile row holds valid rows
             const int nc = 2 * jb;                  // finished 16-column chunks
             PROF_DECL
             if (wv == 0) {
-                // ======== wavefront 0: the diagonal block ======================================================
-                // Only its two tile rows, whose tiles are A and B operand at once (4 KB per 16-column chunk), four
-                // chunks in flight; the factorisation of the block then overlaps the other wavefronts' multiplication.
-                v4d d11 = init_tile(tb, tb, ntr, fo, li, kq);
-                v4d d21 = init_tile(tb + 1, tb, ntr, fo, li, kq);
-                v4d d22 = init_tile(tb + 1, tb + 1, ntr, fo, li, kq);
-                if (jb > 0) {
-                    const double2* p0 = tile2(tb, 0) + fo;
-                    const double2* p1 = tile2(two ? tb + 1 : tb, 0) + fo;
-                    struct Frag { double2 f0a, f0b, f1a, f1b; };
-                    auto loadf = [&](Frag& f_, int c) {
-                        const int o = c * (TSZ / 2);
-                        f_.f0a = p0[o]; f_.f0b = p0[o + 64];
-                        f_.f1a = p1[o]; f_.f1b = p1[o + 64];
-                    };
-                    auto multf = [&](const Frag& f_) {
-                        d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0a.x, f_.f0a.x, d11, 0, 0, 0);
-                        d21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0a.x, f_.f1a.x, d21, 0, 0, 0);
-                        d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f1a.x, f_.f1a.x, d22, 0, 0, 0);
-                        d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0a.y, f_.f0a.y, d11, 0, 0, 0);
-                        d21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0a.y, f_.f1a.y, d21, 0, 0, 0);
-                        d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f1a.y, f_.f1a.y, d22, 0, 0, 0);
-                        d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0b.x, f_.f0b.x, d11, 0, 0, 0);
-                        d21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0b.x, f_.f1b.x, d21, 0, 0, 0);
-                        d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f1b.x, f_.f1b.x, d22, 0, 0, 0);
-                        d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0b.y, f_.f0b.y, d11, 0, 0, 0);
-                        d21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f0b.y, f_.f1b.y, d21, 0, 0, 0);
-                        d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.f1b.y, f_.f1b.y, d22, 0, 0, 0);
-                    };
-                    constexpr int PD = 4;
-                    Frag fb[PD];
-                    const v4d keep22 = d22;
-#pragma unroll
-                    for (int k = 0; k < PD; ++k) if (k < nc) loadf(fb[k], k);
-                    for (int c = 0; c < nc; c += PD) {
-#pragma unroll
-                        for (int k = 0; k < PD; ++k) {
-                            if (c + k < nc) {
-                                multf(fb[k]);
-                                if (c + k + PD < nc) loadf(fb[k], c + k + PD);
-                            }
-                        }
-                    }
-                    if (!two) { d21 = (v4d){0, 0, 0, 0}; d22 = keep22; }   // stand-in operand: padding stays identity
-                }
-                PROF(0);
-                bool ok = cholinv16(d11, j0, 0);
+                // ======== wavefront 0: the diagonal block =====================================================
+                bool ok = cholinv16_dsc(j0, 0);
                 PROF(12);
-                // L21' = W1 * C21'  (d21 = -C21', operand -W1)
+                // L21' = W1 * C21'  (image = -C21', operand -W1)
+                const v4d d21 = img21[lane];
+                v4d d22 = img22[lane];
                 v4d x21 = (v4d){0, 0, 0, 0};
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_)
@@ -210,7 +192,6 @@ struct OpsResident {
                 ok = cholinv16(d22, j0 + 16, 16) && ok;
                 PROF(15);
                 if (lane == 0) sm.flag[0] = ok ? 0 : 1;
-                PROF(2);
                 __syncthreads();                                    // (A) W1, L21, W2 published
                 PROF(1);
                 if (sm.flag[0]) return false;
@@ -227,17 +208,123 @@ struct OpsResident {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
                 PROF(3);
+            } else if (wv == 1) {
+                // ======== wavefront 1: the tile rows R2 = tb+2, R3 = tb+3 of the next diagonal block ============
+                const int R2 = tb + 2, R3 = tb + 3;
+                const bool v2 = R2 < ntr, v3 = R3 < ntr;
+                v4d p20, p21, p30, p31, e11, e21, e22;   // panel tiles (R2|R3, 2jb|2jb+1) and the next diagonal block
+                if (v2) {
+                    p20 = init_tile(R2, tb, ntr, fo, li, kq);      p21 = init_tile(R2, tb + 1, ntr, fo, li, kq);
+                    p30 = init_tile(R3, tb, ntr, fo, li, kq);      p31 = init_tile(R3, tb + 1, ntr, fo, li, kq);
+                    e11 = init_tile(R2, R2, ntr, fo, li, kq);      e21 = init_tile(R3, R2, ntr, fo, li, kq);
+                    e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                    if (jb > 0) {
+                        const double2* q0 = tile2(tb, 0) + fo;
+                        const double2* q1 = tile2(tb + 1, 0) + fo;
+                        const double2* q2 = tile2(R2, 0) + fo;
+                        const double2* q3 = tile2(v3 ? R3 : R2, 0) + fo;
+                        struct Frag { double2 b0a, b0b, b1a, b1b, a2a, a2b, a3a, a3b; };
+                        auto loadf = [&](Frag& f_, int c) {
+                            const int o = c * (TSZ / 2);
+                            f_.b0a = q0[o]; f_.b0b = q0[o + 64]; f_.b1a = q1[o]; f_.b1b = q1[o + 64];
+                            f_.a2a = q2[o]; f_.a2b = q2[o + 64]; f_.a3a = q3[o]; f_.a3b = q3[o + 64];
+                        };
+#define HIPDRT_STEP7(B0, B1, A2, A3)                                                                    \
+                        p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);               \
+                        p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);               \
+                        p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);               \
+                        p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);               \
+                        e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);               \
+                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);               \
+                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);
+                        auto multf = [&](const Frag& f_) {
+                            HIPDRT_STEP7(f_.b0a.x, f_.b1a.x, f_.a2a.x, f_.a3a.x)
+                            HIPDRT_STEP7(f_.b0a.y, f_.b1a.y, f_.a2a.y, f_.a3a.y)
+                            HIPDRT_STEP7(f_.b0b.x, f_.b1b.x, f_.a2b.x, f_.a3b.x)
+                            HIPDRT_STEP7(f_.b0b.y, f_.b1b.y, f_.a2b.y, f_.a3b.y)
+                        };
+#undef HIPDRT_STEP7
+                        Frag fa, fb;
+                        loadf(fa, 0);
+                        for (int c = 0; c < nc; c += 2) {
+                            loadf(fb, c + 1);
+                            multf(fa);
+                            if (c + 2 < nc) loadf(fa, c + 2);
+                            multf(fb);
+                        }
+                        if (!v3) {
+                            // R3 is pure padding (its operand was a stand-in): no panel tiles, identity diagonal
+                            p30 = (v4d){0, 0, 0, 0}; p31 = (v4d){0, 0, 0, 0}; e21 = (v4d){0, 0, 0, 0};
+                            e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                        }
+                    }
+                }
+                __syncthreads();                                    // (A)
+                if (sm.flag[0]) return false;
+                if (v2) {
+                    double wn1[4], l21[4], wn2[4];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        wn1[s_] = -U[(size_t)(j0 + li) * PLD + 4 * s_ + kq];
+                        l21[s_] = sm.t21[li * DLD + 4 * s_ + kq];
+                        wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
+                    }
+                    v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        x20 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p20[s_], x20, 0, 0, 0);
+                        x30 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p30[s_], x30, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x20[s_], p21, 0, 0, 0);
+                        p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x30[s_], p31, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        x21_ = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p21[s_], x21_, 0, 0, 0);
+                        x31 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p31[s_], x31, 0, 0, 0);
+                    }
+                    {
+                        double2* d0 = const_cast<double2*>(tile2(R2, 2 * jb)) + fo;
+                        d0[0] = make_double2(x20[0], x20[1]);   d0[64] = make_double2(x20[2], x20[3]);
+                        d0[128] = make_double2(x21_[0], x21_[1]); d0[192] = make_double2(x21_[2], x21_[3]);
+                    }
+                    if (v3) {
+                        double2* d0 = const_cast<double2*>(tile2(R3, 2 * jb)) + fo;
+                        d0[0] = make_double2(x30[0], x30[1]);   d0[64] = make_double2(x30[2], x30[3]);
+                        d0[128] = make_double2(x31[0], x31[1]); d0[192] = make_double2(x31[2], x31[3]);
+                    }
+                    // the two chunks just produced complete the next diagonal block: a tile's register image is its own
+                    // operand fragment (register s <-> k-step s)
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x20[s_], e11, 0, 0, 0);
+                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x30[s_], e21, 0, 0, 0);
+                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x30[s_], x30[s_], e22, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x21_[s_], e11, 0, 0, 0);
+                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x31[s_], e21, 0, 0, 0);
+                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x31[s_], x31[s_], e22, 0, 0, 0);
+                    }
+                    stage_dsc(e11);
+                    img21[lane] = e21;
+                    img22[lane] = e22;
+                }
             } else {
-                // ======== wavefronts 1..7: the rows below the diagonal block ==================================
-                const int nothers = ntr - (tb + 2);
-                const int npass = nothers > ROW_PER_PASS ? (nothers + ROW_PER_PASS - 1) / ROW_PER_PASS : 1;
+                // ======== wavefronts 2..7: the rows below ======================================================
+                constexpr int OW = RNW - 2;                       // wavefronts in this role
+                const int nothers = ntr - (tb + 4);
+                const int npass = nothers > OW * RMAXT ? (nothers + OW * RMAXT - 1) / (OW * RMAXT) : 1;
 #pragma unroll 1
                 for (int ps = 0; ps < npass; ++ps) {
                     int T[RMAXT];
                     bool act[RMAXT];
 #pragma unroll
                     for (int u = 0; u < RMAXT; ++u) {
-                        T[u] = tb + 2 + (wv - 1) + u * (RNW - 1) + ps * ROW_PER_PASS;
+                        T[u] = tb + 4 + (wv - 2) + u * OW + ps * OW * RMAXT;
                         act[u] = T[u] < ntr;
                     }
                     // ---- (1) accT = -(S' tile) + sum_c L(Cc, c) L(T, c)' --------------------------------------
@@ -546,7 +633,8 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
     ops.sm.t21 = ops.sm.red + 4 * RNW * 4;
     ops.sm.dsc = ops.sm.t21 + 16 * DLD;
     ops.sm.flag = reinterpret_cast<int*>(ops.sm.dsc + 16 * DLD);
-    ops.sm.vec = ops.sm.dsc + 16 * DLD + 8;
+    ops.sm.img = ops.sm.dsc + 16 * DLD + 8;
+    ops.sm.vec = ops.sm.img + 512;
     ops.sm.dvec = ops.sm.vec + VEC;
     ops.sm.U = ops.sm.dvec + VEC;
     // zero U (the upper-right quarter of every inverse block stays zero) and the padding of vec (read by the
@@ -559,7 +647,7 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
 }
 
 static size_t resident_lds_bytes(int NP) {
-    return ((size_t)NP * PLD + 2 * (size_t)(RNP_MAX + 16 + 32) + 64 + 4 * RNW * 4 + 2 * 16 * DLD + 8) * sizeof(double);
+    return ((size_t)NP * PLD + 2 * (size_t)(RNP_MAX + 16 + 32) + 64 + 4 * RNW * 4 + 2 * 16 * DLD + 8 + 512) * sizeof(double);
 }
 
 // scratch doubles per problem for the tile-packed factor: (NP/16)^2 tiles of 256 doubles

@@ -29,6 +29,24 @@ __device__ __forceinline__ unsigned opaque_u32(unsigned v) {
     return v;
 }
 
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for outstanding global
+// loads (vmcnt), so operand tiles prefetched before the barrier stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// sum over the 4 lanes of a quad (lane ^ 1, lane ^ 2) with DPP quad permutes: VALU speed, no LDS crossbar
+__device__ __forceinline__ double quad_sum(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double o = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true),
+                                __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true));
+    v += o;
+    lo = __double2loint(v); hi = __double2hiint(v);
+    o = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true),
+                         __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true));
+    return v + o;
+}
+
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);

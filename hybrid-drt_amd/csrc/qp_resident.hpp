@@ -437,29 +437,17 @@ struct OpsResident {
         double* vec = sm.vec;
         const double* U = sm.U;
         constexpr int UW = RNW - 1;                 // updater wavefronts
-        const int l4 = lane & 3, g4 = lane >> 2;
+        constexpr int FT = (31 + UW - 1) / UW;      // forward: tiles per updater wavefront
+        constexpr int BC = (32 + UW - 1) / UW;      // backward: chunks per updater wavefront
         PROF_DECL
-        // ---- forward: L y = b -----------------------------------------------------------------------------
-        for (int jb = 0; jb < nblk; ++jb) {
-            const int j0 = jb * NB;
-            const int tb = j0 >> 4;
-            const int tbelow = ntr - (tb + 2);                  // row tiles below the block
-            constexpr int FT = (31 + UW - 1) / UW;              // tiles per updater wavefront
-            double2 lv[FT][4];                                  // [tile][chunk*2 + half]
-            if (wv > 0 && tbelow > 0) {
-#pragma unroll
-                for (int u = 0; u < FT; ++u) {
-                    const int tt = (wv - 1) + u * UW;
-                    if (tt < tbelow) {
-                        const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;   // chunks 2jb, 2jb+1 are adjacent
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) lv[u][q] = p[q * 64];
-                    }
-                }
-            }
-            if (wv == 0) {
-                // y = M b with M = inverse of the block's Cholesky factor (upper-right 16x16 of M is zero)
-                const int r = lane & 31;
+        // Two roles, two code paths with matching barrier sequences (per block: one barrier after the diagonal step,
+        // one after the update).  The barriers order LDS traffic only, so the updaters' operand tiles -- fetched TWO
+        // blocks ahead into alternating register buffers -- stay in flight across them.
+        if (wv == 0) {
+            // ======== wavefront 0: multiply by the inverse 32x32 diagonal blocks ================================
+            const int r = lane & 31;
+            for (int jb = 0; jb < nblk; ++jb) {          // forward: y = M b (upper-right 16x16 of M is zero)
+                const int j0 = jb * NB;
                 const double* Mr = U + (size_t)(j0 + r) * PLD;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -472,149 +460,233 @@ struct OpsResident {
                 const double y = (s0 + s1) + (s2 + s3);
                 __builtin_amdgcn_wave_barrier();
                 if (lane < NB) vec[j0 + lane] = y;
+                lds_barrier();
+                PROF(5);
+                lds_barrier();
+                PROF(6);
             }
-            __syncthreads();
-            PROF(5);
-            if (wv > 0 && tbelow > 0) {
-                // q = 2*chunk + half: lane holds columns 8q + l4 and 8q + l4 + 4 of tile row g4
-                double ya[4], yb[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { ya[q] = vec[j0 + 8 * q + l4]; yb[q] = vec[j0 + 8 * q + l4 + 4]; }
-#pragma unroll
-                for (int u = 0; u < FT; ++u) {
-                    const int tt = (wv - 1) + u * UW;
-                    if (tt < tbelow) {
-                        double pv = 0.0;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) pv += lv[u][q].x * ya[q] + lv[u][q].y * yb[q];
-                        pv += __shfl_xor(pv, 1, 64);
-                        pv += __shfl_xor(pv, 2, 64);
-                        if (l4 == 0) {
-                            const int row = (tb + 2 + tt) * 16 + g4;
-                            if (row < n) vec[row] -= pv;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            PROF(6);
-        }
-        // ---- backward: L' x = y ---------------------------------------------------------------------------
-        for (int jb = nblk - 1; jb >= 0; --jb) {
-            const int j0 = jb * NB;
-            const int tb = j0 >> 4;
-            const int nc = 2 * jb;                              // 16-column chunks left of the block
-            const bool two = (tb + 1) < ntr;                    // second tile-row of the block holds valid rows
-            constexpr int BC = (32 + UW - 1) / UW;              // chunks per updater wavefront
-            double2 lb[BC][4];                                  // [chunk][tile*2 + half]
-            if (wv > 0) {
-#pragma unroll
-                for (int u = 0; u < BC; ++u) {
-                    const int c = (wv - 1) + u * UW;
-                    if (c < nc) {
-                        const double2* p0 = tile2(tb, c) + lane;
-                        const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
-                        lb[u][0] = p0[0]; lb[u][1] = p0[64];
-                        lb[u][2] = p1[0]; lb[u][3] = p1[64];
-                    }
-                }
-            }
-            if (wv == 0) {
-                // x = M' y : lane = column c of M
-                const int c = lane & 31;
-                const double* Mc = U + (size_t)j0 * PLD + c;
+            for (int jb = nblk - 1; jb >= 0; --jb) {     // backward: x = M' y, lane = column of M
+                const int j0 = jb * NB;
+                const double* Mc = U + (size_t)j0 * PLD + r;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-                for (int r = 0; r < NB; r += 4) {
-                    s0 += Mc[(size_t)r * PLD] * vec[j0 + r];
-                    s1 += Mc[(size_t)(r + 1) * PLD] * vec[j0 + r + 1];
-                    s2 += Mc[(size_t)(r + 2) * PLD] * vec[j0 + r + 2];
-                    s3 += Mc[(size_t)(r + 3) * PLD] * vec[j0 + r + 3];
+                for (int q = 0; q < NB; q += 4) {
+                    s0 += Mc[(size_t)q * PLD] * vec[j0 + q];
+                    s1 += Mc[(size_t)(q + 1) * PLD] * vec[j0 + q + 1];
+                    s2 += Mc[(size_t)(q + 2) * PLD] * vec[j0 + q + 2];
+                    s3 += Mc[(size_t)(q + 3) * PLD] * vec[j0 + q + 3];
                 }
                 const double xv = (s0 + s1) + (s2 + s3);
                 __builtin_amdgcn_wave_barrier();
                 if (lane < NB) vec[j0 + lane] = xv;
+                lds_barrier();
+                PROF(7);
+                lds_barrier();
+                PROF(8);
             }
-            __syncthreads();
-            PROF(7);
-            if (wv > 0 && nc > 0) {
-                // x of the block: row g4 of tile tb and of tile tb+1 (zero padding beyond n)
-                const double x0 = vec[j0 + g4];
-                const double x1 = two ? vec[j0 + 16 + g4] : 0.0;
+        } else {
+            // ======== wavefronts 1..7: rank-32 updates ========================================================
+            //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane -> row lane/4,
+            //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
+            const int l4 = lane & 3, g4 = lane >> 2;
+            struct Buf { double2 t[FT > BC ? FT : BC][4]; };
+            // ---- forward: L y = b -------------------------------------------------------------------------
+            auto fpre = [&](Buf& B_, int jb) {          // tiles (tb+2+tt, 2jb..2jb+1): [tile][chunk*2 + half]
+                if (jb < nblk) {
+                    const int tb = 2 * jb, tbelow = ntr - (tb + 2);
 #pragma unroll
-                for (int u = 0; u < BC; ++u) {
-                    const int c = (wv - 1) + u * UW;
-                    if (c < nc) {
-                        // lb[u][0..1] = tile tb halves 0,1 ; lb[u][2..3] = tile tb+1 halves 0,1
-                        double s0 = lb[u][0].x * x0 + lb[u][2].x * x1;     // column 16c + l4
-                        double s1 = lb[u][0].y * x0 + lb[u][2].y * x1;     // column 16c + l4 + 4
-                        double s2 = lb[u][1].x * x0 + lb[u][3].x * x1;     // column 16c + 8 + l4
-                        double s3 = lb[u][1].y * x0 + lb[u][3].y * x1;     // column 16c + 12 + l4
+                    for (int u = 0; u < FT; ++u) {
+                        const int tt = (wv - 1) + u * UW;
+                        if (tt < tbelow) {
+                            const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;   // chunks 2jb, 2jb+1 are adjacent
 #pragma unroll
-                        for (int off = 4; off < 64; off <<= 1) {
-                            s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64);
-                            s2 += __shfl_xor(s2, off, 64); s3 += __shfl_xor(s3, off, 64);
-                        }
-                        if (g4 == 0) {
-                            vec[c * 16 + l4] -= s0;     vec[c * 16 + l4 + 4] -= s1;
-                            vec[c * 16 + 8 + l4] -= s2; vec[c * 16 + 12 + l4] -= s3;
+                            for (int q = 0; q < 4; ++q) B_.t[u][q] = p[q * 64];
                         }
                     }
                 }
+            };
+            auto fstep = [&](Buf& B_, int jb) {
+                const int j0 = jb * NB, tb = 2 * jb, tbelow = ntr - (tb + 2);
+                lds_barrier();
+                if (tbelow > 0) {
+                    // q = 2*chunk + half: lane holds columns 8q + l4 and 8q + l4 + 4 of tile row g4
+                    double ya[4], yb[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { ya[q] = vec[j0 + 8 * q + l4]; yb[q] = vec[j0 + 8 * q + l4 + 4]; }
+#pragma unroll
+                    for (int u = 0; u < FT; ++u) {
+                        const int tt = (wv - 1) + u * UW;
+                        if (tt < tbelow) {
+                            double pv = 0.0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) pv += B_.t[u][q].x * ya[q] + B_.t[u][q].y * yb[q];
+                            pv += __shfl_xor(pv, 1, 64);
+                            pv += __shfl_xor(pv, 2, 64);
+                            if (l4 == 0) {
+                                const int row = (tb + 2 + tt) * 16 + g4;
+                                if (row < n) vec[row] -= pv;
+                            }
+                        }
+                    }
+                }
+                fpre(B_, jb + 2);
+                lds_barrier();
+            };
+            {
+                Buf fa, fb;
+                fpre(fa, 0);
+                fpre(fb, 1);
+                for (int jb = 0; jb < nblk; jb += 2) {
+                    fstep(fa, jb);
+                    if (jb + 1 < nblk) fstep(fb, jb + 1);
+                }
             }
-            __syncthreads();
-            PROF(8);
+            // ---- backward: L' x = y -----------------------------------------------------------------------
+            auto bpre = [&](Buf& B_, int jb) {          // tiles (tb..tb+1, c): [chunk][tile*2 + half]
+                if (jb >= 0) {
+                    const int tb = 2 * jb, nc = 2 * jb;
+                    const bool two = (tb + 1) < ntr;
+#pragma unroll
+                    for (int u = 0; u < BC; ++u) {
+                        const int c = (wv - 1) + u * UW;
+                        if (c < nc) {
+                            const double2* p0 = tile2(tb, c) + lane;
+                            const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
+                            B_.t[u][0] = p0[0]; B_.t[u][1] = p0[64];
+                            B_.t[u][2] = p1[0]; B_.t[u][3] = p1[64];
+                        }
+                    }
+                }
+            };
+            auto bstep = [&](Buf& B_, int jb) {
+                const int j0 = jb * NB, tb = 2 * jb, nc = 2 * jb;
+                const bool two = (tb + 1) < ntr;                    // second tile-row of the block holds valid rows
+                lds_barrier();
+                if (nc > 0) {
+                    // x of the block: row g4 of tile tb and of tile tb+1 (zero padding beyond n)
+                    const double x0 = vec[j0 + g4];
+                    const double x1 = two ? vec[j0 + 16 + g4] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < BC; ++u) {
+                        const int c = (wv - 1) + u * UW;
+                        if (c < nc) {
+                            // t[u][0..1] = tile tb halves 0,1 ; t[u][2..3] = tile tb+1 halves 0,1
+                            double s0 = B_.t[u][0].x * x0 + B_.t[u][2].x * x1;     // column 16c + l4
+                            double s1 = B_.t[u][0].y * x0 + B_.t[u][2].y * x1;     // column 16c + l4 + 4
+                            double s2 = B_.t[u][1].x * x0 + B_.t[u][3].x * x1;     // column 16c + 8 + l4
+                            double s3 = B_.t[u][1].y * x0 + B_.t[u][3].y * x1;     // column 16c + 12 + l4
+#pragma unroll
+                            for (int off = 4; off < 64; off <<= 1) {
+                                s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64);
+                                s2 += __shfl_xor(s2, off, 64); s3 += __shfl_xor(s3, off, 64);
+                            }
+                            if (g4 == 0) {
+                                vec[c * 16 + l4] -= s0;     vec[c * 16 + l4 + 4] -= s1;
+                                vec[c * 16 + 8 + l4] -= s2; vec[c * 16 + 12 + l4] -= s3;
+                            }
+                        }
+                    }
+                }
+                bpre(B_, jb - 2);
+                lds_barrier();
+            };
+            {
+                Buf ba, bb;
+                bpre(ba, nblk - 1);
+                bpre(bb, nblk - 2);
+                for (int jb = nblk - 1; jb >= 0; jb -= 2) {
+                    bstep(ba, jb);
+                    if (jb - 1 >= 0) bstep(bb, jb - 1);
+                }
+            }
         }
     }
 
     // -----------------------------------------------------------------------------------------------------
-    // dvec = P * vec ; rows in pairs per wavefront, 16-byte loads, up to 5 column chunks of 128; the next row pair
-    // is in flight while the current one is reduced
+    // dvec = P * vec from the packed lower tiles (1.2 MB instead of the 2.1 MB row-major matrix): every tile is read
+    // once, as two contiguous 1 KB loads, and used for both  y_T += tile x_C  and  y_C += tile' x_T.  The tiles, in
+    // column-major order, are dealt to the wavefronts in equal contiguous runs; a wavefront keeps the column sums of
+    // its current tile column in registers and adds everything into its OWN partial result vector (the LDS array
+    // of the inverse diagonal blocks is dead between two factorisations and serves as scratch), so the final sum
+    // over wavefronts has a fixed order.
     __device__ __forceinline__ void matvec() {
         const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int l4 = lane & 3, g4 = lane >> 2;
+        const int ntr = (n + 15) >> 4;
+        const int NPd = nch * 16;
         const double* xin = sm.vec;
-        double* out = sm.dvec;
-        const int c0 = 2 * lane;
-        double2 xv[5];
-        int co[5];
+        double* yw = sm.U + (size_t)wv * NPd;               // this wavefront's partial result
+        for (int i = lane; i < NPd; i += 64) yw[i] = 0.0;
+        const int ntile = ntr * (ntr + 1) / 2;
+        const int per = (ntile + RNW - 1) / RNW;
+        const int t0 = wv * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
+        // locate (C, T) of tile t0: column C holds ntr - C tiles (T = C .. ntr-1)
+        int C = 0, rem = t0;
+        while (C < ntr && rem >= ntr - C) { rem -= ntr - C; ++C; }
+        int T = C + rem;
+        struct TileR { double2 d0, d1; };
+        auto tload = [&](TileR& r_, int T_, int C_) {
+            const double2* tile = reinterpret_cast<const double2*>(Ppk + ((size_t)T_ * nchp + C_) * 256);
+            r_.d0 = tile[lane]; r_.d1 = tile[64 + lane];
+        };
+        auto advance = [&](int& T_, int& C_) { if (++T_ == ntr) { ++C_; T_ = C_; } };
+        constexpr int PDM = 4;
+        TileR ring[PDM];
+        int Tp = T, Cp = C;                                   // prefetch cursor
+        int tp = t0;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const int c = c0 + 128 * t;
-            xv[t] = make_double2(c < n ? xin[c] : 0.0, c + 1 < n ? xin[c + 1] : 0.0);
-            co[t] = (c + 1 >= ldp) ? 0 : c;                   // clamp (value is multiplied by xv = 0)
-        }
-        struct Rows { double2 a0[5], a1[5]; };
-        auto load = [&](Rows& r_, int i0) {
-            const int i1 = (i0 + 1 < n) ? i0 + 1 : i0;
-            const double* r0 = P + (size_t)i0 * ldp;
-            const double* r1 = P + (size_t)i1 * ldp;
+        for (int k = 0; k < PDM; ++k) { if (tp < t1) { tload(ring[k], Tp, Cp); advance(Tp, Cp); ++tp; } }
+        double xc0 = 0.0, xc1 = 0.0, xc2 = 0.0, xc3 = 0.0, ca0 = 0.0, ca1 = 0.0, ca2 = 0.0, ca3 = 0.0;
+        int Ccur = -1;
+        auto flush = [&]() {
+            if (Ccur >= 0) {
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                r_.a0[t] = *reinterpret_cast<const double2*>(r0 + co[t]);
-                r_.a1[t] = *reinterpret_cast<const double2*>(r1 + co[t]);
+                for (int off = 4; off < 64; off <<= 1) {
+                    ca0 += __shfl_xor(ca0, off, 64); ca1 += __shfl_xor(ca1, off, 64);
+                    ca2 += __shfl_xor(ca2, off, 64); ca3 += __shfl_xor(ca3, off, 64);
+                }
+                if (g4 == 0) {
+                    double* yc = yw + Ccur * 16 + l4;
+                    yc[0] += ca0; yc[4] += ca1; yc[8] += ca2; yc[12] += ca3;
+                }
             }
         };
-        auto reduce = [&](const Rows& r_, int i0) {
-            double s0 = 0.0, s1 = 0.0;
+        for (int t = t0; t < t1; t += PDM) {
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                s0 += r_.a0[t].x * xv[t].x + r_.a0[t].y * xv[t].y;
-                s1 += r_.a1[t].x * xv[t].x + r_.a1[t].y * xv[t].y;
+            for (int k = 0; k < PDM; ++k) {
+                if (t + k < t1) {
+                    const TileR cur = ring[k];
+                    if (tp < t1) { tload(ring[k], Tp, Cp); advance(Tp, Cp); ++tp; }
+                    if (C != Ccur) {
+                        flush();
+                        Ccur = C;
+                        const double* xc = xin + C * 16 + l4;
+                        xc0 = xc[0]; xc1 = xc[4]; xc2 = xc[8]; xc3 = xc[12];
+                        ca0 = ca1 = ca2 = ca3 = 0.0;
+                    }
+                    // lane: row g4 of the tile, columns l4, l4+4 (d0) and l4+8, l4+12 (d1)
+                    double pr = cur.d0.x * xc0 + cur.d0.y * xc1 + cur.d1.x * xc2 + cur.d1.y * xc3;
+                    pr = quad_sum(pr);
+                    if (l4 == 0) yw[T * 16 + g4] += pr;
+                    if (T != C) {                              // the diagonal tile is stored in full
+                        const double xt = xin[T * 16 + g4];
+                        ca0 += cur.d0.x * xt; ca1 += cur.d0.y * xt; ca2 += cur.d1.x * xt; ca3 += cur.d1.y * xt;
+                    }
+                    advance(T, C);
+                }
             }
-            s0 = wsum(s0);
-            s1 = wsum(s1);
-            if (lane == 0) { out[i0] = s0; if (i0 + 1 < n) out[i0 + 1] = s1; }
-        };
-        constexpr int STEP = 2 * RNW;
-        Rows ra, rb;
-        int i0 = 2 * wv;
-        if (i0 < n) load(ra, i0);
-        for (; i0 < n; i0 += 2 * STEP) {
-            if (i0 + STEP < n) load(rb, i0 + STEP);
-            reduce(ra, i0);
-            if (i0 + 2 * STEP < n) load(ra, i0 + 2 * STEP);
-            if (i0 + STEP < n) reduce(rb, i0 + STEP);
         }
+        flush();
+        __syncthreads();
+        for (int i = tid; i < n; i += RT) {
+            double s_ = 0.0;
+#pragma unroll
+            for (int w = 0; w < RNW; ++w) s_ += sm.U[(size_t)w * NPd + i];
+            sm.dvec[i] = s_;
+        }
+        __syncthreads();
+        // the scratch goes back to the factorisation with its upper-right quarters zero
+        for (int i = tid; i < RNW * NPd; i += RT) sm.U[i] = 0.0;
     }
 };
 

@@ -27,7 +27,7 @@ struct hipdrt_plan {
     // per spectrum
     DevBuf z_re, z_im, rv, w, est_w, x, x_in, q, s, rho, xmx, coef_scale, var_floor;
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
-    DevBuf P, L, Ptmp, qpstate, Ppk;
+    DevBuf P, L, Ptmp, qpstate, Ppk, order;
     // history
     int hist_b = -1, hist_cap = 0;
     DevBuf hist_x, hist_w, hist_rho, hist_qp, hist_rows;
@@ -448,6 +448,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
     HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->Ppk.alloc(cap * qp_ppk_doubles(n) * sizeof(double)));
+    HIPDRT_CHECK(p->order.alloc(cap * sizeof(int)));
     HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
 
     // shared matrices on the device
@@ -610,6 +611,10 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
         launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i());
         LAUNCH_OK();
         tm.mark(2);
+        if (B * sizeof(int) <= 48 * 1024) {     // dispatch order from the previous QP's iteration counts
+            launch_lpt_order(st, B, p->qp_iters.i(), p->active.i(), p->order.i());
+            qa.order = p->order.i();
+        }
         TRY(launch_qp(st, qa));
         tm.mark(3);
         TRY(launch_hyper(st, fs, B, it));

@@ -166,6 +166,7 @@ struct QpArgs {
     double* pcost;        // [B] out (may be null)
     int* status;          // [B] out
     const int* active;    // [B] or null: skip problems with active[b]==0
+    const int* order = nullptr;   // [B] or null: workgroup i solves problem order[i] (longest-first dispatch)
     int* iters_accum;     // [B] or null: += iterations
     double* state;        // scratch [B][16][state_ld] for the IPM iterates
     int state_ld;
@@ -173,6 +174,8 @@ struct QpArgs {
     hipdrt_qp_opts opts;
 };
 int launch_qp(hipStream_t st, const QpArgs& a);
+// order[] = problem indices sorted by descending iteration count of the previous solve (inactive ones last)
+void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active, int* order);
 size_t qp_scratch_ld(int n);
 size_t qp_scratch_doubles(int n);
 inline int qp_state_ld(int n) { return round_up(n, 32) + 32; }

@@ -327,7 +327,7 @@ struct OpsMultipass {
 template <int THREADS, int MAXT, int EPT>
 __global__ __launch_bounds__(THREADS) void qp_kernel(QpArgs a, int PR) {
     constexpr int NW = THREADS / 64;
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
     if (a.active && !a.active[b]) return;
     const int n = a.n;
     extern __shared__ double smem[];
@@ -379,6 +379,31 @@ static int launch_qp_ept(hipStream_t st, const QpArgs& a, int PR, size_t lds) {
     e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("qp launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
     return HIPDRT_OK;
+}
+
+// Longest-processing-time-first dispatch: the iteration count of a spectrum's previous QP predicts the next one's,
+// and workgroups are dispatched in blockIdx order, so starting the long problems first trims the tail of the launch
+// (4 problems per CU with 2..9 iterations each otherwise leave a third of the CUs idle at the end).  Rank by brute
+// force (B^2 comparisons, B ~ 1e3); ties keep index order, so the permutation is deterministic.
+__global__ __launch_bounds__(256) void lpt_order_kernel(int B, const int* __restrict__ iters,
+                                                        const int* __restrict__ active, int* __restrict__ order) {
+    extern __shared__ int keys[];
+    for (int i = threadIdx.x; i < B; i += blockDim.x) keys[i] = (active && !active[i]) ? -1 : iters[i];
+    __syncthreads();
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        const int kb = keys[b];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) {
+            const int kj = keys[j];
+            rank += (kj > kb) || (kj == kb && j < b);
+        }
+        order[rank] = b;
+    }
+}
+
+void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active, int* order) {
+    const int blocks = (B + 255) / 256;
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(blocks), dim3(256), (size_t)B * sizeof(int), st, B, iters, active, order);
 }
 
 static int launch_qp_resident(hipStream_t st, const QpArgs& a) {

@@ -691,7 +691,7 @@ struct OpsResident {
 };
 
 __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
     if (a.active && !a.active[b]) return;
     extern __shared__ double smem[];
     OpsResident ops;

@@ -17,15 +17,32 @@ namespace hipdrt {
 static constexpr int HT = 512;
 static constexpr int HNW = HT / 64;
 
+// DPP moves of a double (two dwords); ctrl: quad_perm 0x00-0xFF, row_ror:n = 0x120 + n
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true),
+                            __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// wavefront sum, every lane gets the total: quad permutes and row rotations (VALU speed) inside the 16-lane rows,
+// v_readlane across the four rows -- no LDS crossbar traffic
 __device__ __forceinline__ double hw_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);          // lane ^ 1
+    v += dpp_mov<0x4E>(v);          // lane ^ 2
+    v += dpp_mov<0x124>(v);         // row_ror:4
+    v += dpp_mov<0x128>(v);         // row_ror:8
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 __device__ __forceinline__ double hw_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmax(v, dpp_mov<0xB1>(v));
+    v = fmax(v, dpp_mov<0x4E>(v));
+    v = fmax(v, dpp_mov<0x124>(v));
+    v = fmax(v, dpp_mov<0x128>(v));
+    return fmax(fmax(lane_bcast(v, 0), lane_bcast(v, 16)), fmax(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 __device__ __forceinline__ double hw_min(double v) {
 #pragma unroll
@@ -230,6 +247,50 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         __syncthreads();
         // gamma = X M X + G/(2 sigma^2) + beta I ; gu = gamma @ diag(sqrt s), zero diagonal
         double gmax = 0.0;
+        if (tpl) {
+            // Toeplitz blocks: gu_ij = x_i m_|i-j| (x_j sqrt s_j) [+ (xh_i / sig2) m1_|i-j| (xh_j sqrt s_j) for k = 0],
+            // so the row sums are two convolutions with vectors prepared once per k; per element: two LDS reads, a
+            // multiply, an add and a max.  The maximum is kept per lane and reduced once after all rows.
+            double* vs = tmp;            // x_j sqrt(s_j)
+            double* vh = tmp2;           // xh_j sqrt(s_j)
+            for (int i = tid; i < nd; i += HT) { vs[i] = xd[i] * sq[i]; vh[i] = xh[i] * sq[i]; }
+            __syncthreads();
+            const double* ck = ctp + k * nd;
+            const double* c1 = ctp + nd;
+            double lmax = 0.0;
+            for (int i = wv; i < nd; i += HNW) {
+                const double xi = xd[i];
+                double s0 = 0.0;
+                if (k == 0) {
+                    const double xhs = xh[i] / sig2;
+                    for (int j = lane; j < nd; j += 64) {
+                        const int dd = i > j ? i - j : j - i;
+                        const double gu = xi * (ck[dd] * vs[j]) + xhs * (c1[dd] * vh[j]);
+                        const double gz = (j == i) ? 0.0 : gu;
+                        s0 += gz;
+                        lmax = fmax(lmax, fabs(gz));
+                    }
+                    s0 = hw_sum(s0);
+                    if (lane == 0) {
+                        bsum[i] = s0;
+                        gdia[i] = ((xi * ck[0]) * xi + ((xh[i] * c1[0]) * xh[i]) / sig2) + beta;
+                    }
+                } else {
+                    double mx0 = 0.0;
+                    for (int j = lane; j < nd; j += 64) {
+                        const int dd = i > j ? i - j : j - i;
+                        const double t0 = ck[dd] * vs[j];
+                        const double tz = (j == i) ? 0.0 : t0;
+                        s0 += tz;
+                        mx0 = fmax(mx0, fabs(tz));
+                    }
+                    s0 = hw_sum(s0);
+                    lmax = fmax(lmax, fabs(xi) * mx0);
+                    if (lane == 0) { bsum[i] = xi * s0; gdia[i] = (xi * ck[0]) * xi + beta; }
+                }
+            }
+            gmax = hw_max(lmax);
+        } else
         for (int i = wv; i < nd; i += HNW) {
             const double* row = Mk + (size_t)i * st.ldm;
             const double* row1 = M1 + (size_t)i * st.ldm;

@@ -123,10 +123,39 @@ __global__ __launch_bounds__(HT) void prep_kernel(FitState st) {
     }
 }
 
-// y[i] = sum_j M[i][j] * v[j] for the rows owned by this wavefront; v in LDS; result to LDS out
+// y[i] = sum_j M[i][j] * v[j] for the rows owned by this wavefront; v in LDS; result to LDS out.  Four rows per
+// pass with 16-byte loads (the row loads of a pass are independent, so they are all in flight together).
 __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld, int nrow, int ncol,
                                             const double* __restrict__ v, double* __restrict__ out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (((ld | ncol) & 1) == 0 && (reinterpret_cast<size_t>(M) & 15) == 0) {
+        for (int i0 = 4 * wv; i0 < nrow; i0 += 4 * HNW) {
+            const double* r0 = M + (size_t)i0 * ld;
+            const double* r1 = M + (size_t)(i0 + 1 < nrow ? i0 + 1 : i0) * ld;
+            const double* r2 = M + (size_t)(i0 + 2 < nrow ? i0 + 2 : i0) * ld;
+            const double* r3 = M + (size_t)(i0 + 3 < nrow ? i0 + 3 : i0) * ld;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            for (int j = 2 * lane; j < ncol; j += 128) {
+                const double2 a0 = *reinterpret_cast<const double2*>(r0 + j);
+                const double2 a1 = *reinterpret_cast<const double2*>(r1 + j);
+                const double2 a2 = *reinterpret_cast<const double2*>(r2 + j);
+                const double2 a3 = *reinterpret_cast<const double2*>(r3 + j);
+                const double vx = v[j], vy = v[j + 1];
+                s0 += a0.x * vx + a0.y * vy;
+                s1 += a1.x * vx + a1.y * vy;
+                s2 += a2.x * vx + a2.y * vy;
+                s3 += a3.x * vx + a3.y * vy;
+            }
+            s0 = hw_sum(s0); s1 = hw_sum(s1); s2 = hw_sum(s2); s3 = hw_sum(s3);
+            if (lane == 0) {
+                out[i0] = s0;
+                if (i0 + 1 < nrow) out[i0 + 1] = s1;
+                if (i0 + 2 < nrow) out[i0 + 2] = s2;
+                if (i0 + 3 < nrow) out[i0 + 3] = s3;
+            }
+        }
+        return;
+    }
     for (int i = wv; i < nrow; i += HNW) {
         const double* row = M + (size_t)i * ld;
         double s = 0.0;

@@ -59,37 +59,45 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
             sqJ[k][c] = (j0 + c < n) ? sqrt(sb_[k * n + j0 + c]) : 0.0;
         }
     }
-    for (int k0 = 0; k0 < m; k0 += GK) {
+    // slab k0+GK is fetched (global -> registers) while slab k0 is multiplied out of LDS; the products with w are
+    // formed only when the slab is written to LDS, so nothing waits on the loads inside the MFMA loop
+    double vi[4], vj[4], wkr = 0.0;
+    auto fetch = [&](int k0) {
         const int k = k0 + sk;
-        double wk = 0.0;
-        if (k < m) wk = wb[k];
-        double vi[4] = {0, 0, 0, 0}, vj[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vi[e] = 0.0; vj[e] = 0.0; }
+        wkr = 0.0;
         if (k < m) {
+            wkr = wb[k];
             const double* row = A + (size_t)k * lda;
             if (vec2) {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     const int ci = i0 + sc + e, cj = j0 + sc + e;
-                    if (ci < n) { const double2 t = *reinterpret_cast<const double2*>(row + ci); vi[e] = wk * t.x; vi[e + 1] = wk * t.y; }
-                    if (!diag && cj < n) { const double2 t = *reinterpret_cast<const double2*>(row + cj); vj[e] = wk * t.x; vj[e + 1] = wk * t.y; }
+                    if (ci < n) { const double2 t = *reinterpret_cast<const double2*>(row + ci); vi[e] = t.x; vi[e + 1] = t.y; }
+                    if (!diag && cj < n) { const double2 t = *reinterpret_cast<const double2*>(row + cj); vj[e] = t.x; vj[e + 1] = t.y; }
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ci = i0 + sc + e, cj = j0 + sc + e;
-                    if (ci < n) vi[e] = wk * row[ci];
-                    if (!diag && cj < n) vj[e] = wk * row[cj];
+                    if (ci < n) vi[e] = row[ci];
+                    if (!diag && cj < n) vj[e] = row[cj];
                 }
             }
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < m; k0 += GK) {
         __syncthreads();   // previous slab fully consumed
-        *reinterpret_cast<double2*>(&sI[sk * GLD + sc]) = make_double2(vi[0], vi[1]);
-        *reinterpret_cast<double2*>(&sI[sk * GLD + sc + 2]) = make_double2(vi[2], vi[3]);
+        *reinterpret_cast<double2*>(&sI[sk * GLD + sc]) = make_double2(wkr * vi[0], wkr * vi[1]);
+        *reinterpret_cast<double2*>(&sI[sk * GLD + sc + 2]) = make_double2(wkr * vi[2], wkr * vi[3]);
         if (!diag) {
-            *reinterpret_cast<double2*>(&sJ[sk * GLD + sc]) = make_double2(vj[0], vj[1]);
-            *reinterpret_cast<double2*>(&sJ[sk * GLD + sc + 2]) = make_double2(vj[2], vj[3]);
+            *reinterpret_cast<double2*>(&sJ[sk * GLD + sc]) = make_double2(wkr * vj[0], wkr * vj[1]);
+            *reinterpret_cast<double2*>(&sJ[sk * GLD + sc + 2]) = make_double2(wkr * vj[2], wkr * vj[3]);
         }
         __syncthreads();
+        if (k0 + GK < m) fetch(k0 + GK);
         const double* sj = diag ? sI : sJ;
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
@@ -98,8 +106,6 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
             double a1 = sI[kr * GLD + wi + 16 + (lane & 15)];
             double b0 = sj[kr * GLD + wj + (lane & 15)];
             double b1 = sj[kr * GLD + wj + 16 + (lane & 15)];
-            // operands swapped: the accumulators hold the TRANSPOSED 16x16 sub-tiles (lane&15 = row, (lane>>4)+4*reg
-            // = column), which is the register image the Cholesky kernel wants for its packed copy
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);

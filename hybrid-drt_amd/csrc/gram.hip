@@ -87,6 +87,14 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
             }
         }
     };
+    // 16x16 sub-tiles that are pure padding (beyond n) or lie above the diagonal (the epilogue takes those elements
+    // from the mirror) are not multiplied at all
+    const int nt16 = (n + 15) >> 4;
+    const int tr0 = __builtin_amdgcn_readfirstlane((i0 + wi) >> 4), tc0 = __builtin_amdgcn_readfirstlane((j0 + wj) >> 4);
+    const bool need00 = tr0 < nt16 && tc0 < nt16 && tr0 >= tc0;
+    const bool need01 = tr0 < nt16 && tc0 + 1 < nt16 && tr0 >= tc0 + 1;
+    const bool need10 = tr0 + 1 < nt16 && tc0 < nt16 && tr0 + 1 >= tc0;
+    const bool need11 = tr0 + 1 < nt16 && tc0 + 1 < nt16 && tr0 + 1 >= tc0 + 1;
     fetch(0);
     for (int k0 = 0; k0 < m; k0 += GK) {
         __syncthreads();   // previous slab fully consumed
@@ -106,10 +114,10 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
             double a1 = sI[kr * GLD + wi + 16 + (lane & 15)];
             double b0 = sj[kr * GLD + wj + (lane & 15)];
             double b1 = sj[kr * GLD + wj + 16 + (lane & 15)];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+            if (need00) acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+            if (need01) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
+            if (need10) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
+            if (need11) acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
         }
     }
 

@@ -443,7 +443,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     for (DevBuf* ib : {&p->active, &p->outer_iters, &p->fit_status, &p->qp_iters_total, &p->qp_status, &p->qp_iters})
         HIPDRT_CHECK(ib->alloc(cap * sizeof(int)));
     HIPDRT_CHECK(p->n_active.alloc(sizeof(int)));
-    HIPDRT_CHECK(p->P.alloc(cap * n * p->ldp * sizeof(double)));
+    if (!qp_packed_only(n)) HIPDRT_CHECK(p->P.alloc(cap * n * p->ldp * sizeof(double)));
     HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
     HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
@@ -572,7 +572,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     LAUNCH_OK();
 
     GramL2 g{};
-    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1;
+    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1; g.sym = p->toeplitz_m;
     for (int k = 0; k < 3; ++k) g.mk[k] = p->mk[k].d();
     g.s = p->s.d(); g.rho = p->rho.d();
 
@@ -587,11 +587,12 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     //      every spectrum (weights = 1, s = s_0, rho = rho_0), only q differs -------------------------------
     tm.mark(1);
     for (int k = 0; k < 3; ++k) g.dfac[k] = p->opts.iw_l2_lambda_0 * p->opts.derivative_weights[k];
-    launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d(), g, p->P.d(), p->ldp, 0, nullptr, p->Ppk.d(), 0, qp_nchp(n));
+    double* const Prow = qp_packed_only(n) ? nullptr : p->P.d();   // row-major P only for the multi-pass QP kernel
+    launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, 0, nullptr, p->Ppk.d(), 0, qp_nchp(n));
     launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), nullptr, p->opts.iw_l1_lambda_0, p->q.d(), nullptr);
     LAUNCH_OK();
     tm.mark(2);
-    qa.P = p->P.d(); qa.p_stride = 0; qa.active = nullptr;
+    qa.P = Prow; qa.p_stride = 0; qa.active = nullptr;
     qa.Ppk = p->Ppk.d(); qa.ppk_stride = 0; qa.nchp = qp_nchp(n);
     TRY(launch_qp(st, qa));
     tm.mark(3);
@@ -606,7 +607,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     for (; it < p->opts.max_iter; ++it) {
         tm.mark(1);
         HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
-        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, p->P.d(), p->ldp, (long long)n * p->ldp, p->active.i(),
+        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, (long long)n * p->ldp, p->active.i(),
                        p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
         launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i());
         LAUNCH_OK();
@@ -678,7 +679,7 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
     hipStream_t st = p->ctx->stream;
     const int n = p->n, m = p->m;
     GramL2 g{};
-    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1;
+    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1; g.sym = p->toeplitz_m;
     for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = p->opts.l2_lambda_0 * p->opts.derivative_weights[k]; }
     g.s = p->s.d() + (size_t)b * 3 * n; g.rho = p->rho.d() + (size_t)b * 3;
     launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d() + (size_t)b * m, g, p->Ptmp.d(), p->ldp, 0, nullptr);

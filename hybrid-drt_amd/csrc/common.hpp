@@ -98,7 +98,10 @@ struct GramL2 {
     double dfac[3];        // l2_lambda_0 * derivative_weight[k]   (0 => order skipped)
     int ns;
     int use_rho;
+    int sym;               // penalty matrices are bitwise symmetric (Toeplitz build): read them along rows
 };
+// true when the QP for n unknowns runs on the kernel that reads P only through its packed tile copy (Ppk)
+bool qp_packed_only(int n);
 void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const GramL2& g,
                     double* P, int ldp, long long p_stride, const int* active, double* Ppk = nullptr,
                     long long ppk_stride = 0, int nchp = 0);

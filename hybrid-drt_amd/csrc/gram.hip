@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
 
     // epilogue: + L2, store lower tile and its mirror.  With the swapped operands the accumulator of lane l, register
     // r is element (row = l&15, column = (l>>4) + 4r) of the sub-tile.
-    double* Pb = P + (size_t)b * p_stride;
+    double* Pb = P ? P + (size_t)b * p_stride : nullptr;   // row-major copy is optional (the resident QP kernel reads Ppk)
     double fac[3] = {0, 0, 0};
     if (g.s) {
 #pragma unroll
@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             if (g.dfac[k] > 0.0) {
-                                double mv = g.mk[k][(size_t)i * g.ldm + j];
+                                // (i, j) = (lane&15, lane>>4 + 4r): reading the mirror element keeps the wave's
+                                // addresses contiguous when the matrices are bitwise symmetric
+                                double mv = g.sym ? g.mk[k][(size_t)j * g.ldm + i] : g.mk[k][(size_t)i * g.ldm + j];
                                 if (i >= g.ns && j >= g.ns) mv *= fac[k];
                                 l2 += (sqI[k][i - i0] * mv) * sqJ[k][j - j0];
                             }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* _
                     } else if (g.l2) {
                         v += g.l2[(size_t)b * g.l2_stride + (size_t)i * g.ldl2 + j];
                     }
-                    if (!(diag && j > i)) {            // upper part of a diagonal tile comes from the mirror
+                    if (Pb && !(diag && j > i)) {      // upper part of a diagonal tile comes from the mirror
                         Pb[(size_t)i * ldp + j] = v;
                         if (i != j) Pb[(size_t)j * ldp + i] = v;
                     }

@@ -419,9 +419,11 @@ static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
     return HIPDRT_OK;
 }
 
+bool qp_packed_only(int n) { return n <= RNP_MAX && !getenv("HIPDRT_QP_MULTIPASS"); }
+
 int launch_qp(hipStream_t st, const QpArgs& a) {
     const int n = a.n;
-    if (n <= RNP_MAX && !getenv("HIPDRT_QP_MULTIPASS")) return launch_qp_resident(st, a);
+    if (qp_packed_only(n)) return launch_qp_resident(st, a);
     constexpr int NW = QP_THREADS / 64;
     // panel rows: as many as keep two workgroups per CU (<= 80 kB each), at most NW*MAXT*16
     const size_t fixed = ((size_t)NB * PLD + 2 * (size_t)n + 4 * NW * 4) * sizeof(double) + 64;

@@ -19,7 +19,7 @@ static constexpr int GK = 16;        // K slab
 static constexpr int GLD = 80;       // LDS row stride in doubles (k-rows land 32 banks apart: conflict-free b64 reads)
 
 
-__global__ __launch_bounds__(256) void gram_kernel(int m, int n, const double* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double* __restrict__ A, int lda,
                                                    const double* __restrict__ w, GramL2 g, double* __restrict__ P,
                                                    int ldp, long long p_stride, const int* __restrict__ active,
                                                    int ntile, double* __restrict__ Ppk, long long ppk_stride, int nchp) {

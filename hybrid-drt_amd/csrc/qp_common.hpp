@@ -35,6 +35,24 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {     // quad_perm 0x00-0xFF, row_ror:n = 0x120 + n
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true),
+                            __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true));
+}
+// Column sums of a tile held as lane = 4*row + l4 with four values per lane (columns l4, l4+4, l4+8, l4+12):
+// the sum over the 16 rows of value v ends up in the lanes of 16-lane row v (lane>>4 == v).  Rows 4-apart are
+// combined with DPP row rotations, the four 16-lane rows with a halving exchange (3 cross-lane moves, not 16).
+__device__ __forceinline__ double colsum4(double s0, double s1, double s2, double s3, int lane) {
+    s0 += dpp_mov_d<0x128>(s0); s1 += dpp_mov_d<0x128>(s1); s2 += dpp_mov_d<0x128>(s2); s3 += dpp_mov_d<0x128>(s3);
+    s0 += dpp_mov_d<0x124>(s0); s1 += dpp_mov_d<0x124>(s1); s2 += dpp_mov_d<0x124>(s2); s3 += dpp_mov_d<0x124>(s3);
+    const bool hi5 = (lane & 32) != 0, hi4 = (lane & 16) != 0;
+    const double k0 = (hi5 ? s2 : s0) + __shfl_xor(hi5 ? s0 : s2, 32, 64);
+    const double k1 = (hi5 ? s3 : s1) + __shfl_xor(hi5 ? s1 : s3, 32, 64);
+    return (hi4 ? k1 : k0) + __shfl_xor(hi4 ? k0 : k1, 16, 64);
+}
+
 // sum over the 4 lanes of a quad (lane ^ 1, lane ^ 2) with DPP quad permutes: VALU speed, no LDS crossbar
 __device__ __forceinline__ double quad_sum(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);

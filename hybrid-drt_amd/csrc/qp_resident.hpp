@@ -520,8 +520,7 @@ struct OpsResident {
                             double pv = 0.0;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) pv += B_.t[u][q].x * ya[q] + B_.t[u][q].y * yb[q];
-                            pv += __shfl_xor(pv, 1, 64);
-                            pv += __shfl_xor(pv, 2, 64);
+                            pv = quad_sum(pv);
                             if (l4 == 0) {
                                 const int row = (tb + 2 + tt) * 16 + g4;
                                 if (row < n) vec[row] -= pv;
@@ -575,15 +574,8 @@ struct OpsResident {
                             double s1 = B_.t[u][0].y * x0 + B_.t[u][2].y * x1;     // column 16c + l4 + 4
                             double s2 = B_.t[u][1].x * x0 + B_.t[u][3].x * x1;     // column 16c + 8 + l4
                             double s3 = B_.t[u][1].y * x0 + B_.t[u][3].y * x1;     // column 16c + 12 + l4
-#pragma unroll
-                            for (int off = 4; off < 64; off <<= 1) {
-                                s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64);
-                                s2 += __shfl_xor(s2, off, 64); s3 += __shfl_xor(s3, off, 64);
-                            }
-                            if (g4 == 0) {
-                                vec[c * 16 + l4] -= s0;     vec[c * 16 + l4 + 4] -= s1;
-                                vec[c * 16 + 8 + l4] -= s2; vec[c * 16 + 12 + l4] -= s3;
-                            }
+                            const double f = colsum4(s0, s1, s2, s3, lane);   // column 16c + l4 + 4*(lane>>4)
+                            if ((lane & 12) == 0) vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
                         }
                     }
                 }
@@ -640,15 +632,8 @@ struct OpsResident {
         int Ccur = -1;
         auto flush = [&]() {
             if (Ccur >= 0) {
-#pragma unroll
-                for (int off = 4; off < 64; off <<= 1) {
-                    ca0 += __shfl_xor(ca0, off, 64); ca1 += __shfl_xor(ca1, off, 64);
-                    ca2 += __shfl_xor(ca2, off, 64); ca3 += __shfl_xor(ca3, off, 64);
-                }
-                if (g4 == 0) {
-                    double* yc = yw + Ccur * 16 + l4;
-                    yc[0] += ca0; yc[4] += ca1; yc[8] += ca2; yc[12] += ca3;
-                }
+                const double f = colsum4(ca0, ca1, ca2, ca3, lane);
+                if ((lane & 12) == 0) yw[Ccur * 16 + l4 + 4 * (lane >> 4)] += f;
             }
         };
         for (int t = t0; t < t1; t += PDM) {

@@ -57,6 +57,9 @@ SIGNATURES = {
                                 C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp],
     "hipdrt_impedance_matrix_dev": [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                                     C.c_int, _dp, _dp, _dp, _dp, C.c_int, _vp, _vp, C.c_int, C.POINTER(C.c_float)],
+    "hipdrt_response_lookup": [_vp, C.c_double, C.c_int, C.c_int, _dp, _dp],
+    "hipdrt_response_matrix": [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp,
+                               C.c_int, _dp, _dp],
     "hipdrt_penalty_matrices": [_vp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp],
     "hipdrt_eis_var_matrix": [_vp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp],
     "hipdrt_qp_batch": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.POINTER(QpOpts), _dp, _ip, _dp, _ip],
@@ -206,6 +209,29 @@ class Context:
                                                      _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), int(ny), _vp(dev_re),
                                                      _vp(dev_im), int(repeat), C.byref(ms)))
         return ms.value
+
+    def response_lookup(self, epsilon, td, ny=1000):
+        td = _f64(td)
+        v = np.empty_like(td)
+        _check(self._lib.hipdrt_response_lookup(self._h, float(epsilon), td.size, int(ny), _p(td), _p(v)))
+        return v
+
+    def response_matrix(self, times, tau, step_times, step_sizes, epsilon, mode=MODE_INTERP, lookup=None, ny=1000,
+                        layered=True):
+        times, tau, st, sa = _f64(times), _f64(tau), _f64(step_times), _f64(step_sizes)
+        if st.size != sa.size:
+            raise ValueError("step_times and step_sizes must have the same length")
+        a = np.empty((times.size, tau.size))
+        lay = np.empty((st.size, times.size, tau.size)) if layered else None
+        if lookup is not None:
+            log_td, v = _f64(lookup[0]), _f64(lookup[1])
+            ng, plt, pv = log_td.size, _p(log_td), _p(v)
+        else:
+            ng, plt, pv = 0, None, None
+        _check(self._lib.hipdrt_response_matrix(self._h, _p(times), times.size, _p(tau), tau.size, _p(st), _p(sa), st.size,
+                                                int(mode), float(epsilon), ng, plt, pv, int(ny), _p(a),
+                                                _p(lay) if layered else None))
+        return a, lay
 
     def penalty_matrices(self, ln_tau, epsilon, toeplitz):
         ln_tau = _f64(ln_tau)

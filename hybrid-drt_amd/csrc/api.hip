@@ -139,6 +139,60 @@ int hipdrt_impedance_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, 
     return HIPDRT_OK;
 }
 
+int hipdrt_response_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, const double* td, double* v) {
+    HIPDRT_REQUIRE(ctx && td && v, "NULL pointer");
+    HIPDRT_REQUIRE(ngrid >= 2 && ny >= 2 && ny <= 6000, "ngrid >= 2, 2 <= ny <= 6000");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dtd, dv;
+    const size_t gb = (size_t)ngrid * sizeof(double);
+    TRY(upload(dtd, td, gb, st));
+    HIPDRT_CHECK(dv.alloc(gb));
+    launch_response_lookup(st, epsilon, ngrid, ny, dtd.d(), dv.d());
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(v, dv.p, gb, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+int hipdrt_response_matrix(hipdrt_ctx* ctx, const double* times, int nt, const double* tau, int ntau,
+                           const double* step_times, const double* step_sizes, int nsteps, int mode, double epsilon,
+                           int ngrid, const double* log_td, const double* v, int ny, double* a, double* layered) {
+    HIPDRT_REQUIRE(ctx && times && tau && step_times && step_sizes && a, "NULL pointer");
+    HIPDRT_REQUIRE(nt >= 1 && ntau >= 1 && nsteps >= 1, "nt, ntau, nsteps >= 1");
+    HIPDRT_REQUIRE(mode == HIPDRT_MODE_INTERP || mode == HIPDRT_MODE_TRAPZ, "mode must be INTERP or TRAPZ");
+    if (mode == HIPDRT_MODE_INTERP) {
+        HIPDRT_REQUIRE(log_td && v && ngrid >= 2, "interpolate_grids must be provided for integrate_method 'interp'");
+        HIPDRT_REQUIRE(3 * (size_t)ngrid * sizeof(double) <= 150 * 1024, "lookup too long for LDS staging");
+    } else {
+        HIPDRT_REQUIRE(ny >= 2 && ny <= 6000, "2 <= ny <= 6000");
+    }
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dt, dtau, dst, dsa, lut3, da, dl;
+    TRY(upload(dt, times, (size_t)nt * sizeof(double), st));
+    TRY(upload(dtau, tau, (size_t)ntau * sizeof(double), st));
+    TRY(upload(dst, step_times, (size_t)nsteps * sizeof(double), st));
+    TRY(upload(dsa, step_sizes, (size_t)nsteps * sizeof(double), st));
+    if (mode == HIPDRT_MODE_INTERP) {
+        const size_t gb = (size_t)ngrid * sizeof(double);
+        HIPDRT_CHECK(lut3.alloc(3 * gb));
+        HIPDRT_CHECK(hipMemcpyAsync(lut3.d(), log_td, gb, hipMemcpyHostToDevice, st));
+        HIPDRT_CHECK(hipMemcpyAsync(lut3.d() + ngrid, v, gb, hipMemcpyHostToDevice, st));
+        launch_lookup_slopes(st, ngrid, lut3.d(), lut3.d() + ngrid, lut3.d() + 2 * (size_t)ngrid);
+    }
+    const size_t ab = (size_t)nt * ntau * sizeof(double);
+    HIPDRT_CHECK(da.alloc(ab));
+    if (layered) HIPDRT_CHECK(dl.alloc(ab * nsteps));
+    launch_response_matrix(st, dt.d(), nt, dtau.d(), ntau, dst.d(), dsa.d(), nsteps, mode, epsilon, ngrid, lut3.d(), ny,
+                           da.d(), layered ? dl.d() : nullptr);
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(a, da.p, ab, hipMemcpyDeviceToHost, st));
+    if (layered) HIPDRT_CHECK(hipMemcpyAsync(layered, dl.p, ab * nsteps, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
 // lut6 = {log_wt_re, z_re, slope_re, log_wt_im, z_im, slope_im}
 static int build_lut6(hipStream_t st, DevBuf& lut6, int ngrid, const double* log_wt_re, const double* z_re,
                       const double* log_wt_im, const double* z_im, bool z_on_device) {

@@ -79,6 +79,10 @@ void launch_lookup_slopes(hipStream_t st, int ngrid, const double* xp, const dou
 void launch_impedance_matrix(hipStream_t st, int B, int freq_batched, const double* freq, int nf, const double* tau,
                              int ntau, int mode, int toeplitz, double eps, int ngrid, const double* lut6, int ny,
                              double* a_re, double* a_im, double* cr_scratch);
+void launch_response_lookup(hipStream_t st, double eps, int ngrid, int ny, const double* td, double* v);
+void launch_response_matrix(hipStream_t st, const double* times, int nt, const double* tau, int ntau,
+                            const double* step_times, const double* step_sizes, int nsteps, int mode, double eps,
+                            int ngrid, const double* lut3, int ny, double* a, double* layered);
 void launch_penalty(hipStream_t st, const double* ln_tau, int n, double eps, int toeplitz, double* m0, double* m1,
                     double* m2, int ld, int pad);
 void launch_eis_vmm(hipStream_t st, const double* freq, int nf, double vmm_eps, double reim_cor, int uniform,

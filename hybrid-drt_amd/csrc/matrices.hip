@@ -3,6 +3,8 @@
 //
 //  lookup_kernel          basis.generate_impedance_lookup        hybdrt/matrices/basis.py:648-669
 //  impedance_*_kernel     mat1d.construct_impedance_matrix        hybdrt/matrices/mat1d.py:212-374
+//  response_lookup_kernel basis.generate_response_lookup          hybdrt/matrices/basis.py:672-689, 616-618
+//  response_*_kernel      mat1d.construct_response_matrix         hybdrt/matrices/mat1d.py:16-122
 //  penalty_kernel         mat1d.construct_integrated_derivative_matrix  mat1d.py:125-209, basis.py:382-395
 //  eis_vmm_kernel         mat1d.construct_eis_var_matrix          mat1d.py:493-515
 //
@@ -293,6 +295,96 @@ __global__ void penalty_kernel(const double* __restrict__ ln_tau, int n, double 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Time response of the Gaussian basis to ideal galvanostatic steps (chrono / hybrid fits)
+// ---------------------------------------------------------------------------------------------------------
+// integrand (basis.py:616-618): phi(y) * (1 - exp(-t / (tau * e^y))); one wavefront integrates one (t, tau) pair
+__device__ __forceinline__ double trapz_response(const double* ys, const double* phis, const double* eys, int ny,
+                                                 double tau, double t, int lane) {
+    double s = 0.0;
+    for (int j = lane; j < ny - 1; j += 64) {
+        const double f0 = phis[j] * (1.0 - exp(-t / (tau * eys[j])));
+        const double f1 = phis[j + 1] * (1.0 - exp(-t / (tau * eys[j + 1])));
+        const double d = ys[j + 1] - ys[j];
+        s += d * (f1 + f0) / 2.0;
+    }
+    return wave_sum(s);
+}
+
+// v[i] = trapz over y of the integrand at t/tau = td[i]; grid: ceil(ngrid / 4) blocks of 256 threads
+__global__ __launch_bounds__(256) void response_lookup_kernel(double eps, int ngrid, int ny,
+                                                              const double* __restrict__ td, double* __restrict__ v) {
+    extern __shared__ double sm[];
+    double* ys = sm; double* phis = sm + ny; double* eys = sm + 2 * ny;
+    fill_y_tables(ys, phis, eys, ny, eps);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ngrid) return;
+    const double r = trapz_response(ys, phis, eys, ny, 1.0, td[g], lane);
+    if (lane == 0) v[g] = r;
+}
+
+// interp mode: rows after a step hold np.interp(ln((t - t_k)/tau), log_td, v) * size_k, earlier rows 0; A = sum over
+// the steps in order.  lut3 = {log_td, v, slope}[ngrid] staged in LDS; block = 256 columns x rows_per_block rows.
+__global__ __launch_bounds__(256) void response_interp_kernel(const double* __restrict__ times, int nt,
+                                                              const double* __restrict__ tau, int ntau,
+                                                              const double* __restrict__ step_times,
+                                                              const double* __restrict__ step_sizes, int nsteps,
+                                                              int ngrid, const double* __restrict__ lut3, int rpb,
+                                                              double* __restrict__ a, double* __restrict__ layered) {
+    extern __shared__ double sm[];
+    for (int i = threadIdx.x; i < 3 * ngrid; i += blockDim.x) sm[i] = lut3[i];
+    __syncthreads();
+    const double* xp = sm; const double* fp = sm + ngrid; const double* sl = sm + 2 * ngrid;
+    const double x0 = xp[0], inv_dx = (double)(ngrid - 1) / (xp[ngrid - 1] - xp[0]);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ntau) return;
+    const double tc = tau[c];
+    const int r1 = min(nt, (int)(blockIdx.y + 1) * rpb);
+    for (int r = blockIdx.y * rpb; r < r1; ++r) {
+        const double t = times[r];
+        double acc = 0.0;
+        for (int k = 0; k < nsteps; ++k) {
+            const double st = step_times[k];
+            double val = 0.0;
+            if (t > st) val = np_interp(log((t - st) / tc), xp, fp, sl, ngrid, x0, inv_dx) * step_sizes[k];
+            if (layered) layered[((size_t)k * nt + r) * ntau + c] = val;
+            acc += val;
+        }
+        a[(size_t)r * ntau + c] = acc;
+    }
+}
+
+// trapz mode: one wavefront per entry, ny-point trapezoid per step; grid (ceil(ntau/16), nt)
+__global__ __launch_bounds__(256) void response_trapz_kernel(const double* __restrict__ times, int nt,
+                                                             const double* __restrict__ tau, int ntau,
+                                                             const double* __restrict__ step_times,
+                                                             const double* __restrict__ step_sizes, int nsteps,
+                                                             double eps, int ny, double* __restrict__ a,
+                                                             double* __restrict__ layered) {
+    extern __shared__ double sm[];
+    double* ys = sm; double* phis = sm + ny; double* eys = sm + 2 * ny;
+    fill_y_tables(ys, phis, eys, ny, eps);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.y;
+    const double t = times[r];
+    for (int q = 0; q < 4; ++q) {
+        const int c = blockIdx.x * 16 + q * 4 + wv;
+        if (c >= ntau) continue;
+        double acc = 0.0;
+        for (int k = 0; k < nsteps; ++k) {
+            const double st = step_times[k];
+            double val = 0.0;
+            if (t > st) val = trapz_response(ys, phis, eys, ny, tau[c], t - st, lane) * step_sizes[k];
+            if (layered && lane == 0) layered[((size_t)k * nt + r) * ntau + c] = val;
+            acc += val;
+        }
+        if (lane == 0) a[(size_t)r * ntau + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // EIS variance-estimation matrix: one 256-thread block per row of the (2nf x 2nf) matrix
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void eis_vmm_kernel(const double* __restrict__ freq, int nf, double ve, double cor,
@@ -369,6 +461,26 @@ void launch_impedance_matrix(hipStream_t st, int B, int freq_batched, const doub
     } else {
         hipLaunchKernelGGL(impedance_trapz_kernel, dim3((ntau + 15) / 16, nf, B), dim3(256), 3 * ny * sizeof(double),
                            st, freq_batched, freq, nf, tau, ntau, eps, ny, a_re, a_im);
+    }
+}
+
+void launch_response_lookup(hipStream_t st, double eps, int ngrid, int ny, const double* td, double* v) {
+    hipLaunchKernelGGL(response_lookup_kernel, dim3((ngrid + 3) / 4), dim3(256), 3 * ny * sizeof(double), st, eps, ngrid, ny,
+                       td, v);
+}
+
+void launch_response_matrix(hipStream_t st, const double* times, int nt, const double* tau, int ntau,
+                            const double* step_times, const double* step_sizes, int nsteps, int mode, double eps,
+                            int ngrid, const double* lut3, int ny, double* a, double* layered) {
+    if (mode == HIPDRT_MODE_INTERP) {
+        int rpb = 32;
+        while (rpb > 1 && (long long)((ntau + 255) / 256) * ((nt + rpb - 1) / rpb) < 1024) rpb /= 2;
+        hipLaunchKernelGGL(response_interp_kernel, dim3((ntau + 255) / 256, (nt + rpb - 1) / rpb), dim3(256),
+                           3 * (size_t)ngrid * sizeof(double), st, times, nt, tau, ntau, step_times, step_sizes, nsteps,
+                           ngrid, lut3, rpb, a, layered);
+    } else {
+        hipLaunchKernelGGL(response_trapz_kernel, dim3((ntau + 15) / 16, nt), dim3(256), 3 * ny * sizeof(double), st,
+                           times, nt, tau, ntau, step_times, step_sizes, nsteps, eps, ny, a, layered);
     }
 }
 

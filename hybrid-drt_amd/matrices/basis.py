@@ -18,3 +18,19 @@ def generate_impedance_lookup(basis_type, epsilon, grid_points=2000, zga_params=
     wt_im = np.logspace(-im_lim, im_lim, grid_points)
     z_re, z_im = _ffi.get_context(device).impedance_lookup(epsilon, wt_re, wt_im, ny=1000)
     return (np.log(wt_re), z_re), (np.log(wt_im), z_im)
+
+
+def generate_response_lookup(basis_type, op_mode, step_model, epsilon, grid_points=2000, tau_rise=None,
+                             zga_params=None, device=0):
+    """basis.generate_response_lookup (hybdrt/matrices/basis.py:672-689).
+
+    Returns (log_td_grid, response_grid): the step response of one basis function as a function of
+    ``(t - t_step) / tau`` on the reference's ``np.logspace(-6, 2, n)`` grid; the 1000-point trapezoid integrals
+    (integrand basis.py:616-618) run on the device, one wavefront per table entry."""
+    if basis_type != 'gaussian':
+        raise NotImplementedError("only the default gaussian basis is on the hot path (Cole-Cole/zga need mitlef)")
+    if op_mode != 'galv' or step_model != 'ideal':
+        raise NotImplementedError("only galvanostatic ideal steps (the fit_chrono / fit_hybrid defaults) are built")
+    td_grid = np.logspace(-6, 2, grid_points)
+    response_grid = _ffi.get_context(device).response_lookup(epsilon, td_grid, ny=1000)
+    return np.log(td_grid), response_grid

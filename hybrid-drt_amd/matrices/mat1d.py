@@ -78,6 +78,37 @@ def construct_impedance_matrix(frequencies, part, tau=None, basis_type='gaussian
     return a_re if part == 'real' else a_im
 
 
+def construct_response_matrix(basis_tau, times, step_model, step_times, step_sizes, basis_type='gaussian',
+                              epsilon=0.975, tau_rise=None, op_mode='galv', integrate_method='trapz',
+                              integrate_points=1000, zga_params=None, interpolate_grids=None, device=0):
+    """mat1d.construct_response_matrix (hybdrt/matrices/mat1d.py:16-122): returns (A, A_layered) with
+    ``A @ x`` the time response to the current steps; ``A_layered[k]`` is the contribution of step k.
+    Built for the fit defaults (gaussian basis, galvanostatic, ideal step); 'interp' needs ``interpolate_grids``
+    = (log_td_grid, response_grid) from ``basis.generate_response_lookup``."""
+    if step_model not in ('ideal', 'expdecay'):
+        raise ValueError(f'Invalid step_model {step_model}. Options: ideal, expdecay')
+    if op_mode not in ('galv', 'pot'):
+        raise ValueError(f'Invalid op_mode {op_mode}. Options: galv, pot')
+    if basis_type != 'gaussian' or op_mode != 'galv' or step_model != 'ideal':
+        raise NotImplementedError("only gaussian basis / galvanostatic / ideal step are on the hot path")
+    if integrate_method == 'interp':
+        if interpolate_grids is None:
+            raise ValueError("interpolate_grids must be provided for integrate_method 'interp'")
+        mode = _ffi.MODE_INTERP
+    elif integrate_method == 'trapz':
+        mode = _ffi.MODE_TRAPZ
+    else:
+        raise NotImplementedError("integrate_method 'quad' is not built (scipy.integrate.quad on the host in the reference)")
+    step_times = np.asarray(step_times, dtype=float)
+    step_sizes = np.asarray(step_sizes, dtype=float)
+    times = np.asarray(times, dtype=float)
+    basis_tau = np.asarray(basis_tau, dtype=float)
+    if step_times.size == 0:
+        return np.zeros((times.size, basis_tau.size)), np.zeros((0, times.size, basis_tau.size))
+    return _ffi.get_context(device).response_matrix(times, basis_tau, step_times, step_sizes, epsilon, mode=mode,
+                                                    lookup=interpolate_grids, ny=integrate_points, layered=True)
+
+
 def construct_integrated_derivative_matrix(basis_grid, basis_type='gaussian', order=1, epsilon=1, zga_params=None,
                                            integration_limits=None, device=0):
     """mat1d.construct_integrated_derivative_matrix (hybdrt/matrices/mat1d.py:125-209), orders 0-2."""

@@ -74,6 +74,21 @@ int hipdrt_impedance_matrix_dev(hipdrt_ctx* ctx, int B, int freq_batched, const 
                                 const double* log_wt_im, const double* z_im, int ny,
                                 void* a_re_dev, void* a_im_dev, int repeat, float* elapsed_ms);
 
+/* basis.generate_response_lookup (hybdrt/matrices/basis.py:672-689; integrand basis.py:616-618), Gaussian basis,
+ * galvanostatic ideal step.
+ * in : td[ngrid]   the (t - t_step)/tau abscissae (np.logspace(-6, 2, ngrid))
+ * out: v[ngrid]    ny-point trapezoid integrals over y = linspace(-20,20,ny)                            */
+int hipdrt_response_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, const double* td, double* v);
+
+/* mat1d.construct_response_matrix (hybdrt/matrices/mat1d.py:16-122) for basis_type='gaussian', op_mode='galv',
+ * step_model='ideal'.  times[nt], tau[ntau], step_times/step_sizes[nsteps]; mode INTERP uses the lookup
+ * (log_td, v of length ngrid, np.interp semantics incl. end clamping), mode TRAPZ integrates ny points.
+ * out: a[nt][ntau] = sum over steps; layered[nsteps][nt][ntau] per step (may be NULL)                   */
+int hipdrt_response_matrix(hipdrt_ctx* ctx, const double* times, int nt, const double* tau, int ntau,
+                           const double* step_times, const double* step_sizes, int nsteps, int mode,
+                           double epsilon, int ngrid, const double* log_td, const double* v, int ny,
+                           double* a, double* layered);
+
 /* mat1d.construct_integrated_derivative_matrix (hybdrt/matrices/mat1d.py:125-209), orders 0,1,2 of the
  * Gaussian basis (closed forms basis.py:382-395).  toeplitz != 0: first column scattered (mat1d.py:158-168).
  * out: m0, m1, m2 each [n][n]                                                                        */

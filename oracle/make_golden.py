@@ -110,9 +110,62 @@ def run_trapz_matrices(name, freq, tau, eps):
     print(f"{name}: trapz matrices {out['A_real'].shape}")
 
 
+def chrono_times(n_pre, n_post, t_step, dt_pre=5e-4, t_lo=1e-4, t_hi=50.0):
+    """sample times of a step experiment: n_pre uniform samples ending at the step, n_post log-uniform after it"""
+    pre = t_step - dt_pre * np.arange(n_pre, 0, -1) + dt_pre
+    return np.concatenate([pre, t_step + np.logspace(np.log10(t_lo), np.log10(t_hi), n_post)])
+
+
+def run_response_matrices():
+    """survey row a3: basis.generate_response_lookup (basis.py:672-689) and mat1d.construct_response_matrix
+    (mat1d.py:16-122), gaussian basis / galvanostatic / ideal step, through the reference itself"""
+    sys.path.insert(0, os.path.join(HERE, "refshim"))
+    import oracle_boot  # noqa: F401
+    from hybdrt.matrices import basis, mat1d
+    out = {}
+    tau = np.logspace(-7, 3, 96)
+    eps = 1 / np.mean(np.diff(np.log(tau)))
+    for tag, e in (("eps_grid", eps), ("eps_4p34", 10 / np.log(10))):
+        lg, rg = basis.generate_response_lookup('gaussian', 'galv', 'ideal', e, 2000)
+        out[f"lookup_{tag}_eps"] = e
+        out[f"lookup_{tag}_log_td"] = lg
+        out[f"lookup_{tag}_v"] = rg
+    grids = (out["lookup_eps_grid_log_td"], out["lookup_eps_grid_v"])
+    times = chrono_times(24, 136, 0.05)
+    cases = {
+        "one_step": (np.array([0.05]), np.array([1e-3])),
+        "three_steps": (np.array([0.05, 1.0, 5.0]), np.array([1e-3, -2e-3, 1e-3])),
+        "step_after_end": (np.array([0.05, 1e3]), np.array([1e-3, 5e-4])),
+    }
+    out["tau"] = tau
+    out["times"] = times
+    out["epsilon"] = eps
+    for name, (st, sa) in cases.items():
+        a, lay = mat1d.construct_response_matrix(tau, times, 'ideal', st, sa, basis_type='gaussian', epsilon=eps,
+                                                 op_mode='galv', integrate_method='interp', interpolate_grids=grids)
+        out[f"{name}_step_times"] = st
+        out[f"{name}_step_sizes"] = sa
+        out[f"{name}_A"] = a
+        out[f"{name}_layered"] = lay
+    # trapz mode, small
+    tau_s = np.logspace(-5, 1, 20)
+    eps_s = 1 / np.mean(np.diff(np.log(tau_s)))
+    times_s = chrono_times(4, 20, 0.01, t_lo=1e-4, t_hi=10.0)
+    st, sa = np.array([0.01, 0.5]), np.array([2e-3, -1e-3])
+    a, lay = mat1d.construct_response_matrix(tau_s, times_s, 'ideal', st, sa, basis_type='gaussian', epsilon=eps_s,
+                                             op_mode='galv', integrate_method='trapz', integrate_points=1000)
+    out.update(trapz_tau=tau_s, trapz_times=times_s, trapz_epsilon=eps_s, trapz_step_times=st, trapz_step_sizes=sa,
+               trapz_A=a, trapz_layered=lay)
+    np.savez_compressed(os.path.join(OUT, "refrun_response.npz"), **out)
+    print("refrun_response.npz written:", {k: np.shape(v) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, REPO)
+    if "--only-response" in sys.argv:
+        run_response_matrices()
+        return
     from hipdrt import synth
 
     freq_g, z_g = extract_reference_test_vectors()
@@ -142,6 +195,8 @@ def main():
                        1 / np.mean(np.diff(np.log(np.logspace(-6, 1, 64)))))
     from oracle.drt_oracle import get_basis_tau, get_epsilon_from_ppd
     run_trapz_matrices("trapz_71x91_toeplitz", freq_g, get_basis_tau(freq_g), get_epsilon_from_ppd(10))
+    # (7) chrono response lookup + matrices (survey row a3)
+    run_response_matrices()
 
 
 if __name__ == "__main__":

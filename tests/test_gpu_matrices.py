@@ -135,3 +135,79 @@ def test_eis_var_matrix(ctx):
     np.testing.assert_allclose(mat1d.construct_eis_var_matrix(g["freq"], 0.25, 0.25, None), g["vmm"], rtol=RTOL)
     np.testing.assert_allclose(mat1d.construct_eis_var_matrix(g["freq"], 0.25, 0.25, 'uniform'),
                                orc.construct_eis_var_matrix(g["freq"], 0.25, 0.25, 'uniform'), rtol=RTOL)
+
+
+# ---- chrono response path (survey row a3): basis.generate_response_lookup / mat1d.construct_response_matrix ----
+
+def test_response_lookup_vs_reference_fixture(ctx):
+    from hipdrt.matrices import basis
+    g = load("refrun_response.npz")
+    for tag in ("eps_grid", "eps_4p34"):
+        log_td, v = basis.generate_response_lookup('gaussian', 'galv', 'ideal', float(g[f"lookup_{tag}_eps"]), 2000)
+        np.testing.assert_array_equal(log_td, g[f"lookup_{tag}_log_td"])
+        # the integrand's 1 - exp(-x) cancels for x -> 0 (entries ~1e-7 at td = 1e-6), so the reference's own values
+        # carry an absolute rounding error of ~1e-16; beyond that floor the usual 1e-12 relative holds
+        np.testing.assert_allclose(v, g[f"lookup_{tag}_v"], rtol=RTOL, atol=1e-15)
+
+
+@pytest.mark.parametrize("case", ["one_step", "three_steps", "step_after_end"])
+def test_response_matrix_interp_vs_reference_fixture(ctx, case):
+    from hipdrt.matrices import mat1d
+    g = load("refrun_response.npz")
+    grids = (g["lookup_eps_grid_log_td"], g["lookup_eps_grid_v"])
+    a, lay = mat1d.construct_response_matrix(g["tau"], g["times"], 'ideal', g[f"{case}_step_times"],
+                                             g[f"{case}_step_sizes"], epsilon=float(g["epsilon"]),
+                                             integrate_method='interp', interpolate_grids=grids)
+    ref_a, ref_l = g[f"{case}_A"], g[f"{case}_layered"]
+    assert a.shape == ref_a.shape and lay.shape == ref_l.shape
+    # rows at or before a step are exactly zero in that layer
+    np.testing.assert_array_equal(lay == 0.0, ref_l == 0.0)
+    # abscissa ln((t - t_k)/tau) differs from numpy's by <= 1 ulp of libm's log -> ~1e-13 relative in the interpolant
+    np.testing.assert_allclose(lay, ref_l, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(a, ref_a, rtol=1e-11, atol=1e-18)
+
+
+def test_response_matrix_trapz_vs_reference_fixture(ctx):
+    from hipdrt.matrices import mat1d
+    g = load("refrun_response.npz")
+    a, lay = mat1d.construct_response_matrix(g["trapz_tau"], g["trapz_times"], 'ideal', g["trapz_step_times"],
+                                             g["trapz_step_sizes"], epsilon=float(g["trapz_epsilon"]),
+                                             integrate_method='trapz', integrate_points=1000)
+    # same cancellation floor as the lookup, scaled by the step size (2e-3)
+    np.testing.assert_allclose(lay, g["trapz_layered"], rtol=RTOL, atol=2e-18)
+    np.testing.assert_allclose(a, g["trapz_A"], rtol=RTOL, atol=4e-18)
+
+
+def test_response_matrix_c5_size_vs_oracle(ctx):
+    """C5-sized chrono grid (4096 samples x 1024 tau, one step): HIP vs the CPU restatement on a row subset, and
+    size-independent properties: linearity in the step size, zero rows before the step, monotone saturation."""
+    from hipdrt.matrices import basis, mat1d
+    from oracle import drt_oracle as orc
+    tau = np.logspace(-7, 3, 1024)
+    eps = 1 / np.mean(np.diff(np.log(tau)))
+    t_step = 0.05
+    times = np.concatenate([t_step - 5e-4 * np.arange(96, 0, -1) + 5e-4, t_step + np.logspace(-4, np.log10(50), 4000)])
+    grids = basis.generate_response_lookup('gaussian', 'galv', 'ideal', eps, 2000)
+    a, lay = mat1d.construct_response_matrix(tau, times, 'ideal', [t_step], [1e-3], epsilon=eps,
+                                             integrate_method='interp', interpolate_grids=grids)
+    assert a.shape == (4096, 1024)
+    np.testing.assert_array_equal(a, lay[0])
+    assert not a[:96].any()
+    rows = np.r_[90:100, 500:4096:397]
+    oa, _ = orc.construct_response_matrix(tau, times[rows], [t_step], [1e-3], eps, 'interp', interpolate_grids=grids)
+    np.testing.assert_allclose(a[rows], oa, rtol=1e-11, atol=1e-300)
+    a2, _ = mat1d.construct_response_matrix(tau, times, 'ideal', [t_step], [-2e-3], epsilon=eps,
+                                            integrate_method='interp', interpolate_grids=grids)
+    np.testing.assert_allclose(a2, -2.0 * a, rtol=1e-15, atol=0)
+    assert np.all(np.diff(a[96:], axis=0) >= -1e-18)          # response grows with time ...
+    assert np.all(np.diff(a[96:], axis=1) <= 1e-18)           # ... and is smaller for slower basis functions
+
+
+def test_response_matrix_rejects_unbuilt_branches(ctx):
+    from hipdrt.matrices import mat1d
+    with pytest.raises(ValueError):
+        mat1d.construct_response_matrix([1.0], [1.0], 'ideal', [0.0], [1.0], integrate_method='interp')
+    with pytest.raises(ValueError):
+        mat1d.construct_response_matrix([1.0], [1.0], 'bogus', [0.0], [1.0])
+    with pytest.raises(NotImplementedError):
+        mat1d.construct_response_matrix([1.0], [1.0], 'ideal', [0.0], [1.0], op_mode='pot')

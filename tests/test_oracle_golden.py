@@ -102,3 +102,24 @@ def test_reference_structure_equals_fast():
     a = _fit(g, "fast").fit_parameters
     b = _fit(g, "reference").fit_parameters
     np.testing.assert_allclose(a["x"], b["x"], rtol=1e-10, atol=1e-14)
+
+
+def test_oracle_response_path_matches_reference_run():
+    """survey row a3: response lookup and response matrices (interp with 1 / 3 steps / a step after the last sample,
+    trapz) against the reference's own outputs -- bit-exact, same numpy calls."""
+    from oracle import drt_oracle as orc
+    g = np.load(os.path.join(GOLDEN, "refrun_response.npz"))
+    for tag in ("eps_grid", "eps_4p34"):
+        lg, rg = orc.generate_response_lookup(float(g[f"lookup_{tag}_eps"]))
+        np.testing.assert_array_equal(lg, g[f"lookup_{tag}_log_td"])
+        np.testing.assert_array_equal(rg, g[f"lookup_{tag}_v"])
+    grids = (g["lookup_eps_grid_log_td"], g["lookup_eps_grid_v"])
+    for case in ("one_step", "three_steps", "step_after_end"):
+        a, lay = orc.construct_response_matrix(g["tau"], g["times"], g[f"{case}_step_times"], g[f"{case}_step_sizes"],
+                                               float(g["epsilon"]), 'interp', interpolate_grids=grids)
+        np.testing.assert_array_equal(a, g[f"{case}_A"])
+        np.testing.assert_array_equal(lay, g[f"{case}_layered"])
+    a, lay = orc.construct_response_matrix(g["trapz_tau"], g["trapz_times"], g["trapz_step_times"],
+                                           g["trapz_step_sizes"], float(g["trapz_epsilon"]), 'trapz')
+    np.testing.assert_array_equal(a, g["trapz_A"])
+    np.testing.assert_array_equal(lay, g["trapz_layered"])

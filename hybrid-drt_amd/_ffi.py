@@ -76,6 +76,7 @@ SIGNATURES = {
     "hipdrt_plan_fit": [_vp],
     "hipdrt_plan_download": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip],
     "hipdrt_plan_get_p_matrix": [_vp, C.c_int, _dp],
+    "hipdrt_plan_distribution_var": [_vp, _dp, C.c_int, _dp, _ip],
     "hipdrt_plan_record_history": [_vp, C.c_int],
     "hipdrt_plan_get_history": [_vp, _dp, _dp, _dp, _ip, C.c_int, _ip],
     "hipdrt_plan_timings": [_vp, C.POINTER(C.c_float), _ip],
@@ -330,7 +331,8 @@ class Plan:
     def get(self, which):
         shapes = {"lut_z_re": (self.ngrid,), "lut_z_im": (self.ngrid,), "a_re": (self.nf, self.ntau),
                   "a_im": (self.nf, self.ntau), "rm": (self.m, self.n), "m0": (self.n, self.n),
-                  "m1": (self.n, self.n), "m2": (self.n, self.n), "vmm": (self.m, self.m), "h": (self.n,)}
+                  "m1": (self.n, self.n), "m2": (self.n, self.n), "vmm": (self.m, self.m), "h": (self.n,),
+                  "est_weights": (self.batch, self.m), "rv": (self.batch, self.m)}
         out = np.empty(shapes[which])
         _check(self._lib.hipdrt_plan_get(self._h, which.encode(), _p(out), out.size))
         return out
@@ -339,12 +341,15 @@ class Plan:
         z_re, z_im = _f64(z_re), _f64(z_im)
         _check(self._lib.hipdrt_plan_set_lookup(self._h, _p(z_re), _p(z_im)))
 
+    batch = 0      # spectra of the last upload
+
     def upload(self, z):
         z = np.asarray(z)
         if z.ndim == 1:
             z = z[None, :]
         z_re, z_im = _f64(z.real), _f64(z.imag)
         _check(self._lib.hipdrt_plan_upload(self._h, z.shape[0], _p(z_re), _p(z_im)))
+        self.batch = z.shape[0]
         self.B = z.shape[0]
 
     def fit(self):
@@ -372,6 +377,14 @@ class Plan:
         out = np.empty((self.n, self.n))
         _check(self._lib.hipdrt_plan_get_p_matrix(self._h, int(b), _p(out)))
         return out
+
+    def distribution_var(self, basis_eval, batch):
+        """diag(B P^-1 B') cs^2 for every fitted spectrum; basis_eval (neval, ntau)."""
+        basis_eval = _f64(basis_eval)
+        out = np.empty((int(batch), basis_eval.shape[0]))
+        status = np.empty(int(batch), dtype=np.int32)
+        _check(self._lib.hipdrt_plan_distribution_var(self._h, _p(basis_eval), basis_eval.shape[0], _p(out), _pi(status)))
+        return out, status
 
     def history(self):
         cap = int(self.opts.max_iter)

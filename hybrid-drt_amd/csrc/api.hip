@@ -5,6 +5,7 @@
 #include <memory>
 
 #include "common.hpp"
+#include <vector>
 
 namespace hipdrt {
 static thread_local std::string g_err;
@@ -553,6 +554,8 @@ int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long co
     else if (w == "m0" || w == "m1" || w == "m2") { src = p->mk[w[1] - '0'].d(); rows = cols = p->n; ld = p->ldm; }
     else if (w == "vmm") { src = p->vmm.d(); rows = cols = ld = p->m; }
     else if (w == "h") { src = p->h.d(); rows = 1; cols = ld = p->n; }
+    else if (w == "est_weights") { src = p->est_w.d(); rows = p->B; cols = ld = p->m; }   // per spectrum of the last batch
+    else if (w == "rv") { src = p->rv.d(); rows = p->B; cols = ld = p->m; }
     else { set_error("unknown matrix name: " + w); return HIPDRT_E_INVALID; }
     HIPDRT_REQUIRE(src != nullptr, "matrix not available in this mode");
     HIPDRT_REQUIRE(count == (long long)rows * cols, "count does not match the matrix size");
@@ -739,6 +742,55 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
     launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d() + (size_t)b * m, g, p->Ptmp.d(), p->ldp, 0, nullptr);
     LAUNCH_OK();
     return copy_strided(out, p->Ptmp.d(), n, n, p->ldp, st);
+}
+
+int hipdrt_plan_distribution_var(hipdrt_plan* p, const double* basis_eval, int neval, double* out, int* status) {
+    HIPDRT_REQUIRE(p && basis_eval && out, "NULL pointer");
+    HIPDRT_REQUIRE(p->B > 0, "no fitted batch in the plan");
+    HIPDRT_REQUIRE(neval >= 1, "neval >= 1");
+    HIPDRT_REQUIRE(qp_packed_only(p->n), "posterior variance is only built for n <= 528 unknowns");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const int n = p->n, m = p->m, B = p->B, ntau = p->ntau;
+    const int nex = (neval + 15) / 16, nchp = qp_nchp(n);
+    // final P of every spectrum (calculate_pq with the final weights / s / rho, drt1d.py:1006), packed tiles only
+    GramL2 g{};
+    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1; g.sym = p->toeplitz_m;
+    for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = p->opts.l2_lambda_0 * p->opts.derivative_weights[k]; }
+    g.s = p->s.d(); g.rho = p->rho.d();
+    launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, nullptr, p->ldp, 0, nullptr, p->Ppk.d(),
+                   (long long)qp_ppk_doubles(n), nchp);
+    LAUNCH_OK();
+    // evaluation rows -> packed tiles, shifted past the special-parameter slots
+    DevBuf dbe, bex, scratch, dout, dstat;
+    TRY(upload(dbe, basis_eval, (size_t)neval * ntau * sizeof(double), st));
+    HIPDRT_CHECK(bex.alloc((size_t)nex * nchp * 256 * sizeof(double)));
+    launch_pack_rows(st, neval, ntau, p->ns, dbe.d(), ntau, nex, bex.d(), nchp);
+    LAUNCH_OK();
+    const int chunk = B < 256 ? B : 256;
+    const size_t lsz = dist_var_scratch_doubles(n, nex);
+    HIPDRT_CHECK(scratch.alloc((size_t)chunk * lsz * sizeof(double)));
+    HIPDRT_CHECK(dout.alloc((size_t)B * nex * 16 * sizeof(double)));
+    HIPDRT_CHECK(dstat.alloc((size_t)B * sizeof(int)));
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0) < chunk ? (B - b0) : chunk;
+        TRY(launch_dist_var(st, nb, n, p->Ppk.d() + (size_t)b0 * qp_ppk_doubles(n), (long long)qp_ppk_doubles(n), bex.d(),
+                            nex, scratch.d(), (long long)lsz, dout.d() + (size_t)b0 * nex * 16, (long long)nex * 16,
+                            dstat.i() + b0));
+    }
+    std::vector<double> hv((size_t)B * nex * 16), cs(B);
+    std::vector<int> hs(B);
+    HIPDRT_CHECK(hipMemcpyAsync(hv.data(), dout.p, hv.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(cs.data(), p->coef_scale.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(hs.data(), dstat.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    // estimate_param_cov scales the inverse by coefficient_scale^2 (drt1d.py:4133)
+    for (int b = 0; b < B; ++b) {
+        const double c2 = cs[b] * cs[b];
+        for (int i = 0; i < neval; ++i) out[(size_t)b * neval + i] = hv[((size_t)b * nex) * 16 + i] * c2;
+        if (status) status[b] = hs[b];
+    }
+    return HIPDRT_OK;
 }
 
 int hipdrt_plan_record_history(hipdrt_plan* p, int b) {

@@ -181,6 +181,12 @@ struct QpArgs {
     hipdrt_qp_opts opts;
 };
 int launch_qp(hipStream_t st, const QpArgs& a);
+// posterior variance on an evaluation grid (qp_resident.hpp: cov_kernel_resident); Bex = evaluation rows as packed tiles
+int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long ppk_stride, const double* Bex, int nex,
+                    double* L, long long l_stride, double* out, long long out_stride, int* status);
+size_t dist_var_scratch_doubles(int n, int nex);
+void launch_pack_rows(hipStream_t st, int nrow, int ncol, int col_offset, const double* M, int ldm, int ntile_rows,
+                      double* tiles, int nchp);
 // order[] = problem indices sorted by descending iteration count of the previous solve (inactive ones last)
 void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active, int* order);
 size_t qp_scratch_ld(int n);

@@ -225,6 +225,29 @@ __global__ __launch_bounds__(256) void qvec_kernel(int m, int n, const double* _
     if (i < n) q[(size_t)b * n + i] = -acc + (l1 ? l1[i] : l1_scalar);
 }
 
+// row-major M[nrow][ncol] -> tiles [ntile_rows][nchp][256] in the factor's tile layout, columns shifted right by
+// col_offset (the special-parameter slots), zero padding elsewhere; one wavefront per tile
+__global__ __launch_bounds__(64) void pack_rows_kernel(int nrow, int ncol, int col_offset, const double* __restrict__ M,
+                                                       int ldm, double* __restrict__ tiles, int nchp) {
+    const int tr = blockIdx.y, tc = blockIdx.x, lane = threadIdx.x;
+    double vals[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = tr * 16 + (lane & 15), j = tc * 16 + (lane >> 4) + 4 * r - col_offset;
+        vals[r] = (i < nrow && j >= 0 && j < ncol) ? M[(size_t)i * ldm + j] : 0.0;
+    }
+    double2* tile = reinterpret_cast<double2*>(tiles + ((size_t)tr * nchp + tc) * 256);
+    const int fo = (lane & 15) * 4 + (lane >> 4);
+    tile[fo] = make_double2(vals[0], vals[1]);
+    tile[64 + fo] = make_double2(vals[2], vals[3]);
+}
+
+void launch_pack_rows(hipStream_t st, int nrow, int ncol, int col_offset, const double* M, int ldm, int ntile_rows,
+                      double* tiles, int nchp) {
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(nchp, ntile_rows), dim3(64), 0, st, nrow, ncol, col_offset, M, ldm, tiles,
+                       nchp);
+}
+
 void launch_pack_p(hipStream_t st, int B, int n, const double* P, int ldp, long long p_stride, double* Ppk,
                    long long ppk_stride, int nchp) {
     const int nt = (n + 15) / 16;

@@ -419,6 +419,29 @@ static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
     return HIPDRT_OK;
 }
 
+int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long ppk_stride, const double* Bex, int nex,
+                    double* L, long long l_stride, double* out, long long out_stride, int* status) {
+    if (n > RNP_MAX) { set_error("posterior variance: only built for n <= 528 unknowns"); return HIPDRT_E_INVALID; }
+    const int NP = round_up(n, 32);
+    const size_t lds = resident_lds_bytes(NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_kernel_resident),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(cov): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    CovArgs a;
+    a.B = B; a.n = n; a.Ppk = Ppk; a.ppk_stride = ppk_stride; a.nchp = qp_nchp(n); a.Bex = Bex; a.nex = nex;
+    a.L = L; a.l_stride = l_stride; a.out = out; a.out_stride = out_stride; a.status = status;
+    hipLaunchKernelGGL(cov_kernel_resident, dim3(B), dim3(RT), lds, st, a, NP);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("cov launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    return HIPDRT_OK;
+}
+
+// doubles of factor scratch per spectrum for the posterior-variance kernel: (nch + nex) x nch tiles
+size_t dist_var_scratch_doubles(int n, int nex) {
+    const size_t nch = (size_t)round_up(n, 32) / 16;
+    return (nch + (size_t)nex) * nch * TSZ;
+}
+
 bool qp_packed_only(int n) { return n <= RNP_MAX && !getenv("HIPDRT_QP_MULTIPASS"); }
 
 int launch_qp(hipStream_t st, const QpArgs& a) {

@@ -52,6 +52,10 @@ struct ResSmem {
 struct OpsResident {
     const double* P; int ldp; double* L; int nch; int n; ResSmem sm;   // nch = tiles per tile-row (NP/16)
     const double* Ppk; int nchp;                                       // P in L's tile layout (lower tiles)
+    // Optional extra tile rows appended below the square matrix (tile rows nch .. nch+nex-1 of L, source tiles
+    // Bex[nex][nchp][256]): the factorisation treats them as more panel rows, so they come out as Bex * L^-T --
+    // the multi-right-hand-side triangular solve of the posterior-variance kernel at the price of a taller panel.
+    int nex = 0; const double* Bex = nullptr;
 
     // tile (t, c) starts at ((t*nch + c) * TSZ) doubles; returned in double2 units
     __device__ __forceinline__ const double2* tile2(int t, int c) const {
@@ -123,7 +127,11 @@ struct OpsResident {
     // accumulator image of -(S tile (T, Cc))': lane (li, kq) register rg <-> row li, column kq + 4 rg
     __device__ __forceinline__ v4d init_tile(int T, int Cc, int ntr, int fo, int li, int kq) const {
         v4d a_ = (v4d){0, 0, 0, 0};
-        if (T < ntr) {
+        if (T >= nch) {
+            const double2* tile = reinterpret_cast<const double2*>(Bex + ((size_t)(T - nch) * nchp + Cc) * 256);
+            const double2 d0 = tile[fo], d1 = tile[64 + fo];
+            a_ = (v4d){-d0.x, -d0.y, -d1.x, -d1.y};
+        } else if (T < ntr) {
             const double2* tile = reinterpret_cast<const double2*>(Ppk + ((size_t)T * nchp + Cc) * 256);
             const double2 d0 = tile[fo], d1 = tile[64 + fo];
             a_ = (v4d){-d0.x, -d0.y, -d1.x, -d1.y};
@@ -316,7 +324,9 @@ struct OpsResident {
             } else {
                 // ======== wavefronts 2..7: the rows below ======================================================
                 constexpr int OW = RNW - 2;                       // wavefronts in this role
-                const int nothers = ntr - (tb + 4);
+                const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;   // rows of the square matrix below R3
+                const int nothers = nsq + nex;                               // ... followed by the appended rows
+                const bool two = (tb + 1) < ntr;                             // second tile column is not pure padding
                 const int npass = nothers > OW * RMAXT ? (nothers + OW * RMAXT - 1) / (OW * RMAXT) : 1;
 #pragma unroll 1
                 for (int ps = 0; ps < npass; ++ps) {
@@ -324,8 +334,9 @@ struct OpsResident {
                     bool act[RMAXT];
 #pragma unroll
                     for (int u = 0; u < RMAXT; ++u) {
-                        T[u] = tb + 4 + (wv - 2) + u * OW + ps * OW * RMAXT;
-                        act[u] = T[u] < ntr;
+                        const int slot = (wv - 2) + u * OW + ps * OW * RMAXT;
+                        T[u] = slot < nsq ? tb + 4 + slot : nch + (slot - nsq);
+                        act[u] = slot < nothers;
                     }
                     // ---- (1) accT = -(S' tile) + sum_c L(Cc, c) L(T, c)' --------------------------------------
                     v4d acc[RMAXT][2];
@@ -336,7 +347,7 @@ struct OpsResident {
                             acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
                     if (jb > 0 && act[0]) {
                         const double2* pb0 = tile2(tb, 0) + fo;
-                        const double2* pb1 = tile2(tb + 1, 0) + fo;     // rows below exist => the block is complete
+                        const double2* pb1 = tile2(two ? tb + 1 : tb, 0) + fo;   // stand-in when the row is padding
                         const double2* pa[RMAXT];
 #pragma unroll
                         for (int u = 0; u < RMAXT; ++u) pa[u] = tile2(act[u] ? T[u] : tb, 0) + fo;
@@ -353,13 +364,15 @@ struct OpsResident {
                             for (int u = 0; u < RMAXT; ++u) {
                                 if (act[u]) {
                                     acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0a.x, s_.aa[u].x, acc[u][0], 0, 0, 0);
-                                    acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1a.x, s_.aa[u].x, acc[u][1], 0, 0, 0);
                                     acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0a.y, s_.aa[u].y, acc[u][0], 0, 0, 0);
-                                    acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1a.y, s_.aa[u].y, acc[u][1], 0, 0, 0);
                                     acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0b.x, s_.ab[u].x, acc[u][0], 0, 0, 0);
-                                    acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1b.x, s_.ab[u].x, acc[u][1], 0, 0, 0);
                                     acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0b.y, s_.ab[u].y, acc[u][0], 0, 0, 0);
-                                    acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1b.y, s_.ab[u].y, acc[u][1], 0, 0, 0);
+                                    if (two) {
+                                        acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1a.x, s_.aa[u].x, acc[u][1], 0, 0, 0);
+                                        acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1a.y, s_.aa[u].y, acc[u][1], 0, 0, 0);
+                                        acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1b.x, s_.ab[u].x, acc[u][1], 0, 0, 0);
+                                        acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1b.y, s_.ab[u].y, acc[u][1], 0, 0, 0);
+                                    }
                                 }
                             }
                         };
@@ -674,6 +687,63 @@ struct OpsResident {
         for (int i = tid; i < RNW * NPd; i += RT) sm.U[i] = 0.0;
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// Posterior variance of the distribution on an evaluation grid, the diagonal of
+// drt1d.estimate_distribution_cov (hybdrt/models/drt1d.py:3063-3151, 4116-4138):
+//     var_i = b_i' P^-1 b_i = || L^-1 b_i ||^2 ,   P = L L' ,  b_i = row i of the basis-evaluation matrix
+// (zero in the special-parameter slots).  The rows b_i ride through the factorisation as appended panel rows.
+// ---------------------------------------------------------------------------------------------------------
+struct CovArgs {
+    int B, n;
+    const double* Ppk; long long ppk_stride; int nchp;   // final P of every spectrum, packed tiles
+    const double* Bex; int nex;                          // shared evaluation rows, packed tiles [nex][nchp][256]
+    double* L; long long l_stride;                       // scratch (nch + nex) x nch tiles per spectrum
+    double* out; long long out_stride;                   // [B][16 nex]
+    int* status;                                         // [B]: 0 ok, -1 P not positive definite
+};
+
+__global__ __launch_bounds__(RT) void cov_kernel_resident(CovArgs a, int NP) {
+    const int b = blockIdx.x;
+    extern __shared__ double smem[];
+    OpsResident ops;
+    ops.P = nullptr; ops.ldp = 0;
+    ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
+    ops.Ppk = a.Ppk + (size_t)b * a.ppk_stride; ops.nchp = a.nchp;
+    ops.nex = a.nex; ops.Bex = a.Bex;
+    constexpr int VEC = RNP_MAX + 16 + 32;
+    ops.sm.colbuf = smem;
+    ops.sm.red = ops.sm.colbuf + 64;
+    ops.sm.t21 = ops.sm.red + 4 * RNW * 4;
+    ops.sm.dsc = ops.sm.t21 + 16 * DLD;
+    ops.sm.flag = reinterpret_cast<int*>(ops.sm.dsc + 16 * DLD);
+    ops.sm.img = ops.sm.dsc + 16 * DLD + 8;
+    ops.sm.vec = ops.sm.img + 512;
+    ops.sm.dvec = ops.sm.vec + VEC;
+    ops.sm.U = ops.sm.dvec + VEC;
+    for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
+    for (int i = threadIdx.x; i < VEC; i += RT) { ops.sm.vec[i] = 0.0; ops.sm.dvec[i] = 0.0; }   // no diagonal shift
+    __syncthreads();
+    const bool ok = ops.factor();
+    double* out = a.out + (size_t)b * a.out_stride;
+    if (threadIdx.x == 0) a.status[b] = ok ? 0 : -1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l4 = lane & 3, g4 = lane >> 2;
+    const int nblk = (a.n + NB - 1) / NB;
+    for (int e = wv; e < a.nex; e += RNW) {
+        double s_ = 0.0;
+        if (ok) {
+            for (int c = 0; c < 2 * nblk; ++c) {
+                const double2* t = ops.tile2(ops.nch + e, c) + lane;      // row lane/4, 4 of its 16 columns
+                const double2 d0 = t[0], d1 = t[64];
+                s_ += d0.x * d0.x + d0.y * d0.y + d1.x * d1.x + d1.y * d1.y;
+            }
+            s_ = quad_sum(s_);
+        } else {
+            s_ = __builtin_nan("");
+        }
+        if (l4 == 0) out[e * 16 + g4] = s_;
+    }
+}
 
 __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
     const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;

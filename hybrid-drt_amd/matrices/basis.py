@@ -34,3 +34,15 @@ def generate_response_lookup(basis_type, op_mode, step_model, epsilon, grid_poin
     td_grid = np.logspace(-6, 2, grid_points)
     response_grid = _ffi.get_context(device).response_lookup(epsilon, td_grid, ny=1000)
     return np.log(td_grid), response_grid
+
+
+def construct_func_eval_matrix(basis_grid, eval_grid=None, basis_type='gaussian', epsilon=1, order=0, zga_params=None):
+    """basis.construct_func_eval_matrix (hybdrt/matrices/basis.py:488-514) for the gaussian basis, order 0:
+    em[i, j] = exp(-(epsilon (eval_i - basis_j))^2); a (neval x nbasis) host array (it is an input of the device
+    posterior-variance kernel, not a hot loop)."""
+    if basis_type != 'gaussian' or order != 0:
+        raise NotImplementedError("only the gaussian basis, order 0, is built")
+    basis_grid = np.asarray(basis_grid, dtype=float)
+    eval_grid = basis_grid.copy() if eval_grid is None else np.asarray(eval_grid, dtype=float)
+    xx_basis, xx_eval = np.meshgrid(basis_grid, eval_grid)
+    return np.exp(-(epsilon * (xx_eval - xx_basis)) ** 2)

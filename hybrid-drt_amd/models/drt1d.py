@@ -56,6 +56,7 @@ class DRT:
         self._wt_im = np.logspace(-5.4, 5.4, 2000)
         self._plan = None
         self._plan_key = None
+        self._last_batch = None
         self.basis_tau = None
         self.special_qp_params = {}
         self.fit_parameters = None
@@ -172,7 +173,8 @@ class DRT:
                             'rho_vector': res['rho'][b], 's_vectors': list(res['s_vectors'][b]),
                             'p_matrix': fp['p_matrix'], 'q_vector': fp['q_vector'], 'rm': self._plan.get('rm'),
                             'vmm': self._plan.get('vmm'), 'num_eis': len(frequencies), 'num_chrono': 0,
-                            'qp_iterations': hist['qp_iterations'], 'outer_iterations': int(res['outer_iters'][b])}
+                            'qp_iterations': hist['qp_iterations'], 'outer_iterations': int(res['outer_iters'][b]),
+                            'est_weights': self._plan.get('est_weights')[b], 'rv': self._plan.get('rv')[b]}
         self.cvx_result = {'x': res['x'][b]}
         self.fit_type = 'qphb_eis'
         return fp
@@ -198,6 +200,7 @@ class DRT:
         self.f_fit = frequencies
         plan.record_history(history_of)
         plan.upload(z_batch)
+        self._last_batch = z_batch.shape[0]
         return plan
 
     def fit_staged(self):
@@ -213,6 +216,69 @@ class DRT:
         res['basis_tau'] = self.basis_tau
         res['timings_ms'], res['launches'] = plan.timings()
         return res
+
+    # ---- what DRTMD takes from a finished fit (mapping/drtmd.py:258-279) ----------------------------------------
+    def estimate_distribution_var_batch(self, tau=None, ppd=20, extend_var=False):
+        """Diagonal of DRT.estimate_distribution_cov (drt1d.py:3063-3151; order 0, no normalisation) for every
+        spectrum of the last fitted batch: diag(B P^-1 B') coefficient_scale^2, computed on the device from the
+        Cholesky factor of each final P.  Returns (var (B, len(tau)), ok (B,) bool); ``extend_var`` applies the
+        reference's clamp outside the measured tau range (drt1d.py:3126-3143)."""
+        from ..matrices import basis
+        if self._plan is None or self._last_batch is None:
+            raise Exception('Parameter covariance estimation is only available for qphb fits')
+        if tau is None:
+            tau = self.get_tau_eval(ppd)
+        tau = np.asarray(tau, dtype=float)
+        bm = basis.construct_func_eval_matrix(np.log(self.basis_tau), np.log(tau), self.tau_basis_type,
+                                              epsilon=self.tau_epsilon, order=0)
+        var, status = self._plan.distribution_var(bm, self._last_batch)
+        if extend_var:
+            t_left, t_right = 1 / (2 * np.pi * np.max(self.f_fit)), 1 / (2 * np.pi * np.min(self.f_fit))
+            left_index = int(np.argmin(np.abs(tau - t_left))) + 1
+            right_index = int(np.argmin(np.abs(tau - t_right)))
+            var[:, :left_index] = np.maximum(var[:, :left_index], var[:, left_index][:, None])
+            var[:, right_index:] = np.maximum(var[:, right_index:], var[:, right_index][:, None])
+        return var, status == 0
+
+    def get_tau_eval(self, ppd):
+        """drtbase.get_tau_eval (drtbase.py:263-285): one decade beyond the basis grid on each side."""
+        basis_tau = self.basis_tau
+        log_min, log_max = np.log10(np.min(basis_tau)) - 1, np.log10(np.max(basis_tau)) + 1
+        return np.logspace(log_min, log_max, int((log_max - log_min) * ppd) + 1)
+
+    def estimate_param_cov(self, p_matrix=None):
+        """drt1d.estimate_param_cov (drt1d.py:4116-4138): inv(P) coefficient_scale^2 (host LAPACK; the n x n inverse
+        is not on the batch path, which only needs the distribution variance)."""
+        if p_matrix is None:
+            p_matrix = self.fit_parameters.get('p_matrix', None) if self.fit_parameters else None
+        if p_matrix is None:
+            raise Exception('Parameter covariance estimation is only available for qphb fits')
+        try:
+            return np.linalg.inv(p_matrix) * self.coefficient_scale ** 2
+        except np.linalg.LinAlgError:
+            warnings.warn('Singular P matrix - could not obtain covariance estimate')
+            return None
+
+    def evaluate_rss(self, weights=None, x=None):
+        """drt1d.evaluate_rss (drt1d.py:4433-4455) -> qphb.evaluate_rss (qphb.py:1347-1352)."""
+        w = self.qphb_params['est_weights'] if weights is None else np.asarray(weights, dtype=float)
+        x = self.qphb_history[-1]['x'] if x is None else x
+        rm, rv = self.qphb_params['rm'], self.qphb_params['rv']
+        wrm, wrv = w[:, None] * rm, w * rv
+        return x @ wrm.T @ wrm @ x - 2 * wrv.T @ wrm @ x + wrv.T @ wrv
+
+    def evaluate_llh(self, weights=None, x=None, marginalize_weights=True, alpha_0=2, beta_0=1):
+        """drt1d.evaluate_llh (drt1d.py:4457-4496) -> qphb.evaluate_llh (qphb.py:1355-1377)."""
+        from scipy.special import loggamma
+        w = self.qphb_params['est_weights'] if weights is None else np.asarray(weights, dtype=float)
+        rss = self.evaluate_rss(w, x)
+        if marginalize_weights:
+            alpha_n = alpha_0 - 1 + len(w) / 2
+            beta_n = beta_0 + 0.5 * rss
+            llh = alpha_0 * np.log(beta_0) - alpha_n * np.log(beta_n) + loggamma(alpha_n) - loggamma(alpha_0)
+        else:
+            llh = -0.5 * rss
+        return llh + np.sum(np.log(w))
 
     def _fit(self, frequencies, z_batch, kw, history_of):
         self.stage_batch(frequencies, z_batch, history_of=history_of, **kw)

@@ -194,6 +194,14 @@ int hipdrt_plan_download(hipdrt_plan* plan, double* x, double* fit_x, double* r_
                          double* q_vector, int* outer_iters, int* qp_iters_total, int* status);
 /* final P (calculate_pq) of spectrum b: p[n][n] */
 int hipdrt_plan_get_p_matrix(hipdrt_plan* plan, int b, double* p);
+/* Posterior variance of the fitted distribution on an evaluation grid: the diagonal of
+ * DRT.estimate_distribution_cov (hybdrt/models/drt1d.py:3063-3151 with estimate_param_cov, 4116-4138; order 0, no
+ * normalisation), i.e. what DRTMD.fit_observation stores as obs_drt_var (hybdrt/mapping/drtmd.py:278-279) before its
+ * extend_var post-processing.  basis_eval[neval][ntau] = basis.construct_func_eval_matrix(ln basis_tau, ln tau_eval).
+ * For every fitted spectrum: final P (calculate_pq state), P = L L' on the device, out[b][i] = |L^-1 b_i|^2 * cs_b^2.
+ * status[b] (may be NULL): 0 ok, -1 P not positive definite (the reference's LinAlgError -> None).  n <= 528 only. */
+int hipdrt_plan_distribution_var(hipdrt_plan* plan, const double* basis_eval, int neval, double* out, int* status);
+
 /* per-outer-iteration history of spectrum b recorded when record_history was enabled before the fit:
  * hist_x[iters][n], hist_rho[iters][3], hist_w[iters][m], qp_iters[iters+1]                            */
 int hipdrt_plan_record_history(hipdrt_plan* plan, int b_or_minus1);

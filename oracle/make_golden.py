@@ -160,11 +160,44 @@ def run_response_matrices():
     print("refrun_response.npz written:", {k: np.shape(v) for k, v in out.items()})
 
 
+def run_posterior(DRT, name, freq, z, ctor_kw, tau_eval):
+    """survey 8f rank 1: what DRTMD.fit_observation takes from a finished fit (drtmd.py:258-279): evaluate_llh,
+    evaluate_rss and the diagonal of estimate_distribution_cov on the supergrid (with and without extend_var)"""
+    with _quiet():
+        drt = DRT(**ctor_kw)
+        drt.fit_eis(freq, z)
+        cov = drt.estimate_distribution_cov(tau=tau_eval)
+        cov_ext = drt.estimate_distribution_cov(tau=tau_eval, extend_var=True)
+        llh = drt.evaluate_llh()
+        rss = drt.evaluate_rss()
+        pcov = drt.estimate_param_cov()
+    fp, qp = drt.fit_parameters, drt.qphb_params
+    out = dict(freq=freq, z=z, basis_tau=drt.basis_tau, tau_epsilon=drt.tau_epsilon, tau_eval=tau_eval,
+               coefficient_scale=drt.coefficient_scale, p_matrix=fp["p_matrix"], num_special=drt.get_qp_mat_offset(),
+               dist_var=np.diag(cov), dist_var_ext=np.diag(cov_ext), param_var=np.diag(pcov), llh=llh, rss=rss,
+               x_scaled=drt.qphb_history[-1]["x"], est_weights=qp["est_weights"], rm=qp["rm"], rv=qp["rv"],
+               x=fp["x"])
+    np.savez_compressed(os.path.join(OUT, f"refrun_posterior_{name}.npz"), **out)
+    print(f"posterior_{name}: llh={llh:.6f} rss={rss:.6f} var range {out['dist_var'].min():.3e}..{out['dist_var'].max():.3e}")
+
+
+def run_posteriors(DRT, freq_g, z_g, default):
+    from oracle.drt_oracle import get_basis_tau
+    bt = get_basis_tau(freq_g)
+    sup = np.logspace(np.log10(bt[0]) - 0.5, np.log10(bt[-1]) + 0.5, 10 * 13 + 1)   # a wider "supergrid"
+    run_posterior(DRT, "golden71x91", freq_g, z_g, default, sup)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, REPO)
     if "--only-response" in sys.argv:
         run_response_matrices()
+        return
+    if "--only-posterior" in sys.argv:
+        freq_g, z_g = extract_reference_test_vectors()
+        DRT, cvxopt = _boot_reference()
+        run_posteriors(DRT, freq_g, z_g, dict(fit_inductance=True, fit_capacitance=False, fit_dop=False, fit_ohmic=True))
         return
     from hipdrt import synth
 
@@ -197,6 +230,8 @@ def main():
     run_trapz_matrices("trapz_71x91_toeplitz", freq_g, get_basis_tau(freq_g), get_epsilon_from_ppd(10))
     # (7) chrono response lookup + matrices (survey row a3)
     run_response_matrices()
+    # (8) post-fit quantities DRTMD stores per observation (survey 8f rank 1)
+    run_posteriors(DRT, freq_g, z_g, default)
 
 
 if __name__ == "__main__":

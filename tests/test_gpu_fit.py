@@ -147,6 +147,56 @@ def test_non_uniform_tau_grid_vs_oracle():
         np.testing.assert_allclose(res["z_sigma_tot"][b], ref[b]["z_sigma_tot"], rtol=1e-6)
 
 
+def test_distribution_variance_vs_reference_fixture():
+    """survey 8f rank 1: diag of estimate_distribution_cov on a supergrid after the reference's own known-answer fit.
+    The HIP path gets it from the Cholesky factor (|L^-1 b|^2), the reference from np.linalg.inv: agreement is
+    limited by cond(P) * eps (5e4 * 1e-16 here; measured 4e-14 between the two routes in numpy), tolerance 1e-9
+    relative per entry over 23 decades of magnitude."""
+    from hipdrt.models import DRT
+    from oracle import drt_oracle as orc
+    g = load("refrun_posterior_golden71x91.npz")
+    drt = DRT()
+    drt.fit_eis(g["freq"], g["z"])
+    var, ok = drt.estimate_distribution_var_batch(tau=g["tau_eval"])
+    assert ok.all() and var.shape == (1, len(g["tau_eval"]))
+    np.testing.assert_allclose(var[0], g["dist_var"], rtol=1e-6, atol=1e-12 * g["dist_var"].max())
+    # the fit itself differs from the fixture's by ~1e-9 (IPM trajectory tolerance), so the tight check is against
+    # the oracle evaluated on THIS fit's own P
+    P = drt.fit_parameters["p_matrix"]
+    ref = orc.estimate_distribution_var(P, drt.basis_tau, g["tau_eval"], drt.tau_epsilon, 2, drt.coefficient_scale)
+    np.testing.assert_allclose(var[0], ref, rtol=1e-9, atol=1e-300)
+    vext, _ = drt.estimate_distribution_var_batch(tau=g["tau_eval"], extend_var=True)
+    np.testing.assert_allclose(vext[0], g["dist_var_ext"], rtol=1e-6, atol=1e-12 * g["dist_var"].max())
+    # llh / rss / parameter covariance of the single fit
+    assert drt.evaluate_rss() == pytest.approx(float(g["rss"]), rel=1e-6)
+    assert drt.evaluate_llh() == pytest.approx(float(g["llh"]), rel=1e-7)
+    np.testing.assert_allclose(np.diag(drt.estimate_param_cov()), g["param_var"], rtol=1e-6)
+
+
+def test_distribution_variance_batch_256x512():
+    """C2-size batch (n = 514, 544-point supergrid = 34 appended tile rows): every spectrum against the oracle on its
+    own P; batch member 0 identical to the same spectrum fitted alone."""
+    from hipdrt import synth
+    from hipdrt.mapping import drtmd
+    from hipdrt.models import DRT
+    from oracle import drt_oracle as orc
+    c2 = synth.config_c2()
+    z = synth.zarc2_batch(c2["freq"], 6, first_seed=0)
+    sup = np.logspace(-8.5, 2.5, 544)
+    drt = DRT(fixed_basis_tau=c2["tau"])
+    obs_x, obs_special, res = drtmd.fit_observations(drt, c2["freq"], z, tau_supergrid=None, drt_var=False)
+    var, ok = drt.estimate_distribution_var_batch(tau=sup)
+    assert ok.all() and var.shape == (6, 544) and np.all(var >= 0)
+    for b in (0, 3, 5):
+        P = drt._plan.p_matrix(b)
+        ref = orc.estimate_distribution_var(P, c2["tau"], sup, drt.tau_epsilon, 2, res["coefficient_scale"][b])
+        np.testing.assert_allclose(var[b], ref, rtol=1e-7, atol=1e-14 * ref.max())
+    drt1 = DRT(fixed_basis_tau=c2["tau"])
+    drt1.fit_eis(c2["freq"], z[0])
+    v1, _ = drt1.estimate_distribution_var_batch(tau=sup)
+    np.testing.assert_array_equal(v1[0], var[0])
+
+
 def test_edge_cases():
     from hipdrt.models import DRT
     freq = np.logspace(5, 0, 12)

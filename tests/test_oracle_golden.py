@@ -123,3 +123,18 @@ def test_oracle_response_path_matches_reference_run():
                                            g["trapz_step_sizes"], float(g["trapz_epsilon"]), 'trapz')
     np.testing.assert_array_equal(a, g["trapz_A"])
     np.testing.assert_array_equal(lay, g["trapz_layered"])
+
+
+def test_oracle_posterior_quantities_match_reference_run():
+    """survey 8f rank 1 (what DRTMD stores per observation, drtmd.py:258-279): distribution variance on a supergrid
+    (with / without extend_var), parameter variance, llh and rss -- bit-exact against the reference's own outputs."""
+    g = np.load(os.path.join(GOLDEN, "refrun_posterior_golden71x91.npz"))
+    P, ns, cs = g["p_matrix"], int(g["num_special"]), float(g["coefficient_scale"])
+    eps = float(g["tau_epsilon"])
+    v = orc.estimate_distribution_var(P, g["basis_tau"], g["tau_eval"], eps, ns, cs)
+    np.testing.assert_array_equal(v, g["dist_var"])
+    ve = orc.estimate_distribution_var(P, g["basis_tau"], g["tau_eval"], eps, ns, cs, True, g["freq"])
+    np.testing.assert_array_equal(ve, g["dist_var_ext"])
+    np.testing.assert_array_equal(np.diag(orc.estimate_param_cov(P, cs)), g["param_var"])
+    assert orc.evaluate_rss(g["x_scaled"], g["rm"], g["rv"], g["est_weights"]) == pytest.approx(float(g["rss"]), rel=1e-13)
+    assert orc.evaluate_llh(g["x_scaled"], g["rm"], g["rv"], g["est_weights"]) == pytest.approx(float(g["llh"]), rel=1e-13)

@@ -319,8 +319,10 @@ __device__ __forceinline__ void matvec_P(const double* __restrict__ P, int ldp, 
 template <int THREADS, int MAXT>
 struct OpsMultipass {
     const double* P; int ldp; double* L; int ldl; int n; int PR; QpSmem sm;
+    static constexpr bool kFusedForward = false;
     __device__ __forceinline__ bool factor() { return chol_factor<THREADS, MAXT>(P, ldp, L, ldl, n, PR, sm); }
     __device__ __forceinline__ void solve() { chol_solve<THREADS>(L, ldl, n, sm); }
+    __device__ __forceinline__ void backward() {}
     __device__ __forceinline__ void matvec() { matvec_P<THREADS>(P, ldp, n, sm.vec, sm.dvec); }
 };
 

@@ -231,20 +231,11 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             }
         }
         // ---- factor S = P + diag(di^2)  (di = 1 at the start point) --------------------------------------
-        __syncthreads();
-#pragma unroll
-        FOR_E if (VALID) sm.dvec[i] = di[i] * di[i];
-        __syncthreads();
-        if (!ops.factor()) {
-            status = (start || iters == 0) ? HIPDRT_QP_SINGULAR : HIPDRT_QP_SINGULAR_LATE;
-            break;
-        }
-
         const double mu = gap / (double)n;
         double sigma = 0.0, step = 1.0;
         const int nsolve = start ? 1 : 2;
-#pragma nounroll
-        for (int pc = 0; pc < nsolve; ++pc) {
+        // right-hand side of KKT solve pc (sigma = 0 for the predictor, so its rhs is known before the factorisation)
+        auto set_rhs = [&](int pc) {
 #pragma unroll
             FOR_E {
                 if (VALID) {
@@ -260,8 +251,26 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                     }
                 }
             }
-            __syncthreads();
-            ops.solve();
+        };
+        __syncthreads();
+#pragma unroll
+        FOR_E if (VALID) sm.dvec[i] = di[i] * di[i];
+        if (Ops::kFusedForward) set_rhs(0);     // the factorisation also forward-substitutes the first rhs
+        __syncthreads();
+        if (!ops.factor()) {
+            status = (start || iters == 0) ? HIPDRT_QP_SINGULAR : HIPDRT_QP_SINGULAR_LATE;
+            break;
+        }
+
+#pragma nounroll
+        for (int pc = 0; pc < nsolve; ++pc) {
+            if (Ops::kFusedForward && pc == 0) {
+                ops.backward();
+            } else {
+                set_rhs(pc);
+                __syncthreads();
+                ops.solve();
+            }
             if (start) {
                 double st[2] = {0.0, 0.0}, mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll

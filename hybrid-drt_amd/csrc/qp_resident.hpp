@@ -56,6 +56,10 @@ struct OpsResident {
     // Bex[nex][nchp][256]): the factorisation treats them as more panel rows, so they come out as Bex * L^-T --
     // the multi-right-hand-side triangular solve of the posterior-variance kernel at the price of a taller panel.
     int nex = 0; const double* Bex = nullptr;
+    // The factorisation also forward-substitutes the right-hand side waiting in sm.vec (column by column, as soon as
+    // a block column's tiles sit in registers): the predictor's forward sweep costs no pass over L in HBM.
+    static constexpr bool kFusedForward = true;
+    bool fwd = true;
 
     // tile (t, c) starts at ((t*nch + c) * TSZ) doubles; returned in double2 units
     __device__ __forceinline__ const double2* tile2(int t, int c) const {
@@ -148,6 +152,18 @@ struct OpsResident {
     }
 
     // -----------------------------------------------------------------------------------------------------
+    // fused forward substitution, update of tile row T by block column j0: b_T -= X_T y_j with X_T = (x1 | x2) in
+    // its register image (lane (li, kq): row li, columns kq + 4 rg of each 16-column half)
+    __device__ __forceinline__ void fwd_update(const v4d& x1, const v4d& x2, int T, int j0, int li, int kq) const {
+        double p_ = 0.0;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            p_ += x1[rg] * sm.vec[j0 + kq + 4 * rg] + x2[rg] * sm.vec[j0 + 16 + kq + 4 * rg];
+        p_ += __shfl_xor(p_, 16, 64);
+        p_ += __shfl_xor(p_, 32, 64);
+        if (kq == 0) sm.vec[T * 16 + li] -= p_;
+    }
+
     // operand fragments of a tile held in its register image (rg <-> column kq + 4 rg): k-half h = (x[2h], x[2h+1])
     __device__ __forceinline__ bool factor() {
         const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,6 +231,24 @@ struct OpsResident {
                     w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq], y[s_], w21, 0, 0, 0);
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
+                if (fwd) {
+                    // fused forward substitution: y_j = M_j b_j (b_j has received every earlier column's update)
+                    __builtin_amdgcn_wave_barrier();
+                    const int r = lane & 31;
+                    const double* Mr = U + (size_t)(j0 + r) * PLD;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NB; c += 4) {
+                        s0 += Mr[c] * sm.vec[j0 + c];
+                        s1 += Mr[c + 1] * sm.vec[j0 + c + 1];
+                        s2 += Mr[c + 2] * sm.vec[j0 + c + 2];
+                        s3 += Mr[c + 3] * sm.vec[j0 + c + 3];
+                    }
+                    const double y = (s0 + s1) + (s2 + s3);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < NB) sm.vec[j0 + lane] = y;
+                    lds_barrier();                                  // (A2) y_j published
+                }
                 PROF(3);
             } else if (wv == 1) {
                 // ======== wavefront 1: the tile rows R2 = tb+2, R3 = tb+3 of the next diagonal block ============
@@ -320,6 +354,13 @@ struct OpsResident {
                     stage_dsc(e11);
                     img21[lane] = e21;
                     img22[lane] = e22;
+                    if (fwd) {
+                        lds_barrier();                              // (A2)
+                        fwd_update(x20, x21_, R2, j0, li, kq);
+                        if (v3) fwd_update(x30, x31, R3, j0, li, kq);
+                    }
+                } else if (fwd) {
+                    lds_barrier();                                  // (A2)
                 }
             } else {
                 // ======== wavefronts 2..7: the rows below ======================================================
@@ -428,6 +469,14 @@ struct OpsResident {
                                 d0[192] = make_double2(x2[u][2], x2[u][3]);
                             }
                         }
+                        if (fwd) {
+                            if (ps == 0) lds_barrier();             // (A2) y_j published by wavefront 0
+#pragma unroll
+                            for (int u = 0; u < RMAXT; ++u)
+                                if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0, li, kq);
+                        }
+                    } else if (fwd && ps == 0) {
+                        lds_barrier();                              // (A2)
                     }
                 }
             }
@@ -443,7 +492,7 @@ struct OpsResident {
     // solution, so they are fetched BEFORE the diagonal step of the same block and are in flight meanwhile.
     //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane  ->  row i = lane/4,
     //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
-    __device__ __forceinline__ void solve() {
+    __device__ __forceinline__ void forward() {
         const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int nblk = (n + NB - 1) / NB;
         const int ntr = (n + 15) >> 4;
@@ -477,25 +526,6 @@ struct OpsResident {
                 PROF(5);
                 lds_barrier();
                 PROF(6);
-            }
-            for (int jb = nblk - 1; jb >= 0; --jb) {     // backward: x = M' y, lane = column of M
-                const int j0 = jb * NB;
-                const double* Mc = U + (size_t)j0 * PLD + r;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-                for (int q = 0; q < NB; q += 4) {
-                    s0 += Mc[(size_t)q * PLD] * vec[j0 + q];
-                    s1 += Mc[(size_t)(q + 1) * PLD] * vec[j0 + q + 1];
-                    s2 += Mc[(size_t)(q + 2) * PLD] * vec[j0 + q + 2];
-                    s3 += Mc[(size_t)(q + 3) * PLD] * vec[j0 + q + 3];
-                }
-                const double xv = (s0 + s1) + (s2 + s3);
-                __builtin_amdgcn_wave_barrier();
-                if (lane < NB) vec[j0 + lane] = xv;
-                lds_barrier();
-                PROF(7);
-                lds_barrier();
-                PROF(8);
             }
         } else {
             // ======== wavefronts 1..7: rank-32 updates ========================================================
@@ -553,6 +583,50 @@ struct OpsResident {
                     if (jb + 1 < nblk) fstep(fb, jb + 1);
                 }
             }
+        }
+    }
+
+    __device__ __forceinline__ void backward() {
+        const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int nblk = (n + NB - 1) / NB;
+        const int ntr = (n + 15) >> 4;
+        double* vec = sm.vec;
+        const double* U = sm.U;
+        constexpr int UW = RNW - 1;                 // updater wavefronts
+        constexpr int FT = (31 + UW - 1) / UW;      // forward: tiles per updater wavefront
+        constexpr int BC = (32 + UW - 1) / UW;      // backward: chunks per updater wavefront
+        PROF_DECL
+        // Two roles, two code paths with matching barrier sequences (per block: one barrier after the diagonal step,
+        // one after the update).  The barriers order LDS traffic only, so the updaters' operand tiles -- fetched TWO
+        // blocks ahead into alternating register buffers -- stay in flight across them.
+        if (wv == 0) {
+            // ======== wavefront 0: multiply by the inverse 32x32 diagonal blocks ================================
+            const int r = lane & 31;
+            for (int jb = nblk - 1; jb >= 0; --jb) {     // backward: x = M' y, lane = column of M
+                const int j0 = jb * NB;
+                const double* Mc = U + (size_t)j0 * PLD + r;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                for (int q = 0; q < NB; q += 4) {
+                    s0 += Mc[(size_t)q * PLD] * vec[j0 + q];
+                    s1 += Mc[(size_t)(q + 1) * PLD] * vec[j0 + q + 1];
+                    s2 += Mc[(size_t)(q + 2) * PLD] * vec[j0 + q + 2];
+                    s3 += Mc[(size_t)(q + 3) * PLD] * vec[j0 + q + 3];
+                }
+                const double xv = (s0 + s1) + (s2 + s3);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < NB) vec[j0 + lane] = xv;
+                lds_barrier();
+                PROF(7);
+                lds_barrier();
+                PROF(8);
+            }
+        } else {
+            // ======== wavefronts 1..7: rank-32 updates ========================================================
+            //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane -> row lane/4,
+            //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
+            const int l4 = lane & 3, g4 = lane >> 2;
+            struct Buf { double2 t[FT > BC ? FT : BC][4]; };
             // ---- backward: L' x = y -----------------------------------------------------------------------
             auto bpre = [&](Buf& B_, int jb) {          // tiles (tb..tb+1, c): [chunk][tile*2 + half]
                 if (jb >= 0) {
@@ -605,6 +679,12 @@ struct OpsResident {
                 }
             }
         }
+    }
+
+    // vec := S^-1 vec
+    __device__ __forceinline__ void solve() {
+        forward();
+        backward();
     }
 
     // -----------------------------------------------------------------------------------------------------
@@ -710,7 +790,7 @@ __global__ __launch_bounds__(RT) void cov_kernel_resident(CovArgs a, int NP) {
     ops.P = nullptr; ops.ldp = 0;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk + (size_t)b * a.ppk_stride; ops.nchp = a.nchp;
-    ops.nex = a.nex; ops.Bex = a.Bex;
+    ops.nex = a.nex; ops.Bex = a.Bex; ops.fwd = false;
     constexpr int VEC = RNP_MAX + 16 + 32;
     ops.sm.colbuf = smem;
     ops.sm.red = ops.sm.colbuf + 64;

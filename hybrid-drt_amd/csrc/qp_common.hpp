@@ -72,15 +72,21 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// wavefront sum / max, every lane gets the result: DPP quad permutes and row rotations inside the 16-lane rows,
+// v_readlane across the four rows (no LDS crossbar)
 __device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov_d<0xB1>(v);
+    v += dpp_mov_d<0x4E>(v);
+    v += dpp_mov_d<0x124>(v);
+    v += dpp_mov_d<0x128>(v);
+    return (bcast_lane(v, 0) + bcast_lane(v, 16)) + (bcast_lane(v, 32) + bcast_lane(v, 48));
 }
 __device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmax(v, dpp_mov_d<0xB1>(v));
+    v = fmax(v, dpp_mov_d<0x4E>(v));
+    v = fmax(v, dpp_mov_d<0x124>(v));
+    v = fmax(v, dpp_mov_d<0x128>(v));
+    return fmax(fmax(bcast_lane(v, 0), bcast_lane(v, 16)), fmax(bcast_lane(v, 32), bcast_lane(v, 48)));
 }
 
 template <int NW>

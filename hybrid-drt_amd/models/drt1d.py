@@ -246,19 +246,6 @@ class DRT:
         log_min, log_max = np.log10(np.min(basis_tau)) - 1, np.log10(np.max(basis_tau)) + 1
         return np.logspace(log_min, log_max, int((log_max - log_min) * ppd) + 1)
 
-    def estimate_param_cov(self, p_matrix=None):
-        """drt1d.estimate_param_cov (drt1d.py:4116-4138): inv(P) coefficient_scale^2 (host LAPACK; the n x n inverse
-        is not on the batch path, which only needs the distribution variance)."""
-        if p_matrix is None:
-            p_matrix = self.fit_parameters.get('p_matrix', None) if self.fit_parameters else None
-        if p_matrix is None:
-            raise Exception('Parameter covariance estimation is only available for qphb fits')
-        try:
-            return np.linalg.inv(p_matrix) * self.coefficient_scale ** 2
-        except np.linalg.LinAlgError:
-            warnings.warn('Singular P matrix - could not obtain covariance estimate')
-            return None
-
     def evaluate_rss(self, weights=None, x=None):
         """drt1d.evaluate_rss (drt1d.py:4433-4455) -> qphb.evaluate_rss (qphb.py:1347-1352)."""
         w = self.qphb_params['est_weights'] if weights is None else np.asarray(weights, dtype=float)

@@ -65,7 +65,8 @@ def test_qp_vs_reference_run(ctx, name):
         assert abs(res["pcost"][i] - float(g[f"qp{i}_pcost"])) <= 1e-9 * abs(float(g[f"qp{i}_pcost"]))
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 31, 32, 33, 64, 100, 257, 514, 600])
+@pytest.mark.parametrize("n", [1, 2, 5, 16, 17, 31, 32, 33, 48, 49, 64, 65, 80, 96, 97, 100, 129, 257, 400, 480, 497, 512, 513,
+                               514, 527, 528, 529, 600])
 def test_qp_random_spd_vs_oracle(ctx, n):
     from oracle.coneqp import coneqp_boxlow
     rng = np.random.default_rng(n)

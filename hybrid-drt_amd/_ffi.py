@@ -57,6 +57,7 @@ SIGNATURES = {
                                 C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp],
     "hipdrt_impedance_matrix_dev": [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                                     C.c_int, _dp, _dp, _dp, _dp, C.c_int, _vp, _vp, C.c_int, C.POINTER(C.c_float)],
+    "hipdrt_chrono_var_matrix": [_vp, _dp, C.c_int, _ip, C.c_int, C.c_double, C.c_int, _dp],
     "hipdrt_response_lookup": [_vp, C.c_double, C.c_int, C.c_int, _dp, _dp],
     "hipdrt_response_matrix": [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp,
                                C.c_int, _dp, _dp],
@@ -210,6 +211,14 @@ class Context:
                                                      _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), int(ny), _vp(dev_re),
                                                      _vp(dev_im), int(repeat), C.byref(ms)))
         return ms.value
+
+    def chrono_var_matrix(self, tt, seg, vmm_epsilon, uniform=False):
+        tt = _f64(tt)
+        seg = np.ascontiguousarray(seg, dtype=np.int32)
+        out = np.empty((tt.size, tt.size))
+        _check(self._lib.hipdrt_chrono_var_matrix(self._h, _p(tt), tt.size, _pi(seg), seg.size - 1, float(vmm_epsilon),
+                                                  int(bool(uniform)), _p(out)))
+        return out
 
     def response_lookup(self, epsilon, td, ny=1000):
         td = _f64(td)

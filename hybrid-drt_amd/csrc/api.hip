@@ -140,6 +140,23 @@ int hipdrt_impedance_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, 
     return HIPDRT_OK;
 }
 
+int hipdrt_chrono_var_matrix(hipdrt_ctx* ctx, const double* tt, int nt, const int* seg, int nseg, double vmm_epsilon,
+                             int uniform, double* vmm) {
+    HIPDRT_REQUIRE(ctx && tt && seg && vmm, "NULL pointer");
+    HIPDRT_REQUIRE(nt >= 1 && nseg >= 1, "nt >= 1, nseg >= 1");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dtt, dseg, dv;
+    TRY(upload(dtt, tt, (size_t)nt * sizeof(double), st));
+    TRY(upload(dseg, seg, (size_t)(nseg + 1) * sizeof(int), st));
+    HIPDRT_CHECK(dv.alloc((size_t)nt * nt * sizeof(double)));
+    launch_chrono_vmm(st, dtt.d(), nt, dseg.i(), nseg, vmm_epsilon, uniform, dv.d());
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(vmm, dv.p, (size_t)nt * nt * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
 int hipdrt_response_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, const double* td, double* v) {
     HIPDRT_REQUIRE(ctx && td && v, "NULL pointer");
     HIPDRT_REQUIRE(ngrid >= 2 && ny >= 2 && ny <= 6000, "ngrid >= 2, 2 <= ny <= 6000");

@@ -7,6 +7,7 @@
 //  response_*_kernel      mat1d.construct_response_matrix         hybdrt/matrices/mat1d.py:16-122
 //  penalty_kernel         mat1d.construct_integrated_derivative_matrix  mat1d.py:125-209, basis.py:382-395
 //  eis_vmm_kernel         mat1d.construct_eis_var_matrix          mat1d.py:493-515
+//  chrono_vmm_kernel      mat1d.construct_chrono_var_matrix       mat1d.py:457-490 (transformed times: utils/chrono.py:5-44)
 //
 // Layout: every matrix row-major float64.  The interp build is HBM-write bound (2*nf*ntau*8 B per
 // frequency grid); the lookup tables (3 arrays x 2 parts x ngrid x 8 B = 96 kB at ngrid=2000) are staged
@@ -462,6 +463,39 @@ void launch_impedance_matrix(hipStream_t st, int B, int freq_batched, const doub
         hipLaunchKernelGGL(impedance_trapz_kernel, dim3((ntau + 15) / 16, nf, B), dim3(256), 3 * ny * sizeof(double),
                            st, freq_batched, freq, nf, tau, ntau, eps, ny, a_re, a_im);
     }
+}
+
+// Chrono variance-estimation matrix: one 256-thread block per row.  tt = transformed sample times, seg[nseg+1] =
+// sample index bounds of the step segments (no correlation across segments), rows normalised to sum 1.
+__global__ __launch_bounds__(256) void chrono_vmm_kernel(const double* __restrict__ tt, int nt,
+                                                         const int* __restrict__ seg, int nseg, double eps, int uniform,
+                                                         double* __restrict__ vmm) {
+    __shared__ double red[4];
+    const int i = blockIdx.x;
+    int a = 0, b = nt;
+    if (!uniform) {
+        for (int k = 0; k < nseg; ++k)
+            if (i >= seg[k] && i < seg[k + 1]) { a = seg[k]; b = seg[k + 1]; }
+    }
+    const double ti = tt[i];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < nt; j += blockDim.x) {
+        double v = 0.0;
+        if (uniform) v = 1.0;
+        else if (j >= a && j < b) { const double dd = eps * (ti - tt[j]); v = exp(-(dd * dd)); }
+        vmm[(size_t)i * nt + j] = v;
+        s += v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int j = threadIdx.x; j < nt; j += blockDim.x) vmm[(size_t)i * nt + j] /= tot;
+}
+
+void launch_chrono_vmm(hipStream_t st, const double* tt, int nt, const int* seg, int nseg, double eps, int uniform,
+                       double* vmm) {
+    hipLaunchKernelGGL(chrono_vmm_kernel, dim3(nt), dim3(256), 0, st, tt, nt, seg, nseg, eps, uniform, vmm);
 }
 
 void launch_response_lookup(hipStream_t st, double eps, int ngrid, int ny, const double* td, double* v) {

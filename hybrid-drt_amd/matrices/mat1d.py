@@ -131,6 +131,45 @@ def construct_capacitance_impedance_vector(frequencies):
     return 1 / (1j * 2 * np.pi * frequencies)
 
 
+def get_step_indices_from_step_times(times, step_times):
+    """preprocessing.get_step_indices_from_step_times (hybdrt/preprocessing.py:161-178): index of the first sample at
+    or after each step time."""
+    times = np.asarray(times, dtype=float)
+    return np.array([int(np.argmin(np.where(times < st, np.inf, times - st))) for st in step_times], dtype=int)
+
+
+def chrono_time_transform(times, step_times):
+    """utils.chrono.get_time_transforms(...)[1] (hybdrt/utils/chrono.py:5-44): linear before the first step,
+    log(time since step) within each step segment, segments laid end to end (O(nt) host work feeding the kernel)."""
+    times = np.atleast_1d(np.asarray(times, dtype=float))
+    t_sample = np.min(np.diff(times))
+    start_times = np.array(step_times, dtype=float)
+    trans_base = np.log(t_sample / 4)
+    trans_offsets = np.concatenate([[0], np.cumsum(np.log(start_times[1:] - start_times[:-1]) - trans_base)])
+    tt = np.zeros_like(times)
+    before = times < start_times[0]
+    tt[before] = times[before] - start_times[0]
+    for i, start_time in enumerate(start_times):
+        end_time = np.inf if i == len(start_times) - 1 else start_times[i + 1]
+        idx = np.where((times >= start_time) & (times < end_time))
+        if len(idx[0]) > 0:
+            tt[idx] = trans_offsets[i] + np.log(np.maximum(times[idx] - start_time, t_sample / 2)) - trans_base
+    return tt
+
+
+def construct_chrono_var_matrix(times, step_times, vmm_epsilon, error_structure=None, device=0):
+    """mat1d.construct_chrono_var_matrix (hybdrt/matrices/mat1d.py:457-490): (nt, nt) variance-estimation weights,
+    built on the device from the transformed times and the step segments."""
+    times = np.asarray(times, dtype=float)
+    if error_structure is None:
+        tt = chrono_time_transform(times, step_times)
+        seg = np.concatenate(([0], get_step_indices_from_step_times(times, step_times), [len(times)]))
+        return _ffi.get_context(device).chrono_var_matrix(tt, seg, vmm_epsilon, uniform=False)
+    if error_structure == 'uniform':
+        return _ffi.get_context(device).chrono_var_matrix(np.zeros(len(times)), [0, len(times)], vmm_epsilon, uniform=True)
+    raise ValueError(f'Invalid error_structure {error_structure}. Options: None, uniform')
+
+
 def construct_eis_var_matrix(frequencies, vmm_epsilon, reim_cor, error_structure, device=0):
     """mat1d.construct_eis_var_matrix (hybdrt/matrices/mat1d.py:493-515)."""
     if error_structure not in (None, 'uniform'):

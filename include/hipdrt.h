@@ -74,6 +74,13 @@ int hipdrt_impedance_matrix_dev(hipdrt_ctx* ctx, int B, int freq_batched, const 
                                 const double* log_wt_im, const double* z_im, int ny,
                                 void* a_re_dev, void* a_im_dev, int repeat, float* elapsed_ms);
 
+/* mat1d.construct_chrono_var_matrix (hybdrt/matrices/mat1d.py:457-490).  tt[nt] = the samples' transformed times
+ * (utils/chrono.py:5-44 fwd_transform), seg[nseg+1] = sample-index bounds of the step segments
+ * ([0, step indices..., nt], preprocessing.py:161-178); uniform != 0 -> error_structure='uniform' (ones / nt).
+ * out: vmm[nt][nt], Gaussian in transformed time inside a segment, zero across segments, rows normalised.   */
+int hipdrt_chrono_var_matrix(hipdrt_ctx* ctx, const double* tt, int nt, const int* seg, int nseg,
+                             double vmm_epsilon, int uniform, double* vmm);
+
 /* basis.generate_response_lookup (hybdrt/matrices/basis.py:672-689; integrand basis.py:616-618), Gaussian basis,
  * galvanostatic ideal step.
  * in : td[ngrid]   the (t - t_step)/tau abscissae (np.logspace(-6, 2, ngrid))

@@ -156,6 +156,11 @@ def run_response_matrices():
                                              op_mode='galv', integrate_method='trapz', integrate_points=1000)
     out.update(trapz_tau=tau_s, trapz_times=times_s, trapz_epsilon=eps_s, trapz_step_times=st, trapz_step_sizes=sa,
                trapz_A=a, trapz_layered=lay)
+    # chrono variance-estimation matrices (survey row a5, mat1d.py:457-490): flexible and uniform error structure
+    for name in ("one_step", "three_steps"):
+        st = cases[name][0]
+        out[f"{name}_vmm"] = mat1d.construct_chrono_var_matrix(times, st, 0.25, None)
+    out["uniform_vmm"] = mat1d.construct_chrono_var_matrix(times, cases["one_step"][0], 0.25, 'uniform')
     np.savez_compressed(os.path.join(OUT, "refrun_response.npz"), **out)
     print("refrun_response.npz written:", {k: np.shape(v) for k, v in out.items()})
 

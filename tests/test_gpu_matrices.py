@@ -211,3 +211,17 @@ def test_response_matrix_rejects_unbuilt_branches(ctx):
         mat1d.construct_response_matrix([1.0], [1.0], 'bogus', [0.0], [1.0])
     with pytest.raises(NotImplementedError):
         mat1d.construct_response_matrix([1.0], [1.0], 'ideal', [0.0], [1.0], op_mode='pot')
+
+
+@pytest.mark.parametrize("case", ["one_step", "three_steps"])
+def test_chrono_var_matrix_vs_reference_fixture(ctx, case):
+    """survey row a5 (chrono half): Gaussian in transformed time, block diagonal per step, rows normalised."""
+    from hipdrt.matrices import mat1d
+    g = load("refrun_response.npz")
+    vmm = mat1d.construct_chrono_var_matrix(g["times"], g[f"{case}_step_times"], 0.25, None)
+    ref = g[f"{case}_vmm"]
+    np.testing.assert_array_equal(vmm == 0.0, ref == 0.0)            # no correlation across steps
+    np.testing.assert_allclose(vmm, ref, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(vmm.sum(axis=1), 1.0, rtol=1e-14)
+    uni = mat1d.construct_chrono_var_matrix(g["times"], g["one_step_step_times"], 0.25, 'uniform')
+    np.testing.assert_array_equal(uni, g["uniform_vmm"])

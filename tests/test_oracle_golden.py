@@ -123,6 +123,12 @@ def test_oracle_response_path_matches_reference_run():
                                            g["trapz_step_sizes"], float(g["trapz_epsilon"]), 'trapz')
     np.testing.assert_array_equal(a, g["trapz_A"])
     np.testing.assert_array_equal(lay, g["trapz_layered"])
+    # chrono variance-estimation matrices (row a5)
+    for case in ("one_step", "three_steps"):
+        np.testing.assert_array_equal(orc.construct_chrono_var_matrix(g["times"], g[f"{case}_step_times"], 0.25),
+                                      g[f"{case}_vmm"])
+    np.testing.assert_array_equal(orc.construct_chrono_var_matrix(g["times"], g["one_step_step_times"], 0.25, 'uniform'),
+                                  g["uniform_vmm"])
 
 
 def test_oracle_posterior_quantities_match_reference_run():

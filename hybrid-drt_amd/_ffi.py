@@ -78,6 +78,8 @@ SIGNATURES = {
     "hipdrt_plan_download": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip],
     "hipdrt_plan_get_p_matrix": [_vp, C.c_int, _dp],
     "hipdrt_plan_distribution_var": [_vp, _dp, C.c_int, _dp, _ip],
+    "hipdrt_plan_set_state": [_vp, _dp, _dp, _dp, _dp],
+    "hipdrt_plan_continue": [_vp, C.POINTER(FitOpts), C.c_double, C.c_int],
     "hipdrt_plan_record_history": [_vp, C.c_int],
     "hipdrt_plan_get_history": [_vp, _dp, _dp, _dp, _ip, C.c_int, _ip],
     "hipdrt_plan_timings": [_vp, C.POINTER(C.c_float), _ip],
@@ -363,6 +365,13 @@ class Plan:
 
     def fit(self):
         _check(self._lib.hipdrt_plan_fit(self._h))
+
+    def set_state(self, x=None, rho=None, s=None, weights=None):
+        arrs = [None if a is None else _f64(a) for a in (x, rho, s, weights)]
+        _check(self._lib.hipdrt_plan_set_state(self._h, *[None if a is None else _p(a) for a in arrs]))
+
+    def continue_fit(self, opts, weight_factor=1.0, min_iter=2):
+        _check(self._lib.hipdrt_plan_continue(self._h, C.byref(opts), float(weight_factor), int(min_iter)))
 
     def record_history(self, b):
         _check(self._lib.hipdrt_plan_record_history(self._h, int(b)))

@@ -39,7 +39,7 @@ struct hipdrt_plan {
     FitState state() const {
         FitState st{};
         st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm; st.toeplitz_m = toeplitz_m;
-        st.opts = opts;
+        st.opts = opts; st.continue_mode = 0; st.min_iter = 1;
         st.rm = rm.d(); st.vmm = vmm.d();
         for (int k = 0; k < 3; ++k) st.mk[k] = mk[k].d();
         st.z_re = z_re.d(); st.z_im = z_im.d();
@@ -700,6 +700,87 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
         if (n_active == 0) break;
     }
     // ---- calculate_pq's q with the final weights (qphb.py:1154-1183) ---------------------------------------
+    tm.mark(4);
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr);
+    LAUNCH_OK();
+    tm.mark(-1);
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    tm.collect(p->t_ms, p->launches);
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_set_state(hipdrt_plan* p, const double* x, const double* rho, const double* s, const double* weights) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const size_t B = p->B, n = p->n, m = p->m;
+    if (x) {
+        HIPDRT_CHECK(hipMemcpyAsync(p->x.p, x, B * n * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPDRT_CHECK(hipMemcpyAsync(p->x_in.p, x, B * n * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (rho) HIPDRT_CHECK(hipMemcpyAsync(p->rho.p, rho, B * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (s) HIPDRT_CHECK(hipMemcpyAsync(p->s.p, s, B * 3 * n * sizeof(double), hipMemcpyHostToDevice, st));
+    if (weights) HIPDRT_CHECK(hipMemcpyAsync(p->w.p, weights, B * m * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+// drt1d._continue_from_init (hybdrt/models/drt1d.py:1270-1365) for the fitted batch: the same outer loop re-entered from
+// the state on the device (x, s, rho, weights; est_weights, xmx norms and data scale stay) with updated hyper-parameters.
+int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double weight_factor, int min_iter) {
+    HIPDRT_REQUIRE(p && opts, "NULL pointer");
+    HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
+    HIPDRT_REQUIRE(opts->max_iter >= 1 && min_iter >= 1, "max_iter, min_iter >= 1");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const int B = p->B, n = p->n, m = p->m;
+    FitState fs = p->state();
+    fs.opts = *opts; fs.continue_mode = 1; fs.min_iter = min_iter;
+    PhaseTimer tm(st);
+    tm.mark(4);
+    if (p->hist_b >= 0) HIPDRT_CHECK(hipMemsetAsync(p->hist_rows.p, 0, sizeof(int), st));
+    {   // every spectrum takes part again; QP iteration totals restart
+        std::vector<int> ones(B, 1);
+        HIPDRT_CHECK(hipMemcpyAsync(p->active.p, ones.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPDRT_CHECK(hipMemsetAsync(p->qp_iters_total.p, 0, (size_t)B * sizeof(int), st));
+        HIPDRT_CHECK(hipStreamSynchronize(st));
+    }
+    GramL2 g{};
+    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1; g.sym = p->toeplitz_m;
+    for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = opts->l2_lambda_0 * opts->derivative_weights[k]; }
+    g.s = p->s.d(); g.rho = p->rho.d();
+    QpArgs qa{};
+    qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
+    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n);
+    qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
+    qa.iters_accum = p->qp_iters_total.i(); qa.opts = opts->qp;
+    qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);
+    double* const Prow = qp_packed_only(n) ? nullptr : p->P.d();
+    qa.P = Prow; qa.p_stride = (long long)n * p->ldp; qa.active = p->active.i();
+    qa.Ppk = p->Ppk.d(); qa.ppk_stride = (long long)qp_ppk_doubles(n); qa.nchp = qp_nchp(n);
+    for (int it = 0; it < opts->max_iter; ++it) {
+        tm.mark(1);
+        HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
+        if (weight_factor != 1.0) launch_scale_weights(st, fs, B, weight_factor);
+        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, (long long)n * p->ldp, p->active.i(),
+                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
+        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i());
+        LAUNCH_OK();
+        tm.mark(2);
+        if (B * sizeof(int) <= 48 * 1024) {
+            launch_lpt_order(st, B, p->qp_iters.i(), p->active.i(), p->order.i());
+            qa.order = p->order.i();
+        }
+        TRY(launch_qp(st, qa));
+        tm.mark(3);
+        TRY(launch_hyper(st, fs, B, it));
+        LAUNCH_OK();
+        int n_active = 0;
+        HIPDRT_CHECK(hipMemcpyAsync(&n_active, p->n_active.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPDRT_CHECK(hipStreamSynchronize(st));
+        if (n_active == 0) break;
+    }
     tm.mark(4);
     launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr);
     LAUNCH_OK();

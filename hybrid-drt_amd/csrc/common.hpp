@@ -126,6 +126,8 @@ void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, 
 struct FitState {
     int nf, m, n, ns, ldrm, ldm;
     int toeplitz_m;        // penalty blocks are symmetric Toeplitz (uniform ln-tau grid): first column suffices
+    int continue_mode;     // warm restart (_continue_from_init): xmx norms stay frozen
+    int min_iter;          // a spectrum may only stop once it has done this many outer iterations (fit: 1)
     hipdrt_fit_opts opts;
     // shared (plan) matrices
     const double* rm;      // [m][ldrm]  stacked [Re; Im] response matrix incl. special columns
@@ -149,6 +151,7 @@ size_t hyper_lds_bytes(int n, int m, int ns);
 int launch_prep(hipStream_t s, const FitState& st, int B);
 int launch_init_weights(hipStream_t s, const FitState& st, int B);
 int launch_hyper(hipStream_t s, const FitState& st, int B, int it);
+void launch_scale_weights(hipStream_t s, const FitState& st, int B, double factor);
 void launch_assemble_rm(hipStream_t s, const FitState& st, const double* a_re, const double* a_im, const double* freq,
                         double* rm, int idx_rinf, int idx_induc);
 void launch_special_penalty(hipStream_t s, double* m0, double* m1, double* m2, int ld, int idx_rinf, int idx_induc,

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         __syncthreads();
     }
 
-    if (it == 0) {   // xmx_norms frozen after the first iteration (drt1d.py:946-951)
+    if (it == 0 && !st.continue_mode) {   // xmx_norms frozen after the first iteration (drt1d.py:946-951)
         for (int k = 0; k < 3; ++k) {
             const double* Mk = st.mk[k] + (size_t)ns * st.ldm + ns;
             if (tpl) toeplitz_matvec(ctp + k * nd, nd, xd, tmp2);
@@ -417,9 +417,10 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
     }
     if (tid == 0) {
         st.outer_iters[b] = it + 1;
-        if (conv) { st.active[b] = 0; st.fit_status[b] = 0; }
+        const bool stop = conv && it + 1 >= st.min_iter;      // `converged and it >= min_iter - 1` (drt1d.py:1356)
+        if (stop) { st.active[b] = 0; st.fit_status[b] = 0; }
         else if (it + 1 >= st.opts.max_iter) { st.active[b] = 0; st.fit_status[b] = 1; }
-        if (!conv && it + 1 < st.opts.max_iter) atomicAdd(st.n_active, 1);
+        if (!stop && it + 1 < st.opts.max_iter) atomicAdd(st.n_active, 1);
     }
 }
 
@@ -488,6 +489,18 @@ int launch_init_weights(hipStream_t s, const FitState& st, int B) {
     hipLaunchKernelGGL(init_weights_kernel, dim3(B), dim3(HT), lds, s, st);
     hipLaunchKernelGGL(record_init_qp_kernel, dim3(1), dim3(64), 0, s, st);
     return 0;
+}
+
+// weights = weights * weight_factor at the top of every warm-restart iteration (drt1d.py:1322)
+__global__ void scale_weights_kernel(FitState st, double factor) {
+    const int b = blockIdx.y;
+    if (!st.active[b]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < st.m) st.w[(size_t)b * st.m + i] *= factor;
+}
+
+void launch_scale_weights(hipStream_t s, const FitState& st, int B, double factor) {
+    hipLaunchKernelGGL(scale_weights_kernel, dim3((st.m + 255) / 256, B), dim3(256), 0, s, st, factor);
 }
 
 int launch_hyper(hipStream_t s, const FitState& st, int B, int it) {

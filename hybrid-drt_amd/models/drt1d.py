@@ -217,6 +217,56 @@ class DRT:
         res['timings_ms'], res['launches'] = plan.timings()
         return res
 
+    # ---- warm restarts of the device loop (drt1d.py:1270-1365) and the candidate generators on top (1497-1632) ---
+    def continue_from_init(self, x_init=None, rho_vector=None, s_vectors=None, weights=None, weight_factor=1,
+                           xtol=1e-2, max_iter=10, min_iter=2, history_of=-1, **kw):
+        """DRT._continue_from_init for the last fitted batch: the outer loop re-entered on the device from the given
+        state (arrays with a leading batch axis; None = the state left by the previous call) with ``kw`` updating the
+        hyper-parameters (e.g. s_0, l2_lambda_0).  est_weights, xmx norms and the data scale stay as fitted.
+        Returns the same dict of arrays as fit_eis_batch (outer_iters = iterations of this call)."""
+        if self._plan is None or self._last_batch is None:
+            raise Exception('continue_from_init needs a finished qphb fit')
+        fit_kw = dict(self.fit_kwargs)
+        fit_kw.update(kw)
+        fit_kw.update(xtol=xtol, max_iter=max_iter)
+        opts, _, _ = self._make_opts(fit_kw)
+        plan = self._plan
+        plan.set_state(x=x_init, rho=rho_vector, s=s_vectors, weights=weights)
+        plan.record_history(history_of)
+        plan.continue_fit(opts, weight_factor=weight_factor, min_iter=min_iter)
+        res = self.collect_staged()
+        if history_of >= 0:
+            res['history'] = plan.history()
+        return res
+
+    def generate_candidates_s0(self, multiplier, steps, xtol=1e-2, max_iter=10, history_of=-1):
+        """DRT._generate_candidates_s0 (drt1d.py:1497-1565) for every spectrum of the last fitted batch: step i
+        restarts with s_0 * multiplier^i, l2_lambda_0 / multiplier^i and (multiplier > 1) the baseline s vectors
+        scaled by multiplier^i.  Returns the list of per-step result dicts."""
+        base = self.collect_staged()
+        s_base = base['s_vectors'].copy()
+        s_in = s_base.copy()
+        s_0 = np.broadcast_to(np.asarray(self.fit_kwargs['s_0'], dtype=float), (3,)).copy()
+        out = []
+        for i in range(1, steps + 1):
+            f = multiplier ** i
+            s_in = s_base * f if multiplier > 1 else s_in * multiplier
+            res = self.continue_from_init(s_vectors=s_in, xtol=xtol, max_iter=max_iter, history_of=history_of,
+                                          s_0=s_0 * f, l2_lambda_0=self.fit_kwargs['l2_lambda_0'] / f)
+            s_in = res['s_vectors'].copy()
+            out.append(res)
+        return out
+
+    def generate_candidates_weights(self, multiplier, steps, xtol=1e-2, max_iter=10, history_of=-1):
+        """DRT._generate_candidates_weights (drt1d.py:1567-1632): step i restarts with weight_factor = multiplier^i.
+        As in the reference (whose shallow list copy lets iterate_qphb update the stored s vectors in place) every
+        step starts from the s vectors the previous step ended with."""
+        out = []
+        for i in range(1, steps + 1):
+            out.append(self.continue_from_init(weight_factor=multiplier ** i, xtol=xtol, max_iter=max_iter,
+                                               history_of=history_of))
+        return out
+
     # ---- what DRTMD takes from a finished fit (mapping/drtmd.py:258-279) ----------------------------------------
     def estimate_distribution_var_batch(self, tau=None, ppd=20, extend_var=False):
         """Diagonal of DRT.estimate_distribution_cov (drt1d.py:3063-3151; order 0, no normalisation) for every

@@ -214,6 +214,17 @@ int hipdrt_plan_distribution_var(hipdrt_plan* plan, const double* basis_eval, in
 int hipdrt_plan_record_history(hipdrt_plan* plan, int b_or_minus1);
 int hipdrt_plan_get_history(hipdrt_plan* plan, double* hist_x, double* hist_rho, double* hist_w,
                             int* qp_iters, int max_rows, int* rows);
+/* Overwrite parts of the fitted batch's state on the device (NULL = keep): x[B][n] (also becomes the previous iterate),
+ * rho[B][3], s[B][3][n], weights[B][m].  The inputs of drt1d._continue_from_init (x_init, rho_vector, s_vectors, weights). */
+int hipdrt_plan_set_state(hipdrt_plan* plan, const double* x, const double* rho, const double* s, const double* weights);
+
+/* drt1d._continue_from_init (hybdrt/models/drt1d.py:1270-1365), EIS fits: re-enter the outer loop from the state on the
+ * device with updated hyper-parameters (opts: s_0, l2_lambda_0, ..., xtol, max_iter), at least min_iter iterations;
+ * every iteration first multiplies the weights by weight_factor.  est_weights, xmx norms and the data scale are kept.
+ * Results through hipdrt_plan_download / _get_history as after hipdrt_plan_fit (outer_iters = iterations of this call).
+ * Used by the candidate generators (drt1d.py:1497-1632) and PFRT (2558-2700).                                       */
+int hipdrt_plan_continue(hipdrt_plan* plan, const hipdrt_fit_opts* opts, double weight_factor, int min_iter);
+
 /* kernel-time breakdown of the last hipdrt_plan_fit in ms (HIP events on the ctx stream):
  * t[0]=total, t[1]=gram, t[2]=qp, t[3]=hyper, t[4]=setup/other; launches[5] same order                 */
 int hipdrt_plan_timings(hipdrt_plan* plan, float* t, int* launches);

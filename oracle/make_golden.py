@@ -186,6 +186,25 @@ def run_posterior(DRT, name, freq, z, ctor_kw, tau_eval):
     print(f"posterior_{name}: llh={llh:.6f} rss={rss:.6f} var range {out['dist_var'].min():.3e}..{out['dist_var'].max():.3e}")
 
 
+def run_candidates(DRT, name, freq, z, ctor_kw):
+    """survey 8f rank 3: warm restarts of the outer loop (_continue_from_init) as the candidate generators drive them
+    (drt1d.py:1497-1632): 2 s_0 steps x4 and 3 weight steps x0.5, every per-iteration state."""
+    with _quiet():
+        drt = DRT(**ctor_kw)
+        drt.fit_eis(freq, z)
+        base_x = drt.qphb_history[-1]["x"].copy()
+        cx_s, hist_s, _ = drt._generate_candidates_s0(4, 2, 1e-2, 10)
+        cx_w, hist_w, _ = drt._generate_candidates_weights(0.5, 3, 1e-2, 10)
+    out = dict(freq=freq, z=z, base_x=base_x)
+    for tag, hist in (("s0", hist_s), ("w", hist_w)):
+        out[f"{tag}_x"] = np.array([h["x"] for h in hist])
+        out[f"{tag}_rho"] = np.array([h["rho_vector"] for h in hist])
+        out[f"{tag}_weights"] = np.array([h["weights"] for h in hist])
+        out[f"{tag}_s"] = np.array([np.array(h["s_vectors"]) for h in hist])
+    np.savez_compressed(os.path.join(OUT, f"refrun_candidates_{name}.npz"), **out)
+    print(f"candidates_{name}: s0 history {len(hist_s)}, weights history {len(hist_w)}")
+
+
 def run_posteriors(DRT, freq_g, z_g, default):
     from oracle.drt_oracle import get_basis_tau
     bt = get_basis_tau(freq_g)
@@ -198,6 +217,12 @@ def main():
     sys.path.insert(0, REPO)
     if "--only-response" in sys.argv:
         run_response_matrices()
+        return
+    if "--only-candidates" in sys.argv:
+        freq_g, z_g = extract_reference_test_vectors()
+        DRT, cvxopt = _boot_reference()
+        run_candidates(DRT, "golden71x91", freq_g, z_g, dict(fit_inductance=True, fit_capacitance=False, fit_dop=False,
+                                                              fit_ohmic=True))
         return
     if "--only-posterior" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()
@@ -237,6 +262,8 @@ def main():
     run_response_matrices()
     # (8) post-fit quantities DRTMD stores per observation (survey 8f rank 1)
     run_posteriors(DRT, freq_g, z_g, default)
+    # (9) warm restarts / candidate generation (survey 8f rank 3)
+    run_candidates(DRT, "golden71x91", freq_g, z_g, default)
 
 
 if __name__ == "__main__":

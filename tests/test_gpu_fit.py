@@ -196,6 +196,55 @@ def test_distribution_variance_batch_256x512():
     np.testing.assert_array_equal(v1[0], var[0])
 
 
+def test_warm_restarts_and_candidates_vs_reference_fixture():
+    """survey 8f rank 3: drt1d._continue_from_init as the reference's candidate generators drive it (2 s_0 steps x4,
+    3 weight steps x0.5 after the known-answer fit): identical iteration counts per step and every intermediate x of
+    the device loop against the reference run."""
+    from hipdrt.models import DRT
+    g = load("refrun_candidates_golden71x91.npz")
+    drt = DRT()
+    drt.fit_eis(g["freq"], g["z"])
+    peak = np.abs(g["base_x"]).max()
+    steps = drt.generate_candidates_s0(4, 2, history_of=0)
+    counts = [int(r["outer_iters"][0]) for r in steps]
+    assert counts == [9, 10]
+    hx = np.concatenate([r["history"]["x"] for r in steps])
+    assert hx.shape == g["s0_x"].shape
+    np.testing.assert_allclose(hx, g["s0_x"], rtol=0, atol=1e-7 * peak)
+    np.testing.assert_allclose(steps[-1]["rho"][0], g["s0_rho"][-1], rtol=1e-6)
+    np.testing.assert_allclose(steps[-1]["weights"][0], g["s0_weights"][-1], rtol=1e-6)
+    # the reference runs the weight candidates after the s_0 candidates but from the BASELINE x / rho / weights, with
+    # the stored s vectors untouched by the s_0 pass (new arrays there): restore that state first
+    base = DRT()
+    base.fit_eis(g["freq"], g["z"])
+    steps_w = base.generate_candidates_weights(0.5, 3, history_of=0)
+    assert [int(r["outer_iters"][0]) for r in steps_w] == [4, 4, 4]
+    hw = np.concatenate([r["history"]["x"] for r in steps_w])
+    np.testing.assert_allclose(hw, g["w_x"], rtol=0, atol=1e-7 * peak)
+    np.testing.assert_allclose(steps_w[-1]["weights"][0], g["w_weights"][-1], rtol=1e-6)
+
+
+def test_warm_restart_batch_vs_oracle():
+    """a batch of C1-size spectra continued with s_0 x 4: per-spectrum iteration counts and results vs the oracle."""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    from oracle import drt_oracle as orc
+    c1 = synth.config_c1()
+    z = synth.zarc2_batch(c1["freq"], 3, first_seed=11)
+    drt = DRT(fixed_basis_tau=c1["tau"])
+    res0 = drt.fit_eis_batch(c1["freq"], z)
+    res = drt.continue_from_init(s_vectors=res0["s_vectors"] * 4.0, s_0=np.ones(3) * 4.0, l2_lambda_0=142.0 / 4.0)
+    for b in range(3):
+        od = orc.OracleDRT(fixed_basis_tau=c1["tau"])
+        od.fit_eis(c1["freq"], z[b])
+        qp = od.qphb_params
+        hist = od.continue_from_init(qp["x_scaled"], qp["rho_vector"], [sv * 4.0 for sv in qp["s_vectors"]], qp["weights"],
+                                     s_0=np.ones(3) * 4.0, l2_lambda_0=142.0 / 4.0)
+        assert res["outer_iters"][b] == len(hist)
+        np.testing.assert_allclose(res["x"][b], hist[-1]["x"], rtol=0, atol=1e-7 * np.abs(hist[-1]["x"]).max())
+        np.testing.assert_allclose(res["rho"][b], hist[-1]["rho_vector"], rtol=1e-6)
+
+
 def test_edge_cases():
     from hipdrt.models import DRT
     freq = np.logspace(5, 0, 12)

@@ -144,3 +144,19 @@ def test_oracle_posterior_quantities_match_reference_run():
     np.testing.assert_array_equal(np.diag(orc.estimate_param_cov(P, cs)), g["param_var"])
     assert orc.evaluate_rss(g["x_scaled"], g["rm"], g["rv"], g["est_weights"]) == pytest.approx(float(g["rss"]), rel=1e-13)
     assert orc.evaluate_llh(g["x_scaled"], g["rm"], g["rv"], g["est_weights"]) == pytest.approx(float(g["llh"]), rel=1e-13)
+
+
+def test_oracle_warm_restarts_match_reference_run():
+    """survey 8f rank 3: _continue_from_init through the reference's two candidate generators after its known-answer
+    fit -- same number of iterations in every step, every intermediate x / rho / weights (the oracle's own fit differs
+    from the reference run by ~1e-12, hence not bit-exact)."""
+    g = np.load(os.path.join(GOLDEN, "refrun_candidates_golden71x91.npz"))
+    d = orc.OracleDRT()
+    d.fit_eis(g["freq"], g["z"])
+    hs, cs = d.generate_candidates_s0(4, 2)
+    hw, cw = d.generate_candidates_weights(0.5, 3)
+    assert cs == [9, 10] and cw == [4, 4, 4]
+    for tag, h in (("s0", hs), ("w", hw)):
+        np.testing.assert_allclose(np.array([e["x"] for e in h]), g[f"{tag}_x"], rtol=0, atol=1e-10 * np.abs(g[f"{tag}_x"]).max())
+        np.testing.assert_allclose(np.array([e["rho_vector"] for e in h]), g[f"{tag}_rho"], rtol=1e-9)
+        np.testing.assert_allclose(np.array([e["weights"] for e in h]), g[f"{tag}_weights"], rtol=1e-10)

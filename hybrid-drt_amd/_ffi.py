@@ -78,6 +78,7 @@ SIGNATURES = {
     "hipdrt_plan_download": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip],
     "hipdrt_plan_get_p_matrix": [_vp, C.c_int, _dp],
     "hipdrt_plan_distribution_var": [_vp, _dp, C.c_int, _dp, _ip],
+    "hipdrt_plan_llh_terms": [_vp, _dp, _dp],
     "hipdrt_plan_set_state": [_vp, _dp, _dp, _dp, _dp],
     "hipdrt_plan_continue": [_vp, C.POINTER(FitOpts), C.c_double, C.c_int],
     "hipdrt_plan_record_history": [_vp, C.c_int],
@@ -365,6 +366,11 @@ class Plan:
 
     def fit(self):
         _check(self._lib.hipdrt_plan_fit(self._h))
+
+    def llh_terms(self):
+        rss, slw = np.empty(self.batch), np.empty(self.batch)
+        _check(self._lib.hipdrt_plan_llh_terms(self._h, _p(rss), _p(slw)))
+        return rss, slw
 
     def set_state(self, x=None, rho=None, s=None, weights=None):
         arrs = [None if a is None else _f64(a) for a in (x, rho, s, weights)]

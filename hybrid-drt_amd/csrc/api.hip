@@ -709,6 +709,22 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     return HIPDRT_OK;
 }
 
+int hipdrt_plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) {
+    HIPDRT_REQUIRE(p && rss && sum_log_w, "NULL pointer");
+    HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const size_t bb = (size_t)p->B * sizeof(double);
+    DevBuf d1, d2;
+    HIPDRT_CHECK(d1.alloc(bb)); HIPDRT_CHECK(d2.alloc(bb));
+    TRY(launch_llh(st, p->state(), p->B, d1.d(), d2.d()));
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(rss, d1.p, bb, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(sum_log_w, d2.p, bb, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
 int hipdrt_plan_set_state(hipdrt_plan* p, const double* x, const double* rho, const double* s, const double* weights) {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");

@@ -491,6 +491,46 @@ int launch_init_weights(hipStream_t s, const FitState& st, int B) {
     return 0;
 }
 
+// Ingredients of DRT.evaluate_llh(weights=estimate_weights(x), x) (drt1d.py:4457-4496, qphb.py:1347-1377) as the PFRT
+// driver evaluates it after every step (drt1d.py:2618-2622): weights re-estimated from the current x alone
+// (est_weights=None), then rss = x'(WR)'(WR)x - 2 (Wy)'(WR)x + (Wy)'(Wy) and sum(log w).  grid = B.
+__global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict__ rss, double* __restrict__ slw) {
+    extern __shared__ double sm[];
+    __shared__ double red[HNW];
+    const int b = blockIdx.x, tid = threadIdx.x, n = st.n, m = st.m;
+    double* xs = sm;
+    double* yh = xs + n;        // rm @ x
+    double* r2 = yh + m;        // residual^2
+    double* sh = r2 + m;        // vmm @ residual^2
+    const double* rv = st.rv + (size_t)b * m;
+    for (int i = tid; i < n; i += HT) xs[i] = st.x[(size_t)b * n + i];
+    __syncthreads();
+    rows_matvec(st.rm, st.ldrm, m, n, xs, yh);
+    __syncthreads();
+    for (int i = tid; i < m; i += HT) { const double r = yh[i] - rv[i]; r2[i] = r * r; }
+    __syncthreads();
+    rows_matvec(st.vmm, m, m, m, r2, sh);
+    __syncthreads();
+    const double vf = st.var_floor[b];
+    double a = 0.0, c2 = 0.0, d = 0.0, lw = 0.0;
+    for (int i = tid; i < m; i += HT) {
+        double v = sh[i];
+        if (v < vf) v = vf;
+        const double w = fmax(1.0 / sqrt(v), 1e-10);
+        const double wy = w * yh[i], wr = w * rv[i];
+        a += wy * wy; c2 += wr * wy; d += wr * wr; lw += log(w);
+    }
+    a = blk_sum(a, red); c2 = blk_sum(c2, red); d = blk_sum(d, red); lw = blk_sum(lw, red);
+    if (tid == 0) { rss[b] = a - 2.0 * c2 + d; slw[b] = lw; }
+}
+
+int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw) {
+    const size_t lds = (size_t)(st.n + 3 * st.m) * sizeof(double);
+    if (int rc = set_lds(reinterpret_cast<const void*>(llh_kernel), lds)) return rc;
+    hipLaunchKernelGGL(llh_kernel, dim3(B), dim3(HT), lds, s, st, rss, slw);
+    return 0;
+}
+
 // weights = weights * weight_factor at the top of every warm-restart iteration (drt1d.py:1322)
 __global__ void scale_weights_kernel(FitState st, double factor) {
     const int b = blockIdx.y;

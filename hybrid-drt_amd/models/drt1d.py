@@ -267,6 +267,42 @@ class DRT:
                                                history_of=history_of))
         return out
 
+    def evaluate_step_llh_batch(self, alpha_0=2, beta_0=1):
+        """evaluate_llh(weights=estimate_weights(x), x) (drt1d.py:2618-2622) for the current x of every spectrum of
+        the batch: residuals, re-estimated weights and both sums on the device, the two lgamma constants here."""
+        from scipy.special import loggamma
+        rss, slw = self._plan.llh_terms()
+        alpha_n = alpha_0 - 1 + self._plan.m / 2
+        beta_n = beta_0 + 0.5 * rss
+        return alpha_0 * np.log(beta_0) - alpha_n * np.log(beta_n) + loggamma(alpha_n) - loggamma(alpha_0) + slw
+
+    def pfrt_fit_eis_batch(self, frequencies, z_batch, factors=None, max_iter_per_step=10, max_init_iter=20,
+                           xtol=1e-2, nonneg=True, **kw):
+        """DRT.pfrt_fit_eis (drt1d.py:2558-2690) for B spectra at once: a full fit at the first regularisation factor
+        (s_0 * f, l2_lambda_0 / f), then one warm restart per further factor on the device.  Returns
+        {'factors', 'step_x' (S, B, n) scaled-space solutions, 'step_llh' (S, B), 'step_iters' (S, B)}."""
+        base = qphb.get_default_hypers(True, False, 'gaussian')
+        base.update({k: v for k, v in kw.items() if k in base})
+        if factors is None:
+            factors = np.logspace(-1, 1, 11)
+        s_0 = np.broadcast_to(np.asarray(base['s_0'], dtype=float), (3,))
+
+        def step_hypers(f):
+            return dict(s_0=s_0 * f, l2_lambda_0=base['l2_lambda_0'] / f)
+
+        init_kw = dict(kw)
+        init_kw.update(step_hypers(factors[0]))
+        res = self.fit_eis_batch(frequencies, z_batch, nonneg=nonneg, max_iter=max_init_iter, xtol=xtol, **init_kw)
+        step_x, step_llh, step_iters = [res['x'].copy()], [self.evaluate_step_llh_batch()], [res['outer_iters'].copy()]
+        for f in factors[1:]:
+            res = self.continue_from_init(xtol=xtol, max_iter=max_iter_per_step, **step_hypers(f))
+            step_x.append(res['x'].copy())
+            step_llh.append(self.evaluate_step_llh_batch())
+            step_iters.append(res['outer_iters'].copy())
+        self.pfrt_result = {'factors': np.asarray(factors), 'step_x': np.array(step_x), 'step_llh': np.array(step_llh),
+                            'step_iters': np.array(step_iters)}
+        return self.pfrt_result
+
     # ---- what DRTMD takes from a finished fit (mapping/drtmd.py:258-279) ----------------------------------------
     def estimate_distribution_var_batch(self, tau=None, ppd=20, extend_var=False):
         """Diagonal of DRT.estimate_distribution_cov (drt1d.py:3063-3151; order 0, no normalisation) for every

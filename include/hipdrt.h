@@ -214,6 +214,12 @@ int hipdrt_plan_distribution_var(hipdrt_plan* plan, const double* basis_eval, in
 int hipdrt_plan_record_history(hipdrt_plan* plan, int b_or_minus1);
 int hipdrt_plan_get_history(hipdrt_plan* plan, double* hist_x, double* hist_rho, double* hist_w,
                             int* qp_iters, int max_rows, int* rows);
+/* Ingredients of DRT.evaluate_llh(weights=qphb.estimate_weights(x, rv, vmm, rm), x=x) (hybdrt/models/drt1d.py:4457-4496,
+ * qphb.py:1347-1377) for the current x of every spectrum, as the PFRT driver evaluates it after each step
+ * (drt1d.py:2618-2622): out rss[B] = weighted residual sum of squares, sum_log_w[B] = sum(log(weights)).
+ * llh = a0 ln b0 - an ln(b0 + rss/2) + lgamma(an) - lgamma(a0) + sum_log_w with an = a0 - 1 + m/2.                 */
+int hipdrt_plan_llh_terms(hipdrt_plan* plan, double* rss, double* sum_log_w);
+
 /* Overwrite parts of the fitted batch's state on the device (NULL = keep): x[B][n] (also becomes the previous iterate),
  * rho[B][3], s[B][3][n], weights[B][m].  The inputs of drt1d._continue_from_init (x_init, rho_vector, s_vectors, weights). */
 int hipdrt_plan_set_state(hipdrt_plan* plan, const double* x, const double* rho, const double* s, const double* weights);

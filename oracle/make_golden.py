@@ -201,6 +201,13 @@ def run_candidates(DRT, name, freq, z, ctor_kw):
         out[f"{tag}_rho"] = np.array([h["rho_vector"] for h in hist])
         out[f"{tag}_weights"] = np.array([h["weights"] for h in hist])
         out[f"{tag}_s"] = np.array([np.array(h["s_vectors"]) for h in hist])
+    # PFRT (drt1d.py:2558-2700): full fit at factor 0.1, ten warm restarts up to factor 10
+    with _quiet():
+        drt2 = DRT(**ctor_kw)
+        drt2.pfrt_fit_eis(freq, z)
+    pr = drt2.pfrt_result
+    out.update(pfrt_factors=pr["factors"], pfrt_step_x=np.array(pr["step_x"]), pfrt_step_llh=np.array(pr["step_llh"]),
+               pfrt_history_len=len(drt2.pfrt_history), pfrt_init_len=len(drt2.qphb_history))
     np.savez_compressed(os.path.join(OUT, f"refrun_candidates_{name}.npz"), **out)
     print(f"candidates_{name}: s0 history {len(hist_s)}, weights history {len(hist_w)}")
 

@@ -224,6 +224,19 @@ def test_warm_restarts_and_candidates_vs_reference_fixture():
     np.testing.assert_allclose(steps_w[-1]["weights"][0], g["w_weights"][-1], rtol=1e-6)
 
 
+def test_pfrt_fit_vs_reference_fixture():
+    """DRT.pfrt_fit_eis (11 regularisation factors: one full fit + ten warm restarts) against the reference run:
+    per-step iteration counts (58 in total), every step's final x and its log-likelihood."""
+    from hipdrt.models import DRT
+    g = load("refrun_candidates_golden71x91.npz")
+    drt = DRT()
+    pr = drt.pfrt_fit_eis_batch(g["freq"], g["z"][None, :])
+    assert int(pr["step_iters"].sum()) == int(g["pfrt_history_len"])
+    assert int(pr["step_iters"][0, 0]) == int(g["pfrt_init_len"])
+    np.testing.assert_allclose(pr["step_x"][:, 0], g["pfrt_step_x"], rtol=0, atol=1e-7 * np.abs(g["pfrt_step_x"]).max())
+    np.testing.assert_allclose(pr["step_llh"][:, 0], g["pfrt_step_llh"], rtol=1e-7)
+
+
 def test_warm_restart_batch_vs_oracle():
     """a batch of C1-size spectra continued with s_0 x 4: per-spectrum iteration counts and results vs the oracle."""
     from hipdrt import synth

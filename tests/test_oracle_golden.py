@@ -160,3 +160,12 @@ def test_oracle_warm_restarts_match_reference_run():
         np.testing.assert_allclose(np.array([e["x"] for e in h]), g[f"{tag}_x"], rtol=0, atol=1e-10 * np.abs(g[f"{tag}_x"]).max())
         np.testing.assert_allclose(np.array([e["rho_vector"] for e in h]), g[f"{tag}_rho"], rtol=1e-9)
         np.testing.assert_allclose(np.array([e["weights"] for e in h]), g[f"{tag}_weights"], rtol=1e-10)
+
+
+def test_oracle_pfrt_matches_reference_run():
+    g = np.load(os.path.join(GOLDEN, "refrun_candidates_golden71x91.npz"))
+    d = orc.OracleDRT()
+    r = d.pfrt_fit_eis(g["freq"], g["z"])
+    assert sum(r["counts"]) == int(g["pfrt_history_len"]) and r["counts"][0] == int(g["pfrt_init_len"])
+    np.testing.assert_allclose(r["step_x"], g["pfrt_step_x"], rtol=0, atol=1e-10 * np.abs(g["pfrt_step_x"]).max())
+    np.testing.assert_allclose(r["step_llh"], g["pfrt_step_llh"], rtol=1e-9)

@@ -167,8 +167,10 @@ __global__ __launch_bounds__(1024) void impedance_interp_kernel(
                 const double re1 = np_interp(xb, L.xr, L.fr, L.sr, ng, x0r, idr);
                 const double im1 = np_interp(xb, L.xi, L.fi, L.si, ng, x0i, idi);
                 if (even) {
-                    *reinterpret_cast<double2*>(a_re + o) = make_double2(re0, re1);
-                    *reinterpret_cast<double2*>(a_im + o) = make_double2(im0, im1);
+                    // written once, read later by another kernel: non-temporal 16-byte stores
+                    typedef double v2d_t __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store((v2d_t){re0, re1}, reinterpret_cast<v2d_t*>(a_re + o));
+                    __builtin_nontemporal_store((v2d_t){im0, im1}, reinterpret_cast<v2d_t*>(a_im + o));
                 } else {
                     a_re[o] = re0; a_re[o + 1] = re1;
                     a_im[o] = im0; a_im[o + 1] = im1;

@@ -57,6 +57,8 @@ SIGNATURES = {
                                 C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp],
     "hipdrt_impedance_matrix_dev": [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                                     C.c_int, _dp, _dp, _dp, _dp, C.c_int, _vp, _vp, C.c_int, C.POINTER(C.c_float)],
+    "hipdrt_phasor_z_matrix": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp],
+    "hipdrt_phasor_v_matrix": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp],
     "hipdrt_chrono_var_matrix": [_vp, _dp, C.c_int, _ip, C.c_int, C.c_double, C.c_int, _dp],
     "hipdrt_response_lookup": [_vp, C.c_double, C.c_int, C.c_int, _dp, _dp],
     "hipdrt_response_matrix": [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp,
@@ -214,6 +216,21 @@ class Context:
                                                      _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), int(ny), _vp(dev_re),
                                                      _vp(dev_im), int(repeat), C.byref(ms)))
         return ms.value
+
+    def phasor_z_matrix(self, freq, nu, nu_epsilon):
+        freq, nu = _f64(freq), _f64(nu)
+        zr, zi = np.empty((freq.size, nu.size)), np.empty((freq.size, nu.size))
+        _check(self._lib.hipdrt_phasor_z_matrix(self._h, _p(freq), freq.size, _p(nu), nu.size, float(nu_epsilon), _p(zr),
+                                                _p(zi)))
+        return zr + 1j * zi
+
+    def phasor_v_matrix(self, times, nu, nu_epsilon, step_times, step_sizes):
+        times, nu, st, sa = _f64(times), _f64(nu), _f64(step_times), _f64(step_sizes)
+        rm = np.empty((times.size, nu.size))
+        lay = np.empty((st.size, times.size, nu.size))
+        _check(self._lib.hipdrt_phasor_v_matrix(self._h, _p(times), times.size, _p(nu), nu.size, float(nu_epsilon), _p(st),
+                                                _p(sa), st.size, _p(rm), _p(lay)))
+        return rm, lay
 
     def chrono_var_matrix(self, tt, seg, vmm_epsilon, uniform=False):
         tt = _f64(tt)

@@ -140,6 +140,47 @@ int hipdrt_impedance_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, 
     return HIPDRT_OK;
 }
 
+int hipdrt_phasor_z_matrix(hipdrt_ctx* ctx, const double* freq, int nf, const double* basis_nu, int n_nu, double nu_epsilon,
+                           double* zm_re, double* zm_im) {
+    HIPDRT_REQUIRE(ctx && freq && basis_nu && zm_re && zm_im, "NULL pointer");
+    HIPDRT_REQUIRE(nf >= 1 && n_nu >= 1 && nu_epsilon > 0.0, "nf, n_nu >= 1, nu_epsilon > 0");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf df, dn, dr, di;
+    TRY(upload(df, freq, (size_t)nf * sizeof(double), st));
+    TRY(upload(dn, basis_nu, (size_t)n_nu * sizeof(double), st));
+    const size_t ob = (size_t)nf * n_nu * sizeof(double);
+    HIPDRT_CHECK(dr.alloc(ob)); HIPDRT_CHECK(di.alloc(ob));
+    launch_phasor_z(st, df.d(), nf, dn.d(), n_nu, nu_epsilon, dr.d(), di.d());
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(zm_re, dr.p, ob, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(zm_im, di.p, ob, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+int hipdrt_phasor_v_matrix(hipdrt_ctx* ctx, const double* times, int nt, const double* basis_nu, int n_nu, double nu_epsilon,
+                           const double* step_times, const double* step_sizes, int nsteps, double* rm, double* layered) {
+    HIPDRT_REQUIRE(ctx && times && basis_nu && step_times && step_sizes && rm, "NULL pointer");
+    HIPDRT_REQUIRE(nt >= 1 && n_nu >= 1 && nsteps >= 1 && nu_epsilon > 0.0, "nt, n_nu, nsteps >= 1, nu_epsilon > 0");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf dt, dn, ds, da, dr, dl;
+    TRY(upload(dt, times, (size_t)nt * sizeof(double), st));
+    TRY(upload(dn, basis_nu, (size_t)n_nu * sizeof(double), st));
+    TRY(upload(ds, step_times, (size_t)nsteps * sizeof(double), st));
+    TRY(upload(da, step_sizes, (size_t)nsteps * sizeof(double), st));
+    const size_t ob = (size_t)nt * n_nu * sizeof(double);
+    HIPDRT_CHECK(dr.alloc(ob));
+    if (layered) HIPDRT_CHECK(dl.alloc(ob * nsteps));
+    launch_phasor_v(st, dt.d(), nt, dn.d(), n_nu, nu_epsilon, ds.d(), da.d(), nsteps, dr.d(), layered ? dl.d() : nullptr);
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(rm, dr.p, ob, hipMemcpyDeviceToHost, st));
+    if (layered) HIPDRT_CHECK(hipMemcpyAsync(layered, dl.p, ob * nsteps, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
 int hipdrt_chrono_var_matrix(hipdrt_ctx* ctx, const double* tt, int nt, const int* seg, int nseg, double vmm_epsilon,
                              int uniform, double* vmm) {
     HIPDRT_REQUIRE(ctx && tt && seg && vmm, "NULL pointer");

@@ -79,6 +79,10 @@ void launch_lookup_slopes(hipStream_t st, int ngrid, const double* xp, const dou
 void launch_impedance_matrix(hipStream_t st, int B, int freq_batched, const double* freq, int nf, const double* tau,
                              int ntau, int mode, int toeplitz, double eps, int ngrid, const double* lut6, int ny,
                              double* a_re, double* a_im, double* cr_scratch);
+void launch_phasor_z(hipStream_t st, const double* freq, int nf, const double* nu, int nnu, double eps, double* zre,
+                     double* zim);
+void launch_phasor_v(hipStream_t st, const double* times, int nt, const double* nu, int nnu, double eps,
+                     const double* step_times, const double* step_sizes, int nsteps, double* rm, double* layered);
 void launch_chrono_vmm(hipStream_t st, const double* tt, int nt, const int* seg, int nseg, double eps, int uniform,
                        double* vmm);
 void launch_response_lookup(hipStream_t st, double eps, int ngrid, int ny, const double* td, double* v);

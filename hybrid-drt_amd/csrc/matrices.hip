@@ -7,6 +7,7 @@
 //  response_*_kernel      mat1d.construct_response_matrix         hybdrt/matrices/mat1d.py:16-122
 //  penalty_kernel         mat1d.construct_integrated_derivative_matrix  mat1d.py:125-209, basis.py:382-395
 //  eis_vmm_kernel         mat1d.construct_eis_var_matrix          mat1d.py:493-515
+//  phasor_z_kernel / phasor_v_kernel  phasance.construct_phasor_z_matrix / _v_matrix   hybdrt/matrices/phasance.py:108-144
 //  chrono_vmm_kernel      mat1d.construct_chrono_var_matrix       mat1d.py:457-490 (transformed times: utils/chrono.py:5-44)
 //
 // Layout: every matrix row-major float64.  The interp build is HBM-write bound (2*nf*ntau*8 B per
@@ -465,6 +466,93 @@ void launch_impedance_matrix(hipStream_t st, int B, int freq_batched, const doub
         hipLaunchKernelGGL(impedance_trapz_kernel, dim3((ntau + 15) / 16, nf, B), dim3(256), 3 * ny * sizeof(double),
                            st, freq_batched, freq, nf, tau, ntau, eps, ny, a_re, a_im);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Distribution of phasances (gaussian nu basis, normalize=False)
+// ---------------------------------------------------------------------------------------------------------
+// erf(x + i y) by Abramowitz & Stegun 7.1.29 (|y| <= ~1: here y = -pi / (4 eps)); absolute error ~1e-16
+__device__ __forceinline__ void cerf(double x, double y, double& re, double& im) {
+    const double PI = 3.141592653589793;
+    const double ex2 = exp(-x * x);
+    re = erf(x);
+    const double s = sin(x * y), xy2 = 2.0 * x * y;
+    const double c2 = cos(xy2), s2 = sin(xy2);
+    if (x != 0.0) { re += ex2 * 2.0 * s * s / (2.0 * PI * x); im = ex2 * s2 / (2.0 * PI * x); }
+    else im = ex2 * y / PI;
+    double sre = 0.0, sim = 0.0;
+    for (int n = 1; n <= 32; ++n) {
+        const double dn = (double)n;
+        const double en = exp(-0.25 * dn * dn) / (dn * dn + 4.0 * x * x);
+        const double ch = cosh(dn * y), sh = sinh(dn * y);
+        sre += en * (2.0 * x - 2.0 * x * ch * c2 + dn * sh * s2);
+        sim += en * (2.0 * x * ch * s2 + dn * sh * c2);
+    }
+    re += 2.0 / PI * ex2 * sre;
+    im += 2.0 / PI * ex2 * sim;
+}
+
+// zm[r][c] = F(b) - F(a),  F(nu) = sqrt(pi)/2 (j w)^nu_m / eps * (j w)^(ln(j w) / 4 eps^2) * erf(eps (nu - nu_m) - ln(j w) / 2 eps),
+// (a, b) = (min(0, sgn nu_m), max(0, sgn nu_m))   (phasance.py:19-33, 62-82)
+__global__ void phasor_z_kernel(const double* __restrict__ freq, int nf, const double* __restrict__ nu, int nnu, double eps,
+                                double* __restrict__ zre, double* __restrict__ zim) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= nnu) return;
+    const double PI = 3.141592653589793;
+    const double lw = log(2.0 * PI * freq[r]), num = nu[c];
+    const double sg = (num > 0.0) ? 1.0 : ((num < 0.0) ? -1.0 : 0.0);
+    const double a = fmin(0.0, sg), b = fmax(0.0, sg);
+    // prefactor exp(nu_m L + L^2 / (4 eps^2)), L = ln(j w) = lw + j pi/2
+    const double q = 1.0 / (4.0 * eps * eps);
+    const double e_re = num * lw + (lw * lw - 0.25 * PI * PI) * q;
+    const double e_im = num * 0.5 * PI + PI * lw * q;
+    const double mag = 0.5 * sqrt(PI) / eps * exp(e_re);
+    const double p_re = mag * cos(e_im), p_im = mag * sin(e_im);
+    const double y = -PI / (4.0 * eps), xoff = -lw / (2.0 * eps);
+    double br, bi, ar, ai;
+    cerf(eps * (b - num) + xoff, y, br, bi);
+    cerf(eps * (a - num) + xoff, y, ar, ai);
+    const double dr = br - ar, di = bi - ai;
+    zre[(size_t)r * nnu + c] = p_re * dr - p_im * di;
+    zim[(size_t)r * nnu + c] = p_re * di + p_im * dr;
+}
+
+// rm_layered[k][r][c] = size_k (G(b) - G(a)) for t_r > t_k, G(nu) = sqrt(pi)/2 dt^-nu_m / Gamma(1 - nu_m) / eps *
+// dt^(ln dt / 4 eps^2) * erf(eps (nu - nu_m) + ln dt / 2 eps), dt = t_r - t_k; rm = sum over k  (phasance.py:38-52, 121-144)
+__global__ void phasor_v_kernel(const double* __restrict__ times, int nt, const double* __restrict__ nu, int nnu, double eps,
+                                const double* __restrict__ step_times, const double* __restrict__ step_sizes, int nsteps,
+                                double* __restrict__ rm, double* __restrict__ layered) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= nnu) return;
+    const double PI = 3.141592653589793;
+    const double num = nu[c], t = times[r];
+    const double sg = (num > 0.0) ? 1.0 : ((num < 0.0) ? -1.0 : 0.0);
+    const double a = fmin(0.0, sg), b = fmax(0.0, sg);
+    const double gin = 1.0 / tgamma(1.0 - num);
+    double acc = 0.0;
+    for (int k = 0; k < nsteps; ++k) {
+        double val = 0.0;
+        if (t > step_times[k]) {
+            const double ldt = log(t - step_times[k]);
+            const double pre = 0.5 * sqrt(PI) * (exp(-num * ldt) * gin) / eps * exp(ldt * ldt / (4.0 * eps * eps));
+            const double xo = ldt / (2.0 * eps);
+            val = step_sizes[k] * (pre * erf(eps * (b - num) + xo) - pre * erf(eps * (a - num) + xo));
+        }
+        if (layered) layered[((size_t)k * nt + r) * nnu + c] = val;
+        acc += val;
+    }
+    rm[(size_t)r * nnu + c] = acc;
+}
+
+void launch_phasor_z(hipStream_t st, const double* freq, int nf, const double* nu, int nnu, double eps, double* zre,
+                     double* zim) {
+    hipLaunchKernelGGL(phasor_z_kernel, dim3((nnu + 63) / 64, nf), dim3(64), 0, st, freq, nf, nu, nnu, eps, zre, zim);
+}
+
+void launch_phasor_v(hipStream_t st, const double* times, int nt, const double* nu, int nnu, double eps,
+                     const double* step_times, const double* step_sizes, int nsteps, double* rm, double* layered) {
+    hipLaunchKernelGGL(phasor_v_kernel, dim3((nnu + 63) / 64, nt), dim3(64), 0, st, times, nt, nu, nnu, eps, step_times,
+                       step_sizes, nsteps, rm, layered);
 }
 
 // Chrono variance-estimation matrix: one 256-thread block per row.  tt = transformed sample times, seg[nseg+1] =

@@ -74,6 +74,16 @@ int hipdrt_impedance_matrix_dev(hipdrt_ctx* ctx, int B, int freq_batched, const 
                                 const double* log_wt_im, const double* z_im, int ny,
                                 void* a_re_dev, void* a_im_dev, int repeat, float* elapsed_ms);
 
+/* phasance.construct_phasor_z_matrix (hybdrt/matrices/phasance.py:108-118), nu_basis_type='gaussian', normalize=False:
+ * the distribution-of-phasances impedance columns.  out: zm_re, zm_im [nf][n_nu] (real and imaginary part).           */
+int hipdrt_phasor_z_matrix(hipdrt_ctx* ctx, const double* freq, int nf, const double* basis_nu, int n_nu,
+                           double nu_epsilon, double* zm_re, double* zm_im);
+/* phasance.construct_phasor_v_matrix (phasance.py:121-144), gaussian nu basis, galvanostatic ideal steps.
+ * out: rm[nt][n_nu] = sum over steps; layered[nsteps][nt][n_nu] (may be NULL)                                        */
+int hipdrt_phasor_v_matrix(hipdrt_ctx* ctx, const double* times, int nt, const double* basis_nu, int n_nu,
+                           double nu_epsilon, const double* step_times, const double* step_sizes, int nsteps,
+                           double* rm, double* layered);
+
 /* mat1d.construct_chrono_var_matrix (hybdrt/matrices/mat1d.py:457-490).  tt[nt] = the samples' transformed times
  * (utils/chrono.py:5-44 fwd_transform), seg[nseg+1] = sample-index bounds of the step segments
  * ([0, step indices..., nt], preprocessing.py:161-178); uniform != 0 -> error_structure='uniform' (ones / nt).

@@ -161,6 +161,19 @@ def run_response_matrices():
         st = cases[name][0]
         out[f"{name}_vmm"] = mat1d.construct_chrono_var_matrix(times, st, 0.25, None)
     out["uniform_vmm"] = mat1d.construct_chrono_var_matrix(times, cases["one_step"][0], 0.25, 'uniform')
+    # distribution-of-phasances matrices (survey row a18, phasance.py:108-184): the fit's nu grid and epsilon
+    from hybdrt.matrices import phasance
+    basis_nu = np.concatenate([np.linspace(-1, -0.4, 25), np.linspace(0.4, 1, 25)])
+    nu_eps = 1 / np.median(np.diff(np.sort(basis_nu)))
+    f_dop = np.logspace(5, 1, 64)
+    out.update(dop_nu=basis_nu, dop_epsilon=nu_eps, dop_freq=f_dop,
+               dop_zm=phasance.construct_phasor_z_matrix(f_dop, basis_nu, 'gaussian', nu_eps),
+               dop_scale=phasance.phasor_scale_vector(basis_nu, tau))
+    vm, vlay = phasance.construct_phasor_v_matrix(times, basis_nu, 'gaussian', nu_eps, 'ideal', cases["three_steps"][0],
+                                                   cases["three_steps"][1])
+    out.update(dop_vm=vm, dop_vm_layered=vlay)
+    for eps_small in (2.0,):
+        out[f"dop_zm_eps{eps_small:g}"] = phasance.construct_phasor_z_matrix(f_dop, basis_nu, 'gaussian', eps_small)
     np.savez_compressed(os.path.join(OUT, "refrun_response.npz"), **out)
     print("refrun_response.npz written:", {k: np.shape(v) for k, v in out.items()})
 

@@ -225,3 +225,24 @@ def test_chrono_var_matrix_vs_reference_fixture(ctx, case):
     np.testing.assert_allclose(vmm.sum(axis=1), 1.0, rtol=1e-14)
     uni = mat1d.construct_chrono_var_matrix(g["times"], g["one_step_step_times"], 0.25, 'uniform')
     np.testing.assert_array_equal(uni, g["uniform_vmm"])
+
+
+def test_phasance_matrices_vs_reference_fixture(ctx):
+    """survey row a18: distribution-of-phasances columns (complex erf on the device, A&S 7.1.29)."""
+    from hipdrt.matrices import phasance
+    g = load("refrun_response.npz")
+    nu, eps = g["dop_nu"], float(g["dop_epsilon"])
+    zm = phasance.construct_phasor_z_matrix(g["dop_freq"], nu, 'gaussian', eps)
+    ref = g["dop_zm"]
+    # each entry is a difference of two erf values times a prefactor of up to 2e4: relative to the row's largest entry
+    np.testing.assert_allclose(zm, ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
+    # a wide basis (eps = 2): both erf values sit near +-1 and their difference loses digits in the reference as well
+    # (each erf carries ~1e-16 absolute error); 6e-11 observed
+    zm2 = phasance.construct_phasor_z_matrix(g["dop_freq"], nu, 'gaussian', 2.0)
+    np.testing.assert_allclose(zm2, g["dop_zm_eps2"], rtol=1e-9, atol=1e-13 * np.abs(g["dop_zm_eps2"]).max())
+    vm, vlay = phasance.construct_phasor_v_matrix(g["times"], nu, 'gaussian', eps, 'ideal', g["three_steps_step_times"],
+                                                  g["three_steps_step_sizes"])
+    np.testing.assert_array_equal(vlay == 0.0, g["dop_vm_layered"] == 0.0)
+    np.testing.assert_allclose(vlay, g["dop_vm_layered"], rtol=1e-11, atol=1e-13 * np.abs(g["dop_vm_layered"]).max())
+    np.testing.assert_allclose(vm, g["dop_vm"], rtol=1e-11, atol=1e-13 * np.abs(g["dop_vm"]).max())
+    np.testing.assert_array_equal(phasance.phasor_scale_vector(nu, g["tau"]), g["dop_scale"])

@@ -123,6 +123,13 @@ def test_oracle_response_path_matches_reference_run():
                                            g["trapz_step_sizes"], float(g["trapz_epsilon"]), 'trapz')
     np.testing.assert_array_equal(a, g["trapz_A"])
     np.testing.assert_array_equal(lay, g["trapz_layered"])
+    # distribution-of-phasances matrices (row a18)
+    eps = float(g["dop_epsilon"])
+    np.testing.assert_array_equal(orc.construct_phasor_z_matrix(g["dop_freq"], g["dop_nu"], eps), g["dop_zm"])
+    vm, vl = orc.construct_phasor_v_matrix(g["times"], g["dop_nu"], eps, g["three_steps_step_times"], g["three_steps_step_sizes"])
+    np.testing.assert_array_equal(vm, g["dop_vm"])
+    np.testing.assert_array_equal(vl, g["dop_vm_layered"])
+    np.testing.assert_array_equal(orc.phasor_scale_vector(g["dop_nu"], g["tau"]), g["dop_scale"])
     # chrono variance-estimation matrices (row a5)
     for case in ("one_step", "three_steps"):
         np.testing.assert_array_equal(orc.construct_chrono_var_matrix(g["times"], g[f"{case}_step_times"], 0.25),

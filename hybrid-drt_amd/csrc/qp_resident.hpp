@@ -41,16 +41,29 @@ struct ResSmem {
     double* U;       // [NP][PLD]   inverse diagonal blocks
     double* vec;     // [NP + 32]
     double* dvec;    // [NP + 32]
-    double* colbuf;  // [64]
     double* red;     // [4][RNW][4]
     double* t21;     // [16][DLD]   L21 of the current block
     double* dsc;     // [16][DLD]   diagonal block being factored
     double* img;     // [2][64][4]  register images of -D21', -D22' of the next diagonal block
     int* flag;       // [4]
+
+    // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
+    static constexpr int VEC = 528 + 16 + 32;      // RNP_MAX + 16 + 32: NP <= 544
+    static constexpr int FIXED = 4 * (512 / 64) * 4 + 2 * 16 * 17 + 8 + 512 + 2 * VEC;   // doubles before U
+    __device__ __forceinline__ void carve(double* smem) {
+        red = smem;
+        t21 = red + 4 * (512 / 64) * 4;
+        dsc = t21 + 16 * 17;
+        flag = reinterpret_cast<int*>(dsc + 16 * 17);
+        img = dsc + 16 * 17 + 8;
+        vec = img + 512;
+        dvec = vec + VEC;
+        U = dvec + VEC;
+    }
 };
 
 struct OpsResident {
-    const double* P; int ldp; double* L; int nch; int n; ResSmem sm;   // nch = tiles per tile-row (NP/16)
+    double* L; int nch; int n; ResSmem sm;                             // nch = tiles per tile-row (NP/16)
     const double* Ppk; int nchp;                                       // P in L's tile layout (lower tiles)
     // Optional extra tile rows appended below the square matrix (tile rows nch .. nch+nex-1 of L, source tiles
     // Bex[nex][nchp][256]): the factorisation treats them as more panel rows, so they come out as Bex * L^-T --
@@ -787,20 +800,11 @@ __global__ __launch_bounds__(RT) void cov_kernel_resident(CovArgs a, int NP) {
     const int b = blockIdx.x;
     extern __shared__ double smem[];
     OpsResident ops;
-    ops.P = nullptr; ops.ldp = 0;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk + (size_t)b * a.ppk_stride; ops.nchp = a.nchp;
     ops.nex = a.nex; ops.Bex = a.Bex; ops.fwd = false;
-    constexpr int VEC = RNP_MAX + 16 + 32;
-    ops.sm.colbuf = smem;
-    ops.sm.red = ops.sm.colbuf + 64;
-    ops.sm.t21 = ops.sm.red + 4 * RNW * 4;
-    ops.sm.dsc = ops.sm.t21 + 16 * DLD;
-    ops.sm.flag = reinterpret_cast<int*>(ops.sm.dsc + 16 * DLD);
-    ops.sm.img = ops.sm.dsc + 16 * DLD + 8;
-    ops.sm.vec = ops.sm.img + 512;
-    ops.sm.dvec = ops.sm.vec + VEC;
-    ops.sm.U = ops.sm.dvec + VEC;
+    constexpr int VEC = ResSmem::VEC;
+    ops.sm.carve(smem);
     for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
     for (int i = threadIdx.x; i < VEC; i += RT) { ops.sm.vec[i] = 0.0; ops.sm.dvec[i] = 0.0; }   // no diagonal shift
     __syncthreads();
@@ -830,20 +834,9 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
     if (a.active && !a.active[b]) return;
     extern __shared__ double smem[];
     OpsResident ops;
-    ops.P = a.P + (size_t)b * a.p_stride; ops.ldp = a.ldp;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk ? a.Ppk + (size_t)b * a.ppk_stride : nullptr; ops.nchp = a.nchp;
-    // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
-    constexpr int VEC = RNP_MAX + 16 + 32;                 // NP <= 544
-    ops.sm.colbuf = smem;
-    ops.sm.red = ops.sm.colbuf + 64;
-    ops.sm.t21 = ops.sm.red + 4 * RNW * 4;
-    ops.sm.dsc = ops.sm.t21 + 16 * DLD;
-    ops.sm.flag = reinterpret_cast<int*>(ops.sm.dsc + 16 * DLD);
-    ops.sm.img = ops.sm.dsc + 16 * DLD + 8;
-    ops.sm.vec = ops.sm.img + 512;
-    ops.sm.dvec = ops.sm.vec + VEC;
-    ops.sm.U = ops.sm.dvec + VEC;
+    ops.sm.carve(smem);
     // zero U (the upper-right quarter of every inverse block stays zero) and the padding of vec (read by the
     // updates of the last, partial block)
     for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
@@ -854,7 +847,7 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
 }
 
 static size_t resident_lds_bytes(int NP) {
-    return ((size_t)NP * PLD + 2 * (size_t)(RNP_MAX + 16 + 32) + 64 + 4 * RNW * 4 + 2 * 16 * DLD + 8 + 512) * sizeof(double);
+    return ((size_t)NP * PLD + ResSmem::FIXED) * sizeof(double);
 }
 
 // scratch doubles per problem for the tile-packed factor: (NP/16)^2 tiles of 256 doubles

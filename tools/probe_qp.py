@@ -29,11 +29,13 @@ for rep in range(3):
     prof = ctx.qp_profile(reset=True)
     it = int(res["iterations"][0])
     print(f"B={B} iters={it} wall {dt*1e3:.1f} ms (incl. H2D of {Ps.nbytes/1e6:.0f} MB)")
-names = ["gemm", "panel_store", "diag", "trsm", "writeback", "fwd_diag", "fwd_upd", "bwd_diag", "bwd_upd", "matvec", "total"]
+# slots as seen by wavefront 0 of workgroup 0: [1] waiting at barrier A for the other wavefronts' rank-k update (beyond its
+# own diagonal chain, slots 12/14/15), [3] W21 + fused forward step, [4] waiting at barrier B (stores drained)
+names = ["-", "wait_rank_k", "-", "w21_fwd", "wait_stores", "fwd_diag", "fwd_upd", "bwd_diag", "bwd_upd", "matvec", "total"]
 if prof[10]:
     tot = prof[10]
     print("in-kernel ticks of WG0:", {n: prof[i] for i, n in enumerate(names)}, "factorizations:", prof[11])
-    print("chain: chol1", prof[12], "inv1", prof[13], "l21+d2", prof[14], "chol2", prof[15]); print("shares:", {n: round(prof[i] / tot, 3) for i, n in enumerate(names)})
+    print("diagonal chain: cholinv1", prof[12], "l21+d2", prof[14], "cholinv2", prof[15]); print("shares:", {n: round(prof[i] / tot, 3) for i, n in enumerate(names)})
 from oracle.coneqp import coneqp_boxlow
 r = coneqp_boxlow(P, q, h)
 print("oracle iters", r["iterations"], "max rel err", np.max(np.abs(res["x"][0] - r["x"])) / np.abs(r["x"]).max())

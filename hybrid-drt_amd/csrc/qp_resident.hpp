@@ -14,16 +14,22 @@
 //    MFMA, so the triangular solve against the diagonal block runs on the matrix pipe from registers:
 //        X1' = W1 C1' ,  C2' -= L21 X1' ,  X2' = W2 C2'      (W = inverse of a 16x16 diagonal Cholesky block)
 //    -- no LDS panel, no thread-per-row substitution.
-//  * Wavefront 0 owns only the two tile rows of the diagonal block: it finishes its (shorter) rank-k update
-//    first and factors / inverts the two 16x16 diagonal blocks (lane = row, column broadcast through LDS, rsqrt
-//    pivots; inverse by lane = column substitution) while the other wavefronts are still multiplying.
+//  * Wave roles.  Wavefront 0 does nothing but factor and invert the two 16x16 diagonal blocks of a block column
+//    (register-only Gauss-Jordan on [D | I], lane = row, pivots / multipliers / finished rows broadcast with
+//    v_readlane).  Wavefront 1 owns the two tile rows of the NEXT diagonal block: their panel tiles in the current
+//    column and, one column ahead, the whole rank-k update of the next diagonal block, handed to wavefront 0 through
+//    LDS -- so the sequential diagonal work of column j+1 overlaps everybody else's rank-k update of column j+1.
+//    Wavefronts 2..7 own all rows below.
 //  * LDS array U[NP][33] keeps, for every finished block, the INVERSE of its 32x32 diagonal Cholesky block
 //    [[W1, 0], [-W2 L21 W1, W2]], so the triangular solves do one 32x32 mat-vec per block instead of a 32-step
 //    substitution chain and never fetch diagonal blocks from HBM (the diagonal-block tiles of L are not even
 //    written to HBM).
-//  * Solves: per 32-block the mat-vec by wavefront 0; wavefronts 1..7 apply the rank-32 updates from operands
-//    that were fetched (contiguous tiles) before the diagonal step started.
-//  * P x: two rows x 5 column chunks of 16-byte loads per lane, next row pair in flight while reducing.
+//  * The predictor's forward substitution is fused into the factorisation (a block column's tiles update the
+//    right-hand side while they are still in registers).  Separate solves: per 32-block the mat-vec by wavefront 0;
+//    wavefronts 1..7 apply the rank-32 updates from tiles fetched two blocks ahead, across LDS-only barriers.
+//  * P x from the packed lower tiles: every tile is read once and used for y_T += tile x_C and y_C += tile' x_T.
+//  * Optional extra tile rows appended below the matrix turn the same factorisation into a multi-right-hand-side
+//    triangular solve (posterior variance, cov_kernel_resident).
 #pragma once
 #include "qp_common.hpp"
 
@@ -32,7 +38,6 @@ namespace hipdrt {
 static constexpr int RT = 512;           // threads
 static constexpr int RNW = RT / 64;      // 8 wavefronts
 static constexpr int RMAXT = 4;          // tile rows per wavefront and pass
-static constexpr int ROW_PER_PASS = (RNW - 1) * RMAXT;   // off-diagonal tile rows handled per pass
 static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
 static constexpr int DLD = 17;           // row stride of the 16x16 LDS scratch blocks

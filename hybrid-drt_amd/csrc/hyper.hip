@@ -165,13 +165,14 @@ __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld
     }
 }
 
-// same for a symmetric Toeplitz matrix given by its first column c (LDS): y[i] = sum_j c[|i-j|] v[j]
+// same for a symmetric Toeplitz matrix given by its mirrored first column (LDS, c[d] valid for -(nd-1) <= d <= nd-1):
+// y[i] = sum_j c[i - j] v[j]
 __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, int nd, const double* __restrict__ v,
                                                 double* __restrict__ out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int i = wv; i < nd; i += HNW) {
         double s = 0.0;
-        for (int j = lane; j < nd; j += 64) { const int dd = i > j ? i - j : j - i; s += c[dd] * v[j]; }
+        for (int j = lane; j < nd; j += 64) s += c[i - j] * v[j];
         s = hw_sum(s);
         if (lane == 0) out[i] = s;
     }
@@ -240,11 +241,15 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
     double* tmp = xh + nd;        // [max(m, nd)]
     const int tl = m > nd ? m : nd;
     double* tmp2 = tmp + tl;      // [max(m, nd)]
-    double* ctp = tmp2 + tl;      // [3][nd] first columns of the Toeplitz penalty blocks (uniform ln-tau grids)
+    // [3][2 nd - 1] first columns of the Toeplitz penalty blocks (uniform ln-tau grids), mirrored around index nd - 1
+    // so that entry (i, j) is cx[i - j + nd - 1] without an absolute value
+    double* ctp = tmp2 + tl;
+    const int cw = 2 * nd - 1;
     const bool tpl = st.toeplitz_m != 0;
     if (tpl) {
-        for (int e = tid; e < 3 * nd; e += HT) {
-            const int k = e / nd, dd = e % nd;
+        for (int e = tid; e < 3 * cw; e += HT) {
+            const int k = e / cw, o = e % cw;
+            const int dd = o >= nd - 1 ? o - (nd - 1) : (nd - 1) - o;
             ctp[e] = st.mk[k][(size_t)ns * st.ldm + ns + dd];
         }
     }
@@ -284,20 +289,23 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             double* vh = tmp2;           // xh_j sqrt(s_j)
             for (int i = tid; i < nd; i += HT) { vs[i] = xd[i] * sq[i]; vh[i] = xh[i] * sq[i]; }
             __syncthreads();
-            const double* ck = ctp + k * nd;
-            const double* c1 = ctp + nd;
+            const double* ck = ctp + k * cw + (nd - 1);      // ck[i - j]
+            const double* c1 = ctp + cw + (nd - 1);
             double lmax = 0.0;
             for (int i = wv; i < nd; i += HNW) {
                 const double xi = xd[i];
+                const int jd = i & ~63;                        // the 64-column chunk that holds the diagonal
                 double s0 = 0.0;
                 if (k == 0) {
                     const double xhs = xh[i] / sig2;
-                    for (int j = lane; j < nd; j += 64) {
-                        const int dd = i > j ? i - j : j - i;
-                        const double gu = xi * (ck[dd] * vs[j]) + xhs * (c1[dd] * vh[j]);
-                        const double gz = (j == i) ? 0.0 : gu;
-                        s0 += gz;
-                        lmax = fmax(lmax, fabs(gz));
+                    for (int j0 = 0; j0 < nd; j0 += 64) {
+                        const int j = j0 + lane;
+                        if (j < nd) {
+                            double gu = xi * (ck[i - j] * vs[j]) + xhs * (c1[i - j] * vh[j]);
+                            if (j0 == jd && j == i) gu = 0.0;
+                            s0 += gu;
+                            lmax = fmax(lmax, fabs(gu));
+                        }
                     }
                     s0 = hw_sum(s0);
                     if (lane == 0) {
@@ -306,12 +314,14 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
                     }
                 } else {
                     double mx0 = 0.0;
-                    for (int j = lane; j < nd; j += 64) {
-                        const int dd = i > j ? i - j : j - i;
-                        const double t0 = ck[dd] * vs[j];
-                        const double tz = (j == i) ? 0.0 : t0;
-                        s0 += tz;
-                        mx0 = fmax(mx0, fabs(tz));
+                    for (int j0 = 0; j0 < nd; j0 += 64) {
+                        const int j = j0 + lane;
+                        if (j < nd) {
+                            double t0 = ck[i - j] * vs[j];
+                            if (j0 == jd && j == i) t0 = 0.0;
+                            s0 += t0;
+                            mx0 = fmax(mx0, fabs(t0));
+                        }
                     }
                     s0 = hw_sum(s0);
                     lmax = fmax(lmax, fabs(xi) * mx0);
@@ -326,10 +336,9 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             const double xi = xd[i], xhi = xh[i];
             double sacc = 0.0, mxx = 0.0, dg = 0.0;
             for (int j = lane; j < nd; j += 64) {
-                const int dd = i > j ? i - j : j - i;
-                const double mij = tpl ? ctp[k * nd + dd] : row[j];
+                const double mij = row[j];
                 double g = (xi * mij) * xd[j];
-                if (k == 0) g += ((xhi * (tpl ? ctp[nd + dd] : row1[j])) * xh[j]) / sig2;
+                if (k == 0) g += ((xhi * row1[j]) * xh[j]) / sig2;
                 if (j == i) dg = g + beta;
                 else {
                     const double gu = g * sq[j];
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             tmp[i] = sqrt(sh) * xd[i];       // v = S^1/2 x for solve_rho
         }
         __syncthreads();
-        if (tpl) toeplitz_matvec(ctp + k * nd, nd, tmp, tmp2);
+        if (tpl) toeplitz_matvec(ctp + k * cw + (nd - 1), nd, tmp, tmp2);
         else rows_matvec(Mk, st.ldm, nd, nd, tmp, tmp2);
         __syncthreads();
         double part = 0.0;
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
     if (it == 0 && !st.continue_mode) {   // xmx_norms frozen after the first iteration (drt1d.py:946-951)
         for (int k = 0; k < 3; ++k) {
             const double* Mk = st.mk[k] + (size_t)ns * st.ldm + ns;
-            if (tpl) toeplitz_matvec(ctp + k * nd, nd, xd, tmp2);
+            if (tpl) toeplitz_matvec(ctp + k * cw + (nd - 1), nd, xd, tmp2);
             else rows_matvec(Mk, st.ldm, nd, nd, xd, tmp2);
             __syncthreads();
             double part = 0.0;
@@ -468,7 +477,7 @@ __global__ void make_h_kernel(double* h, int n, int ns, int nonneg) {
 size_t hyper_lds_bytes(int n, int m, int ns) {
     const int nd = n - ns;
     const int tl = m > nd ? m : nd;
-    return ((size_t)n + 4 * (size_t)nd + 2 * (size_t)tl + 3 * (size_t)nd) * sizeof(double);
+    return ((size_t)n + 4 * (size_t)nd + 2 * (size_t)tl + 3 * (size_t)(2 * nd - 1)) * sizeof(double);
 }
 
 int launch_prep(hipStream_t s, const FitState& st, int B) {

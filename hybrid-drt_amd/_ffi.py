@@ -295,6 +295,28 @@ class Context:
                                          _pi(status)))
         return dict(x=x, iterations=iters, pcost=pcost, status=status)
 
+    def fit_eis_batch(self, freq, z, tau, epsilon, wt_re, wt_im, toeplitz_a=False, toeplitz_m=False, opts=None,
+                      ny=1000):
+        """the one-shot C entry point hipdrt_fit_eis_batch (interp mode): plan create, upload, fit, download, destroy"""
+        freq, tau, wt_re, wt_im = _f64(freq), _f64(tau), _f64(wt_re), _f64(wt_im)
+        z = np.atleast_2d(np.asarray(z))
+        z_re, z_im = _f64(z.real), _f64(z.imag)
+        lre, lim = np.log(wt_re), np.log(wt_im)
+        opts = opts if opts is not None else default_fit_opts()
+        B, nf, ntau = z.shape[0], freq.size, tau.size
+        n = ntau + int(opts.fit_ohmic) + int(opts.fit_inductance)
+        out = {"x": np.empty((B, n)), "fit_x": np.empty((B, ntau)), "R_inf": np.empty(B), "inductance": np.empty(B),
+               "weights": np.empty((B, 2 * nf)), "coefficient_scale": np.empty(B), "rho": np.empty((B, 3)),
+               "q_vector": np.empty((B, n)), "outer_iters": np.empty(B, dtype=np.int32),
+               "status": np.empty(B, dtype=np.int32)}
+        _check(self._lib.hipdrt_fit_eis_batch(self._h, B, _p(freq), nf, _p(z_re), _p(z_im), _p(tau), ntau, float(epsilon),
+                                              MODE_INTERP, int(bool(toeplitz_a)), int(bool(toeplitz_m)), wt_re.size,
+                                              int(ny), _p(wt_re), _p(wt_im), _p(lre), _p(lim), C.byref(opts),
+                                              _p(out["x"]), _p(out["fit_x"]), _p(out["R_inf"]), _p(out["inductance"]),
+                                              _p(out["weights"]), _p(out["coefficient_scale"]), _p(out["rho"]),
+                                              _p(out["q_vector"]), _pi(out["outer_iters"]), _pi(out["status"])))
+        return out
+
     def qp_profile(self, reset=True):
         buf = (C.c_ulonglong * 16)()
         _check(self._lib.hipdrt_qp_profile(self._h, buf, 16, int(reset)))

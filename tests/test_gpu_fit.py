@@ -298,6 +298,26 @@ def test_randomized_fits_vs_oracle(seed):
         assert res["qp_iters_total"][b] == sum(l["iterations"] for l in od.qp_log), (seed, b)   # incl. the initial-weights QP
 
 
+def test_one_shot_c_entry_point_matches_plan_path():
+    """hipdrt_fit_eis_batch (create plan, upload, fit, download, destroy in one C call) gives bit-identical results to
+    the staged plan path the Python driver uses."""
+    from hipdrt import synth, _ffi
+    from hipdrt.models import DRT
+    c1 = synth.config_c1()
+    z = synth.zarc2_batch(c1["freq"], 5, first_seed=3)
+    drt = DRT(fixed_basis_tau=c1["tau"])
+    ref = drt.fit_eis_batch(c1["freq"], z)
+    opts, _, _ = drt._make_opts({})
+    from hipdrt.matrices import mat1d
+    from hipdrt.utils.array import is_uniform
+    tpl_a = mat1d.impedance_matrix_is_toeplitz(c1["freq"], c1["tau"], drt.frequency_precision)
+    tpl_m = is_uniform(np.log(c1["tau"]))
+    out = _ffi.get_context(0).fit_eis_batch(c1["freq"], z, c1["tau"], drt.tau_epsilon, drt._wt_re, drt._wt_im,
+                                            toeplitz_a=tpl_a, toeplitz_m=tpl_m, opts=opts)
+    for key in ("x", "fit_x", "R_inf", "inductance", "weights", "rho", "q_vector", "outer_iters", "status"):
+        np.testing.assert_array_equal(out[key], ref[key], err_msg=key)
+
+
 def test_edge_cases():
     from hipdrt.models import DRT
     freq = np.logspace(5, 0, 12)

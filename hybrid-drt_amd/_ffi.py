@@ -35,7 +35,8 @@ class FitOpts(C.Structure):
         ("ohmic_penalty", C.c_double), ("inductance_penalty", C.c_double), ("inductance_scale", C.c_double),
         ("eis_vmm_epsilon", C.c_double), ("eis_reim_cor", C.c_double), ("xtol", C.c_double),
         ("max_iter", C.c_int), ("nonneg", C.c_int), ("scale_data", C.c_int), ("fit_ohmic", C.c_int),
-        ("fit_inductance", C.c_int), ("eis_error_uniform", C.c_int), ("qp", QpOpts),
+        ("fit_inductance", C.c_int), ("eis_error_uniform", C.c_int),
+        ("outlier_p", C.c_double), ("iw_alpha", C.c_double), ("iw_beta", C.c_double), ("qp", QpOpts),
     ]
 
 

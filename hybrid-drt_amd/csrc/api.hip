@@ -28,7 +28,7 @@ struct hipdrt_plan {
     // per spectrum
     DevBuf z_re, z_im, rv, w, est_w, x, x_in, q, s, rho, xmx, coef_scale, var_floor;
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
-    DevBuf P, L, Ptmp, qpstate, Ppk, order;
+    DevBuf P, L, Ptmp, qpstate, Ppk, order, vmm_base;
     // history
     int hist_b = -1, hist_cap = 0;
     DevBuf hist_x, hist_w, hist_rho, hist_qp, hist_rows;
@@ -40,7 +40,7 @@ struct hipdrt_plan {
         FitState st{};
         st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm; st.toeplitz_m = toeplitz_m;
         st.opts = opts; st.continue_mode = 0; st.min_iter = 1;
-        st.rm = rm.d(); st.vmm = vmm.d();
+        st.rm = rm.d(); st.vmm = vmm.d(); st.vmm_iw = vmm_base.p ? vmm_base.d() : vmm.d();
         for (int k = 0; k < 3; ++k) st.mk[k] = mk[k].d();
         st.z_re = z_re.d(); st.z_im = z_im.d();
         st.rv = rv.d(); st.w = w.d(); st.est_w = est_w.d();
@@ -460,6 +460,7 @@ void hipdrt_default_fit_opts(hipdrt_fit_opts* o) {
     o->eis_vmm_epsilon = 0.25; o->eis_reim_cor = 0.25;
     o->xtol = 1e-2; o->max_iter = 50; o->nonneg = 1; o->scale_data = 1; o->fit_ohmic = 1; o->fit_inductance = 1;
     o->eis_error_uniform = 0;
+    o->outlier_p = -1.0; o->iw_alpha = -1.0; o->iw_beta = -1.0;
     o->qp = default_qp_opts();
 }
 
@@ -562,6 +563,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->Ppk.alloc(cap * qp_ppk_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->order.alloc(cap * sizeof(int)));
+    if (p->opts.outlier_p > 0.0) HIPDRT_CHECK(p->vmm_base.alloc((size_t)m * m * sizeof(double)));
     HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
 
     // shared matrices on the device
@@ -571,6 +573,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
                            p->opts.ohmic_penalty, p->opts.inductance_penalty);
     launch_eis_vmm(st, p->freq.d(), nf, p->opts.eis_vmm_epsilon, p->opts.eis_reim_cor, p->opts.eis_error_uniform,
                    p->vmm.d());
+    if (p->vmm_base.p) launch_vmm_exclude_self(st, p->vmm.d(), m, p->vmm_base.d());
     launch_make_h(st, p->h.d(), n, ns, p->opts.nonneg);
     LAUNCH_OK();
     HIPDRT_CHECK(hipStreamSynchronize(st));
@@ -711,7 +714,23 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     qa.Ppk = p->Ppk.d(); qa.ppk_stride = 0; qa.nchp = qp_nchp(n);
     TRY(launch_qp(st, qa));
     tm.mark(3);
-    TRY(launch_init_weights(st, fs, B));
+    if (p->opts.outlier_p > 0.0) {
+        // qphb.py:1629-1656: weights from the first overfit with outlier down-weighting (variance matrix without each
+        // point's own residual), a second ridge QP weighted by them (per-spectrum P now), weights again
+        TRY(launch_init_weights(st, fs, B, 0));
+        LAUNCH_OK();
+        tm.mark(1);
+        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->est_w.d(), g, Prow, p->ldp, (long long)n * p->ldp, nullptr,
+                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
+        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->est_w.d(), p->rv.d(), nullptr, p->opts.iw_l1_lambda_0, p->q.d(),
+                    nullptr);
+        LAUNCH_OK();
+        tm.mark(2);
+        qa.p_stride = (long long)n * p->ldp; qa.ppk_stride = (long long)qp_ppk_doubles(n);
+        TRY(launch_qp(st, qa));
+        tm.mark(3);
+    }
+    TRY(launch_init_weights(st, fs, B, 1));
     LAUNCH_OK();
 
     // ---- outer loop (drt1d.py:877-988) ----------------------------------------------------------------------

@@ -136,6 +136,7 @@ struct FitState {
     // shared (plan) matrices
     const double* rm;      // [m][ldrm]  stacked [Re; Im] response matrix incl. special columns
     const double* vmm;     // [m][m]
+    const double* vmm_iw;  // [m][m]  variance matrix of initialize_weights (self-excluded rows when outlier_p is set)
     const double* mk[3];   // [n][ldm]   padded penalty matrices
     // per-spectrum
     const double *z_re, *z_im;   // [B][nf]
@@ -153,7 +154,9 @@ struct FitState {
 };
 size_t hyper_lds_bytes(int n, int m, int ns);
 int launch_prep(hipStream_t s, const FitState& st, int B);
-int launch_init_weights(hipStream_t s, const FitState& st, int B);
+// stage 0: weights from the first overfit only (outlier branch); stage 1: final est_weights -> init weights, x reset
+int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage);
+void launch_vmm_exclude_self(hipStream_t s, const double* vmm, int m, double* out);
 int launch_hyper(hipStream_t s, const FitState& st, int B, int it);
 void launch_scale_weights(hipStream_t s, const FitState& st, int B, double factor);
 int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw);

@@ -179,16 +179,44 @@ __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, in
 }
 
 // estimate_weights for spectrum b: xs = LDS x[n]; tmp = LDS [m]; result written to w_out[m] (global)
-__device__ void estimate_weights_dev(const FitState& st, int b, const double* xs, double* tmp, double* tmp2,
-                                     const double* est_w, double* w_out) {
+// estimate_weights (qphb.py:1545-1594) for spectrum b with variance matrix V: xs = LDS x[n]; tmp, tmp2 = LDS [m]; with
+// outlier_p > 0 also tmp3, tmp4 = LDS [m] (solve_outlier_t / outlier_tvt, qphb.py:1497-1539:
+// s_hat = sqrt(t) o V (sqrt(t) o r^2) + (1 - t) o r^2).  Result written to w_out[m] (global).
+__device__ void estimate_weights_dev(const FitState& st, int b, const double* V, const double* xs, double* tmp, double* tmp2,
+                                     double* tmp3, double* tmp4, const double* est_w, double* w_out) {
     const int m = st.m, n = st.n, tid = threadIdx.x;
     const double* rv = st.rv + (size_t)b * m;
+    const double op = st.opts.outlier_p;
     rows_matvec(st.rm, st.ldrm, m, n, xs, tmp);        // rm @ x
     __syncthreads();
-    for (int i = tid; i < m; i += HT) { const double r = tmp[i] - rv[i]; tmp[i] = r * r; }
+    for (int i = tid; i < m; i += HT) {
+        const double r = tmp[i] - rv[i];
+        if (op > 0.0) tmp3[i] = r;
+        tmp[i] = r * r;
+    }
     __syncthreads();
-    rows_matvec(st.vmm, m, m, m, tmp, tmp2);           // vmm @ resid**2
+    rows_matvec(V, m, m, m, tmp, tmp2);                // V @ resid**2
     __syncthreads();
+    if (op > 0.0) {
+        const double s2pi = sqrt(2.0 * 3.141592653589793);
+        for (int i = tid; i < m; i += HT) {
+            const double r = tmp3[i], ar = fabs(r), sb = sqrt(tmp2[i]);
+            const double pdf_in = 1.0 / (sb * s2pi) * exp(-0.5 * (r * r) / (sb * sb));
+            const double pdf_out = 1.0 / (ar * s2pi) * exp(-0.5 * (r * r) / (ar * ar));
+            double t = 1.0 - op * pdf_out / ((1.0 - op) * pdf_in + op * pdf_out);
+            if (sb > ar) t = 1.0;
+            tmp3[i] = t;                                // outlier_t
+            tmp4[i] = sqrt(t) * tmp[i];                 // sqrt(t) o r^2
+        }
+        __syncthreads();
+        rows_matvec(V, m, m, m, tmp4, tmp2);
+        __syncthreads();
+        for (int i = tid; i < m; i += HT) {
+            const double t = tmp3[i];
+            tmp2[i] = sqrt(t) * tmp2[i] + (1.0 - t) * tmp[i];
+        }
+        __syncthreads();
+    }
     const double vf = st.var_floor[b];
     for (int i = tid; i < m; i += HT) {
         double sh = tmp2[i];
@@ -205,23 +233,48 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* xs
     __syncthreads();
 }
 
-// after the initial-weights QP: est_weights = estimate_weights(x_overfit, est_weights=None); weights = est
-__global__ __launch_bounds__(HT) void init_weights_kernel(FitState st) {
+// after an initial-weights QP: est_weights = estimate_weights(x_overfit, est_weights=None) on the initialize_weights
+// variance matrix; stage 1 also sets weights = solve_init_weight_scale(est_weights) (qphb.py:1471-1479, 1679) and resets x
+__global__ __launch_bounds__(HT) void init_weights_kernel(FitState st, int stage) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, tid = threadIdx.x, n = st.n, m = st.m;
     double* xs = sm;
     double* tmp = xs + n;
     double* tmp2 = tmp + m;
+    double* tmp3 = tmp2 + m;
+    double* tmp4 = tmp3 + m;
     if (st.qp_status[b] < 0) {
         if (tid == 0) { st.active[b] = 0; st.fit_status[b] = -1; }
         return;
     }
     for (int i = tid; i < n; i += HT) xs[i] = st.x[(size_t)b * n + i];
     __syncthreads();
-    estimate_weights_dev(st, b, xs, tmp, tmp2, nullptr, st.est_w + (size_t)b * m);
-    for (int i = tid; i < m; i += HT) st.w[(size_t)b * m + i] = st.est_w[(size_t)b * m + i];
+    estimate_weights_dev(st, b, st.vmm_iw, xs, tmp, tmp2, tmp3, tmp4, nullptr, st.est_w + (size_t)b * m);
+    if (stage == 0) return;
+    const double al = st.opts.iw_alpha, be = st.opts.iw_beta;
+    for (int i = tid; i < m; i += HT) {
+        double w = st.est_w[(size_t)b * m + i];
+        if (al > 0.0) {
+            const double bq = 0.5 - al + 1.0;
+            const double sh = (-bq + sqrt(bq * bq + 2.0 * be * (1.0 / (w * w)))) / (2.0 * be);
+            w = 1.0 / sqrt(sh);
+        }
+        st.w[(size_t)b * m + i] = w;
+    }
     // the outer loop starts from x = 1e-6 (drt1d.py:612), not from x_overfit
     for (int i = tid; i < n; i += HT) st.x[(size_t)b * n + i] = 1e-6;
+}
+
+// variance matrix without each point's own residual, rows renormalised (qphb.py:1644-1648)
+__global__ void vmm_exclude_self_kernel(const double* __restrict__ vmm, int m, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= m) return;
+    const double d = vmm[(size_t)i * m + i];
+    out[(size_t)i * m + j] = (i == j) ? 0.0 : vmm[(size_t)i * m + j] / (1.0 - d);
+}
+
+void launch_vmm_exclude_self(hipStream_t s, const double* vmm, int m, double* out) {
+    hipLaunchKernelGGL(vmm_exclude_self_kernel, dim3((m + 255) / 256, m), dim3(256), 0, s, vmm, m, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -400,7 +453,8 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
 
     // weights
     double* wg = st.w + (size_t)b * m;
-    estimate_weights_dev(st, b, xs, tmp, tmp2, st.est_w + (size_t)b * m, wg);
+    double* tmp3 = ctp + 3 * cw;       // [2][m], only present (and only touched) when outlier_p is set
+    estimate_weights_dev(st, b, st.vmm, xs, tmp, tmp2, tmp3, tmp3 + m, st.est_w + (size_t)b * m, wg);
 
     // convergence (qphb.py:597-603, 969-970)
     double* xin = st.x_in + (size_t)b * n;
@@ -492,11 +546,11 @@ static int set_lds(const void* f, size_t bytes) {
     return 0;
 }
 
-int launch_init_weights(hipStream_t s, const FitState& st, int B) {
-    const size_t lds = ((size_t)st.n + 2 * (size_t)st.m) * sizeof(double);
+int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage) {
+    const size_t lds = ((size_t)st.n + 4 * (size_t)st.m) * sizeof(double);
     if (int rc = set_lds(reinterpret_cast<const void*>(init_weights_kernel), lds)) return rc;
-    hipLaunchKernelGGL(init_weights_kernel, dim3(B), dim3(HT), lds, s, st);
-    hipLaunchKernelGGL(record_init_qp_kernel, dim3(1), dim3(64), 0, s, st);
+    hipLaunchKernelGGL(init_weights_kernel, dim3(B), dim3(HT), lds, s, st, stage);
+    if (stage == 1) hipLaunchKernelGGL(record_init_qp_kernel, dim3(1), dim3(64), 0, s, st);
     return 0;
 }
 
@@ -553,7 +607,7 @@ void launch_scale_weights(hipStream_t s, const FitState& st, int B, double facto
 }
 
 int launch_hyper(hipStream_t s, const FitState& st, int B, int it) {
-    const size_t lds = hyper_lds_bytes(st.n, st.m, st.ns);
+    const size_t lds = hyper_lds_bytes(st.n, st.m, st.ns) + (st.opts.outlier_p > 0.0 ? 2 * (size_t)st.m * sizeof(double) : 0);
     if (int rc = set_lds(reinterpret_cast<const void*>(hyper_kernel), lds)) return rc;
     hipLaunchKernelGGL(hyper_kernel, dim3(B), dim3(HT), lds, s, st, it);
     return 0;

@@ -125,8 +125,8 @@ class DRT:
             raise NotImplementedError("penalty_type 'discrete' is deprecated in the reference and not built")
         if not kw['eff_hp'] or kw['weight_factor'] != 1:
             raise NotImplementedError("only eff_hp=True, weight_factor=1 (the defaults) are built")
-        if hypers['outlier_p'] is not None or hypers['iw_alpha'] is not None or hypers['iw_beta'] is not None:
-            raise NotImplementedError("outlier_p / iw_alpha / iw_beta are optional branches not built yet")
+        if (hypers['iw_alpha'] is None) != (hypers['iw_beta'] is None):
+            raise ValueError('iw_alpha and iw_beta must be given together')
         if kw['eis_error_structure'] not in (None, 'uniform'):
             raise ValueError(f"Invalid eis_error_structure {kw['eis_error_structure']}")
         o = _ffi.default_fit_opts()
@@ -136,6 +136,10 @@ class DRT:
             for k in range(3):
                 getattr(o, name)[k] = float(vals[k])
         o.l1_lambda_0, o.l2_lambda_0 = float(hypers['l1_lambda_0']), float(hypers['l2_lambda_0'])
+        # optional branches of the weight estimation (None <-> -1)
+        o.outlier_p = -1.0 if hypers['outlier_p'] is None else float(hypers['outlier_p'])
+        o.iw_alpha = -1.0 if hypers['iw_alpha'] is None else float(hypers['iw_alpha'])
+        o.iw_beta = -1.0 if hypers['iw_beta'] is None else float(hypers['iw_beta'])
         o.iw_l1_lambda_0, o.iw_l2_lambda_0 = float(kw['iw_l1_lambda_0']), float(kw['iw_l2_lambda_0'])
         o.ohmic_penalty, o.inductance_penalty = float(kw['ohmic_penalty']), float(kw['inductance_penalty'])
         o.inductance_scale = float(kw['inductance_scale'])

@@ -166,6 +166,9 @@ typedef struct {
     int scale_data;                  /* 1 */
     int fit_ohmic, fit_inductance;   /* 1, 1 */
     int eis_error_uniform;           /* 0 (eis_error_structure=None) */
+    /* optional branches of the weight estimation; <= 0 means None (the reference defaults) */
+    double outlier_p;                /* prior outlier probability, qphb.py:1497-1553, 1629-1656 */
+    double iw_alpha, iw_beta;        /* prior on the initial weights, qphb.py:1471-1479, 1679 */
     hipdrt_qp_opts qp;
 } hipdrt_fit_opts;
 

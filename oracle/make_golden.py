@@ -238,6 +238,15 @@ def main():
     if "--only-response" in sys.argv:
         run_response_matrices()
         return
+    if "--only-options" in sys.argv:
+        freq_g, z_g = extract_reference_test_vectors()
+        DRT, cvxopt = _boot_reference()
+        default = dict(fit_inductance=True, fit_capacitance=False, fit_dop=False, fit_ohmic=True)
+        run_case(DRT, cvxopt, "golden71x91_outlier", freq_g, z_g, default, dict(outlier_p=0.05), save_mats=False,
+                 save_qps=False)
+        run_case(DRT, cvxopt, "golden71x91_iw", freq_g, z_g, default, dict(iw_alpha=1.5, iw_beta=0.5), save_mats=False,
+                 save_qps=False)
+        return
     if "--only-candidates" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()
         DRT, cvxopt = _boot_reference()
@@ -257,6 +266,10 @@ def main():
     default = dict(fit_inductance=True, fit_capacitance=False, fit_dop=False, fit_ohmic=True)
     # (1) the reference's own test inputs, with all intermediates
     run_case(DRT, cvxopt, "golden71x91", freq_g, z_g, default, {})
+    # (1b) optional branches of the weight estimation: outlier down-weighting and the initial-weight prior
+    run_case(DRT, cvxopt, "golden71x91_outlier", freq_g, z_g, default, dict(outlier_p=0.05), save_mats=False, save_qps=False)
+    run_case(DRT, cvxopt, "golden71x91_iw", freq_g, z_g, default, dict(iw_alpha=1.5, iw_beta=0.5), save_mats=False,
+             save_qps=False)
     # (2) same inputs, DRT coefficients allowed negative (h = 1e5 branch of make_h_constraint)
     run_case(DRT, cvxopt, "golden71x91_neg", freq_g, z_g, default, dict(nonneg=False), save_mats=False)
     # (3) C1 variant: 71 freqs x fixed 121-point tau grid, 2-ZARC seed 0

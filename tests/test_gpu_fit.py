@@ -318,6 +318,22 @@ def test_one_shot_c_entry_point_matches_plan_path():
         np.testing.assert_array_equal(out[key], ref[key], err_msg=key)
 
 
+@pytest.mark.parametrize("name,kw", [("outlier", dict(outlier_p=0.05)), ("iw", dict(iw_alpha=1.5, iw_beta=0.5))])
+def test_optional_weight_branches_vs_reference_run(name, kw):
+    """outlier_p (qphb.py:1497-1553, 1629-1656: two initial QPs, outlier-aware variance estimation in every iteration)
+    and iw_alpha / iw_beta (prior on the initial weights) against reference runs on the known-answer inputs."""
+    from hipdrt.models import DRT
+    g = load(f"refrun_golden71x91_{name}.npz")
+    drt = DRT()
+    drt.fit_eis(g["freq"], g["z"], **kw)
+    assert drt.qphb_params["outer_iterations"] == int(g["outer_iterations"])
+    xs = g["x_scaled"]
+    np.testing.assert_allclose(drt.cvx_result["x"], xs, rtol=0, atol=1e-7 * np.abs(xs).max())
+    np.testing.assert_allclose(drt.qphb_params["est_weights"], g["est_weights"], rtol=1e-7)
+    np.testing.assert_allclose(drt.qphb_params["weights"], g["weights"], rtol=1e-6)
+    np.testing.assert_allclose(drt.fit_parameters["x"], g["x"], rtol=0, atol=1e-7 * np.abs(g["x"]).max())
+
+
 def test_edge_cases():
     from hipdrt.models import DRT
     freq = np.logspace(5, 0, 12)

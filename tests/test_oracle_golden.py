@@ -176,3 +176,13 @@ def test_oracle_pfrt_matches_reference_run():
     assert sum(r["counts"]) == int(g["pfrt_history_len"]) and r["counts"][0] == int(g["pfrt_init_len"])
     np.testing.assert_allclose(r["step_x"], g["pfrt_step_x"], rtol=0, atol=1e-10 * np.abs(g["pfrt_step_x"]).max())
     np.testing.assert_allclose(r["step_llh"], g["pfrt_step_llh"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name,kw", [("outlier", dict(outlier_p=0.05)), ("iw", dict(iw_alpha=1.5, iw_beta=0.5))])
+def test_oracle_optional_weight_branches_match_reference_run(name, kw):
+    g = np.load(os.path.join(GOLDEN, f"refrun_golden71x91_{name}.npz"))
+    d = orc.OracleDRT()
+    d.fit_eis(g["freq"], g["z"], keep_history=True, **kw)
+    assert [l["iterations"] for l in d.qp_log] == list(g["qp_iterations"])
+    np.testing.assert_array_equal(d.qphb_params["est_weights"], g["est_weights"])
+    np.testing.assert_allclose(d.qphb_params["x_scaled"], g["x_scaled"], rtol=0, atol=1e-11 * np.abs(g["x_scaled"]).max())

@@ -84,6 +84,7 @@ SIGNATURES = {
     "hipdrt_plan_llh_terms": [_vp, _dp, _dp],
     "hipdrt_plan_set_state": [_vp, _dp, _dp, _dp, _dp],
     "hipdrt_plan_continue": [_vp, C.POINTER(FitOpts), C.c_double, C.c_int],
+    "hipdrt_plan_param_var": [_vp, _dp, _ip],
     "hipdrt_plan_record_history": [_vp, C.c_int],
     "hipdrt_plan_get_history": [_vp, _dp, _dp, _dp, _ip, C.c_int, _ip],
     "hipdrt_plan_timings": [_vp, C.POINTER(C.c_float), _ip],
@@ -448,6 +449,12 @@ class Plan:
         out = np.empty((int(batch), basis_eval.shape[0]))
         status = np.empty(int(batch), dtype=np.int32)
         _check(self._lib.hipdrt_plan_distribution_var(self._h, _p(basis_eval), basis_eval.shape[0], _p(out), _pi(status)))
+        return out, status
+
+    def param_var(self, batch):
+        out = np.empty((int(batch), self.n))
+        status = np.empty(int(batch), dtype=np.int32)
+        _check(self._lib.hipdrt_plan_param_var(self._h, _p(out), _pi(status)))
         return out, status
 
     def history(self):

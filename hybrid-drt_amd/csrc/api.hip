@@ -918,14 +918,16 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
     return copy_strided(out, p->Ptmp.d(), n, n, p->ldp, st);
 }
 
-int hipdrt_plan_distribution_var(hipdrt_plan* p, const double* basis_eval, int neval, double* out, int* status) {
-    HIPDRT_REQUIRE(p && basis_eval && out, "NULL pointer");
+// out[b][i] = rows_i' P_b^-1 rows_i * cs_b^2 for the fitted batch; rows[nrow][ncol] sits at columns col_offset.. of the
+// unknown vector (zero elsewhere)
+static int plan_quadratic_forms(hipdrt_plan* p, const double* basis_eval, int neval, int ncol, int col_offset, double* out,
+                                int* status) {
     HIPDRT_REQUIRE(p->B > 0, "no fitted batch in the plan");
     HIPDRT_REQUIRE(neval >= 1, "neval >= 1");
     HIPDRT_REQUIRE(qp_packed_only(p->n), "posterior variance is only built for n <= 528 unknowns");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
-    const int n = p->n, m = p->m, B = p->B, ntau = p->ntau;
+    const int n = p->n, m = p->m, B = p->B;
     const int nex = (neval + 15) / 16, nchp = qp_nchp(n);
     // final P of every spectrum (calculate_pq with the final weights / s / rho, drt1d.py:1006), packed tiles only
     GramL2 g{};
@@ -937,9 +939,9 @@ int hipdrt_plan_distribution_var(hipdrt_plan* p, const double* basis_eval, int n
     LAUNCH_OK();
     // evaluation rows -> packed tiles, shifted past the special-parameter slots
     DevBuf dbe, bex, scratch, dout, dstat;
-    TRY(upload(dbe, basis_eval, (size_t)neval * ntau * sizeof(double), st));
+    TRY(upload(dbe, basis_eval, (size_t)neval * ncol * sizeof(double), st));
     HIPDRT_CHECK(bex.alloc((size_t)nex * nchp * 256 * sizeof(double)));
-    launch_pack_rows(st, neval, ntau, p->ns, dbe.d(), ntau, nex, bex.d(), nchp);
+    launch_pack_rows(st, neval, ncol, col_offset, dbe.d(), ncol, nex, bex.d(), nchp);
     LAUNCH_OK();
     const int chunk = B < 256 ? B : 256;
     const size_t lsz = dist_var_scratch_doubles(n, nex);
@@ -965,6 +967,19 @@ int hipdrt_plan_distribution_var(hipdrt_plan* p, const double* basis_eval, int n
         if (status) status[b] = hs[b];
     }
     return HIPDRT_OK;
+}
+
+int hipdrt_plan_distribution_var(hipdrt_plan* p, const double* basis_eval, int neval, double* out, int* status) {
+    HIPDRT_REQUIRE(p && basis_eval && out, "NULL pointer");
+    return plan_quadratic_forms(p, basis_eval, neval, p->ntau, p->ns, out, status);
+}
+
+int hipdrt_plan_param_var(hipdrt_plan* p, double* out, int* status) {
+    HIPDRT_REQUIRE(p && out, "NULL pointer");
+    const int n = p->n;
+    std::vector<double> eye((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) eye[(size_t)i * n + i] = 1.0;
+    return plan_quadratic_forms(p, eye.data(), n, n, 0, out, status);
 }
 
 int hipdrt_plan_record_history(hipdrt_plan* p, int b) {

@@ -330,6 +330,14 @@ class DRT:
             var[:, right_index:] = np.maximum(var[:, right_index:], var[:, right_index][:, None])
         return var, status == 0
 
+    def estimate_param_var_batch(self):
+        """np.diag(DRT.estimate_param_cov()) (drt1d.py:4116-4138) for every spectrum of the last fitted batch, from the
+        Cholesky factor of each final P on the device.  Returns (var (B, n), ok (B,) bool)."""
+        if self._plan is None or self._last_batch is None:
+            raise Exception('Parameter covariance estimation is only available for qphb fits')
+        var, status = self._plan.param_var(self._last_batch)
+        return var, status == 0
+
     def get_tau_eval(self, ppd):
         """drtbase.get_tau_eval (drtbase.py:263-285): one decade beyond the basis grid on each side."""
         basis_tau = self.basis_tau

@@ -221,6 +221,9 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* plan, int b, double* p);
  * For every fitted spectrum: final P (calculate_pq state), P = L L' on the device, out[b][i] = |L^-1 b_i|^2 * cs_b^2.
  * status[b] (may be NULL): 0 ok, -1 P not positive definite (the reference's LinAlgError -> None).  n <= 528 only. */
 int hipdrt_plan_distribution_var(hipdrt_plan* plan, const double* basis_eval, int neval, double* out, int* status);
+/* same machinery with the identity as evaluation rows: out[b][i] = diag(inv(P_b))_i * cs_b^2, the parameter variances
+ * np.diag(DRT.estimate_param_cov()) (hybdrt/models/drt1d.py:4116-4138) of every fitted spectrum.  n <= 528 only.     */
+int hipdrt_plan_param_var(hipdrt_plan* plan, double* out, int* status);
 
 /* per-outer-iteration history of spectrum b recorded when record_history was enabled before the fit:
  * hist_x[iters][n], hist_rho[iters][3], hist_w[iters][m], qp_iters[iters+1]                            */

@@ -167,6 +167,9 @@ def test_distribution_variance_vs_reference_fixture():
     np.testing.assert_allclose(var[0], ref, rtol=1e-9, atol=1e-300)
     vext, _ = drt.estimate_distribution_var_batch(tau=g["tau_eval"], extend_var=True)
     np.testing.assert_allclose(vext[0], g["dist_var_ext"], rtol=1e-6, atol=1e-12 * g["dist_var"].max())
+    pv, pok = drt.estimate_param_var_batch()
+    np.testing.assert_allclose(pv[0], g["param_var"], rtol=1e-6)
+    np.testing.assert_allclose(pv[0], np.diag(np.linalg.inv(P)) * drt.coefficient_scale ** 2, rtol=1e-9)
     # llh / rss of the single fit (host arithmetic on the downloaded state)
     assert drt.evaluate_rss() == pytest.approx(float(g["rss"]), rel=1e-6)
     assert drt.evaluate_llh() == pytest.approx(float(g["llh"]), rel=1e-7)

@@ -44,3 +44,36 @@ def config_c1():
 
 def config_c2():
     return dict(freq=np.logspace(6, -1, 256), tau=np.logspace(-8, 2, 512))
+
+
+def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, t_step=0.05, dt_pre=5e-4,
+                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57):
+    """Joint time/frequency-domain measurement of the same 2-ZARC cell (SURVEY.md section 8d, config 5 family):
+    a galvanostatic step of ``i_step`` at ``t_step`` (n_pre uniform samples before it, n_post log-uniform after it)
+    whose voltage comes from the closed-form response of an RC (Debye) discretisation of the two ZARCs, plus the
+    impedance spectrum of :func:`zarc2_spectrum` on ``logspace(f_hi, f_lo, nf)``.
+
+    Returns (times, i_signal, v_signal, freq, z).
+    """
+    p = dict(BASE)
+    rng = np.random.default_rng(50_000 + seed)
+    freq = np.logspace(np.log10(f_hi), np.log10(f_lo), nf)
+    z = zarc2_spectrum(freq, seed)
+    pre = t_step - dt_pre * np.arange(n_pre, 0, -1)
+    times = np.concatenate([pre, t_step + np.logspace(np.log10(t_lo), np.log10(t_hi), n_post)])
+    i_signal = np.where(times >= t_step, i_step, 0.0)
+    lt = np.linspace(-6.0, 1.0, n_rc)
+    taus = 10.0 ** lt
+
+    def gamma(r, t0, beta):   # Cole-Cole distribution of relaxation times, integrated over one ln(tau) cell
+        u = np.log(taus / t0)
+        g = r / (2 * np.pi) * np.sin((1 - beta) * np.pi) / (np.cosh(beta * u) - np.cos((1 - beta) * np.pi))
+        return g * np.log(10.0) * (lt[1] - lt[0])
+
+    rk = gamma(p["r1"], p["tau1"], p["beta1"]) + gamma(p["r2"], p["tau2"], p["beta2"])
+    post = times >= t_step
+    dt = times[post] - t_step
+    v = np.zeros(len(times))
+    v[post] = i_step * (p["r_inf"] + (rk[None, :] * (1.0 - np.exp(-dt[:, None] / taus[None, :]))).sum(axis=1))
+    v_signal = v + v0 + v_noise * rng.standard_normal(len(times))
+    return times, i_signal, v_signal, freq, z

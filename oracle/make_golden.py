@@ -225,6 +225,64 @@ def run_candidates(DRT, name, freq, z, ctor_kw):
     print(f"candidates_{name}: s0 history {len(hist_s)}, weights history {len(hist_w)}")
 
 
+def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
+    """config-5 family (drt1d.py:1244-1268 -> 102-1104): joint chrono + EIS fit, optionally with the distribution of
+    phasances; every prepared quantity the build's host layer must reproduce, the QP matrices, the per-iteration
+    history and the extracted parameters.  ``data`` = (times, i, v, freq, z); times None -> fit_eis."""
+    times, i_sig, v_sig, freq, z = data
+    log = []
+    cvxopt.solvers.options["_oracle_log"] = log
+    with _quiet():
+        drt = DRT(**ctor_kw)
+        if times is None:
+            drt.fit_eis(freq, z, **fit_kw)
+        else:
+            drt.fit_hybrid(times, i_sig, v_sig, freq, z, **fit_kw)
+    cvxopt.solvers.options["_oracle_log"] = None
+    fp, qp = drt.fit_parameters, drt.qphb_params
+    sp = drt.special_qp_params
+    out = dict(freq=freq, z=z, basis_tau=drt.basis_tau, tau_epsilon=drt.tau_epsilon,
+               special_names=np.array(list(sp.keys())), special_index=np.array([v["index"] for v in sp.values()]),
+               special_size=np.array([v.get("size", 1) for v in sp.values()]),
+               special_nonneg=np.array([v["nonneg"] for v in sp.values()]),
+               coefficient_scale=drt.coefficient_scale, impedance_scale=drt.impedance_scale,
+               rm=qp["rm"], rv=qp["rv"], vmm=qp["vmm"], l1_lambda_vector=qp["l1_lambda_vector"],
+               m0=qp["penalty_matrices"]["m0"], m1=qp["penalty_matrices"]["m1"], m2=qp["penalty_matrices"]["m2"],
+               est_weights=qp["est_weights"], init_weights=qp["init_weights"], weights=qp["true_weights"],
+               scaled_weights=qp["weights"], rho_vector=qp["rho_vector"], s_vectors=np.array(qp["s_vectors"]),
+               xmx_norms=qp["xmx_norms"], qp_iterations=np.array([l["iterations"] for l in log]),
+               outer_iterations=len(drt.qphb_history),
+               hist_x=np.array([h["x"] for h in drt.qphb_history]),
+               hist_rho=np.array([h["rho_vector"] for h in drt.qphb_history]),
+               hist_weights=np.array([h["weights"] for h in drt.qphb_history]),
+               x=fp["x"], R_inf=fp["R_inf"], inductance=fp["inductance"], z_sigma_tot=fp["z_sigma_tot"],
+               q_vector=fp["q_vector"], p_matrix=fp["p_matrix"], x_scaled=np.array(list(drt.cvx_result["x"])))
+    if drt.fit_dop:
+        out.update(basis_nu=drt.basis_nu, nu_epsilon=drt.nu_epsilon, dop_scale_vector=drt.dop_scale_vector,
+                   dop_rho_vector=qp["dop_rho_vector"], dop_xmx_norms=qp["dop_xmx_norms"], x_dop=fp["x_dop"],
+                   hist_dop_rho=np.array([h["dop_rho_vector"] for h in drt.qphb_history]))
+    if times is not None:
+        out.update(times=times, i_signal=i_sig, v_signal=v_sig, sample_times=drt.get_fit_times(),
+                   step_times=drt.step_times, step_sizes=drt.step_sizes,
+                   nonconsec_step_times=drt.nonconsec_step_times,
+                   input_signal_scale=drt.input_signal_scale, response_signal_scale=drt.response_signal_scale,
+                   scaled_response_offset=drt.scaled_response_offset, v_baseline_scale=drt.v_baseline_scale,
+                   vz_strength_vec=qp["vz_strength_vec"], num_chrono=qp["num_chrono"],
+                   v_baseline=fp["v_baseline"], vz_offset=fp["vz_offset"], v_sigma_tot=fp["v_sigma_tot"],
+                   response_matrix=drt.fit_matrices["response"], inf_response=drt.fit_matrices["inf_response"])
+    np.savez_compressed(os.path.join(OUT, f"refrun_{name}.npz"), **out)
+    print(f"{name}: m x n = {qp['rm'].shape}, outer={out['outer_iterations']} qp_iters={out['qp_iterations'].tolist()}")
+
+
+def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
+    from hipdrt import synth
+    base = dict(fit_inductance=True, fit_capacitance=False, fit_ohmic=True)
+    run_hybrid_case(DRT, cvxopt, "golden71x91_dop", (None, None, None, freq_g, z_g), dict(base, fit_dop=True), {})
+    meas = synth.hybrid_measurement(seed=0)
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0", meas, dict(base, fit_dop=False), {})
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop", meas, dict(base, fit_dop=True), {})
+
+
 def run_posteriors(DRT, freq_g, z_g, default):
     from oracle.drt_oracle import get_basis_tau
     bt = get_basis_tau(freq_g)
@@ -237,6 +295,11 @@ def main():
     sys.path.insert(0, REPO)
     if "--only-response" in sys.argv:
         run_response_matrices()
+        return
+    if "--only-hybrid" in sys.argv:
+        freq_g, z_g = extract_reference_test_vectors()
+        DRT, cvxopt = _boot_reference()
+        run_hybrid_cases(DRT, cvxopt, freq_g, z_g)
         return
     if "--only-options" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()
@@ -297,6 +360,8 @@ def main():
     run_posteriors(DRT, freq_g, z_g, default)
     # (9) warm restarts / candidate generation (survey 8f rank 3)
     run_candidates(DRT, "golden71x91", freq_g, z_g, default)
+    # (10) distribution of phasances inside fit_eis, and joint chrono + EIS fits (config-5 family)
+    run_hybrid_cases(DRT, cvxopt, freq_g, z_g)
 
 
 if __name__ == "__main__":

@@ -186,3 +186,32 @@ def test_oracle_optional_weight_branches_match_reference_run(name, kw):
     assert [l["iterations"] for l in d.qp_log] == list(g["qp_iterations"])
     np.testing.assert_array_equal(d.qphb_params["est_weights"], g["est_weights"])
     np.testing.assert_allclose(d.qphb_params["x_scaled"], g["x_scaled"], rtol=0, atol=1e-11 * np.abs(g["x_scaled"]).max())
+
+
+# ---- config-5 family: distribution of phasances inside the loop, joint chrono + EIS fits ----------------------------
+@pytest.mark.parametrize("name", ["golden71x91_dop", "hybrid_s0", "hybrid_s0_dop"])
+def test_general_loop_reproduces_reference_trajectory(name):
+    """oracle.qphb_fit_prepared (the loop of drt1d.py:551-1006 with the DOP pass of qphb.py:822-933 and the vz_offset
+    column rewrite of drt1d.py:973-979) on the reference run's own matrices: identical outer / IPM iteration counts,
+    every iterate, hyper-parameters, weights, the rewritten matrix and calculate_pq's outputs."""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case(name)
+    hyp = orc.get_default_hypers()
+    if "x_dop" in special:
+        hyp.update(orc.get_default_dop_hypers())
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    r = orc.qphb_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, vz=vz)
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    assert len(r["history"]) == int(g["outer_iterations"])
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(np.array([h["rho_vector"] for h in r["history"]]), g["hist_rho"], rtol=1e-8)
+    np.testing.assert_allclose(r["weights"], g["weights"], rtol=1e-8)
+    np.testing.assert_allclose(np.array(r["s_vectors"]), g["s_vectors"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(r["rzm"], g["rm"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(r["p_matrix"], g["p_matrix"], rtol=1e-8, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    np.testing.assert_allclose(r["q_vector"], g["q_vector"], rtol=1e-8, atol=1e-8 * np.abs(g["q_vector"]).max())
+    np.testing.assert_allclose(r["l1_lambda_vector"], g["l1_lambda_vector"])
+    if "x_dop" in special:
+        np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in r["history"]]), g["hist_dop_rho"], rtol=1e-8)
+        np.testing.assert_allclose(r["dop_xmx_norms"], g["dop_xmx_norms"], rtol=1e-7)
+    np.testing.assert_allclose(r["xmx_norms"], g["xmx_norms"], rtol=1e-7)

@@ -40,6 +40,17 @@ class FitOpts(C.Structure):
     ]
 
 
+class PreparedDesc(C.Structure):
+    """hipdrt_prepared_desc (include/hipdrt.h)"""
+    _fields_ = [
+        ("m", C.c_int), ("n", C.c_int), ("ns", C.c_int), ("dop_start", C.c_int), ("dop_size", C.c_int),
+        ("vz_index", C.c_int), ("vb_start", C.c_int), ("vb_size", C.c_int), ("num_chrono", C.c_int),
+        ("toeplitz_m", C.c_int), ("dop_l2_lambda_0", C.c_double), ("dop_derivative_weights", C.c_double * 3),
+        ("dop_s_alpha", C.c_double * 3), ("dop_rho_alpha", C.c_double * 3), ("dop_s_0", C.c_double * 3),
+        ("dop_rho_0", C.c_double * 3),
+    ]
+
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 _vp = C.c_void_p
@@ -72,6 +83,9 @@ SIGNATURES = {
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            _dp, _dp, _dp, _dp, C.POINTER(FitOpts), C.c_int, C.POINTER(_vp)],
+    "hipdrt_plan_create_prepared": [_vp, C.POINTER(PreparedDesc), _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(FitOpts),
+                                    C.c_int, C.POINTER(_vp)],
+    "hipdrt_plan_upload_prepared": [_vp, C.c_int, C.c_int, _dp, _dp],
     "hipdrt_plan_destroy": [_vp],
     "hipdrt_plan_dims": [_vp, _ip, _ip, _ip],
     "hipdrt_plan_get": [_vp, C.c_char_p, _dp, C.c_longlong],
@@ -472,6 +486,57 @@ class Plan:
         _check(self._lib.hipdrt_plan_timings(self._h, t, l))
         names = ("total", "gram", "qp", "hyper", "other")
         return {k: float(t[i]) for i, k in enumerate(names)}, {k: int(l[i]) for i, k in enumerate(names)}
+
+
+class PreparedPlan(Plan):
+    """hipdrt_plan_create_prepared: the device loop on caller-prepared matrices (any data type; optional x_dop block
+    and vz_offset column).  `desc` is a PreparedDesc, penalty = [m0, m1, m2] (n, n), vmm (m, m), h / l1 (n,)."""
+
+    def __init__(self, ctx: Context, desc: PreparedDesc, penalty, vmm, h, l1, vz_strength=None,
+                 opts: FitOpts | None = None, capacity=1):
+        self._lib = load_library()
+        self.ctx = ctx
+        self.desc = desc
+        self.opts = opts if opts is not None else default_fit_opts()
+        mk = [_f64(a) for a in penalty]
+        vmm, h, l1 = _f64(vmm), _f64(h), _f64(l1)
+        vzs = None if vz_strength is None else _f64(vz_strength)
+        hnd = _vp()
+        _check(self._lib.hipdrt_plan_create_prepared(ctx._h, C.byref(desc), _p(mk[0]), _p(mk[1]), _p(mk[2]), _p(vmm),
+                                                     _p(h), _p(l1), _p(vzs), C.byref(self.opts), int(capacity),
+                                                     C.byref(hnd)))
+        self._h = hnd
+        self.n, self.m, self.ns = desc.n, desc.m, desc.ns
+        self.nf, self.ntau, self.ngrid = 0, desc.n - desc.ns, 0
+        self.capacity = int(capacity)
+        self.B = 0
+        self.rm_batched = False
+
+    def upload(self, rzm, rzv):
+        """rzm (m, n) shared or (B, m, n) per measurement; rzv (B, m)"""
+        rzm, rzv = _f64(rzm), _f64(rzv)
+        if rzv.ndim == 1:
+            rzv = rzv[None, :]
+        batched = rzm.ndim == 3
+        _check(self._lib.hipdrt_plan_upload_prepared(self._h, rzv.shape[0], int(batched), _p(rzm), _p(rzv)))
+        self.batch = self.B = rzv.shape[0]
+        self.rm_batched = batched
+
+    def get(self, which):
+        B = self.batch
+        shapes = {"m0": (self.n, self.n), "m1": (self.n, self.n), "m2": (self.n, self.n), "vmm": (self.m, self.m),
+                  "h": (self.n,), "est_weights": (B, self.m), "rv": (B, self.m), "xmx": (B, 3), "dop_rho": (B, 3),
+                  "dop_xmx": (B, 3), "hist_dop_rho": (int(self.opts.max_iter), 3),
+                  "rzm": (B, self.m, self.n) if self.rm_batched else (self.m, self.n)}
+        out = np.empty(shapes[which])
+        _check(self._lib.hipdrt_plan_get(self._h, which.encode(), _p(out), out.size))
+        return out
+
+    def history(self):
+        h = super().history()
+        if self.desc.dop_size > 0:
+            h["dop_rho"] = self.get("hist_dop_rho")[:len(h["x"])]
+        return h
 
 
 _default_ctx = {}

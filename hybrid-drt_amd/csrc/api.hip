@@ -23,6 +23,11 @@ struct hipdrt_plan {
     int capacity = 0, B = 0;
     double eps = 0;
     hipdrt_fit_opts opts{};
+    // prepared-matrix plans (hipdrt_plan_create_prepared)
+    int prepared = 0;
+    hipdrt_prepared_desc desc{};
+    long long rm_stride = 0;
+    DevBuf vz_strength, dop_rho, dop_xmx, hist_dop_rho;
     // shared
     DevBuf freq, tau, ln_tau, wt_re, wt_im, lut6, a_re, a_im, cr, rm, mk[3], vmm, h, l1;
     // per spectrum
@@ -40,6 +45,9 @@ struct hipdrt_plan {
         FitState st{};
         st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm; st.toeplitz_m = toeplitz_m;
         st.opts = opts; st.continue_mode = 0; st.min_iter = 1;
+        st.prepared = prepared; st.desc = desc; st.rm_stride = rm_stride; st.rm_rw = rm.d();
+        st.vz_strength = vz_strength.d(); st.dop_rho = dop_rho.d(); st.dop_xmx = dop_xmx.d();
+        st.hist_dop_rho = hist_dop_rho.d();
         st.rm = rm.d(); st.vmm = vmm.d(); st.vmm_iw = vmm_base.p ? vmm_base.d() : vmm.d();
         for (int k = 0; k < 3; ++k) st.mk[k] = mk[k].d();
         st.z_re = z_re.d(); st.z_im = z_im.d();
@@ -487,6 +495,33 @@ static int plan_build_matrices(hipdrt_plan* p, bool build_lookup) {
     return 0;
 }
 
+// work space for `capacity` spectra
+static int plan_alloc_batch(hipdrt_plan* p) {
+    const size_t cap = (size_t)p->capacity;
+    const int n = p->n, m = p->m, nf = p->nf > 0 ? p->nf : 1;
+    HIPDRT_CHECK(p->z_re.alloc(cap * nf * sizeof(double))); HIPDRT_CHECK(p->z_im.alloc(cap * nf * sizeof(double)));
+    HIPDRT_CHECK(p->rv.alloc(cap * m * sizeof(double))); HIPDRT_CHECK(p->w.alloc(cap * m * sizeof(double)));
+    HIPDRT_CHECK(p->est_w.alloc(cap * m * sizeof(double)));
+    HIPDRT_CHECK(p->x.alloc(cap * n * sizeof(double))); HIPDRT_CHECK(p->x_in.alloc(cap * n * sizeof(double)));
+    HIPDRT_CHECK(p->q.alloc(cap * n * sizeof(double)));
+    HIPDRT_CHECK(p->s.alloc(cap * 3 * n * sizeof(double)));
+    HIPDRT_CHECK(p->rho.alloc(cap * 3 * sizeof(double))); HIPDRT_CHECK(p->xmx.alloc(cap * 3 * sizeof(double)));
+    HIPDRT_CHECK(p->coef_scale.alloc(cap * sizeof(double))); HIPDRT_CHECK(p->var_floor.alloc(cap * sizeof(double)));
+    HIPDRT_CHECK(p->pcost.alloc(cap * sizeof(double)));
+    for (DevBuf* ib : {&p->active, &p->outer_iters, &p->fit_status, &p->qp_iters_total, &p->qp_status, &p->qp_iters})
+        HIPDRT_CHECK(ib->alloc(cap * sizeof(int)));
+    HIPDRT_CHECK(p->n_active.alloc(sizeof(int)));
+    if (!qp_packed_only(n)) HIPDRT_CHECK(p->P.alloc(cap * n * p->ldp * sizeof(double)));
+    HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n) * sizeof(double)));
+    HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
+    HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
+    HIPDRT_CHECK(p->Ppk.alloc(cap * qp_ppk_doubles(n) * sizeof(double)));
+    HIPDRT_CHECK(p->order.alloc(cap * sizeof(int)));
+    if (p->opts.outlier_p > 0.0) HIPDRT_CHECK(p->vmm_base.alloc((size_t)m * m * sizeof(double)));
+    HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
+    return 0;
+}
+
 int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double* tau, int ntau, double epsilon,
                        int mode, int toeplitz_a, int toeplitz_m, int ngrid, int ny, const double* wt_re,
                        const double* wt_im, const double* log_wt_re, const double* log_wt_im,
@@ -543,28 +578,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     TRY(upload(p->ln_tau, ln_tau.data(), (size_t)ntau * sizeof(double), st));
     HIPDRT_CHECK(hipStreamSynchronize(st));   // host vectors above go out of scope
 
-    // per-spectrum buffers
-    const size_t cap = (size_t)capacity;
-    HIPDRT_CHECK(p->z_re.alloc(cap * nf * sizeof(double))); HIPDRT_CHECK(p->z_im.alloc(cap * nf * sizeof(double)));
-    HIPDRT_CHECK(p->rv.alloc(cap * m * sizeof(double))); HIPDRT_CHECK(p->w.alloc(cap * m * sizeof(double)));
-    HIPDRT_CHECK(p->est_w.alloc(cap * m * sizeof(double)));
-    HIPDRT_CHECK(p->x.alloc(cap * n * sizeof(double))); HIPDRT_CHECK(p->x_in.alloc(cap * n * sizeof(double)));
-    HIPDRT_CHECK(p->q.alloc(cap * n * sizeof(double)));
-    HIPDRT_CHECK(p->s.alloc(cap * 3 * n * sizeof(double)));
-    HIPDRT_CHECK(p->rho.alloc(cap * 3 * sizeof(double))); HIPDRT_CHECK(p->xmx.alloc(cap * 3 * sizeof(double)));
-    HIPDRT_CHECK(p->coef_scale.alloc(cap * sizeof(double))); HIPDRT_CHECK(p->var_floor.alloc(cap * sizeof(double)));
-    HIPDRT_CHECK(p->pcost.alloc(cap * sizeof(double)));
-    for (DevBuf* ib : {&p->active, &p->outer_iters, &p->fit_status, &p->qp_iters_total, &p->qp_status, &p->qp_iters})
-        HIPDRT_CHECK(ib->alloc(cap * sizeof(int)));
-    HIPDRT_CHECK(p->n_active.alloc(sizeof(int)));
-    if (!qp_packed_only(n)) HIPDRT_CHECK(p->P.alloc(cap * n * p->ldp * sizeof(double)));
-    HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n) * sizeof(double)));
-    HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
-    HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
-    HIPDRT_CHECK(p->Ppk.alloc(cap * qp_ppk_doubles(n) * sizeof(double)));
-    HIPDRT_CHECK(p->order.alloc(cap * sizeof(int)));
-    if (p->opts.outlier_p > 0.0) HIPDRT_CHECK(p->vmm_base.alloc((size_t)m * m * sizeof(double)));
-    HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
+    TRY(plan_alloc_batch(p.get()));
 
     // shared matrices on the device
     TRY(plan_build_matrices(p.get(), true));
@@ -578,6 +592,68 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     LAUNCH_OK();
     HIPDRT_CHECK(hipStreamSynchronize(st));
     *out = p.release();
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, const double* m0, const double* m1,
+                                const double* m2, const double* vmm, const double* h, const double* l1,
+                                const double* vz_strength, const hipdrt_fit_opts* opts, int capacity, hipdrt_plan** out) {
+    HIPDRT_REQUIRE(ctx && d && m0 && m1 && m2 && vmm && h && l1 && out, "NULL pointer");
+    HIPDRT_REQUIRE(d->m >= 2 && d->n >= 2 && d->ns >= 0 && d->ns < d->n && capacity >= 1, "m, n >= 2, 0 <= ns < n, capacity >= 1");
+    HIPDRT_REQUIRE(d->n <= 2048, "n <= 2048");
+    HIPDRT_REQUIRE(d->dop_size >= 0 && (d->dop_size == 0 || (d->dop_start >= 0 && d->dop_start + d->dop_size <= d->ns)),
+                   "the x_dop block must lie inside the special parameters");
+    HIPDRT_REQUIRE(d->dop_size <= d->n - d->ns, "x_dop block larger than the DRT block");
+    HIPDRT_REQUIRE(d->vz_index < d->ns && (d->vz_index < 0 || vz_strength), "vz_offset column / strength vector");
+    HIPDRT_REQUIRE(d->vb_size >= 0 && d->vb_start >= 0 && d->vb_start + d->vb_size <= d->ns, "v_baseline columns");
+    HIPDRT_REQUIRE(d->num_chrono >= 0 && d->num_chrono <= d->m, "num_chrono");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<hipdrt_plan> p(new hipdrt_plan());
+    p->ctx = ctx;
+    if (opts) p->opts = *opts; else hipdrt_default_fit_opts(&p->opts);
+    p->prepared = 1; p->desc = *d;
+    p->n = d->n; p->m = d->m; p->ns = d->ns; p->ntau = d->n - d->ns; p->nf = 0; p->toeplitz_m = d->toeplitz_m;
+    p->capacity = capacity;
+    const int n = p->n, m = p->m;
+    p->ldrm = round_up(n, 2); p->ldm = round_up(n, 2); p->ldp = round_up(n, 2); p->ldl = (int)qp_scratch_ld(n);
+    const double* mk[3] = {m0, m1, m2};
+    for (int k = 0; k < 3; ++k) {
+        HIPDRT_CHECK(p->mk[k].alloc((size_t)n * p->ldm * sizeof(double)));
+        HIPDRT_CHECK(hipMemsetAsync(p->mk[k].p, 0, p->mk[k].bytes, st));
+        HIPDRT_CHECK(hipMemcpy2DAsync(p->mk[k].p, (size_t)p->ldm * sizeof(double), mk[k], (size_t)n * sizeof(double),
+                                      (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, st));
+    }
+    TRY(upload(p->vmm, vmm, (size_t)m * m * sizeof(double), st));
+    TRY(upload(p->h, h, (size_t)n * sizeof(double), st));
+    TRY(upload(p->l1, l1, (size_t)n * sizeof(double), st));
+    if (vz_strength) TRY(upload(p->vz_strength, vz_strength, (size_t)m * sizeof(double), st));
+    TRY(plan_alloc_batch(p.get()));
+    HIPDRT_CHECK(p->dop_rho.alloc((size_t)capacity * 3 * sizeof(double)));
+    HIPDRT_CHECK(p->dop_xmx.alloc((size_t)capacity * 3 * sizeof(double)));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    *out = p.release();
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_upload_prepared(hipdrt_plan* p, int B, int rm_batched, const double* rzm, const double* rzv) {
+    HIPDRT_REQUIRE(p && rzm && rzv, "NULL pointer");
+    HIPDRT_REQUIRE(p->prepared, "not a prepared plan");
+    HIPDRT_REQUIRE(B >= 1 && B <= p->capacity, "1 <= B <= capacity");
+    HIPDRT_REQUIRE(rm_batched || p->desc.vz_index < 0, "a vz_offset column needs one response matrix per measurement");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const int n = p->n, m = p->m;
+    const size_t nmat = rm_batched ? (size_t)B : 1;
+    const size_t need = nmat * m * p->ldrm * sizeof(double);
+    if (p->rm.bytes < need) HIPDRT_CHECK(p->rm.alloc(need));
+    HIPDRT_CHECK(hipMemsetAsync(p->rm.p, 0, need, st));
+    HIPDRT_CHECK(hipMemcpy2DAsync(p->rm.p, (size_t)p->ldrm * sizeof(double), rzm, (size_t)n * sizeof(double),
+                                  (size_t)n * sizeof(double), nmat * m, hipMemcpyHostToDevice, st));
+    HIPDRT_CHECK(hipMemcpyAsync(p->rv.p, rzv, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    p->rm_stride = rm_batched ? (long long)m * p->ldrm : 0;
+    p->B = B;
     return HIPDRT_OK;
 }
 
@@ -617,6 +693,11 @@ int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long co
     else if (w == "h") { src = p->h.d(); rows = 1; cols = ld = p->n; }
     else if (w == "est_weights") { src = p->est_w.d(); rows = p->B; cols = ld = p->m; }   // per spectrum of the last batch
     else if (w == "rv") { src = p->rv.d(); rows = p->B; cols = ld = p->m; }
+    else if (w == "xmx") { src = p->xmx.d(); rows = p->B; cols = ld = 3; }
+    else if (w == "dop_rho" && p->prepared) { src = p->dop_rho.d(); rows = p->B; cols = ld = 3; }
+    else if (w == "dop_xmx" && p->prepared) { src = p->dop_xmx.d(); rows = p->B; cols = ld = 3; }
+    else if (w == "rzm") { src = p->rm.d(); rows = (p->rm_stride ? p->B : 1) * p->m; cols = p->n; ld = p->ldrm; }
+    else if (w == "hist_dop_rho" && p->prepared && p->hist_b >= 0) { src = p->hist_dop_rho.d(); rows = p->hist_cap; cols = ld = 3; }
     else { set_error("unknown matrix name: " + w); return HIPDRT_E_INVALID; }
     HIPDRT_REQUIRE(src != nullptr, "matrix not available in this mode");
     HIPDRT_REQUIRE(count == (long long)rows * cols, "count does not match the matrix size");
@@ -638,6 +719,7 @@ int hipdrt_plan_set_lookup(hipdrt_plan* p, const double* z_re, const double* z_i
 
 int hipdrt_plan_upload(hipdrt_plan* p, int B, const double* z_re, const double* z_im) {
     HIPDRT_REQUIRE(p && z_re && z_im, "NULL pointer");
+    HIPDRT_REQUIRE(!p->prepared, "prepared plans take hipdrt_plan_upload_prepared");
     HIPDRT_REQUIRE(B >= 1 && B <= p->capacity, "1 <= B <= capacity");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
@@ -647,6 +729,20 @@ int hipdrt_plan_upload(hipdrt_plan* p, int B, const double* z_re, const double* 
     HIPDRT_CHECK(hipStreamSynchronize(st));
     p->B = B;
     return HIPDRT_OK;
+}
+
+// L2 part of P in hyper-parameter form (calculate_qp_l2_matrix, qphb.py:53-120) for the plan's current state
+static GramL2 plan_l2(const hipdrt_plan* p, double l2_lambda_0, const double* derivative_weights, double dop_l2_lambda_0) {
+    GramL2 g{};
+    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1;
+    g.sym = p->prepared ? 0 : p->toeplitz_m;      // caller-supplied matrices are not assumed bitwise symmetric
+    for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = l2_lambda_0 * derivative_weights[k]; }
+    g.s = p->s.d(); g.rho = p->rho.d();
+    if (p->prepared && p->desc.dop_size > 0) {
+        g.dop_start = p->desc.dop_start; g.dop_size = p->desc.dop_size; g.dop_rho = p->dop_rho.d();
+        for (int k = 0; k < 3; ++k) g.dop_dfac[k] = dop_l2_lambda_0 * p->desc.dop_derivative_weights[k];
+    }
+    return g;
 }
 
 namespace {
@@ -679,6 +775,7 @@ struct PhaseTimer {
 int hipdrt_plan_fit(hipdrt_plan* p) {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no spectra staged (call hipdrt_plan_upload)");
+    HIPDRT_REQUIRE(!(p->prepared && p->opts.outlier_p > 0.0), "outlier_p is not available on prepared plans");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
     const int B = p->B, n = p->n, m = p->m;
@@ -689,10 +786,12 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     launch_prep(st, fs, B);
     LAUNCH_OK();
 
-    GramL2 g{};
-    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1; g.sym = p->toeplitz_m;
-    for (int k = 0; k < 3; ++k) g.mk[k] = p->mk[k].d();
-    g.s = p->s.d(); g.rho = p->rho.d();
+    // initialize_weights runs with iw_l2_lambda_0 and the DOP / DRT ratio kept (drt1d.py:640-646)
+    const double dop_l2 = p->prepared ? p->desc.dop_l2_lambda_0 : 0.0;
+    GramL2 g = plan_l2(p, p->opts.iw_l2_lambda_0, p->opts.derivative_weights,
+                       dop_l2 / p->opts.l2_lambda_0 * p->opts.iw_l2_lambda_0);
+    const long long astr = p->rm_stride;
+    const bool shared_rm = astr == 0;
 
     QpArgs qa{};
     qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
@@ -704,14 +803,17 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     // ---- initialize_weights (qphb.py:1609-1681): one un-weighted, weakly penalised QP; P is the same for
     //      every spectrum (weights = 1, s = s_0, rho = rho_0), only q differs -------------------------------
     tm.mark(1);
-    for (int k = 0; k < 3; ++k) g.dfac[k] = p->opts.iw_l2_lambda_0 * p->opts.derivative_weights[k];
     double* const Prow = qp_packed_only(n) ? nullptr : p->P.d();   // row-major P only for the multi-pass QP kernel
-    launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, 0, nullptr, p->Ppk.d(), 0, qp_nchp(n));
-    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), nullptr, p->opts.iw_l1_lambda_0, p->q.d(), nullptr);
+    const long long pstr = (long long)n * p->ldp, pkstr = (long long)qp_ppk_doubles(n);
+    // one P for the whole batch when the response matrix is shared, else one per measurement
+    launch_gram_l2(st, shared_rm ? 1 : B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, shared_rm ? 0 : pstr, nullptr,
+                   p->Ppk.d(), shared_rm ? 0 : pkstr, qp_nchp(n), astr);
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), nullptr, p->opts.iw_l1_lambda_0, p->q.d(), nullptr,
+                astr);
     LAUNCH_OK();
     tm.mark(2);
-    qa.P = Prow; qa.p_stride = 0; qa.active = nullptr;
-    qa.Ppk = p->Ppk.d(); qa.ppk_stride = 0; qa.nchp = qp_nchp(n);
+    qa.P = Prow; qa.p_stride = shared_rm ? 0 : pstr; qa.active = nullptr;
+    qa.Ppk = p->Ppk.d(); qa.ppk_stride = shared_rm ? 0 : pkstr; qa.nchp = qp_nchp(n);
     TRY(launch_qp(st, qa));
     tm.mark(3);
     if (p->opts.outlier_p > 0.0) {
@@ -721,9 +823,9 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
         LAUNCH_OK();
         tm.mark(1);
         launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->est_w.d(), g, Prow, p->ldp, (long long)n * p->ldp, nullptr,
-                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
+                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n), astr);
         launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->est_w.d(), p->rv.d(), nullptr, p->opts.iw_l1_lambda_0, p->q.d(),
-                    nullptr);
+                    nullptr, astr);
         LAUNCH_OK();
         tm.mark(2);
         qa.p_stride = (long long)n * p->ldp; qa.ppk_stride = (long long)qp_ppk_doubles(n);
@@ -734,7 +836,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     LAUNCH_OK();
 
     // ---- outer loop (drt1d.py:877-988) ----------------------------------------------------------------------
-    for (int k = 0; k < 3; ++k) g.dfac[k] = p->opts.l2_lambda_0 * p->opts.derivative_weights[k];
+    g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, dop_l2);
     qa.p_stride = (long long)n * p->ldp; qa.active = p->active.i();
     qa.ppk_stride = (long long)qp_ppk_doubles(n);
     int it = 0;
@@ -742,8 +844,8 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
         tm.mark(1);
         HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
         launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, (long long)n * p->ldp, p->active.i(),
-                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
-        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i());
+                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n), astr);
+        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i(), astr);
         LAUNCH_OK();
         tm.mark(2);
         if (B * sizeof(int) <= 48 * 1024) {     // dispatch order from the previous QP's iteration counts
@@ -761,7 +863,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     }
     // ---- calculate_pq's q with the final weights (qphb.py:1154-1183) ---------------------------------------
     tm.mark(4);
-    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr);
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr, astr);
     LAUNCH_OK();
     tm.mark(-1);
     HIPDRT_CHECK(hipStreamSynchronize(st));
@@ -822,10 +924,8 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
         HIPDRT_CHECK(hipMemsetAsync(p->qp_iters_total.p, 0, (size_t)B * sizeof(int), st));
         HIPDRT_CHECK(hipStreamSynchronize(st));
     }
-    GramL2 g{};
-    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1; g.sym = p->toeplitz_m;
-    for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = opts->l2_lambda_0 * opts->derivative_weights[k]; }
-    g.s = p->s.d(); g.rho = p->rho.d();
+    HIPDRT_REQUIRE(!p->prepared, "warm restarts are not available on prepared plans");
+    GramL2 g = plan_l2(p, opts->l2_lambda_0, opts->derivative_weights, 0.0);
     QpArgs qa{};
     qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
     qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n);
@@ -909,11 +1009,11 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
     const int n = p->n, m = p->m;
-    GramL2 g{};
-    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1; g.sym = p->toeplitz_m;
-    for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = p->opts.l2_lambda_0 * p->opts.derivative_weights[k]; }
+    GramL2 g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, p->prepared ? p->desc.dop_l2_lambda_0 : 0.0);
     g.s = p->s.d() + (size_t)b * 3 * n; g.rho = p->rho.d() + (size_t)b * 3;
-    launch_gram_l2(st, 1, m, n, p->rm.d(), p->ldrm, p->w.d() + (size_t)b * m, g, p->Ptmp.d(), p->ldp, 0, nullptr);
+    if (g.dop_size > 0) g.dop_rho = p->dop_rho.d() + (size_t)b * 3;
+    launch_gram_l2(st, 1, m, n, p->rm.d() + (size_t)b * p->rm_stride, p->ldrm, p->w.d() + (size_t)b * m, g, p->Ptmp.d(),
+                   p->ldp, 0, nullptr);
     LAUNCH_OK();
     return copy_strided(out, p->Ptmp.d(), n, n, p->ldp, st);
 }
@@ -930,12 +1030,9 @@ static int plan_quadratic_forms(hipdrt_plan* p, const double* basis_eval, int ne
     const int n = p->n, m = p->m, B = p->B;
     const int nex = (neval + 15) / 16, nchp = qp_nchp(n);
     // final P of every spectrum (calculate_pq with the final weights / s / rho, drt1d.py:1006), packed tiles only
-    GramL2 g{};
-    g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1; g.sym = p->toeplitz_m;
-    for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = p->opts.l2_lambda_0 * p->opts.derivative_weights[k]; }
-    g.s = p->s.d(); g.rho = p->rho.d();
+    GramL2 g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, p->prepared ? p->desc.dop_l2_lambda_0 : 0.0);
     launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, nullptr, p->ldp, 0, nullptr, p->Ppk.d(),
-                   (long long)qp_ppk_doubles(n), nchp);
+                   (long long)qp_ppk_doubles(n), nchp, p->rm_stride);
     LAUNCH_OK();
     // evaluation rows -> packed tiles, shifted past the special-parameter slots
     DevBuf dbe, bex, scratch, dout, dstat;
@@ -992,6 +1089,7 @@ int hipdrt_plan_record_history(hipdrt_plan* p, int b) {
         HIPDRT_CHECK(p->hist_w.alloc((size_t)p->hist_cap * p->m * sizeof(double)));
         HIPDRT_CHECK(p->hist_rho.alloc((size_t)p->hist_cap * 3 * sizeof(double)));
         HIPDRT_CHECK(p->hist_qp.alloc((size_t)(p->hist_cap + 1) * sizeof(int)));
+        HIPDRT_CHECK(p->hist_dop_rho.alloc((size_t)p->hist_cap * 3 * sizeof(double)));
     }
     return HIPDRT_OK;
 }

@@ -109,19 +109,25 @@ struct GramL2 {
     int ns;
     int use_rho;
     int sym;               // penalty matrices are bitwise symmetric (Toeplitz build): read them along rows
+    // x_dop block (qphb.py:92-100): entries with both indices in [dop_start, dop_start + dop_size) are scaled by
+    // dop_dfac[k] * dop_rho[b][k] instead
+    int dop_start, dop_size;
+    const double* dop_rho; // [B][3]
+    double dop_dfac[3];    // dop_l2_lambda_0 * dop_derivative_weight[k]
 };
 // true when the QP for n unknowns runs on the kernel that reads P only through its packed tile copy (Ppk)
 bool qp_packed_only(int n);
+// a_stride: doubles between the response matrices of consecutive problems (0 = one shared matrix)
 void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const GramL2& g,
                     double* P, int ldp, long long p_stride, const int* active, double* Ppk = nullptr,
-                    long long ppk_stride = 0, int nchp = 0);
+                    long long ppk_stride = 0, int nchp = 0, long long a_stride = 0);
 // row-major symmetric P -> accumulator-native lower tiles
 void launch_pack_p(hipStream_t st, int B, int n, const double* P, int ldp, long long p_stride, double* Ppk,
                    long long ppk_stride, int nchp);
 inline int qp_nchp(int n) { return round_up(n, 32) / 16; }
 inline size_t qp_ppk_doubles(int n) { return (size_t)qp_nchp(n) * qp_nchp(n) * 256; }
 void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,
-                 const double* l1, double l1_scalar, double* q, const int* active);
+                 const double* l1, double l1_scalar, double* q, const int* active, long long a_stride = 0);
 void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w,
                           const double* b, const double* l2, long long l2_stride, int ldl2, const double* l1,
                           double* P, int ldp, long long p_stride, double* q, const int* active);
@@ -133,6 +139,14 @@ struct FitState {
     int continue_mode;     // warm restart (_continue_from_init): xmx norms stay frozen
     int min_iter;          // a spectrum may only stop once it has done this many outer iterations (fit: 1)
     hipdrt_fit_opts opts;
+    // prepared-matrix plans (hipdrt_plan_create_prepared): any data type, optional x_dop block and vz_offset column
+    int prepared;
+    hipdrt_prepared_desc desc;
+    long long rm_stride;   // doubles between the response matrices of consecutive spectra (0 = shared)
+    double* rm_rw;         // == rm when the matrices are per spectrum (the vz_offset column is rewritten every iteration)
+    const double* vz_strength;   // [m]
+    double *dop_rho, *dop_xmx;   // [B][3]
+    double* hist_dop_rho;
     // shared (plan) matrices
     const double* rm;      // [m][ldrm]  stacked [Re; Im] response matrix incl. special columns
     const double* vmm;     // [m][m]

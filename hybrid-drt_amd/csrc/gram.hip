@@ -19,12 +19,15 @@ static constexpr int GK = 16;        // K slab
 static constexpr int GLD = 80;       // LDS row stride in doubles (k-rows land 32 banks apart: conflict-free b64 reads)
 
 
+template <bool DOP>
 __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double* __restrict__ A, int lda,
                                                    const double* __restrict__ w, GramL2 g, double* __restrict__ P,
                                                    int ldp, long long p_stride, const int* __restrict__ active,
-                                                   int ntile, double* __restrict__ Ppk, long long ppk_stride, int nchp) {
+                                                   int ntile, double* __restrict__ Ppk, long long ppk_stride, int nchp,
+                                                   long long a_stride) {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
+    A += (size_t)b * a_stride;
     // decode lower-triangular tile index -> (ti >= tj)
     int t = blockIdx.x, ti = 0;
     while (t >= ti + 1) { t -= ti + 1; ++ti; }
@@ -124,11 +127,16 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
     // epilogue: + L2, store lower tile and its mirror.  With the swapped operands the accumulator of lane l, register
     // r is element (row = l&15, column = (l>>4) + 4r) of the sub-tile.
     double* Pb = P ? P + (size_t)b * p_stride : nullptr;   // row-major copy is optional (the resident QP kernel reads Ppk)
-    double fac[3] = {0, 0, 0};
+    double fac[3] = {0, 0, 0}, dfac2[3] = {0, 0, 0};
     if (g.s) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) fac[k] = g.dfac[k] * (g.use_rho ? g.rho[(size_t)b * 3 + k] : 1.0);
+        if (DOP) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dfac2[k] = g.dop_dfac[k] * (g.use_rho ? g.dop_rho[(size_t)b * 3 + k] : 1.0);
+        }
     }
+    const int dop_lo = DOP ? g.dop_start : 0, dop_hi = DOP ? g.dop_start + g.dop_size : 0;
     double* Pk = Ppk ? Ppk + (size_t)b * ppk_stride : nullptr;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -151,6 +159,7 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
                                 // addresses contiguous when the matrices are bitwise symmetric
                                 double mv = g.sym ? g.mk[k][(size_t)j * g.ldm + i] : g.mk[k][(size_t)i * g.ldm + j];
                                 if (i >= g.ns && j >= g.ns) mv *= fac[k];
+                                else if (DOP && i >= dop_lo && i < dop_hi && j >= dop_lo && j < dop_hi) mv *= dfac2[k];
                                 l2 += (sqI[k][i - i0] * mv) * sqJ[k][j - j0];
                             }
                         }
@@ -204,9 +213,11 @@ __global__ __launch_bounds__(64) void pack_p_kernel(int n, const double* __restr
 __global__ __launch_bounds__(256) void qvec_kernel(int m, int n, const double* __restrict__ A, int lda,
                                                    const double* __restrict__ w, const double* __restrict__ y,
                                                    const double* __restrict__ l1, double l1_scalar,
-                                                   double* __restrict__ q, const int* __restrict__ active) {
+                                                   double* __restrict__ q, const int* __restrict__ active,
+                                                   long long a_stride) {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
+    A += (size_t)b * a_stride;
     __shared__ double sw[256], swy[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const double* wb = w + (size_t)b * m;
@@ -257,17 +268,21 @@ void launch_pack_p(hipStream_t st, int B, int n, const double* P, int ldp, long 
 
 void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const GramL2& g,
                     double* P, int ldp, long long p_stride, const int* active, double* Ppk, long long ppk_stride,
-                    int nchp) {
+                    int nchp, long long a_stride) {
     const int nt = (n + GT - 1) / GT;
     const int ntile = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(gram_kernel, dim3(ntile, B), dim3(256), 0, st, m, n, A, lda, w, g, P, ldp, p_stride, active,
-                       ntile, Ppk, ppk_stride, nchp);
+    if (g.s && g.dop_size > 0)
+        hipLaunchKernelGGL(gram_kernel<true>, dim3(ntile, B), dim3(256), 0, st, m, n, A, lda, w, g, P, ldp, p_stride,
+                           active, ntile, Ppk, ppk_stride, nchp, a_stride);
+    else
+        hipLaunchKernelGGL(gram_kernel<false>, dim3(ntile, B), dim3(256), 0, st, m, n, A, lda, w, g, P, ldp, p_stride,
+                           active, ntile, Ppk, ppk_stride, nchp, a_stride);
 }
 
 void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,
-                 const double* l1, double l1_scalar, double* q, const int* active) {
+                 const double* l1, double l1_scalar, double* q, const int* active, long long a_stride) {
     hipLaunchKernelGGL(qvec_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, m, n, A, lda, w, y, l1, l1_scalar, q,
-                       active);
+                       active, a_stride);
 }
 
 void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w,

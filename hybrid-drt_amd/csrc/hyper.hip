@@ -123,6 +123,35 @@ __global__ __launch_bounds__(HT) void prep_kernel(FitState st) {
     }
 }
 
+// prepared plans: the data vector is already scaled; var floor of estimate_weights + state init.  grid = B
+__global__ __launch_bounds__(HT) void prep_prepared_kernel(FitState st) {
+    __shared__ double red[HNW];
+    const int b = blockIdx.x, tid = threadIdx.x, m = st.m, n = st.n;
+    const double* rv = st.rv + (size_t)b * m;
+    double s1 = 0.0;
+    for (int i = tid; i < m; i += HT) s1 += rv[i];
+    const double mean = blk_sum(s1, red) / (double)m;
+    double s2 = 0.0;
+    for (int i = tid; i < m; i += HT) { const double dv = rv[i] - mean; s2 += dv * dv; }
+    const double var = blk_sum(s2, red) / (double)m;
+    for (int i = tid; i < m; i += HT) st.w[(size_t)b * m + i] = 1.0;
+    for (int k = 0; k < 3; ++k)
+        for (int i = tid; i < n; i += HT) st.s[((size_t)b * 3 + k) * n + i] = st.opts.s_0[k];
+    for (int i = tid; i < n; i += HT) { st.x[(size_t)b * n + i] = 1e-6; st.x_in[(size_t)b * n + i] = 1e-6; }
+    if (tid == 0) {
+        st.coef_scale[b] = 1.0;
+        st.var_floor[b] = var * 1e-7;
+        for (int k = 0; k < 3; ++k) {
+            st.rho[(size_t)b * 3 + k] = st.opts.rho_0[k]; st.xmx[(size_t)b * 3 + k] = 1.0;
+            st.dop_rho[(size_t)b * 3 + k] = st.desc.dop_rho_0[k]; st.dop_xmx[(size_t)b * 3 + k] = 1.0;
+        }
+        st.active[b] = 1;
+        st.outer_iters[b] = 0;
+        st.fit_status[b] = 1;
+        st.qp_iters_total[b] = 0;
+    }
+}
+
 // y[i] = sum_j M[i][j] * v[j] for the rows owned by this wavefront; v in LDS; result to LDS out.  Four rows per
 // pass with 16-byte loads (the row loads of a pass are independent, so they are all in flight together).
 __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld, int nrow, int ncol,
@@ -187,7 +216,7 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* V,
     const int m = st.m, n = st.n, tid = threadIdx.x;
     const double* rv = st.rv + (size_t)b * m;
     const double op = st.opts.outlier_p;
-    rows_matvec(st.rm, st.ldrm, m, n, xs, tmp);        // rm @ x
+    rows_matvec(st.rm + (size_t)b * st.rm_stride, st.ldrm, m, n, xs, tmp);        // rm @ x
     __syncthreads();
     for (int i = tid; i < m; i += HT) {
         const double r = tmp[i] - rv[i];
@@ -322,14 +351,16 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
     }
     __syncthreads();
 
-    for (int k = 0; k < 3; ++k) {
-        if (!(st.opts.derivative_weights[k] > 0.0)) continue;
-        double* sk = st.s + ((size_t)b * 3 + k) * n + ns;
-        const double* Mk = st.mk[k] + (size_t)ns * st.ldm + ns;
-        const double* M1 = st.mk[1] + (size_t)ns * st.ldm + ns;
-        const double alpha = st.opts.s_alpha[k];
-        const double beta = (alpha - 1.0) / st.opts.s_0[k];
-        const double sig2 = 2.0 * st.opts.sigma_ds[k] * st.opts.sigma_ds[k];
+    // solve_s + solve_rho (qphb.py:320-356, 385-405) of one derivative order on one block of x: the DRT coefficients
+    // (with the G matrix for k = 0) or the x_dop block (qphb.py:822-933, no G matrix)
+    auto update_block = [&](const int k, const double* xd, const int nd, const int off, const bool tpl, const bool use_g,
+                            const double alpha, const double s0, const double sigma, const double ra, const double r0,
+                            double* rho_out, const double* xmx_in) {
+        double* sk = st.s + ((size_t)b * 3 + k) * n + off;
+        const double* Mk = st.mk[k] + (size_t)off * st.ldm + off;
+        const double* M1 = st.mk[1] + (size_t)off * st.ldm + off;
+        const double beta = (alpha - 1.0) / s0;
+        const double sig2 = 2.0 * sigma * sigma;
         for (int i = tid; i < nd; i += HT) sq[i] = sqrt(sk[i]);
         __syncthreads();
         // gamma = X M X + G/(2 sigma^2) + beta I ; gu = gamma @ diag(sqrt s), zero diagonal
@@ -349,7 +380,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
                 const double xi = xd[i];
                 const int jd = i & ~63;                        // the 64-column chunk that holds the diagonal
                 double s0 = 0.0;
-                if (k == 0) {
+                if (use_g) {
                     const double xhs = xh[i] / sig2;
                     for (int j0 = 0; j0 < nd; j0 += 64) {
                         const int j = j0 + lane;
@@ -391,7 +422,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             for (int j = lane; j < nd; j += 64) {
                 const double mij = row[j];
                 double g = (xi * mij) * xd[j];
-                if (k == 0) g += ((xhi * row1[j]) * xh[j]) / sig2;
+                if (use_g) g += ((xhi * row1[j]) * xh[j]) / sig2;
                 if (j == i) dg = g + beta;
                 else {
                     const double gu = g * sq[j];
@@ -430,11 +461,24 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         for (int i = tid; i < nd; i += HT) part += tmp[i] * tmp2[i];
         const double xsmsx = blk_sum(part, red);
         if (tid == 0) {
-            const double ra = st.opts.rho_alpha[k];
-            const double rb = ra / st.opts.rho_0[k];
-            st.rho[(size_t)b * 3 + k] = ra / (xsmsx / st.xmx[(size_t)b * 3 + k] + rb);
+            const double rb = ra / r0;
+            rho_out[k] = ra / (xsmsx / xmx_in[k] + rb);
         }
         __syncthreads();
+    };
+    for (int k = 0; k < 3; ++k) {
+        if (!(st.opts.derivative_weights[k] > 0.0)) continue;
+        update_block(k, xs + ns, n - ns, ns, st.toeplitz_m != 0, k == 0, st.opts.s_alpha[k], st.opts.s_0[k],
+                     st.opts.sigma_ds[k], st.opts.rho_alpha[k], st.opts.rho_0[k], st.rho + (size_t)b * 3,
+                     st.xmx + (size_t)b * 3);
+    }
+    if (st.prepared && st.desc.dop_size > 0) {
+        for (int k = 0; k < 3; ++k) {
+            if (!(st.desc.dop_derivative_weights[k] > 0.0)) continue;
+            update_block(k, xs + st.desc.dop_start, st.desc.dop_size, st.desc.dop_start, false, false,
+                         st.desc.dop_s_alpha[k], st.desc.dop_s_0[k], 1.0, st.desc.dop_rho_alpha[k],
+                         st.desc.dop_rho_0[k], st.dop_rho + (size_t)b * 3, st.dop_xmx + (size_t)b * 3);
+        }
     }
 
     if (it == 0 && !st.continue_mode) {   // xmx_norms frozen after the first iteration (drt1d.py:946-951)
@@ -448,6 +492,18 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             const double v = blk_sum(part, red);
             if (tid == 0) st.xmx[(size_t)b * 3 + k] = v;
             __syncthreads();
+        }
+        if (st.prepared && st.desc.dop_size > 0) {      // dop_xmx_norms (drt1d.py:953-960)
+            const int d0 = st.desc.dop_start, dn = st.desc.dop_size;
+            for (int k = 0; k < 3; ++k) {
+                rows_matvec(st.mk[k] + (size_t)d0 * st.ldm + d0, st.ldm, dn, dn, xs + d0, tmp2);
+                __syncthreads();
+                double part = 0.0;
+                for (int i = tid; i < dn; i += HT) part += xs[d0 + i] * tmp2[i];
+                const double v = blk_sum(part, red);
+                if (tid == 0) st.dop_xmx[(size_t)b * 3 + k] = v;
+                __syncthreads();
+            }
         }
     }
 
@@ -476,7 +532,24 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         for (int i = tid; i < n; i += HT) st.hist_x[(size_t)it * n + i] = xs[i];
         for (int i = tid; i < m; i += HT) st.hist_w[(size_t)it * m + i] = wg[i];
         if (tid < 3) st.hist_rho[(size_t)it * 3 + tid] = st.rho[(size_t)b * 3 + tid];
+        if (tid < 3 && st.prepared && st.desc.dop_size > 0)
+            st.hist_dop_rho[(size_t)it * 3 + tid] = st.dop_rho[(size_t)b * 3 + tid];
         if (tid == 0) { st.hist_qp[it + 1] = st.qp_iters[b]; st.hist_rows[0] = it + 1; }
+    }
+    if (st.prepared && st.desc.vz_index >= 0) {
+        // drt1d.py:973-979: the vz_offset column becomes the current prediction of the matrix without the baseline and
+        // offset columns (rzm_vz was copied while the offset column was still zero), impedance rows negated, times the
+        // strength vector.  The weights above were estimated with the previous column, as in iterate_qphb.
+        __syncthreads();
+        const int vz = st.desc.vz_index;
+        for (int i = tid; i < n; i += HT)
+            if (i == vz || (i >= st.desc.vb_start && i < st.desc.vb_start + st.desc.vb_size)) xs[i] = 0.0;
+        __syncthreads();
+        double* rmb = st.rm_rw + (size_t)b * st.rm_stride;
+        rows_matvec(rmb, st.ldrm, m, n, xs, tmp);
+        __syncthreads();
+        for (int i = tid; i < m; i += HT)
+            rmb[(size_t)i * st.ldrm + vz] = (i < st.desc.num_chrono ? tmp[i] : -tmp[i]) * st.vz_strength[i];
     }
     if (tid == 0) {
         st.outer_iters[b] = it + 1;
@@ -535,7 +608,8 @@ size_t hyper_lds_bytes(int n, int m, int ns) {
 }
 
 int launch_prep(hipStream_t s, const FitState& st, int B) {
-    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(HT), 0, s, st);
+    if (st.prepared) hipLaunchKernelGGL(prep_prepared_kernel, dim3(B), dim3(HT), 0, s, st);
+    else hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(HT), 0, s, st);
     return 0;
 }
 
@@ -568,7 +642,7 @@ __global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict
     const double* rv = st.rv + (size_t)b * m;
     for (int i = tid; i < n; i += HT) xs[i] = st.x[(size_t)b * n + i];
     __syncthreads();
-    rows_matvec(st.rm, st.ldrm, m, n, xs, yh);
+    rows_matvec(st.rm + (size_t)b * st.rm_stride, st.ldrm, m, n, xs, yh);
     __syncthreads();
     for (int i = tid; i < m; i += HT) { const double r = yh[i] - rv[i]; r2[i] = r * r; }
     __syncthreads();

@@ -247,6 +247,38 @@ int hipdrt_plan_set_state(hipdrt_plan* plan, const double* x, const double* rho,
  * Used by the candidate generators (drt1d.py:1497-1632) and PFRT (2558-2700).                                       */
 int hipdrt_plan_continue(hipdrt_plan* plan, const hipdrt_fit_opts* opts, double weight_factor, int min_iter);
 
+/* ---- prepared-matrix plans: the same device loop for any data type (config-5 family) -----------------------------
+ * DRT._qphb_fit_core (hybdrt/models/drt1d.py:551-1006) is data-type agnostic once _prep_for_fit / _format_qp_matrices
+ * (5439-5558, 5736-5963) have produced the stacked matrix rzm, the data vector rzv, the padded penalty matrices and the
+ * stacked variance-estimation matrix.  A prepared plan takes exactly those (built by the caller from the stand-alone
+ * builders above) and runs initialize_weights + the iterate_qphb loop on the device, including
+ *   - the x_dop hyper-parameter pass (hybdrt/models/qphb.py:822-933) and the DOP block of the L2 matrix (qphb.py:92-100),
+ *   - the per-iteration rewrite of the vz_offset column of a hybrid fit (drt1d.py:973-979).
+ * Weight factors are 1 (hybrid_weight_factor_method=None, drt1d.py:785-787).                                          */
+typedef struct {
+    int m, n, ns;              /* rows of rzm, unknowns, special (non-DRT) unknowns ahead of the DRT block            */
+    int dop_start, dop_size;   /* the x_dop block inside the specials (dop_size 0: none)                              */
+    int vz_index;              /* column of vz_offset (-1: none)                                                      */
+    int vb_start, vb_size;     /* v_baseline columns: excluded from the vz prediction (drt1d.py:507-511)              */
+    int num_chrono;            /* rows [0, num_chrono) are chrono samples, the rest [Re; Im] impedance rows           */
+    int toeplitz_m;            /* DRT block of the penalty matrices is symmetric Toeplitz (uniform ln tau)            */
+    double dop_l2_lambda_0;                                       /* qphb.py:243-253 */
+    double dop_derivative_weights[3], dop_s_alpha[3], dop_rho_alpha[3], dop_s_0[3], dop_rho_0[3];
+} hipdrt_prepared_desc;
+/* m0,m1,m2 [n][n] padded penalty matrices; vmm [m][m]; h [n] (make_h_constraint, qphb.py:521-557); l1 [n]
+ * (l1_lambda_vector, drt1d.py:552-556); vz_strength [m] (drt1d.py:514-519; NULL when vz_index < 0).
+ * opts: the fit options (scale_data / rp_scale / fit_ohmic / fit_inductance / eis_* are ignored: the caller prepared
+ * the data).                                                                                                         */
+int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* desc, const double* m0, const double* m1,
+                                const double* m2, const double* vmm, const double* h, const double* l1,
+                                const double* vz_strength, const hipdrt_fit_opts* opts, int capacity,
+                                hipdrt_plan** out);
+/* stage B measurements: rzm [B][m][n] (rm_batched != 0) or one shared [m][n]; rzv [B][m].  A vz_offset column needs
+ * per-measurement matrices.  Then hipdrt_plan_fit; results through hipdrt_plan_download (x, weights, rho, s_vectors,
+ * q_vector, iteration counts, status; pass NULL for fit_x / r_inf / induc), hipdrt_plan_get_p_matrix and
+ * hipdrt_plan_get ("dop_rho" [B][3], "xmx", "dop_xmx" [B][3], "est_weights", "rzm" [B or 1][m][n] = final matrix). */
+int hipdrt_plan_upload_prepared(hipdrt_plan* plan, int B, int rm_batched, const double* rzm, const double* rzv);
+
 /* kernel-time breakdown of the last hipdrt_plan_fit in ms (HIP events on the ctx stream):
  * t[0]=total, t[1]=gram, t[2]=qp, t[3]=hyper, t[4]=setup/other; launches[5] same order                 */
 int hipdrt_plan_timings(hipdrt_plan* plan, float* t, int* launches);

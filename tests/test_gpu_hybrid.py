@@ -1,0 +1,82 @@
+"""GPU: the config-5 family (distribution of phasances inside the loop, joint chrono + EIS fits) through the prepared-plan
+entry points of the C-ABI, against the reference-run fixtures and the oracle's general loop."""
+import numpy as np
+import pytest
+
+from oracle import drt_oracle as orc
+from hybrid_util import load_case, initial_rzm_and_vz
+
+pytestmark = pytest.mark.gpu
+
+
+def make_desc(ffi, g, special, rzm0, vz, hyp):
+    d = ffi.PreparedDesc()
+    d.m, d.n = rzm0.shape
+    d.ns = int(sum(v["size"] for v in special.values()))
+    d.dop_start, d.dop_size = (special["x_dop"]["index"], special["x_dop"]["size"]) if "x_dop" in special else (0, 0)
+    d.vz_index = vz["index"] if vz else -1
+    d.vb_start, d.vb_size = (vz["vb"][0], vz["vb"][1] - vz["vb"][0]) if vz else (0, 0)
+    d.num_chrono = vz["num_chrono"] if vz else 0
+    d.toeplitz_m = 0
+    if "x_dop" in special:
+        d.dop_l2_lambda_0 = hyp["dop_l2_lambda_0"]
+        for k in range(3):
+            d.dop_derivative_weights[k] = hyp["dop_derivative_weights"][k]
+            d.dop_s_alpha[k] = hyp["dop_s_alpha"][k]
+            d.dop_rho_alpha[k] = hyp["dop_rho_alpha"][k]
+            d.dop_s_0[k] = hyp["dop_s_0"][k]
+            d.dop_rho_0[k] = hyp["dop_rho_0"][k]
+    return d
+
+
+@pytest.mark.parametrize("name", ["golden71x91_dop", "hybrid_s0", "hybrid_s0_dop"])
+@pytest.mark.parametrize("batched", [False, True])
+def test_prepared_plan_reproduces_reference_trajectory(name, batched):
+    from hipdrt import _ffi as ffi
+    g, special = load_case(name)
+    hyp = orc.get_default_hypers()
+    if "x_dop" in special:
+        hyp.update(orc.get_default_dop_hypers())
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    if vz is not None and not batched:
+        pytest.skip("a vz_offset column needs per-measurement matrices")
+    ref = orc.qphb_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, vz=vz)
+    n = rzm0.shape[1]
+    h = orc.make_h_constraint(n, special, True)
+    ctx = ffi.get_context()
+    desc = make_desc(ffi, g, special, rzm0, vz, hyp)
+    B = 3 if batched else 1
+    plan = ffi.PreparedPlan(ctx, desc, [g["m0"], g["m1"], g["m2"]], g["vmm"], h, ref["l1_lambda_vector"],
+                            vz_strength=vz["strength"] if vz else None, capacity=B)
+    rzv = np.tile(g["rv"], (B, 1))
+    if batched:     # members 0 and 2 are the fixture's measurement, member 1 a scaled copy (different trajectory)
+        rzv[1] *= 0.5
+    plan.upload(np.tile(rzm0, (B, 1, 1)) if batched else rzm0, rzv)
+    b = B - 1
+    plan.record_history(b)
+    plan.fit()
+    out = plan.download(s_vectors=True)
+    hist = plan.history()
+    assert out["status"][b] == 0
+    assert hist["qp_iterations"].tolist() == g["qp_iterations"].tolist()
+    assert out["outer_iters"][b] == int(g["outer_iterations"])
+    np.testing.assert_allclose(hist["x"], g["hist_x"], rtol=1e-6, atol=2e-7)
+    np.testing.assert_allclose(hist["rho"], g["hist_rho"], rtol=1e-6)
+    np.testing.assert_allclose(out["weights"][b], g["weights"], rtol=1e-6)
+    np.testing.assert_allclose(out["s_vectors"][b], g["s_vectors"], rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(plan.get("xmx")[b], g["xmx_norms"], rtol=1e-6)
+    if "x_dop" in special:
+        np.testing.assert_allclose(hist["dop_rho"], g["hist_dop_rho"], rtol=1e-6)
+        np.testing.assert_allclose(plan.get("dop_xmx")[b], g["dop_xmx_norms"], rtol=1e-6)
+    pm = plan.p_matrix(b)
+    np.testing.assert_allclose(pm, g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    np.testing.assert_allclose(out["q_vector"][b], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
+    if vz is not None:
+        np.testing.assert_allclose(plan.get("rzm")[b], g["rm"], rtol=0, atol=1e-7)
+    if batched:
+        np.testing.assert_array_equal(out["x"][0], out["x"][2])           # identical inputs -> identical bits
+        assert not np.allclose(out["x"][1], out["x"][0])
+        # the scaled member against its own oracle run
+        r1 = orc.qphb_fit_prepared(rzm0, rzv[1], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, vz=vz)
+        assert out["outer_iters"][1] == len(r1["history"])
+        np.testing.assert_allclose(out["x"][1], r1["x"], rtol=1e-6, atol=2e-7)

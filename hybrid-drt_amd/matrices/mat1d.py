@@ -121,6 +121,27 @@ def construct_integrated_derivative_matrix(basis_grid, basis_type='gaussian', or
     return mats[order]
 
 
+def construct_ohmic_response_vector(times, step_model, step_times, step_sizes, tau_rise, input_signal, smooth,
+                                    op_mode='galv'):
+    """mat1d.construct_ohmic_response_vector (hybdrt/matrices/mat1d.py:398-420): the response of R_inf is the input
+    signal itself -- the ideal steps when ``smooth``, else the measured signal minus its pre-step mean."""
+    from .. import preprocessing as pp
+    if op_mode != 'galv':
+        raise ValueError('Ohmic response vector not implemented for potentiostatic mode')
+    times = np.asarray(times, dtype=float)
+    if smooth:
+        return pp.generate_model_signal(times, step_times, step_sizes, tau_rise, step_model)
+    input_signal = np.asarray(input_signal, dtype=float)
+    return input_signal - np.mean(input_signal[times < step_times[0]])
+
+
+def construct_inductance_response_vector(times, step_model, step_times, step_sizes, tau_rise, op_mode='galv'):
+    """mat1d.construct_inductance_response_vector (mat1d.py:377-395): zero for ideal steps."""
+    if step_model != 'ideal':
+        raise NotImplementedError("only the ideal step model is built")
+    return np.zeros(len(times))
+
+
 def construct_inductance_impedance_vector(frequencies):
     """mat1d.py:446-447."""
     return 1j * 2 * np.pi * frequencies

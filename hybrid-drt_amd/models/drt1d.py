@@ -13,6 +13,7 @@ from .. import _ffi, preprocessing as pp
 from ..matrices import mat1d
 from ..utils.array import is_uniform
 from . import qphb
+from .prepared import PreparedFitMixin
 
 _FIT_KW_DEFAULTS = dict(  # DRT._qphb_fit_core keyword defaults (drt1d.py:102-137) that the device loop honours
     nonneg=True, scale_data=True, ohmic_penalty=1e-6, inductance_penalty=1e-6, inductance_scale=1e-5,
@@ -20,16 +21,24 @@ _FIT_KW_DEFAULTS = dict(  # DRT._qphb_fit_core keyword defaults (drt1d.py:102-13
     iw_l1_lambda_0=1e-4, iw_l2_lambda_0=1e-4, eff_hp=True, weight_factor=1, xtol=1e-2, max_iter=50)
 
 
-class DRT:
+class DRT(PreparedFitMixin):
     def __init__(self, fixed_basis_tau=None, tau_supergrid=None, tau_basis_type='gaussian', tau_epsilon=None,
                  basis_tau_ppd=10, extend_basis_decades=1, interpolate_integrals=True, fit_dop=False,
                  fit_inductance=True, fit_ohmic=True, fit_capacitance=False, frequency_precision=10,
+                 fixed_basis_nu=None, nu_basis_type='gaussian', nu_epsilon=None, normalize_dop=True,
+                 step_model='ideal', chrono_mode='galv',
                  print_diagnostics=False, warn=True, device=0, context=None):
         """DRTBase.__init__ (hybdrt/models/drtbase.py:21-159): epsilon rule and the lookup tables."""
         if tau_basis_type != 'gaussian':
             raise NotImplementedError("only the default gaussian basis is on the hot path")
-        if fit_dop or fit_capacitance:
-            raise NotImplementedError("fit_dop / fit_capacitance are later scope rows (SURVEY.md 8)")
+        if fit_capacitance:
+            raise NotImplementedError("fit_capacitance is not built")
+        if nu_basis_type != 'gaussian' or not normalize_dop:
+            raise NotImplementedError("only the default gaussian, normalised distribution of phasances is built")
+        if step_model != 'ideal' or chrono_mode != 'galv':
+            raise NotImplementedError("only ideal galvanostatic steps are built")
+        self.basis_nu = None if fixed_basis_nu is None else np.asarray(fixed_basis_nu, dtype=float)
+        self.nu_epsilon = nu_epsilon
         if fixed_basis_tau is not None and tau_supergrid is not None:
             warnings.warn('If fixed_basis_tau is provided, tau_supergrid will be ignored')
         self.fixed_basis_tau = None if fixed_basis_tau is None else np.asarray(fixed_basis_tau, dtype=float)
@@ -37,7 +46,7 @@ class DRT:
         self.tau_basis_type = tau_basis_type
         self.tau_epsilon = tau_epsilon
         self.extend_basis_decades = extend_basis_decades
-        self.fit_inductance, self.fit_ohmic, self.fit_capacitance, self.fit_dop = fit_inductance, fit_ohmic, False, False
+        self.fit_inductance, self.fit_ohmic, self.fit_capacitance, self.fit_dop = fit_inductance, fit_ohmic, False, bool(fit_dop)
         self.frequency_precision = frequency_precision
         self.print_diagnostics, self.warn = print_diagnostics, warn
         self.device = device
@@ -113,7 +122,7 @@ class DRT:
 
     def _make_opts(self, fit_kw):
         kw = dict(_FIT_KW_DEFAULTS)
-        hypers = qphb.get_default_hypers(True, False, 'gaussian')
+        hypers = qphb.get_default_hypers(True, self.fit_dop, 'gaussian')
         for key, val in fit_kw.items():
             if key in kw:
                 kw[key] = val
@@ -157,6 +166,14 @@ class DRT:
         z = np.asarray(z, dtype=complex)
         if len(frequencies) != len(z):
             raise ValueError('Length of frequencies and z must be equal')    # utils/validation.check_eis_data
+        kw = dict(kw)
+        for old, new in (('error_structure', 'eis_error_structure'), ('vmm_epsilon', 'eis_vmm_epsilon'),
+                         ('vmm_reim_cor', 'eis_reim_cor')):     # fit_eis's own keyword names (drt1d.py:1215-1241)
+            if old in kw:
+                kw[new] = kw.pop(old)
+        if self.fit_dop:     # the x_dop block changes the matrix layout: prepared-matrix plan (models/prepared.py)
+            return self._store_single(*self._fit_prepared([(None, None, None, frequencies, z)], kw, history_of=0),
+                                      'qphb_eis')
         res = self._fit(frequencies, z[None, :], kw, history_of=0)
         b = 0
         fp = {'x': res['fit_x'][b], 'R_inf': res['R_inf'][b] if self.fit_ohmic else 0,

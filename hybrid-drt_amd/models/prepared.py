@@ -1,0 +1,399 @@
+"""Host orchestration of the fits that go through a prepared-matrix plan (config-5 family): ``DRT.fit_hybrid`` and any
+fit with the distribution of phasances (``fit_dop=True``).
+
+Mirrors the data-type agnostic part of hybdrt.models.DRT: ``_prep_for_fit`` (drt1d.py:5439-5558),
+``process_chrono_signals`` / ``scale_data`` (drtbase.py:285-514), ``_format_qp_matrices`` (drt1d.py:5736-5963), the
+set-up half of ``_qphb_fit_core`` (drt1d.py:365-636) and ``extract_qphb_parameters`` (6228-6289).  Every matrix is
+built by a device kernel (response / impedance / phasance / penalty / variance matrices); this module only lays the
+blocks side by side, applies the O(m) scalings the reference applies and hands them to ``_ffi.PreparedPlan``, which
+runs initialize_weights and the whole iterate_qphb loop on the GPU."""
+import warnings
+
+import numpy as np
+
+from .. import _ffi, preprocessing as pp
+from ..matrices import mat1d, phasance
+from ..utils.array import is_uniform
+from . import background, qphb
+
+_CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (drt1d.py:102-129)
+    step_times=None, step_sizes=None, offset_steps=True, step_offset_size=None, offset_baseline=True,
+    smooth_inf_response=True, v_baseline_penalty=1e-6, vz_offset=True, vz_offset_scale=1, vz_offset_eps=1,
+    chrono_error_structure='uniform', chrono_vmm_epsilon=4)
+
+_UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False, remove_extremes=False,
+                    remove_outliers=False, series_neg=False, solve_rp=False, update_scale=False,
+                    init_weights_separately=False, eis_weight_factor=None, chrono_weight_factor=None,
+                    hybrid_weight_factor_method=None, peak_locations=None, neg_allowed_tau_range=None,
+                    v_baseline_deg=0, v_baseline_sqrt=False)
+
+
+class PreparedFitMixin:
+    """Methods of DRT for chrono + EIS (+ DOP) fits."""
+
+    basis_nu = None
+    nu_epsilon = None
+    nu_basis_type = 'gaussian'
+    normalize_dop = True
+    step_model = 'ideal'
+    chrono_mode = 'galv'
+
+    # ---- drt1d.py:365-408 ---------------------------------------------------------------------------------------
+    def _general_special_params(self, has_chrono, has_eis, vz_offset):
+        sp = {}
+
+        def add(name, nonneg, size=1):
+            sp[name] = {'index': int(sum(v['size'] for v in sp.values())), 'nonneg': nonneg, 'size': size}
+        if has_chrono:
+            add('v_baseline', False, 1)
+        if vz_offset and has_chrono and has_eis:
+            add('vz_offset', False)
+        if self.fit_ohmic:
+            add('R_inf', True)
+        if self.fit_inductance:
+            add('inductance', True)
+        if self.fit_dop:
+            if self.basis_nu is None:
+                self.basis_nu = np.concatenate([np.linspace(-1, -0.4, 25), np.linspace(0.4, 1, 25)])
+            if self.nu_epsilon is None:
+                self.nu_epsilon = 1 / np.median(np.diff(np.sort(self.basis_nu)))
+            add('x_dop', True, len(self.basis_nu))
+        return sp
+
+    def _lookups(self, ctx):
+        """drtbase.py:138-156: impedance and response lookup tables of the instance's epsilon (device kernels)."""
+        key = float(self.tau_epsilon)
+        if getattr(self, '_lut_key', None) != key:
+            z_re, z_im = ctx.impedance_lookup(key, self._wt_re, self._wt_im)
+            td = np.logspace(-6, 2, 2000)
+            self._luts = dict(z=((np.log(self._wt_re), z_re), (np.log(self._wt_im), z_im)),
+                              response=(np.log(td), ctx.response_lookup(key, td)))
+            self._lut_key = key
+        return self._luts
+
+    def _vz_strength(self, sample_times, frequencies, step_times, vz_offset_eps):
+        """DRT._get_vz_strength_vec (drt1d.py:6173-6226): 1 where the two data sets overlap in time scale, Gaussian
+        decay in log time scale away from the overlap, 0 before the first step."""
+        rbf = lambda y, eps: np.exp(-(eps * y) ** 2)
+        deltas = pp.get_time_since_step(sample_times, step_times, prestep_value=-1)
+        chrono_tau_min = np.min(deltas[deltas > 0])
+        f_inv = 1 / (2 * np.pi * frequencies)
+        eis_tau_max = np.max(f_inv)
+        cs = np.ones(len(deltas))
+        far = deltas >= eis_tau_max
+        cs[far] = rbf(np.log(deltas[far] / eis_tau_max), vz_offset_eps)
+        cs[deltas == -1] = 0
+        es = np.ones(len(frequencies))
+        fast = f_inv <= chrono_tau_min
+        es[fast] = rbf(np.log(f_inv[fast] / chrono_tau_min), vz_offset_eps)
+        return cs, es
+
+    # ---- _prep_for_fit + _format_qp_matrices + the set-up half of _qphb_fit_core --------------------------------------
+    def _prepare_measurement(self, ctx, times, i_signal, v_signal, frequencies, z, kw, ckw, hypers):
+        has_chrono, has_eis = times is not None, frequencies is not None
+        integrate_mode = _ffi.MODE_INTERP if self.integrate_method == 'interp' else _ffi.MODE_TRAPZ
+        prep = {}
+        # process_chrono_signals (drtbase.py:285-373), no downsampling
+        if has_chrono:
+            times, i_signal, v_signal = (np.array(a, dtype=float) for a in (times, i_signal, v_signal))
+            if not (len(times) == len(i_signal) == len(v_signal)):
+                raise ValueError('times, i_signal, and v_signal must have same length')   # validation.check_chrono_data
+            step_times, step_sizes = ckw['step_times'], ckw['step_sizes']
+            if step_times is None:
+                step_times, step_sizes, _ = pp.process_input_signal(times, i_signal, self.step_model,
+                                                                    ckw['offset_steps'], ckw['step_offset_size'])
+            else:
+                step_times = np.asarray(step_times, dtype=float)
+                if step_sizes is None:
+                    step_sizes = pp.get_step_sizes(times, i_signal, step_times)
+            step_sizes = np.asarray(step_sizes, dtype=float)
+            if len(step_times) > 1:
+                gap = np.diff(step_times) > 1.1 * np.min(np.diff(times))
+                nonconsec = np.insert(step_times[1:][gap], 0, step_times[0])
+            else:
+                nonconsec = step_times
+            prep.update(sample_times=times, step_times=step_times, step_sizes=step_sizes, nonconsec_step_times=nonconsec)
+        else:
+            step_times = step_sizes = None
+        if has_eis:
+            frequencies = np.array(frequencies, dtype=float)
+            z = np.array(z, dtype=complex)
+            if len(frequencies) != len(z):
+                raise ValueError('Length of frequencies and z must be equal')
+
+        # basis grid and epsilon (drt1d.py:5471-5487)
+        if self.fixed_basis_tau is not None:
+            basis_tau = self.fixed_basis_tau
+        else:
+            basis_tau = pp.get_basis_tau(frequencies, times, step_times, tau_grid=self.tau_supergrid,
+                                         extend_decades=self.extend_basis_decades)
+        if self.tau_epsilon is None:
+            self.tau_epsilon = 1 / np.mean(np.diff(np.log(basis_tau)))
+        eps = float(self.tau_epsilon)
+        ntau = len(basis_tau)
+        luts = self._lookups(ctx) if integrate_mode == _ffi.MODE_INTERP else dict(z=None, response=None)
+        sp = self._general_special_params(has_chrono, has_eis, ckw['vz_offset'])
+        ns = int(sum(v['size'] for v in sp.values()))
+        n = ns + ntau
+        dop = (sp['x_dop']['index'], sp['x_dop']['index'] + sp['x_dop']['size']) if self.fit_dop else None
+
+        # scale_data (drtbase.py:439-514)
+        rp_est = pp.estimate_rp(times, step_times, step_sizes, v_signal, self.step_model, z) if kw['scale_data'] else 1.0
+        coefficient_scale = rp_est / hypers['rp_scale'] if kw['scale_data'] else 1.0
+        input_scale = response_scale = None
+        if has_chrono:
+            input_scale = np.max(np.abs(step_sizes)) if kw['scale_data'] else 1.0
+            response_scale = input_scale * rp_est / hypers['rp_scale'] if kw['scale_data'] else 1.0
+            v_scaled = v_signal / response_scale
+            response_baseline = np.median(v_scaled[times < step_times[0]])
+        impedance_scale = coefficient_scale
+
+        # DOP column scaling (drt1d.py:5767-5788)
+        if self.fit_dop:
+            dop_scale = phasance.phasor_scale_vector(self.basis_nu,
+                                                     self.tau_supergrid if self.tau_supergrid is not None else basis_tau)
+            dop_scale = dop_scale / (np.sqrt(np.pi) / self.nu_epsilon)        # basis.get_basis_func_area, gaussian
+        else:
+            dop_scale = None
+
+        # ---- matrices, each built on the device; blocks laid out as in _format_qp_matrices -------------------
+        blocks, rows = [], []
+        num_chrono = 0
+        if has_chrono:
+            num_chrono = len(times)
+            rm = np.zeros((num_chrono, n))
+            a, _ = ctx.response_matrix(times, basis_tau, step_times, step_sizes, eps, mode=integrate_mode,
+                                       lookup=luts['response'], layered=False)
+            rm[:, ns:] = a / input_scale
+            vb, vb_scale = background.get_baseline_matrix(times, 0, normalize=True)
+            rm[:, sp['v_baseline']['index']:sp['v_baseline']['index'] + 1] = vb
+            if 'inductance' in sp:
+                rm[:, sp['inductance']['index']] = (mat1d.construct_inductance_response_vector(
+                    times, self.step_model, step_times, step_sizes, None) / input_scale) * kw['inductance_scale']
+            if 'R_inf' in sp:
+                rm[:, sp['R_inf']['index']] = mat1d.construct_ohmic_response_vector(
+                    times, self.step_model, step_times, step_sizes, None, i_signal, ckw['smooth_inf_response']) / input_scale
+            if self.fit_dop:
+                rm_dop, _ = ctx.phasor_v_matrix(times, self.basis_nu, self.nu_epsilon, step_times, step_sizes)
+                rm[:, dop[0]:dop[1]] = (rm_dop / input_scale) * dop_scale
+            blocks.append(rm)
+            scaled_response_offset = -response_baseline if ckw['offset_baseline'] else 0.0
+            rows.append(v_scaled + scaled_response_offset)
+            prep.update(v_baseline_scale=vb_scale, scaled_response_offset=scaled_response_offset,
+                        response_matrix=a, inf_response=rm[:, sp['R_inf']['index']] * input_scale if 'R_inf' in sp else None)
+        if has_eis:
+            nf = len(frequencies)
+            tpl_a = mat1d.impedance_matrix_is_toeplitz(frequencies, basis_tau, self.frequency_precision)
+            a_re, a_im = ctx.impedance_matrix(frequencies, basis_tau, eps, mode=integrate_mode, toeplitz=tpl_a,
+                                              lookups=luts['z'])
+            zm = np.zeros((nf, n), dtype=complex)
+            if 'inductance' in sp:
+                zm[:, sp['inductance']['index']] = mat1d.construct_inductance_impedance_vector(frequencies) * kw['inductance_scale']
+            if 'R_inf' in sp:
+                zm[:, sp['R_inf']['index']] = 1
+            if self.fit_dop:
+                zm[:, dop[0]:dop[1]] = ctx.phasor_z_matrix(frequencies, self.basis_nu, self.nu_epsilon) * dop_scale
+            zm[:, ns:] = a_re + 1j * a_im
+            blocks.append(np.vstack([zm.real, zm.imag]))
+            z_scaled = z / impedance_scale
+            rows.append(np.concatenate([z_scaled.real, z_scaled.imag]))
+        rzm = np.vstack(blocks)
+        rzv = np.concatenate(rows)
+        m = len(rzv)
+
+        # penalty matrices (drt1d.py:5673-5734, 5863-5910)
+        ln_tau = np.log(basis_tau)
+        tpl_m = is_uniform(ln_tau)
+        m_drt = ctx.penalty_matrices(ln_tau, eps, tpl_m)
+        m_dop = ctx.penalty_matrices(self.basis_nu, self.nu_epsilon, is_uniform(self.basis_nu)) if self.fit_dop else None
+        pen = []
+        for k in range(3):
+            mk = np.zeros((n, n))
+            if 'v_baseline' in sp:
+                mk[sp['v_baseline']['index'], sp['v_baseline']['index']] = ckw['v_baseline_penalty']
+            if 'inductance' in sp:
+                mk[sp['inductance']['index'], sp['inductance']['index']] = kw['inductance_penalty']
+            if 'R_inf' in sp:
+                mk[sp['R_inf']['index'], sp['R_inf']['index']] = kw['ohmic_penalty']
+            if 'vz_offset' in sp:
+                mk[sp['vz_offset']['index'], sp['vz_offset']['index']] = 1 / ckw['vz_offset_scale']
+            if self.fit_dop:
+                mk[dop[0]:dop[1], dop[0]:dop[1]] = m_dop[k]
+            mk[ns:, ns:] = m_drt[k]
+            pen.append(mk)
+
+        # variance-estimation matrix (drt1d.py:614-636)
+        vmm = np.zeros((m, m))
+        if has_chrono:
+            vmm[:num_chrono, :num_chrono] = mat1d.construct_chrono_var_matrix(
+                times, prep['nonconsec_step_times'], ckw['chrono_vmm_epsilon'], ckw['chrono_error_structure'])
+        if has_eis:
+            vmm[num_chrono:, num_chrono:] = ctx.eis_var_matrix(frequencies, kw['eis_vmm_epsilon'], kw['eis_reim_cor'],
+                                                              kw['eis_error_structure'] == 'uniform')
+
+        # vz_offset strength (drt1d.py:500-522), l1 vector (552-556), h (qphb.py:521-557)
+        vz_strength = None
+        if 'vz_offset' in sp:
+            cs, es = self._vz_strength(times, frequencies, prep['nonconsec_step_times'], ckw['vz_offset_eps'])
+            vz_strength = np.concatenate([cs, np.tile(es, 2)])
+        l1 = np.zeros(n)
+        l1[ns:] = hypers['l1_lambda_0']
+        if self.fit_dop:
+            l1[dop[0]:dop[1]] = hypers['dop_l1_lambda_0']
+        h = qphb.make_h_constraint(None, n, sp, kw['nonneg'])
+
+        prep.update(rzm=rzm, rzv=rzv, pen=pen, vmm=vmm, special=sp, ns=ns, n=n, m=m, dop=dop, l1=l1, h=h,
+                    vz_strength=vz_strength, num_chrono=num_chrono, num_eis=len(frequencies) if has_eis else 0,
+                    basis_tau=basis_tau, toeplitz_m=tpl_m, coefficient_scale=coefficient_scale,
+                    impedance_scale=impedance_scale, input_signal_scale=input_scale, response_signal_scale=response_scale,
+                    dop_scale_vector=dop_scale, frequencies=frequencies)
+        return prep
+
+    def _prepared_desc(self, prep, hypers):
+        d = _ffi.PreparedDesc()
+        sp = prep['special']
+        d.m, d.n, d.ns = prep['m'], prep['n'], prep['ns']
+        d.dop_start, d.dop_size = (prep['dop'][0], prep['dop'][1] - prep['dop'][0]) if prep['dop'] else (0, 0)
+        d.vz_index = sp['vz_offset']['index'] if 'vz_offset' in sp else -1
+        d.vb_start, d.vb_size = (sp['v_baseline']['index'], sp['v_baseline']['size']) if 'v_baseline' in sp else (0, 0)
+        d.num_chrono = prep['num_chrono']
+        d.toeplitz_m = int(prep['toeplitz_m'])
+        if prep['dop']:
+            d.dop_l2_lambda_0 = float(hypers['dop_l2_lambda_0'])
+            for name in ('dop_derivative_weights', 'dop_s_alpha', 'dop_rho_alpha', 'dop_s_0', 'dop_rho_0'):
+                vals = np.broadcast_to(np.asarray(hypers[name], dtype=float), (3,))
+                for k in range(3):
+                    getattr(d, name)[k] = float(vals[k])
+        return d
+
+    def _split_kwargs(self, fit_kw):
+        """chrono / hybrid keywords of _qphb_fit_core that this build honours; the rest goes to DRT._make_opts"""
+        ckw = dict(_CHRONO_KW_DEFAULTS)
+        rest = {}
+        for key, val in fit_kw.items():
+            if key in ckw:
+                ckw[key] = val
+            elif key in _UNSUPPORTED:
+                if val != _UNSUPPORTED[key]:
+                    raise NotImplementedError(f"{key}={val!r} is not built (only the default {_UNSUPPORTED[key]!r})")
+            else:
+                rest[key] = val
+        if ckw['chrono_error_structure'] not in (None, 'uniform'):
+            raise ValueError(f"Invalid error_structure {ckw['chrono_error_structure']}")
+        return ckw, rest
+
+    def _fit_prepared(self, measurements, fit_kw, history_of=-1):
+        """measurements: list of (times, i_signal, v_signal, frequencies, z) of identical shapes (one protocol)."""
+        ckw, rest = self._split_kwargs(fit_kw)
+        opts, hypers, kw = self._make_opts(rest)
+        if opts.outlier_p > 0:
+            raise NotImplementedError("outlier_p is only built for plain EIS fits")
+        ctx = self._context if self._context is not None else _ffi.get_context(self.device)
+        preps = [self._prepare_measurement(ctx, *meas, kw, ckw, hypers) for meas in measurements]
+        p0 = preps[0]
+        for pr in preps[1:]:
+            if pr['rzm'].shape != p0['rzm'].shape or pr['special'] != p0['special']:
+                raise ValueError('all measurements of a batch must share one protocol (same m, n, special parameters)')
+        shared = all(pr is p0 or (np.array_equal(pr['rzm'], p0['rzm'])) for pr in preps) and 'vz_offset' not in p0['special']
+        for pr in preps[1:]:     # one plan = one set of shared penalty / variance matrices
+            if not (np.array_equal(pr['vmm'], p0['vmm']) and all(np.array_equal(a, b) for a, b in zip(pr['pen'], p0['pen']))):
+                raise ValueError('all measurements of a batch must share the basis grid and the sampling grids')
+        desc = self._prepared_desc(p0, hypers)
+        if self._plan is not None:
+            self._plan.close()
+            self._plan_key = None
+        plan = _ffi.PreparedPlan(ctx, desc, p0['pen'], p0['vmm'], p0['h'], p0['l1'], vz_strength=p0['vz_strength'],
+                                 opts=opts, capacity=len(preps))
+        self._plan = plan
+        plan.upload(p0['rzm'] if shared else np.stack([pr['rzm'] for pr in preps]), np.stack([pr['rzv'] for pr in preps]))
+        plan.record_history(history_of)
+        plan.fit()
+        out = plan.download(s_vectors=True)
+        self.basis_tau = p0['basis_tau']
+        self.special_qp_params = p0['special']
+        self.fit_kwargs = dict(hypers, **kw, **ckw)
+        return preps, out, hypers, kw, ckw
+
+    # ---- extract_qphb_parameters (drt1d.py:6228-6289) + the sigma vectors (1071-1081) -------------------------------
+    def _extract(self, prep, x, weights, kw, ckw):
+        sp, ns, nc = prep['special'], prep['ns'], prep['num_chrono']
+        cs = prep['coefficient_scale']
+        fp = {'x': x[ns:] * cs,
+              'R_inf': x[sp['R_inf']['index']] * cs if 'R_inf' in sp else 0}
+        if 'v_baseline' in sp:
+            a = sp['v_baseline']['index']
+            vbx = x[a:a + sp['v_baseline']['size']] * (1.0 / prep['v_baseline_scale'])
+            vbx[0] -= prep['scaled_response_offset']
+            fp['v_baseline'] = vbx * prep['response_signal_scale']
+        if 'vz_offset' in sp:
+            fp['vz_offset'] = x[sp['vz_offset']['index']]
+        fp['inductance'] = x[sp['inductance']['index']] * (cs * kw['inductance_scale']) if 'inductance' in sp else 0
+        fp['C_inv'] = 0
+        if prep['dop']:
+            fp['x_dop'] = x[prep['dop'][0]:prep['dop'][1]] * (prep['dop_scale_vector'] * cs)
+        sigma = 1.0 / weights
+        nf = prep['num_eis']
+        fp['v_sigma_tot'] = sigma[:nc] * prep['response_signal_scale'] if nc else None
+        fp['v_sigma_res'] = None
+        fp['z_sigma_tot'] = (sigma[nc:nc + nf] + 1j * sigma[nc + nf:]) * prep['impedance_scale'] if nf else None
+        fp['vz_offset_eps'] = ckw['vz_offset_eps']
+        return fp
+
+    def _store_single(self, preps, out, hypers, kw, ckw, fit_type):
+        b, prep, plan = 0, preps[0], self._plan
+        if out['status'][b] < 0:
+            raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+        if out['status'][b] == 1 and self.warn:
+            warnings.warn(f"Solution did not converge within {kw['max_iter']} iterations. This is usually not an issue.")
+        fp = self._extract(prep, out['x'][b], out['weights'][b], kw, ckw)
+        fp['p_matrix'] = plan.p_matrix(b)
+        fp['q_vector'] = out['q_vector'][b]
+        self.fit_parameters = fp
+        self.coefficient_scale = prep['coefficient_scale']
+        self.impedance_scale = prep['impedance_scale']
+        self.input_signal_scale, self.response_signal_scale = prep['input_signal_scale'], prep['response_signal_scale']
+        self.step_times, self.step_sizes = prep.get('step_times'), prep.get('step_sizes')
+        self.dop_scale_vector = prep['dop_scale_vector']
+        hist = plan.history()
+        self.qphb_history = [dict(x=hist['x'][i], rho_vector=hist['rho'][i], weights=hist['weights'][i],
+                                  dop_rho_vector=hist['dop_rho'][i] if 'dop_rho' in hist else None)
+                             for i in range(len(hist['x']))]
+        rzm_final = plan.get('rzm')
+        self.qphb_params = {'weights': out['weights'][b], 'true_weights': out['weights'][b], 'rho_vector': out['rho'][b],
+                            'dop_rho_vector': plan.get('dop_rho')[b] if prep['dop'] else None,
+                            's_vectors': list(out['s_vectors'][b]), 'p_matrix': fp['p_matrix'], 'q_vector': fp['q_vector'],
+                            'rm': rzm_final[b] if rzm_final.ndim == 3 else rzm_final, 'rv': prep['rzv'], 'vmm': prep['vmm'],
+                            'penalty_matrices': {f'm{k}': prep['pen'][k] for k in range(3)},
+                            'l1_lambda_vector': prep['l1'], 'num_eis': prep['num_eis'], 'num_chrono': prep['num_chrono'],
+                            'vz_strength_vec': prep['vz_strength'] if prep['vz_strength'] is not None else 1,
+                            'xmx_norms': plan.get('xmx')[b], 'est_weights': plan.get('est_weights')[b],
+                            'qp_iterations': hist['qp_iterations'], 'outer_iterations': int(out['outer_iters'][b]),
+                            'hypers': hypers}
+        self.cvx_result = {'x': out['x'][b]}
+        self.fit_type = fit_type
+        self._prep = prep
+        return fp
+
+    # ---- public fits --------------------------------------------------------------------------------------------------
+    def fit_hybrid(self, times, i_signal, v_signal, frequencies, z, **kw):
+        """DRT.fit_hybrid (drt1d.py:1244-1268): joint fit of one chrono measurement and one impedance spectrum."""
+        res = self._fit_prepared([(times, i_signal, v_signal, frequencies, z)], kw, history_of=0)
+        return self._store_single(*res, 'qphb_hybrid')
+
+    def fit_chrono(self, times, i_signal, v_signal, error_structure='uniform', vmm_epsilon=4, **kw):
+        """DRT.fit_chrono (drt1d.py:1195-1213)."""
+        res = self._fit_prepared([(times, i_signal, v_signal, None, None)],
+                                 dict(kw, chrono_error_structure=error_structure, chrono_vmm_epsilon=vmm_epsilon),
+                                 history_of=0)
+        return self._store_single(*res, 'qphb_chrono')
+
+    def fit_hybrid_batch(self, times, i_batch, v_batch, frequencies, z_batch, **kw):
+        """B joint measurements of one protocol (same sample times / frequencies), fitted concurrently: the hybrid
+        counterpart of fit_eis_batch.  Returns a dict of arrays (x in data units, per-measurement specials)."""
+        meas = [(times, i_batch[b], v_batch[b], frequencies, z_batch[b]) for b in range(len(z_batch))]
+        preps, out, hypers, fkw, ckw = self._fit_prepared(meas, kw)
+        fps = [self._extract(pr, out['x'][b], out['weights'][b], fkw, ckw) for b, pr in enumerate(preps)]
+        res = {key: np.array([fp[key] for fp in fps]) for key in fps[0] if fps[0][key] is not None and key != 'vz_offset_eps'}
+        res.update(x_scaled=out['x'], outer_iters=out['outer_iters'], status=out['status'],
+                   qp_iters_total=out['qp_iters_total'], rho=out['rho'], weights=out['weights'])
+        return res

@@ -10,17 +10,20 @@ from .. import _ffi
 
 def get_default_hypers(eff_hp=True, fit_dop=False, nu_basis_type='gaussian'):
     """qphb.get_default_hypers (hybdrt/models/qphb.py:208-255)."""
-    if fit_dop:
-        raise NotImplementedError("DOP terms are a later scope row (SURVEY.md 8, C5)")
     if eff_hp:
         s_alpha = np.array([5, 10, 25])
         rho_alpha = np.array([0.15, 0.2, 0.25])
     else:
         s_alpha = np.array([1.05, 1.15, 2.5])
         rho_alpha = np.array([0.05, 0.1, 0.05])
-    return dict(rp_scale=14, derivative_weights=np.array([1.5, 1.0, 0.5]), sigma_ds=np.array([1, 1000, 1000]),
-                l1_lambda_0=0, l2_lambda_0=142, iw_alpha=None, iw_beta=None, s_alpha=s_alpha, s_0=np.ones(3),
-                rho_alpha=rho_alpha, rho_0=np.ones(3), outlier_p=None)
+    hypers = dict(rp_scale=14, derivative_weights=np.array([1.5, 1.0, 0.5]), sigma_ds=np.array([1, 1000, 1000]),
+                  l1_lambda_0=0, l2_lambda_0=142, iw_alpha=None, iw_beta=None, s_alpha=s_alpha, s_0=np.ones(3),
+                  rho_alpha=rho_alpha, rho_0=np.ones(3), outlier_p=None)
+    if fit_dop:      # qphb.py:243-253
+        hypers.update(dop_l2_lambda_0=10, dop_l1_lambda_0=0, dop_derivative_weights=np.array([0.5, 1.0, 0.5]),
+                      dop_s_alpha=np.array([5, 10, 25]), dop_rho_alpha=np.array([0.15, 0.2, 0.25]),
+                      dop_s_0=np.ones(3), dop_rho_0=np.ones(3), dop_sigma_ds=np.array([1, 1000, 1000]))
+    return hypers
 
 
 def get_num_special(special_qp_params):

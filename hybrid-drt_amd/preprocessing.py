@@ -1,12 +1,98 @@
-"""Host-side grid / scale rules of hybdrt/preprocessing.py that sit on the EIS fit path."""
+"""Host-side grid / scale / step-detection rules of hybdrt/preprocessing.py that sit on the fit paths (O(samples)
+numpy bookkeeping that decides grids and scales; the matrices and the optimisation run on the device)."""
 import numpy as np
 
 
+# ---- chrono signals: step detection (preprocessing.py:17-158), ideal step model ---------------------------------
+def identify_steps(y, allow_consecutive=True, rthresh=50, athresh=1e-10):
+    """preprocessing.identify_steps (17-37): indices where |diff| exceeds rthresh x its median (and athresh)."""
+    dy = np.abs(np.diff(y))
+    step_idx = np.where((dy >= np.median(dy) * rthresh) & (dy >= athresh))[0] + 1
+    if not allow_consecutive:
+        gap = np.concatenate(([2], np.diff(step_idx)))
+        step_idx = step_idx[gap > 1]
+    return step_idx
+
+
+def get_step_indices_from_step_times(times, step_times):
+    """preprocessing.py:161-178: first sample at or after each step time."""
+    times = np.asarray(times)
+    out = []
+    for st in step_times:
+        delta = np.where(times >= st, times - st, np.inf)
+        out.append(int(np.argmin(delta)))
+    return np.array(out, dtype=int)
+
+
+def get_step_sizes(times, y, step_times, step_index=None):
+    """preprocessing.get_step_sizes (109-133): mean level after minus mean level before every step."""
+    if step_index is None:
+        step_index = get_step_indices_from_step_times(times, step_times)
+    n_steps = len(step_times)
+    sizes = np.zeros(n_steps)
+    for k in range(n_steps):
+        end = len(y) if k == n_steps - 1 else step_index[k + 1]
+        start = 0 if k == 0 else step_index[k - 1]
+        sizes[k] = np.mean(y[step_index[k]:end]) - np.mean(y[start:step_index[k]])
+    return sizes
+
+
+def get_step_info(times, y, allow_consecutive=True, offset_step_times=False, offset_size=None, rthresh=50,
+                  athresh=1e-10):
+    """preprocessing.get_step_info (59-106): the observed step is assumed to have happened one (minimum) sample period
+    earlier, less a hair so that it never coincides with the previous sample."""
+    step_idx = identify_steps(y, allow_consecutive, rthresh, athresh)
+    step_times = np.array(times)[step_idx].copy()
+    if offset_step_times:
+        if offset_size is None:
+            offset_size = -np.min(np.diff(times)) * (1 - 1e-8)
+        step_times += offset_size
+    return step_times, get_step_sizes(times, y, step_times, step_index=step_idx)
+
+
+def process_input_signal(times, input_signal, step_model, offset_steps, offset_size=None, rthresh=50):
+    """preprocessing.process_input_signal (136-158) for step_model='ideal'."""
+    if step_model != 'ideal':
+        raise NotImplementedError("only the ideal step model is built (expdecay fits the input signal on the host)")
+    step_times, step_sizes = get_step_info(times, input_signal, True, offset_steps, offset_size, rthresh)
+    return step_times, step_sizes, None
+
+
+def generate_model_signal(times, step_times, step_sizes, tau_rise=None, step_model='ideal'):
+    """preprocessing.generate_model_signal (181-207), ideal steps: sum of step_size * unit_step(t - step_time)."""
+    if step_model != 'ideal':
+        raise NotImplementedError("only the ideal step model is built")
+    signal = np.zeros(len(times))
+    for st, sa in zip(step_times, step_sizes):
+        signal += sa * (np.asarray(times) >= st)
+    return signal
+
+
+def get_time_since_step(times, step_times, prestep_value=None):
+    """preprocessing.get_time_since_step (918-950): time since the last step, floored at the sample period; samples
+    before the first step are dropped unless prestep_value is given."""
+    times = np.asarray(times)
+    t_sample = np.min(np.diff(times)) if len(times) > 1 else times[0]
+    parts = []
+    if prestep_value is not None:
+        parts.append(np.tile(prestep_value, int(np.sum(times < step_times[0]))))
+    for i, start in enumerate(step_times):
+        end = np.inf if i == len(step_times) - 1 else step_times[i + 1]
+        sel = (times >= start) & (times < end)
+        if np.any(sel):
+            parts.append(np.maximum(times[sel] - start, t_sample))
+    return np.concatenate(parts)
+
+
 def get_tau_lim(frequencies, times=None, step_times=None):
-    """preprocessing.py:953-972 (EIS branch; chrono data is a later scope row)."""
+    """preprocessing.get_tau_lim (953-972)."""
+    tau_min, tau_max = np.inf, -np.inf
+    if frequencies is not None:
+        tau_min, tau_max = 1 / (2 * np.pi * np.max(frequencies)), 1 / (2 * np.pi * np.min(frequencies))
     if times is not None:
-        raise NotImplementedError("chrono/hybrid data are not in this build's scope yet (SURVEY.md 8, C5)")
-    return 1 / (2 * np.pi * np.max(frequencies)), 1 / (2 * np.pi * np.min(frequencies))
+        deltas = get_time_since_step(times, step_times)
+        tau_min, tau_max = min(tau_min, np.min(deltas)), max(tau_max, np.max(deltas))
+    return tau_min, tau_max
 
 
 def get_num_decades(frequencies, times=None, step_times=None):
@@ -53,7 +139,30 @@ def get_epsilon_from_ppd(ppd, factor=1):
 
 
 def estimate_rp(times, step_times, input_step_sizes, response_signal, step_model, z):
-    """preprocessing.py:764-841, EIS branch: span of the real part."""
+    """preprocessing.estimate_rp (764-841): span between the smallest and largest apparent resistance seen by either
+    data set (per-step (v - v_before) / step size for chrono data, the real part for EIS)."""
+    r_min, r_max = np.inf, 0.0
     if times is not None:
-        raise NotImplementedError("chrono/hybrid data are not in this build's scope yet")
-    return np.max(z.real) - np.min(z.real)
+        times = np.asarray(times)
+        step_times = np.asarray(step_times, dtype=float)
+        input_step_sizes = np.asarray(input_step_sizes, dtype=float)
+        if step_model == 'ideal':
+            # consecutive "steps" less than 20 us apart are one real step (finite rise time)
+            first = np.concatenate(([0], np.where(np.diff(step_times) > 2e-5)[0] + 1))
+            if len(first) < len(step_times):
+                bounds = list(first) + [len(input_step_sizes)]
+                input_step_sizes = np.array([np.sum(input_step_sizes[a:b]) for a, b in zip(bounds[:-1], bounds[1:])])
+                step_times = step_times[first]
+        step_index = [int(np.argmin(np.where(times >= st, times - st, np.inf))) for st in step_times]
+        lo = np.full(len(step_index), np.nan)
+        hi = np.full(len(step_index), np.nan)
+        for i, a in enumerate(step_index):
+            b = len(times) if i == len(step_index) - 1 else step_index[i + 1]
+            if a == b:
+                continue          # truncated step
+            r = (response_signal[a:b] - response_signal[a - 1]) / input_step_sizes[i]
+            lo[i], hi[i] = np.min(r), np.max(r)
+        r_min, r_max = np.nanmean(lo), np.nanpercentile(hi, 99)
+    if z is not None:
+        r_min, r_max = min(r_min, np.min(z.real)), max(r_max, np.max(z.real))
+    return r_max - r_min

@@ -80,3 +80,88 @@ def test_prepared_plan_reproduces_reference_trajectory(name, batched):
         r1 = orc.qphb_fit_prepared(rzm0, rzv[1], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, vz=vz)
         assert out["outer_iters"][1] == len(r1["history"])
         np.testing.assert_allclose(out["x"][1], r1["x"], rtol=1e-6, atol=2e-7)
+
+
+def _check_fit(drt, g, special, dop):
+    fp, qp = drt.fit_parameters, drt.qphb_params
+    assert drt.special_qp_params == special
+    assert qp["qp_iterations"].tolist() == g["qp_iterations"].tolist()
+    assert qp["outer_iterations"] == int(g["outer_iterations"])
+    # matrices the host layer composed from the device builders
+    rzm0 = g["rm"].copy()
+    mine = qp["rm"].copy()
+    if "vz_offset" in special:
+        np.testing.assert_allclose(mine[:, special["vz_offset"]["index"]], g["rm"][:, special["vz_offset"]["index"]],
+                                   rtol=0, atol=1e-7)
+        mine[:, special["vz_offset"]["index"]] = 0
+        rzm0[:, special["vz_offset"]["index"]] = 0
+    np.testing.assert_allclose(mine, rzm0, rtol=1e-9, atol=1e-11 * np.abs(rzm0).max())
+    np.testing.assert_allclose(qp["rv"], g["rv"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(qp["vmm"], g["vmm"], rtol=1e-12, atol=1e-15)
+    for k in range(3):
+        ref = g[f"m{k}"]
+        np.testing.assert_allclose(qp["penalty_matrices"][f"m{k}"], ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
+    np.testing.assert_allclose(qp["l1_lambda_vector"], g["l1_lambda_vector"])
+    # results, reference's own criterion (tests/test_drt_fit.py: np.allclose) and tighter on the coefficients
+    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(drt.cvx_result["x"], g["x_scaled"], rtol=1e-6, atol=2e-7)
+    np.testing.assert_allclose(fp["R_inf"], g["R_inf"], rtol=1e-6)
+    np.testing.assert_allclose(fp["inductance"], g["inductance"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
+    np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
+    np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    np.testing.assert_allclose(qp["rho_vector"], g["rho_vector"], rtol=1e-6)
+    if dop:
+        np.testing.assert_allclose(fp["x_dop"], g["x_dop"], rtol=1e-5, atol=1e-8 * np.abs(g["x_dop"]).max())
+        np.testing.assert_allclose(qp["dop_rho_vector"], g["dop_rho_vector"], rtol=1e-6)
+        np.testing.assert_allclose(drt.dop_scale_vector, g["dop_scale_vector"], rtol=1e-13)
+
+
+def test_fit_eis_with_dop_matches_reference_run():
+    """DRT(fit_dop=True).fit_eis on the reference test's own spectrum (drt1d.py:1215-1241 with the x_dop block)."""
+    from hipdrt.models import DRT
+    g, special = load_case("golden71x91_dop")
+    drt = DRT(fit_dop=True)
+    drt.fit_eis(g["freq"], g["z"])
+    np.testing.assert_allclose(drt.basis_tau, g["basis_tau"], rtol=1e-13)
+    _check_fit(drt, g, special, True)
+    assert drt.fit_type == "qphb_eis"
+
+
+@pytest.mark.parametrize("dop", [False, True])
+def test_fit_hybrid_matches_reference_run(dop):
+    """DRT.fit_hybrid (drt1d.py:1244-1268) end to end: step detection, scaling, device-built response / impedance /
+    phasance / penalty / variance matrices, the device loop with the vz_offset column rewrite, parameter extraction."""
+    from hipdrt.models import DRT
+    g, special = load_case("hybrid_s0_dop" if dop else "hybrid_s0")
+    drt = DRT(fit_dop=dop)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"])
+    np.testing.assert_allclose(drt.basis_tau, g["basis_tau"], rtol=1e-13)
+    np.testing.assert_array_equal(drt.step_times, g["step_times"])
+    np.testing.assert_allclose(drt.response_signal_scale, g["response_signal_scale"], rtol=1e-14)
+    _check_fit(drt, g, special, dop)
+    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
+    np.testing.assert_allclose(fp["vz_offset"], g["vz_offset"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(fp["v_sigma_tot"], g["v_sigma_tot"], rtol=1e-6)
+    assert drt.fit_type == "qphb_hybrid"
+    with pytest.raises(NotImplementedError):
+        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], downsample=True)
+    with pytest.raises(ValueError):
+        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], not_a_keyword=1)
+
+
+def test_fit_hybrid_batch_members_match_single_fits():
+    """four jittered cells measured with one protocol, fitted concurrently: each member equals its own single fit"""
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    meas = [synth.hybrid_measurement(seed=s) for s in range(4)]
+    times, freq = meas[0][0], meas[0][3]
+    drt = DRT()
+    res = drt.fit_hybrid_batch(times, [m_[1] for m_ in meas], [m_[2] for m_ in meas], freq, [m_[4] for m_ in meas])
+    assert res["x"].shape[0] == 4 and np.all(res["status"] == 0)
+    for b in (0, 3):
+        single = DRT()
+        fp = single.fit_hybrid(*meas[b])
+        np.testing.assert_array_equal(res["x"][b], fp["x"])
+        np.testing.assert_array_equal(res["vz_offset"][b], fp["vz_offset"])
+        assert res["outer_iters"][b] == single.qphb_params["outer_iterations"]

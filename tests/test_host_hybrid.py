@@ -1,0 +1,75 @@
+"""CPU: host logic of the chrono / hybrid fits (step detection, scaling, grids, vz_offset strength, DOP column scaling)
+against the values the reference produced on the same measurement (tests/golden/refrun_hybrid_s0*.npz)."""
+import numpy as np
+import pytest
+
+from hybrid_util import load_case
+
+
+@pytest.fixture(scope="module")
+def case():
+    return load_case("hybrid_s0_dop")
+
+
+def test_synthetic_measurement_is_reproducible(case):
+    from hipdrt import synth
+    g, _ = case
+    times, i_sig, v_sig, freq, z = synth.hybrid_measurement(seed=0)
+    np.testing.assert_array_equal(times, g["times"])
+    np.testing.assert_array_equal(i_sig, g["i_signal"])
+    np.testing.assert_array_equal(v_sig, g["v_signal"])
+    np.testing.assert_array_equal(z, g["z"])
+
+
+def test_step_detection_and_scaling(case):
+    from hipdrt import preprocessing as pp
+    g, _ = case
+    st, sa, tr = pp.process_input_signal(g["times"], g["i_signal"], 'ideal', True)
+    assert tr is None
+    np.testing.assert_array_equal(st, g["step_times"])
+    np.testing.assert_array_equal(sa, g["step_sizes"])
+    rp = pp.estimate_rp(g["times"], st, sa, g["v_signal"], 'ideal', g["z"])
+    np.testing.assert_allclose(rp / 14, g["coefficient_scale"], rtol=1e-14)
+    np.testing.assert_allclose(np.max(np.abs(sa)) * rp / 14, g["response_signal_scale"], rtol=1e-14)
+    np.testing.assert_allclose(pp.get_basis_tau(g["freq"], g["times"], st), g["basis_tau"], rtol=1e-13)
+    # step sizes from given step times, consecutive-step condensation in estimate_rp
+    np.testing.assert_allclose(pp.get_step_sizes(g["times"], g["i_signal"], st), sa)
+    two = np.array([st[0], st[0] + 1e-5])
+    assert np.isfinite(pp.estimate_rp(g["times"], two, np.array([sa[0] / 2, sa[0] / 2]), g["v_signal"], 'ideal', None))
+
+
+def test_time_since_step_and_model_signal(case):
+    from hipdrt import preprocessing as pp
+    g, _ = case
+    t = g["times"]
+    d = pp.get_time_since_step(t, g["step_times"], prestep_value=-1)
+    assert len(d) == len(t) and np.all(d[t < g["step_times"][0]] == -1)
+    assert np.min(d[d > 0]) >= np.min(np.diff(t))
+    sig = pp.generate_model_signal(t, g["step_times"], g["step_sizes"])
+    np.testing.assert_allclose(sig * 1.0 / g["input_signal_scale"], g["inf_response"] / g["input_signal_scale"])
+
+
+def test_vz_strength_and_dop_scale(case):
+    from hipdrt.models import DRT
+    from hipdrt.matrices import phasance
+    g, _ = case
+    drt = DRT.__new__(DRT)
+    cs, es = drt._vz_strength(g["times"], g["freq"], g["nonconsec_step_times"], 1)
+    np.testing.assert_allclose(np.concatenate([cs, np.tile(es, 2)]), g["vz_strength_vec"], rtol=1e-13)
+    sv = phasance.phasor_scale_vector(g["basis_nu"], g["basis_tau"]) / (np.sqrt(np.pi) / g["nu_epsilon"])
+    np.testing.assert_allclose(sv, g["dop_scale_vector"], rtol=1e-13)
+
+
+def test_special_parameter_layout(case):
+    from hipdrt.models import DRT
+    g, special = case
+    drt = DRT.__new__(DRT)
+    drt.fit_ohmic = drt.fit_inductance = drt.fit_dop = True
+    drt.basis_nu = None
+    drt.nu_epsilon = None
+    sp = drt._general_special_params(True, True, True)
+    assert sp == special
+    np.testing.assert_allclose(drt.nu_epsilon, g["nu_epsilon"])
+    np.testing.assert_allclose(drt.basis_nu, g["basis_nu"])
+    drt.fit_dop = False
+    assert list(drt._general_special_params(False, True, True)) == ["R_inf", "inductance"]

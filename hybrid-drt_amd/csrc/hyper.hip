@@ -270,7 +270,7 @@ __global__ __launch_bounds__(HT) void init_weights_kernel(FitState st, int stage
     double* xs = sm;
     double* tmp = xs + n;
     double* tmp2 = tmp + m;
-    double* tmp3 = tmp2 + m;
+    double* tmp3 = tmp2 + m;      // [2][m] present only when outlier_p is set
     double* tmp4 = tmp3 + m;
     if (st.qp_status[b] < 0) {
         if (tid == 0) { st.active[b] = 0; st.fit_status[b] = -1; }
@@ -606,6 +606,7 @@ size_t hyper_lds_bytes(int n, int m, int ns) {
     const int tl = m > nd ? m : nd;
     return ((size_t)n + 4 * (size_t)nd + 2 * (size_t)tl + 3 * (size_t)(2 * nd - 1)) * sizeof(double);
 }
+static constexpr size_t kLdsLimit = 160 * 1024 - 256;     // per-workgroup LDS of a gfx950 CU, less the static part
 
 int launch_prep(hipStream_t s, const FitState& st, int B) {
     if (st.prepared) hipLaunchKernelGGL(prep_prepared_kernel, dim3(B), dim3(HT), 0, s, st);
@@ -621,7 +622,9 @@ static int set_lds(const void* f, size_t bytes) {
 }
 
 int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage) {
-    const size_t lds = ((size_t)st.n + 4 * (size_t)st.m) * sizeof(double);
+    // x + two row vectors, two more only for the outlier branch
+    const size_t lds = ((size_t)st.n + (st.opts.outlier_p > 0.0 ? 4 : 2) * (size_t)st.m) * sizeof(double);
+    if (lds > kLdsLimit) { set_error("initialize_weights: m too large for the LDS-resident kernel"); return HIPDRT_E_INVALID; }
     if (int rc = set_lds(reinterpret_cast<const void*>(init_weights_kernel), lds)) return rc;
     hipLaunchKernelGGL(init_weights_kernel, dim3(B), dim3(HT), lds, s, st, stage);
     if (stage == 1) hipLaunchKernelGGL(record_init_qp_kernel, dim3(1), dim3(64), 0, s, st);
@@ -680,8 +683,17 @@ void launch_scale_weights(hipStream_t s, const FitState& st, int B, double facto
     hipLaunchKernelGGL(scale_weights_kernel, dim3((st.m + 255) / 256, B), dim3(256), 0, s, st, factor);
 }
 
-int launch_hyper(hipStream_t s, const FitState& st, int B, int it) {
-    const size_t lds = hyper_lds_bytes(st.n, st.m, st.ns) + (st.opts.outlier_p > 0.0 ? 2 * (size_t)st.m * sizeof(double) : 0);
+int launch_hyper(hipStream_t s, const FitState& st_in, int B, int it) {
+    FitState st = st_in;
+    const size_t extra = st.opts.outlier_p > 0.0 ? 2 * (size_t)st.m * sizeof(double) : 0;
+    size_t lds = hyper_lds_bytes(st.n, st.m, st.ns) + extra;
+    if (lds > kLdsLimit && st.toeplitz_m && extra == 0) {
+        // large joint fits (config 5: m = 5120, n = 1078): no room for the mirrored Toeplitz columns next to the
+        // m-vectors; the general row-streaming form of the same updates reads the penalty blocks from L2 instead
+        st.toeplitz_m = 0;
+        lds -= 3 * (size_t)(2 * (st.n - st.ns) - 1) * sizeof(double);
+    }
+    if (lds > kLdsLimit) { set_error("hyper-parameter kernel: problem too large for LDS (m, n)"); return HIPDRT_E_INVALID; }
     if (int rc = set_lds(reinterpret_cast<const void*>(hyper_kernel), lds)) return rc;
     hipLaunchKernelGGL(hyper_kernel, dim3(B), dim3(HT), lds, s, st, it);
     return 0;

@@ -1,0 +1,148 @@
+"""Drop-in for hybdrt/mapping/resolve.py: coherent re-optimisation of neighbouring observations.
+
+The single fits' P matrices sit on the block diagonal of one large QP; a second-derivative Gaussian filter across the
+observation index couples equal coefficients of neighbouring observations.  The assembly is O((nr nc)^2) bookkeeping on
+the host exactly as in the reference; the QP itself (n = nr * nc up to 2048 unknowns, same coneqp trajectory) is solved
+by the device kernel behind ``hipdrt_qp_batch``.  Like the reference, this needs hybrid fits: the data-dependent unknowns
+``v_baseline`` and ``vz_offset`` are eliminated first (resolve.py:23-24)."""
+from copy import deepcopy
+
+import numpy as np
+from scipy.ndimage import gaussian_filter1d, median_filter
+
+from .. import _ffi
+from ..matrices.basis import construct_func_eval_matrix
+
+
+def get_offset_pq(drt):
+    """resolve.get_offset_pq (hybdrt/mapping/resolve.py:11-64): P, q of a fitted DRT without the v_baseline / vz_offset
+    unknowns, their fitted values folded into q."""
+    p, q = drt.fit_parameters['p_matrix'], drt.fit_parameters['q_vector']
+    sp = drt.special_qp_params
+    num_remove = sum(sp[k]['size'] for k in ('v_baseline', 'vz_offset'))     # KeyError on non-hybrid fits, as upstream
+    x_remove = np.empty(num_remove)
+    vb = sp['v_baseline']
+    # inverse of extract_qphb_parameters' baseline scaling (drt1d.py:6244-6259)
+    coef = np.array(drt.fit_parameters['v_baseline'], dtype=float) / drt.response_signal_scale
+    coef[0] += drt.scaled_response_offset
+    x_remove[vb['index']:vb['index'] + vb['size']] = coef * drt.v_baseline_scale
+    x_remove[sp['vz_offset']['index']] = drt.fit_parameters['vz_offset']
+    return p[num_remove:, num_remove:], q[num_remove:] + x_remove @ p[:num_remove, num_remove:]
+
+
+def resize_pq(p, q, special_offset, tau_indices, match_tau_indices):
+    """resolve.resize_pq (67-134): embed (or crop) an observation's DRT block into the common supergrid slice; the
+    special-parameter block and its couplings keep their place.  One offset rule serves all four expand / truncate
+    combinations; it equals the reference wherever the reference is self-consistent (both expanding branches, which is
+    all `truncate=False` ever reaches; its two left-truncating branches drop `special_offset` from some indices,
+    resolve.py:107-108, 124-129, and misplace or fail to broadcast when special parameters exist)."""
+    left = tau_indices[0] - match_tau_indices[0]
+    right = tau_indices[1] - match_tau_indices[1]
+    ntau_new = match_tau_indices[1] - match_tau_indices[0]
+    so = int(special_offset)
+    size = so + ntau_new
+    # source slice of the observation's own DRT index range, destination slice in the common range
+    src0, dst0 = (0, left) if left >= 0 else (-left, 0)
+    ntau_old = tau_indices[1] - tau_indices[0]
+    src1, dst1 = (ntau_old, ntau_new + right) if right <= 0 else (ntau_old - right, ntau_new)
+    p_out, q_out = np.zeros((size, size)), np.zeros(size)
+    p_out[:so, :so] = p[:so, :so]
+    q_out[:so] = q[:so]
+    s, d = slice(so + src0, so + src1), slice(so + dst0, so + dst1)
+    p_out[d, d] = p[s, s]
+    q_out[d] = q[s]
+    p_out[d, :so] = p[s, :so]
+    p_out[:so, d] = p[:so, s]
+    return p_out, q_out
+
+
+def offset_special_dict(special_qp_params):
+    """resolve.offset_special_dict (137-159): the special-parameter table after removing v_baseline / vz_offset."""
+    gone = {k: special_qp_params[k] for k in ('v_baseline', 'vz_offset') if k in special_qp_params}
+    out = deepcopy({k: v for k, v in special_qp_params.items() if k not in gone})
+    for key, v in out.items():
+        v['index'] = v['index'] - int(sum(g.get('size', 1) for g in gone.values() if g['index'] < v['index']))
+    return out
+
+
+def get_tau_indices(obs_tau_indices, truncate=False):
+    """resolve.get_tau_indices (162-173)"""
+    lefts, rights = [t[0] for t in obs_tau_indices], [t[1] for t in obs_tau_indices]
+    return (max(lefts), min(rights)) if truncate else (min(lefts), max(rights))
+
+
+def resolve_observations(obs_drt_list, obs_tau_indices, nonneg, obs_psi=None, truncate=False, sigma=1, lambda_psi=1,
+                         unpack=False, tau_filter_sigma=0, special_filter_sigma=0, device=0):
+    """resolve.resolve_observations (189-341).  Returns (x_opt (nr, nc), match_tau_indices), or the unpacked
+    (x_drt, x_special, match_tau_indices).  Raises ValueError when the QP breaks down (cvxopt's error)."""
+    match = get_tau_indices(obs_tau_indices, truncate=truncate)
+    special = offset_special_dict(obs_drt_list[0].special_qp_params)
+    so = int(sum(v.get('size', 1) for v in special.values()))
+    pq = [resize_pq(*get_offset_pq(drt), so, obs_tau_indices[i], match) for i, drt in enumerate(obs_drt_list)]
+    nr, nc = len(pq), len(pq[0][1])
+
+    # smoothness across observations, applied to the coefficients at their true scale (resolve.py:232-245, 271-272)
+    ly = gaussian_filter1d(np.eye(nr), sigma=sigma, mode='reflect', order=2)
+    scale_vec = np.array([drt.coefficient_scale for drt in obs_drt_list])
+    lys = ly @ np.diag(scale_vec / gaussian_filter1d(median_filter(scale_vec, 3), 2))
+    my = lys.T @ lys
+    param_scale = np.ones(nc)
+    if 'R_inf' in special:
+        x_inf = np.array([drt.fit_parameters['R_inf'] / drt.coefficient_scale for drt in obs_drt_list])
+        param_scale[special['R_inf']['index']] = (5 * np.std(x_inf)) ** -2
+    dop = None
+    if 'x_dop' in special:
+        x_dop = np.array([drt.fit_parameters['x_dop'] / (drt.coefficient_scale * drt.dop_scale_vector)
+                          for drt in obs_drt_list])
+        dop = (special['x_dop']['index'], special['x_dop']['index'] + special['x_dop'].get('size', 1))
+        param_scale[dop[0]:dop[1]] = (np.std(x_dop, axis=0) + 0.1 * np.std(x_dop)) ** -2
+    m_full = np.zeros((nr * nc, nr * nc))
+    diag = np.arange(nc)
+    for i in range(nr):
+        for j in range(nr):
+            m_full[i * nc + diag, j * nc + diag] = param_scale * my[i, j] * lambda_psi
+    if tau_filter_sigma > 0 or special_filter_sigma > 0:       # resolve.py:279-299, 319-320
+        filt = np.eye(nc)
+        if special_filter_sigma > 0 and dop is not None:
+            filt[dop[0]:dop[1], dop[0]:dop[1]] = construct_func_eval_matrix(
+                np.arange(dop[0], dop[1]), epsilon=1 / (np.sqrt(2) * special_filter_sigma), order=0)
+        if tau_filter_sigma > 0:
+            filt[so:, so:] = construct_func_eval_matrix(np.arange(nc - so), epsilon=1 / (np.sqrt(2) * tau_filter_sigma),
+                                                        order=0)
+        full = np.kron(np.eye(nr), filt)
+        m_full = full @ m_full @ full
+    p_matrix = m_full
+    for i, (p, _) in enumerate(pq):
+        p_matrix[i * nc:(i + 1) * nc, i * nc:(i + 1) * nc] += p
+    q_vector = np.concatenate([q for _, q in pq])
+    h = np.zeros(nr * nc) if nonneg else 10 * np.ones(nr * nc)
+    for v in special.values():
+        if v['nonneg']:
+            for i in range(nr):
+                h[v['index'] + i * nc:v['index'] + v.get('size', 1) + i * nc] = 0
+
+    res = _ffi.get_context(device).qp_batch(p_matrix[None], q_vector[None], h)
+    if res['status'][0] < 0:
+        raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+    resolve_observations.last_qp = dict(iterations=int(res['iterations'][0]), status=int(res['status'][0]))
+    x_opt = res['x'][0].reshape(nr, nc)
+    if unpack:
+        x_drt, x_special = unpack_resolved_x(x_opt, obs_drt_list, special)
+        return x_drt, x_special, match
+    return x_opt, match
+
+
+def unpack_resolved_x(x, obs_drt_list, special_dict):
+    """resolve.unpack_resolved_x (344-376): coefficients back in data units."""
+    so = int(sum(v.get('size', 1) for v in special_dict.values()))
+    cs = np.array([drt.coefficient_scale for drt in obs_drt_list])
+    x_drt = x[:, so:] * cs[:, None]
+    x_special = {}
+    for key, info in special_dict.items():
+        xk = x[:, info['index']:info['index'] + info.get('size', 1)] * cs[:, None]
+        if key == 'x_dop':
+            xk = xk * np.array([drt.dop_scale_vector for drt in obs_drt_list])
+        elif key == 'inductance':
+            xk = xk * np.array([drt.inductance_scale for drt in obs_drt_list])[:, None]
+        x_special[key] = xk.flatten() if info.get('size', 1) == 1 else xk
+    return x_drt, x_special

@@ -354,6 +354,9 @@ class PreparedFitMixin:
         self.input_signal_scale, self.response_signal_scale = prep['input_signal_scale'], prep['response_signal_scale']
         self.step_times, self.step_sizes = prep.get('step_times'), prep.get('step_sizes')
         self.dop_scale_vector = prep['dop_scale_vector']
+        self.scaled_response_offset = prep.get('scaled_response_offset')
+        self.v_baseline_scale = prep.get('v_baseline_scale')
+        self.inductance_scale = kw['inductance_scale']
         hist = plan.history()
         self.qphb_history = [dict(x=hist['x'][i], rho_vector=hist['rho'][i], weights=hist['weights'][i],
                                   dop_rho_vector=hist['dop_rho'][i] if 'dop_rho' in hist else None)

@@ -47,18 +47,25 @@ def config_c2():
 
 
 def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, t_step=0.05, dt_pre=5e-4,
-                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57):
+                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57, jitter=False):
     """Joint time/frequency-domain measurement of the same 2-ZARC cell (SURVEY.md section 8d, config 5 family):
     a galvanostatic step of ``i_step`` at ``t_step`` (n_pre uniform samples before it, n_post log-uniform after it)
     whose voltage comes from the closed-form response of an RC (Debye) discretisation of the two ZARCs, plus the
     impedance spectrum of :func:`zarc2_spectrum` on ``logspace(f_hi, f_lo, nf)``.
 
-    Returns (times, i_signal, v_signal, freq, z).
+    ``jitter=True`` perturbs (R1, R2, tau1, tau2) exactly as :func:`zarc2_spectrum` does for batch members, in both
+    data sets.  Returns (times, i_signal, v_signal, freq, z).
     """
     p = dict(BASE)
+    if jitter:
+        g = np.random.default_rng(10_000 + seed).standard_normal(4)
+        p["r1"] *= np.exp(0.2 * g[0])
+        p["r2"] *= np.exp(0.2 * g[1])
+        p["tau1"] *= np.exp(0.5 * g[2])
+        p["tau2"] *= np.exp(0.5 * g[3])
     rng = np.random.default_rng(50_000 + seed)
     freq = np.logspace(np.log10(f_hi), np.log10(f_lo), nf)
-    z = zarc2_spectrum(freq, seed)
+    z = zarc2_spectrum(freq, seed, jitter=jitter)
     pre = t_step - dt_pre * np.arange(n_pre, 0, -1)
     times = np.concatenate([pre, t_step + np.logspace(np.log10(t_lo), np.log10(t_hi), n_post)])
     i_signal = np.where(times >= t_step, i_step, 0.0)

@@ -283,6 +283,53 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop", meas, dict(base, fit_dop=True), {})
 
 
+def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7):
+    """survey 8f rank 2: mapping/resolve.py:189-341 -- coherent re-optimisation of neighbouring observations (block
+    diagonal P of the single fits + a smoothness penalty across observations).  The reference only supports hybrid
+    fits here (get_offset_pq indexes v_baseline / vz_offset unconditionally).  Saves what resolve consumes from every
+    fitted DRT object and what it returns."""
+    from hipdrt import synth
+    from hybdrt.mapping import resolve
+    base = dict(fit_inductance=True, fit_capacitance=False, fit_ohmic=True, fit_dop=fit_dop)
+    drts = []
+    with _quiet():
+        for s_ in range(n_obs):
+            drt = DRT(**base)
+            drt.fit_hybrid(*synth.hybrid_measurement(seed=s_, jitter=True, n_post=120, nf=31))
+            drts.append(drt)
+    ntau = len(drts[0].basis_tau)
+    assert all(len(d.basis_tau) == ntau for d in drts)
+    tau_idx = [(0, ntau)] * n_obs
+    log = []
+    cvxopt.solvers.options["_oracle_log"] = log
+    with _quiet():
+        x_opt, match = resolve.resolve_observations(drts, tau_idx, True)
+        x_opt_s3, _ = resolve.resolve_observations(drts, tau_idx, True, sigma=2, lambda_psi=10)
+    cvxopt.solvers.options["_oracle_log"] = None
+    sp = drts[0].special_qp_params
+    out = dict(n_obs=n_obs, ntau=ntau, special_names=np.array(list(sp.keys())),
+               special_index=np.array([v["index"] for v in sp.values()]),
+               special_size=np.array([v.get("size", 1) for v in sp.values()]),
+               special_nonneg=np.array([v["nonneg"] for v in sp.values()]),
+               p_matrix=np.array([d.fit_parameters["p_matrix"] for d in drts]),
+               q_vector=np.array([d.fit_parameters["q_vector"] for d in drts]),
+               v_baseline=np.array([d.fit_parameters["v_baseline"] for d in drts]),
+               vz_offset=np.array([d.fit_parameters["vz_offset"] for d in drts]),
+               R_inf=np.array([d.fit_parameters["R_inf"] for d in drts]),
+               coefficient_scale=np.array([d.coefficient_scale for d in drts]),
+               response_signal_scale=np.array([d.response_signal_scale for d in drts]),
+               scaled_response_offset=np.array([d.scaled_response_offset for d in drts]),
+               v_baseline_scale=np.array([d.v_baseline_scale for d in drts]),
+               x_opt=x_opt, match_tau_indices=np.array(match), x_opt_sigma2_lambda10=x_opt_s3,
+               qp_iterations=np.array([l["iterations"] for l in log]),
+               qp0_P_diag=np.diag(log[0]["P"]), qp0_q=log[0]["q"], qp0_h=log[0]["h"])
+    if fit_dop:
+        out.update(x_dop=np.array([d.fit_parameters["x_dop"] for d in drts]),
+                   dop_scale_vector=np.array([d.dop_scale_vector for d in drts]))
+    np.savez_compressed(os.path.join(OUT, f"refrun_resolve_{name}.npz"), **out)
+    print(f"resolve_{name}: {n_obs} obs x {x_opt.shape[1]} params, qp iterations {out['qp_iterations'].tolist()}")
+
+
 def run_posteriors(DRT, freq_g, z_g, default):
     from oracle.drt_oracle import get_basis_tau
     bt = get_basis_tau(freq_g)
@@ -295,6 +342,11 @@ def main():
     sys.path.insert(0, REPO)
     if "--only-response" in sys.argv:
         run_response_matrices()
+        return
+    if "--only-resolve" in sys.argv:
+        DRT, cvxopt = _boot_reference()
+        run_resolve(DRT, cvxopt, "hybrid7", False)
+        run_resolve(DRT, cvxopt, "hybrid7_dop", True)
         return
     if "--only-hybrid" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()
@@ -362,6 +414,9 @@ def main():
     run_candidates(DRT, "golden71x91", freq_g, z_g, default)
     # (10) distribution of phasances inside fit_eis, and joint chrono + EIS fits (config-5 family)
     run_hybrid_cases(DRT, cvxopt, freq_g, z_g)
+    # (11) coherent multi-observation re-optimisation (survey 8f rank 2)
+    run_resolve(DRT, cvxopt, "hybrid7", False)
+    run_resolve(DRT, cvxopt, "hybrid7_dop", True)
 
 
 if __name__ == "__main__":

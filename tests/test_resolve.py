@@ -1,0 +1,123 @@
+"""Coherent multi-observation re-optimisation (hybdrt/mapping/resolve.py): the oracle against the
+reference-run fixtures (CPU), the product's host assembly + device QP against the same (GPU)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+KEYS = ["p_matrix", "q_vector", "v_baseline", "vz_offset", "R_inf", "coefficient_scale", "response_signal_scale",
+        "scaled_response_offset", "v_baseline_scale"]
+
+
+def load(name):
+    g = np.load(os.path.join(GOLDEN, f"refrun_resolve_{name}.npz"))
+    special = {str(k): dict(index=int(i), size=int(s), nonneg=bool(nn))
+               for k, i, s, nn in zip(g["special_names"], g["special_index"], g["special_size"], g["special_nonneg"])}
+    keys = KEYS + (["x_dop", "dop_scale_vector"] if "x_dop" in g else [])
+    obs = [{k: g[k][i] for k in keys} for i in range(int(g["n_obs"]))]
+    return g, special, obs
+
+
+def as_drt(o, special):
+    """what resolve reads from a fitted DRT object"""
+    fp = {k: o[k] for k in ("p_matrix", "q_vector", "v_baseline", "vz_offset", "R_inf")}
+    if "x_dop" in o:
+        fp["x_dop"] = o["x_dop"]
+    return types.SimpleNamespace(fit_parameters=fp, special_qp_params=special, coefficient_scale=float(o["coefficient_scale"]),
+                                 response_signal_scale=float(o["response_signal_scale"]),
+                                 scaled_response_offset=float(o["scaled_response_offset"]),
+                                 v_baseline_scale=o["v_baseline_scale"], dop_scale_vector=o.get("dop_scale_vector"),
+                                 inductance_scale=1e-5)
+
+
+@pytest.mark.parametrize("name", ["hybrid7", "hybrid7_dop"])
+def test_oracle_resolve_matches_reference_run(name):
+    from oracle import resolve_oracle as ro
+    g, special, obs = load(name)
+    x, res, (P, q, h) = ro.resolve_observations(obs, special)
+    assert res["iterations"] == int(g["qp_iterations"][0])
+    np.testing.assert_allclose(np.diag(P), g["qp0_P_diag"], rtol=1e-12)
+    np.testing.assert_allclose(q, g["qp0_q"], rtol=1e-12, atol=1e-12 * np.abs(g["qp0_q"]).max())
+    np.testing.assert_array_equal(h, g["qp0_h"])
+    np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=1e-9 * np.abs(g["x_opt"]).max())   # host BLAS may differ
+    x2, res2, _ = ro.resolve_observations(obs, special, sigma=2, lambda_psi=10)
+    assert res2["iterations"] == int(g["qp_iterations"][1])
+    np.testing.assert_allclose(x2, g["x_opt_sigma2_lambda10"], rtol=0, atol=1e-9 * np.abs(g["x_opt"]).max())
+
+
+def test_resize_pq_and_special_shift():
+    from hipdrt.mapping import resolve
+    rng = np.random.default_rng(0)
+    so, nt = 2, 6
+    p = rng.standard_normal((so + nt, so + nt))
+    p = p + p.T
+    q = rng.standard_normal(so + nt)
+    # expand: observation covers supergrid slots [3, 9) of the common [1, 11)
+    pe, qe = resolve.resize_pq(p, q, so, (3, 9), (1, 11))
+    assert pe.shape == (so + 10, so + 10)
+    np.testing.assert_array_equal(pe[so + 2:so + 8, so + 2:so + 8], p[so:, so:])
+    np.testing.assert_array_equal(pe[:so, so + 2:so + 8], p[:so, so:])
+    np.testing.assert_array_equal(qe[so + 2:so + 8], q[so:])
+    assert np.count_nonzero(pe) == np.count_nonzero(p) and np.all(qe[so:so + 2] == 0)
+    # identity
+    pi, qi = resolve.resize_pq(p, q, so, (3, 9), (3, 9))
+    np.testing.assert_array_equal(pi, p)
+    np.testing.assert_array_equal(qi, q)
+    # truncate both sides to [4, 8)
+    pt, qt = resolve.resize_pq(p, q, so, (3, 9), (4, 8))
+    np.testing.assert_array_equal(pt[so:, so:], p[so + 1:so + 5, so + 1:so + 5])
+    np.testing.assert_array_equal(pt[:so, so:], p[:so, so + 1:so + 5])
+    np.testing.assert_array_equal(qt[so:], q[so + 1:so + 5])
+    # expand left, truncate right
+    px, qx = resolve.resize_pq(p, q, so, (3, 9), (1, 7))
+    np.testing.assert_array_equal(px[so + 2:, so + 2:], p[so:so + 4, so:so + 4])
+    assert resolve.get_tau_indices([(3, 9), (1, 7)]) == (1, 9)
+    assert resolve.get_tau_indices([(3, 9), (1, 7)], truncate=True) == (3, 7)
+    sp = {"v_baseline": dict(index=0, size=1, nonneg=False), "vz_offset": dict(index=1, size=1, nonneg=False),
+          "R_inf": dict(index=2, size=1, nonneg=True), "x_dop": dict(index=3, size=50, nonneg=True)}
+    sh = resolve.offset_special_dict(sp)
+    assert list(sh) == ["R_inf", "x_dop"] and sh["R_inf"]["index"] == 0 and sh["x_dop"]["index"] == 1
+    assert sp["R_inf"]["index"] == 2          # input untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hybrid7", "hybrid7_dop"])
+def test_device_resolve_matches_reference_run(name):
+    from hipdrt.mapping import resolve
+    g, special, obs = load(name)
+    drts = [as_drt(o, special) for o in obs]
+    nt = int(g["ntau"])
+    x, match = resolve.resolve_observations(drts, [(0, nt)] * len(drts), True)
+    assert match == (0, nt)
+    assert resolve.resolve_observations.last_qp["iterations"] == int(g["qp_iterations"][0])
+    scale = np.abs(g["x_opt"]).max()
+    np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=1e-7 * scale)
+    x2, _ = resolve.resolve_observations(drts, [(0, nt)] * len(drts), True, sigma=2, lambda_psi=10)
+    assert resolve.resolve_observations.last_qp["iterations"] == int(g["qp_iterations"][1])
+    np.testing.assert_allclose(x2, g["x_opt_sigma2_lambda10"], rtol=0, atol=1e-7 * scale)
+    x_drt, x_special, _ = resolve.resolve_observations(drts, [(0, nt)] * len(drts), True, unpack=True)
+    so = len(g["x_opt"][0]) - nt
+    np.testing.assert_allclose(x_drt, g["x_opt"][:, so:] * g["coefficient_scale"][:, None], rtol=0,
+                               atol=1e-7 * scale * g["coefficient_scale"].max())
+    assert set(x_special) == {k for k in special if k not in ("v_baseline", "vz_offset")}
+
+
+@pytest.mark.gpu
+def test_fit_hybrid_then_resolve_end_to_end():
+    """seven device fits of jittered cells -> resolve: the whole mapping step against the reference's run of the same"""
+    from hipdrt.models import DRT
+    from hipdrt.mapping import resolve
+    from hipdrt import synth
+    g, special, _ = load("hybrid7")
+    drts = []
+    for s_ in range(int(g["n_obs"])):
+        d = DRT(warn=False)
+        d.fit_hybrid(*synth.hybrid_measurement(seed=s_, jitter=True, n_post=120, nf=31))
+        drts.append(d)
+    np.testing.assert_allclose([d.coefficient_scale for d in drts], g["coefficient_scale"], rtol=1e-13)
+    nt = int(g["ntau"])
+    x, _ = resolve.resolve_observations(drts, [(0, nt)] * len(drts), True)
+    np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=1e-5 * np.abs(g["x_opt"]).max())

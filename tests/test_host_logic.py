@@ -19,8 +19,9 @@ def test_basis_tau_and_epsilon_rules():
     sg = np.logspace(-9, 3, 121)
     np.testing.assert_array_equal(pp.get_basis_tau(g["freq"], tau_grid=sg), sg[12:104])
     assert pp.estimate_rp(None, None, None, None, None, g["z"]) == g["z"].real.max() - g["z"].real.min()
-    with pytest.raises(NotImplementedError):
-        pp.get_tau_lim(g["freq"], times=np.arange(3.0))
+    # chrono data widens the limits to the time since the step (floored at the sample period)
+    lo, hi = pp.get_tau_lim(g["freq"], times=np.array([0.0, 1.0, 2.0, 1000.0]), step_times=np.array([0.5]))
+    assert lo == 1 / (2 * np.pi * g["freq"].max()) and hi == 999.5
 
 
 def test_toeplitz_decisions_match_oracle():

@@ -207,6 +207,8 @@ class DRT(PreparedFitMixin):
         z_batch = np.asarray(z_batch, dtype=complex)
         if z_batch.ndim != 2 or z_batch.shape[1] != len(frequencies):
             raise ValueError('z_batch must have shape (B, len(frequencies))')
+        if self.fit_dop:
+            return self._fit_prepared_batch([(None, None, None, frequencies, zb) for zb in z_batch], kw)
         return self._fit(frequencies, z_batch, kw, history_of=-1)
 
     # staged form: inputs made resident in HBM once, the fit launched separately (what bench.py times)

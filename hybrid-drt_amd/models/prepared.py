@@ -71,6 +71,14 @@ class PreparedFitMixin:
             self._lut_key = key
         return self._luts
 
+    def _memo(self, name, fn, *args):
+        """members of a batch share grids: identical device builds (same inputs, byte for byte) are done once per fit call"""
+        key = (name,) + tuple(a.tobytes() if isinstance(a, np.ndarray) else a for a in args)
+        memo = self.__dict__.setdefault('_build_memo', {})
+        if key not in memo:
+            memo[key] = fn()
+        return memo[key]
+
     def _vz_strength(self, sample_times, frequencies, step_times, vz_offset_eps):
         """DRT._get_vz_strength_vec (drt1d.py:6173-6226): 1 where the two data sets overlap in time scale, Gaussian
         decay in log time scale away from the overlap, 0 before the first step."""
@@ -184,15 +192,17 @@ class PreparedFitMixin:
         if has_eis:
             nf = len(frequencies)
             tpl_a = mat1d.impedance_matrix_is_toeplitz(frequencies, basis_tau, self.frequency_precision)
-            a_re, a_im = ctx.impedance_matrix(frequencies, basis_tau, eps, mode=integrate_mode, toeplitz=tpl_a,
-                                              lookups=luts['z'])
+            a_re, a_im = self._memo('zm', lambda: ctx.impedance_matrix(frequencies, basis_tau, eps, mode=integrate_mode,
+                                                                       toeplitz=tpl_a, lookups=luts['z']),
+                                    frequencies, basis_tau, eps, integrate_mode)
             zm = np.zeros((nf, n), dtype=complex)
             if 'inductance' in sp:
                 zm[:, sp['inductance']['index']] = mat1d.construct_inductance_impedance_vector(frequencies) * kw['inductance_scale']
             if 'R_inf' in sp:
                 zm[:, sp['R_inf']['index']] = 1
             if self.fit_dop:
-                zm[:, dop[0]:dop[1]] = ctx.phasor_z_matrix(frequencies, self.basis_nu, self.nu_epsilon) * dop_scale
+                zm[:, dop[0]:dop[1]] = self._memo('zdop', lambda: ctx.phasor_z_matrix(frequencies, self.basis_nu, self.nu_epsilon),
+                                                  frequencies, self.basis_nu, float(self.nu_epsilon)) * dop_scale
             zm[:, ns:] = a_re + 1j * a_im
             blocks.append(np.vstack([zm.real, zm.imag]))
             z_scaled = z / impedance_scale
@@ -204,8 +214,9 @@ class PreparedFitMixin:
         # penalty matrices (drt1d.py:5673-5734, 5863-5910)
         ln_tau = np.log(basis_tau)
         tpl_m = is_uniform(ln_tau)
-        m_drt = ctx.penalty_matrices(ln_tau, eps, tpl_m)
-        m_dop = ctx.penalty_matrices(self.basis_nu, self.nu_epsilon, is_uniform(self.basis_nu)) if self.fit_dop else None
+        m_drt = self._memo('mdrt', lambda: ctx.penalty_matrices(ln_tau, eps, tpl_m), ln_tau, eps)
+        m_dop = self._memo('mdop', lambda: ctx.penalty_matrices(self.basis_nu, self.nu_epsilon, is_uniform(self.basis_nu)),
+                           self.basis_nu, float(self.nu_epsilon)) if self.fit_dop else None
         pen = []
         for k in range(3):
             mk = np.zeros((n, n))
@@ -223,13 +234,18 @@ class PreparedFitMixin:
             pen.append(mk)
 
         # variance-estimation matrix (drt1d.py:614-636)
-        vmm = np.zeros((m, m))
-        if has_chrono:
-            vmm[:num_chrono, :num_chrono] = mat1d.construct_chrono_var_matrix(
-                times, prep['nonconsec_step_times'], ckw['chrono_vmm_epsilon'], ckw['chrono_error_structure'])
-        if has_eis:
-            vmm[num_chrono:, num_chrono:] = ctx.eis_var_matrix(frequencies, kw['eis_vmm_epsilon'], kw['eis_reim_cor'],
-                                                              kw['eis_error_structure'] == 'uniform')
+        def build_vmm():
+            v = np.zeros((m, m))
+            if has_chrono:
+                v[:num_chrono, :num_chrono] = mat1d.construct_chrono_var_matrix(
+                    times, prep['nonconsec_step_times'], ckw['chrono_vmm_epsilon'], ckw['chrono_error_structure'])
+            if has_eis:
+                v[num_chrono:, num_chrono:] = ctx.eis_var_matrix(frequencies, kw['eis_vmm_epsilon'], kw['eis_reim_cor'],
+                                                                kw['eis_error_structure'] == 'uniform')
+            return v
+        vmm = self._memo('vmm', build_vmm, times if has_chrono else 0, prep.get('nonconsec_step_times', 0),
+                         frequencies if has_eis else 0, ckw['chrono_vmm_epsilon'], str(ckw['chrono_error_structure']),
+                         kw['eis_vmm_epsilon'], kw['eis_reim_cor'], str(kw['eis_error_structure']))
 
         # vz_offset strength (drt1d.py:500-522), l1 vector (552-556), h (qphb.py:521-557)
         vz_strength = None
@@ -289,15 +305,17 @@ class PreparedFitMixin:
         if opts.outlier_p > 0:
             raise NotImplementedError("outlier_p is only built for plain EIS fits")
         ctx = self._context if self._context is not None else _ffi.get_context(self.device)
+        self._build_memo = {}
         preps = [self._prepare_measurement(ctx, *meas, kw, ckw, hypers) for meas in measurements]
+        self._build_memo = {}
         p0 = preps[0]
         for pr in preps[1:]:
             if pr['rzm'].shape != p0['rzm'].shape or pr['special'] != p0['special']:
                 raise ValueError('all measurements of a batch must share one protocol (same m, n, special parameters)')
-        shared = all(pr is p0 or (np.array_equal(pr['rzm'], p0['rzm'])) for pr in preps) and 'vz_offset' not in p0['special']
-        for pr in preps[1:]:     # one plan = one set of shared penalty / variance matrices
-            if not (np.array_equal(pr['vmm'], p0['vmm']) and all(np.array_equal(a, b) for a, b in zip(pr['pen'], p0['pen']))):
+            # one plan = one set of shared penalty / variance matrices (memoised builds: identical inputs -> same object)
+            if pr['vmm'] is not p0['vmm'] or not np.array_equal(pr['basis_tau'], p0['basis_tau']):
                 raise ValueError('all measurements of a batch must share the basis grid and the sampling grids')
+        shared = 'vz_offset' not in p0['special'] and all(np.array_equal(pr['rzm'], p0['rzm']) for pr in preps[1:])
         desc = self._prepared_desc(p0, hypers)
         if self._plan is not None:
             self._plan.close()
@@ -394,9 +412,13 @@ class PreparedFitMixin:
         """B joint measurements of one protocol (same sample times / frequencies), fitted concurrently: the hybrid
         counterpart of fit_eis_batch.  Returns a dict of arrays (x in data units, per-measurement specials)."""
         meas = [(times, i_batch[b], v_batch[b], frequencies, z_batch[b]) for b in range(len(z_batch))]
+        return self._fit_prepared_batch(meas, kw)
+
+    def _fit_prepared_batch(self, meas, kw):
         preps, out, hypers, fkw, ckw = self._fit_prepared(meas, kw)
         fps = [self._extract(pr, out['x'][b], out['weights'][b], fkw, ckw) for b, pr in enumerate(preps)]
         res = {key: np.array([fp[key] for fp in fps]) for key in fps[0] if fps[0][key] is not None and key != 'vz_offset_eps'}
-        res.update(x_scaled=out['x'], outer_iters=out['outer_iters'], status=out['status'],
-                   qp_iters_total=out['qp_iters_total'], rho=out['rho'], weights=out['weights'])
+        res.update(x_scaled=out['x'], fit_x=res['x'], outer_iters=out['outer_iters'], status=out['status'],
+                   qp_iters_total=out['qp_iters_total'], rho=out['rho'], weights=out['weights'],
+                   coefficient_scale=np.array([pr['coefficient_scale'] for pr in preps]), basis_tau=preps[0]['basis_tau'])
         return res

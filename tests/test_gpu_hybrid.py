@@ -225,3 +225,19 @@ def test_config5_full_size_joint_fit_with_dop():
     assert 0.3 < np.sqrt(np.mean(resid ** 2)) < 3.0            # both data sets reproduced at their noise level
     assert np.all(fp["x"] >= -1e-12) and np.all(fp["x_dop"] >= -1e-12) and fp["R_inf"] >= 0
     assert abs(fp["R_inf"] - 1.0) < 0.3                        # the synthetic cell's series resistance (DOP terms share it)
+
+
+def test_fit_eis_batch_with_dop_shares_one_matrix_set():
+    """fit_eis_batch with fit_dop=True: one shared response matrix for the batch, members equal their single fits"""
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    freq = np.logspace(5, 0, 61)
+    zb = synth.zarc2_batch(freq, 5)
+    drt = DRT(fit_dop=True, warn=False)
+    res = drt.fit_eis_batch(freq, zb)
+    assert not drt._plan.rm_batched and res["x_dop"].shape == (5, 50)
+    single = DRT(fit_dop=True, warn=False)
+    fp = single.fit_eis(freq, zb[3])
+    np.testing.assert_array_equal(res["fit_x"][3], fp["x"])
+    np.testing.assert_array_equal(res["x_dop"][3], fp["x_dop"])
+    assert res["outer_iters"][3] == single.qphb_params["outer_iterations"]

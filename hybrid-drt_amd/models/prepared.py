@@ -191,47 +191,55 @@ class PreparedFitMixin:
                         response_matrix=a, inf_response=rm[:, sp['R_inf']['index']] * input_scale if 'R_inf' in sp else None)
         if has_eis:
             nf = len(frequencies)
-            tpl_a = mat1d.impedance_matrix_is_toeplitz(frequencies, basis_tau, self.frequency_precision)
-            a_re, a_im = self._memo('zm', lambda: ctx.impedance_matrix(frequencies, basis_tau, eps, mode=integrate_mode,
-                                                                       toeplitz=tpl_a, lookups=luts['z']),
-                                    frequencies, basis_tau, eps, integrate_mode)
-            zm = np.zeros((nf, n), dtype=complex)
-            if 'inductance' in sp:
-                zm[:, sp['inductance']['index']] = mat1d.construct_inductance_impedance_vector(frequencies) * kw['inductance_scale']
-            if 'R_inf' in sp:
-                zm[:, sp['R_inf']['index']] = 1
-            if self.fit_dop:
-                zm[:, dop[0]:dop[1]] = self._memo('zdop', lambda: ctx.phasor_z_matrix(frequencies, self.basis_nu, self.nu_epsilon),
-                                                  frequencies, self.basis_nu, float(self.nu_epsilon)) * dop_scale
-            zm[:, ns:] = a_re + 1j * a_im
-            blocks.append(np.vstack([zm.real, zm.imag]))
+
+            def build_eis_block():
+                tpl_a = mat1d.impedance_matrix_is_toeplitz(frequencies, basis_tau, self.frequency_precision)
+                a_re, a_im = ctx.impedance_matrix(frequencies, basis_tau, eps, mode=integrate_mode, toeplitz=tpl_a,
+                                                  lookups=luts['z'])
+                zm = np.zeros((nf, n), dtype=complex)
+                if 'inductance' in sp:
+                    zm[:, sp['inductance']['index']] = mat1d.construct_inductance_impedance_vector(frequencies) * kw['inductance_scale']
+                if 'R_inf' in sp:
+                    zm[:, sp['R_inf']['index']] = 1
+                if self.fit_dop:
+                    zm[:, dop[0]:dop[1]] = ctx.phasor_z_matrix(frequencies, self.basis_nu, self.nu_epsilon) * dop_scale
+                zm[:, ns:] = a_re + 1j * a_im
+                return np.vstack([zm.real, zm.imag])
+            # independent of the measured values: one build per batch
+            blocks.append(self._memo('eis_block', build_eis_block, frequencies, basis_tau, eps, integrate_mode, n,
+                                     float(kw['inductance_scale']), dop_scale if dop_scale is not None else 0))
             z_scaled = z / impedance_scale
             rows.append(np.concatenate([z_scaled.real, z_scaled.imag]))
-        rzm = np.vstack(blocks)
+        rzm = blocks[0] if len(blocks) == 1 else np.vstack(blocks)
         rzv = np.concatenate(rows)
         m = len(rzv)
 
         # penalty matrices (drt1d.py:5673-5734, 5863-5910)
         ln_tau = np.log(basis_tau)
         tpl_m = is_uniform(ln_tau)
-        m_drt = self._memo('mdrt', lambda: ctx.penalty_matrices(ln_tau, eps, tpl_m), ln_tau, eps)
-        m_dop = self._memo('mdop', lambda: ctx.penalty_matrices(self.basis_nu, self.nu_epsilon, is_uniform(self.basis_nu)),
-                           self.basis_nu, float(self.nu_epsilon)) if self.fit_dop else None
-        pen = []
-        for k in range(3):
-            mk = np.zeros((n, n))
-            if 'v_baseline' in sp:
-                mk[sp['v_baseline']['index'], sp['v_baseline']['index']] = ckw['v_baseline_penalty']
-            if 'inductance' in sp:
-                mk[sp['inductance']['index'], sp['inductance']['index']] = kw['inductance_penalty']
-            if 'R_inf' in sp:
-                mk[sp['R_inf']['index'], sp['R_inf']['index']] = kw['ohmic_penalty']
-            if 'vz_offset' in sp:
-                mk[sp['vz_offset']['index'], sp['vz_offset']['index']] = 1 / ckw['vz_offset_scale']
-            if self.fit_dop:
-                mk[dop[0]:dop[1], dop[0]:dop[1]] = m_dop[k]
-            mk[ns:, ns:] = m_drt[k]
-            pen.append(mk)
+
+        def build_penalties():
+            m_drt = self._memo('mdrt', lambda: ctx.penalty_matrices(ln_tau, eps, tpl_m), ln_tau, eps)
+            m_dop = self._memo('mdop', lambda: ctx.penalty_matrices(self.basis_nu, self.nu_epsilon, is_uniform(self.basis_nu)),
+                               self.basis_nu, float(self.nu_epsilon)) if self.fit_dop else None
+            pen = []
+            for k in range(3):
+                mk = np.zeros((n, n))
+                if 'v_baseline' in sp:
+                    mk[sp['v_baseline']['index'], sp['v_baseline']['index']] = ckw['v_baseline_penalty']
+                if 'inductance' in sp:
+                    mk[sp['inductance']['index'], sp['inductance']['index']] = kw['inductance_penalty']
+                if 'R_inf' in sp:
+                    mk[sp['R_inf']['index'], sp['R_inf']['index']] = kw['ohmic_penalty']
+                if 'vz_offset' in sp:
+                    mk[sp['vz_offset']['index'], sp['vz_offset']['index']] = 1 / ckw['vz_offset_scale']
+                if self.fit_dop:
+                    mk[dop[0]:dop[1], dop[0]:dop[1]] = m_dop[k]
+                mk[ns:, ns:] = m_drt[k]
+                pen.append(mk)
+            return pen
+        pen = self._memo('pen', build_penalties, ln_tau, eps, n, str(sorted(sp.items())), float(ckw['v_baseline_penalty']),
+                         float(kw['inductance_penalty']), float(kw['ohmic_penalty']), float(ckw['vz_offset_scale']))
 
         # variance-estimation matrix (drt1d.py:614-636)
         def build_vmm():
@@ -315,7 +323,8 @@ class PreparedFitMixin:
             # one plan = one set of shared penalty / variance matrices (memoised builds: identical inputs -> same object)
             if pr['vmm'] is not p0['vmm'] or not np.array_equal(pr['basis_tau'], p0['basis_tau']):
                 raise ValueError('all measurements of a batch must share the basis grid and the sampling grids')
-        shared = 'vz_offset' not in p0['special'] and all(np.array_equal(pr['rzm'], p0['rzm']) for pr in preps[1:])
+        shared = 'vz_offset' not in p0['special'] and all(pr['rzm'] is p0['rzm'] or np.array_equal(pr['rzm'], p0['rzm'])
+                                                         for pr in preps[1:])
         desc = self._prepared_desc(p0, hypers)
         if self._plan is not None:
             self._plan.close()

@@ -47,14 +47,15 @@ def config_c2():
 
 
 def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, t_step=0.05, dt_pre=5e-4,
-                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57, jitter=False):
+                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57, jitter=False, extra_steps=()):
     """Joint time/frequency-domain measurement of the same 2-ZARC cell (SURVEY.md section 8d, config 5 family):
     a galvanostatic step of ``i_step`` at ``t_step`` (n_pre uniform samples before it, n_post log-uniform after it)
     whose voltage comes from the closed-form response of an RC (Debye) discretisation of the two ZARCs, plus the
     impedance spectrum of :func:`zarc2_spectrum` on ``logspace(f_hi, f_lo, nf)``.
 
     ``jitter=True`` perturbs (R1, R2, tau1, tau2) exactly as :func:`zarc2_spectrum` does for batch members, in both
-    data sets.  Returns (times, i_signal, v_signal, freq, z).
+    data sets.  ``extra_steps`` = ((delay, current change), ...) appends further current steps, each followed by its own
+    n_post log-uniform samples (superposition of the RC responses).  Returns (times, i_signal, v_signal, freq, z).
     """
     p = dict(BASE)
     if jitter:
@@ -67,8 +68,17 @@ def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, 
     freq = np.logspace(np.log10(f_hi), np.log10(f_lo), nf)
     z = zarc2_spectrum(freq, seed, jitter=jitter)
     pre = t_step - dt_pre * np.arange(n_pre, 0, -1)
-    times = np.concatenate([pre, t_step + np.logspace(np.log10(t_lo), np.log10(t_hi), n_post)])
-    i_signal = np.where(times >= t_step, i_step, 0.0)
+    steps = [(t_step, i_step)]
+    for delay, di in extra_steps:
+        steps.append((steps[-1][0] + delay, di))
+    segs = [pre]
+    for k, (ts, _) in enumerate(steps):
+        t_end = t_hi if k == len(steps) - 1 else 0.999 * (steps[k + 1][0] - ts)
+        segs.append(ts + np.logspace(np.log10(t_lo), np.log10(t_end), n_post))
+    times = np.concatenate(segs)
+    i_signal = np.zeros(len(times))
+    for ts, di in steps:
+        i_signal += np.where(times >= ts, di, 0.0)
     lt = np.linspace(-6.0, 1.0, n_rc)
     taus = 10.0 ** lt
 
@@ -78,9 +88,10 @@ def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, 
         return g * np.log(10.0) * (lt[1] - lt[0])
 
     rk = gamma(p["r1"], p["tau1"], p["beta1"]) + gamma(p["r2"], p["tau2"], p["beta2"])
-    post = times >= t_step
-    dt = times[post] - t_step
     v = np.zeros(len(times))
-    v[post] = i_step * (p["r_inf"] + (rk[None, :] * (1.0 - np.exp(-dt[:, None] / taus[None, :]))).sum(axis=1))
+    for ts, di in steps:
+        post = times >= ts
+        dt = times[post] - ts
+        v[post] += di * (p["r_inf"] + (rk[None, :] * (1.0 - np.exp(-dt[:, None] / taus[None, :]))).sum(axis=1))
     v_signal = v + v0 + v_noise * rng.standard_normal(len(times))
     return times, i_signal, v_signal, freq, z

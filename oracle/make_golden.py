@@ -236,6 +236,8 @@ def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
         drt = DRT(**ctor_kw)
         if times is None:
             drt.fit_eis(freq, z, **fit_kw)
+        elif freq is None:
+            drt.fit_chrono(times, i_sig, v_sig, **fit_kw)
         else:
             drt.fit_hybrid(times, i_sig, v_sig, freq, z, **fit_kw)
     cvxopt.solvers.options["_oracle_log"] = None
@@ -255,8 +257,12 @@ def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
                hist_x=np.array([h["x"] for h in drt.qphb_history]),
                hist_rho=np.array([h["rho_vector"] for h in drt.qphb_history]),
                hist_weights=np.array([h["weights"] for h in drt.qphb_history]),
-               x=fp["x"], R_inf=fp["R_inf"], inductance=fp["inductance"], z_sigma_tot=fp["z_sigma_tot"],
+               x=fp["x"], R_inf=fp["R_inf"], inductance=fp["inductance"],
                q_vector=fp["q_vector"], p_matrix=fp["p_matrix"], x_scaled=np.array(list(drt.cvx_result["x"])))
+    if freq is not None:
+        out["z_sigma_tot"] = fp["z_sigma_tot"]
+    else:
+        del out["freq"], out["z"], out["impedance_scale"]
     if drt.fit_dop:
         out.update(basis_nu=drt.basis_nu, nu_epsilon=drt.nu_epsilon, dop_scale_vector=drt.dop_scale_vector,
                    dop_rho_vector=qp["dop_rho_vector"], dop_xmx_norms=qp["dop_xmx_norms"], x_dop=fp["x_dop"],
@@ -268,7 +274,7 @@ def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
                    input_signal_scale=drt.input_signal_scale, response_signal_scale=drt.response_signal_scale,
                    scaled_response_offset=drt.scaled_response_offset, v_baseline_scale=drt.v_baseline_scale,
                    vz_strength_vec=qp["vz_strength_vec"], num_chrono=qp["num_chrono"],
-                   v_baseline=fp["v_baseline"], vz_offset=fp["vz_offset"], v_sigma_tot=fp["v_sigma_tot"],
+                   v_baseline=fp["v_baseline"], vz_offset=fp.get("vz_offset", np.nan), v_sigma_tot=fp["v_sigma_tot"],
                    response_matrix=drt.fit_matrices["response"], inf_response=drt.fit_matrices["inf_response"])
     np.savez_compressed(os.path.join(OUT, f"refrun_{name}.npz"), **out)
     print(f"{name}: m x n = {qp['rm'].shape}, outer={out['outer_iterations']} qp_iters={out['qp_iterations'].tolist()}")
@@ -281,6 +287,13 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     meas = synth.hybrid_measurement(seed=0)
     run_hybrid_case(DRT, cvxopt, "hybrid_s0", meas, dict(base, fit_dop=False), {})
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop", meas, dict(base, fit_dop=True), {})
+    # chrono-only fit (drt1d.py:1195-1213) and a three-step protocol with the non-default chrono options
+    run_hybrid_case(DRT, cvxopt, "chrono_s1", meas[:3] + (None, None), dict(base, fit_dop=False), {})
+    meas3 = synth.hybrid_measurement(seed=2, n_post=80, extra_steps=((2.0, -2e-3), (3.0, 1e-3)))
+    run_hybrid_case(DRT, cvxopt, "hybrid_3step_opts", meas3, dict(base, fit_dop=False),
+                    dict(vz_offset=False, chrono_error_structure=None, smooth_inf_response=False, offset_baseline=False,
+                         chrono_vmm_epsilon=2, vz_offset_eps=2))
+    run_hybrid_case(DRT, cvxopt, "hybrid_3step", meas3, dict(base, fit_dop=False), dict(vz_offset_scale=0.5, vz_offset_eps=2))
 
 
 def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7):

@@ -29,7 +29,7 @@ def make_desc(ffi, g, special, rzm0, vz, hyp):
     return d
 
 
-@pytest.mark.parametrize("name", ["golden71x91_dop", "hybrid_s0", "hybrid_s0_dop"])
+@pytest.mark.parametrize("name", ["golden71x91_dop", "hybrid_s0", "hybrid_s0_dop", "chrono_s1", "hybrid_3step"])
 @pytest.mark.parametrize("batched", [False, True])
 def test_prepared_plan_reproduces_reference_trajectory(name, batched):
     from hipdrt import _ffi as ffi
@@ -107,7 +107,8 @@ def _check_fit(drt, g, special, dop):
     np.testing.assert_allclose(drt.cvx_result["x"], g["x_scaled"], rtol=1e-6, atol=2e-7)
     np.testing.assert_allclose(fp["R_inf"], g["R_inf"], rtol=1e-6)
     np.testing.assert_allclose(fp["inductance"], g["inductance"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
+    if "z_sigma_tot" in g:
+        np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
     np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
     np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
     np.testing.assert_allclose(qp["rho_vector"], g["rho_vector"], rtol=1e-6)
@@ -241,3 +242,36 @@ def test_fit_eis_batch_with_dop_shares_one_matrix_set():
     np.testing.assert_array_equal(res["fit_x"][3], fp["x"])
     np.testing.assert_array_equal(res["x_dop"][3], fp["x_dop"])
     assert res["outer_iters"][3] == single.qphb_params["outer_iterations"]
+
+
+def test_fit_chrono_matches_reference_run():
+    """DRT.fit_chrono (drt1d.py:1195-1213): chrono-only fit, no vz_offset column, uniform error structure"""
+    from hipdrt.models import DRT
+    g, special = load_case("chrono_s1")
+    drt = DRT()
+    fp = drt.fit_chrono(g["times"], g["i_signal"], g["v_signal"])
+    np.testing.assert_allclose(drt.basis_tau, g["basis_tau"], rtol=1e-13)
+    _check_fit(drt, g, special, False)
+    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
+    np.testing.assert_allclose(fp["v_sigma_tot"], g["v_sigma_tot"], rtol=1e-6)
+    assert fp["z_sigma_tot"] is None and drt.fit_type == "qphb_chrono"
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("hybrid_3step", dict(vz_offset_scale=0.5, vz_offset_eps=2)),
+    ("hybrid_3step_opts", dict(vz_offset=False, chrono_error_structure=None, smooth_inf_response=False,
+                               offset_baseline=False, chrono_vmm_epsilon=2, vz_offset_eps=2)),
+])
+def test_fit_hybrid_three_step_protocol_and_options(name, kw):
+    """three current steps (step detection, per-step response layers, segment-wise chrono variance matrix) and the
+    non-default chrono keywords"""
+    from hipdrt.models import DRT
+    g, special = load_case(name)
+    drt = DRT(warn=False)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], **kw)
+    np.testing.assert_array_equal(drt.step_times, g["step_times"])
+    np.testing.assert_allclose(drt.step_sizes, g["step_sizes"], rtol=1e-14)
+    _check_fit(drt, g, special, False)
+    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-6)
+    if "vz_offset" in special:
+        np.testing.assert_allclose(fp["vz_offset"], g["vz_offset"], rtol=1e-5, atol=1e-8)

@@ -171,7 +171,7 @@ class DRT(PreparedFitMixin):
                          ('vmm_reim_cor', 'eis_reim_cor')):     # fit_eis's own keyword names (drt1d.py:1215-1241)
             if old in kw:
                 kw[new] = kw.pop(old)
-        if self.fit_dop:     # the x_dop block changes the matrix layout: prepared-matrix plan (models/prepared.py)
+        if self.fit_dop or kw.get('solve_rp'):     # x_dop block / host-side rescale: prepared-matrix plan (models/prepared.py)
             return self._store_single(*self._fit_prepared([(None, None, None, frequencies, z)], kw, history_of=0),
                                       'qphb_eis')
         res = self._fit(frequencies, z[None, :], kw, history_of=0)
@@ -207,7 +207,7 @@ class DRT(PreparedFitMixin):
         z_batch = np.asarray(z_batch, dtype=complex)
         if z_batch.ndim != 2 or z_batch.shape[1] != len(frequencies):
             raise ValueError('z_batch must have shape (B, len(frequencies))')
-        if self.fit_dop:
+        if self.fit_dop or kw.get('solve_rp'):
             return self._fit_prepared_batch([(None, None, None, frequencies, zb) for zb in z_batch], kw)
         return self._fit(frequencies, z_batch, kw, history_of=-1)
 

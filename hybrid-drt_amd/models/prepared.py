@@ -19,10 +19,10 @@ from . import background, qphb
 _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (drt1d.py:102-129)
     step_times=None, step_sizes=None, offset_steps=True, step_offset_size=None, offset_baseline=True,
     smooth_inf_response=True, v_baseline_penalty=1e-6, vz_offset=True, vz_offset_scale=1, vz_offset_eps=1,
-    chrono_error_structure='uniform', chrono_vmm_epsilon=4)
+    chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False)
 
 _UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False, remove_extremes=False,
-                    remove_outliers=False, series_neg=False, solve_rp=False, update_scale=False,
+                    remove_outliers=False, series_neg=False, update_scale=False,
                     init_weights_separately=False, eis_weight_factor=None, chrono_weight_factor=None,
                     hybrid_weight_factor_method=None, peak_locations=None, neg_allowed_tau_range=None,
                     v_baseline_deg=0, v_baseline_sqrt=False)
@@ -273,6 +273,44 @@ class PreparedFitMixin:
                     dop_scale_vector=dop_scale, frequencies=frequencies)
         return prep
 
+    def _solve_data_scale(self, ctx, prep, hypers, kw):
+        """DRT._solve_data_scale + the rescaling block of _qphb_fit_core (drt1d.py:568-606, 5421-5437;
+        qphb.estimate_x_rp 1684-1717): a lightly penalised QP (l2_lambda_0 = 1e-4 with the DOP / DRT ratio kept, scalar
+        l1 = 1e-3, unit weights; Gram and QP on the device) gives Rp = basis_area * sum|x_drt|; the data are rescaled to
+        rp_scale / Rp and the DOP columns to the DRT magnitude."""
+        n, ns, dop = prep['n'], prep['ns'], prep['dop']
+        l2 = np.zeros((n, n))
+        for k, dw in enumerate(hypers['derivative_weights']):
+            if dw > 0:          # s = s_0 = 1 and rho = rho_0 = 1 at this point (drt1d.py:559-566)
+                mk = prep['pen'][k].copy()
+                mk[ns:, ns:] *= 1e-4 * dw * hypers['rho_0'][k]
+                if dop:
+                    mk[dop[0]:dop[1], dop[0]:dop[1]] *= (hypers['dop_l2_lambda_0'] / hypers['l2_lambda_0'] * 1e-4
+                                                         * hypers['dop_derivative_weights'][k] * hypers['dop_rho_0'][k])
+                sq = np.sqrt(np.full(n, float(hypers['s_0'][k])))
+                l2 += (sq[:, None] * mk) * sq[None, :]
+        p_mat, q_vec = ctx.weighted_gram(prep['rzm'], np.ones(prep['m']), prep['rzv'], l2=l2, l1=np.full(n, 1e-3))
+        res = ctx.qp_batch(p_mat, q_vec, prep['h'])
+        if res['status'][0] < 0:
+            raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+        x_rp = res['x'][0]
+        rp_est = np.sum(np.abs(x_rp[ns:])) * (np.sqrt(np.pi) / self.tau_epsilon)        # predict_r_p(absolute, raw)
+        factor = hypers['rp_scale'] / rp_est
+        prep['rzv'] = prep['rzv'] * factor
+        # update_data_scale (drtbase.py:516-536), galvanostatic
+        prep['coefficient_scale'] /= factor
+        prep['impedance_scale'] /= factor
+        if prep['response_signal_scale'] is not None:
+            prep['response_signal_scale'] /= factor
+            prep['scaled_response_offset'] *= factor
+        if dop:
+            dop_factor = np.max(np.abs(x_rp[ns:])) / np.max(np.abs(x_rp[dop[0]:dop[1]]))
+            prep['dop_scale_vector'] = prep['dop_scale_vector'] / dop_factor
+            rzm = prep['rzm'].copy()           # the block may be shared between batch members
+            rzm[:, dop[0]:dop[1]] /= dop_factor
+            prep['rzm'] = rzm
+        prep['rp_qp_iterations'] = int(res['iterations'][0])
+
     def _prepared_desc(self, prep, hypers):
         d = _ffi.PreparedDesc()
         sp = prep['special']
@@ -316,6 +354,9 @@ class PreparedFitMixin:
         self._build_memo = {}
         preps = [self._prepare_measurement(ctx, *meas, kw, ckw, hypers) for meas in measurements]
         self._build_memo = {}
+        if ckw['solve_rp'] and kw['scale_data']:
+            for pr in preps:
+                self._solve_data_scale(ctx, pr, hypers, kw)
         p0 = preps[0]
         for pr in preps[1:]:
             if pr['rzm'].shape != p0['rzm'].shape or pr['special'] != p0['special']:

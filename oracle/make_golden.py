@@ -294,6 +294,12 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
                     dict(vz_offset=False, chrono_error_structure=None, smooth_inf_response=False, offset_baseline=False,
                          chrono_vmm_epsilon=2, vz_offset_eps=2))
     run_hybrid_case(DRT, cvxopt, "hybrid_3step", meas3, dict(base, fit_dop=False), dict(vz_offset_scale=0.5, vz_offset_eps=2))
+    # solve_rp=True (drt1d.py:568-606, 5421-5437): one extra QP re-estimates Rp, data and DOP columns are rescaled
+    run_hybrid_case(DRT, cvxopt, "golden71x91_dop_solverp", (None, None, None, freq_g, z_g), dict(base, fit_dop=True),
+                    dict(solve_rp=True))
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop_solverp", meas, dict(base, fit_dop=True), dict(solve_rp=True))
+    run_hybrid_case(DRT, cvxopt, "golden71x91_solverp", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
+                    dict(solve_rp=True))
 
 
 def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7):

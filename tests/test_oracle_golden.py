@@ -216,3 +216,34 @@ def test_general_loop_reproduces_reference_trajectory(name):
         np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in r["history"]]), g["hist_dop_rho"], rtol=1e-8)
         np.testing.assert_allclose(r["dop_xmx_norms"], g["dop_xmx_norms"], rtol=1e-7)
     np.testing.assert_allclose(r["xmx_norms"], g["xmx_norms"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("name,base", [("golden71x91_solverp", None), ("golden71x91_dop_solverp", "golden71x91_dop"),
+                                       ("hybrid_s0_dop_solverp", "hybrid_s0_dop")])
+def test_general_loop_solve_rp_branch(name, base):
+    """solve_rp=True (drt1d.py:568-606): the oracle re-derives the Rp QP, the data rescale and the DOP column rescale from
+    the un-rescaled inputs (recovered from the companion fixture of the same measurement without solve_rp) and then
+    follows the reference's trajectory."""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case(name)
+    hyp = orc.get_default_hypers()
+    if "x_dop" in special:
+        hyp.update(orc.get_default_dop_hypers())
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    if base is not None:
+        gb, _ = load_case(base)
+        sf = float(gb["coefficient_scale"] / g["coefficient_scale"])
+        rzv0 = gb["rv"]
+        a = special["x_dop"]["index"]
+        rzm0[:, a:a + special["x_dop"]["size"]] *= gb["dop_scale_vector"] / g["dop_scale_vector"]
+    else:
+        cs0 = (g["z"].real.max() - g["z"].real.min()) / 14
+        sf = cs0 / float(g["coefficient_scale"])
+        rzv0 = g["rv"] / sf
+    r = orc.qphb_fit_prepared(rzm0, rzv0, [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, vz=vz,
+                              solve_rp=dict(basis_area=np.sqrt(np.pi) / float(g["tau_epsilon"])))
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(r["scale_factor"], sf, rtol=1e-8)
+    np.testing.assert_allclose(r["rzv"], g["rv"], rtol=1e-7, atol=1e-8 * np.abs(g["rv"]).max())
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r["rzm"], g["rm"], rtol=0, atol=1e-7 * np.abs(g["rm"]).max())

@@ -299,3 +299,39 @@ def test_solve_rp_matches_reference_run(name):
     if "times" in g:
         np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
         np.testing.assert_allclose(drt.response_signal_scale, g["response_signal_scale"], rtol=1e-8)
+
+
+def test_prepared_plan_argument_validation():
+    """error behaviour of the prepared-plan entry points: bad layouts are refused with HIPDRT_E_INVALID and a message"""
+    from hipdrt import _ffi as ffi
+    ctx = ffi.get_context()
+    n, m = 12, 20
+    eye = np.eye(n)
+    vmm = np.full((m, m), 1.0 / m)
+
+    def desc(**kw):
+        d = ffi.PreparedDesc()
+        d.m, d.n, d.ns = m, n, 4
+        d.vz_index = -1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    with pytest.raises(ffi.HipDrtError, match="x_dop block"):
+        ffi.PreparedPlan(ctx, desc(dop_start=3, dop_size=3), [eye] * 3, vmm, np.zeros(n), np.zeros(n))
+    with pytest.raises(ffi.HipDrtError, match="vz_offset"):
+        ffi.PreparedPlan(ctx, desc(vz_index=1), [eye] * 3, vmm, np.zeros(n), np.zeros(n))      # no strength vector
+    with pytest.raises(ffi.HipDrtError, match="larger than the DRT block"):
+        ffi.PreparedPlan(ctx, desc(ns=10, dop_start=0, dop_size=10), [eye] * 3, vmm, np.zeros(n), np.zeros(n))
+    plan = ffi.PreparedPlan(ctx, desc(vz_index=1, vb_start=0, vb_size=1, num_chrono=8), [eye] * 3, vmm, np.zeros(n),
+                            np.zeros(n), vz_strength=np.ones(m), capacity=2)
+    rng = np.random.default_rng(0)
+    with pytest.raises(ffi.HipDrtError, match="per measurement"):
+        plan.upload(rng.standard_normal((m, n)), rng.standard_normal((2, m)))                    # shared matrix + vz column
+    with pytest.raises(ffi.HipDrtError, match="capacity"):
+        plan.upload(rng.standard_normal((3, m, n)), rng.standard_normal((3, m)))
+    with pytest.raises(ffi.HipDrtError, match="prepared plans take"):
+        ffi.Plan.upload(plan, np.zeros((1, 5), dtype=complex))
+    plan.upload(rng.standard_normal((2, m, n)), rng.standard_normal((2, m)))
+    plan.fit()                                                                                   # tiny random problem runs
+    out = plan.download()
+    assert np.all(np.isfinite(out["x"])) and np.all(out["outer_iters"] >= 1)

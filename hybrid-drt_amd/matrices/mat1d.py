@@ -142,6 +142,21 @@ def construct_inductance_response_vector(times, step_model, step_times, step_siz
     return np.zeros(len(times))
 
 
+def construct_capacitance_response_vector(times, step_model, step_times, step_sizes, tau_rise, op_mode='galv'):
+    """mat1d.construct_capacitance_response_vector (mat1d.py:423-443): a series capacitance integrates the current --
+    step_size * (t - t_step) after every ideal step."""
+    if step_model != 'ideal':
+        raise ValueError('Capacitance response not implemented for non-ideal steps')
+    if op_mode != 'galv':
+        raise ValueError('Capacitance response vector not implemented for potentiostatic mode')
+    times = np.asarray(times, dtype=float)
+    crv = np.zeros(len(times))
+    for st, sa in zip(step_times, step_sizes):
+        after = times >= st
+        crv[after] += sa * (times[after] - st)
+    return crv
+
+
 def construct_inductance_impedance_vector(frequencies):
     """mat1d.py:446-447."""
     return 1j * 2 * np.pi * frequencies

@@ -17,6 +17,7 @@ from .prepared import PreparedFitMixin
 
 _FIT_KW_DEFAULTS = dict(  # DRT._qphb_fit_core keyword defaults (drt1d.py:102-137) that the device loop honours
     nonneg=True, scale_data=True, ohmic_penalty=1e-6, inductance_penalty=1e-6, inductance_scale=1e-5,
+    capacitance_penalty=1e-6, capacitance_scale=1e-3,
     penalty_type='integral', eis_error_structure=None, eis_vmm_epsilon=0.25, eis_reim_cor=0.25,
     iw_l1_lambda_0=1e-4, iw_l2_lambda_0=1e-4, eff_hp=True, weight_factor=1, xtol=1e-2, max_iter=50)
 
@@ -31,8 +32,6 @@ class DRT(PreparedFitMixin):
         """DRTBase.__init__ (hybdrt/models/drtbase.py:21-159): epsilon rule and the lookup tables."""
         if tau_basis_type != 'gaussian':
             raise NotImplementedError("only the default gaussian basis is on the hot path")
-        if fit_capacitance:
-            raise NotImplementedError("fit_capacitance is not built")
         if nu_basis_type != 'gaussian' or not normalize_dop:
             raise NotImplementedError("only the default gaussian, normalised distribution of phasances is built")
         if step_model != 'ideal' or chrono_mode != 'galv':
@@ -46,7 +45,7 @@ class DRT(PreparedFitMixin):
         self.tau_basis_type = tau_basis_type
         self.tau_epsilon = tau_epsilon
         self.extend_basis_decades = extend_basis_decades
-        self.fit_inductance, self.fit_ohmic, self.fit_capacitance, self.fit_dop = fit_inductance, fit_ohmic, False, bool(fit_dop)
+        self.fit_inductance, self.fit_ohmic, self.fit_capacitance, self.fit_dop = fit_inductance, fit_ohmic, bool(fit_capacitance), bool(fit_dop)
         self.frequency_precision = frequency_precision
         self.print_diagnostics, self.warn = print_diagnostics, warn
         self.device = device
@@ -171,7 +170,7 @@ class DRT(PreparedFitMixin):
                          ('vmm_reim_cor', 'eis_reim_cor')):     # fit_eis's own keyword names (drt1d.py:1215-1241)
             if old in kw:
                 kw[new] = kw.pop(old)
-        if self.fit_dop or kw.get('solve_rp'):     # x_dop block / host-side rescale: prepared-matrix plan (models/prepared.py)
+        if self.fit_dop or self.fit_capacitance or kw.get('solve_rp'):   # extra columns / host-side rescale: prepared-matrix plan
             return self._store_single(*self._fit_prepared([(None, None, None, frequencies, z)], kw, history_of=0),
                                       'qphb_eis')
         res = self._fit(frequencies, z[None, :], kw, history_of=0)
@@ -207,7 +206,7 @@ class DRT(PreparedFitMixin):
         z_batch = np.asarray(z_batch, dtype=complex)
         if z_batch.ndim != 2 or z_batch.shape[1] != len(frequencies):
             raise ValueError('z_batch must have shape (B, len(frequencies))')
-        if self.fit_dop or kw.get('solve_rp'):
+        if self.fit_dop or self.fit_capacitance or kw.get('solve_rp'):
             return self._fit_prepared_batch([(None, None, None, frequencies, zb) for zb in z_batch], kw)
         return self._fit(frequencies, z_batch, kw, history_of=-1)
 

@@ -52,6 +52,8 @@ class PreparedFitMixin:
             add('R_inf', True)
         if self.fit_inductance:
             add('inductance', True)
+        if self.fit_capacitance:
+            add('C_inv', True)
         if self.fit_dop:
             if self.basis_nu is None:
                 self.basis_nu = np.concatenate([np.linspace(-1, -0.4, 25), np.linspace(0.4, 1, 25)])
@@ -178,6 +180,9 @@ class PreparedFitMixin:
             if 'inductance' in sp:
                 rm[:, sp['inductance']['index']] = (mat1d.construct_inductance_response_vector(
                     times, self.step_model, step_times, step_sizes, None) / input_scale) * kw['inductance_scale']
+            if 'C_inv' in sp:
+                rm[:, sp['C_inv']['index']] = (mat1d.construct_capacitance_response_vector(
+                    times, self.step_model, step_times, step_sizes, None) / input_scale) * kw['capacitance_scale']
             if 'R_inf' in sp:
                 rm[:, sp['R_inf']['index']] = mat1d.construct_ohmic_response_vector(
                     times, self.step_model, step_times, step_sizes, None, i_signal, ckw['smooth_inf_response']) / input_scale
@@ -201,13 +206,16 @@ class PreparedFitMixin:
                     zm[:, sp['inductance']['index']] = mat1d.construct_inductance_impedance_vector(frequencies) * kw['inductance_scale']
                 if 'R_inf' in sp:
                     zm[:, sp['R_inf']['index']] = 1
+                if 'C_inv' in sp:
+                    zm[:, sp['C_inv']['index']] = mat1d.construct_capacitance_impedance_vector(frequencies) * kw['capacitance_scale']
                 if self.fit_dop:
                     zm[:, dop[0]:dop[1]] = ctx.phasor_z_matrix(frequencies, self.basis_nu, self.nu_epsilon) * dop_scale
                 zm[:, ns:] = a_re + 1j * a_im
                 return np.vstack([zm.real, zm.imag])
             # independent of the measured values: one build per batch
             blocks.append(self._memo('eis_block', build_eis_block, frequencies, basis_tau, eps, integrate_mode, n,
-                                     float(kw['inductance_scale']), dop_scale if dop_scale is not None else 0))
+                                     float(kw['inductance_scale']), float(kw['capacitance_scale']),
+                                     dop_scale if dop_scale is not None else 0))
             z_scaled = z / impedance_scale
             rows.append(np.concatenate([z_scaled.real, z_scaled.imag]))
         rzm = blocks[0] if len(blocks) == 1 else np.vstack(blocks)
@@ -231,6 +239,8 @@ class PreparedFitMixin:
                     mk[sp['inductance']['index'], sp['inductance']['index']] = kw['inductance_penalty']
                 if 'R_inf' in sp:
                     mk[sp['R_inf']['index'], sp['R_inf']['index']] = kw['ohmic_penalty']
+                if 'C_inv' in sp:
+                    mk[sp['C_inv']['index'], sp['C_inv']['index']] = kw['capacitance_penalty']
                 if 'vz_offset' in sp:
                     mk[sp['vz_offset']['index'], sp['vz_offset']['index']] = 1 / ckw['vz_offset_scale']
                 if self.fit_dop:
@@ -239,7 +249,8 @@ class PreparedFitMixin:
                 pen.append(mk)
             return pen
         pen = self._memo('pen', build_penalties, ln_tau, eps, n, str(sorted(sp.items())), float(ckw['v_baseline_penalty']),
-                         float(kw['inductance_penalty']), float(kw['ohmic_penalty']), float(ckw['vz_offset_scale']))
+                         float(kw['inductance_penalty']), float(kw['ohmic_penalty']), float(kw['capacitance_penalty']),
+                         float(ckw['vz_offset_scale']))
 
         # variance-estimation matrix (drt1d.py:614-636)
         def build_vmm():
@@ -396,7 +407,7 @@ class PreparedFitMixin:
         if 'vz_offset' in sp:
             fp['vz_offset'] = x[sp['vz_offset']['index']]
         fp['inductance'] = x[sp['inductance']['index']] * (cs * kw['inductance_scale']) if 'inductance' in sp else 0
-        fp['C_inv'] = 0
+        fp['C_inv'] = x[sp['C_inv']['index']] * (cs * kw['capacitance_scale']) if 'C_inv' in sp else 0
         if prep['dop']:
             fp['x_dop'] = x[prep['dop'][0]:prep['dop'][1]] * (prep['dop_scale_vector'] * cs)
         sigma = 1.0 / weights

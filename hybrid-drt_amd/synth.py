@@ -47,7 +47,7 @@ def config_c2():
 
 
 def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, t_step=0.05, dt_pre=5e-4,
-                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57, jitter=False, extra_steps=()):
+                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57, jitter=False, extra_steps=(), c_series=None):
     """Joint time/frequency-domain measurement of the same 2-ZARC cell (SURVEY.md section 8d, config 5 family):
     a galvanostatic step of ``i_step`` at ``t_step`` (n_pre uniform samples before it, n_post log-uniform after it)
     whose voltage comes from the closed-form response of an RC (Debye) discretisation of the two ZARCs, plus the
@@ -55,7 +55,8 @@ def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, 
 
     ``jitter=True`` perturbs (R1, R2, tau1, tau2) exactly as :func:`zarc2_spectrum` does for batch members, in both
     data sets.  ``extra_steps`` = ((delay, current change), ...) appends further current steps, each followed by its own
-    n_post log-uniform samples (superposition of the RC responses).  Returns (times, i_signal, v_signal, freq, z).
+    n_post log-uniform samples (superposition of the RC responses).  ``c_series`` adds a series (blocking) capacitance to
+    both data sets.  Returns (times, i_signal, v_signal, freq, z).
     """
     p = dict(BASE)
     if jitter:
@@ -67,6 +68,8 @@ def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, 
     rng = np.random.default_rng(50_000 + seed)
     freq = np.logspace(np.log10(f_hi), np.log10(f_lo), nf)
     z = zarc2_spectrum(freq, seed, jitter=jitter)
+    if c_series is not None:
+        z = z + 1.0 / (1j * 2 * np.pi * freq * c_series)
     pre = t_step - dt_pre * np.arange(n_pre, 0, -1)
     steps = [(t_step, i_step)]
     for delay, di in extra_steps:
@@ -93,5 +96,7 @@ def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, 
         post = times >= ts
         dt = times[post] - ts
         v[post] += di * (p["r_inf"] + (rk[None, :] * (1.0 - np.exp(-dt[:, None] / taus[None, :]))).sum(axis=1))
+        if c_series is not None:
+            v[post] += di * dt / c_series
     v_signal = v + v0 + v_noise * rng.standard_normal(len(times))
     return times, i_signal, v_signal, freq, z

@@ -68,7 +68,7 @@ def run_case(DRT, cvxopt, name, freq, z, ctor_kw, fit_kw, save_mats=True, save_q
     cvxopt.solvers.options["_oracle_log"] = None
     fp, qp = drt.fit_parameters, drt.qphb_params
     out = dict(freq=freq, z=z, basis_tau=drt.basis_tau, tau_epsilon=drt.tau_epsilon,
-               x=fp["x"], R_inf=fp["R_inf"], inductance=fp["inductance"], z_sigma_tot=fp["z_sigma_tot"],
+               x=fp["x"], R_inf=fp["R_inf"], inductance=fp["inductance"], C_inv=fp["C_inv"], z_sigma_tot=fp["z_sigma_tot"],
                q_vector=fp["q_vector"], x_scaled=np.array(list(drt.cvx_result["x"])),
                coefficient_scale=drt.coefficient_scale,
                est_weights=qp["est_weights"], weights=qp["true_weights"], rho_vector=qp["rho_vector"],
@@ -257,7 +257,7 @@ def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
                hist_x=np.array([h["x"] for h in drt.qphb_history]),
                hist_rho=np.array([h["rho_vector"] for h in drt.qphb_history]),
                hist_weights=np.array([h["weights"] for h in drt.qphb_history]),
-               x=fp["x"], R_inf=fp["R_inf"], inductance=fp["inductance"],
+               x=fp["x"], R_inf=fp["R_inf"], inductance=fp["inductance"], C_inv=fp["C_inv"],
                q_vector=fp["q_vector"], p_matrix=fp["p_matrix"], x_scaled=np.array(list(drt.cvx_result["x"])))
     if freq is not None:
         out["z_sigma_tot"] = fp["z_sigma_tot"]
@@ -300,6 +300,11 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop_solverp", meas, dict(base, fit_dop=True), dict(solve_rp=True))
     run_hybrid_case(DRT, cvxopt, "golden71x91_solverp", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(solve_rp=True))
+    # series capacitance as a special parameter (C_inv column: drt1d.py:5803, 5838, 5888; mat1d.py:423-451)
+    meas_c = synth.hybrid_measurement(seed=3, c_series=20.0, t_hi=5.0)
+    capb = dict(base, fit_capacitance=True)
+    run_hybrid_case(DRT, cvxopt, "eis_cap", (None, None, None) + meas_c[3:], dict(capb, fit_dop=False), {})
+    run_hybrid_case(DRT, cvxopt, "hybrid_cap", meas_c, dict(capb, fit_dop=False), {})
 
 
 def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7):

@@ -352,8 +352,6 @@ def test_edge_cases():
     fp2 = DRT(fit_inductance=False).fit_eis(freq, z)   # one special parameter only
     assert fp2["inductance"] == 0 and np.all(np.isfinite(fp2["x"]))
     with pytest.raises(NotImplementedError):
-        DRT(fit_capacitance=True)
-    with pytest.raises(NotImplementedError):
         DRT(tau_basis_type='Cole-Cole')
 
 

@@ -109,6 +109,8 @@ def _check_fit(drt, g, special, dop, data_rtol=1e-12, mat_rtol=1e-9):
     np.testing.assert_allclose(drt.cvx_result["x"], g["x_scaled"], rtol=1e-6, atol=2e-7)
     np.testing.assert_allclose(fp["R_inf"], g["R_inf"], rtol=1e-6)
     np.testing.assert_allclose(fp["inductance"], g["inductance"], rtol=1e-5, atol=1e-12)
+    if "C_inv" in g:
+        np.testing.assert_allclose(fp["C_inv"], g["C_inv"], rtol=1e-5, atol=1e-10)
     if "z_sigma_tot" in g:
         np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
     np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
@@ -335,3 +337,18 @@ def test_prepared_plan_argument_validation():
     plan.fit()                                                                                   # tiny random problem runs
     out = plan.download()
     assert np.all(np.isfinite(out["x"])) and np.all(out["outer_iters"] >= 1)
+
+
+def test_fit_capacitance_matches_reference_run():
+    """fit_capacitance=True: the C_inv column (1/(j omega) in the impedance block, the integrated current in the chrono
+    block; drt1d.py:5803, 5838, 5888, mat1d.py:423-451) in an EIS fit and in a joint fit of a cell with a series capacitor"""
+    from hipdrt.models import DRT
+    g, special = load_case("eis_cap")
+    drt = DRT(fit_capacitance=True, warn=False)
+    drt.fit_eis(g["freq"], g["z"])
+    _check_fit(drt, g, special, False)
+    g, special = load_case("hybrid_cap")
+    drt = DRT(fit_capacitance=True, warn=False)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"])
+    _check_fit(drt, g, special, False)
+    assert abs(fp["C_inv"] - 1 / 20.0) < 0.01          # the synthetic cell's 20 F series capacitor

@@ -19,13 +19,12 @@ from . import background, qphb
 _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (drt1d.py:102-129)
     step_times=None, step_sizes=None, offset_steps=True, step_offset_size=None, offset_baseline=True,
     smooth_inf_response=True, v_baseline_penalty=1e-6, vz_offset=True, vz_offset_scale=1, vz_offset_eps=1,
-    chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False)
+    chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False)
 
 _UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False, remove_extremes=False,
                     remove_outliers=False, series_neg=False, update_scale=False,
                     init_weights_separately=False, eis_weight_factor=None, chrono_weight_factor=None,
-                    hybrid_weight_factor_method=None, peak_locations=None, neg_allowed_tau_range=None,
-                    v_baseline_deg=0, v_baseline_sqrt=False)
+                    hybrid_weight_factor_method=None, peak_locations=None, neg_allowed_tau_range=None)
 
 
 class PreparedFitMixin:
@@ -39,13 +38,13 @@ class PreparedFitMixin:
     chrono_mode = 'galv'
 
     # ---- drt1d.py:365-408 ---------------------------------------------------------------------------------------
-    def _general_special_params(self, has_chrono, has_eis, vz_offset):
+    def _general_special_params(self, has_chrono, has_eis, vz_offset, n_baseline=1):
         sp = {}
 
         def add(name, nonneg, size=1):
             sp[name] = {'index': int(sum(v['size'] for v in sp.values())), 'nonneg': nonneg, 'size': size}
         if has_chrono:
-            add('v_baseline', False, 1)
+            add('v_baseline', False, n_baseline)
         if vz_offset and has_chrono and has_eis:
             add('vz_offset', False)
         if self.fit_ohmic:
@@ -142,7 +141,8 @@ class PreparedFitMixin:
         eps = float(self.tau_epsilon)
         ntau = len(basis_tau)
         luts = self._lookups(ctx) if integrate_mode == _ffi.MODE_INTERP else dict(z=None, response=None)
-        sp = self._general_special_params(has_chrono, has_eis, ckw['vz_offset'])
+        sp = self._general_special_params(has_chrono, has_eis, ckw['vz_offset'],
+                                          int(ckw['v_baseline_deg']) + 1 + int(bool(ckw['v_baseline_sqrt'])))
         ns = int(sum(v['size'] for v in sp.values()))
         n = ns + ntau
         dop = (sp['x_dop']['index'], sp['x_dop']['index'] + sp['x_dop']['size']) if self.fit_dop else None
@@ -175,8 +175,9 @@ class PreparedFitMixin:
             a, _ = ctx.response_matrix(times, basis_tau, step_times, step_sizes, eps, mode=integrate_mode,
                                        lookup=luts['response'], layered=False)
             rm[:, ns:] = a / input_scale
-            vb, vb_scale = background.get_baseline_matrix(times, 0, normalize=True)
-            rm[:, sp['v_baseline']['index']:sp['v_baseline']['index'] + 1] = vb
+            vb, vb_scale = background.get_baseline_matrix(times, int(ckw['v_baseline_deg']), normalize=True,
+                                                          sqrt=bool(ckw['v_baseline_sqrt']))
+            rm[:, sp['v_baseline']['index']:sp['v_baseline']['index'] + sp['v_baseline']['size']] = vb
             if 'inductance' in sp:
                 rm[:, sp['inductance']['index']] = (mat1d.construct_inductance_response_vector(
                     times, self.step_model, step_times, step_sizes, None) / input_scale) * kw['inductance_scale']
@@ -233,8 +234,14 @@ class PreparedFitMixin:
             pen = []
             for k in range(3):
                 mk = np.zeros((n, n))
-                if 'v_baseline' in sp:
-                    mk[sp['v_baseline']['index'], sp['v_baseline']['index']] = ckw['v_baseline_penalty']
+                if 'v_baseline' in sp:      # scalar or one penalty per baseline coefficient (drt1d.py:5872-5886)
+                    a0, nb = sp['v_baseline']['index'], sp['v_baseline']['size']
+                    pens = np.broadcast_to(np.asarray(ckw['v_baseline_penalty'], dtype=float), (nb,)) \
+                        if np.ndim(ckw['v_baseline_penalty']) == 0 or len(ckw['v_baseline_penalty']) == nb else None
+                    if pens is None:
+                        raise ValueError("If v_baseline_penalty is iterable, it must match the number of v_baseline "
+                                         f"parameters. Number of v_baseline parameters is {nb}")
+                    mk[np.arange(a0, a0 + nb), np.arange(a0, a0 + nb)] = pens
                 if 'inductance' in sp:
                     mk[sp['inductance']['index'], sp['inductance']['index']] = kw['inductance_penalty']
                 if 'R_inf' in sp:
@@ -248,7 +255,7 @@ class PreparedFitMixin:
                 mk[ns:, ns:] = m_drt[k]
                 pen.append(mk)
             return pen
-        pen = self._memo('pen', build_penalties, ln_tau, eps, n, str(sorted(sp.items())), float(ckw['v_baseline_penalty']),
+        pen = self._memo('pen', build_penalties, ln_tau, eps, n, str(sorted(sp.items())), str(ckw['v_baseline_penalty']),
                          float(kw['inductance_penalty']), float(kw['ohmic_penalty']), float(kw['capacitance_penalty']),
                          float(ckw['vz_offset_scale']))
 

@@ -300,6 +300,9 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop_solverp", meas, dict(base, fit_dop=True), dict(solve_rp=True))
     run_hybrid_case(DRT, cvxopt, "golden71x91_solverp", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(solve_rp=True))
+    # polynomial + square-root voltage baseline (background.py:23-37; three v_baseline coefficients)
+    run_hybrid_case(DRT, cvxopt, "hybrid_vb", meas, dict(base, fit_dop=False),
+                    dict(v_baseline_deg=1, v_baseline_sqrt=True, v_baseline_penalty=[1e-6, 1e-4, 1e-5]))
     # series capacitance as a special parameter (C_inv column: drt1d.py:5803, 5838, 5888; mat1d.py:423-451)
     meas_c = synth.hybrid_measurement(seed=3, c_series=20.0, t_hi=5.0)
     capb = dict(base, fit_capacitance=True)

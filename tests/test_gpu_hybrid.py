@@ -352,3 +352,20 @@ def test_fit_capacitance_matches_reference_run():
     fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"])
     _check_fit(drt, g, special, False)
     assert abs(fp["C_inv"] - 1 / 20.0) < 0.01          # the synthetic cell's 20 F series capacitor
+
+
+def test_polynomial_baseline_matches_reference_run():
+    """v_baseline_deg=1, v_baseline_sqrt=True with one penalty per coefficient: three baseline columns, all excluded from
+    the vz_offset prediction; extract_qphb_parameters' per-column scaling"""
+    from hipdrt.models import DRT
+    g, special = load_case("hybrid_vb")
+    assert special["v_baseline"]["size"] == 3
+    drt = DRT(warn=False)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], v_baseline_deg=1,
+                        v_baseline_sqrt=True, v_baseline_penalty=[1e-6, 1e-4, 1e-5])
+    _check_fit(drt, g, special, False)
+    np.testing.assert_allclose(drt.v_baseline_scale, g["v_baseline_scale"], rtol=1e-14)
+    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-5, atol=1e-9 * np.abs(g["v_baseline"]).max())
+    with pytest.raises(ValueError):
+        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], v_baseline_deg=1,
+                       v_baseline_penalty=[1e-6, 1e-4, 1e-5])

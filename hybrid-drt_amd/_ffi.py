@@ -86,6 +86,7 @@ SIGNATURES = {
     "hipdrt_plan_create_prepared": [_vp, C.POINTER(PreparedDesc), _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(FitOpts),
                                     C.c_int, C.POINTER(_vp)],
     "hipdrt_plan_upload_prepared": [_vp, C.c_int, C.c_int, _dp, _dp],
+    "hipdrt_plan_set_weight_factors": [_vp, C.c_double, _dp, C.c_int],
     "hipdrt_plan_destroy": [_vp],
     "hipdrt_plan_dims": [_vp, _ip, _ip, _ip],
     "hipdrt_plan_get": [_vp, C.c_char_p, _dp, C.c_longlong],
@@ -433,6 +434,14 @@ class Plan:
 
     def continue_fit(self, opts, weight_factor=1.0, min_iter=2):
         _check(self._lib.hipdrt_plan_continue(self._h, C.byref(opts), float(weight_factor), int(min_iter)))
+
+    def set_weight_factors(self, weight_factor=1.0, row_factors=None):
+        """weight_factor / chrono- and EIS-row factors of _qphb_fit_core; row_factors (m,) or (capacity, m)"""
+        rf = None if row_factors is None else _f64(row_factors)
+        if rf is not None and rf.ndim == 2 and rf.shape[0] < self.capacity:     # the C side reads capacity rows
+            rf = _f64(np.vstack([rf, np.ones((self.capacity - rf.shape[0], rf.shape[1]))]))
+        _check(self._lib.hipdrt_plan_set_weight_factors(self._h, float(weight_factor), _p(rf),
+                                                        int(rf is not None and rf.ndim == 2)))
 
     def record_history(self, b):
         _check(self._lib.hipdrt_plan_record_history(self._h, int(b)))

@@ -28,6 +28,11 @@ struct hipdrt_plan {
     hipdrt_prepared_desc desc{};
     long long rm_stride = 0;
     DevBuf vz_strength, dop_rho, dop_xmx, hist_dop_rho;
+    // weight factors (hipdrt_plan_set_weight_factors): w_eff = w * row factor * weight_factor is what the QP sees
+    double weight_factor = 1.0;
+    int wrow_batched = 0;
+    DevBuf wrow, w_eff;
+    bool has_weight_factors() const { return weight_factor != 1.0 || wrow.p != nullptr; }
     // shared
     DevBuf freq, tau, ln_tau, wt_re, wt_im, lut6, a_re, a_im, cr, rm, mk[3], vmm, h, l1;
     // per spectrum
@@ -657,6 +662,24 @@ int hipdrt_plan_upload_prepared(hipdrt_plan* p, int B, int rm_batched, const dou
     return HIPDRT_OK;
 }
 
+int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const double* row_factors, int batched) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_REQUIRE(weight_factor > 0.0, "weight_factor > 0");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    p->weight_factor = weight_factor;
+    p->wrow_batched = batched ? 1 : 0;
+    if (row_factors) {
+        const size_t cnt = (batched ? (size_t)p->capacity : 1) * p->m;
+        TRY(upload(p->wrow, row_factors, cnt * sizeof(double), st));
+    } else {
+        p->wrow.release();
+    }
+    if (p->has_weight_factors() && !p->w_eff.p) HIPDRT_CHECK(p->w_eff.alloc((size_t)p->capacity * p->m * sizeof(double)));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
 int hipdrt_plan_destroy(hipdrt_plan* plan) {
     if (plan) { (void)hipSetDevice(plan->ctx->device); delete plan; }
     return HIPDRT_OK;
@@ -843,9 +866,15 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     for (; it < p->opts.max_iter; ++it) {
         tm.mark(1);
         HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
-        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, (long long)n * p->ldp, p->active.i(),
+        const double* wq = p->w.d();
+        if (p->has_weight_factors()) {           // drt1d.py:889-901: row factors every iteration, weight_factor from the second
+            launch_scale_rows(st, B, m, p->w.d(), p->wrow.d(), p->wrow_batched, it > 0 ? p->weight_factor : 1.0,
+                              p->active.i(), p->w_eff.d());
+            wq = p->w_eff.d();
+        }
+        launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, wq, g, Prow, p->ldp, (long long)n * p->ldp, p->active.i(),
                        p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n), astr);
-        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i(), astr);
+        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, wq, p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i(), astr);
         LAUNCH_OK();
         tm.mark(2);
         if (B * sizeof(int) <= 48 * 1024) {     // dispatch order from the previous QP's iteration counts
@@ -863,7 +892,14 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     }
     // ---- calculate_pq's q with the final weights (qphb.py:1154-1183) ---------------------------------------
     tm.mark(4);
-    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr, astr);
+    const double* wfin = p->w.d();
+    if (p->has_weight_factors()) {
+        // drt1d.py:990-1000: weights *= weight_factor (these are `true_weights`); calculate_pq sees them times the row factors
+        launch_scale_rows(st, B, m, p->w.d(), nullptr, 0, p->weight_factor, nullptr, p->w.d());
+        launch_scale_rows(st, B, m, p->w.d(), p->wrow.d(), p->wrow_batched, 1.0, nullptr, p->w_eff.d());
+        wfin = p->w_eff.d();
+    }
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, wfin, p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr, astr);
     LAUNCH_OK();
     tm.mark(-1);
     HIPDRT_CHECK(hipStreamSynchronize(st));
@@ -925,6 +961,7 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
         HIPDRT_CHECK(hipStreamSynchronize(st));
     }
     HIPDRT_REQUIRE(!p->prepared, "warm restarts are not available on prepared plans");
+    HIPDRT_REQUIRE(!p->has_weight_factors(), "warm restarts take their weight_factor argument; clear the plan's weight factors");
     GramL2 g = plan_l2(p, opts->l2_lambda_0, opts->derivative_weights, 0.0);
     QpArgs qa{};
     qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
@@ -1012,7 +1049,8 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
     GramL2 g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, p->prepared ? p->desc.dop_l2_lambda_0 : 0.0);
     g.s = p->s.d() + (size_t)b * 3 * n; g.rho = p->rho.d() + (size_t)b * 3;
     if (g.dop_size > 0) g.dop_rho = p->dop_rho.d() + (size_t)b * 3;
-    launch_gram_l2(st, 1, m, n, p->rm.d() + (size_t)b * p->rm_stride, p->ldrm, p->w.d() + (size_t)b * m, g, p->Ptmp.d(),
+    const double* wfin = p->has_weight_factors() ? p->w_eff.d() : p->w.d();     // scaled_weights of calculate_pq
+    launch_gram_l2(st, 1, m, n, p->rm.d() + (size_t)b * p->rm_stride, p->ldrm, wfin + (size_t)b * m, g, p->Ptmp.d(),
                    p->ldp, 0, nullptr);
     LAUNCH_OK();
     return copy_strided(out, p->Ptmp.d(), n, n, p->ldp, st);
@@ -1031,8 +1069,8 @@ static int plan_quadratic_forms(hipdrt_plan* p, const double* basis_eval, int ne
     const int nex = (neval + 15) / 16, nchp = qp_nchp(n);
     // final P of every spectrum (calculate_pq with the final weights / s / rho, drt1d.py:1006), packed tiles only
     GramL2 g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, p->prepared ? p->desc.dop_l2_lambda_0 : 0.0);
-    launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, nullptr, p->ldp, 0, nullptr, p->Ppk.d(),
-                   (long long)qp_ppk_doubles(n), nchp, p->rm_stride);
+    launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->has_weight_factors() ? p->w_eff.d() : p->w.d(), g, nullptr, p->ldp, 0,
+                   nullptr, p->Ppk.d(), (long long)qp_ppk_doubles(n), nchp, p->rm_stride);
     LAUNCH_OK();
     // evaluation rows -> packed tiles, shifted past the special-parameter slots
     DevBuf dbe, bex, scratch, dout, dstat;

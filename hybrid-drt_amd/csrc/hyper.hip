@@ -679,6 +679,23 @@ __global__ void scale_weights_kernel(FitState st, double factor) {
     if (i < st.m) st.w[(size_t)b * st.m + i] *= factor;
 }
 
+// out[b][i] = w[b][i] * (rows ? rows[(batched ? b : 0)][i] : 1) * factor   (in place allowed); grid (ceil(m/256), B)
+__global__ void scale_rows_kernel(int m, const double* __restrict__ w, const double* __restrict__ rows, int batched,
+                                  double factor, const int* __restrict__ active, double* __restrict__ out) {
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double v = w[(size_t)b * m + i] * factor;
+    if (rows) v *= rows[(size_t)(batched ? b : 0) * m + i];
+    out[(size_t)b * m + i] = v;
+}
+
+void launch_scale_rows(hipStream_t s, int B, int m, const double* w, const double* rows, int batched, double factor,
+                       const int* active, double* out) {
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((m + 255) / 256, B), dim3(256), 0, s, m, w, rows, batched, factor, active, out);
+}
+
 void launch_scale_weights(hipStream_t s, const FitState& st, int B, double factor) {
     hipLaunchKernelGGL(scale_weights_kernel, dim3((st.m + 255) / 256, B), dim3(256), 0, s, st, factor);
 }

@@ -131,8 +131,8 @@ class DRT(PreparedFitMixin):
                 raise ValueError(f'Invalid keyword argument {key}')     # drt1d.py:415-419
         if kw['penalty_type'] != 'integral':
             raise NotImplementedError("penalty_type 'discrete' is deprecated in the reference and not built")
-        if not kw['eff_hp'] or kw['weight_factor'] != 1:
-            raise NotImplementedError("only eff_hp=True, weight_factor=1 (the defaults) are built")
+        if not kw['eff_hp']:
+            raise NotImplementedError("only eff_hp=True (the default) is built")
         if (hypers['iw_alpha'] is None) != (hypers['iw_beta'] is None):
             raise ValueError('iw_alpha and iw_beta must be given together')
         if kw['eis_error_structure'] not in (None, 'uniform'):
@@ -221,6 +221,7 @@ class DRT(PreparedFitMixin):
         self.fit_kwargs = dict(hypers, **fkw)
         self.f_fit = frequencies
         plan.record_history(history_of)
+        plan.set_weight_factors(fkw['weight_factor'])
         plan.upload(z_batch)
         self._last_batch = z_batch.shape[0]
         return plan

@@ -19,12 +19,12 @@ from . import background, qphb
 _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (drt1d.py:102-129)
     step_times=None, step_sizes=None, offset_steps=True, step_offset_size=None, offset_baseline=True,
     smooth_inf_response=True, v_baseline_penalty=1e-6, vz_offset=True, vz_offset_scale=1, vz_offset_eps=1,
-    chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False)
+    chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False,
+    eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None)
 
 _UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False, remove_extremes=False,
                     remove_outliers=False, series_neg=False, update_scale=False,
-                    init_weights_separately=False, eis_weight_factor=None, chrono_weight_factor=None,
-                    hybrid_weight_factor_method=None, peak_locations=None, neg_allowed_tau_range=None)
+                    init_weights_separately=False, peak_locations=None, neg_allowed_tau_range=None)
 
 
 class PreparedFitMixin:
@@ -329,6 +329,34 @@ class PreparedFitMixin:
             prep['rzm'] = rzm
         prep['rp_qp_iterations'] = int(res['iterations'][0])
 
+    def _hybrid_weight_factors(self, prep, meas, hypers, ckw):
+        """drt1d.py:743-803: (chrono, eis) weight factors of a hybrid fit -- given, or from the two data sets' apparent
+        polarisation resistances ('rp'), or 1."""
+        ef, cf = ckw['eis_weight_factor'], ckw['chrono_weight_factor']
+        if prep['num_chrono'] == 0 or prep['num_eis'] == 0:
+            return 1.0, 1.0            # only hybrid fits apply them
+        if ef is not None and cf is not None:
+            return float(cf), float(ef)
+        if ef is not None or cf is not None:
+            warnings.warn("Both eis_weight_factor and chrono_weight_factor must be provided. If only one is provided, "
+                          "it will be ignored.")
+        method = ckw['hybrid_weight_factor_method']
+        if method is None:
+            return 1.0, 1.0
+        if method == 'rp':
+            times, i_signal, v_signal, frequencies, z = meas
+            rp_eis = pp.estimate_rp(None, None, None, None, None, np.asarray(z))
+            rp_chrono = pp.estimate_rp(prep['sample_times'], prep['step_times'], prep['step_sizes'],
+                                       np.asarray(v_signal, dtype=float), self.step_model, None)
+            rp_tot = prep['coefficient_scale'] * hypers['rp_scale']
+            ef_ = rp_eis ** 0.75 / (rp_chrono ** 0.25 * rp_tot ** 0.5) if ef is None else ef
+            cf_ = rp_chrono ** 0.75 / (rp_eis ** 0.25 * rp_tot ** 0.5) if cf is None else cf
+            return float(cf_), float(ef_)
+        if method == 'weight':
+            raise NotImplementedError("hybrid_weight_factor_method='weight' needs the initial weights on the host "
+                                      "between initialize_weights and the loop; not built")
+        raise ValueError(f"Invalid hybrid_weight_factor_method argument {method}. Options: 'weight', 'rp', None")
+
     def _prepared_desc(self, prep, hypers):
         d = _ffi.PreparedDesc()
         sp = prep['special']
@@ -391,6 +419,13 @@ class PreparedFitMixin:
         plan = _ffi.PreparedPlan(ctx, desc, p0['pen'], p0['vmm'], p0['h'], p0['l1'], vz_strength=p0['vz_strength'],
                                  opts=opts, capacity=len(preps))
         self._plan = plan
+        rows = []
+        for pr, meas in zip(preps, measurements):
+            cf, ef = self._hybrid_weight_factors(pr, meas, hypers, ckw)
+            pr['chrono_weight_factor'], pr['eis_weight_factor'] = cf, ef
+            rows.append(np.concatenate([np.full(pr['num_chrono'], cf), np.full(pr['m'] - pr['num_chrono'], ef)]))
+        rows = np.array(rows)
+        plan.set_weight_factors(kw['weight_factor'], None if np.all(rows == 1.0) else rows)
         plan.upload(p0['rzm'] if shared else np.stack([pr['rzm'] for pr in preps]), np.stack([pr['rzv'] for pr in preps]))
         plan.record_history(history_of)
         plan.fit()
@@ -448,7 +483,9 @@ class PreparedFitMixin:
                                   dop_rho_vector=hist['dop_rho'][i] if 'dop_rho' in hist else None)
                              for i in range(len(hist['x']))]
         rzm_final = plan.get('rzm')
-        self.qphb_params = {'weights': out['weights'][b], 'true_weights': out['weights'][b], 'rho_vector': out['rho'][b],
+        scaled = out['weights'][b] * np.concatenate([np.full(prep['num_chrono'], prep['chrono_weight_factor']),
+                                                     np.full(prep['m'] - prep['num_chrono'], prep['eis_weight_factor'])])
+        self.qphb_params = {'weights': scaled, 'true_weights': out['weights'][b], 'rho_vector': out['rho'][b],
                             'dop_rho_vector': plan.get('dop_rho')[b] if prep['dop'] else None,
                             's_vectors': list(out['s_vectors'][b]), 'p_matrix': fp['p_matrix'], 'q_vector': fp['q_vector'],
                             'rm': rzm_final[b] if rzm_final.ndim == 3 else rzm_final, 'rv': prep['rzv'], 'vmm': prep['vmm'],
@@ -457,7 +494,8 @@ class PreparedFitMixin:
                             'vz_strength_vec': prep['vz_strength'] if prep['vz_strength'] is not None else 1,
                             'xmx_norms': plan.get('xmx')[b], 'est_weights': plan.get('est_weights')[b],
                             'qp_iterations': hist['qp_iterations'], 'outer_iterations': int(out['outer_iters'][b]),
-                            'hypers': hypers}
+                            'hypers': hypers, 'chrono_weight_factor': prep['chrono_weight_factor'],
+                            'eis_weight_factor': prep['eis_weight_factor']}
         self.cvx_result = {'x': out['x'][b]}
         self.fit_type = fit_type
         self._prep = prep

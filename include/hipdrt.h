@@ -279,6 +279,14 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* des
  * hipdrt_plan_get ("dop_rho" [B][3], "xmx", "dop_xmx" [B][3], "est_weights", "rzm" [B or 1][m][n] = final matrix). */
 int hipdrt_plan_upload_prepared(hipdrt_plan* plan, int B, int rm_batched, const double* rzm, const double* rzv);
 
+/* Weight factors of _qphb_fit_core (hybdrt/models/drt1d.py:887-901, 990-1000): every outer iteration solves its QP with
+ * weights * row_factors (chrono_weight_factor on the chrono rows, eis_weight_factor on the impedance rows; NULL = 1),
+ * from the second iteration on also * weight_factor; estimate_weights keeps working on the unscaled weights.  After the
+ * fit hipdrt_plan_download returns weights * weight_factor ("true_weights"); q_vector / p_matrix / the posterior
+ * variances use those times the row factors ("scaled weights").  row_factors: [m], or [capacity][m] when batched != 0.
+ * Applies to every later hipdrt_plan_fit of the plan (any plan kind); (1.0, NULL) switches it off.                     */
+int hipdrt_plan_set_weight_factors(hipdrt_plan* plan, double weight_factor, const double* row_factors, int batched);
+
 /* kernel-time breakdown of the last hipdrt_plan_fit in ms (HIP events on the ctx stream):
  * t[0]=total, t[1]=gram, t[2]=qp, t[3]=hyper, t[4]=setup/other; launches[5] same order                 */
 int hipdrt_plan_timings(hipdrt_plan* plan, float* t, int* launches);

@@ -253,6 +253,8 @@ def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
                est_weights=qp["est_weights"], init_weights=qp["init_weights"], weights=qp["true_weights"],
                scaled_weights=qp["weights"], rho_vector=qp["rho_vector"], s_vectors=np.array(qp["s_vectors"]),
                xmx_norms=qp["xmx_norms"], qp_iterations=np.array([l["iterations"] for l in log]),
+               eis_weight_factor=np.nan if qp["eis_weight_factor"] is None else qp["eis_weight_factor"],
+               chrono_weight_factor=np.nan if qp["chrono_weight_factor"] is None else qp["chrono_weight_factor"],
                outer_iterations=len(drt.qphb_history),
                hist_x=np.array([h["x"] for h in drt.qphb_history]),
                hist_rho=np.array([h["rho_vector"] for h in drt.qphb_history]),
@@ -300,6 +302,12 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop_solverp", meas, dict(base, fit_dop=True), dict(solve_rp=True))
     run_hybrid_case(DRT, cvxopt, "golden71x91_solverp", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(solve_rp=True))
+    # weight factors (drt1d.py:743-803, 887-901, 990-1000)
+    run_hybrid_case(DRT, cvxopt, "golden71x91_wf", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
+                    dict(weight_factor=0.7))
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_wf", meas, dict(base, fit_dop=False),
+                    dict(weight_factor=1.5, eis_weight_factor=2.0, chrono_weight_factor=0.5))
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_wfrp", meas, dict(base, fit_dop=False), dict(hybrid_weight_factor_method='rp'))
     # polynomial + square-root voltage baseline (background.py:23-37; three v_baseline coefficients)
     run_hybrid_case(DRT, cvxopt, "hybrid_vb", meas, dict(base, fit_dop=False),
                     dict(v_baseline_deg=1, v_baseline_sqrt=True, v_baseline_penalty=[1e-6, 1e-4, 1e-5]))

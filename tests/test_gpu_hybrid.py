@@ -369,3 +369,31 @@ def test_polynomial_baseline_matches_reference_run():
     with pytest.raises(ValueError):
         drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], v_baseline_deg=1,
                        v_baseline_penalty=[1e-6, 1e-4, 1e-5])
+
+
+def test_weight_factors_match_reference_runs():
+    """weight_factor on an EIS fit (device plan path), explicit chrono / EIS factors and the 'rp' rule on hybrid fits"""
+    from hipdrt.models import DRT
+    g, special = load_case("golden71x91_wf")
+    drt = DRT(warn=False)
+    fp = drt.fit_eis(g["freq"], g["z"], weight_factor=0.7)
+    assert drt.qphb_params["qp_iterations"].tolist() == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(drt.qphb_params["true_weights"], g["weights"], rtol=1e-6)
+    np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
+    np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
+    drt.fit_eis(g["freq"], g["z"])                       # the factor does not stick to the plan
+    assert drt.qphb_params["outer_iterations"] == 6 and drt.qphb_params["qp_iterations"].tolist() == [6, 2, 3, 2, 2, 2, 2]
+    for name, kw in (("hybrid_s0_wf", dict(weight_factor=1.5, eis_weight_factor=2.0, chrono_weight_factor=0.5)),
+                     ("hybrid_s0_wfrp", dict(hybrid_weight_factor_method='rp'))):
+        g, special = load_case(name)
+        drt = DRT(warn=False)
+        fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], **kw)
+        np.testing.assert_allclose(drt.qphb_params["eis_weight_factor"], g["eis_weight_factor"], rtol=1e-12)
+        np.testing.assert_allclose(drt.qphb_params["chrono_weight_factor"], g["chrono_weight_factor"], rtol=1e-12)
+        _check_fit(drt, g, special, False)
+        np.testing.assert_allclose(drt.qphb_params["true_weights"], g["weights"], rtol=1e-6)
+        np.testing.assert_allclose(drt.qphb_params["weights"], g["scaled_weights"], rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], hybrid_weight_factor_method='weight')

@@ -65,6 +65,7 @@ def test_special_parameter_layout(case):
     g, special = case
     drt = DRT.__new__(DRT)
     drt.fit_ohmic = drt.fit_inductance = drt.fit_dop = True
+    drt.fit_capacitance = False
     drt.basis_nu = None
     drt.nu_epsilon = None
     sp = drt._general_special_params(True, True, True)

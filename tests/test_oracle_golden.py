@@ -247,3 +247,23 @@ def test_general_loop_solve_rp_branch(name, base):
     np.testing.assert_allclose(r["rzv"], g["rv"], rtol=1e-7, atol=1e-8 * np.abs(g["rv"]).max())
     np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(r["rzm"], g["rm"], rtol=0, atol=1e-7 * np.abs(g["rm"]).max())
+
+
+@pytest.mark.parametrize("name,wf", [("golden71x91_wf", 0.7), ("hybrid_s0_wf", 1.5), ("hybrid_s0_wfrp", 1.0)])
+def test_general_loop_weight_factors(name, wf):
+    """weight_factor / chrono- and EIS-row factors (drt1d.py:887-901, 990-1006) in the oracle's general loop"""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case(name)
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    m = len(g["rv"])
+    rows = None
+    if "num_chrono" in g:
+        nc = int(g["num_chrono"])
+        rows = np.concatenate([np.full(nc, float(g["chrono_weight_factor"])), np.full(m - nc, float(g["eis_weight_factor"]))])
+    r = orc.qphb_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, orc.get_default_hypers(),
+                              vz=vz, weight_factor=wf, row_factors=rows)
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(r["weights"], g["weights"], rtol=1e-8)                  # true_weights
+    np.testing.assert_allclose(r["p_matrix"], g["p_matrix"], rtol=1e-8, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    np.testing.assert_allclose(r["q_vector"], g["q_vector"], rtol=1e-8, atol=1e-8 * np.abs(g["q_vector"]).max())

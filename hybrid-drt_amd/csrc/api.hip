@@ -634,6 +634,7 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, 
     TRY(upload(p->l1, l1, (size_t)n * sizeof(double), st));
     if (vz_strength) TRY(upload(p->vz_strength, vz_strength, (size_t)m * sizeof(double), st));
     TRY(plan_alloc_batch(p.get()));
+    if (p->vmm_base.p) launch_vmm_exclude_self(st, p->vmm.d(), m, p->vmm_base.d());     // outlier_p: qphb.py:1644-1648
     HIPDRT_CHECK(p->dop_rho.alloc((size_t)capacity * 3 * sizeof(double)));
     HIPDRT_CHECK(p->dop_xmx.alloc((size_t)capacity * 3 * sizeof(double)));
     HIPDRT_CHECK(hipStreamSynchronize(st));
@@ -798,7 +799,6 @@ struct PhaseTimer {
 int hipdrt_plan_fit(hipdrt_plan* p) {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no spectra staged (call hipdrt_plan_upload)");
-    HIPDRT_REQUIRE(!(p->prepared && p->opts.outlier_p > 0.0), "outlier_p is not available on prepared plans");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
     const int B = p->B, n = p->n, m = p->m;

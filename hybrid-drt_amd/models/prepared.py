@@ -394,8 +394,6 @@ class PreparedFitMixin:
         """measurements: list of (times, i_signal, v_signal, frequencies, z) of identical shapes (one protocol)."""
         ckw, rest = self._split_kwargs(fit_kw)
         opts, hypers, kw = self._make_opts(rest)
-        if opts.outlier_p > 0:
-            raise NotImplementedError("outlier_p is only built for plain EIS fits")
         ctx = self._context if self._context is not None else _ffi.get_context(self.device)
         self._build_memo = {}
         preps = [self._prepare_measurement(ctx, *meas, kw, ckw, hypers) for meas in measurements]

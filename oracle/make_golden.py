@@ -302,6 +302,8 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop_solverp", meas, dict(base, fit_dop=True), dict(solve_rp=True))
     run_hybrid_case(DRT, cvxopt, "golden71x91_solverp", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(solve_rp=True))
+    # outlier-aware weights in a joint fit (qphb.py:1497-1553, 1629-1656)
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_outlier", meas, dict(base, fit_dop=False), dict(outlier_p=0.05))
     # weight factors (drt1d.py:743-803, 887-901, 990-1000)
     run_hybrid_case(DRT, cvxopt, "golden71x91_wf", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(weight_factor=0.7))

@@ -397,3 +397,18 @@ def test_weight_factors_match_reference_runs():
         np.testing.assert_allclose(drt.qphb_params["weights"], g["scaled_weights"], rtol=1e-6)
     with pytest.raises(NotImplementedError):
         drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], hybrid_weight_factor_method='weight')
+
+
+def test_outlier_p_in_a_joint_fit_matches_reference_run():
+    """outlier_p on a prepared plan: self-excluded variance matrix, two initial QPs, outlier-aware weights each iteration"""
+    from hipdrt.models import DRT
+    g, special = load_case("hybrid_s0_outlier")
+    drt = DRT(warn=False)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], outlier_p=0.05)
+    qp = drt.qphb_params
+    # history of the plan starts at the last initial QP
+    assert qp["qp_iterations"].tolist() == g["qp_iterations"].tolist()[1:]
+    assert qp["outer_iterations"] == int(g["outer_iterations"])
+    np.testing.assert_allclose(drt.cvx_result["x"], g["x_scaled"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(qp["true_weights"], g["weights"], rtol=1e-5)
+    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-4, atol=1e-7)

@@ -267,3 +267,15 @@ def test_general_loop_weight_factors(name, wf):
     np.testing.assert_allclose(r["weights"], g["weights"], rtol=1e-8)                  # true_weights
     np.testing.assert_allclose(r["p_matrix"], g["p_matrix"], rtol=1e-8, atol=1e-8 * np.abs(g["p_matrix"]).max())
     np.testing.assert_allclose(r["q_vector"], g["q_vector"], rtol=1e-8, atol=1e-8 * np.abs(g["q_vector"]).max())
+
+
+def test_general_loop_outlier_branch_hybrid():
+    """outlier_p in a joint fit: both initial QPs and the outlier-aware weights of every iteration (48 outer iterations)"""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case("hybrid_s0_outlier")
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    hyp = dict(orc.get_default_hypers(), outlier_p=0.05)
+    r = orc.qphb_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, vz=vz)
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r["weights"], g["weights"], rtol=1e-6)

@@ -400,7 +400,8 @@ class Plan:
         shapes = {"lut_z_re": (self.ngrid,), "lut_z_im": (self.ngrid,), "a_re": (self.nf, self.ntau),
                   "a_im": (self.nf, self.ntau), "rm": (self.m, self.n), "m0": (self.n, self.n),
                   "m1": (self.n, self.n), "m2": (self.n, self.n), "vmm": (self.m, self.m), "h": (self.n,),
-                  "est_weights": (self.batch, self.m), "rv": (self.batch, self.m)}
+                  "est_weights": (self.batch, self.m), "rv": (self.batch, self.m), "xmx": (self.batch, 3),
+                  "outlier_t": (self.batch, self.m)}
         out = np.empty(shapes[which])
         _check(self._lib.hipdrt_plan_get(self._h, which.encode(), _p(out), out.size))
         return out
@@ -535,7 +536,7 @@ class PreparedPlan(Plan):
         B = self.batch
         shapes = {"m0": (self.n, self.n), "m1": (self.n, self.n), "m2": (self.n, self.n), "vmm": (self.m, self.m),
                   "h": (self.n,), "est_weights": (B, self.m), "rv": (B, self.m), "xmx": (B, 3), "dop_rho": (B, 3),
-                  "dop_xmx": (B, 3), "hist_dop_rho": (int(self.opts.max_iter), 3),
+                  "dop_xmx": (B, 3), "hist_dop_rho": (int(self.opts.max_iter), 3), "outlier_t": (B, self.m),
                   "rzm": (B, self.m, self.n) if self.rm_batched else (self.m, self.n)}
         out = np.empty(shapes[which])
         _check(self._lib.hipdrt_plan_get(self._h, which.encode(), _p(out), out.size))

@@ -27,7 +27,7 @@ struct hipdrt_plan {
     int prepared = 0;
     hipdrt_prepared_desc desc{};
     long long rm_stride = 0;
-    DevBuf vz_strength, dop_rho, dop_xmx, hist_dop_rho;
+    DevBuf vz_strength, dop_rho, dop_xmx, hist_dop_rho, outlier_t;
     // weight factors (hipdrt_plan_set_weight_factors): w_eff = w * row factor * weight_factor is what the QP sees
     double weight_factor = 1.0;
     int wrow_batched = 0;
@@ -52,7 +52,7 @@ struct hipdrt_plan {
         st.opts = opts; st.continue_mode = 0; st.min_iter = 1;
         st.prepared = prepared; st.desc = desc; st.rm_stride = rm_stride; st.rm_rw = rm.d();
         st.vz_strength = vz_strength.d(); st.dop_rho = dop_rho.d(); st.dop_xmx = dop_xmx.d();
-        st.hist_dop_rho = hist_dop_rho.d();
+        st.hist_dop_rho = hist_dop_rho.d(); st.outlier_t = outlier_t.d();
         st.rm = rm.d(); st.vmm = vmm.d(); st.vmm_iw = vmm_base.p ? vmm_base.d() : vmm.d();
         for (int k = 0; k < 3; ++k) st.mk[k] = mk[k].d();
         st.z_re = z_re.d(); st.z_im = z_im.d();
@@ -522,7 +522,10 @@ static int plan_alloc_batch(hipdrt_plan* p) {
     HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->Ppk.alloc(cap * qp_ppk_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->order.alloc(cap * sizeof(int)));
-    if (p->opts.outlier_p > 0.0) HIPDRT_CHECK(p->vmm_base.alloc((size_t)m * m * sizeof(double)));
+    if (p->opts.outlier_p > 0.0) {
+        HIPDRT_CHECK(p->vmm_base.alloc((size_t)m * m * sizeof(double)));
+        HIPDRT_CHECK(p->outlier_t.alloc(cap * m * sizeof(double)));
+    }
     HIPDRT_CHECK(p->hist_rows.alloc(sizeof(int)));
     return 0;
 }
@@ -718,6 +721,7 @@ int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long co
     else if (w == "est_weights") { src = p->est_w.d(); rows = p->B; cols = ld = p->m; }   // per spectrum of the last batch
     else if (w == "rv") { src = p->rv.d(); rows = p->B; cols = ld = p->m; }
     else if (w == "xmx") { src = p->xmx.d(); rows = p->B; cols = ld = 3; }
+    else if (w == "outlier_t" && p->outlier_t.p) { src = p->outlier_t.d(); rows = p->B; cols = ld = p->m; }
     else if (w == "dop_rho" && p->prepared) { src = p->dop_rho.d(); rows = p->B; cols = ld = 3; }
     else if (w == "dop_xmx" && p->prepared) { src = p->dop_xmx.d(); rows = p->B; cols = ld = 3; }
     else if (w == "rzm") { src = p->rm.d(); rows = (p->rm_stride ? p->B : 1) * p->m; cols = p->n; ld = p->ldrm; }

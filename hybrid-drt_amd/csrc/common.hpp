@@ -146,6 +146,7 @@ struct FitState {
     double* rm_rw;         // == rm when the matrices are per spectrum (the vz_offset column is rewritten every iteration)
     const double* vz_strength;   // [m]
     double *dop_rho, *dop_xmx;   // [B][3]
+    double* outlier_t;           // [B][m] or null: 1 - posterior outlier probability of the last estimate_weights (outlier_p set)
     double* hist_dop_rho;
     // shared (plan) matrices
     const double* rm;      // [m][ldrm]  stacked [Re; Im] response matrix incl. special columns

@@ -235,6 +235,7 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* V,
             double t = 1.0 - op * pdf_out / ((1.0 - op) * pdf_in + op * pdf_out);
             if (sb > ar) t = 1.0;
             tmp3[i] = t;                                // outlier_t
+            if (st.outlier_t) st.outlier_t[(size_t)b * m + i] = t;
             tmp4[i] = sqrt(t) * tmp[i];                 // sqrt(t) o r^2
         }
         __syncthreads();

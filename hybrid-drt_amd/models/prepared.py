@@ -20,10 +20,11 @@ _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (
     step_times=None, step_sizes=None, offset_steps=True, step_offset_size=None, offset_baseline=True,
     smooth_inf_response=True, v_baseline_penalty=1e-6, vz_offset=True, vz_offset_scale=1, vz_offset_eps=1,
     chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False,
-    eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None)
+    eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None, remove_outliers=False,
+    outlier_thresh=0.75)
 
 _UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False, remove_extremes=False,
-                    remove_outliers=False, series_neg=False, update_scale=False,
+                    series_neg=False, update_scale=False,
                     init_weights_separately=False, peak_locations=None, neg_allowed_tau_range=None)
 
 
@@ -390,9 +391,59 @@ class PreparedFitMixin:
             raise ValueError(f"Invalid error_structure {ckw['chrono_error_structure']}")
         return ckw, rest
 
-    def _fit_prepared(self, measurements, fit_kw, history_of=-1):
+    # keywords _qphb_fit_core does not hand to its outlier-detection pass (drt1d.py:216-247): they take their defaults there
+    _NOT_IN_OUTLIER_PASS = ('vz_offset', 'vz_offset_scale', 'vz_offset_eps', 'eis_weight_factor', 'chrono_weight_factor',
+                            'hybrid_weight_factor_method', 'weight_factor', 'xtol', 'max_iter', 'iw_l1_lambda_0',
+                            'iw_l2_lambda_0', 'remove_outliers', 'outlier_thresh', 'step_sizes')
+
+    def _remove_outliers(self, meas, fit_kw, ckw):
+        """drt1d.py:214-302: an initialize_weights-only pass with the outlier-aware weights (device: max_iter = 0) gives
+        outlier_t; points with 1 - outlier_t above the threshold are dropped (an impedance point if either part is),
+        the step times found before the removal are kept."""
+        times, i_signal, v_signal, frequencies, z = meas
+        pass_kw = {k: v for k, v in fit_kw.items() if k not in self._NOT_IN_OUTLIER_PASS}
+        preps, plan = self._fit_prepared([meas], dict(pass_kw, max_iter=0), _init_only=True)
+        nc = preps[0]['num_chrono']
+        flagged = (1 - plan.get('outlier_t')[0]) > ckw['outlier_thresh']
+        chrono_idx = flagged[:nc] if times is not None else None
+        eis_idx = None
+        if frequencies is not None:
+            nf = len(frequencies)
+            eis_idx = flagged[nc:nc + nf] | flagged[nc + nf:]
+        self.chrono_outlier_index, self.eis_outlier_index = chrono_idx, eis_idx
+        self.chrono_outliers = self.eis_outliers = None
+        step_times = preps[0].get('step_times')
+        if times is not None and np.any(chrono_idx):
+            if self.warn:
+                warnings.warn('Found outliers in chrono data at the following '
+                              f'indices: {np.where(chrono_idx)[0].tolist()}. These data points will be removed before fitting')
+            times, i_signal, v_signal = (np.asarray(a) for a in (times, i_signal, v_signal))
+            self.chrono_outliers = (times[chrono_idx], i_signal[chrono_idx], v_signal[chrono_idx])
+            times, i_signal, v_signal = times[~chrono_idx], i_signal[~chrono_idx], v_signal[~chrono_idx]
+        if frequencies is not None and np.any(eis_idx):
+            if self.warn:
+                warnings.warn('Found outliers in EIS data at the following '
+                              f'indices: {np.where(eis_idx)[0].tolist()}. These data points will be removed before fitting')
+            frequencies, z = np.asarray(frequencies), np.asarray(z)
+            self.eis_outliers = (frequencies[eis_idx], z[eis_idx])
+            frequencies, z = frequencies[~eis_idx], z[~eis_idx]
+        return (times, i_signal, v_signal, frequencies, z), step_times
+
+    def _fit_prepared(self, measurements, fit_kw, history_of=-1, _init_only=False):
         """measurements: list of (times, i_signal, v_signal, frequencies, z) of identical shapes (one protocol)."""
         ckw, rest = self._split_kwargs(fit_kw)
+        if ckw['remove_outliers']:
+            if rest.get('outlier_p') is None:
+                raise ValueError('If remove_outliers is True, the prior probability of outlier presence, outlier_p, '
+                                 'must be specified. A good starting value might be 0.01-0.05')
+            if len(measurements) != 1:
+                raise NotImplementedError("remove_outliers changes the data size per measurement: single fits only")
+            meas, step_times = self._remove_outliers(measurements[0], fit_kw, ckw)
+            measurements = [meas]
+            fit_kw = dict(fit_kw, remove_outliers=False, outlier_p=None)
+            if step_times is not None:
+                fit_kw.update(step_times=step_times, step_sizes=None)
+            ckw, rest = self._split_kwargs(fit_kw)
         opts, hypers, kw = self._make_opts(rest)
         ctx = self._context if self._context is not None else _ffi.get_context(self.device)
         self._build_memo = {}
@@ -425,8 +476,10 @@ class PreparedFitMixin:
         rows = np.array(rows)
         plan.set_weight_factors(kw['weight_factor'], None if np.all(rows == 1.0) else rows)
         plan.upload(p0['rzm'] if shared else np.stack([pr['rzm'] for pr in preps]), np.stack([pr['rzv'] for pr in preps]))
-        plan.record_history(history_of)
+        plan.record_history(-1 if _init_only else history_of)
         plan.fit()
+        if _init_only:
+            return preps, plan
         out = plan.download(s_vectors=True)
         self.basis_tau = p0['basis_tau']
         self.special_qp_params = p0['special']

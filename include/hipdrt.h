@@ -276,7 +276,9 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* des
 /* stage B measurements: rzm [B][m][n] (rm_batched != 0) or one shared [m][n]; rzv [B][m].  A vz_offset column needs
  * per-measurement matrices.  Then hipdrt_plan_fit; results through hipdrt_plan_download (x, weights, rho, s_vectors,
  * q_vector, iteration counts, status; pass NULL for fit_x / r_inf / induc), hipdrt_plan_get_p_matrix and
- * hipdrt_plan_get ("dop_rho" [B][3], "xmx", "dop_xmx" [B][3], "est_weights", "rzm" [B or 1][m][n] = final matrix). */
+ * hipdrt_plan_get ("dop_rho" [B][3], "xmx", "dop_xmx" [B][3], "est_weights", "rzm" [B or 1][m][n] = final matrix;
+ * with outlier_p set also "outlier_t" [B][m], qphb.py:1497-1520, of the last weight estimation -- with max_iter = 0 that
+ * is initialize_weights', which is what remove_outliers thresholds, drt1d.py:817-833).                                  */
 int hipdrt_plan_upload_prepared(hipdrt_plan* plan, int B, int rm_batched, const double* rzm, const double* rzv);
 
 /* Weight factors of _qphb_fit_core (hybdrt/models/drt1d.py:887-901, 990-1000): every outer iteration solves its QP with

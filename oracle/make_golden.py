@@ -265,6 +265,10 @@ def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
         out["z_sigma_tot"] = fp["z_sigma_tot"]
     else:
         del out["freq"], out["z"], out["impedance_scale"]
+    if fit_kw.get("remove_outliers"):
+        out["eis_outlier_index"] = drt.eis_outlier_index
+        if times is not None:
+            out["chrono_outlier_index"] = drt.chrono_outlier_index
     if drt.fit_dop:
         out.update(basis_nu=drt.basis_nu, nu_epsilon=drt.nu_epsilon, dop_scale_vector=drt.dop_scale_vector,
                    dop_rho_vector=qp["dop_rho_vector"], dop_xmx_norms=qp["dop_xmx_norms"], x_dop=fp["x_dop"],
@@ -304,6 +308,14 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
                     dict(solve_rp=True))
     # outlier-aware weights in a joint fit (qphb.py:1497-1553, 1629-1656)
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_outlier", meas, dict(base, fit_dop=False), dict(outlier_p=0.05))
+    # remove_outliers (drt1d.py:214-302, 817-833): an initialize_weights-only pass flags points, the fit runs without them
+    t_o, i_o, v_o, f_o, z_o = synth.hybrid_measurement(seed=4)
+    z_o = z_o.copy(); v_o = v_o.copy()
+    z_o[10] += 0.3; z_o[25] -= 0.25j; v_o[100] += 5e-5; v_o[180] -= 8e-5
+    run_hybrid_case(DRT, cvxopt, "hybrid_rmout", (t_o, i_o, v_o, f_o, z_o), dict(base, fit_dop=False),
+                    dict(remove_outliers=True, outlier_p=0.05))
+    run_hybrid_case(DRT, cvxopt, "eis_rmout", (None, None, None, f_o, z_o), dict(base, fit_dop=False),
+                    dict(remove_outliers=True, outlier_p=0.05))
     # weight factors (drt1d.py:743-803, 887-901, 990-1000)
     run_hybrid_case(DRT, cvxopt, "golden71x91_wf", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(weight_factor=0.7))

@@ -412,3 +412,26 @@ def test_outlier_p_in_a_joint_fit_matches_reference_run():
     np.testing.assert_allclose(drt.cvx_result["x"], g["x_scaled"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(qp["true_weights"], g["weights"], rtol=1e-5)
     np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["eis_rmout", "hybrid_rmout"])
+def test_remove_outliers_matches_reference_run(name):
+    """remove_outliers=True: the initialize_weights-only detection pass flags the same points as the reference, the fit on
+    the cleaned data follows the same trajectory"""
+    from hipdrt.models import DRT
+    g, special = load_case(name)
+    drt = DRT(warn=False)
+    if "times" in g:
+        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], remove_outliers=True, outlier_p=0.05)
+        np.testing.assert_array_equal(drt.chrono_outlier_index, g["chrono_outlier_index"])
+        n_pass1 = 2
+    else:
+        drt.fit_eis(g["freq"], g["z"], remove_outliers=True, outlier_p=0.05)
+        n_pass1 = 2
+    np.testing.assert_array_equal(drt.eis_outlier_index, g["eis_outlier_index"])
+    assert np.array_equal(np.where(g["eis_outlier_index"])[0], [10, 25])            # the two corrupted impedance points
+    g2 = {k: g[k] for k in g.files}
+    g2["qp_iterations"] = g["qp_iterations"][n_pass1:]                              # the detection pass' two QPs come first
+    _check_fit(drt, g2, special, False)
+    with pytest.raises(ValueError):
+        drt.fit_eis(g["freq"], g["z"], remove_outliers=True)

@@ -170,7 +170,8 @@ class DRT(PreparedFitMixin):
                          ('vmm_reim_cor', 'eis_reim_cor')):     # fit_eis's own keyword names (drt1d.py:1215-1241)
             if old in kw:
                 kw[new] = kw.pop(old)
-        if self.fit_dop or self.fit_capacitance or kw.get('solve_rp') or kw.get('remove_outliers'):   # prepared-matrix plan
+        if self.fit_dop or self.fit_capacitance or kw.get('solve_rp') or kw.get('remove_outliers') \
+                or kw.get('remove_extremes'):   # prepared-matrix plan
             return self._store_single(*self._fit_prepared([(None, None, None, frequencies, z)], kw, history_of=0),
                                       'qphb_eis')
         res = self._fit(frequencies, z[None, :], kw, history_of=0)

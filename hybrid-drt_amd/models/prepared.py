@@ -21,9 +21,9 @@ _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (
     smooth_inf_response=True, v_baseline_penalty=1e-6, vz_offset=True, vz_offset_scale=1, vz_offset_eps=1,
     chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False,
     eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None, remove_outliers=False,
-    outlier_thresh=0.75)
+    outlier_thresh=0.75, remove_extremes=False, extreme_kw=None)
 
-_UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False, remove_extremes=False,
+_UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False,
                     series_neg=False, update_scale=False,
                     init_weights_separately=False, peak_locations=None, neg_allowed_tau_range=None)
 
@@ -432,6 +432,31 @@ class PreparedFitMixin:
     def _fit_prepared(self, measurements, fit_kw, history_of=-1, _init_only=False):
         """measurements: list of (times, i_signal, v_signal, frequencies, z) of identical shapes (one protocol)."""
         ckw, rest = self._split_kwargs(fit_kw)
+        if ckw['remove_extremes']:
+            # drt1d.py:187-212: rough pre-filter on the raw signals (quantile-range rule), before anything else
+            if len(measurements) != 1:
+                raise NotImplementedError("remove_extremes changes the data size per measurement: single fits only")
+            ekw = ckw['extreme_kw'] if ckw['extreme_kw'] is not None else {'qr_size': 0.8, 'qr_thresh': 1.5}
+            times, i_signal, v_signal, frequencies, z = measurements[0]
+            if times is not None:
+                times, i_signal, v_signal = (np.asarray(a) for a in (times, i_signal, v_signal))
+                flag = pp.identify_extreme_values(i_signal, **ekw) | pp.identify_extreme_values(v_signal, **ekw)
+                if np.any(flag):
+                    if self.warn:
+                        warnings.warn('Identified extreme values in chrono data at the following '
+                                      f'indices: {np.where(flag)[0].tolist()}. These data points will be removed before fitting')
+                    times, i_signal, v_signal = times[~flag], i_signal[~flag], v_signal[~flag]
+            if frequencies is not None:
+                frequencies, z = np.asarray(frequencies), np.asarray(z)
+                flag = pp.identify_extreme_values(z.real, **ekw) | pp.identify_extreme_values(z.imag, **ekw)
+                if np.any(flag):
+                    if self.warn:
+                        warnings.warn('Identified extreme values in EIS data at the following '
+                                      f'indices: {np.where(flag)[0].tolist()}. These data points will be removed before fitting')
+                    frequencies, z = frequencies[~flag], z[~flag]
+            measurements = [(times, i_signal, v_signal, frequencies, z)]
+            fit_kw = dict(fit_kw, remove_extremes=False)
+            ckw, rest = self._split_kwargs(fit_kw)
         if ckw['remove_outliers']:
             if rest.get('outlier_p') is None:
                 raise ValueError('If remove_outliers is True, the prior probability of outlier presence, outlier_p, '

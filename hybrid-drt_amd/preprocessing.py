@@ -166,3 +166,16 @@ def estimate_rp(times, step_times, input_step_sizes, response_signal, step_model
     if z is not None:
         r_min, r_max = min(r_min, np.min(z.real)), max(r_max, np.max(z.real))
     return r_max - r_min
+
+
+def get_quantile_limits(y, qr_size=0.5, qr_thresh=1.5):
+    """preprocessing.get_quantile_limits (844-851): the central quantile range stretched by qr_thresh on both sides."""
+    q_lo = np.percentile(y, 50 - 100 * qr_size / 2)
+    q_hi = np.percentile(y, 50 + 100 * qr_size / 2)
+    return q_lo - (q_hi - q_lo) * qr_thresh, q_hi + (q_hi - q_lo) * qr_thresh
+
+
+def identify_extreme_values(y, qr_size=0.5, qr_thresh=1.5):
+    """preprocessing.identify_extreme_values (854-857)."""
+    y_min, y_max = get_quantile_limits(y, qr_size, qr_thresh)
+    return (y < y_min) | (y > y_max)

@@ -435,3 +435,15 @@ def test_remove_outliers_matches_reference_run(name):
     _check_fit(drt, g2, special, False)
     with pytest.raises(ValueError):
         drt.fit_eis(g["freq"], g["z"], remove_outliers=True)
+
+
+def test_remove_extremes_matches_reference_run():
+    """remove_extremes=True: quantile-range pre-filter of the raw data (preprocessing.py:844-857), then the normal fit"""
+    from hipdrt.models import DRT
+    from hipdrt import preprocessing as pp
+    g, special = load_case("eis_rmext")
+    flag = pp.identify_extreme_values(g["z"].real, 0.8, 1.5) | pp.identify_extreme_values(g["z"].imag, 0.8, 1.5)
+    assert np.sum(flag) == len(g["z"]) - g["rm"].shape[0] // 2 and flag[10] and flag[40]
+    drt = DRT(warn=False)
+    drt.fit_eis(g["freq"], g["z"], remove_extremes=True)
+    _check_fit(drt, g, special, False)

@@ -35,7 +35,7 @@ class FitOpts(C.Structure):
         ("ohmic_penalty", C.c_double), ("inductance_penalty", C.c_double), ("inductance_scale", C.c_double),
         ("eis_vmm_epsilon", C.c_double), ("eis_reim_cor", C.c_double), ("xtol", C.c_double),
         ("max_iter", C.c_int), ("nonneg", C.c_int), ("scale_data", C.c_int), ("fit_ohmic", C.c_int),
-        ("fit_inductance", C.c_int), ("eis_error_uniform", C.c_int),
+        ("fit_inductance", C.c_int), ("eis_error_uniform", C.c_int), ("update_scale", C.c_int),
         ("outlier_p", C.c_double), ("iw_alpha", C.c_double), ("iw_beta", C.c_double), ("qp", QpOpts),
     ]
 
@@ -45,7 +45,8 @@ class PreparedDesc(C.Structure):
     _fields_ = [
         ("m", C.c_int), ("n", C.c_int), ("ns", C.c_int), ("dop_start", C.c_int), ("dop_size", C.c_int),
         ("vz_index", C.c_int), ("vb_start", C.c_int), ("vb_size", C.c_int), ("num_chrono", C.c_int),
-        ("toeplitz_m", C.c_int), ("dop_l2_lambda_0", C.c_double), ("dop_derivative_weights", C.c_double * 3),
+        ("toeplitz_m", C.c_int), ("basis_area", C.c_double), ("dop_l2_lambda_0", C.c_double),
+        ("dop_derivative_weights", C.c_double * 3),
         ("dop_s_alpha", C.c_double * 3), ("dop_rho_alpha", C.c_double * 3), ("dop_s_0", C.c_double * 3),
         ("dop_rho_0", C.c_double * 3),
     ]

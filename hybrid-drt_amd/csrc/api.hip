@@ -50,6 +50,7 @@ struct hipdrt_plan {
         FitState st{};
         st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm; st.toeplitz_m = toeplitz_m;
         st.opts = opts; st.continue_mode = 0; st.min_iter = 1;
+        st.basis_area = prepared ? desc.basis_area : (eps > 0 ? 1.7724538509055159 / eps : 0.0);   // sqrt(pi) / epsilon
         st.prepared = prepared; st.desc = desc; st.rm_stride = rm_stride; st.rm_rw = rm.d();
         st.vz_strength = vz_strength.d(); st.dop_rho = dop_rho.d(); st.dop_xmx = dop_xmx.d();
         st.hist_dop_rho = hist_dop_rho.d(); st.outlier_t = outlier_t.d();
@@ -472,6 +473,7 @@ void hipdrt_default_fit_opts(hipdrt_fit_opts* o) {
     o->ohmic_penalty = 1e-6; o->inductance_penalty = 1e-6; o->inductance_scale = 1e-5;
     o->eis_vmm_epsilon = 0.25; o->eis_reim_cor = 0.25;
     o->xtol = 1e-2; o->max_iter = 50; o->nonneg = 1; o->scale_data = 1; o->fit_ohmic = 1; o->fit_inductance = 1;
+    o->update_scale = 0;
     o->eis_error_uniform = 0;
     o->outlier_p = -1.0; o->iw_alpha = -1.0; o->iw_beta = -1.0;
     o->qp = default_qp_opts();
@@ -615,6 +617,7 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, 
     HIPDRT_REQUIRE(d->vz_index < d->ns && (d->vz_index < 0 || vz_strength), "vz_offset column / strength vector");
     HIPDRT_REQUIRE(d->vb_size >= 0 && d->vb_start >= 0 && d->vb_start + d->vb_size <= d->ns, "v_baseline columns");
     HIPDRT_REQUIRE(d->num_chrono >= 0 && d->num_chrono <= d->m, "num_chrono");
+    HIPDRT_REQUIRE(!(opts && opts->update_scale) || d->basis_area > 0.0, "update_scale needs desc.basis_area");
     HIPDRT_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     std::unique_ptr<hipdrt_plan> p(new hipdrt_plan());

@@ -138,6 +138,7 @@ struct FitState {
     int toeplitz_m;        // penalty blocks are symmetric Toeplitz (uniform ln-tau grid): first column suffices
     int continue_mode;     // warm restart (_continue_from_init): xmx norms stay frozen
     int min_iter;          // a spectrum may only stop once it has done this many outer iterations (fit: 1)
+    double basis_area;     // area of one tau basis function (sqrt(pi) / epsilon): predict_r_p of update_scale
     hipdrt_fit_opts opts;
     // prepared-matrix plans (hipdrt_plan_create_prepared): any data type, optional x_dop block and vz_offset column
     int prepared;

@@ -552,9 +552,27 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         for (int i = tid; i < m; i += HT)
             rmb[(size_t)i * st.ldrm + vz] = (i < st.desc.num_chrono ? tmp[i] : -tmp[i]) * st.vz_strength[i];
     }
+    const bool stop = conv && it + 1 >= st.min_iter;          // `converged and it >= min_iter - 1` (drt1d.py:1356)
+    if (st.opts.update_scale && st.opts.scale_data && it >= 1 && !stop && it + 1 < st.opts.max_iter && !st.continue_mode) {
+        // drt1d.py:903-927, executed by the reference at the top of the NEXT iteration (it > 1 there): keep the apparent
+        // polarisation resistance at rp_scale by rescaling the data and everything that carries its units
+        __syncthreads();
+        double part = 0.0;
+        for (int i = ns + tid; i < n; i += HT) part += fabs(xs[i]);
+        const double rp = blk_sum(part, red) * st.basis_area;                 // predict_r_p(absolute=True, raw=True)
+        const double sf = sqrt(st.opts.rp_scale / rp);                        // damped scale factor
+        for (int i = tid; i < n; i += HT) xin[i] *= sf;
+        double* rvb = st.rv + (size_t)b * m;
+        double* ewb = st.est_w + (size_t)b * m;
+        for (int i = tid; i < m; i += HT) { rvb[i] *= sf; ewb[i] /= sf; wg[i] /= sf; }
+        if (tid < 3) {
+            st.xmx[(size_t)b * 3 + tid] *= sqrt(sf);                          // as coded upstream (drt1d.py:918)
+            if (st.prepared && st.desc.dop_size > 0) st.dop_xmx[(size_t)b * 3 + tid] *= sqrt(sf);
+        }
+        if (tid == 0) { st.coef_scale[b] /= sf; st.var_floor[b] *= sf * sf; }
+    }
     if (tid == 0) {
         st.outer_iters[b] = it + 1;
-        const bool stop = conv && it + 1 >= st.min_iter;      // `converged and it >= min_iter - 1` (drt1d.py:1356)
         if (stop) { st.active[b] = 0; st.fit_status[b] = 0; }
         else if (it + 1 >= st.opts.max_iter) { st.active[b] = 0; st.fit_status[b] = 1; }
         if (!stop && it + 1 < st.opts.max_iter) atomicAdd(st.n_active, 1);

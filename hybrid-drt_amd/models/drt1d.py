@@ -17,7 +17,7 @@ from .prepared import PreparedFitMixin
 
 _FIT_KW_DEFAULTS = dict(  # DRT._qphb_fit_core keyword defaults (drt1d.py:102-137) that the device loop honours
     nonneg=True, scale_data=True, ohmic_penalty=1e-6, inductance_penalty=1e-6, inductance_scale=1e-5,
-    capacitance_penalty=1e-6, capacitance_scale=1e-3,
+    capacitance_penalty=1e-6, capacitance_scale=1e-3, update_scale=False,
     penalty_type='integral', eis_error_structure=None, eis_vmm_epsilon=0.25, eis_reim_cor=0.25,
     iw_l1_lambda_0=1e-4, iw_l2_lambda_0=1e-4, eff_hp=True, weight_factor=1, xtol=1e-2, max_iter=50)
 
@@ -156,6 +156,7 @@ class DRT(PreparedFitMixin):
         o.nonneg, o.scale_data = int(bool(kw['nonneg'])), int(bool(kw['scale_data']))
         o.fit_ohmic, o.fit_inductance = int(self.fit_ohmic), int(self.fit_inductance)
         o.eis_error_uniform = int(kw['eis_error_structure'] == 'uniform')
+        o.update_scale = int(bool(kw['update_scale']))
         return o, hypers, kw
 
     # ---- the fits ------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (
     outlier_thresh=0.75, remove_extremes=False, extreme_kw=None)
 
 _UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False,
-                    series_neg=False, update_scale=False,
+                    series_neg=False,
                     init_weights_separately=False, peak_locations=None, neg_allowed_tau_range=None)
 
 
@@ -367,6 +367,7 @@ class PreparedFitMixin:
         d.vb_start, d.vb_size = (sp['v_baseline']['index'], sp['v_baseline']['size']) if 'v_baseline' in sp else (0, 0)
         d.num_chrono = prep['num_chrono']
         d.toeplitz_m = int(prep['toeplitz_m'])
+        d.basis_area = float(np.sqrt(np.pi) / self.tau_epsilon)
         if prep['dop']:
             d.dop_l2_lambda_0 = float(hypers['dop_l2_lambda_0'])
             for name in ('dop_derivative_weights', 'dop_s_alpha', 'dop_rho_alpha', 'dop_s_0', 'dop_rho_0'):
@@ -506,6 +507,18 @@ class PreparedFitMixin:
         if _init_only:
             return preps, plan
         out = plan.download(s_vectors=True)
+        if opts.update_scale:
+            # the device divided its scale (started at 1) by every update's factor: fold it into the host-side scales
+            # (update_data_scale, drtbase.py:516-536) and take the rescaled data vector back
+            rv_dev = plan.get('rv')
+            for b, pr in enumerate(preps):
+                f = float(out['coefficient_scale'][b])
+                pr['coefficient_scale'] *= f
+                pr['impedance_scale'] *= f
+                if pr['response_signal_scale'] is not None:
+                    pr['response_signal_scale'] *= f
+                    pr['scaled_response_offset'] /= f
+                pr['rzv'] = rv_dev[b]
         self.basis_tau = p0['basis_tau']
         self.special_qp_params = p0['special']
         self.fit_kwargs = dict(hypers, **kw, **ckw)

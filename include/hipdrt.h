@@ -166,6 +166,7 @@ typedef struct {
     int scale_data;                  /* 1 */
     int fit_ohmic, fit_inductance;   /* 1, 1 */
     int eis_error_uniform;           /* 0 (eis_error_structure=None) */
+    int update_scale;                /* 0; 1: re-scale the data every iteration from the second on (drt1d.py:903-927) */
     /* optional branches of the weight estimation; <= 0 means None (the reference defaults) */
     double outlier_p;                /* prior outlier probability, qphb.py:1497-1553, 1629-1656 */
     double iw_alpha, iw_beta;        /* prior on the initial weights, qphb.py:1471-1479, 1679 */
@@ -262,6 +263,7 @@ typedef struct {
     int vb_start, vb_size;     /* v_baseline columns: excluded from the vz prediction (drt1d.py:507-511)              */
     int num_chrono;            /* rows [0, num_chrono) are chrono samples, the rest [Re; Im] impedance rows           */
     int toeplitz_m;            /* DRT block of the penalty matrices is symmetric Toeplitz (uniform ln tau)            */
+    double basis_area;         /* area of one tau basis function, sqrt(pi)/epsilon for the Gaussian basis (update_scale) */
     double dop_l2_lambda_0;                                       /* qphb.py:243-253 */
     double dop_derivative_weights[3], dop_s_alpha[3], dop_rho_alpha[3], dop_s_0[3], dop_rho_0[3];
 } hipdrt_prepared_desc;

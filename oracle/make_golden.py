@@ -319,6 +319,10 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     z_x = z_o.copy(); z_x[10] += 5.0; z_x[40] -= 4.0j        # gross errors: remove_extremes (drt1d.py:187-212)
     run_hybrid_case(DRT, cvxopt, "eis_rmext", (None, None, None, f_o, z_x), dict(base, fit_dop=False),
                     dict(remove_extremes=True))
+    # update_scale=True (drt1d.py:903-927)
+    run_hybrid_case(DRT, cvxopt, "golden71x91_upscale", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
+                    dict(update_scale=True))
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop_upscale", meas, dict(base, fit_dop=True), dict(update_scale=True))
     # weight factors (drt1d.py:743-803, 887-901, 990-1000)
     run_hybrid_case(DRT, cvxopt, "golden71x91_wf", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(weight_factor=0.7))

@@ -447,3 +447,28 @@ def test_remove_extremes_matches_reference_run():
     drt = DRT(warn=False)
     drt.fit_eis(g["freq"], g["z"], remove_extremes=True)
     _check_fit(drt, g, special, False)
+
+
+def test_update_scale_matches_reference_runs():
+    """update_scale=True on the EIS plan path and on a prepared (hybrid + DOP) plan: the rescale runs inside the hyper kernel"""
+    from hipdrt.models import DRT
+    g, special = load_case("golden71x91_upscale")
+    drt = DRT(warn=False)
+    fp = drt.fit_eis(g["freq"], g["z"], update_scale=True)
+    assert drt.qphb_params["qp_iterations"].tolist() == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(drt.coefficient_scale, g["coefficient_scale"], rtol=1e-8)
+    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(fp["R_inf"], g["R_inf"], rtol=1e-6)
+    np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
+    np.testing.assert_allclose(drt.qphb_params["rv"], g["rv"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(drt.qphb_params["est_weights"], g["est_weights"], rtol=1e-6)
+    np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
+    np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    g, special = load_case("hybrid_s0_dop_upscale")
+    drt = DRT(fit_dop=True, warn=False)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], update_scale=True)
+    np.testing.assert_allclose(drt.coefficient_scale, g["coefficient_scale"], rtol=1e-8)
+    np.testing.assert_allclose(drt.response_signal_scale, g["response_signal_scale"], rtol=1e-8)
+    _check_fit(drt, g, special, True, data_rtol=1e-7, mat_rtol=1e-8)
+    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-6)
+    np.testing.assert_allclose(drt.qphb_params["xmx_norms"], g["xmx_norms"], rtol=1e-6)

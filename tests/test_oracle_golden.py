@@ -279,3 +279,33 @@ def test_general_loop_outlier_branch_hybrid():
     assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
     np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(r["weights"], g["weights"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,base", [("golden71x91_upscale", "golden71x91_dop"), ("hybrid_s0_dop_upscale", "hybrid_s0_dop")])
+def test_general_loop_update_scale(name, base):
+    """update_scale=True (drt1d.py:903-927): per-iteration rescale of the data, x_in, xmx norms and weights; the oracle
+    starts from the un-rescaled data vector (final one divided by the accumulated factor) and must end at the fixture's"""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case(name)
+    hyp = orc.get_default_hypers()
+    if "x_dop" in special:
+        hyp.update(orc.get_default_dop_hypers())
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    if "times" in g:
+        gb, _ = load_case(base)
+        total = float(gb["coefficient_scale"] / g["coefficient_scale"])
+        rzv0 = gb["rv"]
+    else:
+        cs0 = (g["z"].real.max() - g["z"].real.min()) / 14
+        total = cs0 / float(g["coefficient_scale"])
+        rzv0 = g["rv"] / total
+    r = orc.qphb_fit_prepared(rzm0, rzv0, [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, vz=vz,
+                              update_scale=dict(basis_area=np.sqrt(np.pi) / float(g["tau_epsilon"])))
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    assert abs(total - 1) > 1e-4                      # the scale really moved
+    np.testing.assert_allclose(r["data_scale"], total, rtol=1e-8)
+    np.testing.assert_allclose(r["rzv"], g["rv"], rtol=1e-7, atol=1e-9 * np.abs(g["rv"]).max())
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r["weights"], g["weights"], rtol=1e-7)
+    np.testing.assert_allclose(r["est_weights"], g["est_weights"], rtol=1e-7)
+    np.testing.assert_allclose(r["xmx_norms"], g["xmx_norms"], rtol=1e-6)

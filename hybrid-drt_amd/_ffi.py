@@ -36,6 +36,7 @@ class FitOpts(C.Structure):
         ("eis_vmm_epsilon", C.c_double), ("eis_reim_cor", C.c_double), ("xtol", C.c_double),
         ("max_iter", C.c_int), ("nonneg", C.c_int), ("scale_data", C.c_int), ("fit_ohmic", C.c_int),
         ("fit_inductance", C.c_int), ("eis_error_uniform", C.c_int), ("update_scale", C.c_int),
+        ("eff_hp", C.c_int),
         ("outlier_p", C.c_double), ("iw_alpha", C.c_double), ("iw_beta", C.c_double), ("qp", QpOpts),
     ]
 
@@ -88,6 +89,7 @@ SIGNATURES = {
                                     C.c_int, C.POINTER(_vp)],
     "hipdrt_plan_upload_prepared": [_vp, C.c_int, C.c_int, _dp, _dp],
     "hipdrt_plan_set_weight_factors": [_vp, C.c_double, _dp, C.c_int],
+    "hipdrt_plan_set_init_h": [_vp, _dp],
     "hipdrt_plan_destroy": [_vp],
     "hipdrt_plan_dims": [_vp, _ip, _ip, _ip],
     "hipdrt_plan_get": [_vp, C.c_char_p, _dp, C.c_longlong],
@@ -444,6 +446,10 @@ class Plan:
             rf = _f64(np.vstack([rf, np.ones((self.capacity - rf.shape[0], rf.shape[1]))]))
         _check(self._lib.hipdrt_plan_set_weight_factors(self._h, float(weight_factor), _p(rf),
                                                         int(rf is not None and rf.ndim == 2)))
+
+    def set_init_h(self, h_init):
+        h = None if h_init is None else _f64(h_init)
+        _check(self._lib.hipdrt_plan_set_init_h(self._h, _p(h)))
 
     def record_history(self, b):
         _check(self._lib.hipdrt_plan_record_history(self._h, int(b)))

@@ -31,7 +31,7 @@ struct hipdrt_plan {
     // weight factors (hipdrt_plan_set_weight_factors): w_eff = w * row factor * weight_factor is what the QP sees
     double weight_factor = 1.0;
     int wrow_batched = 0;
-    DevBuf wrow, w_eff;
+    DevBuf wrow, w_eff, h_init;
     bool has_weight_factors() const { return weight_factor != 1.0 || wrow.p != nullptr; }
     // shared
     DevBuf freq, tau, ln_tau, wt_re, wt_im, lut6, a_re, a_im, cr, rm, mk[3], vmm, h, l1;
@@ -473,7 +473,7 @@ void hipdrt_default_fit_opts(hipdrt_fit_opts* o) {
     o->ohmic_penalty = 1e-6; o->inductance_penalty = 1e-6; o->inductance_scale = 1e-5;
     o->eis_vmm_epsilon = 0.25; o->eis_reim_cor = 0.25;
     o->xtol = 1e-2; o->max_iter = 50; o->nonneg = 1; o->scale_data = 1; o->fit_ohmic = 1; o->fit_inductance = 1;
-    o->update_scale = 0;
+    o->update_scale = 0; o->eff_hp = 1;
     o->eis_error_uniform = 0;
     o->outlier_p = -1.0; o->iw_alpha = -1.0; o->iw_beta = -1.0;
     o->qp = default_qp_opts();
@@ -687,6 +687,15 @@ int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const d
     return HIPDRT_OK;
 }
 
+int hipdrt_plan_set_init_h(hipdrt_plan* p, const double* h_init) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    if (!h_init) { p->h_init.release(); return HIPDRT_OK; }
+    TRY(upload(p->h_init, h_init, (size_t)p->n * sizeof(double), p->ctx->stream));
+    HIPDRT_CHECK(hipStreamSynchronize(p->ctx->stream));
+    return HIPDRT_OK;
+}
+
 int hipdrt_plan_destroy(hipdrt_plan* plan) {
     if (plan) { (void)hipSetDevice(plan->ctx->device); delete plan; }
     return HIPDRT_OK;
@@ -844,6 +853,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     tm.mark(2);
     qa.P = Prow; qa.p_stride = shared_rm ? 0 : pstr; qa.active = nullptr;
     qa.Ppk = p->Ppk.d(); qa.ppk_stride = shared_rm ? 0 : pkstr; qa.nchp = qp_nchp(n);
+    if (p->h_init.p) qa.h = p->h_init.d();          // initialize_weights' own constraint vector
     TRY(launch_qp(st, qa));
     tm.mark(3);
     if (p->opts.outlier_p > 0.0) {
@@ -867,6 +877,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
 
     // ---- outer loop (drt1d.py:877-988) ----------------------------------------------------------------------
     g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, dop_l2);
+    qa.h = p->h.d();
     qa.p_stride = (long long)n * p->ldp; qa.active = p->active.i();
     qa.ppk_stride = (long long)qp_ppk_doubles(n);
     int it = 0;

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
     // (with the G matrix for k = 0) or the x_dop block (qphb.py:822-933, no G matrix)
     auto update_block = [&](const int k, const double* xd, const int nd, const int off, const bool tpl, const bool use_g,
                             const double alpha, const double s0, const double sigma, const double ra, const double r0,
-                            double* rho_out, const double* xmx_in) {
+                            double* rho_out, const double* xmx_in, const double reff) {
         double* sk = st.s + ((size_t)b * 3 + k) * n + off;
         const double* Mk = st.mk[k] + (size_t)off * st.ldm + off;
         const double* M1 = st.mk[1] + (size_t)off * st.ldm + off;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             const double* c1 = ctp + cw + (nd - 1);
             double lmax = 0.0;
             for (int i = wv; i < nd; i += HNW) {
-                const double xi = xd[i];
+                const double xi = xd[i], xr = reff * xi;      // rho_k_eff * x_i (1 under eff_hp, qphb.py:747-750)
                 const int jd = i & ~63;                        // the 64-column chunk that holds the diagonal
                 double s0 = 0.0;
                 if (use_g) {
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
                     for (int j0 = 0; j0 < nd; j0 += 64) {
                         const int j = j0 + lane;
                         if (j < nd) {
-                            double gu = xi * (ck[i - j] * vs[j]) + xhs * (c1[i - j] * vh[j]);
+                            double gu = xr * (ck[i - j] * vs[j]) + xhs * (c1[i - j] * vh[j]);
                             if (j0 == jd && j == i) gu = 0.0;
                             s0 += gu;
                             lmax = fmax(lmax, fabs(gu));
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
                     s0 = hw_sum(s0);
                     if (lane == 0) {
                         bsum[i] = s0;
-                        gdia[i] = ((xi * ck[0]) * xi + ((xh[i] * c1[0]) * xh[i]) / sig2) + beta;
+                        gdia[i] = ((xr * ck[0]) * xi + ((xh[i] * c1[0]) * xh[i]) / sig2) + beta;
                     }
                 } else {
                     double mx0 = 0.0;
@@ -409,8 +409,8 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
                         }
                     }
                     s0 = hw_sum(s0);
-                    lmax = fmax(lmax, fabs(xi) * mx0);
-                    if (lane == 0) { bsum[i] = xi * s0; gdia[i] = (xi * ck[0]) * xi + beta; }
+                    lmax = fmax(lmax, fabs(xr) * mx0);
+                    if (lane == 0) { bsum[i] = xr * s0; gdia[i] = (xr * ck[0]) * xi + beta; }
                 }
             }
             gmax = hw_max(lmax);
@@ -418,11 +418,11 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         for (int i = wv; i < nd; i += HNW) {
             const double* row = Mk + (size_t)i * st.ldm;
             const double* row1 = M1 + (size_t)i * st.ldm;
-            const double xi = xd[i], xhi = xh[i];
+            const double xi = xd[i], xhi = xh[i], xr = reff * xi;
             double sacc = 0.0, mxx = 0.0, dg = 0.0;
             for (int j = lane; j < nd; j += 64) {
                 const double mij = row[j];
-                double g = (xi * mij) * xd[j];
+                double g = (xr * mij) * xd[j];
                 if (use_g) g += ((xhi * row1[j]) * xh[j]) / sig2;
                 if (j == i) dg = g + beta;
                 else {
@@ -471,14 +471,15 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         if (!(st.opts.derivative_weights[k] > 0.0)) continue;
         update_block(k, xs + ns, n - ns, ns, st.toeplitz_m != 0, k == 0, st.opts.s_alpha[k], st.opts.s_0[k],
                      st.opts.sigma_ds[k], st.opts.rho_alpha[k], st.opts.rho_0[k], st.rho + (size_t)b * 3,
-                     st.xmx + (size_t)b * 3);
+                     st.xmx + (size_t)b * 3, st.opts.eff_hp ? 1.0 : st.rho[(size_t)b * 3 + k]);
     }
     if (st.prepared && st.desc.dop_size > 0) {
         for (int k = 0; k < 3; ++k) {
             if (!(st.desc.dop_derivative_weights[k] > 0.0)) continue;
             update_block(k, xs + st.desc.dop_start, st.desc.dop_size, st.desc.dop_start, false, false,
                          st.desc.dop_s_alpha[k], st.desc.dop_s_0[k], 1.0, st.desc.dop_rho_alpha[k],
-                         st.desc.dop_rho_0[k], st.dop_rho + (size_t)b * 3, st.dop_xmx + (size_t)b * 3);
+                         st.desc.dop_rho_0[k], st.dop_rho + (size_t)b * 3, st.dop_xmx + (size_t)b * 3,
+                         st.opts.eff_hp ? 1.0 : st.dop_rho[(size_t)b * 3 + k]);
         }
     }
 

@@ -121,7 +121,7 @@ class DRT(PreparedFitMixin):
 
     def _make_opts(self, fit_kw):
         kw = dict(_FIT_KW_DEFAULTS)
-        hypers = qphb.get_default_hypers(True, self.fit_dop, 'gaussian')
+        hypers = qphb.get_default_hypers(bool(fit_kw.get('eff_hp', True)), self.fit_dop, 'gaussian')
         for key, val in fit_kw.items():
             if key in kw:
                 kw[key] = val
@@ -131,8 +131,6 @@ class DRT(PreparedFitMixin):
                 raise ValueError(f'Invalid keyword argument {key}')     # drt1d.py:415-419
         if kw['penalty_type'] != 'integral':
             raise NotImplementedError("penalty_type 'discrete' is deprecated in the reference and not built")
-        if not kw['eff_hp']:
-            raise NotImplementedError("only eff_hp=True (the default) is built")
         if (hypers['iw_alpha'] is None) != (hypers['iw_beta'] is None):
             raise ValueError('iw_alpha and iw_beta must be given together')
         if kw['eis_error_structure'] not in (None, 'uniform'):
@@ -157,6 +155,7 @@ class DRT(PreparedFitMixin):
         o.fit_ohmic, o.fit_inductance = int(self.fit_ohmic), int(self.fit_inductance)
         o.eis_error_uniform = int(kw['eis_error_structure'] == 'uniform')
         o.update_scale = int(bool(kw['update_scale']))
+        o.eff_hp = int(bool(kw['eff_hp']))
         return o, hypers, kw
 
     # ---- the fits ------------------------------------------------------------------------------------------
@@ -172,7 +171,7 @@ class DRT(PreparedFitMixin):
             if old in kw:
                 kw[new] = kw.pop(old)
         if self.fit_dop or self.fit_capacitance or kw.get('solve_rp') or kw.get('remove_outliers') \
-                or kw.get('remove_extremes'):   # prepared-matrix plan
+                or kw.get('remove_extremes') or kw.get('neg_allowed_tau_range') is not None:   # prepared-matrix plan
             return self._store_single(*self._fit_prepared([(None, None, None, frequencies, z)], kw, history_of=0),
                                       'qphb_eis')
         res = self._fit(frequencies, z[None, :], kw, history_of=0)

@@ -21,11 +21,11 @@ _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (
     smooth_inf_response=True, v_baseline_penalty=1e-6, vz_offset=True, vz_offset_scale=1, vz_offset_eps=1,
     chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False,
     eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None, remove_outliers=False,
-    outlier_thresh=0.75, remove_extremes=False, extreme_kw=None)
+    outlier_thresh=0.75, remove_extremes=False, extreme_kw=None, neg_allowed_tau_range=None)
 
 _UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False,
                     series_neg=False,
-                    init_weights_separately=False, peak_locations=None, neg_allowed_tau_range=None)
+                    init_weights_separately=False, peak_locations=None)
 
 
 class PreparedFitMixin:
@@ -283,9 +283,20 @@ class PreparedFitMixin:
         l1[ns:] = hypers['l1_lambda_0']
         if self.fit_dop:
             l1[dop[0]:dop[1]] = hypers['dop_l1_lambda_0']
-        h = qphb.make_h_constraint(None, n, sp, kw['nonneg'])
+        # DRT._get_neg_allowed_indices (drt1d.py:82-91): the loop's QPs allow negative coefficients only inside the window,
+        # initialize_weights is called without it (drt1d.py:657-660)
+        h_init = None
+        if ckw['neg_allowed_tau_range'] is not None:
+            if kw['nonneg']:
+                raise ValueError("If nonneg==True, neg_allowed_tau_range cannot be specified")
+            lo, hi = ckw['neg_allowed_tau_range']
+            idx = np.where((basis_tau >= lo) & (basis_tau <= hi))[0] + ns
+            h = qphb.make_h_constraint(None, n, sp, False, neg_allowed_indices=idx)
+            h_init = qphb.make_h_constraint(None, n, sp, False)
+        else:
+            h = qphb.make_h_constraint(None, n, sp, kw['nonneg'])
 
-        prep.update(rzm=rzm, rzv=rzv, pen=pen, vmm=vmm, special=sp, ns=ns, n=n, m=m, dop=dop, l1=l1, h=h,
+        prep.update(rzm=rzm, rzv=rzv, pen=pen, vmm=vmm, special=sp, ns=ns, n=n, m=m, dop=dop, l1=l1, h=h, h_init=h_init,
                     vz_strength=vz_strength, num_chrono=num_chrono, num_eis=len(frequencies) if has_eis else 0,
                     basis_tau=basis_tau, toeplitz_m=tpl_m, coefficient_scale=coefficient_scale,
                     impedance_scale=impedance_scale, input_signal_scale=input_scale, response_signal_scale=response_scale,
@@ -501,6 +512,7 @@ class PreparedFitMixin:
             rows.append(np.concatenate([np.full(pr['num_chrono'], cf), np.full(pr['m'] - pr['num_chrono'], ef)]))
         rows = np.array(rows)
         plan.set_weight_factors(kw['weight_factor'], None if np.all(rows == 1.0) else rows)
+        plan.set_init_h(p0['h_init'])
         plan.upload(p0['rzm'] if shared else np.stack([pr['rzm'] for pr in preps]), np.stack([pr['rzv'] for pr in preps]))
         plan.record_history(-1 if _init_only else history_of)
         plan.fit()

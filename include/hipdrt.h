@@ -167,6 +167,7 @@ typedef struct {
     int fit_ohmic, fit_inductance;   /* 1, 1 */
     int eis_error_uniform;           /* 0 (eis_error_structure=None) */
     int update_scale;                /* 0; 1: re-scale the data every iteration from the second on (drt1d.py:903-927) */
+    int eff_hp;                      /* 1; 0: solve_s sees rho_k instead of 1 (qphb.py:747-750; other default alphas) */
     /* optional branches of the weight estimation; <= 0 means None (the reference defaults) */
     double outlier_p;                /* prior outlier probability, qphb.py:1497-1553, 1629-1656 */
     double iw_alpha, iw_beta;        /* prior on the initial weights, qphb.py:1471-1479, 1679 */
@@ -290,6 +291,10 @@ int hipdrt_plan_upload_prepared(hipdrt_plan* plan, int B, int rm_batched, const 
  * variances use those times the row factors ("scaled weights").  row_factors: [m], or [capacity][m] when batched != 0.
  * Applies to every later hipdrt_plan_fit of the plan (any plan kind); (1.0, NULL) switches it off.                     */
 int hipdrt_plan_set_weight_factors(hipdrt_plan* plan, double weight_factor, const double* row_factors, int batched);
+/* Constraint vector of the initialize_weights QP when it differs from the loop's (neg_allowed_tau_range: the loop allows
+ * negative coefficients only inside a tau window, initialize_weights everywhere; hybdrt/models/drt1d.py:467, 657-660 vs
+ * 944, hybdrt/models/qphb.py:521-557).  h_init[n]; NULL restores the plan's single h.                                   */
+int hipdrt_plan_set_init_h(hipdrt_plan* plan, const double* h_init);
 
 /* kernel-time breakdown of the last hipdrt_plan_fit in ms (HIP events on the ctx stream):
  * t[0]=total, t[1]=gram, t[2]=qp, t[3]=hyper, t[4]=setup/other; launches[5] same order                 */

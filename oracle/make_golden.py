@@ -323,6 +323,11 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "golden71x91_upscale", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(update_scale=True))
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_dop_upscale", meas, dict(base, fit_dop=True), dict(update_scale=True))
+    # eff_hp=False (qphb.py:208-222, 747-750) and a window of allowed negative coefficients (drt1d.py:82-91)
+    run_hybrid_case(DRT, cvxopt, "golden71x91_noeff", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
+                    dict(eff_hp=False))
+    run_hybrid_case(DRT, cvxopt, "golden71x91_negwin", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
+                    dict(nonneg=False, neg_allowed_tau_range=(1e-5, 1e-3)))
     # weight factors (drt1d.py:743-803, 887-901, 990-1000)
     run_hybrid_case(DRT, cvxopt, "golden71x91_wf", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(weight_factor=0.7))

@@ -472,3 +472,25 @@ def test_update_scale_matches_reference_runs():
     _check_fit(drt, g, special, True, data_rtol=1e-7, mat_rtol=1e-8)
     np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-6)
     np.testing.assert_allclose(drt.qphb_params["xmx_norms"], g["xmx_norms"], rtol=1e-6)
+
+
+def test_eff_hp_false_and_negative_window_match_reference_runs():
+    from hipdrt.models import DRT
+    g, special = load_case("golden71x91_noeff")
+    drt = DRT(warn=False)
+    fp = drt.fit_eis(g["freq"], g["z"], eff_hp=False)           # EIS plan path, Toeplitz branch of the hyper kernel
+    qp = drt.qphb_params
+    assert qp["qp_iterations"].tolist() == g["qp_iterations"].tolist() and qp["outer_iterations"] == 24
+    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(qp["rho_vector"], g["rho_vector"], rtol=1e-6)
+    np.testing.assert_allclose(np.array(qp["s_vectors"]), g["s_vectors"], rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    assert drt.fit_kwargs["s_alpha"].tolist() == [1.05, 1.15, 2.5]
+    g, special = load_case("golden71x91_negwin")
+    drt = DRT(warn=False)
+    fp = drt.fit_eis(g["freq"], g["z"], nonneg=False, neg_allowed_tau_range=(1e-5, 1e-3))
+    _check_fit(drt, g, special, False)
+    inside = (g["basis_tau"] >= 1e-5) & (g["basis_tau"] <= 1e-3)
+    assert fp["x"][~inside].min() >= -1e-12
+    with pytest.raises(ValueError):
+        drt.fit_eis(g["freq"], g["z"], neg_allowed_tau_range=(1e-5, 1e-3))

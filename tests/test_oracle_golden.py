@@ -309,3 +309,25 @@ def test_general_loop_update_scale(name, base):
     np.testing.assert_allclose(r["weights"], g["weights"], rtol=1e-7)
     np.testing.assert_allclose(r["est_weights"], g["est_weights"], rtol=1e-7)
     np.testing.assert_allclose(r["xmx_norms"], g["xmx_norms"], rtol=1e-6)
+
+
+def test_general_loop_eff_hp_false_and_negative_window():
+    """eff_hp=False (rho_k enters solve_s, qphb.py:747-750, with the other default alphas) and neg_allowed_tau_range
+    (loop QPs allow negative coefficients only inside the window, the initial QP everywhere)"""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case("golden71x91_noeff")
+    hyp = dict(orc.get_default_hypers(), s_alpha=np.array([1.05, 1.15, 2.5]), rho_alpha=np.array([0.05, 0.1, 0.05]),
+               eff_hp=False)
+    rzm0, _ = initial_rzm_and_vz(g, special)
+    r = orc.qphb_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp)
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(np.array([h["rho_vector"] for h in r["history"]]), g["hist_rho"], rtol=1e-8)
+    g, special = load_case("golden71x91_negwin")
+    rzm0, _ = initial_rzm_and_vz(g, special)
+    idx = np.where((g["basis_tau"] >= 1e-5) & (g["basis_tau"] <= 1e-3))[0] + 2
+    r = orc.qphb_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, orc.get_default_hypers(),
+                              nonneg=False, neg_allowed_indices=idx)
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
+    assert np.min(np.delete(r["x"], idx)) >= -1e-9          # outside the window the coefficients stay non-negative

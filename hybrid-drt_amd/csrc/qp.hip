@@ -211,6 +211,162 @@ __device__ __forceinline__ bool chol_factor(const double* __restrict__ P, int ld
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// One large problem on G co-resident workgroups (launch_qp forms groups only when B*G <= number of CUs).
+// Barrier among the G workgroups of a problem: monotonic counter in global memory; the fences make the stores to L
+// visible across CUs and XCDs (release: L2 write-back, acquire: L1 / non-local L2 invalidate).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void group_barrier(int* ctr, int G, int& epoch) {
+    __syncthreads();                       // all stores of this workgroup issued and acknowledged (vmcnt(0))
+    if (threadIdx.x == 0) {
+        ++epoch;
+        __threadfence();
+        atomicAdd(ctr, 1);
+        const int target = G * epoch;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+// Left-looking blocked Cholesky as chol_factor, the rows below the diagonal block of every block column dealt out to
+// the G workgroups in chunks.  Every workgroup recomputes and factors the 32x32 diagonal block itself (a 2-tile rank-k
+// update: cheaper than publishing it and waiting), so one barrier per block column suffices; tiles, the per-row
+// substitution and the diagonal factorisation are computed exactly as in chol_factor, i.e. the factor is bit-identical.
+template <int THREADS, int MAXT>
+__device__ __forceinline__ bool chol_factor_group(const double* __restrict__ P, int ldp, double* __restrict__ L, int ldl,
+                                                  int n, int PR, const QpSmem& sm, int G, int g, int* ctr, int& epoch) {
+    constexpr int NW = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nblk = (n + NB - 1) / NB;
+    const int li = lane & 15, kq = lane >> 4;
+    bool ok_all = true;
+    for (int jb = 0; jb < nblk; ++jb) {
+        const int j0 = jb * NB;
+        const int nv = (n - j0) < NB ? (n - j0) : NB;
+        // one pass = rows [rowbase, rowbase + cr): rank-k update on MFMA into the LDS panel, (diagonal pass: factor the
+        // block,) forward substitution against L11 one thread per row, coalesced write-back
+        auto pass = [&](const int rowbase, const int cr, const bool diag, const bool store) -> bool {
+            const int ntile = (cr + 15) >> 4;
+            v4d acc[MAXT][2];
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) { acc[u][0] = (v4d){0, 0, 0, 0}; acc[u][1] = (v4d){0, 0, 0, 0}; }
+            int brow0 = j0 + li;       if (brow0 > n - 1) brow0 = n - 1;
+            int brow1 = j0 + 16 + li;  if (brow1 > n - 1) brow1 = n - 1;
+            const double* pb0 = L + (size_t)brow0 * ldl + 4 * kq;
+            const double* pb1 = L + (size_t)brow1 * ldl + 4 * kq;
+            const double* pa[MAXT];
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {
+                int ar = rowbase + (wv + u * NW) * 16 + li;
+                if (ar > n - 1) ar = n - 1;
+                pa[u] = L + (size_t)ar * ldl + 4 * kq;
+            }
+            if (wv < ntile) {
+                for (int k0 = 0; k0 < j0; k0 += 16) {
+                    const double2 b0a = *reinterpret_cast<const double2*>(pb0 + k0);
+                    const double2 b0b = *reinterpret_cast<const double2*>(pb0 + k0 + 2);
+                    const double2 b1a = *reinterpret_cast<const double2*>(pb1 + k0);
+                    const double2 b1b = *reinterpret_cast<const double2*>(pb1 + k0 + 2);
+#pragma unroll
+                    for (int u = 0; u < MAXT; ++u) {
+                        if (wv + u * NW < ntile) {
+                            const double2 aa = *reinterpret_cast<const double2*>(pa[u] + k0);
+                            const double2 ab = *reinterpret_cast<const double2*>(pa[u] + k0 + 2);
+                            acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa.x, b0a.x, acc[u][0], 0, 0, 0);
+                            acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa.x, b1a.x, acc[u][1], 0, 0, 0);
+                            acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa.y, b0a.y, acc[u][0], 0, 0, 0);
+                            acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa.y, b1a.y, acc[u][1], 0, 0, 0);
+                            acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab.x, b0b.x, acc[u][0], 0, 0, 0);
+                            acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab.x, b1b.x, acc[u][1], 0, 0, 0);
+                            acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab.y, b0b.y, acc[u][0], 0, 0, 0);
+                            acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab.y, b1b.y, acc[u][1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {
+                const int t = wv + u * NW;
+                if (t < ntile) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int lr = t * 16 + (lane >> 4) + 4 * rg;
+                            const int row = rowbase + lr;
+                            const int cc = ct * 16 + (lane & 15);
+                            const int col = j0 + cc;
+                            double v = 0.0;
+                            if (row < n && col < n) {
+                                const int pr_ = row > col ? row : col, pc_ = row > col ? col : row;
+                                v = P[(size_t)pr_ * ldp + pc_];
+                                if (row == col) v += sm.dvec[row];
+                                v -= acc[u][ct][rg];
+                            }
+                            sm.panel[lr * PLD + cc] = v;
+                        }
+                }
+            }
+            __syncthreads();
+            if (diag) {
+                if (wv == 0) {
+                    const bool ok = factor_diag_block(sm.panel, sm.l11, nv, lane);
+                    const unsigned long long bad = __ballot(!ok);
+                    if (lane == 0) sm.flag[0] = bad ? 1 : 0;
+                }
+                __syncthreads();
+                if (sm.flag[0]) return false;
+                for (int e = tid; e < NB * NB; e += THREADS) {
+                    const int r = e >> 5, c = e & 31;
+                    sm.panel[r * PLD + c] = sm.l11[r * PLD + c];
+                }
+            } else {
+                for (int rr = tid; rr < cr; rr += THREADS) {
+                    double v[NB];
+                    double* prow = sm.panel + rr * PLD;
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) v[c] = prow[c];
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) {
+                        if (c < nv) {
+                            double t = v[c];
+#pragma unroll
+                            for (int k = 0; k < c; ++k) t -= v[k] * sm.l11[c * PLD + k];
+                            v[c] = t / sm.l11[c * PLD + c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) prow[c] = v[c];
+                }
+            }
+            __syncthreads();
+            if (store) {
+                for (int e = tid; e < cr * NB; e += THREADS) {
+                    const int r = e >> 5, c = e & 31;
+                    if (c < nv) L[(size_t)(rowbase + r) * ldl + j0 + c] = sm.panel[r * PLD + c];
+                }
+            }
+            __syncthreads();
+            return true;
+        };
+        if (!pass(j0, nv, true, g == 0)) { ok_all = false; break; }       // identical in every workgroup of the group
+        const int rem = n - (j0 + NB);
+        if (rem > 0) {
+            int pr = (((rem + G - 1) / G) + 15) & ~15;
+            if (pr > PR) pr = PR;
+            const int nchunk = (rem + pr - 1) / pr;
+            for (int c = g; c < nchunk; c += G) {
+                const int c0 = c * pr;
+                const int cr = (rem - c0) < pr ? (rem - c0) : pr;
+                pass(j0 + NB + c0, cr, false, true);
+            }
+        }
+        group_barrier(ctr, G, epoch);          // column block complete before anyone's next rank-k update reads it
+    }
+    return ok_all;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // vec := S^-1 vec  with S = L L'
 // ---------------------------------------------------------------------------------------------------------
 template <int THREADS>
@@ -301,10 +457,11 @@ __device__ __forceinline__ void chol_solve(const double* __restrict__ L, int ldl
 // out[i] = sum_j P[i][j] * vec[j]   (P symmetric, full storage); one wavefront per row
 template <int THREADS>
 __device__ __forceinline__ void matvec_P(const double* __restrict__ P, int ldp, int n, const double* __restrict__ xin,
-                         double* __restrict__ out) {
+                         double* __restrict__ out, int r0 = 0, int r1 = -1) {
     constexpr int NW = THREADS / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = wv; i < n; i += NW) {
+    if (r1 < 0) r1 = n;
+    for (int i = r0 + wv; i < r1; i += NW) {
         const double* row = P + (size_t)i * ldp;
         double s = 0.0;
         for (int j = lane; j < n; j += 64) s += row[j] * xin[j];
@@ -325,6 +482,53 @@ struct OpsMultipass {
     __device__ __forceinline__ void backward() {}
     __device__ __forceinline__ void matvec() { matvec_P<THREADS>(P, ldp, n, sm.vec, sm.dvec); }
 };
+
+template <int THREADS, int MAXT>
+struct OpsGroup {
+    const double* P; int ldp; double* L; int ldl; int n; int PR; QpSmem sm;
+    int G, g; int* ctr; int epoch; double* gvec;
+    static constexpr bool kFusedForward = false;
+    __device__ __forceinline__ bool factor() {
+        return chol_factor_group<THREADS, MAXT>(P, ldp, L, ldl, n, PR, sm, G, g, ctr, epoch);
+    }
+    __device__ __forceinline__ void solve() { chol_solve<THREADS>(L, ldl, n, sm); }
+    __device__ __forceinline__ void backward() {}
+    // P x: every workgroup does its share of the rows (same per-row arithmetic as matvec_P, so the same bits), the
+    // pieces meet in a global vector
+    __device__ __forceinline__ void matvec() {
+        const int per = (n + G - 1) / G;
+        const int r0 = g * per, r1 = (r0 + per) < n ? (r0 + per) : n;
+        matvec_P<THREADS>(P, ldp, n, sm.vec, gvec, r0, r1);
+        group_barrier(ctr, G, epoch);
+        for (int i = threadIdx.x; i < n; i += THREADS) sm.dvec[i] = gvec[i];
+    }
+};
+
+// G workgroups per problem: the factorisation is shared, everything else (O(n^2) sweeps, O(n) vector work, all
+// decisions) runs redundantly and identically in each, so no further communication is needed
+template <int THREADS, int MAXT, int EPT>
+__global__ __launch_bounds__(THREADS) void qp_kernel_group(QpArgs a, int PR, int G) {
+    constexpr int NW = THREADS / 64;
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int b = a.order ? a.order[slot] : slot;
+    if (a.active && !a.active[b]) return;
+    const int n = a.n;
+    extern __shared__ double smem[];
+    OpsGroup<THREADS, MAXT> ops;
+    ops.P = a.P + (size_t)b * a.p_stride; ops.ldp = a.ldp;
+    ops.L = a.L + (size_t)b * a.l_stride; ops.ldl = a.ldl; ops.n = n; ops.PR = PR;
+    ops.G = G; ops.g = g; ops.ctr = a.gsync + slot; ops.epoch = 0; ops.gvec = a.gvec + (size_t)slot * a.state_ld;
+    ops.sm.panel = smem;
+    ops.sm.l11 = ops.sm.panel + (size_t)PR * PLD;
+    ops.sm.vec = ops.sm.l11 + NB * PLD;
+    ops.sm.dvec = ops.sm.vec + n;
+    ops.sm.red = ops.sm.dvec + n;
+    ops.sm.flag = reinterpret_cast<int*>(ops.sm.red + 4 * NW * 4);
+    IpmSmem is{ops.sm.vec, ops.sm.dvec, ops.sm.red};
+    QpArgs ag = a;
+    ag.state = a.gstate;
+    ipm_solve<THREADS, EPT>(ag, b, ops, is, (int)blockIdx.x, g == 0);
+}
 
 template <int THREADS, int MAXT, int EPT>
 __global__ __launch_bounds__(THREADS) void qp_kernel(QpArgs a, int PR) {
@@ -370,6 +574,40 @@ int qp_profile_read(unsigned long long* out, int n, int reset) {
 
 static constexpr int QP_THREADS = 512;
 static constexpr int QP_MAXT = 2;
+
+template <int EPT>
+static int launch_qp_group_ept(hipStream_t st, const QpArgs& a, int PR, size_t lds, int G) {
+    auto kern = qp_kernel_group<QP_THREADS, QP_MAXT, EPT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(qp group): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    e = hipMemsetAsync(a.gsync, 0, (size_t)a.B * sizeof(int), st);
+    if (e != hipSuccess) { set_error(std::string("qp group sync reset: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    hipLaunchKernelGGL(kern, dim3(a.B * G), dim3(QP_THREADS), lds, st, a, PR, G);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("qp group launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    return HIPDRT_OK;
+}
+
+static int device_cus() {
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return cus;
+}
+
+// Workgroups per problem for the multi-pass kernel: up to 8 when the launch would otherwise leave most CUs idle and the
+// problem is big enough for the split to pay (at least 4 chunks of 64 rows below the first diagonal block)
+int qp_group_size(int B, int n) {
+    if (qp_packed_only(n) || n < 640 || getenv("HIPDRT_QP_NOGROUP")) return 1;
+    int G = device_cus() / (B > 0 ? B : 1);
+    if (G > 8) G = 8;
+    if (B * G > qp_group_slots()) G = qp_group_slots() / B;
+    return G >= 2 ? G : 1;
+}
 
 template <int EPT>
 static int launch_qp_ept(hipStream_t st, const QpArgs& a, int PR, size_t lds) {
@@ -460,6 +698,15 @@ int launch_qp(hipStream_t st, const QpArgs& a) {
     const size_t lds = fixed + (size_t)PR * PLD * sizeof(double);
     if (lds > 160 * 1024) { set_error("qp: problem too large for LDS"); return HIPDRT_E_INVALID; }
     const int ept = (n + QP_THREADS - 1) / QP_THREADS;
+    const int G = (a.gstate && a.gsync && a.gvec) ? qp_group_size(a.B, n) : 1;
+    if (G > 1) {
+        switch (ept) {
+            case 2: return launch_qp_group_ept<2>(st, a, PR, lds, G);
+            case 3: return launch_qp_group_ept<3>(st, a, PR, lds, G);
+            case 4: return launch_qp_group_ept<4>(st, a, PR, lds, G);
+            default: break;
+        }
+    }
     switch (ept) {
         case 1: return launch_qp_ept<1>(st, a, PR, lds);
         case 2: return launch_qp_ept<2>(st, a, PR, lds);

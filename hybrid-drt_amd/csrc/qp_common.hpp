@@ -149,7 +149,10 @@ struct IpmSmem {
 // The interior-point iteration.  O(n) vectors live in registers, element i owned by thread i % THREADS.
 // ---------------------------------------------------------------------------------------------------------
 template <int THREADS, int EPT, class Ops>
-__device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, const IpmSmem& sm) {
+__device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, const IpmSmem& sm, int slot = -1,
+                                          bool leader = true) {
+    // slot / leader: several workgroups may run the same problem redundantly (qp.hip, workgroup groups); each then keeps
+    // its own copy of the iterates and only the leader writes the results
     constexpr int NW = THREADS / 64;
     const int n = a.n;
     const unsigned tid = threadIdx.x;      // unsigned indices: SGPR base + 32-bit VGPR offset addressing, no per-vector
@@ -161,7 +164,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     // The O(n) iterates live in a per-problem global scratch (L1/L2 resident, 16 vectors), element i touched
     // only by its owner thread, so no synchronisation is needed for them; keeping them out of registers leaves
     // the 128-VGPR budget of the 1024-thread kernel to the factorisation / solve phases (fewer spills there).
-    double* const S_ = a.state + (size_t)b * a.state_stride;
+    double* const S_ = a.state + (size_t)(slot >= 0 ? slot : b) * a.state_stride;
     const int sld = a.state_ld;
 #define SV(k) (S_ + (size_t)(k) * sld)
     double* const x = SV(0); double* const z = SV(1); double* const s = SV(2); double* const d = SV(3);
@@ -357,9 +360,11 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     }
 
     PROF(10);
+    if (leader) {
 #pragma unroll
-    FOR_E if (VALID) a.x[(size_t)b * n + i] = x[i];
-    if (tid == 0) {
+        FOR_E if (VALID) a.x[(size_t)b * n + i] = x[i];
+    }
+    if (tid == 0 && leader) {
 #ifdef HIPDRT_QP_PROFILE
         if (b == 0) atomicAdd(&g_qp_prof[11], (unsigned long long)(iters + 1));
 #endif

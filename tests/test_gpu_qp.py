@@ -127,3 +127,50 @@ def test_solve_convex_opt_mirror(ctx):
     ref = g["qp1_x"]
     assert out['iterations'] == int(g["qp_iterations"][1]) and out['status'] == 'optimal'
     np.testing.assert_allclose(np.array(list(out['x'])), ref, rtol=1e-6, atol=1e-7 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n,B", [(641, 1), (700, 3), (1078, 1), (1078, 5), (1500, 2)])
+def test_workgroup_groups_are_bit_identical_to_single_workgroup(n, B):
+    """n > 640 and far fewer problems than CUs: several workgroups share one factorisation (qp_kernel_group).  Tiles,
+    substitutions and the redundant diagonal blocks are computed exactly as by the single-workgroup kernel, so x, costs
+    and iteration counts must agree bit for bit; the oracle pins the values."""
+    import os
+    from hipdrt import _ffi
+    from oracle.coneqp import coneqp_boxlow
+    rng = np.random.default_rng(n + B)
+    ctx = _ffi.get_context()
+    Ps, qs = [], []
+    for b in range(B):
+        A = rng.standard_normal((n + 50, n)) / np.sqrt(n)
+        xt = np.maximum(rng.standard_normal(n), 0)
+        Ps.append(A.T @ A + 1e-3 * np.eye(n))
+        qs.append(-A.T @ (A @ xt))
+    Ps, qs = np.array(Ps), np.array(qs)
+    h = np.zeros(n)
+    h[:3] = 1000.0
+    res = ctx.qp_batch(Ps, qs, h)
+    os.environ["HIPDRT_QP_NOGROUP"] = "1"
+    try:
+        ref = ctx.qp_batch(Ps, qs, h)
+    finally:
+        del os.environ["HIPDRT_QP_NOGROUP"]
+    np.testing.assert_array_equal(res["x"], ref["x"])
+    np.testing.assert_array_equal(res["iterations"], ref["iterations"])
+    np.testing.assert_array_equal(res["pcost"], ref["pcost"])
+    assert np.all(res["status"] == 0)
+    if n <= 1078:
+        r = coneqp_boxlow(Ps[0], qs[0], h)
+        assert r["iterations"] == res["iterations"][0]
+        np.testing.assert_allclose(res["x"][0], r["x"], rtol=0, atol=1e-9 * np.abs(r["x"]).max())
+
+
+def test_workgroup_group_reports_breakdown_consistently():
+    """an indefinite P breaks the factorisation down in every workgroup of the group at the same block: no deadlock,
+    status < 0 like the single-workgroup kernel"""
+    from hipdrt import _ffi
+    ctx = _ffi.get_context()
+    n = 800
+    P = np.eye(n)
+    P[300, 300] = -5.0
+    res = ctx.qp_batch(P[None], np.ones((1, n)), np.zeros(n))
+    assert res["status"][0] < 0

@@ -600,13 +600,14 @@ static int device_cus() {
 }
 
 // Workgroups per problem for the multi-pass kernel: up to 16 when the launch would otherwise leave most CUs idle and the
-// problem is big enough for the split to pay (at least 4 chunks of 64 rows below the first diagonal block)
+// problem is big enough for the split to pay (chunks of at least 64 rows below the first diagonal block)
 int qp_group_size(int B, int n) {
-    if (qp_packed_only(n) || n < 640 || getenv("HIPDRT_QP_NOGROUP")) return 1;
+    if (qp_packed_only(n) || getenv("HIPDRT_QP_NOGROUP")) return 1;
     int G = device_cus() / (B > 0 ? B : 1);
     int gmax = 16;
     if (const char* e = getenv("HIPDRT_QP_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 32) gmax = v; }   // tuning knob
     if (G > gmax) G = gmax;
+    if (G > (n - NB) / 64) G = (n - NB) / 64;          // keep at least 64 panel rows per workgroup in the first column
     if (B * G > qp_group_slots()) G = qp_group_slots() / B;
     return G >= 2 ? G : 1;
 }

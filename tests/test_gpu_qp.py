@@ -129,9 +129,9 @@ def test_solve_convex_opt_mirror(ctx):
     np.testing.assert_allclose(np.array(list(out['x'])), ref, rtol=1e-6, atol=1e-7 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("n,B", [(641, 1), (700, 3), (1078, 1), (1078, 5), (1500, 2)])
+@pytest.mark.parametrize("n,B", [(529, 1), (564, 2), (641, 1), (700, 3), (1078, 1), (1078, 5), (1500, 2)])
 def test_workgroup_groups_are_bit_identical_to_single_workgroup(n, B):
-    """n > 640 and far fewer problems than CUs: several workgroups share one factorisation (qp_kernel_group).  Tiles,
+    """n > 528 and far fewer problems than CUs: several workgroups share one factorisation (qp_kernel_group).  Tiles,
     substitutions and the redundant diagonal blocks are computed exactly as by the single-workgroup kernel, so x, costs
     and iteration counts must agree bit for bit; the oracle pins the values."""
     import os

@@ -20,6 +20,7 @@
 //   * P x: one wavefront per row, coalesced, shuffle-reduced.
 // LDS: panel (PR x 33 doubles) + L11 (32 x 33) + two length-n vectors  ~= 77 kB at PR = 224, so two
 // workgroups share a CU and one's sequential phases overlap the other's MFMA phases.
+#include <mutex>
 #include <cstdlib>
 
 #include "qp_common.hpp"
@@ -583,9 +584,27 @@ static int launch_qp_group_ept(hipStream_t st, const QpArgs& a, int PR, size_t l
     if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(qp group): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
     e = hipMemsetAsync(a.gsync, 0, (size_t)a.B * sizeof(int), st);
     if (e != hipSuccess) { set_error(std::string("qp group sync reset: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    // The workgroups of a group spin on a barrier, so a group launch must become fully resident.  Two group launches from
+    // different streams could each grab part of the CUs and wait for the rest forever; they are therefore chained through
+    // an event per device (stream-ordered: the host never blocks, other kernels still overlap freely).
+    static std::mutex mtx;
+    static hipEvent_t last[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mtx);
+    hipEvent_t& ev = last[dev & 63];
+    if (ev) {
+        e = hipStreamWaitEvent(st, ev, 0);
+        if (e != hipSuccess) { set_error(std::string("qp group chain: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    } else {
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) { ev = nullptr; set_error(std::string("qp group event: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    }
     hipLaunchKernelGGL(kern, dim3(a.B * G), dim3(QP_THREADS), lds, st, a, PR, G);
     e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("qp group launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    e = hipEventRecord(ev, st);
+    if (e != hipSuccess) { set_error(std::string("qp group record: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
     return HIPDRT_OK;
 }
 

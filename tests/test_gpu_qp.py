@@ -174,3 +174,29 @@ def test_workgroup_group_reports_breakdown_consistently():
     P[300, 300] = -5.0
     res = ctx.qp_batch(P[None], np.ones((1, n)), np.zeros(n))
     assert res["status"][0] < 0
+
+
+def test_concurrent_group_launches_from_two_streams_do_not_deadlock():
+    """two host threads, two HIP streams, each launching grouped QPs (16 spinning workgroups per problem x 12 problems =
+    192 of 256 CUs per launch): the launches are chained through a per-device event, so both always become resident"""
+    import threading
+    from hipdrt import _ffi
+    rng = np.random.default_rng(0)
+    n, B = 700, 12
+    A = rng.standard_normal((n + 20, n)) / np.sqrt(n)
+    P = A.T @ A + 1e-3 * np.eye(n)
+    q = -A.T @ (A @ np.maximum(rng.standard_normal(n), 0))
+    out = {}
+
+    def work(tag):
+        ctx = _ffi.Context(0)
+        for rep in range(4):
+            out[tag] = ctx.qp_batch(np.tile(P, (B, 1, 1)), np.tile(q, (B, 1)), np.zeros(n))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+        assert not t.is_alive(), "grouped QP launches hung"
+    np.testing.assert_array_equal(out[0]["x"], out[1]["x"])
+    assert np.all(out[0]["status"] == 0)

@@ -46,7 +46,9 @@ class PreparedDesc(C.Structure):
     _fields_ = [
         ("m", C.c_int), ("n", C.c_int), ("ns", C.c_int), ("dop_start", C.c_int), ("dop_size", C.c_int),
         ("vz_index", C.c_int), ("vb_start", C.c_int), ("vb_size", C.c_int), ("num_chrono", C.c_int),
-        ("toeplitz_m", C.c_int), ("basis_area", C.c_double), ("dop_l2_lambda_0", C.c_double),
+        ("toeplitz_m", C.c_int), ("basis_area", C.c_double), ("init_weights_separately", C.c_int),
+        ("weight_method", C.c_int), ("fixed_chrono_factor", C.c_double), ("fixed_eis_factor", C.c_double),
+        ("dop_l2_lambda_0", C.c_double),
         ("dop_derivative_weights", C.c_double * 3),
         ("dop_s_alpha", C.c_double * 3), ("dop_rho_alpha", C.c_double * 3), ("dop_s_0", C.c_double * 3),
         ("dop_rho_0", C.c_double * 3),
@@ -544,6 +546,7 @@ class PreparedPlan(Plan):
         shapes = {"m0": (self.n, self.n), "m1": (self.n, self.n), "m2": (self.n, self.n), "vmm": (self.m, self.m),
                   "h": (self.n,), "est_weights": (B, self.m), "rv": (B, self.m), "xmx": (B, 3), "dop_rho": (B, 3),
                   "dop_xmx": (B, 3), "hist_dop_rho": (int(self.opts.max_iter), 3), "outlier_t": (B, self.m),
+                  "weight_factors": (B, 2),
                   "rzm": (B, self.m, self.n) if self.rm_batched else (self.m, self.n)}
         out = np.empty(shapes[which])
         _check(self._lib.hipdrt_plan_get(self._h, which.encode(), _p(out), out.size))

@@ -31,7 +31,7 @@ struct hipdrt_plan {
     // weight factors (hipdrt_plan_set_weight_factors): w_eff = w * row factor * weight_factor is what the QP sees
     double weight_factor = 1.0;
     int wrow_batched = 0;
-    DevBuf wrow, w_eff, h_init;
+    DevBuf wrow, w_eff, h_init, wfac;
     bool has_weight_factors() const { return weight_factor != 1.0 || wrow.p != nullptr; }
     // shared
     DevBuf freq, tau, ln_tau, wt_re, wt_im, lut6, a_re, a_im, cr, rm, mk[3], vmm, h, l1;
@@ -747,6 +747,7 @@ int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long co
     else if (w == "rv") { src = p->rv.d(); rows = p->B; cols = ld = p->m; }
     else if (w == "xmx") { src = p->xmx.d(); rows = p->B; cols = ld = 3; }
     else if (w == "outlier_t" && p->outlier_t.p) { src = p->outlier_t.d(); rows = p->B; cols = ld = p->m; }
+    else if (w == "weight_factors" && p->wfac.p) { src = p->wfac.d(); rows = p->B; cols = ld = 2; }
     else if (w == "dop_rho" && p->prepared) { src = p->dop_rho.d(); rows = p->B; cols = ld = 3; }
     else if (w == "dop_xmx" && p->prepared) { src = p->dop_xmx.d(); rows = p->B; cols = ld = 3; }
     else if (w == "rzm") { src = p->rm.d(); rows = (p->rm_stride ? p->B : 1) * p->m; cols = p->n; ld = p->ldrm; }
@@ -858,6 +859,33 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     tm.mark(1);
     double* const Prow = qp_packed_only(n) ? nullptr : p->P.d();   // row-major P only for the multi-pass QP kernel
     const long long pstr = (long long)n * p->ldp, pkstr = (long long)qp_ppk_doubles(n);
+    const int nc = p->prepared ? p->desc.num_chrono : 0;
+    const bool separately = p->prepared && p->desc.init_weights_separately && nc > 0 && nc < m;
+    HIPDRT_REQUIRE(!(separately && p->opts.outlier_p > 0.0), "init_weights_separately with outlier_p is not built");
+    if (separately) {
+        // drt1d.py:648-672: initialize_weights once for the chrono rows and once for the impedance rows.  A QP that sees
+        // only one block = unit weights on its rows and zero on the others (the zero rows add exact zeros to P and q)
+        qa.P = Prow; qa.p_stride = shared_rm ? 0 : pstr; qa.active = nullptr;
+        qa.Ppk = p->Ppk.d(); qa.ppk_stride = shared_rm ? 0 : pkstr; qa.nchp = qp_nchp(n);
+        if (p->h_init.p) qa.h = p->h_init.d();
+        const int bounds[3] = {0, nc, m};
+        for (int blk = 0; blk < 2; ++blk) {
+            tm.mark(1);
+            launch_row_mask(st, B, m, bounds[blk], bounds[blk + 1], p->w.d());
+            launch_gram_l2(st, shared_rm ? 1 : B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, shared_rm ? 0 : pstr,
+                           nullptr, p->Ppk.d(), shared_rm ? 0 : pkstr, qp_nchp(n), astr);
+            launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), nullptr, p->opts.iw_l1_lambda_0, p->q.d(),
+                        nullptr, astr);
+            LAUNCH_OK();
+            tm.mark(2);
+            TRY(launch_qp(st, qa));
+            tm.mark(3);
+            TRY(launch_init_weights(st, fs, B, 2, bounds[blk], bounds[blk + 1]));
+            LAUNCH_OK();
+        }
+        TRY(launch_init_weights(st, fs, B, 3));
+        LAUNCH_OK();
+    } else {
     // one P for the whole batch when the response matrix is shared, else one per measurement
     launch_gram_l2(st, shared_rm ? 1 : B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, shared_rm ? 0 : pstr, nullptr,
                    p->Ppk.d(), shared_rm ? 0 : pkstr, qp_nchp(n), astr);
@@ -888,6 +916,16 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     }
     TRY(launch_init_weights(st, fs, B, 1));
     LAUNCH_OK();
+    }
+    if (p->prepared && p->desc.weight_method == 1 && nc > 0 && nc < m) {
+        // hybrid_weight_factor_method='weight' (drt1d.py:748-760): per-measurement row factors from the initial weights
+        if (!p->w_eff.p) HIPDRT_CHECK(p->w_eff.alloc((size_t)p->capacity * m * sizeof(double)));
+        if (p->wrow.bytes < (size_t)p->capacity * m * sizeof(double)) HIPDRT_CHECK(p->wrow.alloc((size_t)p->capacity * m * sizeof(double)));
+        if (!p->wfac.p) HIPDRT_CHECK(p->wfac.alloc((size_t)p->capacity * 2 * sizeof(double)));
+        p->wrow_batched = 1;
+        launch_weight_method(st, fs, B, p->desc.fixed_chrono_factor, p->desc.fixed_eis_factor, p->wrow.d(), p->wfac.d());
+        LAUNCH_OK();
+    }
 
     // ---- outer loop (drt1d.py:877-988) ----------------------------------------------------------------------
     g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, dop_l2);

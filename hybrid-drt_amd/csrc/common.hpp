@@ -171,7 +171,11 @@ struct FitState {
 size_t hyper_lds_bytes(int n, int m, int ns);
 int launch_prep(hipStream_t s, const FitState& st, int B);
 // stage 0: weights from the first overfit only (outlier branch); stage 1: final est_weights -> init weights, x reset
-int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage);
+// stage 2: est_weights of rows [r0, r1) only (init_weights_separately); stage 3: final step only
+int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage, int r0 = 0, int r1 = 0);
+void launch_row_mask(hipStream_t s, int B, int m, int r0, int r1, double* w);
+void launch_weight_method(hipStream_t s, const FitState& st, int B, double fixed_chrono, double fixed_eis, double* wrow,
+                          double* wfac);
 void launch_vmm_exclude_self(hipStream_t s, const double* vmm, int m, double* out);
 int launch_hyper(hipStream_t s, const FitState& st, int B, int it);
 void launch_scale_weights(hipStream_t s, const FitState& st, int B, double factor);

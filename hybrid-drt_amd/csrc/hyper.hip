@@ -212,7 +212,8 @@ __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, in
 // outlier_p > 0 also tmp3, tmp4 = LDS [m] (solve_outlier_t / outlier_tvt, qphb.py:1497-1539:
 // s_hat = sqrt(t) o V (sqrt(t) o r^2) + (1 - t) o r^2).  Result written to w_out[m] (global).
 __device__ void estimate_weights_dev(const FitState& st, int b, const double* V, const double* xs, double* tmp, double* tmp2,
-                                     double* tmp3, double* tmp4, const double* est_w, double* w_out) {
+                                     double* tmp3, double* tmp4, const double* est_w, double* w_out, int r0 = 0, int r1 = -1,
+                                     double vf_range = -1.0) {
     const int m = st.m, n = st.n, tid = threadIdx.x;
     const double* rv = st.rv + (size_t)b * m;
     const double op = st.opts.outlier_p;
@@ -247,8 +248,9 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* V,
         }
         __syncthreads();
     }
-    const double vf = st.var_floor[b];
-    for (int i = tid; i < m; i += HT) {
+    const double vf = vf_range >= 0.0 ? vf_range : st.var_floor[b];
+    if (r1 < 0) r1 = m;
+    for (int i = r0 + tid; i < r1; i += HT) {
         double sh = tmp2[i];
         if (sh < vf) sh = vf;
         double wh = 1.0 / sqrt(sh);                      // s_hat ** -0.5
@@ -265,8 +267,11 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* V,
 
 // after an initial-weights QP: est_weights = estimate_weights(x_overfit, est_weights=None) on the initialize_weights
 // variance matrix; stage 1 also sets weights = solve_init_weight_scale(est_weights) (qphb.py:1471-1479, 1679) and resets x
-__global__ __launch_bounds__(HT) void init_weights_kernel(FitState st, int stage) {
+// stage 2 (init_weights_separately, drt1d.py:648-672): est_weights of the rows [r0, r1) only, from the QP that saw only
+// those rows, with the variance floor of that data block; stage 3: just the final step (weights from est_weights, x reset)
+__global__ __launch_bounds__(HT) void init_weights_kernel(FitState st, int stage, int r0, int r1) {
     extern __shared__ double sm[];
+    __shared__ double red[HNW];
     const int b = blockIdx.x, tid = threadIdx.x, n = st.n, m = st.m;
     double* xs = sm;
     double* tmp = xs + n;
@@ -277,9 +282,23 @@ __global__ __launch_bounds__(HT) void init_weights_kernel(FitState st, int stage
         if (tid == 0) { st.active[b] = 0; st.fit_status[b] = -1; }
         return;
     }
-    for (int i = tid; i < n; i += HT) xs[i] = st.x[(size_t)b * n + i];
-    __syncthreads();
-    estimate_weights_dev(st, b, st.vmm_iw, xs, tmp, tmp2, tmp3, tmp4, nullptr, st.est_w + (size_t)b * m);
+    if (stage != 3) {
+        for (int i = tid; i < n; i += HT) xs[i] = st.x[(size_t)b * n + i];
+        __syncthreads();
+        if (stage == 2) {
+            const double* rv = st.rv + (size_t)b * m;
+            double s1 = 0.0;
+            for (int i = r0 + tid; i < r1; i += HT) s1 += rv[i];
+            const double mean = blk_sum(s1, red) / (double)(r1 - r0);
+            double s2 = 0.0;
+            for (int i = r0 + tid; i < r1; i += HT) { const double dv = rv[i] - mean; s2 += dv * dv; }
+            const double var = blk_sum(s2, red) / (double)(r1 - r0);          // np.var of this block's data
+            estimate_weights_dev(st, b, st.vmm_iw, xs, tmp, tmp2, tmp3, tmp4, nullptr, st.est_w + (size_t)b * m, r0, r1,
+                                 var * 1e-7);
+            return;
+        }
+        estimate_weights_dev(st, b, st.vmm_iw, xs, tmp, tmp2, tmp3, tmp4, nullptr, st.est_w + (size_t)b * m);
+    }
     if (stage == 0) return;
     const double al = st.opts.iw_alpha, be = st.opts.iw_beta;
     for (int i = tid; i < m; i += HT) {
@@ -641,13 +660,48 @@ static int set_lds(const void* f, size_t bytes) {
     return 0;
 }
 
-int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage) {
+// w[b][i] = 1 inside [r0, r1), 0 elsewhere: the QP of init_weights_separately sees one data block at a time
+__global__ void row_mask_kernel(int m, int r0, int r1, double* __restrict__ w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) w[(size_t)blockIdx.y * m + i] = (i >= r0 && i < r1) ? 1.0 : 0.0;
+}
+
+void launch_row_mask(hipStream_t s, int B, int m, int r0, int r1, double* w) {
+    hipLaunchKernelGGL(row_mask_kernel, dim3((m + 255) / 256, B), dim3(256), 0, s, m, r0, r1, w);
+}
+
+// hybrid_weight_factor_method='weight' (drt1d.py:748-760): chrono / EIS row factors from the ratio of the two blocks'
+// weight scales mean(est_w^-2)^-1/2; a fixed value (> 0) overrides either.  wrow[b][m], wfac[b] = {chrono, eis}.  grid B
+__global__ __launch_bounds__(HT) void weight_method_kernel(FitState st, double fixed_chrono, double fixed_eis,
+                                                           double* __restrict__ wrow, double* __restrict__ wfac) {
+    __shared__ double red[HNW];
+    const int b = blockIdx.x, tid = threadIdx.x, m = st.m, nc = st.desc.num_chrono;
+    const double* ew = st.est_w + (size_t)b * m;
+    double sc = 0.0, se = 0.0;
+    for (int i = tid; i < nc; i += HT) sc += 1.0 / (ew[i] * ew[i]);
+    for (int i = nc + tid; i < m; i += HT) se += 1.0 / (ew[i] * ew[i]);
+    sc = blk_sum(sc, red);
+    se = blk_sum(se, red);
+    const double cws = 1.0 / sqrt(sc / (double)nc), ews = 1.0 / sqrt(se / (double)(m - nc));
+    const double ratio = sqrt(sqrt(ews / cws));
+    const double cf = fixed_chrono > 0.0 ? fixed_chrono : ratio;
+    const double ef = fixed_eis > 0.0 ? fixed_eis : 1.0 / ratio;
+    for (int i = tid; i < m; i += HT) wrow[(size_t)b * m + i] = i < nc ? cf : ef;
+    if (tid == 0) { wfac[2 * b] = cf; wfac[2 * b + 1] = ef; }
+}
+
+void launch_weight_method(hipStream_t s, const FitState& st, int B, double fixed_chrono, double fixed_eis, double* wrow,
+                          double* wfac) {
+    hipLaunchKernelGGL(weight_method_kernel, dim3(B), dim3(HT), 0, s, st, fixed_chrono, fixed_eis, wrow, wfac);
+}
+
+int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage, int r0, int r1) {
     // x + two row vectors, two more only for the outlier branch
     const size_t lds = ((size_t)st.n + (st.opts.outlier_p > 0.0 ? 4 : 2) * (size_t)st.m) * sizeof(double);
     if (lds > kLdsLimit) { set_error("initialize_weights: m too large for the LDS-resident kernel"); return HIPDRT_E_INVALID; }
     if (int rc = set_lds(reinterpret_cast<const void*>(init_weights_kernel), lds)) return rc;
-    hipLaunchKernelGGL(init_weights_kernel, dim3(B), dim3(HT), lds, s, st, stage);
-    if (stage == 1) hipLaunchKernelGGL(record_init_qp_kernel, dim3(1), dim3(64), 0, s, st);
+    hipLaunchKernelGGL(init_weights_kernel, dim3(B), dim3(HT), lds, s, st, stage, r0, r1);
+    if (stage == 1 || stage == 3) hipLaunchKernelGGL(record_init_qp_kernel, dim3(1), dim3(64), 0, s, st);
     return 0;
 }
 

@@ -21,11 +21,12 @@ _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (
     smooth_inf_response=True, v_baseline_penalty=1e-6, vz_offset=True, vz_offset_scale=1, vz_offset_eps=1,
     chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False,
     eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None, remove_outliers=False,
-    outlier_thresh=0.75, remove_extremes=False, extreme_kw=None, neg_allowed_tau_range=None)
+    outlier_thresh=0.75, remove_extremes=False, extreme_kw=None, neg_allowed_tau_range=None,
+    init_weights_separately=False)
 
 _UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False,
                     series_neg=False,
-                    init_weights_separately=False, peak_locations=None)
+                    peak_locations=None)
 
 
 class PreparedFitMixin:
@@ -365,8 +366,8 @@ class PreparedFitMixin:
             cf_ = rp_chrono ** 0.75 / (rp_eis ** 0.25 * rp_tot ** 0.5) if cf is None else cf
             return float(cf_), float(ef_)
         if method == 'weight':
-            raise NotImplementedError("hybrid_weight_factor_method='weight' needs the initial weights on the host "
-                                      "between initialize_weights and the loop; not built")
+            # decided on the device after initialize_weights (weight_method_kernel); a given factor stays fixed
+            return ('weight', cf, ef)
         raise ValueError(f"Invalid hybrid_weight_factor_method argument {method}. Options: 'weight', 'rp', None")
 
     def _prepared_desc(self, prep, hypers):
@@ -499,6 +500,14 @@ class PreparedFitMixin:
         shared = 'vz_offset' not in p0['special'] and all(pr['rzm'] is p0['rzm'] or np.array_equal(pr['rzm'], p0['rzm'])
                                                          for pr in preps[1:])
         desc = self._prepared_desc(p0, hypers)
+        hybrid = p0['num_chrono'] > 0 and p0['num_eis'] > 0
+        desc.init_weights_separately = int(bool(ckw['init_weights_separately']) and hybrid)
+        weight_on_device = (hybrid and ckw['hybrid_weight_factor_method'] == 'weight'
+                            and (ckw['eis_weight_factor'] is None or ckw['chrono_weight_factor'] is None))
+        if weight_on_device:
+            desc.weight_method = 1
+            desc.fixed_chrono_factor = -1.0 if ckw['chrono_weight_factor'] is None else float(ckw['chrono_weight_factor'])
+            desc.fixed_eis_factor = -1.0 if ckw['eis_weight_factor'] is None else float(ckw['eis_weight_factor'])
         if self._plan is not None:
             self._plan.close()
             self._plan_key = None
@@ -507,10 +516,12 @@ class PreparedFitMixin:
         self._plan = plan
         rows = []
         for pr, meas in zip(preps, measurements):
-            cf, ef = self._hybrid_weight_factors(pr, meas, hypers, ckw)
+            cf, ef = self._hybrid_weight_factors(pr, meas, hypers, ckw)[-2:] if weight_on_device else \
+                self._hybrid_weight_factors(pr, meas, hypers, ckw)
             pr['chrono_weight_factor'], pr['eis_weight_factor'] = cf, ef
-            rows.append(np.concatenate([np.full(pr['num_chrono'], cf), np.full(pr['m'] - pr['num_chrono'], ef)]))
-        rows = np.array(rows)
+            if not weight_on_device:
+                rows.append(np.concatenate([np.full(pr['num_chrono'], cf), np.full(pr['m'] - pr['num_chrono'], ef)]))
+        rows = np.array(rows) if rows else np.ones((1, 1))
         plan.set_weight_factors(kw['weight_factor'], None if np.all(rows == 1.0) else rows)
         plan.set_init_h(p0['h_init'])
         plan.upload(p0['rzm'] if shared else np.stack([pr['rzm'] for pr in preps]), np.stack([pr['rzv'] for pr in preps]))
@@ -519,6 +530,10 @@ class PreparedFitMixin:
         if _init_only:
             return preps, plan
         out = plan.download(s_vectors=True)
+        if weight_on_device:
+            wf = plan.get('weight_factors')
+            for b, pr in enumerate(preps):
+                pr['chrono_weight_factor'], pr['eis_weight_factor'] = float(wf[b, 0]), float(wf[b, 1])
         if opts.update_scale:
             # the device divided its scale (started at 1) by every update's factor: fold it into the host-side scales
             # (update_data_scale, drtbase.py:516-536) and take the rescaled data vector back

@@ -265,6 +265,12 @@ typedef struct {
     int num_chrono;            /* rows [0, num_chrono) are chrono samples, the rest [Re; Im] impedance rows           */
     int toeplitz_m;            /* DRT block of the penalty matrices is symmetric Toeplitz (uniform ln tau)            */
     double basis_area;         /* area of one tau basis function, sqrt(pi)/epsilon for the Gaussian basis (update_scale) */
+    int init_weights_separately; /* 1: initialize_weights once per data block (chrono rows, impedance rows), each QP seeing
+                                  only its block and each block with its own variance floor (drt1d.py:648-672)         */
+    int weight_method;         /* 1: hybrid_weight_factor_method='weight' -- row factors from the blocks' weight scales
+                                  after initialize_weights (drt1d.py:748-760); fixed_*_factor > 0 overrides one of them;
+                                  the factors used are returned by hipdrt_plan_get("weight_factors") [B][2] = chrono, eis */
+    double fixed_chrono_factor, fixed_eis_factor;
     double dop_l2_lambda_0;                                       /* qphb.py:243-253 */
     double dop_derivative_weights[3], dop_s_alpha[3], dop_rho_alpha[3], dop_s_0[3], dop_rho_0[3];
 } hipdrt_prepared_desc;

@@ -334,6 +334,10 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_wf", meas, dict(base, fit_dop=False),
                     dict(weight_factor=1.5, eis_weight_factor=2.0, chrono_weight_factor=0.5))
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_wfrp", meas, dict(base, fit_dop=False), dict(hybrid_weight_factor_method='rp'))
+    # separate initial weights per data block, and the 'weight' rule for the hybrid factors (drt1d.py:648-672, 748-760)
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_iwsep", meas, dict(base, fit_dop=False), dict(init_weights_separately=True))
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_wfw", meas, dict(base, fit_dop=False),
+                    dict(init_weights_separately=True, hybrid_weight_factor_method='weight'))
     # polynomial + square-root voltage baseline (background.py:23-37; three v_baseline coefficients)
     run_hybrid_case(DRT, cvxopt, "hybrid_vb", meas, dict(base, fit_dop=False),
                     dict(v_baseline_deg=1, v_baseline_sqrt=True, v_baseline_penalty=[1e-6, 1e-4, 1e-5]))

@@ -395,8 +395,8 @@ def test_weight_factors_match_reference_runs():
         _check_fit(drt, g, special, False)
         np.testing.assert_allclose(drt.qphb_params["true_weights"], g["weights"], rtol=1e-6)
         np.testing.assert_allclose(drt.qphb_params["weights"], g["scaled_weights"], rtol=1e-6)
-    with pytest.raises(NotImplementedError):
-        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], hybrid_weight_factor_method='weight')
+    with pytest.raises(ValueError):
+        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], hybrid_weight_factor_method='nope')
 
 
 def test_outlier_p_in_a_joint_fit_matches_reference_run():
@@ -494,3 +494,24 @@ def test_eff_hp_false_and_negative_window_match_reference_runs():
     assert fp["x"][~inside].min() >= -1e-12
     with pytest.raises(ValueError):
         drt.fit_eis(g["freq"], g["z"], neg_allowed_tau_range=(1e-5, 1e-3))
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("hybrid_s0_iwsep", dict(init_weights_separately=True)),
+    ("hybrid_s0_wfw", dict(init_weights_separately=True, hybrid_weight_factor_method='weight')),
+])
+def test_separate_initial_weights_and_weight_rule_match_reference_runs(name, kw):
+    """both run inside hipdrt_plan_fit: two masked initial QPs with per-block variance floors, row factors from the
+    initial weights' block scales"""
+    from hipdrt.models import DRT
+    g, special = load_case(name)
+    drt = DRT(warn=False)
+    drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], **kw)
+    g2 = {k: g[k] for k in g.files}
+    g2["qp_iterations"] = g["qp_iterations"][1:]            # the plan's history starts at the last initial QP
+    _check_fit(drt, g2, special, False)
+    np.testing.assert_allclose(drt.qphb_params["est_weights"], g["est_weights"], rtol=1e-6)
+    if "weight" in str(kw.get("hybrid_weight_factor_method")):
+        np.testing.assert_allclose(drt.qphb_params["eis_weight_factor"], g["eis_weight_factor"], rtol=1e-7)
+        np.testing.assert_allclose(drt.qphb_params["chrono_weight_factor"], g["chrono_weight_factor"], rtol=1e-7)
+        np.testing.assert_allclose(drt.qphb_params["weights"], g["scaled_weights"], rtol=1e-6)

@@ -331,3 +331,20 @@ def test_general_loop_eff_hp_false_and_negative_window():
     assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
     np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
     assert np.min(np.delete(r["x"], idx)) >= -1e-9          # outside the window the coefficients stay non-negative
+
+
+@pytest.mark.parametrize("name", ["hybrid_s0_iwsep", "hybrid_s0_wfw"])
+def test_general_loop_separate_initial_weights_and_weight_rule(name):
+    """init_weights_separately (one initialize_weights per data block, drt1d.py:648-672) and
+    hybrid_weight_factor_method='weight' (factors from the blocks' weight scales, 748-760)"""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case(name)
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    nc = int(g["num_chrono"])
+    r = orc.qphb_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, orc.get_default_hypers(), vz=vz,
+                              init_separately=dict(num_chrono=nc),
+                              weight_method=dict(num_chrono=nc) if name.endswith("wfw") else None)
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(r["est_weights"], g["est_weights"], rtol=1e-8)
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(r["p_matrix"], g["p_matrix"], rtol=1e-8, atol=1e-8 * np.abs(g["p_matrix"]).max())

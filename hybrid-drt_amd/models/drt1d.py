@@ -171,7 +171,8 @@ class DRT(PreparedFitMixin):
             if old in kw:
                 kw[new] = kw.pop(old)
         if self.fit_dop or self.fit_capacitance or kw.get('solve_rp') or kw.get('remove_outliers') \
-                or kw.get('remove_extremes') or kw.get('neg_allowed_tau_range') is not None:   # prepared-matrix plan
+                or kw.get('remove_extremes') or kw.get('neg_allowed_tau_range') is not None \
+                or kw.get('series_neg'):   # prepared-matrix plan
             return self._store_single(*self._fit_prepared([(None, None, None, frequencies, z)], kw, history_of=0),
                                       'qphb_eis')
         res = self._fit(frequencies, z[None, :], kw, history_of=0)

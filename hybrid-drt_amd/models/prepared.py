@@ -22,10 +22,9 @@ _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (
     chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False,
     eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None, remove_outliers=False,
     outlier_thresh=0.75, remove_extremes=False, extreme_kw=None, neg_allowed_tau_range=None,
-    init_weights_separately=False)
+    init_weights_separately=False, series_neg=False)
 
 _UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False,
-                    series_neg=False,
                     peak_locations=None)
 
 
@@ -146,7 +145,11 @@ class PreparedFitMixin:
         sp = self._general_special_params(has_chrono, has_eis, ckw['vz_offset'],
                                           int(ckw['v_baseline_deg']) + 1 + int(bool(ckw['v_baseline_sqrt'])))
         ns = int(sum(v['size'] for v in sp.values()))
-        n = ns + ntau
+        series_neg = bool(ckw['series_neg'])
+        if series_neg and not kw['nonneg']:
+            raise ValueError('Only one of series_neg and nonneg may be True')
+        ndrt = 2 * ntau if series_neg else ntau         # series_neg: a second, sign-flipped copy of the basis (drt1d.py:5497-5530)
+        n = ns + ndrt
         dop = (sp['x_dop']['index'], sp['x_dop']['index'] + sp['x_dop']['size']) if self.fit_dop else None
 
         # scale_data (drtbase.py:439-514)
@@ -176,7 +179,9 @@ class PreparedFitMixin:
             rm = np.zeros((num_chrono, n))
             a, _ = ctx.response_matrix(times, basis_tau, step_times, step_sizes, eps, mode=integrate_mode,
                                        lookup=luts['response'], layered=False)
-            rm[:, ns:] = a / input_scale
+            rm[:, ns:ns + ntau] = a / input_scale
+            if series_neg:
+                rm[:, ns + ntau:] = -(a / input_scale)
             vb, vb_scale = background.get_baseline_matrix(times, int(ckw['v_baseline_deg']), normalize=True,
                                                           sqrt=bool(ckw['v_baseline_sqrt']))
             rm[:, sp['v_baseline']['index']:sp['v_baseline']['index'] + sp['v_baseline']['size']] = vb
@@ -213,11 +218,13 @@ class PreparedFitMixin:
                     zm[:, sp['C_inv']['index']] = mat1d.construct_capacitance_impedance_vector(frequencies) * kw['capacitance_scale']
                 if self.fit_dop:
                     zm[:, dop[0]:dop[1]] = ctx.phasor_z_matrix(frequencies, self.basis_nu, self.nu_epsilon) * dop_scale
-                zm[:, ns:] = a_re + 1j * a_im
+                zm[:, ns:ns + ntau] = a_re + 1j * a_im
+                if series_neg:
+                    zm[:, ns + ntau:] = -(a_re + 1j * a_im)
                 return np.vstack([zm.real, zm.imag])
             # independent of the measured values: one build per batch
             blocks.append(self._memo('eis_block', build_eis_block, frequencies, basis_tau, eps, integrate_mode, n,
-                                     float(kw['inductance_scale']), float(kw['capacitance_scale']),
+                                     float(kw['inductance_scale']), float(kw['capacitance_scale']), series_neg,
                                      dop_scale if dop_scale is not None else 0))
             z_scaled = z / impedance_scale
             rows.append(np.concatenate([z_scaled.real, z_scaled.imag]))
@@ -254,10 +261,10 @@ class PreparedFitMixin:
                     mk[sp['vz_offset']['index'], sp['vz_offset']['index']] = 1 / ckw['vz_offset_scale']
                 if self.fit_dop:
                     mk[dop[0]:dop[1], dop[0]:dop[1]] = m_dop[k]
-                mk[ns:, ns:] = m_drt[k]
+                mk[ns:, ns:] = np.kron(np.eye(2), m_drt[k]) if series_neg else m_drt[k]
                 pen.append(mk)
             return pen
-        pen = self._memo('pen', build_penalties, ln_tau, eps, n, str(sorted(sp.items())), str(ckw['v_baseline_penalty']),
+        pen = self._memo('pen', build_penalties, ln_tau, eps, n, str(sorted(sp.items())), series_neg, str(ckw['v_baseline_penalty']),
                          float(kw['inductance_penalty']), float(kw['ohmic_penalty']), float(kw['capacitance_penalty']),
                          float(ckw['vz_offset_scale']))
 
@@ -299,7 +306,7 @@ class PreparedFitMixin:
 
         prep.update(rzm=rzm, rzv=rzv, pen=pen, vmm=vmm, special=sp, ns=ns, n=n, m=m, dop=dop, l1=l1, h=h, h_init=h_init,
                     vz_strength=vz_strength, num_chrono=num_chrono, num_eis=len(frequencies) if has_eis else 0,
-                    basis_tau=basis_tau, toeplitz_m=tpl_m, coefficient_scale=coefficient_scale,
+                    basis_tau=basis_tau, toeplitz_m=tpl_m and not series_neg, coefficient_scale=coefficient_scale,
                     impedance_scale=impedance_scale, input_signal_scale=input_scale, response_signal_scale=response_scale,
                     dop_scale_vector=dop_scale, frequencies=frequencies)
         return prep

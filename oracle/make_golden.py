@@ -338,6 +338,9 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_iwsep", meas, dict(base, fit_dop=False), dict(init_weights_separately=True))
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_wfw", meas, dict(base, fit_dop=False),
                     dict(init_weights_separately=True, hybrid_weight_factor_method='weight'))
+    # series_neg: a sign-flipped second copy of the basis (drt1d.py:5497-5530)
+    run_hybrid_case(DRT, cvxopt, "golden71x91_sneg", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
+                    dict(series_neg=True))
     # polynomial + square-root voltage baseline (background.py:23-37; three v_baseline coefficients)
     run_hybrid_case(DRT, cvxopt, "hybrid_vb", meas, dict(base, fit_dop=False),
                     dict(v_baseline_deg=1, v_baseline_sqrt=True, v_baseline_penalty=[1e-6, 1e-4, 1e-5]))

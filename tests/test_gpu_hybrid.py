@@ -515,3 +515,16 @@ def test_separate_initial_weights_and_weight_rule_match_reference_runs(name, kw)
         np.testing.assert_allclose(drt.qphb_params["eis_weight_factor"], g["eis_weight_factor"], rtol=1e-7)
         np.testing.assert_allclose(drt.qphb_params["chrono_weight_factor"], g["chrono_weight_factor"], rtol=1e-7)
         np.testing.assert_allclose(drt.qphb_params["weights"], g["scaled_weights"], rtol=1e-6)
+
+
+def test_series_neg_matches_reference_run():
+    """series_neg=True: 2 x ntau non-negative coefficients over [A, -A], block-diagonal penalties (non-Toeplitz branch of the
+    hyper kernel)"""
+    from hipdrt.models import DRT
+    g, special = load_case("golden71x91_sneg")
+    drt = DRT(warn=False)
+    fp = drt.fit_eis(g["freq"], g["z"], series_neg=True)
+    assert len(fp["x"]) == 2 * len(g["basis_tau"])
+    _check_fit(drt, g, special, False)
+    with pytest.raises(ValueError):
+        drt.fit_eis(g["freq"], g["z"], series_neg=True, nonneg=False)

@@ -190,7 +190,7 @@ def test_oracle_optional_weight_branches_match_reference_run(name, kw):
 
 # ---- config-5 family: distribution of phasances inside the loop, joint chrono + EIS fits ----------------------------
 @pytest.mark.parametrize("name", ["golden71x91_dop", "hybrid_s0", "hybrid_s0_dop", "chrono_s1", "hybrid_3step",
-                                  "hybrid_3step_opts", "eis_cap", "hybrid_cap", "hybrid_vb"])
+                                  "hybrid_3step_opts", "eis_cap", "hybrid_cap", "hybrid_vb", "golden71x91_sneg"])
 def test_general_loop_reproduces_reference_trajectory(name):
     """oracle.qphb_fit_prepared (the loop of drt1d.py:551-1006 with the DOP pass of qphb.py:822-933 and the vz_offset
     column rewrite of drt1d.py:973-979) on the reference run's own matrices: identical outer / IPM iteration counts,

@@ -22,9 +22,9 @@ _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (
     chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False,
     eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None, remove_outliers=False,
     outlier_thresh=0.75, remove_extremes=False, extreme_kw=None, neg_allowed_tau_range=None,
-    init_weights_separately=False, series_neg=False)
+    init_weights_separately=False, series_neg=False, discard_first_n=None)
 
-_UNSUPPORTED = dict(discard_first_n=None, downsample=False, subtract_background=False,
+_UNSUPPORTED = dict(downsample=False, subtract_background=False,
                     peak_locations=None)
 
 
@@ -452,6 +452,20 @@ class PreparedFitMixin:
     def _fit_prepared(self, measurements, fit_kw, history_of=-1, _init_only=False):
         """measurements: list of (times, i_signal, v_signal, frequencies, z) of identical shapes (one protocol)."""
         ckw, rest = self._split_kwargs(fit_kw)
+        if ckw['discard_first_n'] is not None and any(meas[0] is not None for meas in measurements):
+            # drt1d.py:167-178: drop the first samples of every step; the step is then assumed to have happened that much
+            # earlier than the first kept sample
+            nd = int(ckw['discard_first_n'])
+            cleaned, offset = [], ckw['step_offset_size']
+            for times, i_signal, v_signal, frequencies, z in measurements:
+                dt_short = np.min(np.diff(times))
+                _, (times, i_signal, v_signal) = pp.discard_first_n_chrono(times, i_signal, v_signal, nd, self.chrono_mode)
+                if ckw['step_offset_size'] is None:
+                    offset = -(dt_short + np.min(np.diff(times)) * (nd - 1e-8))
+                cleaned.append((times, i_signal, v_signal, frequencies, z))
+            measurements = cleaned
+            fit_kw = dict(fit_kw, discard_first_n=None, step_offset_size=offset)
+            ckw, rest = self._split_kwargs(fit_kw)
         if ckw['remove_extremes']:
             # drt1d.py:187-212: rough pre-filter on the raw signals (quantile-range rule), before anything else
             if len(measurements) != 1:

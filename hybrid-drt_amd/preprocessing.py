@@ -179,3 +179,13 @@ def identify_extreme_values(y, qr_size=0.5, qr_thresh=1.5):
     """preprocessing.identify_extreme_values (854-857)."""
     y_min, y_max = get_quantile_limits(y, qr_size, qr_thresh)
     return (y < y_min) | (y > y_max)
+
+
+def discard_first_n_chrono(times, i_signal, v_signal, n, op_mode='galv', step_indices=None):
+    """preprocessing.discard_first_n_chrono (471-504): drop the first n samples of every segment (the pre-step segment
+    included) -- for instruments whose first points after a step are perturbed.  Returns (kept indices, (t, i, v))."""
+    if step_indices is None:
+        step_indices = identify_steps(i_signal if op_mode == 'galv' else v_signal, False)
+    bounds = np.concatenate(([0], step_indices, [len(times)]))
+    keep = np.concatenate([np.arange(a + n, b) for a, b in zip(bounds[:-1], bounds[1:])])
+    return keep, (np.asarray(times)[keep], np.asarray(i_signal)[keep], np.asarray(v_signal)[keep])

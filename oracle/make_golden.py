@@ -341,6 +341,8 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     # series_neg: a sign-flipped second copy of the basis (drt1d.py:5497-5530)
     run_hybrid_case(DRT, cvxopt, "golden71x91_sneg", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(series_neg=True))
+    # discard_first_n (drt1d.py:167-178, preprocessing.py:471-504)
+    run_hybrid_case(DRT, cvxopt, "hybrid_s0_discard", meas, dict(base, fit_dop=False), dict(discard_first_n=2))
     # polynomial + square-root voltage baseline (background.py:23-37; three v_baseline coefficients)
     run_hybrid_case(DRT, cvxopt, "hybrid_vb", meas, dict(base, fit_dop=False),
                     dict(v_baseline_deg=1, v_baseline_sqrt=True, v_baseline_penalty=[1e-6, 1e-4, 1e-5]))

@@ -528,3 +528,17 @@ def test_series_neg_matches_reference_run():
     _check_fit(drt, g, special, False)
     with pytest.raises(ValueError):
         drt.fit_eis(g["freq"], g["z"], series_neg=True, nonneg=False)
+
+
+def test_discard_first_n_matches_reference_run():
+    """discard_first_n=2: first two samples of every segment dropped, step time inferred from the shortened record"""
+    from hipdrt.models import DRT
+    from hipdrt import preprocessing as pp
+    g, special = load_case("hybrid_s0_discard")
+    keep, (t, i_, v_) = pp.discard_first_n_chrono(g["times"], g["i_signal"], g["v_signal"], 2)
+    assert len(t) == int(g["num_chrono"]) == len(g["times"]) - 4 and keep[0] == 2
+    drt = DRT(warn=False)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], discard_first_n=2)
+    np.testing.assert_allclose(drt.step_times, g["step_times"], rtol=1e-14)
+    _check_fit(drt, g, special, False)
+    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)

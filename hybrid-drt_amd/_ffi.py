@@ -79,6 +79,8 @@ SIGNATURES = {
     "hipdrt_response_lookup": [_vp, C.c_double, C.c_int, C.c_int, _dp, _dp],
     "hipdrt_response_matrix": [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp,
                                C.c_int, _dp, _dp],
+    "hipdrt_nonuniform_gaussian_filter1d": [_vp, _dp, C.c_int, _dp, _ip, C.c_int, _ip, _dp, C.c_int, _dp, _dp, C.c_longlong,
+                                            _ip, _ip, _dp],
     "hipdrt_penalty_matrices": [_vp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp],
     "hipdrt_eis_var_matrix": [_vp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp],
     "hipdrt_qp_batch": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.POINTER(QpOpts), _dp, _ip, _dp, _ip],
@@ -284,6 +286,16 @@ class Context:
                                                 int(mode), float(epsilon), ng, plt, pv, int(ny), _p(a),
                                                 _p(lay) if layered else None))
         return a, lay
+
+    def nonuniform_gaussian_filter1d(self, y, sigma, seg, filtered, nodes, node_delta, weights, woff, radius):
+        """segment-wise blended Gaussian filter; see hipdrt.filters.nonuniform_gaussian_filter1d for the set-up"""
+        y, sigma, nodes, node_delta, weights = _f64(y), _f64(sigma), _f64(nodes), _f64(node_delta), _f64(weights)
+        seg, filtered, woff, radius = (np.ascontiguousarray(a, dtype=np.int32) for a in (seg, filtered, woff, radius))
+        out = np.empty_like(y)
+        _check(self._lib.hipdrt_nonuniform_gaussian_filter1d(self._h, _p(y), y.size, _p(sigma), _pi(seg), seg.size - 1,
+                                                             _pi(filtered), _p(nodes), nodes.shape[1], _p(node_delta),
+                                                             _p(weights), weights.size, _pi(woff), _pi(radius), _p(out)))
+        return out
 
     def penalty_matrices(self, ln_tau, epsilon, toeplitz):
         ln_tau = _f64(ln_tau)

@@ -345,6 +345,39 @@ int hipdrt_impedance_matrix(hipdrt_ctx* ctx, int B, int freq_batched, const doub
     return HIPDRT_OK;
 }
 
+int hipdrt_nonuniform_gaussian_filter1d(hipdrt_ctx* ctx, const double* y, int n, const double* sigma, const int* seg, int nseg,
+                                        const int* filtered, const double* nodes, int K, const double* node_delta,
+                                        const double* weights, long long nweights, const int* woff, const int* radius,
+                                        double* out) {
+    HIPDRT_REQUIRE(ctx && y && sigma && seg && filtered && nodes && node_delta && weights && woff && radius && out, "NULL pointer");
+    HIPDRT_REQUIRE(n >= 1 && nseg >= 1 && K >= 1 && nweights >= 1, "n, nseg, K, nweights >= 1");
+    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // sample -> segment map (or -1 for an unfiltered segment)
+    std::vector<int> seg_of(n, -1);
+    for (int s_ = 0; s_ < nseg; ++s_) {
+        HIPDRT_REQUIRE(seg[s_] >= 0 && seg[s_] <= seg[s_ + 1] && seg[s_ + 1] <= n, "segment bounds");
+        if (filtered[s_]) for (int i = seg[s_]; i < seg[s_ + 1]; ++i) seg_of[i] = s_;
+    }
+    DevBuf dy, dsg, dso, dseg, dnodes, dnd, dw, dwo, drad, dout;
+    TRY(upload(dy, y, (size_t)n * sizeof(double), st));
+    TRY(upload(dsg, sigma, (size_t)n * sizeof(double), st));
+    TRY(upload(dso, seg_of.data(), (size_t)n * sizeof(int), st));
+    TRY(upload(dseg, seg, (size_t)(nseg + 1) * sizeof(int), st));
+    TRY(upload(dnodes, nodes, (size_t)nseg * K * sizeof(double), st));
+    TRY(upload(dnd, node_delta, (size_t)nseg * sizeof(double), st));
+    TRY(upload(dw, weights, (size_t)nweights * sizeof(double), st));
+    TRY(upload(dwo, woff, (size_t)nseg * K * sizeof(int), st));
+    TRY(upload(drad, radius, (size_t)nseg * K * sizeof(int), st));
+    HIPDRT_CHECK(dout.alloc((size_t)n * sizeof(double)));
+    launch_nonuniform_gauss(st, dy.d(), n, dsg.d(), dso.i(), dseg.i(), dnodes.d(), K, dnd.d(), dw.d(), dwo.i(), drad.i(),
+                            dout.d());
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
 int hipdrt_penalty_matrices(hipdrt_ctx* ctx, const double* ln_tau, int n, double epsilon, int toeplitz, double* m0,
                             double* m1, double* m2) {
     HIPDRT_REQUIRE(ctx && ln_tau && m0 && m1 && m2, "NULL pointer");

@@ -89,6 +89,9 @@ void launch_response_lookup(hipStream_t st, double eps, int ngrid, int ny, const
 void launch_response_matrix(hipStream_t st, const double* times, int nt, const double* tau, int ntau,
                             const double* step_times, const double* step_sizes, int nsteps, int mode, double eps,
                             int ngrid, const double* lut3, int ny, double* a, double* layered);
+void launch_nonuniform_gauss(hipStream_t st, const double* y, int n, const double* sigma, const int* seg_of, const int* seg,
+                             const double* nodes, int K, const double* node_delta, const double* weights, const int* woff,
+                             const int* radius, double* out);
 void launch_penalty(hipStream_t st, const double* ln_tau, int n, double eps, int toeplitz, double* m0, double* m1,
                     double* m2, int ld, int pad);
 void launch_eis_vmm(hipStream_t st, const double* freq, int nf, double vmm_eps, double reim_cor, int uniform,

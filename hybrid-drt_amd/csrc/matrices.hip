@@ -619,4 +619,64 @@ void launch_eis_vmm(hipStream_t st, const double* freq, int nf, double vmm_eps, 
     hipLaunchKernelGGL(eis_vmm_kernel, dim3(2 * nf), dim3(256), 0, st, freq, nf, vmm_eps, reim_cor, uniform, vmm);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// filters.nonuniform_gaussian_filter1d (hybdrt/filters/_filters.py:261-343), order 0, mode 'reflect', empty=False: the
+// anti-aliasing filter of the chrono down-sampling (preprocessing.filter_chrono_signal, 507-572).  Every sample has its own
+// sigma; the reference evaluates scipy's gaussian_filter1d at log-spaced sigma nodes and blends the node outputs with
+// triangular weights in log sigma.  Here one thread per sample evaluates only the (at most two) nodes that carry weight,
+// with scipy's symmetric correlation order  y[i] w0 + sum_j (y[i-j] + y[i+j]) w_j  and its 'reflect' boundary
+// (d c b a | a b c d | d c b a).  weights[woff[k] + j], j = 0..radius[k], are the normalised kernel halves (host: numpy,
+// exactly as scipy builds them); a node with radius < 0 returns the input (sigma below min_sigma).
+// seg[s], seg[s+1] bound the step segments: the reference filters every segment separately.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nonuniform_gauss_kernel(const double* __restrict__ y, int n,
+                                                               const double* __restrict__ sigma,
+                                                               const int* __restrict__ seg_of, const int* __restrict__ seg,
+                                                               const double* __restrict__ nodes, int K,
+                                                               const double* __restrict__ node_delta,
+                                                               const double* __restrict__ weights,
+                                                               const int* __restrict__ woff, const int* __restrict__ radius,
+                                                               double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = seg_of[i];
+    if (s < 0) { out[i] = y[i]; return; }                 // segment without filtering (all sigma zero)
+    const int a = seg[s], len = seg[s + 1] - a, li = i - a;
+    const double sg = sigma[i];
+    const int kb = s * K;                                  // nodes are per segment
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double node = nodes[kb + k];
+        if (!(node > 0.0)) continue;                       // unused slot
+        double nw = fabs(log(sg / node)) / node_delta[s];
+        if (nw >= 1.0) nw = 1.0;
+        nw = 1.0 - nw;
+        if (nw == 0.0) continue;                           // exact zero: adds nothing in the reference either
+        double v;
+        const int r = radius[kb + k];
+        if (r < 0) {
+            v = y[i];
+        } else {
+            const double* w = weights + woff[kb + k];
+            v = y[i] * w[0];
+            for (int j = 1; j <= r; ++j) {
+                int lo = li - j, hi = li + j;
+                // scipy 'reflect': period 2 len, mirrored about the half-sample edges
+                if (lo < 0) { lo = -lo - 1; if (lo >= len) { lo %= 2 * len; if (lo >= len) lo = 2 * len - 1 - lo; } }
+                if (hi >= len) { hi %= 2 * len; if (hi >= len) hi = 2 * len - 1 - hi; }
+                v += (y[a + lo] + y[a + hi]) * w[j];
+            }
+        }
+        acc += v * nw;
+    }
+    out[i] = acc;
+}
+
+void launch_nonuniform_gauss(hipStream_t st, const double* y, int n, const double* sigma, const int* seg_of, const int* seg,
+                             const double* nodes, int K, const double* node_delta, const double* weights, const int* woff,
+                             const int* radius, double* out) {
+    hipLaunchKernelGGL(nonuniform_gauss_kernel, dim3((n + 255) / 256), dim3(256), 0, st, y, n, sigma, seg_of, seg, nodes, K,
+                       node_delta, weights, woff, radius, out);
+}
+
 }  // namespace hipdrt

@@ -22,9 +22,9 @@ _CHRONO_KW_DEFAULTS = dict(  # _qphb_fit_core chrono / hybrid keyword defaults (
     chrono_error_structure='uniform', chrono_vmm_epsilon=4, solve_rp=False, v_baseline_deg=0, v_baseline_sqrt=False,
     eis_weight_factor=None, chrono_weight_factor=None, hybrid_weight_factor_method=None, remove_outliers=False,
     outlier_thresh=0.75, remove_extremes=False, extreme_kw=None, neg_allowed_tau_range=None,
-    init_weights_separately=False, series_neg=False, discard_first_n=None)
+    init_weights_separately=False, series_neg=False, discard_first_n=None, downsample=False, downsample_kw=None)
 
-_UNSUPPORTED = dict(downsample=False, subtract_background=False,
+_UNSUPPORTED = dict(subtract_background=False,
                     peak_locations=None)
 
 
@@ -141,6 +141,14 @@ class PreparedFitMixin:
             self.tau_epsilon = 1 / np.mean(np.diff(np.log(basis_tau)))
         eps = float(self.tau_epsilon)
         ntau = len(basis_tau)
+        if has_chrono and ckw['downsample']:
+            # drtbase.py:324-340: anti-aliased down-sampling (device filter) once the steps and the basis grid are known;
+            # everything below works on the kept samples
+            dkw = ckw['downsample_kw'] if ckw['downsample_kw'] is not None else {'prestep_samples': 10, 'target_times': None}
+            times, i_signal, v_signal, sample_index = pp.downsample_data(
+                times, i_signal, v_signal, stepwise_sample_times=True, step_times=prep['nonconsec_step_times'],
+                op_mode=self.chrono_mode, device=self.device, **dkw)
+            prep.update(sample_times=times, sample_index=sample_index)
         luts = self._lookups(ctx) if integrate_mode == _ffi.MODE_INTERP else dict(z=None, response=None)
         sp = self._general_special_params(has_chrono, has_eis, ckw['vz_offset'],
                                           int(ckw['v_baseline_deg']) + 1 + int(bool(ckw['v_baseline_sqrt'])))

@@ -189,3 +189,84 @@ def discard_first_n_chrono(times, i_signal, v_signal, n, op_mode='galv', step_in
     bounds = np.concatenate(([0], step_indices, [len(times)]))
     keep = np.concatenate([np.arange(a + n, b) for a, b in zip(bounds[:-1], bounds[1:])])
     return keep, (np.asarray(times)[keep], np.asarray(i_signal)[keep], np.asarray(v_signal)[keep])
+
+
+# ---- down-sampling with anti-aliasing (preprocessing.py:335-470, 507-589) ---------------------------------------------
+def nearest_index(x_array, x_val):
+    """utils.array.nearest_index without a constraint"""
+    return int(np.argmin(np.abs(np.asarray(x_array) - x_val)))
+
+
+def sigma_from_decimate_index(y, decimate_index, truncate=4.0):
+    """preprocessing.sigma_from_decimate_index (575-589): filter width that reaches halfway to the nearest kept sample
+    at `truncate` standard deviations; kept samples with kept neighbours are not filtered."""
+    sigmas = np.zeros(len(y))
+    diff = np.diff(decimate_index)
+    min_diff = np.minimum(np.insert(diff, 0, diff[0]), np.append(diff, diff[-1]))
+    sigma_dec = min_diff / (2 * truncate)
+    sigma_dec[min_diff < 2] = 0
+    sigmas[decimate_index] = sigma_dec
+    return sigmas
+
+
+def filter_chrono_signal(times, y, step_index=None, input_signal=None, decimate_index=None, sigma_factor=0.01,
+                         max_sigma=None, device=0):
+    """preprocessing.filter_chrono_signal (507-572; no outlier removal, no median pre-filter): per step segment a Gaussian
+    filter whose width grows with the time since the step (sigma ~ e (t - t_step) / 2, in samples, times sigma_factor),
+    capped by max_sigma and by the decimation widths; the correlations run on the device."""
+    from . import filters
+    if step_index is None and input_signal is None:
+        raise ValueError('Either step_index or input_signal must be provided')
+    if step_index is None:
+        step_index = identify_steps(input_signal, allow_consecutive=False)
+    times = np.asarray(times, dtype=float)
+    step_index = np.array(step_index)
+    bounds = step_index
+    if bounds[0] > 0:
+        bounds = np.insert(bounds, 0, 0)
+    if bounds[-1] < len(y):
+        bounds = np.append(bounds, len(y))
+    t_sample = np.median(np.diff(times))
+    if max_sigma is None:
+        max_sigma = sigma_factor / t_sample
+    dec = sigma_from_decimate_index(y, decimate_index) if decimate_index is not None else None
+    sigmas = np.empty(len(y))
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        t_step = times[a:b]
+        sg = sigma_factor * ((np.exp(1) * (t_step - (t_step[0] - t_sample)) / 2) / t_sample)
+        sg[sg > max_sigma] = max_sigma
+        if dec is not None:
+            sg = np.minimum(dec[a:b], sg)
+        sigmas[a:b] = sg
+    return filters.nonuniform_gaussian_filter1d_segments(y, sigmas, bounds, device=device)
+
+
+def downsample_data(times, i_signal, v_signal, target_times=None, stepwise_sample_times=True, step_times=None,
+                    step_model=None, method='match', antialiased=True, filter_kw=None, op_mode='galv', prestep_samples=20,
+                    device=0):
+    """preprocessing.downsample_data (335-470), method='match': keep the samples closest to `target_times` after every step
+    (all post-step samples when None) and the whole pre-step record, after an anti-aliasing filter matched to the local
+    decimation.  Returns (sample_times, sample_i, sample_v, sample_index)."""
+    if method != 'match':
+        raise NotImplementedError("only method='match' is built")
+    if not stepwise_sample_times:
+        raise NotImplementedError("only stepwise_sample_times=True is built")
+    times, i_signal, v_signal = (np.asarray(a, dtype=float) for a in (times, i_signal, v_signal))
+    if step_times is None:
+        step_indices = identify_steps(i_signal if op_mode == 'galv' else v_signal, step_model == 'ideal')
+        step_times = times[step_indices]
+    else:
+        step_indices = get_step_indices_from_step_times(times, step_times)
+    if target_times is not None:
+        target = np.unique(np.concatenate([np.asarray(target_times) + ts for ts in step_times]))
+        sample_index = np.unique(np.array([nearest_index(times, tt) for tt in target]))
+    else:
+        sample_index = np.arange(step_indices[0], len(times), dtype=int)
+    if step_indices[0] > 0 and prestep_samples > 0:
+        sample_index = np.unique(np.concatenate((np.arange(0, step_indices[0], dtype=int), sample_index)))
+    if antialiased:
+        fkw = filter_kw or {}
+        step_index = identify_steps(i_signal if op_mode == 'galv' else v_signal, allow_consecutive=False)
+        i_signal = filter_chrono_signal(times, i_signal, step_index=step_index, decimate_index=sample_index, device=device, **fkw)
+        v_signal = filter_chrono_signal(times, v_signal, step_index=step_index, decimate_index=sample_index, device=device, **fkw)
+    return times[sample_index], i_signal[sample_index], v_signal[sample_index], sample_index

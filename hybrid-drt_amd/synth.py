@@ -47,7 +47,7 @@ def config_c2():
 
 
 def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, t_step=0.05, dt_pre=5e-4,
-                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57, jitter=False, extra_steps=(), c_series=None):
+                       t_lo=1e-4, t_hi=50.0, i_step=1e-3, v0=0.1, v_noise=2e-6, n_rc=57, jitter=False, extra_steps=(), c_series=None, uniform_dt=None):
     """Joint time/frequency-domain measurement of the same 2-ZARC cell (SURVEY.md section 8d, config 5 family):
     a galvanostatic step of ``i_step`` at ``t_step`` (n_pre uniform samples before it, n_post log-uniform after it)
     whose voltage comes from the closed-form response of an RC (Debye) discretisation of the two ZARCs, plus the
@@ -56,7 +56,8 @@ def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, 
     ``jitter=True`` perturbs (R1, R2, tau1, tau2) exactly as :func:`zarc2_spectrum` does for batch members, in both
     data sets.  ``extra_steps`` = ((delay, current change), ...) appends further current steps, each followed by its own
     n_post log-uniform samples (superposition of the RC responses).  ``c_series`` adds a series (blocking) capacitance to
-    both data sets.  Returns (times, i_signal, v_signal, freq, z).
+    both data sets.  ``uniform_dt`` samples every segment uniformly instead (a raw potentiostat record: n_post samples at
+    that period).  Returns (times, i_signal, v_signal, freq, z).
     """
     p = dict(BASE)
     if jitter:
@@ -70,14 +71,15 @@ def hybrid_measurement(seed=0, n_pre=24, n_post=200, nf=41, f_hi=1e5, f_lo=1e1, 
     z = zarc2_spectrum(freq, seed, jitter=jitter)
     if c_series is not None:
         z = z + 1.0 / (1j * 2 * np.pi * freq * c_series)
-    pre = t_step - dt_pre * np.arange(n_pre, 0, -1)
+    pre = t_step - (uniform_dt if uniform_dt is not None else dt_pre) * np.arange(n_pre, 0, -1)
     steps = [(t_step, i_step)]
     for delay, di in extra_steps:
         steps.append((steps[-1][0] + delay, di))
     segs = [pre]
     for k, (ts, _) in enumerate(steps):
         t_end = t_hi if k == len(steps) - 1 else 0.999 * (steps[k + 1][0] - ts)
-        segs.append(ts + np.logspace(np.log10(t_lo), np.log10(t_end), n_post))
+        segs.append(ts + (uniform_dt * np.arange(1, n_post + 1) if uniform_dt is not None
+                          else np.logspace(np.log10(t_lo), np.log10(t_end), n_post)))
     times = np.concatenate(segs)
     i_signal = np.zeros(len(times))
     for ts, di in steps:

@@ -106,6 +106,19 @@ int hipdrt_response_matrix(hipdrt_ctx* ctx, const double* times, int nt, const d
                            double epsilon, int ngrid, const double* log_td, const double* v, int ny,
                            double* a, double* layered);
 
+/* filters.nonuniform_gaussian_filter1d (hybdrt/filters/_filters.py:261-343; order 0, mode 'reflect', empty=False) applied
+ * segment by segment: the anti-aliasing filter of the chrono down-sampling (preprocessing.filter_chrono_signal, 507-572,
+ * called by downsample_data, 423-432).  y[n], sigma[n] (per-sample filter widths in samples, already capped);
+ * seg[nseg+1] sample-index bounds of the step segments; per segment s its log-spaced sigma nodes nodes[s*K .. s*K+K)
+ * (0 = unused slot), node_delta[nseg] = log spacing of the nodes, radius[s*K+k] = int(4 sigma + 0.5) or -1 for a node
+ * below min_sigma (output = input), weights[woff[s*K+k] + j], j = 0..radius, the normalised Gaussian kernel halves
+ * (scipy.ndimage._filters._gaussian_kernel1d); filtered[s] = 0 skips a segment (all widths zero).  out[n].
+ * The caller (hipdrt.filters / hipdrt.preprocessing) derives nodes and kernels exactly as the reference does. */
+int hipdrt_nonuniform_gaussian_filter1d(hipdrt_ctx* ctx, const double* y, int n, const double* sigma, const int* seg,
+                                        int nseg, const int* filtered, const double* nodes, int K,
+                                        const double* node_delta, const double* weights, long long nweights,
+                                        const int* woff, const int* radius, double* out);
+
 /* mat1d.construct_integrated_derivative_matrix (hybdrt/matrices/mat1d.py:125-209), orders 0,1,2 of the
  * Gaussian basis (closed forms basis.py:382-395).  toeplitz != 0: first column scattered (mat1d.py:158-168).
  * out: m0, m1, m2 each [n][n]                                                                        */

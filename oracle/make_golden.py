@@ -273,6 +273,10 @@ def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
         out.update(basis_nu=drt.basis_nu, nu_epsilon=drt.nu_epsilon, dop_scale_vector=drt.dop_scale_vector,
                    dop_rho_vector=qp["dop_rho_vector"], dop_xmx_norms=qp["dop_xmx_norms"], x_dop=fp["x_dop"],
                    hist_dop_rho=np.array([h["dop_rho_vector"] for h in drt.qphb_history]))
+    if fit_kw.get("downsample"):
+        out["sample_index"] = drt.sample_index
+        out["sample_v"] = drt.raw_response_signal
+        out["downsample_target_times"] = fit_kw["downsample_kw"]["target_times"]
     if times is not None:
         out.update(times=times, i_signal=i_sig, v_signal=v_sig, sample_times=drt.get_fit_times(),
                    step_times=drt.step_times, step_sizes=drt.step_sizes,
@@ -343,6 +347,11 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
                     dict(series_neg=True))
     # discard_first_n (drt1d.py:167-178, preprocessing.py:471-504)
     run_hybrid_case(DRT, cvxopt, "hybrid_s0_discard", meas, dict(base, fit_dop=False), dict(discard_first_n=2))
+    # anti-aliased down-sampling of a densely sampled record (drtbase.py:324-340, preprocessing.py:335-470, 507-589)
+    dense = synth.hybrid_measurement(seed=5, n_pre=200, n_post=6000, uniform_dt=2.5e-4, v_noise=2e-5)
+    tt = np.concatenate(([0], np.logspace(-3.5, np.log10(1.45), 81)))
+    run_hybrid_case(DRT, cvxopt, "hybrid_downsample", dense, dict(base, fit_dop=False),
+                    dict(downsample=True, downsample_kw=dict(prestep_samples=10, target_times=tt)))
     # polynomial + square-root voltage baseline (background.py:23-37; three v_baseline coefficients)
     run_hybrid_case(DRT, cvxopt, "hybrid_vb", meas, dict(base, fit_dop=False),
                     dict(v_baseline_deg=1, v_baseline_sqrt=True, v_baseline_penalty=[1e-6, 1e-4, 1e-5]))

@@ -74,3 +74,17 @@ def test_special_parameter_layout(case):
     np.testing.assert_allclose(drt.basis_nu, g["basis_nu"])
     drt.fit_dop = False
     assert list(drt._general_special_params(False, True, True)) == ["R_inf", "inductance"]
+
+
+def test_antialias_filter_oracle_matches_reference_run():
+    """oracle/filters_oracle.py (scipy-based restatement of the blended Gaussian filter and its width rule) reproduces the
+    down-sampled, filtered voltage record of the reference run; the host-side width rule of the product agrees with it"""
+    from oracle import filters_oracle
+    from hipdrt import preprocessing as pp
+    g, _ = load_case("hybrid_downsample")
+    idx = g["sample_index"]
+    step_index = pp.identify_steps(g["i_signal"], allow_consecutive=False)
+    vf = filters_oracle.filter_chrono_signal(g["times"], g["v_signal"], step_index, idx)
+    np.testing.assert_allclose(vf[idx], g["sample_v"], rtol=0, atol=1e-14 * np.abs(g["sample_v"]).max())
+    sd = pp.sigma_from_decimate_index(g["v_signal"], idx)
+    assert sd.max() > 1 and np.all(sd[np.setdiff1d(np.arange(len(sd)), idx)] == 0)

@@ -150,7 +150,7 @@ def test_fit_hybrid_matches_reference_run(dop):
     np.testing.assert_allclose(fp["v_sigma_tot"], g["v_sigma_tot"], rtol=1e-6)
     assert drt.fit_type == "qphb_hybrid"
     with pytest.raises(NotImplementedError):
-        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], downsample=True)
+        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], subtract_background=True)
     with pytest.raises(ValueError):
         drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], not_a_keyword=1)
 

@@ -82,6 +82,7 @@ def main():
                          "round-robin to them, so the low-occupancy tail of one step overlaps the next step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix-build", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the single-spectrum and config-5 timings")
     args = ap.parse_args()
 
     import torch
@@ -222,6 +223,26 @@ def main():
                                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": byts,
                                             "avg_launch_ms": ms / reps}
+        if world == 1 and not args.no_other_configs:
+            # the other BASELINE configs as measured here (parity cases, not the bench metric): configs[1] one spectrum
+            # 256 x 512, configs[4] one joint chrono + EIS fit with DOP (512 f + 4096 t x 1024 tau); wall time of the
+            # second call (plans and lookup tables warm), inputs handed over as host arrays
+            other = {}
+            t0 = time.perf_counter()
+            one = drt.fit_eis_batch(freq, z[:1])
+            other["config1_single_spectrum_256x512"] = {"seconds": time.perf_counter() - t0,
+                                                        "outer_iterations": int(one["outer_iters"][0])}
+            meas = synth.hybrid_measurement(seed=0, n_pre=96, n_post=4000, nf=512)
+            d5 = DRT(fixed_basis_tau=np.logspace(-7, 3, 1024), fit_dop=True, warn=False, device=local)
+            d5.fit_hybrid(*meas, max_iter=2)
+            t0 = time.perf_counter()
+            d5.fit_hybrid(*meas)
+            tm5 = d5._plan.timings()[0]
+            other["config4_joint_fit_dop_512f_4096t_1024tau"] = {
+                "seconds": time.perf_counter() - t0, "device_loop_seconds": tm5["total"] / 1e3,
+                "qp_seconds": tm5["qp"] / 1e3, "rows": int(d5.qphb_params["rm"].shape[0]),
+                "unknowns": int(d5.qphb_params["rm"].shape[1]), "outer_iterations": int(d5.qphb_params["outer_iterations"])}
+            out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(freq, tau, z)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

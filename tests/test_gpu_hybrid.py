@@ -542,3 +542,53 @@ def test_discard_first_n_matches_reference_run():
     np.testing.assert_allclose(drt.step_times, g["step_times"], rtol=1e-14)
     _check_fit(drt, g, special, False)
     np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_randomised_joint_fits_follow_the_oracle(seed):
+    """randomised differential test of the prepared path: protocol (samples, steps, frequencies), cell, noise, DOP, series
+    capacitance, baseline degree and vz options vary; the device loop must reproduce the oracle's loop on the same
+    (device-built) matrices -- identical outer / IPM iteration counts over the first twelve outer iterations (the
+    reference's iteration is not always contractive beyond that, see the config-5 test) and the iterates."""
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    rng = np.random.default_rng(1000 + seed)
+    dop = bool(rng.integers(2))
+    cap = bool(rng.integers(2)) and not dop
+    steps = ((float(rng.uniform(0.5, 3.0)), float(-rng.uniform(0.5, 2.0) * 1e-3)),) if rng.integers(2) else ()
+    meas = synth.hybrid_measurement(seed=seed, n_pre=int(rng.integers(8, 40)), n_post=int(rng.integers(50, 160)),
+                                    nf=int(rng.integers(21, 52)), f_hi=10 ** rng.uniform(4, 5.5), f_lo=10 ** rng.uniform(0, 1.5),
+                                    v_noise=10 ** rng.uniform(-6.5, -5), jitter=True, extra_steps=steps,
+                                    c_series=float(rng.uniform(5, 50)) if cap else None, t_hi=float(rng.uniform(5, 50)))
+    kw = dict(max_iter=12)
+    if rng.integers(2):
+        kw.update(vz_offset_eps=float(rng.uniform(0.5, 3)), vz_offset_scale=float(rng.uniform(0.3, 3)))
+    if rng.integers(3) == 0:
+        kw.update(vz_offset=False)
+    if rng.integers(3) == 0:
+        kw.update(v_baseline_deg=1)
+    if rng.integers(3) == 0:
+        kw.update(chrono_error_structure=None, chrono_vmm_epsilon=float(rng.uniform(1, 6)))
+    drt = DRT(fit_dop=dop, fit_capacitance=cap, warn=False)
+    drt.fit_hybrid(*meas, **kw)
+    qp, special = drt.qphb_params, drt.special_qp_params
+    rzm0 = qp["rm"].copy()
+    vz = None
+    if "vz_offset" in special:
+        vi = special["vz_offset"]["index"]
+        rzm0[:, vi] = 0
+        vb = special["v_baseline"]
+        vz = dict(index=vi, strength=qp["vz_strength_vec"], num_chrono=qp["num_chrono"],
+                  vb=(vb["index"], vb["index"] + vb["size"]))
+    hyp = orc.get_default_hypers()
+    if dop:
+        hyp.update(orc.get_default_dop_hypers())
+    ref = orc.qphb_fit_prepared(rzm0, qp["rv"], [qp["penalty_matrices"][f"m{k}"] for k in range(3)], qp["vmm"], special, hyp,
+                                vz=vz, max_iter=12)
+    assert [l["iterations"] for l in ref["qp_log"]] == qp["qp_iterations"].tolist(), (seed, kw, dop, cap)
+    hx = np.array([h["x"] for h in ref["history"]])
+    dx = np.array([h["x"] for h in drt.qphb_history])
+    assert hx.shape == dx.shape
+    scale = np.abs(hx).max(axis=1, keepdims=True)
+    assert np.abs(dx - hx).max() / scale.max() < 2e-6, np.abs((dx - hx) / scale).max(axis=1)
+    np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)

@@ -330,6 +330,8 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     # eff_hp=False (qphb.py:208-222, 747-750) and a window of allowed negative coefficients (drt1d.py:82-91)
     run_hybrid_case(DRT, cvxopt, "golden71x91_noeff", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(eff_hp=False))
+    run_hybrid_case(DRT, cvxopt, "golden71x91_dop_noeff", (None, None, None, freq_g, z_g), dict(base, fit_dop=True),
+                    dict(eff_hp=False))
     run_hybrid_case(DRT, cvxopt, "golden71x91_negwin", (None, None, None, freq_g, z_g), dict(base, fit_dop=False),
                     dict(nonneg=False, neg_allowed_tau_range=(1e-5, 1e-3)))
     # weight factors (drt1d.py:743-803, 887-901, 990-1000)

@@ -486,6 +486,10 @@ def test_eff_hp_false_and_negative_window_match_reference_runs():
     np.testing.assert_allclose(np.array(qp["s_vectors"]), g["s_vectors"], rtol=1e-5, atol=1e-10)
     np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
     assert drt.fit_kwargs["s_alpha"].tolist() == [1.05, 1.15, 2.5]
+    g, special = load_case("golden71x91_dop_noeff")             # dop_rho_k in the DOP block's solve_s
+    drt = DRT(fit_dop=True, warn=False)
+    drt.fit_eis(g["freq"], g["z"], eff_hp=False)
+    _check_fit(drt, g, special, True)
     g, special = load_case("golden71x91_negwin")
     drt = DRT(warn=False)
     fp = drt.fit_eis(g["freq"], g["z"], nonneg=False, neg_allowed_tau_range=(1e-5, 1e-3))
@@ -592,3 +596,56 @@ def test_randomised_joint_fits_follow_the_oracle(seed):
     scale = np.abs(hx).max(axis=1, keepdims=True)
     assert np.abs(dx - hx).max() / scale.max() < 2e-6, np.abs((dx - hx) / scale).max(axis=1)
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_option_combinations_follow_the_oracle(seed):
+    """random combinations of the _qphb_fit_core options on an EIS fit (prepared path): solve_rp, update_scale,
+    weight_factor, eff_hp, series_neg, outlier_p, DOP -- each pinned alone by a reference-run fixture, here together
+    against the oracle's general loop, which applies them in the reference's order"""
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    rng = np.random.default_rng(2000 + seed)
+    freq = np.logspace(rng.uniform(4.5, 6), rng.uniform(-1, 0.5), int(rng.integers(31, 72)))
+    z = synth.zarc2_spectrum(freq, seed=seed, jitter=True)
+    dop = bool(rng.integers(2))
+    kw = dict(max_iter=10, solve_rp=True)            # solve_rp routes every draw through the prepared path
+    if rng.integers(2):
+        kw["update_scale"] = True
+    if rng.integers(2):
+        kw["weight_factor"] = float(rng.uniform(0.6, 1.6))
+    if rng.integers(3) == 0:
+        kw["eff_hp"] = False
+    if rng.integers(3) == 0:
+        kw["series_neg"] = True
+    if rng.integers(3) == 0:
+        kw["outlier_p"] = float(rng.uniform(0.01, 0.1))
+    drt = DRT(fit_dop=dop, warn=False)
+    drt.fit_eis(freq, z, **kw)
+    qp, special, prep = drt.qphb_params, drt.special_qp_params, drt._prep
+    hyp = dict(qp["hypers"])
+    hyp["eff_hp"] = kw.get("eff_hp", True)
+    # un-do the host-side rescales to get the loop's inputs: data vector before solve_rp / update_scale, DOP columns before
+    # the solve_rp rescale
+    cs0 = (z.real.max() - z.real.min()) / 14
+    rzv0 = np.concatenate([z.real, z.imag]) / cs0
+    rzm0 = qp["rm"].copy()
+    if dop:
+        a, b = prep["dop"]
+        from hipdrt.matrices import phasance
+        scale0 = phasance.phasor_scale_vector(drt.basis_nu, drt.basis_tau) / (np.sqrt(np.pi) / drt.nu_epsilon)
+        rzm0[:, a:b] *= scale0 / prep["dop_scale_vector"]
+    area = np.sqrt(np.pi) / drt.tau_epsilon
+    ref = orc.qphb_fit_prepared(rzm0, rzv0, [qp["penalty_matrices"][f"m{k}"] for k in range(3)], qp["vmm"], special, hyp,
+                                max_iter=10, solve_rp=dict(basis_area=area),
+                                update_scale=dict(basis_area=area) if kw.get("update_scale") else None,
+                                weight_factor=kw.get("weight_factor", 1))
+    n_extra = 1 + (1 if kw.get("outlier_p") else 0)          # Rp QP (+ first outlier QP) precede the plan's history
+    assert [l["iterations"] for l in ref["qp_log"]][n_extra:] == qp["qp_iterations"].tolist(), (seed, kw, dop)
+    assert prep["rp_qp_iterations"] == ref["qp_log"][0]["iterations"]
+    hx = np.array([h["x"] for h in ref["history"]])
+    dx = np.array([h["x"] for h in drt.qphb_history])
+    assert hx.shape == dx.shape
+    assert np.abs(dx - hx).max() / np.abs(hx).max() < 5e-6, (seed, kw, dop)
+    np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
+    np.testing.assert_allclose(drt.coefficient_scale, cs0 / (ref["scale_factor"] * ref["data_scale"]), rtol=1e-7)

@@ -348,3 +348,17 @@ def test_general_loop_separate_initial_weights_and_weight_rule(name):
     np.testing.assert_allclose(r["est_weights"], g["est_weights"], rtol=1e-8)
     np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(r["p_matrix"], g["p_matrix"], rtol=1e-8, atol=1e-8 * np.abs(g["p_matrix"]).max())
+
+
+def test_general_loop_dop_pass_without_eff_hp():
+    """eff_hp=False with the distribution of phasances: dop_rho_k enters the DOP block's solve_s (qphb.py:858-861)"""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case("golden71x91_dop_noeff")
+    hyp = dict(orc.get_default_hypers(), s_alpha=np.array([1.05, 1.15, 2.5]), rho_alpha=np.array([0.05, 0.1, 0.05]),
+               eff_hp=False)
+    hyp.update(orc.get_default_dop_hypers())
+    rzm0, _ = initial_rzm_and_vz(g, special)
+    r = orc.qphb_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp)
+    assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
+    np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in r["history"]]), g["hist_dop_rho"], rtol=1e-8)

@@ -516,6 +516,8 @@ class PreparedFitMixin:
         self._build_memo = {}
         preps = [self._prepare_measurement(ctx, *meas, kw, ckw, hypers) for meas in measurements]
         self._build_memo = {}
+        for pr in preps:        # the loop's inputs before any host- or device-side rescale (diagnostics, tests)
+            pr['rzv_initial'], pr['rzm_initial'] = pr['rzv'], pr['rzm']
         if ckw['solve_rp'] and kw['scale_data']:
             for pr in preps:
                 self._solve_data_scale(ctx, pr, hypers, kw)

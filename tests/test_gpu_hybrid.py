@@ -649,3 +649,60 @@ def test_randomised_option_combinations_follow_the_oracle(seed):
     assert np.abs(dx - hx).max() / np.abs(hx).max() < 5e-6, (seed, kw, dop)
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
     np.testing.assert_allclose(drt.coefficient_scale, cs0 / (ref["scale_factor"] * ref["data_scale"]), rtol=1e-7)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomised_joint_fits_with_option_combinations(seed):
+    """random option combinations on joint fits: solve_rp, update_scale, weight factors (given / 'rp' / 'weight'),
+    init_weights_separately, eff_hp, series_neg, outlier_p, DOP, series capacitance -- device loop vs the oracle's general
+    loop from the same un-rescaled inputs"""
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    rng = np.random.default_rng(3000 + seed)
+    dop = bool(rng.integers(2))
+    cap = bool(rng.integers(3) == 0) and not dop
+    meas = synth.hybrid_measurement(seed=seed, n_pre=int(rng.integers(8, 30)), n_post=int(rng.integers(50, 120)),
+                                    nf=int(rng.integers(21, 45)), v_noise=10 ** rng.uniform(-6.5, -5), jitter=True,
+                                    c_series=float(rng.uniform(5, 50)) if cap else None)
+    kw = dict(max_iter=10)
+    pick = lambda p: rng.random() < p
+    if pick(0.5): kw["solve_rp"] = True
+    if pick(0.5): kw["update_scale"] = True
+    if pick(0.4): kw["weight_factor"] = float(rng.uniform(0.6, 1.6))
+    mode = rng.integers(4)
+    if mode == 1: kw.update(eis_weight_factor=float(rng.uniform(0.5, 2)), chrono_weight_factor=float(rng.uniform(0.5, 2)))
+    if mode == 2: kw["hybrid_weight_factor_method"] = "rp"
+    if mode == 3: kw["hybrid_weight_factor_method"] = "weight"
+    if pick(0.4): kw["init_weights_separately"] = True
+    if pick(0.3): kw["eff_hp"] = False
+    if pick(0.25): kw["series_neg"] = True
+    if pick(0.3) and not kw.get("init_weights_separately"): kw["outlier_p"] = float(rng.uniform(0.01, 0.1))
+    drt = DRT(fit_dop=dop, fit_capacitance=cap, warn=False)
+    drt.fit_hybrid(*meas, **kw)
+    qp, special, prep = drt.qphb_params, drt.special_qp_params, drt._prep
+    hyp = dict(qp["hypers"])
+    hyp["eff_hp"] = kw.get("eff_hp", True)
+    rzm0 = prep["rzm_initial"].copy()
+    vi = special["vz_offset"]["index"]
+    vb = special["v_baseline"]
+    vz = dict(index=vi, strength=qp["vz_strength_vec"], num_chrono=qp["num_chrono"], vb=(vb["index"], vb["index"] + vb["size"]))
+    nc, m = qp["num_chrono"], len(qp["rv"])
+    area = np.sqrt(np.pi) / drt.tau_epsilon
+    rows = None
+    if mode in (1, 2):
+        rows = np.concatenate([np.full(nc, qp["chrono_weight_factor"]), np.full(m - nc, qp["eis_weight_factor"])])
+    ref = orc.qphb_fit_prepared(rzm0, prep["rzv_initial"], [qp["penalty_matrices"][f"m{k}"] for k in range(3)], qp["vmm"],
+                                special, hyp, vz=vz, max_iter=10,
+                                solve_rp=dict(basis_area=area) if kw.get("solve_rp") else None,
+                                update_scale=dict(basis_area=area) if kw.get("update_scale") else None,
+                                weight_factor=kw.get("weight_factor", 1), row_factors=rows,
+                                init_separately=dict(num_chrono=nc) if kw.get("init_weights_separately") else None,
+                                weight_method=dict(num_chrono=nc) if mode == 3 else None)
+    n_extra = (1 if kw.get("solve_rp") else 0) + (1 if kw.get("outlier_p") or kw.get("init_weights_separately") else 0)
+    assert [l["iterations"] for l in ref["qp_log"]][n_extra:] == qp["qp_iterations"].tolist(), (seed, kw, dop, cap)
+    hx = np.array([h["x"] for h in ref["history"]])
+    dx = np.array([h["x"] for h in drt.qphb_history])
+    assert hx.shape == dx.shape
+    assert np.abs(dx - hx).max() / np.abs(hx).max() < 5e-6, (seed, kw, dop, cap)
+    np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
+    np.testing.assert_allclose(qp["rm"], ref["rzm"], rtol=0, atol=1e-6 * np.abs(ref["rzm"]).max())

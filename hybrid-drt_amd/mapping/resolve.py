@@ -72,7 +72,7 @@ def get_tau_indices(obs_tau_indices, truncate=False):
 
 
 def resolve_observations(obs_drt_list, obs_tau_indices, nonneg, obs_psi=None, truncate=False, sigma=1, lambda_psi=1,
-                         unpack=False, tau_filter_sigma=0, special_filter_sigma=0, device=0):
+                         unpack=False, tau_filter_sigma=0, special_filter_sigma=0, device=0, _assemble_only=False):
     """resolve.resolve_observations (189-341).  Returns (x_opt (nr, nc), match_tau_indices), or the unpacked
     (x_drt, x_special, match_tau_indices).  Raises ValueError when the QP breaks down (cvxopt's error)."""
     match = get_tau_indices(obs_tau_indices, truncate=truncate)
@@ -121,6 +121,8 @@ def resolve_observations(obs_drt_list, obs_tau_indices, nonneg, obs_psi=None, tr
             for i in range(nr):
                 h[v['index'] + i * nc:v['index'] + v.get('size', 1) + i * nc] = 0
 
+    if _assemble_only:
+        return p_matrix, q_vector, h, special, match, nr, nc
     res = _ffi.get_context(device).qp_batch(p_matrix[None], q_vector[None], h)
     if res['status'][0] < 0:
         raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
@@ -146,3 +148,58 @@ def unpack_resolved_x(x, obs_drt_list, special_dict):
             xk = xk * np.array([drt.inductance_scale for drt in obs_drt_list])[:, None]
         x_special[key] = xk.flatten() if info.get('size', 1) == 1 else xk
     return x_drt, x_special
+
+
+def resolve_group(obs_drt_list, obs_tau_indices, nonneg, num_tau_super, batch_size=7, overlap=2, truncate=False, sigma=1,
+                  lambda_psi=1, tau_filter_sigma=0, special_filter_sigma=0, device=0):
+    """DRTMD.resolve_group (hybdrt/mapping/drtmd.py:486-559) for observations already sorted along psi: overlapping batches
+    of `batch_size` observations are re-optimised coherently (resolve_observations each) and the overlaps averaged with
+    weights growing with the distance from the batch edge.  The batches are independent QPs of one size, so they go to the
+    device as ONE batched launch.  Returns (obs_x_resolved (num_obs, num_tau_super), obs_special_resolved dict)."""
+    num_obs = len(obs_drt_list)
+    batch_size = min(batch_size, num_obs)
+    stride = max(batch_size - overlap, 1)
+    num_batches = 1 + int(np.ceil((num_obs - batch_size) / stride))
+    starts = []
+    for start in range(0, num_obs, stride):
+        if num_obs - start < batch_size:
+            start = max(0, num_obs - batch_size)          # a full batch for the last one
+        starts.append(start)
+        if start + batch_size >= num_obs:
+            break
+    if num_obs == 1:
+        raise ValueError("Only one observation included in resolution group")
+    probs = [resolve_observations(obs_drt_list[a:a + batch_size], obs_tau_indices[a:a + batch_size], nonneg,
+                                  truncate=truncate, sigma=sigma, lambda_psi=lambda_psi, tau_filter_sigma=tau_filter_sigma,
+                                  special_filter_sigma=special_filter_sigma, _assemble_only=True) for a in starts]
+    sizes = {pr[0].shape for pr in probs}
+    if len(sizes) != 1:
+        raise NotImplementedError("batches whose common tau ranges differ in length would need separate launches")
+    res = _ffi.get_context(device).qp_batch(np.stack([pr[0] for pr in probs]), np.stack([pr[1] for pr in probs]),
+                                            np.stack([pr[2] for pr in probs]))
+    if np.any(res['status'] < 0):
+        raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+    resolve_group.last_qp = dict(iterations=res['iterations'].tolist())
+    special = probs[0][3]
+    x_batch = np.zeros((len(starts), num_obs, num_tau_super))
+    sp_batch = {k: np.zeros((len(starts), num_obs) + ((v.get('size', 1),) if v.get('size', 1) > 1 else ()))
+                for k, v in special.items()}
+    margins = -np.ones((len(starts), num_obs))
+    for i, (a, pr) in enumerate(zip(starts, probs)):
+        _, _, _, sp_, match, nr, nc = pr
+        x_drt, x_special = unpack_resolved_x(res['x'][i].reshape(nr, nc), obs_drt_list[a:a + batch_size], sp_)
+        x_batch[i, a:a + batch_size, match[0]:match[1]] = x_drt
+        for k, v in x_special.items():
+            sp_batch[k][i, a:a + batch_size] = v
+        margins[i, a:a + batch_size] = np.minimum(np.arange(batch_size), np.arange(batch_size)[::-1])
+    if overlap > 0 and num_obs > 1:
+        w = margins + 0.1                          # drtmd.py:541-546: edge observations still count a little
+        w[w < 0] = 0
+        x_res = np.average(x_batch, axis=0, weights=np.repeat(w[:, :, None], num_tau_super, axis=2))
+        sp_res = {k: np.average(v, axis=0, weights=w if v.ndim == 2 else np.repeat(w[:, :, None], v.shape[-1], axis=2))
+                  for k, v in sp_batch.items()}
+    else:
+        # without overlap every observation is written by exactly one batch
+        x_res = x_batch.sum(axis=0)
+        sp_res = {k: v.sum(axis=0) for k, v in sp_batch.items()}
+    return x_res, sp_res

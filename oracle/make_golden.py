@@ -411,6 +411,47 @@ def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7):
     print(f"resolve_{name}: {n_obs} obs x {x_opt.shape[1]} params, qp iterations {out['qp_iterations'].tolist()}")
 
 
+def run_resolve_group(cvxopt, name, n_obs=16, batch_size=7, overlap=2):
+    """the reference's own DRTMD (mapping/drtmd.py:186-329, 432-559) driven with array data: n_obs joint fits along one psi
+    axis, then resolve_group -- overlapping batches of coupled QPs, margin-weighted average of the overlaps."""
+    from hipdrt import synth
+    from hybdrt.mapping.drtmd import DRTMD
+    sup = np.logspace(-8, 4, 121)
+    with _quiet():
+        dmd = DRTMD(tau_supergrid=sup, psi_dim_names=['T'], print_progress=False, warn=False)
+        for k in range(n_obs):
+            m = synth.hybrid_measurement(seed=100 + k, jitter=True, n_post=100, nf=31)
+            dmd.add_observation(np.array([float(k)]), (m[0], m[1], m[2]), (m[3], m[4]), group_id='g')
+        dmd.fit_all()
+    log = []
+    cvxopt.solvers.options["_oracle_log"] = log
+    with _quiet():
+        dmd.resolve_group('g', batch_size=batch_size, overlap=overlap, psi_sort_dims=['T'])
+    cvxopt.solvers.options["_oracle_log"] = None
+    drts = [dmd.get_fit(i) for i in range(n_obs)]
+    sp = drts[0].special_qp_params
+    out = dict(n_obs=n_obs, batch_size=batch_size, overlap=overlap, n_super=len(sup),
+               obs_tau_indices=np.array(dmd.obs_tau_indices), special_names=np.array(list(sp.keys())),
+               special_index=np.array([v["index"] for v in sp.values()]),
+               special_size=np.array([v.get("size", 1) for v in sp.values()]),
+               special_nonneg=np.array([v["nonneg"] for v in sp.values()]),
+               p_matrix=np.array([d.fit_parameters["p_matrix"] for d in drts]),
+               q_vector=np.array([d.fit_parameters["q_vector"] for d in drts]),
+               v_baseline=np.array([d.fit_parameters["v_baseline"] for d in drts]),
+               vz_offset=np.array([d.fit_parameters["vz_offset"] for d in drts]),
+               R_inf=np.array([d.fit_parameters["R_inf"] for d in drts]),
+               coefficient_scale=np.array([d.coefficient_scale for d in drts]),
+               response_signal_scale=np.array([d.response_signal_scale for d in drts]),
+               scaled_response_offset=np.array([d.scaled_response_offset for d in drts]),
+               v_baseline_scale=np.array([d.v_baseline_scale for d in drts]),
+               inductance_scale=np.array([d.inductance_scale for d in drts]),
+               obs_x=dmd.obs_x, obs_x_resolved=dmd.obs_x_resolved,
+               R_inf_resolved=dmd.obs_special_resolved["R_inf"], inductance_resolved=dmd.obs_special_resolved["inductance"],
+               qp_iterations=np.array([l["iterations"] for l in log]))
+    np.savez_compressed(os.path.join(OUT, f"refrun_resolve_group_{name}.npz"), **out)
+    print(f"resolve_group_{name}: {n_obs} obs, {len(log)} batches, qp iterations {out['qp_iterations'].tolist()}")
+
+
 def run_posteriors(DRT, freq_g, z_g, default):
     from oracle.drt_oracle import get_basis_tau
     bt = get_basis_tau(freq_g)
@@ -428,6 +469,7 @@ def main():
         DRT, cvxopt = _boot_reference()
         run_resolve(DRT, cvxopt, "hybrid7", False)
         run_resolve(DRT, cvxopt, "hybrid7_dop", True)
+        run_resolve_group(cvxopt, "hybrid16")
         return
     if "--only-hybrid" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()
@@ -498,6 +540,7 @@ def main():
     # (11) coherent multi-observation re-optimisation (survey 8f rank 2)
     run_resolve(DRT, cvxopt, "hybrid7", False)
     run_resolve(DRT, cvxopt, "hybrid7_dop", True)
+    run_resolve_group(cvxopt, "hybrid16")
 
 
 if __name__ == "__main__":

@@ -121,3 +121,26 @@ def test_fit_hybrid_then_resolve_end_to_end():
     nt = int(g["ntau"])
     x, _ = resolve.resolve_observations(drts, [(0, nt)] * len(drts), True)
     np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=1e-5 * np.abs(g["x_opt"]).max())
+
+
+@pytest.mark.gpu
+def test_resolve_group_matches_reference_drtmd():
+    """the reference's own DRTMD.resolve_group on 16 joint fits (3 overlapping batches of 7): all batch QPs in one device
+    launch, same iteration counts, same margin-weighted averages"""
+    from hipdrt.mapping import resolve
+    g = np.load(os.path.join(GOLDEN, "refrun_resolve_group_hybrid16.npz"))
+    special = {str(k): dict(index=int(i), size=int(s), nonneg=bool(nn))
+               for k, i, s, nn in zip(g["special_names"], g["special_index"], g["special_size"], g["special_nonneg"])}
+    obs = [{k: g[k][i] for k in KEYS} for i in range(int(g["n_obs"]))]
+    drts = [as_drt(o, special) for o in obs]
+    for d, ls in zip(drts, g["inductance_scale"]):
+        d.inductance_scale = float(ls)
+    tau_idx = [tuple(int(v) for v in t) for t in g["obs_tau_indices"]]
+    x_res, sp_res = resolve.resolve_group(drts, tau_idx, True, int(g["n_super"]), batch_size=int(g["batch_size"]),
+                                          overlap=int(g["overlap"]))
+    assert resolve.resolve_group.last_qp["iterations"] == g["qp_iterations"].tolist()
+    scale = np.abs(g["obs_x_resolved"]).max()
+    np.testing.assert_allclose(x_res, g["obs_x_resolved"], rtol=0, atol=1e-7 * scale)
+    np.testing.assert_allclose(sp_res["R_inf"], g["R_inf_resolved"], rtol=1e-6)
+    np.testing.assert_allclose(sp_res["inductance"], g["inductance_resolved"], rtol=1e-5, atol=1e-12)
+    assert np.abs(x_res - g["obs_x"]).max() > 1e-4 * scale           # the coupling moved the coefficients

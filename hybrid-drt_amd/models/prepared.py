@@ -667,10 +667,31 @@ class PreparedFitMixin:
         meas = [(times, i_batch[b], v_batch[b], frequencies, z_batch[b]) for b in range(len(z_batch))]
         return self._fit_prepared_batch(meas, kw)
 
+    def batch_fits(self):
+        """Per-observation views of the last prepared batch fit, carrying what the mapping step reads from a fitted DRT
+        (fit_parameters incl. p_matrix / q_vector, special_qp_params, the scale attributes): feed them to
+        hipdrt.mapping.resolve.resolve_observations / resolve_group."""
+        import types
+        preps, fps = self._last_prepared
+        fits = []
+        for b, (pr, fp) in enumerate(zip(preps, fps)):
+            fp = dict(fp, p_matrix=self._plan.p_matrix(b))
+            fits.append(types.SimpleNamespace(
+                fit_parameters=fp, special_qp_params=pr['special'], coefficient_scale=pr['coefficient_scale'],
+                impedance_scale=pr['impedance_scale'], response_signal_scale=pr['response_signal_scale'],
+                scaled_response_offset=pr.get('scaled_response_offset'), v_baseline_scale=pr.get('v_baseline_scale'),
+                dop_scale_vector=pr['dop_scale_vector'], inductance_scale=self.inductance_scale, basis_tau=pr['basis_tau']))
+        return fits
+
     def _fit_prepared_batch(self, meas, kw):
         preps, out, hypers, fkw, ckw = self._fit_prepared(meas, kw)
+        self.inductance_scale = fkw['inductance_scale']
         fps = [self._extract(pr, out['x'][b], out['weights'][b], fkw, ckw) for b, pr in enumerate(preps)]
-        res = {key: np.array([fp[key] for fp in fps]) for key in fps[0] if fps[0][key] is not None and key != 'vz_offset_eps'}
+        for b, fp in enumerate(fps):
+            fp['q_vector'] = out['q_vector'][b]
+        self._last_prepared = (preps, fps)
+        res = {key: np.array([fp[key] for fp in fps]) for key in fps[0]
+               if fps[0][key] is not None and key not in ('vz_offset_eps', 'q_vector')}
         res.update(x_scaled=out['x'], fit_x=res['x'], outer_iters=out['outer_iters'], status=out['status'],
                    qp_iters_total=out['qp_iters_total'], rho=out['rho'], weights=out['weights'],
                    coefficient_scale=np.array([pr['coefficient_scale'] for pr in preps]), basis_tau=preps[0]['basis_tau'])

@@ -144,3 +144,21 @@ def test_resolve_group_matches_reference_drtmd():
     np.testing.assert_allclose(sp_res["R_inf"], g["R_inf_resolved"], rtol=1e-6)
     np.testing.assert_allclose(sp_res["inductance"], g["inductance_resolved"], rtol=1e-5, atol=1e-12)
     assert np.abs(x_res - g["obs_x"]).max() > 1e-4 * scale           # the coupling moved the coefficients
+
+
+@pytest.mark.gpu
+def test_batch_fits_feed_resolve_like_single_fits():
+    """fit_hybrid_batch + DRT.batch_fits() -> resolve_observations gives what seven single fits give"""
+    from hipdrt.models import DRT
+    from hipdrt.mapping import resolve
+    from hipdrt import synth
+    g, special, _ = load("hybrid7")
+    meas = [synth.hybrid_measurement(seed=s_, jitter=True, n_post=120, nf=31) for s_ in range(int(g["n_obs"]))]
+    drt = DRT(warn=False)
+    drt.fit_hybrid_batch(meas[0][0], [m[1] for m in meas], [m[2] for m in meas], meas[0][3], [m[4] for m in meas])
+    fits = drt.batch_fits()
+    nt = int(g["ntau"])
+    x, _ = resolve.resolve_observations(fits, [(0, nt)] * len(fits), True)
+    np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=1e-5 * np.abs(g["x_opt"]).max())
+    np.testing.assert_allclose(fits[3].fit_parameters["p_matrix"], g["p_matrix"][3], rtol=1e-5,
+                               atol=1e-7 * np.abs(g["p_matrix"][3]).max())

@@ -46,7 +46,7 @@ class PreparedDesc(C.Structure):
     _fields_ = [
         ("m", C.c_int), ("n", C.c_int), ("ns", C.c_int), ("dop_start", C.c_int), ("dop_size", C.c_int),
         ("vz_index", C.c_int), ("vb_start", C.c_int), ("vb_size", C.c_int), ("num_chrono", C.c_int),
-        ("toeplitz_m", C.c_int), ("basis_area", C.c_double), ("init_weights_separately", C.c_int),
+        ("toeplitz_m", C.c_int), ("chrono_vmm_uniform", C.c_int), ("basis_area", C.c_double), ("init_weights_separately", C.c_int),
         ("weight_method", C.c_int), ("fixed_chrono_factor", C.c_double), ("fixed_eis_factor", C.c_double),
         ("dop_l2_lambda_0", C.c_double),
         ("dop_derivative_weights", C.c_double * 3),

@@ -225,7 +225,19 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* V,
         tmp[i] = r * r;
     }
     __syncthreads();
-    rows_matvec(V, m, m, m, tmp, tmp2);                // V @ resid**2
+    // V @ resid**2.  A uniform chrono block (error_structure='uniform': every chrono row of V is the same vector, zero on the
+    // impedance columns) needs one row only -- same arithmetic per row, so the same bits, without streaming nc x m entries
+    const int ncu = (st.prepared && st.desc.chrono_vmm_uniform && V == st.vmm && op <= 0.0) ? st.desc.num_chrono : 0;
+    if (ncu > 0) {
+        rows_matvec(V, m, 1, m, tmp, tmp2);
+        if (ncu < m) rows_matvec(V + (size_t)ncu * m, m, m - ncu, m, tmp, tmp2 + ncu);
+        __syncthreads();
+        const double s0 = tmp2[0];
+        __syncthreads();
+        for (int i = 1 + tid; i < ncu; i += HT) tmp2[i] = s0;
+    } else {
+        rows_matvec(V, m, m, m, tmp, tmp2);
+    }
     __syncthreads();
     if (op > 0.0) {
         const double s2pi = sqrt(2.0 * 3.141592653589793);

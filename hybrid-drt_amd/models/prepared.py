@@ -313,7 +313,7 @@ class PreparedFitMixin:
             h = qphb.make_h_constraint(None, n, sp, kw['nonneg'])
 
         prep.update(rzm=rzm, rzv=rzv, pen=pen, vmm=vmm, special=sp, ns=ns, n=n, m=m, dop=dop, l1=l1, h=h, h_init=h_init,
-                    vz_strength=vz_strength, num_chrono=num_chrono, num_eis=len(frequencies) if has_eis else 0,
+                    vz_strength=vz_strength, num_chrono=num_chrono, chrono_uniform=ckw['chrono_error_structure'] == 'uniform', num_eis=len(frequencies) if has_eis else 0,
                     basis_tau=basis_tau, toeplitz_m=tpl_m and not series_neg, coefficient_scale=coefficient_scale,
                     impedance_scale=impedance_scale, input_signal_scale=input_scale, response_signal_scale=response_scale,
                     dop_scale_vector=dop_scale, frequencies=frequencies)
@@ -395,6 +395,7 @@ class PreparedFitMixin:
         d.num_chrono = prep['num_chrono']
         d.toeplitz_m = int(prep['toeplitz_m'])
         d.basis_area = float(np.sqrt(np.pi) / self.tau_epsilon)
+        d.chrono_vmm_uniform = int(prep['num_chrono'] > 0 and prep['chrono_uniform'])
         if prep['dop']:
             d.dop_l2_lambda_0 = float(hypers['dop_l2_lambda_0'])
             for name in ('dop_derivative_weights', 'dop_s_alpha', 'dop_rho_alpha', 'dop_s_0', 'dop_rho_0'):

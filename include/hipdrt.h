@@ -277,6 +277,7 @@ typedef struct {
     int vb_start, vb_size;     /* v_baseline columns: excluded from the vz prediction (drt1d.py:507-511)              */
     int num_chrono;            /* rows [0, num_chrono) are chrono samples, the rest [Re; Im] impedance rows           */
     int toeplitz_m;            /* DRT block of the penalty matrices is symmetric Toeplitz (uniform ln tau)            */
+    int chrono_vmm_uniform;    /* chrono block of vmm is the 'uniform' error structure (all rows equal): one row is read */
     double basis_area;         /* area of one tau basis function, sqrt(pi)/epsilon for the Gaussian basis (update_scale) */
     int init_weights_separately; /* 1: initialize_weights once per data block (chrono rows, impedance rows), each QP seeing
                                   only its block and each block with its own variance floor (drt1d.py:648-672)         */

@@ -706,3 +706,27 @@ def test_randomised_joint_fits_with_option_combinations(seed):
     assert np.abs(dx - hx).max() / np.abs(hx).max() < 5e-6, (seed, kw, dop, cap)
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
     np.testing.assert_allclose(qp["rm"], ref["rzm"], rtol=0, atol=1e-6 * np.abs(ref["rzm"]).max())
+
+
+def test_uniform_chrono_variance_shortcut_is_bit_identical():
+    """chrono_vmm_uniform=1 reads one chrono row of the variance matrix instead of all of them: same bits everywhere"""
+    from hipdrt import _ffi as ffi
+    g, special = load_case("hybrid_s0_dop")
+    hyp = dict(orc.get_default_hypers(), **orc.get_default_dop_hypers())
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    nc = int(g["num_chrono"])
+    assert np.all(g["vmm"][:nc, :nc] == g["vmm"][0, 0]) and np.all(g["vmm"][:nc, nc:] == 0)
+    h = orc.make_h_constraint(rzm0.shape[1], special, True)
+    l1 = g["l1_lambda_vector"]
+    outs = []
+    for flag in (0, 1):
+        desc = make_desc(ffi, g, special, rzm0, vz, hyp)
+        desc.chrono_vmm_uniform = flag
+        plan = ffi.PreparedPlan(ffi.get_context(), desc, [g["m0"], g["m1"], g["m2"]], g["vmm"], h, l1,
+                                vz_strength=vz["strength"], capacity=1)
+        plan.upload(rzm0[None], g["rv"][None])
+        plan.fit()
+        outs.append(plan.download(s_vectors=True))
+    for key in ("x", "weights", "rho", "s_vectors", "q_vector"):
+        np.testing.assert_array_equal(outs[0][key], outs[1][key])
+    assert outs[0]["outer_iters"][0] == outs[1]["outer_iters"][0] == int(g["outer_iterations"])

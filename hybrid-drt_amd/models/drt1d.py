@@ -365,6 +365,100 @@ class DRT(PreparedFitMixin):
         log_min, log_max = np.log10(np.min(basis_tau)) - 1, np.log10(np.max(basis_tau)) + 1
         return np.logspace(log_min, log_max, int((log_max - log_min) * ppd) + 1)
 
+    # ---- evaluation of a fitted model (drt1d.py:2965-3062, 3273-3362, 3500-3542, 3552-3571) ----------------------------------
+    series_neg = False
+
+    def _fitted_parameters(self, x):
+        if x is None:
+            return self.fit_parameters
+        if isinstance(x, dict):
+            return x
+        raise NotImplementedError("pass a fit_parameters dict (raw coefficient vectors are re-scaled inside the fit)")
+
+    def get_drt_params(self, x=None, sign=1):
+        """drt1d.get_drt_params (2965-2988): the DRT coefficients; with series_neg the requested sign's share."""
+        x = self._fitted_parameters(x)['x']
+        if self.series_neg:
+            nt = len(self.basis_tau)
+            if sign == 1:
+                return x[:nt]
+            if sign == -1:
+                return -x[nt:]
+            if sign == 0:
+                return x[:nt] - x[nt:]
+            raise ValueError(f'Invalid sign {sign}. Options: -1, 0, 1')
+        return x
+
+    def predict_r_p(self, sign=None, absolute=False, x=None):
+        """drt1d.predict_r_p (3552-3571): polarisation resistance = area of one basis function x sum of coefficients."""
+        if sign is None:
+            sign = 0 if self.series_neg else 1
+        xd = self.get_drt_params(x, sign)
+        return (np.sum(np.abs(xd)) if absolute else np.sum(xd)) * (np.sqrt(np.pi) / self.tau_epsilon)
+
+    def predict_drt(self, tau=None, ppd=20, x=None, order=0, sign=1, normalize=False, normalize_by=None, abs_norm=False):
+        """drt1d.predict_drt (3043-3062), order 0: gamma(tau) = basis matrix @ coefficients."""
+        from ..matrices import basis
+        if tau is None:
+            tau = self.get_tau_eval(ppd)
+        bm = basis.construct_func_eval_matrix(np.log(self.basis_tau), np.log(tau), self.tau_basis_type,
+                                              epsilon=self.tau_epsilon, order=order)
+        xd = self.get_drt_params(x, sign)
+        if normalize_by is not None:
+            normalize = True
+        norm = 1 if not normalize else (normalize_by if normalize_by is not None
+                                        else self.predict_r_p(x=x, absolute=abs_norm))
+        return bm @ xd / norm
+
+    predict_distribution = predict_drt          # deprecated upstream name (drt1d.py:3033-3041)
+
+    def predict_z(self, frequencies, include_vz_offset=True, x=None, include_dop=True, include_drt=True,
+                  include_inductance=True, include_ohmic=True, include_cap=True):
+        """drt1d.predict_z (3500-3542): model impedance at arbitrary frequencies; the Z' / Z'' (and phasance) matrices of the
+        prediction grid are built on the device."""
+        from ..matrices import phasance
+        frequencies = np.asarray(frequencies, dtype=float)
+        fp = self._fitted_parameters(x)
+        ctx = self._context if self._context is not None else _ffi.get_context(self.device)
+        z = np.zeros(len(frequencies), dtype=complex)
+        if include_drt:
+            mode = _ffi.MODE_INTERP if self.integrate_method == 'interp' else _ffi.MODE_TRAPZ
+            lookups = None
+            if mode == _ffi.MODE_INTERP:
+                lookups = self._lookups(ctx)['z']
+            tpl = mat1d.impedance_matrix_is_toeplitz(frequencies, self.basis_tau, self.frequency_precision)
+            a_re, a_im = ctx.impedance_matrix(frequencies, self.basis_tau, self.tau_epsilon, mode=mode, toeplitz=tpl,
+                                              lookups=lookups)
+            xd = fp['x']
+            if self.series_neg:
+                nt = len(self.basis_tau)
+                xd = xd[:nt] - xd[nt:]
+            z += (a_re + 1j * a_im) @ xd
+        if include_ohmic:
+            z += fp.get('R_inf', 0)
+        if include_inductance:
+            z += fp.get('inductance', 0) * 2j * np.pi * frequencies
+        if include_cap:
+            z += fp.get('C_inv', 0) * (2j * np.pi * frequencies) ** -1
+        if fp.get('x_dop') is not None and include_dop:
+            z += phasance.construct_phasor_z_matrix(frequencies, self.basis_nu, 'gaussian', self.nu_epsilon,
+                                                    device=self.device) @ fp['x_dop']
+        if include_vz_offset and fp.get('vz_offset', 0) != 0:
+            # drt1d.py:3537-3540: EIS predictions of a hybrid fit carry the fitted offset, faded outside the overlap
+            z *= (1 - fp['vz_offset'] * self._eis_vz_strength(frequencies, fp.get('vz_offset_eps', 1)))
+        return z
+
+    def _eis_vz_strength(self, frequencies, vz_offset_eps):
+        """EIS half of DRT._get_vz_strength_vec (drt1d.py:6173-6226) relative to the FIT's sample times."""
+        prep = self._prep
+        deltas = pp.get_time_since_step(prep['sample_times'], prep['nonconsec_step_times'], prestep_value=-1)
+        chrono_tau_min = np.min(deltas[deltas > 0])
+        f_inv = 1 / (2 * np.pi * frequencies)
+        es = np.ones(len(frequencies))
+        fast = f_inv <= chrono_tau_min
+        es[fast] = np.exp(-(vz_offset_eps * np.log(f_inv[fast] / chrono_tau_min)) ** 2)
+        return es
+
     def evaluate_rss(self, weights=None, x=None):
         """drt1d.evaluate_rss (drt1d.py:4433-4455) -> qphb.evaluate_rss (qphb.py:1347-1352)."""
         w = self.qphb_params['est_weights'] if weights is None else np.asarray(weights, dtype=float)

@@ -626,6 +626,7 @@ class PreparedFitMixin:
         self.scaled_response_offset = prep.get('scaled_response_offset')
         self.v_baseline_scale = prep.get('v_baseline_scale')
         self.inductance_scale = kw['inductance_scale']
+        self.series_neg = bool(ckw['series_neg'])
         hist = plan.history()
         self.qphb_history = [dict(x=hist['x'][i], rho_vector=hist['rho'][i], weights=hist['weights'][i],
                                   dop_rho_vector=hist['dop_rho'][i] if 'dop_rho' in hist else None)

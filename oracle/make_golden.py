@@ -452,6 +452,37 @@ def run_resolve_group(cvxopt, name, n_obs=16, batch_size=7, overlap=2):
     print(f"resolve_group_{name}: {n_obs} obs, {len(log)} batches, qp iterations {out['qp_iterations'].tolist()}")
 
 
+def run_predict(DRT, freq_g, z_g):
+    """evaluation of fitted models (drt1d.py:3043-3062, 3500-3542, 3552-3571): predict_drt, predict_z on a grid other than
+    the fit's, predict_r_p, for an EIS fit, an EIS + DOP fit and a joint fit with DOP (upstream's series_neg evaluation
+    path raises in get_drt_params, so it is not a parity case)"""
+    from hipdrt import synth
+    base = dict(fit_inductance=True, fit_capacitance=False, fit_ohmic=True)
+    meas = synth.hybrid_measurement(seed=0)
+    f_pred = np.logspace(5.5, -0.5, 37)
+    out = dict(f_pred=f_pred)
+    cases = {"eis": (dict(base, fit_dop=False), (None, None, None, freq_g, z_g), {}),
+             "eis_dop": (dict(base, fit_dop=True), (None, None, None, freq_g, z_g), {}),
+             "hybrid_dop": (dict(base, fit_dop=True), meas, {})}
+    for tag, (ctor, data, kw) in cases.items():
+        with _quiet():
+            drt = DRT(**ctor)
+            if data[0] is None:
+                drt.fit_eis(data[3], data[4], **kw)
+            else:
+                drt.fit_hybrid(*data, **kw)
+            tau = drt.get_tau_eval(20)
+            out[f"{tag}_tau"] = tau
+            out[f"{tag}_gamma"] = drt.predict_drt(tau=tau, sign=0 if kw.get("series_neg") else 1)
+            out[f"{tag}_gamma_norm"] = drt.predict_drt(tau=tau, normalize=True, sign=0 if kw.get("series_neg") else 1)
+            out[f"{tag}_z"] = drt.predict_z(f_pred)
+            out[f"{tag}_z_noL"] = drt.predict_z(f_pred, include_inductance=False, include_vz_offset=False)
+            out[f"{tag}_rp"] = drt.predict_r_p()
+            out[f"{tag}_rp_abs"] = drt.predict_r_p(absolute=True)
+    np.savez_compressed(os.path.join(OUT, "refrun_predict.npz"), **out)
+    print("refrun_predict.npz:", {k: np.shape(v) for k, v in out.items() if k.endswith("_z")})
+
+
 def run_posteriors(DRT, freq_g, z_g, default):
     from oracle.drt_oracle import get_basis_tau
     bt = get_basis_tau(freq_g)
@@ -464,6 +495,11 @@ def main():
     sys.path.insert(0, REPO)
     if "--only-response" in sys.argv:
         run_response_matrices()
+        return
+    if "--only-predict" in sys.argv:
+        freq_g, z_g = extract_reference_test_vectors()
+        DRT, cvxopt = _boot_reference()
+        run_predict(DRT, freq_g, z_g)
         return
     if "--only-resolve" in sys.argv:
         DRT, cvxopt = _boot_reference()
@@ -541,6 +577,8 @@ def main():
     run_resolve(DRT, cvxopt, "hybrid7", False)
     run_resolve(DRT, cvxopt, "hybrid7_dop", True)
     run_resolve_group(cvxopt, "hybrid16")
+    # (12) evaluation of fitted models
+    run_predict(DRT, freq_g, z_g)
 
 
 if __name__ == "__main__":

@@ -730,3 +730,35 @@ def test_uniform_chrono_variance_shortcut_is_bit_identical():
     for key in ("x", "weights", "rho", "s_vectors", "q_vector"):
         np.testing.assert_array_equal(outs[0][key], outs[1][key])
     assert outs[0]["outer_iters"][0] == outs[1]["outer_iters"][0] == int(g["outer_iterations"])
+
+
+def test_predict_functions_match_reference_run():
+    """predict_drt / predict_z (on a frequency grid other than the fit's) / predict_r_p of fitted models"""
+    import os
+    from conftest import GOLDEN
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    g = np.load(os.path.join(GOLDEN, "refrun_predict.npz"))
+    gg, _ = load_case("golden71x91_dop")
+    freq, z = gg["freq"], gg["z"]
+    meas = synth.hybrid_measurement(seed=0)
+    cases = {"eis": (dict(), (None, None, None, freq, z), {}), "eis_dop": (dict(fit_dop=True), (None, None, None, freq, z), {}),
+             "hybrid_dop": (dict(fit_dop=True), meas, {})}
+    for tag, (ctor, data, kw) in cases.items():
+        drt = DRT(warn=False, **ctor)
+        if data[0] is None:
+            drt.fit_eis(data[3], data[4], **kw)
+        else:
+            drt.fit_hybrid(*data, **kw)
+        sign = 0 if kw.get("series_neg") else 1
+        tau = drt.get_tau_eval(20)
+        np.testing.assert_allclose(tau, g[f"{tag}_tau"], rtol=1e-13)
+        gam = g[f"{tag}_gamma"]
+        np.testing.assert_allclose(drt.predict_drt(tau=tau, sign=sign), gam, rtol=1e-5, atol=1e-7 * np.abs(gam).max())
+        np.testing.assert_allclose(drt.predict_drt(tau=tau, sign=sign, normalize=True), g[f"{tag}_gamma_norm"], rtol=1e-5,
+                                   atol=1e-7 * np.abs(g[f"{tag}_gamma_norm"]).max())
+        np.testing.assert_allclose(drt.predict_z(g["f_pred"]), g[f"{tag}_z"], rtol=1e-6, atol=1e-8, err_msg=tag)
+        np.testing.assert_allclose(drt.predict_z(g["f_pred"], include_inductance=False, include_vz_offset=False),
+                                   g[f"{tag}_z_noL"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(drt.predict_r_p(), g[f"{tag}_rp"], rtol=1e-6)
+        np.testing.assert_allclose(drt.predict_r_p(absolute=True), g[f"{tag}_rp_abs"], rtol=1e-6)

@@ -448,6 +448,80 @@ class DRT(PreparedFitMixin):
             z *= (1 - fp['vz_offset'] * self._eis_vz_strength(frequencies, fp.get('vz_offset_eps', 1)))
         return z
 
+    def predict_v_baseline(self, times, x_vb=None):
+        """drt1d.predict_v_baseline (3471-3478): polynomial (+ sqrt) baseline in data units."""
+        from . import background
+        fp = self.fit_parameters
+        if 'v_baseline' not in fp:
+            return np.zeros(len(times))
+        vb_mat = background.get_baseline_matrix(times, int(self.fit_kwargs.get('v_baseline_deg', 0)), normalize=False,
+                                                sqrt=bool(self.fit_kwargs.get('v_baseline_sqrt', False)))
+        return vb_mat @ (fp['v_baseline'] if x_vb is None else x_vb)
+
+    def predict_response(self, times=None, input_signal=None, step_times=None, step_sizes=None, op_mode=None,
+                         offset_steps=None, step_offset_size=None, include_dop=True, include_drt=True, include_ohmic=True,
+                         include_cap=True, smooth_inf_response=None, x=None, include_vz_offset=True, v_baseline=None):
+        """drt1d.predict_response (3363-3469; no background model): voltage response of the fitted model to the fitted
+        (or given) current steps at the fit times or any other times; response / phasance matrices built on the device."""
+        from ..matrices import phasance
+        if (op_mode or self.chrono_mode) != 'galv':
+            raise ValueError('only galvanostatic predictions are built')
+        prep = self._prep
+        use_fit_times = times is None
+        times = np.asarray(prep['sample_times'] if times is None else times, dtype=float)
+        offset_steps = self.fit_kwargs['offset_steps'] if offset_steps is None else offset_steps
+        step_offset_size = self.fit_kwargs['step_offset_size'] if step_offset_size is None else step_offset_size
+        smooth = self.fit_kwargs['smooth_inf_response'] if smooth_inf_response is None else smooth_inf_response
+        if input_signal is not None and step_times is not None:
+            raise ValueError('Either input_signal OR (step_times and step_sizes) should be provided; '
+                             'received input_signal and step_times')
+        if step_times is not None and step_sizes is None:
+            raise ValueError('If input signal steps are provided, both step_times and step_sizes must be provided; '
+                             'received step_times only')
+        if input_signal is None and step_times is None:
+            step_times, step_sizes = prep['step_times'], prep['step_sizes']
+            raw_input = prep.get('raw_input_signal')
+        elif step_times is not None:
+            raw_input = pp.generate_model_signal(times, step_times, step_sizes, None, 'ideal')
+        else:
+            raw_input = np.asarray(input_signal, dtype=float)
+            step_times, step_sizes, _ = pp.process_input_signal(times, raw_input, self.step_model, offset_steps, step_offset_size)
+        fp = self._fitted_parameters(x)
+        ctx = self._context if self._context is not None else _ffi.get_context(self.device)
+        response = np.zeros(len(times))
+        if include_drt:
+            mode = _ffi.MODE_INTERP if self.integrate_method == 'interp' else _ffi.MODE_TRAPZ
+            lookup = self._lookups(ctx)['response'] if mode == _ffi.MODE_INTERP else None
+            a, _ = ctx.response_matrix(times, self.basis_tau, step_times, step_sizes, self.tau_epsilon, mode=mode, lookup=lookup,
+                                       layered=False)
+            xd = fp['x']
+            if self.series_neg:
+                nt = len(self.basis_tau)
+                xd = xd[:nt] - xd[nt:]
+            response += a @ xd
+        if include_ohmic:
+            response += mat1d.construct_ohmic_response_vector(times, self.step_model, step_times, step_sizes, None, raw_input,
+                                                              smooth) * fp.get('R_inf', 0)
+        if include_cap and fp.get('C_inv', 0) != 0:
+            response += fp['C_inv'] * mat1d.construct_capacitance_response_vector(times, self.step_model, step_times,
+                                                                                 step_sizes, None)
+        if fp.get('x_dop') is not None and include_dop:
+            rm_dop, _ = phasance.construct_phasor_v_matrix(times, self.basis_nu, 'gaussian', self.nu_epsilon, self.step_model,
+                                                           step_times, step_sizes, device=self.device)
+            response += rm_dop @ fp['x_dop']
+        if include_vz_offset and fp.get('vz_offset', 0) != 0:
+            # chrono half of _get_vz_strength_vec relative to the FIT's frequencies (drt1d.py:6200-6213)
+            nonconsec = prep['nonconsec_step_times']
+            deltas = pp.get_time_since_step(times, nonconsec, prestep_value=-1)
+            eis_tau_max = np.max(1 / (2 * np.pi * prep['frequencies']))
+            cs = np.ones(len(deltas))
+            far = deltas >= eis_tau_max
+            cs[far] = np.exp(-(fp.get('vz_offset_eps', 1) * np.log(deltas[far] / eis_tau_max)) ** 2)
+            cs[deltas == -1] = 0
+            response *= (1 + fp['vz_offset'] * cs)
+        response += self.predict_v_baseline(times) if v_baseline is None else v_baseline
+        return response
+
     def _eis_vz_strength(self, frequencies, vz_offset_eps):
         """EIS half of DRT._get_vz_strength_vec (drt1d.py:6173-6226) relative to the FIT's sample times."""
         prep = self._prep

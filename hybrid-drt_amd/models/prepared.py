@@ -122,7 +122,8 @@ class PreparedFitMixin:
                 nonconsec = np.insert(step_times[1:][gap], 0, step_times[0])
             else:
                 nonconsec = step_times
-            prep.update(sample_times=times, step_times=step_times, step_sizes=step_sizes, nonconsec_step_times=nonconsec)
+            prep.update(sample_times=times, step_times=step_times, step_sizes=step_sizes, nonconsec_step_times=nonconsec,
+                        raw_input_signal=i_signal)
         else:
             step_times = step_sizes = None
         if has_eis:
@@ -148,7 +149,7 @@ class PreparedFitMixin:
             times, i_signal, v_signal, sample_index = pp.downsample_data(
                 times, i_signal, v_signal, stepwise_sample_times=True, step_times=prep['nonconsec_step_times'],
                 op_mode=self.chrono_mode, device=self.device, **dkw)
-            prep.update(sample_times=times, sample_index=sample_index)
+            prep.update(sample_times=times, sample_index=sample_index, raw_input_signal=i_signal)
         luts = self._lookups(ctx) if integrate_mode == _ffi.MODE_INTERP else dict(z=None, response=None)
         sp = self._general_special_params(has_chrono, has_eis, ckw['vz_offset'],
                                           int(ckw['v_baseline_deg']) + 1 + int(bool(ckw['v_baseline_sqrt'])))

@@ -463,12 +463,15 @@ def run_predict(DRT, freq_g, z_g):
     out = dict(f_pred=f_pred)
     cases = {"eis": (dict(base, fit_dop=False), (None, None, None, freq_g, z_g), {}),
              "eis_dop": (dict(base, fit_dop=True), (None, None, None, freq_g, z_g), {}),
-             "hybrid_dop": (dict(base, fit_dop=True), meas, {})}
+             "hybrid_dop": (dict(base, fit_dop=True), meas, {}),
+             "chrono": (dict(base, fit_dop=False), meas[:3] + (None, None), {})}
     for tag, (ctor, data, kw) in cases.items():
         with _quiet():
             drt = DRT(**ctor)
             if data[0] is None:
                 drt.fit_eis(data[3], data[4], **kw)
+            elif data[3] is None:
+                drt.fit_chrono(*data[:3], **kw)
             else:
                 drt.fit_hybrid(*data, **kw)
             tau = drt.get_tau_eval(20)
@@ -479,6 +482,12 @@ def run_predict(DRT, freq_g, z_g):
             out[f"{tag}_z_noL"] = drt.predict_z(f_pred, include_inductance=False, include_vz_offset=False)
             out[f"{tag}_rp"] = drt.predict_r_p()
             out[f"{tag}_rp_abs"] = drt.predict_r_p(absolute=True)
+            if data[0] is not None:
+                t_pred = np.concatenate([data[0][::7], [data[0][-1] * 1.5]])
+                out[f"{tag}_v_fit"] = drt.predict_response()
+                out[f"{tag}_t_pred"] = t_pred
+                out[f"{tag}_v_pred"] = drt.predict_response(times=t_pred)
+                out[f"{tag}_v_pred_parts"] = drt.predict_response(times=t_pred, include_dop=False, include_vz_offset=False)
     np.savez_compressed(os.path.join(OUT, "refrun_predict.npz"), **out)
     print("refrun_predict.npz:", {k: np.shape(v) for k, v in out.items() if k.endswith("_z")})
 

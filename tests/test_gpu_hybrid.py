@@ -743,13 +743,21 @@ def test_predict_functions_match_reference_run():
     freq, z = gg["freq"], gg["z"]
     meas = synth.hybrid_measurement(seed=0)
     cases = {"eis": (dict(), (None, None, None, freq, z), {}), "eis_dop": (dict(fit_dop=True), (None, None, None, freq, z), {}),
-             "hybrid_dop": (dict(fit_dop=True), meas, {})}
+             "hybrid_dop": (dict(fit_dop=True), meas, {}), "chrono": (dict(), meas[:3] + (None, None), {})}
     for tag, (ctor, data, kw) in cases.items():
         drt = DRT(warn=False, **ctor)
         if data[0] is None:
             drt.fit_eis(data[3], data[4], **kw)
+        elif data[3] is None:
+            drt.fit_chrono(*data[:3], **kw)
         else:
             drt.fit_hybrid(*data, **kw)
+        if data[0] is not None:       # predict_response at the fit times, at other times, with parts switched off
+            vs = np.abs(g[f"{tag}_v_fit"]).max()
+            np.testing.assert_allclose(drt.predict_response(), g[f"{tag}_v_fit"], rtol=0, atol=1e-7 * vs, err_msg=tag)
+            np.testing.assert_allclose(drt.predict_response(times=g[f"{tag}_t_pred"]), g[f"{tag}_v_pred"], rtol=0, atol=1e-7 * vs)
+            np.testing.assert_allclose(drt.predict_response(times=g[f"{tag}_t_pred"], include_dop=False, include_vz_offset=False),
+                                       g[f"{tag}_v_pred_parts"], rtol=0, atol=1e-7 * vs)
         sign = 0 if kw.get("series_neg") else 1
         tau = drt.get_tau_eval(20)
         np.testing.assert_allclose(tau, g[f"{tag}_tau"], rtol=1e-13)

@@ -335,16 +335,30 @@ class DRT(PreparedFitMixin):
         Cholesky factor of each final P.  Returns (var (B, len(tau)), ok (B,) bool); ``extend_var`` applies the
         reference's clamp outside the measured tau range (drt1d.py:3126-3143)."""
         from ..matrices import basis
-        if self._plan is None or self._last_batch is None:
+        prepared = isinstance(self._plan, _ffi.PreparedPlan)
+        if self._plan is None or (self._last_batch is None and not prepared):
             raise Exception('Parameter covariance estimation is only available for qphb fits')
         if tau is None:
             tau = self.get_tau_eval(ppd)
         tau = np.asarray(tau, dtype=float)
         bm = basis.construct_func_eval_matrix(np.log(self.basis_tau), np.log(tau), self.tau_basis_type,
                                               epsilon=self.tau_epsilon, order=0)
-        var, status = self._plan.distribution_var(bm, self._last_batch)
+        if prepared:
+            if self.series_neg:
+                raise NotImplementedError("distribution variance of series_neg fits is not built")
+            # the device loop of a prepared plan runs at unit scale: estimate_param_cov's coefficient_scale^2 is applied here
+            var, status = self._plan.distribution_var(bm, self._plan.batch)
+            preps = self._last_prepared[0] if getattr(self, '_last_prepared', None) and \
+                len(self._last_prepared[0]) == self._plan.batch else [self._prep]
+            var = var * np.array([pr['coefficient_scale'] for pr in preps])[:, None] ** 2
+        else:
+            var, status = self._plan.distribution_var(bm, self._last_batch)
         if extend_var:
-            t_left, t_right = 1 / (2 * np.pi * np.max(self.f_fit)), 1 / (2 * np.pi * np.min(self.f_fit))
+            if prepared:
+                pr = self._prep
+                t_left, t_right = pp.get_tau_lim(pr['frequencies'], pr.get('sample_times'), pr.get('nonconsec_step_times'))
+            else:
+                t_left, t_right = 1 / (2 * np.pi * np.max(self.f_fit)), 1 / (2 * np.pi * np.min(self.f_fit))
             left_index = int(np.argmin(np.abs(tau - t_left))) + 1
             right_index = int(np.argmin(np.abs(tau - t_right)))
             var[:, :left_index] = np.maximum(var[:, :left_index], var[:, left_index][:, None])
@@ -411,6 +425,27 @@ class DRT(PreparedFitMixin):
         return bm @ xd / norm
 
     predict_distribution = predict_drt          # deprecated upstream name (drt1d.py:3033-3041)
+
+    def predict_drt_ci(self, tau=None, ppd=20, x=None, order=0, sign=1, normalize=False, normalize_by=None,
+                       quantiles=(0.025, 0.975)):
+        """drt1d.predict_drt_ci (3208-3231): credible band of gamma(tau) from the posterior variance (device kernel) around
+        predict_drt; (None, None) when the precision matrix is not positive definite."""
+        from scipy.special import erf
+        if order != 0 or normalize or normalize_by is not None:
+            raise NotImplementedError("only the order-0, un-normalised band is built")
+        if tau is None:
+            tau = self.get_tau_eval(ppd)
+        var, ok = self.estimate_distribution_var_batch(tau=tau)
+        if not ok[0]:
+            return None, None
+        mu = self.predict_drt(tau=tau, x=x, sign=sign)
+        # utils.stats.std_normal_quantile (stats.py:108-116): the reference inverts a 2000-point table of the normal CDF
+        s_grid = np.linspace(0, 14, 2000)
+        cdf = 0.5 * (1 + erf(s_grid / np.sqrt(2)))
+        q = np.asarray(quantiles, dtype=float)
+        s_lo, s_hi = np.interp(np.abs(q - 0.5) + 0.5, cdf, s_grid) * np.sign(q - 0.5)
+        sigma = np.sqrt(var[0])
+        return mu + s_lo * sigma, mu + s_hi * sigma
 
     def predict_z(self, frequencies, include_vz_offset=True, x=None, include_dop=True, include_drt=True,
                   include_inductance=True, include_ohmic=True, include_cap=True):

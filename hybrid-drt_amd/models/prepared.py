@@ -649,6 +649,7 @@ class PreparedFitMixin:
         self.cvx_result = {'x': out['x'][b]}
         self.fit_type = fit_type
         self._prep = prep
+        self._last_prepared = None
         return fp
 
     # ---- public fits --------------------------------------------------------------------------------------------------

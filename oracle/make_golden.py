@@ -482,6 +482,9 @@ def run_predict(DRT, freq_g, z_g):
             out[f"{tag}_z_noL"] = drt.predict_z(f_pred, include_inductance=False, include_vz_offset=False)
             out[f"{tag}_rp"] = drt.predict_r_p()
             out[f"{tag}_rp_abs"] = drt.predict_r_p(absolute=True)
+            lo, hi = drt.predict_drt_ci(tau=tau)
+            out[f"{tag}_ci_lo"], out[f"{tag}_ci_hi"] = lo, hi
+            out[f"{tag}_dist_var_ext"] = np.diag(drt.estimate_distribution_cov(tau=tau, extend_var=True))
             if data[0] is not None:
                 t_pred = np.concatenate([data[0][::7], [data[0][-1] * 1.5]])
                 out[f"{tag}_v_fit"] = drt.predict_response()

@@ -770,3 +770,9 @@ def test_predict_functions_match_reference_run():
                                    g[f"{tag}_z_noL"], rtol=1e-6, atol=1e-8)
         np.testing.assert_allclose(drt.predict_r_p(), g[f"{tag}_rp"], rtol=1e-6)
         np.testing.assert_allclose(drt.predict_r_p(absolute=True), g[f"{tag}_rp_abs"], rtol=1e-6)
+        lo, hi = drt.predict_drt_ci(tau=tau)
+        band = np.abs(g[f"{tag}_ci_hi"] - g[f"{tag}_ci_lo"]).max()
+        np.testing.assert_allclose(lo, g[f"{tag}_ci_lo"], rtol=0, atol=1e-6 * band, err_msg=tag)
+        np.testing.assert_allclose(hi, g[f"{tag}_ci_hi"], rtol=0, atol=1e-6 * band)
+        var_ext, ok = drt.estimate_distribution_var_batch(tau=tau, extend_var=True)
+        np.testing.assert_allclose(var_ext[0], g[f"{tag}_dist_var_ext"], rtol=1e-5, atol=1e-9 * g[f"{tag}_dist_var_ext"].max())

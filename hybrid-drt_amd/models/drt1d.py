@@ -483,6 +483,39 @@ class DRT(PreparedFitMixin):
             z *= (1 - fp['vz_offset'] * self._eis_vz_strength(frequencies, fp.get('vz_offset_eps', 1)))
         return z
 
+    def predict_dop(self, nu=None, x=None, normalize=False, normalize_tau=None, order=0, return_nu=False,
+                    normalize_quantiles=(0, 1), include_ideal=True):
+        """drt1d.predict_dop (3273-3345) for the gaussian nu basis: distribution of phasances on a nu grid, optionally
+        normalised by the phasor scale of the data's tau range, with the ideal elements (R_inf at nu = 0, inductance at
+        nu = 1, C_inv at nu = -1) added as upstream does."""
+        from ..matrices import basis, phasance
+        if order != 0:
+            raise NotImplementedError("only order 0 is built")
+        if nu is None:
+            nu = np.unique(np.concatenate([self.basis_nu, np.linspace(-1, 1, 1001)]))
+            nu = np.unique(np.concatenate([nu, np.array([-1, 0, 1])]))
+        else:
+            nu = np.sort(nu)
+        fp = self._fitted_parameters(x)
+        dop = basis.construct_func_eval_matrix(self.basis_nu, nu, 'gaussian', epsilon=self.nu_epsilon, order=0) @ fp['x_dop']
+        area = np.sqrt(np.pi) / self.nu_epsilon
+        if normalize:
+            if normalize_tau is None:
+                pr = self._prep
+                normalize_tau = np.array(pp.get_tau_lim(pr['frequencies'], pr.get('sample_times'), pr.get('step_times')))
+            norm = phasance.phasor_scale_vector(nu, normalize_tau, normalize_quantiles) / area
+        else:
+            norm = 1
+        dop = dop / norm
+        if include_ideal:
+            for value, key in ((0, 'R_inf'), (1, 'inductance'), (-1, 'C_inv')):
+                idx = np.where(nu == value)
+                ideal = self.fit_parameters[key]
+                if normalize:
+                    ideal = ideal / (norm[idx] * area)
+                dop[idx] += ideal
+        return (nu, dop) if return_nu else dop
+
     def predict_v_baseline(self, times, x_vb=None):
         """drt1d.predict_v_baseline (3471-3478): polynomial (+ sqrt) baseline in data units."""
         from . import background

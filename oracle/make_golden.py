@@ -485,6 +485,10 @@ def run_predict(DRT, freq_g, z_g):
             lo, hi = drt.predict_drt_ci(tau=tau)
             out[f"{tag}_ci_lo"], out[f"{tag}_ci_hi"] = lo, hi
             out[f"{tag}_dist_var_ext"] = np.diag(drt.estimate_distribution_cov(tau=tau, extend_var=True))
+            if ctor.get("fit_dop"):
+                out[f"{tag}_dop_nu"], out[f"{tag}_dop"] = drt.predict_dop(return_nu=True)
+                out[f"{tag}_dop_norm"] = drt.predict_dop(normalize=True)
+                out[f"{tag}_dop_coarse"] = drt.predict_dop(nu=np.linspace(-1, 1, 21), include_ideal=False)
             if data[0] is not None:
                 t_pred = np.concatenate([data[0][::7], [data[0][-1] * 1.5]])
                 out[f"{tag}_v_fit"] = drt.predict_response()

@@ -752,6 +752,15 @@ def test_predict_functions_match_reference_run():
             drt.fit_chrono(*data[:3], **kw)
         else:
             drt.fit_hybrid(*data, **kw)
+        if ctor.get("fit_dop"):
+            nu, dop = drt.predict_dop(return_nu=True)
+            np.testing.assert_array_equal(nu, g[f"{tag}_dop_nu"])
+            ds = np.abs(g[f"{tag}_dop"]).max()
+            np.testing.assert_allclose(dop, g[f"{tag}_dop"], rtol=1e-5, atol=1e-7 * ds, err_msg=tag)
+            np.testing.assert_allclose(drt.predict_dop(normalize=True), g[f"{tag}_dop_norm"], rtol=1e-5,
+                                       atol=1e-7 * np.abs(g[f"{tag}_dop_norm"]).max())
+            np.testing.assert_allclose(drt.predict_dop(nu=np.linspace(-1, 1, 21), include_ideal=False), g[f"{tag}_dop_coarse"],
+                                       rtol=1e-5, atol=1e-7 * ds)
         if data[0] is not None:       # predict_response at the fit times, at other times, with parts switched off
             vs = np.abs(g[f"{tag}_v_fit"]).max()
             np.testing.assert_allclose(drt.predict_response(), g[f"{tag}_v_fit"], rtol=0, atol=1e-7 * vs, err_msg=tag)

@@ -368,8 +368,14 @@ class DRT(PreparedFitMixin):
     def estimate_param_var_batch(self):
         """np.diag(DRT.estimate_param_cov()) (drt1d.py:4116-4138) for every spectrum of the last fitted batch, from the
         Cholesky factor of each final P on the device.  Returns (var (B, n), ok (B,) bool)."""
-        if self._plan is None or self._last_batch is None:
+        prepared = isinstance(self._plan, _ffi.PreparedPlan)
+        if self._plan is None or (self._last_batch is None and not prepared):
             raise Exception('Parameter covariance estimation is only available for qphb fits')
+        if prepared:     # the prepared loop runs at unit scale: coefficient_scale^2 of estimate_param_cov applied here
+            var, status = self._plan.param_var(self._plan.batch)
+            preps = self._last_prepared[0] if getattr(self, '_last_prepared', None) and \
+                len(self._last_prepared[0]) == self._plan.batch else [self._prep]
+            return var * np.array([pr['coefficient_scale'] for pr in preps])[:, None] ** 2, status == 0
         var, status = self._plan.param_var(self._last_batch)
         return var, status == 0
 

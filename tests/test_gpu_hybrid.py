@@ -785,3 +785,15 @@ def test_predict_functions_match_reference_run():
         np.testing.assert_allclose(hi, g[f"{tag}_ci_hi"], rtol=0, atol=1e-6 * band)
         var_ext, ok = drt.estimate_distribution_var_batch(tau=tau, extend_var=True)
         np.testing.assert_allclose(var_ext[0], g[f"{tag}_dist_var_ext"], rtol=1e-5, atol=1e-9 * g[f"{tag}_dist_var_ext"].max())
+
+
+def test_parameter_variances_of_a_joint_fit():
+    """diag(inv(P)) cs^2 for a prepared-plan fit against numpy on the downloaded P (estimate_param_cov, drt1d.py:4116-4138)"""
+    from hipdrt.models import DRT
+    g, _ = load_case("hybrid_s0_dop")
+    drt = DRT(fit_dop=True, warn=False)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"])
+    var, ok = drt.estimate_param_var_batch()
+    assert ok[0]
+    ref = np.diag(np.linalg.inv(fp["p_matrix"])) * drt.coefficient_scale ** 2
+    np.testing.assert_allclose(var[0], ref, rtol=1e-6)

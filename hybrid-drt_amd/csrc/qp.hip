@@ -244,10 +244,14 @@ __device__ __forceinline__ bool chol_factor_group(const double* __restrict__ P, 
     for (int jb = 0; jb < nblk; ++jb) {
         const int j0 = jb * NB;
         const int nv = (n - j0) < NB ? (n - j0) : NB;
-        // one pass = rows [rowbase, rowbase + cr): rank-k update on MFMA into the LDS panel, (diagonal pass: factor the
-        // block,) forward substitution against L11 one thread per row, coalesced write-back
-        auto pass = [&](const int rowbase, const int cr, const bool diag, const bool store) -> bool {
-            const int ntile = (cr + 15) >> 4;
+        // one pass = (optionally) the 32 rows of the diagonal block in panel rows 0..31, followed by `cr` panel rows starting
+        // at `chunkbase`: rank-k update on MFMA into the LDS panel -- the two diagonal tiles on wavefronts 0 and 1 while the
+        // others already work on the chunk's tiles --, factorisation of the diagonal block, forward substitution of the
+        // chunk rows against L11 one thread per row, coalesced write-back
+        auto pass = [&](const bool with_diag, const int chunkbase, const int cr, const bool store_diag) -> bool {
+            const int off = with_diag ? NB : 0;                       // panel row of the chunk's first row
+            const int ntile = (off >> 4) + ((cr + 15) >> 4);
+            auto tile_row = [&](int t) { return (with_diag && t < 2) ? j0 + 16 * t : chunkbase + 16 * (t - (off >> 4)); };
             v4d acc[MAXT][2];
 #pragma unroll
             for (int u = 0; u < MAXT; ++u) { acc[u][0] = (v4d){0, 0, 0, 0}; acc[u][1] = (v4d){0, 0, 0, 0}; }
@@ -258,7 +262,7 @@ __device__ __forceinline__ bool chol_factor_group(const double* __restrict__ P, 
             const double* pa[MAXT];
 #pragma unroll
             for (int u = 0; u < MAXT; ++u) {
-                int ar = rowbase + (wv + u * NW) * 16 + li;
+                int ar = tile_row(wv + u * NW) + li;
                 if (ar > n - 1) ar = n - 1;
                 pa[u] = L + (size_t)ar * ldl + 4 * kq;
             }
@@ -289,12 +293,13 @@ __device__ __forceinline__ bool chol_factor_group(const double* __restrict__ P, 
             for (int u = 0; u < MAXT; ++u) {
                 const int t = wv + u * NW;
                 if (t < ntile) {
+                    const int trow = tile_row(t);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
                             const int lr = t * 16 + (lane >> 4) + 4 * rg;
-                            const int row = rowbase + lr;
+                            const int row = trow + (lane >> 4) + 4 * rg;
                             const int cc = ct * 16 + (lane & 15);
                             const int col = j0 + cc;
                             double v = 0.0;
@@ -309,7 +314,7 @@ __device__ __forceinline__ bool chol_factor_group(const double* __restrict__ P, 
                 }
             }
             __syncthreads();
-            if (diag) {
+            if (with_diag) {
                 if (wv == 0) {
                     const bool ok = factor_diag_block(sm.panel, sm.l11, nv, lane);
                     const unsigned long long bad = __ballot(!ok);
@@ -317,50 +322,52 @@ __device__ __forceinline__ bool chol_factor_group(const double* __restrict__ P, 
                 }
                 __syncthreads();
                 if (sm.flag[0]) return false;
-                for (int e = tid; e < NB * NB; e += THREADS) {
-                    const int r = e >> 5, c = e & 31;
-                    sm.panel[r * PLD + c] = sm.l11[r * PLD + c];
-                }
-            } else {
-                for (int rr = tid; rr < cr; rr += THREADS) {
-                    double v[NB];
-                    double* prow = sm.panel + rr * PLD;
+            }
+            for (int rr = tid; rr < cr; rr += THREADS) {
+                double v[NB];
+                double* prow = sm.panel + (off + rr) * PLD;
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) v[c] = prow[c];
+                for (int c = 0; c < NB; ++c) v[c] = prow[c];
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) {
-                        if (c < nv) {
-                            double t = v[c];
+                for (int c = 0; c < NB; ++c) {
+                    if (c < nv) {
+                        double t = v[c];
 #pragma unroll
-                            for (int k = 0; k < c; ++k) t -= v[k] * sm.l11[c * PLD + k];
-                            v[c] = t / sm.l11[c * PLD + c];
-                        }
+                        for (int k = 0; k < c; ++k) t -= v[k] * sm.l11[c * PLD + k];
+                        v[c] = t / sm.l11[c * PLD + c];
                     }
-#pragma unroll
-                    for (int c = 0; c < NB; ++c) prow[c] = v[c];
                 }
+#pragma unroll
+                for (int c = 0; c < NB; ++c) prow[c] = v[c];
             }
             __syncthreads();
-            if (store) {
-                for (int e = tid; e < cr * NB; e += THREADS) {
+            if (with_diag && store_diag) {
+                for (int e = tid; e < nv * NB; e += THREADS) {
                     const int r = e >> 5, c = e & 31;
-                    if (c < nv) L[(size_t)(rowbase + r) * ldl + j0 + c] = sm.panel[r * PLD + c];
+                    if (c < nv) L[(size_t)(j0 + r) * ldl + j0 + c] = sm.l11[r * PLD + c];
                 }
+            }
+            for (int e = tid; e < cr * NB; e += THREADS) {
+                const int r = e >> 5, c = e & 31;
+                if (c < nv) L[(size_t)(chunkbase + r) * ldl + j0 + c] = sm.panel[(off + r) * PLD + c];
             }
             __syncthreads();
             return true;
         };
-        if (!pass(j0, nv, true, g == 0)) { ok_all = false; break; }       // identical in every workgroup of the group
+        // This workgroup's first chunk of the rows below the diagonal block shares a pass with the (redundant) diagonal
+        // block; further chunks (only when the column is taller than G full panels) follow on their own
         const int rem = n - (j0 + NB);
-        if (rem > 0) {
-            int pr = (((rem + G - 1) / G) + 15) & ~15;
-            if (pr > PR) pr = PR;
-            const int nchunk = (rem + pr - 1) / pr;
-            for (int c = g; c < nchunk; c += G) {
-                const int c0 = c * pr;
-                const int cr = (rem - c0) < pr ? (rem - c0) : pr;
-                pass(j0 + NB + c0, cr, false, true);
-            }
+        int pr = rem > 0 ? (((rem + G - 1) / G) + 15) & ~15 : 16;
+        if (pr > PR - NB) pr = PR - NB;
+        const int nchunk = rem > 0 ? (rem + pr - 1) / pr : 0;
+        {
+            const int c0 = g * pr;
+            const int cr = g < nchunk ? ((rem - c0) < pr ? (rem - c0) : pr) : 0;
+            if (!pass(true, j0 + NB + c0, cr, g == 0)) { ok_all = false; break; }     // same outcome in every workgroup
+        }
+        for (int c = g + G; c < nchunk; c += G) {
+            const int c0 = c * pr;
+            pass(false, j0 + NB + c0, (rem - c0) < pr ? (rem - c0) : pr, false);
         }
         group_barrier(ctr, G, epoch);          // column block complete before anyone's next rank-k update reads it
     }

@@ -397,10 +397,11 @@ __device__ __forceinline__ void chol_solve(const double* __restrict__ L, int ldl
             double rdiag = 1.0;
 #pragma unroll
             for (int c = 0; c < NB; ++c) if (c == r) rdiag = lr[c];
+            rdiag = 1.0 / rdiag;             // one division per lane, not one per step of the dependent chain
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 if (c < nv) {
-                    const double yc = bcast_lane(bb / rdiag, c);
+                    const double yc = bcast_lane(bb * rdiag, c);
                     if (r > c) bb -= lr[c] * yc;
                     else if (r == c) bb = yc;
                 }
@@ -437,10 +438,11 @@ __device__ __forceinline__ void chol_solve(const double* __restrict__ L, int ldl
 #pragma unroll
             for (int r = 0; r < NB; ++r) if (r == c) cdiag = lc[r];
             if (j0 + c >= n) cdiag = 1.0;
+            cdiag = 1.0 / cdiag;
 #pragma unroll
             for (int r = NB - 1; r >= 0; --r) {
                 if (r < nv) {
-                    const double xr = bcast_lane(yy / cdiag, r);
+                    const double xr = bcast_lane(yy * cdiag, r);
                     if (c < r) yy -= lc[r] * xr;
                     else if (c == r) yy = xr;
                 }

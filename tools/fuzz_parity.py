@@ -1,0 +1,26 @@
+"""Runs the randomised differential tests of tests/test_gpu_hybrid.py for many more seeds than the suite does and reports the
+seeds that fail (diagnostic; needs a GPU).  python tools/fuzz_parity.py [first] [count]"""
+import os, sys, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import warnings
+warnings.filterwarnings("ignore")
+import test_gpu_hybrid as t
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = []
+for name in ("test_randomised_joint_fits_follow_the_oracle", "test_randomised_option_combinations_follow_the_oracle",
+             "test_randomised_joint_fits_with_option_combinations"):
+    fn = getattr(t, name)
+    fn = getattr(fn, "__wrapped__", fn)
+    nfail = 0
+    for seed in range(first, first + count):
+        try:
+            fn(seed)
+        except Exception as e:          # noqa: BLE001
+            nfail += 1
+            bad.append((name, seed, str(e).splitlines()[0][:200]))
+    print(f"{name}: {count - nfail}/{count} seeds ok", flush=True)
+for b in bad:
+    print("FAIL", b)

@@ -453,13 +453,14 @@ class Plan:
     def continue_fit(self, opts, weight_factor=1.0, min_iter=2):
         _check(self._lib.hipdrt_plan_continue(self._h, C.byref(opts), float(weight_factor), int(min_iter)))
 
-    def set_weight_factors(self, weight_factor=1.0, row_factors=None):
-        """weight_factor / chrono- and EIS-row factors of _qphb_fit_core; row_factors (m,) or (capacity, m)"""
+    def set_weight_factors(self, weight_factor=1.0, row_factors=None, late=False):
+        """weight_factor / chrono- and EIS-row factors of _qphb_fit_core; row_factors (m,) or (capacity, m); late=True: the
+        rows are a vector-valued weight_factor (applied from the second iteration on)"""
         rf = None if row_factors is None else _f64(row_factors)
         if rf is not None and rf.ndim == 2 and rf.shape[0] < self.capacity:     # the C side reads capacity rows
             rf = _f64(np.vstack([rf, np.ones((self.capacity - rf.shape[0], rf.shape[1]))]))
         _check(self._lib.hipdrt_plan_set_weight_factors(self._h, float(weight_factor), _p(rf),
-                                                        int(rf is not None and rf.ndim == 2)))
+                                                        int(rf is not None and rf.ndim == 2) | (2 if late else 0)))
 
     def set_init_h(self, h_init):
         h = None if h_init is None else _f64(h_init)

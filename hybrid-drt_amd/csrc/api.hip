@@ -31,6 +31,7 @@ struct hipdrt_plan {
     // weight factors (hipdrt_plan_set_weight_factors): w_eff = w * row factor * weight_factor is what the QP sees
     double weight_factor = 1.0;
     int wrow_batched = 0;
+    int wrow_late = 0;      // row factors are a vector-valued weight_factor: applied from the second iteration on only
     DevBuf wrow, w_eff, h_init, wfac;
     bool has_weight_factors() const { return weight_factor != 1.0 || wrow.p != nullptr; }
     // shared
@@ -721,7 +722,8 @@ int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const d
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
     p->weight_factor = weight_factor;
-    p->wrow_batched = batched ? 1 : 0;
+    p->wrow_batched = (batched & 1) ? 1 : 0;
+    p->wrow_late = (batched & 2) ? 1 : 0;
     if (row_factors) {
         const size_t cnt = (batched ? (size_t)p->capacity : 1) * p->m;
         TRY(upload(p->wrow, row_factors, cnt * sizeof(double), st));
@@ -971,8 +973,8 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
         HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
         const double* wq = p->w.d();
         if (p->has_weight_factors()) {           // drt1d.py:889-901: row factors every iteration, weight_factor from the second
-            launch_scale_rows(st, B, m, p->w.d(), p->wrow.d(), p->wrow_batched, it > 0 ? p->weight_factor : 1.0,
-                              p->active.i(), p->w_eff.d());
+            launch_scale_rows(st, B, m, p->w.d(), (p->wrow_late && it == 0) ? nullptr : p->wrow.d(), p->wrow_batched,
+                              it > 0 ? p->weight_factor : 1.0, p->active.i(), p->w_eff.d());
             wq = p->w_eff.d();
         }
         launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, wq, g, Prow, p->ldp, (long long)n * p->ldp, p->active.i(),
@@ -998,8 +1000,13 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     const double* wfin = p->w.d();
     if (p->has_weight_factors()) {
         // drt1d.py:990-1000: weights *= weight_factor (these are `true_weights`); calculate_pq sees them times the row factors
-        launch_scale_rows(st, B, m, p->w.d(), nullptr, 0, p->weight_factor, nullptr, p->w.d());
-        launch_scale_rows(st, B, m, p->w.d(), p->wrow.d(), p->wrow_batched, 1.0, nullptr, p->w_eff.d());
+        if (p->wrow_late) {      // vector weight_factor: part of the weights themselves, no separate "scaled" weights
+            launch_scale_rows(st, B, m, p->w.d(), p->wrow.d(), p->wrow_batched, p->weight_factor, nullptr, p->w.d());
+            launch_scale_rows(st, B, m, p->w.d(), nullptr, 0, 1.0, nullptr, p->w_eff.d());
+        } else {
+            launch_scale_rows(st, B, m, p->w.d(), nullptr, 0, p->weight_factor, nullptr, p->w.d());
+            launch_scale_rows(st, B, m, p->w.d(), p->wrow.d(), p->wrow_batched, 1.0, nullptr, p->w_eff.d());
+        }
         wfin = p->w_eff.d();
     }
     launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, wfin, p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr, astr);

@@ -201,6 +201,55 @@ class DRT(PreparedFitMixin):
         self.fit_type = 'qphb_eis'
         return fp
 
+    # ---- Kramers-Kronig test (drt1d.py:1370-1491) -----------------------------------------------------------------------
+    def kk_fit(self, frequencies, z, nonneg=False, l2_lambda_0=1e-2, extend_basis_decades=2, outlier_index=None):
+        """DRT.kk_fit (1393-1411): weakly regularised, sign-unconstrained fit on a basis grid extended by two decades;
+        flagged points stay in the data with a weight factor of 1e-10."""
+        keep = self.extend_basis_decades
+        self.extend_basis_decades = extend_basis_decades
+        try:
+            if outlier_index is not None:
+                wf = np.ones(2 * len(frequencies))
+                wf[outlier_index] = 1e-10
+                wf[np.asarray(outlier_index) + len(frequencies)] = 1e-10
+            else:
+                wf = 1
+            self.fit_eis(frequencies, z, nonneg=nonneg, l2_lambda_0=l2_lambda_0, weight_factor=wf)
+        finally:
+            self.extend_basis_decades = keep
+        self.z_fit = np.asarray(z, dtype=complex)
+
+    def eval_kk_residuals(self, norm="modulus"):
+        from . import kk
+        return kk.normalize_residuals(self.z_fit, self.predict_z(self.f_fit), norm=norm)
+
+    def get_kk_outliers(self, norm="modulus", n_iter=2, p_thresh=1e-4, n_sigma=None, std_sample_fraction=0.6):
+        from . import kk
+        return kk.get_outliers(self.eval_kk_residuals(norm=norm), n_iter, p_thresh, n_sigma=n_sigma,
+                               std_sample_fraction=std_sample_fraction)
+
+    def get_kk_limits(self, outlier_index, max_num_outliers=2):
+        from . import kk
+        return kk.get_limits(self.f_fit, outlier_index, max_num_outliers=max_num_outliers)
+
+    def kk_test(self, frequencies, z, nonneg=False, l2_lambda_0=1e-2, extend_basis_decades=2, norm="modulus",
+                max_num_outliers=2, p_thresh=1e-4, n_sigma=None, std_sample_fraction=0.6, n_iter=2, n_outlier_iter=2,
+                show_plot=False):
+        """DRT.kk_test (1370-1390) without the plot: returns (outlier_index, (f_min, f_max), (f_clean, z_clean))."""
+        from . import kk
+        frequencies, z = np.asarray(frequencies, dtype=float), np.asarray(z, dtype=complex)
+        outlier_index = None
+        for _ in range(n_iter):
+            self.kk_fit(frequencies, z, nonneg=nonneg, l2_lambda_0=l2_lambda_0, extend_basis_decades=extend_basis_decades,
+                        outlier_index=outlier_index)
+            outlier_index = self.get_kk_outliers(norm=norm, p_thresh=p_thresh, n_iter=n_outlier_iter, n_sigma=n_sigma,
+                                                 std_sample_fraction=std_sample_fraction)
+            f_min, f_max = self.get_kk_limits(outlier_index, max_num_outliers=max_num_outliers)
+            fz_clean = kk.trim_data(frequencies, z, f_min, f_max)
+        if show_plot:
+            raise NotImplementedError("plotting is outside this package")
+        return outlier_index, (f_min, f_max), fz_clean
+
     def fit_eis_batch(self, frequencies, z_batch, **kw):
         """B spectra on one frequency grid, fitted concurrently (the reference's DRTMD loop calls
         _qphb_fit_core once per observation, mapping/drtmd.py:245-319).  Returns a dict of arrays."""
@@ -223,7 +272,11 @@ class DRT(PreparedFitMixin):
         self.fit_kwargs = dict(hypers, **fkw)
         self.f_fit = frequencies
         plan.record_history(history_of)
-        plan.set_weight_factors(fkw['weight_factor'])
+        wf = fkw['weight_factor']
+        if np.ndim(wf) > 0:       # vector-valued weight_factor (kk_fit): one factor per data row
+            plan.set_weight_factors(1.0, np.asarray(wf, dtype=float), late=True)
+        else:
+            plan.set_weight_factors(wf)
         plan.upload(z_batch)
         self._last_batch = z_batch.shape[0]
         return plan

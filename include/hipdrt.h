@@ -309,7 +309,9 @@ int hipdrt_plan_upload_prepared(hipdrt_plan* plan, int B, int rm_batched, const 
  * from the second iteration on also * weight_factor; estimate_weights keeps working on the unscaled weights.  After the
  * fit hipdrt_plan_download returns weights * weight_factor ("true_weights"); q_vector / p_matrix / the posterior
  * variances use those times the row factors ("scaled weights").  row_factors: [m], or [capacity][m] when batched != 0.
- * Applies to every later hipdrt_plan_fit of the plan (any plan kind); (1.0, NULL) switches it off.                     */
+ * Applies to every later hipdrt_plan_fit of the plan (any plan kind); (1.0, NULL) switches it off.  batched bit 1 (value
+ * 2): the row factors are a vector-valued weight_factor (kk_fit, drt1d.py:1393-1411) -- applied from the second iteration
+ * on only and folded into the returned weights.                                                                        */
 int hipdrt_plan_set_weight_factors(hipdrt_plan* plan, double weight_factor, const double* row_factors, int batched);
 /* Constraint vector of the initialize_weights QP when it differs from the loop's (neg_allowed_tau_range: the loop allows
  * negative coefficients only inside a tau window, initialize_weights everywhere; hybdrt/models/drt1d.py:467, 657-660 vs

@@ -499,6 +499,24 @@ def run_predict(DRT, freq_g, z_g):
     print("refrun_predict.npz:", {k: np.shape(v) for k, v in out.items() if k.endswith("_z")})
 
 
+def run_kk(DRT, freq_g, z_g):
+    """DRT.kk_test (drt1d.py:1370-1491, models/kk.py): the reference's test spectrum with corrupted ends and two bad points
+    inside; flagged points, frequency limits, normalised residuals and the second (down-weighted) fit"""
+    z = z_g.copy()
+    z[:3] += np.array([0.04, -0.03 + 0.03j, 0.02j])          # high-frequency end
+    z[-2:] += np.array([0.05j, -0.06])                      # low-frequency end
+    z[30] += 0.03
+    z[45] -= 0.025j
+    with _quiet():
+        drt = DRT(fit_inductance=True, fit_capacitance=False, fit_ohmic=True, fit_dop=False)
+        out_idx, (f_min, f_max), (f_c, z_c) = drt.kk_test(freq_g, z, show_plot=False)
+        resid = drt.eval_kk_residuals()
+    np.savez_compressed(os.path.join(OUT, "refrun_kk.npz"), freq=freq_g, z=z, outlier_index=out_idx, f_min=f_min, f_max=f_max,
+                        f_clean=f_c, z_clean=z_c, residuals=resid, x=drt.fit_parameters["x"], basis_tau=drt.basis_tau,
+                        weights=drt.qphb_params["true_weights"], outer_iterations=len(drt.qphb_history))
+    print("refrun_kk.npz: outliers", out_idx.tolist(), "limits", f_min, f_max, "outer", len(drt.qphb_history))
+
+
 def run_posteriors(DRT, freq_g, z_g, default):
     from oracle.drt_oracle import get_basis_tau
     bt = get_basis_tau(freq_g)
@@ -511,6 +529,11 @@ def main():
     sys.path.insert(0, REPO)
     if "--only-response" in sys.argv:
         run_response_matrices()
+        return
+    if "--only-kk" in sys.argv:
+        freq_g, z_g = extract_reference_test_vectors()
+        DRT, cvxopt = _boot_reference()
+        run_kk(DRT, freq_g, z_g)
         return
     if "--only-predict" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()
@@ -595,6 +618,8 @@ def main():
     run_resolve_group(cvxopt, "hybrid16")
     # (12) evaluation of fitted models
     run_predict(DRT, freq_g, z_g)
+    # (13) Kramers-Kronig test
+    run_kk(DRT, freq_g, z_g)
 
 
 if __name__ == "__main__":

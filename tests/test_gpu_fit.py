@@ -390,3 +390,30 @@ def test_full_size_batch_properties():
         w = res["weights"][b]
         np.testing.assert_allclose(res["q_vector"][b], -(w[:, None] * rm).T @ (w * rv), rtol=1e-10,
                                    atol=1e-10 * np.abs(res["q_vector"][b]).max())
+
+
+@pytest.mark.gpu
+def test_kk_test_matches_reference_run():
+    """DRT.kk_test (drt1d.py:1370-1491): two kk_fit passes (the second with the flagged points down-weighted through a
+    vector-valued weight_factor), residual statistics, frequency limits"""
+    import os
+    from conftest import GOLDEN
+    from hipdrt.models import DRT, kk
+    g = np.load(os.path.join(GOLDEN, "refrun_kk.npz"))
+    drt = DRT(warn=False)
+    out_idx, (f_min, f_max), (f_c, z_c) = drt.kk_test(g["freq"], g["z"])
+    np.testing.assert_array_equal(out_idx, g["outlier_index"])
+    assert (f_min, f_max) == (float(g["f_min"]), float(g["f_max"]))
+    np.testing.assert_array_equal(f_c, g["f_clean"])
+    np.testing.assert_array_equal(z_c, g["z_clean"])
+    np.testing.assert_allclose(drt.basis_tau, g["basis_tau"], rtol=1e-13)
+    assert drt.qphb_params["outer_iterations"] == int(g["outer_iterations"])
+    # The second pass (sign-unconstrained, weakly regularised, three points weighted 1e-10: 16-20 IPM iterations per QP) does
+    # not converge in 50 outer iterations and is not contractive: device and oracle agree to 7e-10 after its first outer
+    # iteration and drift apart by iteration 20; the oracle itself ends 4 % away from this fixture when run on another host.
+    # The test's decisions (flagged points, limits) are insensitive to that; the residuals are compared at the 5 % level.
+    res = drt.eval_kk_residuals()
+    np.testing.assert_allclose(res, g["residuals"], rtol=0, atol=5e-2 * np.abs(g["residuals"]).max())
+    # host statistics on the reference's residuals
+    np.testing.assert_array_equal(kk.get_outliers(g["residuals"]), g["outlier_index"])
+    assert kk.get_limits(g["freq"], g["outlier_index"]) == (float(g["f_min"]), float(g["f_max"]))

@@ -7,9 +7,24 @@ import warnings
 warnings.filterwarnings("ignore")
 import test_gpu_hybrid as t
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+first = int(args[0]) if len(args) > 0 else 100
+count = int(args[1]) if len(args) > 1 else 100
 bad = []
+if "--eis" in sys.argv:
+    import test_gpu_fit as tf
+    fn = getattr(tf.test_randomized_fits_vs_oracle, "__wrapped__", tf.test_randomized_fits_vs_oracle)
+    nfail = 0
+    for seed in range(first, first + count):
+        try:
+            fn(seed)
+        except Exception as e:          # noqa: BLE001
+            nfail += 1
+            bad.append(("test_randomized_fits_vs_oracle", seed, str(e).splitlines()[0][:200]))
+    print(f"test_randomized_fits_vs_oracle: {count - nfail}/{count} seeds ok", flush=True)
+    for b in bad:
+        print("FAIL", b)
+    sys.exit(0)
 for name in ("test_randomised_joint_fits_follow_the_oracle", "test_randomised_option_combinations_follow_the_oracle",
              "test_randomised_joint_fits_with_option_combinations"):
     fn = getattr(t, name)

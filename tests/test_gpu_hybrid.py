@@ -641,12 +641,14 @@ def test_randomised_option_combinations_follow_the_oracle(seed):
                                 update_scale=dict(basis_area=area) if kw.get("update_scale") else None,
                                 weight_factor=kw.get("weight_factor", 1))
     n_extra = 1 + (1 if kw.get("outlier_p") else 0)          # Rp QP (+ first outlier QP) precede the plan's history
-    assert [l["iterations"] for l in ref["qp_log"]][n_extra:] == qp["qp_iterations"].tolist(), (seed, kw, dop)
+    assert [l["iterations"] for l in ref["qp_log"]][n_extra:] == qp["qp_iterations"].tolist(), \
+        (seed, kw, dop, [l["iterations"] for l in ref["qp_log"]][n_extra:], qp["qp_iterations"].tolist())
     assert prep["rp_qp_iterations"] == ref["qp_log"][0]["iterations"]
     hx = np.array([h["x"] for h in ref["history"]])
     dx = np.array([h["x"] for h in drt.qphb_history])
     assert hx.shape == dx.shape
-    assert np.abs(dx - hx).max() / np.abs(hx).max() < 5e-6, (seed, kw, dop)
+    drift = np.abs(dx - hx).max(axis=1) / np.abs(hx).max()        # per outer iteration: shows amplification if any
+    assert drift.max() < 5e-6, (seed, kw, dop, [f"{d:.1e}" for d in drift])
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
     np.testing.assert_allclose(drt.coefficient_scale, cs0 / (ref["scale_factor"] * ref["data_scale"]), rtol=1e-7)
 
@@ -699,11 +701,13 @@ def test_randomised_joint_fits_with_option_combinations(seed):
                                 init_separately=dict(num_chrono=nc) if kw.get("init_weights_separately") else None,
                                 weight_method=dict(num_chrono=nc) if mode == 3 else None)
     n_extra = (1 if kw.get("solve_rp") else 0) + (1 if kw.get("outlier_p") or kw.get("init_weights_separately") else 0)
-    assert [l["iterations"] for l in ref["qp_log"]][n_extra:] == qp["qp_iterations"].tolist(), (seed, kw, dop, cap)
+    assert [l["iterations"] for l in ref["qp_log"]][n_extra:] == qp["qp_iterations"].tolist(), \
+        (seed, kw, dop, cap, [l["iterations"] for l in ref["qp_log"]][n_extra:], qp["qp_iterations"].tolist())
     hx = np.array([h["x"] for h in ref["history"]])
     dx = np.array([h["x"] for h in drt.qphb_history])
     assert hx.shape == dx.shape
-    assert np.abs(dx - hx).max() / np.abs(hx).max() < 5e-6, (seed, kw, dop, cap)
+    drift = np.abs(dx - hx).max(axis=1) / np.abs(hx).max()
+    assert drift.max() < 5e-6, (seed, kw, dop, cap, [f"{d:.1e}" for d in drift])
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
     np.testing.assert_allclose(qp["rm"], ref["rzm"], rtol=0, atol=1e-6 * np.abs(ref["rzm"]).max())
 

@@ -623,6 +623,7 @@ class PreparedFitMixin:
         self.impedance_scale = prep['impedance_scale']
         self.input_signal_scale, self.response_signal_scale = prep['input_signal_scale'], prep['response_signal_scale']
         self.step_times, self.step_sizes = prep.get('step_times'), prep.get('step_sizes')
+        self.sample_index = prep.get('sample_index')            # drtbase.py:335: kept samples of a down-sampled record
         self.dop_scale_vector = prep['dop_scale_vector']
         self.scaled_response_offset = prep.get('scaled_response_offset')
         self.v_baseline_scale = prep.get('v_baseline_scale')

@@ -1,5 +1,7 @@
 """Host-side grid / scale / step-detection rules of hybdrt/preprocessing.py that sit on the fit paths (O(samples)
 numpy bookkeeping that decides grids and scales; the matrices and the optimisation run on the device)."""
+import warnings
+
 import numpy as np
 
 
@@ -241,32 +243,103 @@ def filter_chrono_signal(times, y, step_index=None, input_signal=None, decimate_
     return filters.nonuniform_gaussian_filter1d_segments(y, sigmas, bounds, device=device)
 
 
-def downsample_data(times, i_signal, v_signal, target_times=None, stepwise_sample_times=True, step_times=None,
-                    step_model=None, method='match', antialiased=True, filter_kw=None, op_mode='galv', prestep_samples=20,
-                    device=0):
-    """preprocessing.downsample_data (335-470), method='match': keep the samples closest to `target_times` after every step
-    (all post-step samples when None) and the whole pre-step record, after an anti-aliasing filter matched to the local
-    decimation.  Returns (sample_times, sample_i, sample_v, sample_index)."""
-    if method != 'match':
-        raise NotImplementedError("only method='match' is built")
-    if not stepwise_sample_times:
-        raise NotImplementedError("only stepwise_sample_times=True is built")
+def get_decimation_index(times, step_times, t_sample, prestep_points, decimation_interval, decimation_factor,
+                         max_t_sample):
+    """preprocessing.get_decimation_index (620-689): indices kept by progressive decimation.  ``prestep_points`` evenly
+    spaced samples of the pre-step record; after every step the first ``decimation_interval`` + 1 samples at full rate,
+    then stretches of ``decimation_interval`` samples at strides ``int(decimation_factor ** j)``, j = 1, 2, ... (capped at
+    ``int(max_t_sample / t_sample)``; the capped stretch runs to the end of the step), always ending on the last sample
+    before the next step."""
+    times = np.asarray(times, dtype=float)
+    n = len(times)
+    n_pre = int(np.count_nonzero(times < np.min(step_times)))
+    keep = [np.linspace(0, n_pre - 1, prestep_points).round(0).astype(int)]
+    # first sample at or after each step time (the reference's argmin over non-negative delays)
+    starts = [int(np.flatnonzero(times >= st)[np.argmin(times[times >= st])]) for st in step_times]
+    stride_cap = np.inf if max_t_sample is None else int(max_t_sample / t_sample)
+    for k, start in enumerate(starts):
+        stop = n if start == starts[-1] else starts[k + 1]
+        head = np.arange(start, min(start + decimation_interval + 1, stop), dtype=int)
+        keep.append(head)
+        last, j = head[-1], 1
+        while last < stop - 1:
+            stride = min(int(decimation_factor ** j), stride_cap)
+            end = stop if stride == stride_cap else min(last + decimation_interval * stride + 1, stop)
+            part = np.arange(last + stride, end, stride, dtype=int)
+            if len(part) == 0:
+                part = np.array([end - 1])
+            if end == stop and part[-1] < stop - 1:
+                part = np.append(part, stop - 1)
+            keep.append(part)
+            last = part[-1]
+            j += 1
+    return np.unique(np.concatenate(keep))
+
+
+def select_decimation_interval(times, step_times, t_sample, prestep_points, decimation_factor, max_t_sample, target_size):
+    """preprocessing.select_decimation_interval (603-617): interval whose decimated size interpolates to ``target_size``
+    over twelve trial intervals between 2 and 1000."""
+    intervals = np.logspace(np.log10(2), np.log10(1000), 12).astype(int)
+    sizes = [len(get_decimation_index(times, step_times, t_sample, prestep_points, iv, decimation_factor, max_t_sample))
+             for iv in intervals]
+    if target_size > sizes[-1]:
+        warnings.warn(f'Cannot achieve target size of {target_size} with selected decimation factor of '
+                      f'{decimation_factor}. Decrease the decimation factor and/or decrease the maximum period')
+    if target_size < sizes[0]:
+        warnings.warn(f'Cannot achieve target size of {target_size} with selected decimation factor of '
+                      f'{decimation_factor}. Increase the decimation factor and/or increase the maximum period')
+    return int(np.interp(target_size, sizes, intervals))
+
+
+def downsample_data(times, i_signal, v_signal, target_times=None, target_size=None, stepwise_sample_times=True,
+                    step_times=None, step_model=None, method='match', decimation_interval=10, decimation_factor=2,
+                    decimation_max_period=None, antialiased=True, filter_kw=None, discard_first_n_points=None,
+                    discard_only=False, op_mode='galv', prestep_samples=20, device=0):
+    """preprocessing.downsample_data (335-470).  method='match': keep the samples closest to `target_times` after every
+    step (all post-step samples when None) and the whole pre-step record; method='decimate': progressive decimation
+    (:func:`get_decimation_index`; `target_size` picks the interval).  Either way after an anti-aliasing filter matched to
+    the local decimation (device kernel).  `discard_first_n_points` then drops that many samples after every step of the
+    down-sampled record (and at its start); `discard_only` skips the down-sampling.
+    Returns (sample_times, sample_i, sample_v, sample_index)."""
+    if method not in ('match', 'decimate'):
+        raise ValueError(f"Invalid downsample method {method}. Options: 'match', 'decimate'")
     times, i_signal, v_signal = (np.asarray(a, dtype=float) for a in (times, i_signal, v_signal))
-    if step_times is None:
-        step_indices = identify_steps(i_signal if op_mode == 'galv' else v_signal, step_model == 'ideal')
-        step_times = times[step_indices]
+    if discard_only:
+        sample_index = np.arange(len(times))
     else:
-        step_indices = get_step_indices_from_step_times(times, step_times)
-    if target_times is not None:
-        target = np.unique(np.concatenate([np.asarray(target_times) + ts for ts in step_times]))
-        sample_index = np.unique(np.array([nearest_index(times, tt) for tt in target]))
-    else:
-        sample_index = np.arange(step_indices[0], len(times), dtype=int)
-    if step_indices[0] > 0 and prestep_samples > 0:
-        sample_index = np.unique(np.concatenate((np.arange(0, step_indices[0], dtype=int), sample_index)))
-    if antialiased:
-        fkw = filter_kw or {}
-        step_index = identify_steps(i_signal if op_mode == 'galv' else v_signal, allow_consecutive=False)
-        i_signal = filter_chrono_signal(times, i_signal, step_index=step_index, decimate_index=sample_index, device=device, **fkw)
-        v_signal = filter_chrono_signal(times, v_signal, step_index=step_index, decimate_index=sample_index, device=device, **fkw)
-    return times[sample_index], i_signal[sample_index], v_signal[sample_index], sample_index
+        if not stepwise_sample_times:       # the whole record as one step starting at t = 0
+            step_times, step_indices = [0], [0]
+        elif step_times is None:
+            if step_model not in ('ideal', 'expdecay'):
+                raise ValueError(f"Invalid step_model {step_model}. Options: ['ideal', 'expdecay']")
+            step_indices = identify_steps(i_signal if op_mode == 'galv' else v_signal, step_model == 'ideal')
+            step_times = times[step_indices]
+        else:
+            step_indices = get_step_indices_from_step_times(times, step_times)
+        if method == 'match':
+            if target_times is not None:
+                target = np.unique(np.concatenate([np.asarray(target_times) + ts for ts in step_times]))
+                sample_index = np.unique(np.array([nearest_index(times, tt) for tt in target]))
+            else:
+                sample_index = np.arange(step_indices[0], len(times), dtype=int)
+            if step_indices[0] > 0 and prestep_samples > 0:
+                sample_index = np.unique(np.concatenate((np.arange(0, step_indices[0], dtype=int), sample_index)))
+        else:
+            t_sample = np.min(np.diff(times))
+            if target_size is not None:
+                decimation_interval = select_decimation_interval(times, step_times, t_sample, prestep_samples,
+                                                                 decimation_factor, decimation_max_period, target_size)
+            sample_index = get_decimation_index(times, step_times, t_sample, prestep_samples, decimation_interval,
+                                                decimation_factor, decimation_max_period)
+        if antialiased and stepwise_sample_times:
+            fkw = filter_kw or {}
+            step_index = identify_steps(i_signal if op_mode == 'galv' else v_signal, allow_consecutive=False)
+            i_signal = filter_chrono_signal(times, i_signal, step_index=step_index, decimate_index=sample_index, device=device, **fkw)
+            v_signal = filter_chrono_signal(times, v_signal, step_index=step_index, decimate_index=sample_index, device=device, **fkw)
+    sample_times, sample_i, sample_v = times[sample_index], i_signal[sample_index], v_signal[sample_index]
+    if discard_first_n_points is not None:
+        starts = np.insert(identify_steps(sample_i if op_mode == 'galv' else sample_v, False), 0, 0)
+        stops = [len(sample_times) if a == starts[-1] else starts[k + 1] for k, a in enumerate(starts)]
+        sel = np.concatenate([np.arange(a + discard_first_n_points, b) for a, b in zip(starts, stops)])
+        sample_times, sample_i, sample_v, sample_index = sample_times[sel], sample_i[sel], sample_v[sel], sample_index[sel]
+    return sample_times, sample_i, sample_v, sample_index

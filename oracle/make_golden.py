@@ -276,7 +276,8 @@ def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
     if fit_kw.get("downsample"):
         out["sample_index"] = drt.sample_index
         out["sample_v"] = drt.raw_response_signal
-        out["downsample_target_times"] = fit_kw["downsample_kw"]["target_times"]
+        if fit_kw["downsample_kw"].get("target_times") is not None:
+            out["downsample_target_times"] = fit_kw["downsample_kw"]["target_times"]
     if times is not None:
         out.update(times=times, i_signal=i_sig, v_signal=v_sig, sample_times=drt.get_fit_times(),
                    step_times=drt.step_times, step_sizes=drt.step_sizes,
@@ -499,6 +500,53 @@ def run_predict(DRT, freq_g, z_g):
     print("refrun_predict.npz:", {k: np.shape(v) for k, v in out.items() if k.endswith("_z")})
 
 
+DECIMATE_CASES = [     # (record, keywords of preprocessing.downsample_data)
+    ("one_step", dict(method='decimate', prestep_samples=10)),
+    ("one_step", dict(method='decimate', prestep_samples=7, decimation_interval=25, decimation_factor=1.5)),
+    ("one_step", dict(method='decimate', prestep_samples=10, decimation_interval=5, decimation_factor=3,
+                      decimation_max_period=0.02)),
+    ("one_step", dict(method='decimate', prestep_samples=10, target_size=400, decimation_factor=1.3)),
+    ("two_step", dict(method='decimate', prestep_samples=12, decimation_interval=8)),
+    ("two_step", dict(method='decimate', prestep_samples=12, target_size=250, decimation_max_period=0.1)),
+    ("two_step", dict(method='decimate', prestep_samples=5, decimation_interval=8, discard_first_n_points=2)),
+    ("two_step", dict(method='match', prestep_samples=5, discard_first_n_points=3, discard_only=True)),
+    ("one_step", dict(method='match', stepwise_sample_times=False, antialiased=True,
+                      target_times=np.concatenate(([0], np.logspace(-3, 0, 40))))),
+]
+
+
+def decimate_records():
+    from hipdrt import synth
+    return dict(one_step=synth.hybrid_measurement(seed=5, n_pre=200, n_post=6000, uniform_dt=2.5e-4, v_noise=2e-5),
+                two_step=synth.hybrid_measurement(seed=6, n_pre=150, n_post=3000, uniform_dt=2.5e-4, v_noise=2e-5,
+                                                  extra_steps=((0.9, -1e-3),)))
+
+
+def run_decimate(DRT, cvxopt):
+    """preprocessing.downsample_data with method='decimate' (335-470, 603-689): kept indices for every keyword set of
+    DECIMATE_CASES (with and without the anti-alias filter, whose filtered voltages are saved too), and one fit_hybrid run
+    that down-samples this way."""
+    from hybdrt import preprocessing as rpp
+    recs = decimate_records()
+    out = {}
+    for k, (rec, kw) in enumerate(DECIMATE_CASES):
+        times, i_sig, v_sig = recs[rec][:3]
+        step_times = times[rpp.identify_steps(i_sig, allow_consecutive=False)]
+        for aa in (False, True):
+            kw2 = dict(kw)
+            kw2.setdefault("antialiased", aa)
+            t_s, i_s, v_s, idx = rpp.downsample_data(times, i_sig, v_sig, step_times=step_times, **kw2)
+            out[f"case{k}_index_aa{int(aa)}"] = idx
+            out[f"case{k}_v_aa{int(aa)}"] = v_s
+            out[f"case{k}_i_aa{int(aa)}"] = i_s
+        print(f"decimate case {k}: {len(times)} -> {len(idx)} samples")
+    np.savez_compressed(os.path.join(OUT, "refrun_decimate.npz"), **out)
+    base = dict(fit_inductance=True, fit_capacitance=False, fit_ohmic=True)
+    run_hybrid_case(DRT, cvxopt, "hybrid_decimate", recs["one_step"], dict(base, fit_dop=False),
+                    dict(downsample=True, downsample_kw=dict(method='decimate', prestep_samples=10, decimation_interval=20,
+                                                             decimation_factor=1.5, decimation_max_period=0.05)))
+
+
 def run_kk(DRT, freq_g, z_g):
     """DRT.kk_test (drt1d.py:1370-1491, models/kk.py): the reference's test spectrum with corrupted ends and two bad points
     inside; flagged points, frequency limits, normalised residuals and the second (down-weighted) fit"""
@@ -529,6 +577,10 @@ def main():
     sys.path.insert(0, REPO)
     if "--only-response" in sys.argv:
         run_response_matrices()
+        return
+    if "--only-decimate" in sys.argv:
+        DRT, cvxopt = _boot_reference()
+        run_decimate(DRT, cvxopt)
         return
     if "--only-kk" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()
@@ -620,6 +672,8 @@ def main():
     run_predict(DRT, freq_g, z_g)
     # (13) Kramers-Kronig test
     run_kk(DRT, freq_g, z_g)
+    # (14) progressive decimation of raw chrono records
+    run_decimate(DRT, cvxopt)
 
 
 if __name__ == "__main__":

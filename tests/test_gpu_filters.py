@@ -46,3 +46,40 @@ def test_fit_hybrid_with_downsampling_matches_reference_run():
     assert drt.qphb_params["num_chrono"] == len(g["sample_index"])
     _check_fit(drt, g, special, False, data_rtol=1e-11)
     np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
+
+
+def test_decimated_records_match_reference_run():
+    """method='decimate' with the anti-alias filter on the device: same kept indices, filtered currents / voltages within
+    1e-13 of the reference's scipy filter"""
+    import os
+    from conftest import GOLDEN
+    from hipdrt import preprocessing as pp
+    from oracle.make_golden import DECIMATE_CASES, decimate_records
+    g = np.load(os.path.join(GOLDEN, "refrun_decimate.npz"))
+    recs = decimate_records()
+    acted = 0
+    for k, (rec, kw) in enumerate(DECIMATE_CASES):
+        times, i_sig, v_sig = recs[rec][:3]
+        st = times[pp.identify_steps(i_sig, allow_consecutive=False)]
+        kw = dict(kw)
+        kw.setdefault("antialiased", True)
+        t_s, i_s, v_s, idx = pp.downsample_data(times, i_sig, v_sig, step_times=st, **kw)
+        np.testing.assert_array_equal(idx, g[f"case{k}_index_aa1"], err_msg=str(kw))
+        np.testing.assert_allclose(v_s, g[f"case{k}_v_aa1"], rtol=0, atol=1e-13 * np.abs(v_sig).max(), err_msg=str(kw))
+        np.testing.assert_allclose(i_s, g[f"case{k}_i_aa1"], rtol=0, atol=1e-13 * np.abs(i_sig).max(), err_msg=str(kw))
+        acted += int(np.abs(v_s - g[f"case{k}_v_aa0"]).max() > 1e-6) if len(v_s) == len(g[f"case{k}_v_aa0"]) else 0
+    assert acted >= 6            # the filter changed the kept samples in the decimated cases
+
+
+def test_fit_hybrid_with_decimation_matches_reference_run():
+    from hipdrt.models import DRT
+    from test_gpu_hybrid import _check_fit
+    g, special = load_case("hybrid_decimate")
+    drt = DRT(warn=False)
+    fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], downsample=True,
+                        downsample_kw=dict(method='decimate', prestep_samples=10, decimation_interval=20,
+                                           decimation_factor=1.5, decimation_max_period=0.05))
+    np.testing.assert_array_equal(drt.sample_index, g["sample_index"])
+    assert drt.qphb_params["num_chrono"] == len(g["sample_index"])
+    _check_fit(drt, g, special, False, data_rtol=1e-11)
+    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)

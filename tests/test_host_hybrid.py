@@ -88,3 +88,26 @@ def test_antialias_filter_oracle_matches_reference_run():
     np.testing.assert_allclose(vf[idx], g["sample_v"], rtol=0, atol=1e-14 * np.abs(g["sample_v"]).max())
     sd = pp.sigma_from_decimate_index(g["v_signal"], idx)
     assert sd.max() > 1 and np.all(sd[np.setdiff1d(np.arange(len(sd)), idx)] == 0)
+
+
+def test_decimation_indices_match_reference_run():
+    """preprocessing.downsample_data, method='decimate' / discard_first_n_points / discard_only / one-step mode, without the
+    (device) anti-alias filter: kept indices and samples bit-identical to the reference's on the same records"""
+    import os
+    from conftest import GOLDEN
+    from hipdrt import preprocessing as pp
+    from oracle.make_golden import DECIMATE_CASES, decimate_records
+    g = np.load(os.path.join(GOLDEN, "refrun_decimate.npz"))
+    recs = decimate_records()
+    for k, (rec, kw) in enumerate(DECIMATE_CASES):
+        if kw.get("antialiased"):
+            continue
+        times, i_sig, v_sig = recs[rec][:3]
+        st = times[pp.identify_steps(i_sig, allow_consecutive=False)]
+        t_s, i_s, v_s, idx = pp.downsample_data(times, i_sig, v_sig, step_times=st, antialiased=False, **kw)
+        np.testing.assert_array_equal(idx, g[f"case{k}_index_aa0"], err_msg=str(kw))
+        np.testing.assert_array_equal(v_s, g[f"case{k}_v_aa0"])
+        np.testing.assert_array_equal(i_s, g[f"case{k}_i_aa0"])
+        np.testing.assert_array_equal(t_s, times[idx])
+    with pytest.raises(ValueError):
+        pp.downsample_data(*recs["one_step"][:3], method='nearest')

@@ -199,7 +199,10 @@ def main():
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
-                         "launches_per_step": launches_step},
+                         "launches_per_step": launches_step,
+                         # the same launch against the other roof: PMC bytes (profiles/qp_traffic.json) / HIP-event time
+                         "traffic_GBps": None if traffic is None else traffic / avg_launch_s / 1e9,
+                         "traffic_frac_of_hbm_peak": None if traffic is None else traffic / avg_launch_s / 8e12},
             "phase_ms_per_step": {k: v / args.steps for k, v in phase.items()},
             "single_stream": None if single_elapsed is None else {
                 "value": world * B * args.steps / single_elapsed, "ms_per_step": single_elapsed / args.steps * 1e3,

@@ -52,16 +52,6 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
     // leading dimension and n are even (always true for the plan's matrices)
     const int sk = tid >> 4, sc = (tid & 15) * 4;
     const bool vec2 = ((lda | n) & 1) == 0;
-    // sqrt(s_k) of the tile's rows / columns once per workgroup (the L2 epilogue needs them per element)
-    __shared__ double sqI[3][GT], sqJ[3][GT];
-    if (g.s) {
-        const double* sb_ = g.s + (size_t)b * 3 * n;
-        for (int e = tid; e < 3 * GT; e += 256) {
-            const int k = e / GT, c = e % GT;
-            sqI[k][c] = (i0 + c < n) ? sqrt(sb_[k * n + i0 + c]) : 0.0;
-            sqJ[k][c] = (j0 + c < n) ? sqrt(sb_[k * n + j0 + c]) : 0.0;
-        }
-    }
     // slab k0+GK is fetched (global -> registers) while slab k0 is multiplied out of LDS; the products with w are
     // formed only when the slab is written to LDS, so nothing waits on the loads inside the MFMA loop
     double vi[4], vj[4], wkr = 0.0;
@@ -124,6 +114,20 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
         }
     }
 
+    // sqrt(s_k) of the tile's rows / columns once per workgroup (the L2 epilogue needs them per element); they take
+    // over the slab buffers, so the kernel needs 20 kB of LDS and eight workgroups fit a CU
+    double (*sqI)[GT] = reinterpret_cast<double (*)[GT]>(sI);
+    double (*sqJ)[GT] = reinterpret_cast<double (*)[GT]>(sJ);
+    if (g.s) {
+        __syncthreads();   // last slab consumed
+        const double* sb_ = g.s + (size_t)b * 3 * n;
+        for (int e = tid; e < 3 * GT; e += 256) {
+            const int k = e / GT, c = e % GT;
+            sqI[k][c] = (i0 + c < n) ? sqrt(sb_[k * n + i0 + c]) : 0.0;
+            sqJ[k][c] = (j0 + c < n) ? sqrt(sb_[k * n + j0 + c]) : 0.0;
+        }
+        __syncthreads();
+    }
     // epilogue: + L2, store lower tile and its mirror.  With the swapped operands the accumulator of lane l, register
     // r is element (row = l&15, column = (l>>4) + 4r) of the sub-tile.
     double* Pb = P ? P + (size_t)b * p_stride : nullptr;   // row-major copy is optional (the resident QP kernel reads Ppk)

@@ -392,6 +392,29 @@ def test_full_size_batch_properties():
                                    atol=1e-10 * np.abs(res["q_vector"][b]).max())
 
 
+def test_full_size_equivariance_properties():
+    """BASELINE configs[2] size: properties that hold bit for bit whatever the size.  (1) Scale equivariance: the fit works
+    on z / coefficient_scale, so multiplying a spectrum by a power of two leaves every scaled quantity (trajectory,
+    weights, iteration counts) unchanged and multiplies the returned distribution by exactly that factor.  (2) The batch
+    is a set: permuting the spectra permutes the results, nothing else (no cross-talk between members, whichever
+    workgroup / dispatch slot a spectrum lands in)."""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    c2 = synth.config_c2()
+    B = 1024
+    z = synth.zarc2_batch(c2["freq"], B)
+    drt = DRT(fixed_basis_tau=c2["tau"])
+    res = drt.fit_eis_batch(c2["freq"], z)
+    factor = np.where(np.arange(B) % 2 == 0, 4.0, 0.125)
+    perm = np.random.default_rng(7).permutation(B)
+    res2 = drt.fit_eis_batch(c2["freq"], (z * factor[:, None])[perm])
+    for key in ("x", "weights", "rho", "outer_iters", "qp_iters_total", "status"):
+        np.testing.assert_array_equal(res2[key], res[key][perm], err_msg=key)
+    np.testing.assert_array_equal(res2["fit_x"], (res["fit_x"] * factor[:, None])[perm])
+    np.testing.assert_array_equal(res2["R_inf"], (res["R_inf"] * factor)[perm])
+    np.testing.assert_array_equal(res2["coefficient_scale"], (res["coefficient_scale"] * factor)[perm])
+
+
 @pytest.mark.gpu
 def test_kk_test_matches_reference_run():
     """DRT.kk_test (drt1d.py:1370-1491): two kk_fit passes (the second with the flagged points down-weighted through a

@@ -85,6 +85,17 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the single-spectrum and config-5 timings")
     args = ap.parse_args()
 
+    lib = os.path.join(ROOT, "hybrid-drt_amd", "libhipdrt.so")
+    if not os.path.exists(lib) and "HIPDRT_LIB" not in os.environ:      # fresh checkout: build the (git-ignored) library once
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            for _ in range(1200):
+                if os.path.exists(lib):
+                    break
+                time.sleep(0.5)
+            time.sleep(2.0)
     import torch
     from hipdrt import synth
     from hipdrt.mapping import dist as hd

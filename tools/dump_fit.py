@@ -1,0 +1,33 @@
+"""Fits a fixed set of spectra (C1 golden-size and C2-size) with whatever library HIPDRT_LIB points to and saves the raw
+results; two dumps compared bit for bit tell whether two builds compute the same thing.
+python tools/dump_fit.py out.npz   /   python tools/dump_fit.py --cmp a.npz b.npz"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+if sys.argv[1] == "--cmp":
+    a, b = np.load(sys.argv[2]), np.load(sys.argv[3])
+    bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
+    print("identical" if not bad else f"DIFFERENT: {bad}")
+    sys.exit(1 if bad else 0)
+from hipdrt import synth
+from hipdrt.models import DRT
+out = {}
+c2 = synth.config_c2()
+z = synth.zarc2_batch(c2["freq"], 96)
+d = DRT(fixed_basis_tau=c2["tau"])
+r = d.fit_eis_batch(c2["freq"], z)
+for k in ("x", "weights", "rho", "outer_iters", "qp_iters_total"):
+    out["c2_" + k] = r[k]
+out["c2_var"] = d.estimate_distribution_var_batch(c2["tau"][::4])
+c1 = synth.config_c1()
+z1 = synth.zarc2_batch(c1["freq"], 16)
+r1 = DRT(fixed_basis_tau=c1["tau"]).fit_eis_batch(c1["freq"], z1)
+for k in ("x", "weights", "outer_iters", "qp_iters_total"):
+    out["c1_" + k] = r1[k]
+f = np.logspace(5.5, -0.5, 60)
+r3 = DRT(basis_tau_ppd=8).fit_eis_batch(f, synth.zarc2_batch(f, 8))      # n = 61: odd number of block columns etc.
+for k in ("x", "outer_iters", "qp_iters_total"):
+    out["d_" + k] = r3[k]
+np.savez(sys.argv[1], **out)
+print("saved", sys.argv[1], {k: v.shape for k, v in out.items() if k.endswith("_x")})

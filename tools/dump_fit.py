@@ -19,7 +19,8 @@ d = DRT(fixed_basis_tau=c2["tau"])
 r = d.fit_eis_batch(c2["freq"], z)
 for k in ("x", "weights", "rho", "outer_iters", "qp_iters_total"):
     out["c2_" + k] = r[k]
-out["c2_var"] = d.estimate_distribution_var_batch(c2["tau"][::4])
+v = d.estimate_distribution_var_batch(c2["tau"][::4])
+out["c2_var"] = np.asarray(v[0] if isinstance(v, tuple) else v)
 c1 = synth.config_c1()
 z1 = synth.zarc2_batch(c1["freq"], 16)
 r1 = DRT(fixed_basis_tau=c1["tau"]).fit_eis_batch(c1["freq"], z1)

@@ -172,6 +172,26 @@ def test_fit_hybrid_batch_members_match_single_fits():
         assert res["outer_iters"][b] == single.qphb_params["outer_iterations"]
 
 
+def test_joint_fits_are_scale_and_order_equivariant():
+    """size-independent properties of the joint chrono + EIS path: multiplying a cell's voltages and impedances by a power
+    of two multiplies its resistances by exactly that factor and leaves the scaled trajectory untouched; the order of the
+    measurements in a batch is irrelevant (bit for bit)"""
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    meas = [synth.hybrid_measurement(seed=s, jitter=True) for s in range(6)]
+    times, freq = meas[0][0], meas[0][3]
+    drt = DRT(fit_dop=True, warn=False)
+    res = drt.fit_hybrid_batch(times, [m_[1] for m_ in meas], [m_[2] for m_ in meas], freq, [m_[4] for m_ in meas])
+    factor = np.array([4.0, 0.25, 2.0, 1.0, 0.5, 8.0])
+    perm = np.array([3, 0, 5, 1, 4, 2])
+    res2 = drt.fit_hybrid_batch(times, [meas[b][1] for b in perm], [meas[b][2] * factor[b] for b in perm], freq,
+                                [meas[b][4] * factor[b] for b in perm])
+    np.testing.assert_array_equal(res2["outer_iters"], res["outer_iters"][perm])
+    np.testing.assert_array_equal(res2["x"], (res["x"] * factor[:, None])[perm])
+    np.testing.assert_array_equal(res2["R_inf"], (res["R_inf"] * factor)[perm])
+    np.testing.assert_array_equal(res2["x_dop"], (res["x_dop"] * factor[:, None])[perm])
+
+
 def test_config5_full_size_joint_fit_with_dop():
     """BASELINE config 5: 512 frequencies + 4096 time samples x 1024 tau with the distribution of phasances
     (m = 5120 rows, n = 1078 unknowns), one measurement, matrices built by the device kernels.

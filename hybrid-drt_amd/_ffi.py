@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HIPDRT_LIB", os.path.join(_HERE, "libhipdrt.so"))
 
 MODE_INTERP, MODE_TRAPZ = 0, 1
-QP_OPTIMAL, QP_MAXITER, QP_SINGULAR_LATE, QP_SINGULAR = 0, 1, 2, -1
+QP_OPTIMAL, QP_MAXITER, QP_SINGULAR_LATE, QP_SINGULAR, QP_ABORTED = 0, 1, 2, -1, -2
 
 
 class HipDrtError(RuntimeError):

@@ -81,6 +81,8 @@ static int upload(DevBuf& buf, const void* src, size_t bytes, hipStream_t st) {
 
 extern "C" {
 
+static int plan_hist_reserve(hipdrt_plan* p, int rows);
+
 const char* hipdrt_last_error(void) { return g_err.c_str(); }
 
 int hipdrt_create(int device, hipdrt_ctx** out) {
@@ -725,7 +727,7 @@ int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const d
     p->wrow_batched = (batched & 1) ? 1 : 0;
     p->wrow_late = (batched & 2) ? 1 : 0;
     if (row_factors) {
-        const size_t cnt = (batched ? (size_t)p->capacity : 1) * p->m;
+        const size_t cnt = ((batched & 1) ? (size_t)p->capacity : 1) * p->m;   // bit 1 (late) does not make it per spectrum
         TRY(upload(p->wrow, row_factors, cnt * sizeof(double), st));
     } else {
         p->wrow.release();
@@ -1056,9 +1058,13 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     HIPDRT_REQUIRE(p && opts, "NULL pointer");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
     HIPDRT_REQUIRE(opts->max_iter >= 1 && min_iter >= 1, "max_iter, min_iter >= 1");
+    // rejected calls must leave the finished fit as it is: every check comes before the first write
+    HIPDRT_REQUIRE(!p->prepared, "warm restarts are not available on prepared plans");
+    HIPDRT_REQUIRE(!p->has_weight_factors(), "warm restarts take their weight_factor argument; clear the plan's weight factors");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
     const int B = p->B, n = p->n, m = p->m;
+    TRY(plan_hist_reserve(p, opts->max_iter));
     FitState fs = p->state();
     fs.opts = *opts; fs.continue_mode = 1; fs.min_iter = min_iter;
     PhaseTimer tm(st);
@@ -1070,8 +1076,6 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
         HIPDRT_CHECK(hipMemsetAsync(p->qp_iters_total.p, 0, (size_t)B * sizeof(int), st));
         HIPDRT_CHECK(hipStreamSynchronize(st));
     }
-    HIPDRT_REQUIRE(!p->prepared, "warm restarts are not available on prepared plans");
-    HIPDRT_REQUIRE(!p->has_weight_factors(), "warm restarts take their weight_factor argument; clear the plan's weight factors");
     GramL2 g = plan_l2(p, opts->l2_lambda_0, opts->derivative_weights, 0.0);
     QpArgs qa{};
     qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
@@ -1228,12 +1232,11 @@ int hipdrt_plan_param_var(hipdrt_plan* p, double* out, int* status) {
     return plan_quadratic_forms(p, eye.data(), n, n, 0, out, status);
 }
 
-int hipdrt_plan_record_history(hipdrt_plan* p, int b) {
-    HIPDRT_REQUIRE(p, "plan is NULL");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
-    p->hist_b = b;
-    if (b >= 0 && p->hist_cap == 0) {
-        p->hist_cap = p->opts.max_iter;
+// history buffers for `rows` outer iterations (grown when a later call asks for more than the first one did)
+static int plan_hist_reserve(hipdrt_plan* p, int rows) {
+    if (rows < 1) rows = 1;
+    if (p->hist_b >= 0 && p->hist_cap < rows) {
+        p->hist_cap = rows;
         HIPDRT_CHECK(p->hist_x.alloc((size_t)p->hist_cap * p->n * sizeof(double)));
         HIPDRT_CHECK(p->hist_w.alloc((size_t)p->hist_cap * p->m * sizeof(double)));
         HIPDRT_CHECK(p->hist_rho.alloc((size_t)p->hist_cap * 3 * sizeof(double)));
@@ -1241,6 +1244,13 @@ int hipdrt_plan_record_history(hipdrt_plan* p, int b) {
         HIPDRT_CHECK(p->hist_dop_rho.alloc((size_t)p->hist_cap * 3 * sizeof(double)));
     }
     return HIPDRT_OK;
+}
+
+int hipdrt_plan_record_history(hipdrt_plan* p, int b) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    p->hist_b = b;
+    return plan_hist_reserve(p, p->opts.max_iter);
 }
 
 int hipdrt_plan_get_history(hipdrt_plan* p, double* hist_x, double* hist_rho, double* hist_w, int* qp_iters,

@@ -213,7 +213,7 @@ struct QpArgs {
     const int* active;    // [B] or null: skip problems with active[b]==0
     const int* order = nullptr;   // [B] or null: workgroup i solves problem order[i] (longest-first dispatch)
     int* iters_accum;     // [B] or null: += iterations
-    double* state;        // scratch [B][16][state_ld] for the IPM iterates
+    double* state;        // scratch [B][17][state_ld] for the IPM iterates
     int state_ld;
     long long state_stride;
     hipdrt_qp_opts opts;
@@ -238,7 +238,7 @@ void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active
 size_t qp_scratch_ld(int n);
 size_t qp_scratch_doubles(int n);
 inline int qp_state_ld(int n) { return round_up(n, 32) + 32; }
-inline size_t qp_state_doubles(int n) { return (size_t)16 * qp_state_ld(n); }
+inline size_t qp_state_doubles(int n) { return (size_t)17 * qp_state_ld(n); }
 int qp_profile_read(unsigned long long* out, int n, int reset);
 
 }  // namespace hipdrt

@@ -25,6 +25,7 @@
 
 #include "qp_common.hpp"
 #include "qp_resident.hpp"
+#include "qp_super.hpp"
 
 namespace hipdrt {
 
@@ -216,6 +217,12 @@ __device__ __forceinline__ bool chol_factor(const double* __restrict__ P, int ld
 // Barrier among the G workgroups of a problem: monotonic counter in global memory; the fences make the stores to L
 // visible across CUs and XCDs (release: L2 write-back, acquire: L1 / non-local L2 invalidate).
 // ---------------------------------------------------------------------------------------------------------
+// The wait is bounded: group mode needs all G workgroups of a problem resident at the same time, which launch_qp
+// arranges on a device it has to itself (B*G <= CUs, one workgroup per CU, group launches chained per device); if
+// something else keeps a partner off the device for GROUP_WAIT_TICKS the waiting workgroup poisons the counter (every
+// later wait of the group then falls through at once) and the problem ends with status HIPDRT_QP_ABORTED.
+static constexpr int GROUP_POISON = 1 << 30;
+static constexpr unsigned long long GROUP_WAIT_TICKS = 400000000ull;     // 4 s of the 100 MHz s_memrealtime clock
 __device__ __forceinline__ void group_barrier(int* ctr, int G, int& epoch) {
     __syncthreads();                       // all stores of this workgroup issued and acknowledged (vmcnt(0))
     if (threadIdx.x == 0) {
@@ -223,7 +230,11 @@ __device__ __forceinline__ void group_barrier(int* ctr, int G, int& epoch) {
         __threadfence();
         atomicAdd(ctr, 1);
         const int target = G * epoch;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > GROUP_WAIT_TICKS) { atomicOr(ctr, GROUP_POISON); break; }
+        }
         __threadfence();
     }
     __syncthreads();
@@ -499,6 +510,9 @@ struct OpsGroup {
     int G, g; int* ctr; int epoch; double* gvec;
     static constexpr bool kFusedForward = false;
     __device__ __forceinline__ bool factor() {
+        // every partner must be through with the previous factor (its triangular sweeps read all of L) before anybody
+        // overwrites L: the iterations no longer meet in a P x product (qp_common.hpp: P x recurrence)
+        group_barrier(ctr, G, epoch);
         return chol_factor_group<THREADS, MAXT>(P, ldp, L, ldl, n, PR, sm, G, g, ctr, epoch);
     }
     __device__ __forceinline__ void solve() { chol_solve<THREADS>(L, ldl, n, sm); }
@@ -538,6 +552,9 @@ __global__ __launch_bounds__(THREADS) void qp_kernel_group(QpArgs a, int PR, int
     QpArgs ag = a;
     ag.state = a.gstate;
     ipm_solve<THREADS, EPT>(ag, b, ops, is, (int)blockIdx.x, g == 0);
+    if (g == 0 && threadIdx.x == 0 &&
+        (__hip_atomic_load(ops.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & GROUP_POISON))
+        a.status[b] = HIPDRT_QP_ABORTED;
 }
 
 template <int THREADS, int MAXT, int EPT>
@@ -565,7 +582,7 @@ size_t qp_scratch_ld(int n) { return (size_t)round_up(n, 16); }
 // doubles of factor scratch per problem (covers both the row-major multipass and the tile-packed resident layout)
 size_t qp_scratch_doubles(int n) {
     size_t d = (size_t)n * qp_scratch_ld(n);
-    if (n <= RNP_MAX) { const size_t r = resident_l_doubles(n); if (r > d) d = r; }
+    if (n <= RNP_MAX) { const size_t r = resident_l_doubles(n); if (r > d) d = r; const size_t s_ = super_l_doubles(n); if (s_ > d) d = s_; }
     return d;
 }
 
@@ -617,14 +634,17 @@ static int launch_qp_group_ept(hipStream_t st, const QpArgs& a, int PR, size_t l
     return HIPDRT_OK;
 }
 
+// CUs of the CURRENT device (cached per device ordinal; a group launch needs one CU per workgroup: 512 threads at
+// ~170 VGPRs and 80 kB of LDS leave no room for a second one)
 static int device_cus() {
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return cus;
+    static std::mutex mtx;
+    static int cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mtx);
+    int& v = cache[dev & 63];
+    if (v <= 0 && (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)) v = 256;
+    return v;
 }
 
 // Workgroups per problem for the multi-pass kernel: up to 16 when the launch would otherwise leave most CUs idle and the
@@ -677,6 +697,25 @@ void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active
     hipLaunchKernelGGL(lpt_order_kernel, dim3(blocks), dim3(256), (size_t)B * sizeof(int), st, B, iters, active, order);
 }
 
+// which kernel serves n <= 528: the super-column kernel (default) or the 32-column one (HIPDRT_QP_KERNEL=resident)
+static bool use_super() {
+    static const bool v = [] { const char* e = getenv("HIPDRT_QP_KERNEL"); return !(e && std::string(e) == "resident"); }();
+    return v;
+}
+
+static int launch_qp_super(hipStream_t st, const QpArgs& a) {
+    const int NP64 = round_up(a.n, 64);
+    if (!a.Ppk) { set_error("qp super: packed copy of P missing"); return HIPDRT_E_INVALID; }
+    const size_t lds = super_lds_bytes(a.n);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_super),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(qp super): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    hipLaunchKernelGGL(qp_kernel_super, dim3(a.B), dim3(ST), lds, st, a, NP64);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("qp launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    return HIPDRT_OK;
+}
+
 static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
     const int NP = round_up(a.n, 32);
     if (!a.Ppk) { set_error("qp resident: packed copy of P missing"); return HIPDRT_E_INVALID; }
@@ -693,6 +732,19 @@ static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
 int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long ppk_stride, const double* Bex, int nex,
                     double* L, long long l_stride, double* out, long long out_stride, int* status) {
     if (n > RNP_MAX) { set_error("posterior variance: only built for n <= 528 unknowns"); return HIPDRT_E_INVALID; }
+    if (use_super()) {
+        const size_t lds = super_lds_bytes(n);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_kernel_super),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(cov): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+        CovArgs a;
+        a.B = B; a.n = n; a.Ppk = Ppk; a.ppk_stride = ppk_stride; a.nchp = qp_nchp(n); a.Bex = Bex; a.nex = nex;
+        a.L = L; a.l_stride = l_stride; a.out = out; a.out_stride = out_stride; a.status = status;
+        hipLaunchKernelGGL(cov_kernel_super, dim3(B), dim3(ST), lds, st, a, round_up(n, 64));
+        e = hipGetLastError();
+        if (e != hipSuccess) { set_error(std::string("cov launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+        return HIPDRT_OK;
+    }
     const int NP = round_up(n, 32);
     const size_t lds = resident_lds_bytes(NP);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_kernel_resident),
@@ -709,7 +761,7 @@ int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long p
 
 // doubles of factor scratch per spectrum for the posterior-variance kernel: (nch + nex) x nch tiles
 size_t dist_var_scratch_doubles(int n, int nex) {
-    const size_t nch = (size_t)round_up(n, 32) / 16;
+    const size_t nch = (size_t)round_up(n, 64) / 16;      // the super-column layout (the wider of the two)
     return (nch + (size_t)nex) * nch * TSZ;
 }
 
@@ -717,7 +769,7 @@ bool qp_packed_only(int n) { return n <= RNP_MAX && !getenv("HIPDRT_QP_MULTIPASS
 
 int launch_qp(hipStream_t st, const QpArgs& a) {
     const int n = a.n;
-    if (qp_packed_only(n)) return launch_qp_resident(st, a);
+    if (qp_packed_only(n)) return use_super() ? launch_qp_super(st, a) : launch_qp_resident(st, a);
     constexpr int NW = QP_THREADS / 64;
     // panel rows: as many as keep two workgroups per CU (<= 80 kB each), at most NW*MAXT*16
     const size_t fixed = ((size_t)NB * PLD + 2 * (size_t)n + 4 * NW * 4) * sizeof(double) + 64;

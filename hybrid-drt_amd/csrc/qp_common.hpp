@@ -160,6 +160,21 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     const double* qg = a.q + (size_t)b * n;
     const double* hg = a.h + (size_t)b * a.h_stride;
     Reducer<NW> red(sm.red);
+    // P x is normally not formed by a pass over P: every step direction solves (P + D) dx = r to the backward error of
+    // the Cholesky solve, so P dx = r - D dx and P x follows the iterate by an O(n) recurrence (start point:
+    // (P + I) x0 = -q - h).  The recurrence carries rounding errors of size eps |P| |step dx| along, a direct product
+    // only eps |P| |x|: `drift` sums max|step dx| since the last direct product, and once it exceeds kDriftTol max|x|
+    // (iterates that come down from a far-away start point: h = 1e5 when nonneg is off) the next residual is taken
+    // from a direct product again.  The rule depends on reduced values only, so it is the same in every thread and for
+    // every batch size.  -DHIPDRT_QP_MATVEC builds the direct product in every iteration (diagnostic).
+#ifdef HIPDRT_QP_MATVEC
+    constexpr bool kRecurPx = false;
+#else
+    constexpr bool kRecurPx = true;
+#endif
+    constexpr double kDriftTol = 8.0;
+    double drift = 0.0;
+    bool refresh = false;
 
     // The O(n) iterates live in a per-problem global scratch (L1/L2 resident, 16 vectors), element i touched
     // only by its owner thread, so no synchronisation is needed for them; keeping them out of registers leaves
@@ -171,6 +186,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     double* const di = SV(4); double* const lm = SV(5); double* const qv = SV(6); double* const hv = SV(7);
     double* const rx = SV(8); double* const rz = SV(9); double* const dx = SV(10); double* const ds = SV(11);
     double* const dz = SV(12); double* const ws3 = SV(13); double* const zz = SV(14); double* const sv = SV(15);
+    double* const px = SV(16);      // P x, carried along by the recurrence below
 #define FOR_E for (unsigned e_ = 0, i = opaque_u32(tid); e_ < (unsigned)EPT; ++e_, i += THREADS)
 #define VALID (i < (unsigned)n)
 #pragma unroll
@@ -193,19 +209,26 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     for (;;) {
         if (!start) {
             // ---- residuals, costs, stopping test ----------------------------------------------------------
-            __syncthreads();
+            if (!kRecurPx || refresh) {
+                __syncthreads();
 #pragma unroll
-            FOR_E if (VALID) sm.vec[i] = x[i];
-            __syncthreads();
-            { PROF_DECL
-            ops.matvec();
-            __syncthreads();
-            PROF(9); }
+                FOR_E if (VALID) sm.vec[i] = x[i];
+                __syncthreads();
+                { PROF_DECL
+                ops.matvec();
+                __syncthreads();
+                PROF(9); }
+                if (kRecurPx) {
+#pragma unroll
+                    FOR_E if (VALID) px[i] = sm.dvec[i];
+                    refresh = false;
+                }
+            }
             double t4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             FOR_E {
                 if (VALID) {
-                    double r = sm.dvec[i] + qv[i];          // P x + q
+                    double r = (kRecurPx ? px[i] : sm.dvec[i]) + qv[i];          // P x + q
                     t4[0] += x[i] * r;                      // x'(Px+q)
                     t4[1] += x[i] * qv[i];                  // x'q
                     r -= z[i];                              // + G'z
@@ -286,6 +309,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 FOR_E {
                     if (VALID) {
                         x[i] = sm.vec[i];
+                        if (kRecurPx) px[i] = (-qv[i] - hv[i]) - x[i];     // (P + I) x = -q - h
                         z[i] = -x[i] - hv[i];
                         s[i] = -z[i];
                         st[0] += s[i] * s[i]; st[1] += z[i] * z[i];
@@ -294,6 +318,13 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 }
                 red.sum(st);
                 red.max(mx);
+                if (kRecurPx) {
+                    double mm[1] = {0.0};
+#pragma unroll
+                    FOR_E if (VALID) mm[0] = fmax(mm[0], fabs(x[i]));
+                    red.max(mm);
+                    drift = mm[0];
+                }
                 const double nrms = sqrt(st[0]), nrmz = sqrt(st[1]);
                 if (mx[0] >= -1e-8 * fmax(nrms, 1.0)) {
 #pragma unroll
@@ -338,11 +369,16 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
         }
         if (start) { start = false; continue; }
         // ---- update ---------------------------------------------------------------------------------------
-        double g2[1] = {0.0};
+        double g2[1] = {0.0}, mm[2] = {0.0, 0.0};
 #pragma unroll
         FOR_E {
             if (VALID) {
+                if (kRecurPx) {
+                    px[i] += step * ((-rx[i] - di[i] * zz[i]) - (di[i] * di[i]) * dx[i]);
+                    mm[0] = fmax(mm[0], fabs(step * dx[i]));
+                }
                 x[i] += step * dx[i];
+                mm[1] = fmax(mm[1], fabs(x[i]));
                 const double dss = (1.0 + step * ds[i]) * lm[i];
                 const double dzz = (1.0 + step * dz[i]) * lm[i];
                 const double sqs = sqrt(dss), sqz = sqrt(dzz);
@@ -356,6 +392,11 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
         }
         red.sum(g2);
         gap = g2[0];
+        if (kRecurPx) {
+            red.max(mm);
+            drift += mm[0];
+            if (drift > kDriftTol * mm[1]) { refresh = true; drift = mm[1]; }
+        }
         ++iters;
     }
 

@@ -201,55 +201,6 @@ class DRT(PreparedFitMixin):
         self.fit_type = 'qphb_eis'
         return fp
 
-    # ---- Kramers-Kronig test (drt1d.py:1370-1491) -----------------------------------------------------------------------
-    def kk_fit(self, frequencies, z, nonneg=False, l2_lambda_0=1e-2, extend_basis_decades=2, outlier_index=None):
-        """DRT.kk_fit (1393-1411): weakly regularised, sign-unconstrained fit on a basis grid extended by two decades;
-        flagged points stay in the data with a weight factor of 1e-10."""
-        keep = self.extend_basis_decades
-        self.extend_basis_decades = extend_basis_decades
-        try:
-            if outlier_index is not None:
-                wf = np.ones(2 * len(frequencies))
-                wf[outlier_index] = 1e-10
-                wf[np.asarray(outlier_index) + len(frequencies)] = 1e-10
-            else:
-                wf = 1
-            self.fit_eis(frequencies, z, nonneg=nonneg, l2_lambda_0=l2_lambda_0, weight_factor=wf)
-        finally:
-            self.extend_basis_decades = keep
-        self.z_fit = np.asarray(z, dtype=complex)
-
-    def eval_kk_residuals(self, norm="modulus"):
-        from . import kk
-        return kk.normalize_residuals(self.z_fit, self.predict_z(self.f_fit), norm=norm)
-
-    def get_kk_outliers(self, norm="modulus", n_iter=2, p_thresh=1e-4, n_sigma=None, std_sample_fraction=0.6):
-        from . import kk
-        return kk.get_outliers(self.eval_kk_residuals(norm=norm), n_iter, p_thresh, n_sigma=n_sigma,
-                               std_sample_fraction=std_sample_fraction)
-
-    def get_kk_limits(self, outlier_index, max_num_outliers=2):
-        from . import kk
-        return kk.get_limits(self.f_fit, outlier_index, max_num_outliers=max_num_outliers)
-
-    def kk_test(self, frequencies, z, nonneg=False, l2_lambda_0=1e-2, extend_basis_decades=2, norm="modulus",
-                max_num_outliers=2, p_thresh=1e-4, n_sigma=None, std_sample_fraction=0.6, n_iter=2, n_outlier_iter=2,
-                show_plot=False):
-        """DRT.kk_test (1370-1390) without the plot: returns (outlier_index, (f_min, f_max), (f_clean, z_clean))."""
-        from . import kk
-        frequencies, z = np.asarray(frequencies, dtype=float), np.asarray(z, dtype=complex)
-        outlier_index = None
-        for _ in range(n_iter):
-            self.kk_fit(frequencies, z, nonneg=nonneg, l2_lambda_0=l2_lambda_0, extend_basis_decades=extend_basis_decades,
-                        outlier_index=outlier_index)
-            outlier_index = self.get_kk_outliers(norm=norm, p_thresh=p_thresh, n_iter=n_outlier_iter, n_sigma=n_sigma,
-                                                 std_sample_fraction=std_sample_fraction)
-            f_min, f_max = self.get_kk_limits(outlier_index, max_num_outliers=max_num_outliers)
-            fz_clean = kk.trim_data(frequencies, z, f_min, f_max)
-        if show_plot:
-            raise NotImplementedError("plotting is outside this package")
-        return outlier_index, (f_min, f_max), fz_clean
-
     def fit_eis_batch(self, frequencies, z_batch, **kw):
         """B spectra on one frequency grid, fitted concurrently (the reference's DRTMD loop calls
         _qphb_fit_core once per observation, mapping/drtmd.py:245-319).  Returns a dict of arrays."""
@@ -273,7 +224,7 @@ class DRT(PreparedFitMixin):
         self.f_fit = frequencies
         plan.record_history(history_of)
         wf = fkw['weight_factor']
-        if np.ndim(wf) > 0:       # vector-valued weight_factor (kk_fit): one factor per data row
+        if np.ndim(wf) > 0:       # vector-valued weight_factor (drt1d.py:889-901): one factor per data row
             plan.set_weight_factors(1.0, np.asarray(wf, dtype=float), late=True)
         else:
             plan.set_weight_factors(wf)
@@ -438,227 +389,7 @@ class DRT(PreparedFitMixin):
         log_min, log_max = np.log10(np.min(basis_tau)) - 1, np.log10(np.max(basis_tau)) + 1
         return np.logspace(log_min, log_max, int((log_max - log_min) * ppd) + 1)
 
-    # ---- evaluation of a fitted model (drt1d.py:2965-3062, 3273-3362, 3500-3542, 3552-3571) ----------------------------------
     series_neg = False
-
-    def _fitted_parameters(self, x):
-        if x is None:
-            return self.fit_parameters
-        if isinstance(x, dict):
-            return x
-        raise NotImplementedError("pass a fit_parameters dict (raw coefficient vectors are re-scaled inside the fit)")
-
-    def get_drt_params(self, x=None, sign=1):
-        """drt1d.get_drt_params (2965-2988): the DRT coefficients; with series_neg the requested sign's share."""
-        x = self._fitted_parameters(x)['x']
-        if self.series_neg:
-            nt = len(self.basis_tau)
-            if sign == 1:
-                return x[:nt]
-            if sign == -1:
-                return -x[nt:]
-            if sign == 0:
-                return x[:nt] - x[nt:]
-            raise ValueError(f'Invalid sign {sign}. Options: -1, 0, 1')
-        return x
-
-    def predict_r_p(self, sign=None, absolute=False, x=None):
-        """drt1d.predict_r_p (3552-3571): polarisation resistance = area of one basis function x sum of coefficients."""
-        if sign is None:
-            sign = 0 if self.series_neg else 1
-        xd = self.get_drt_params(x, sign)
-        return (np.sum(np.abs(xd)) if absolute else np.sum(xd)) * (np.sqrt(np.pi) / self.tau_epsilon)
-
-    def predict_drt(self, tau=None, ppd=20, x=None, order=0, sign=1, normalize=False, normalize_by=None, abs_norm=False):
-        """drt1d.predict_drt (3043-3062), order 0: gamma(tau) = basis matrix @ coefficients."""
-        from ..matrices import basis
-        if tau is None:
-            tau = self.get_tau_eval(ppd)
-        bm = basis.construct_func_eval_matrix(np.log(self.basis_tau), np.log(tau), self.tau_basis_type,
-                                              epsilon=self.tau_epsilon, order=order)
-        xd = self.get_drt_params(x, sign)
-        if normalize_by is not None:
-            normalize = True
-        norm = 1 if not normalize else (normalize_by if normalize_by is not None
-                                        else self.predict_r_p(x=x, absolute=abs_norm))
-        return bm @ xd / norm
-
-    predict_distribution = predict_drt          # deprecated upstream name (drt1d.py:3033-3041)
-
-    def predict_drt_ci(self, tau=None, ppd=20, x=None, order=0, sign=1, normalize=False, normalize_by=None,
-                       quantiles=(0.025, 0.975)):
-        """drt1d.predict_drt_ci (3208-3231): credible band of gamma(tau) from the posterior variance (device kernel) around
-        predict_drt; (None, None) when the precision matrix is not positive definite."""
-        from scipy.special import erf
-        if order != 0 or normalize or normalize_by is not None:
-            raise NotImplementedError("only the order-0, un-normalised band is built")
-        if tau is None:
-            tau = self.get_tau_eval(ppd)
-        var, ok = self.estimate_distribution_var_batch(tau=tau)
-        if not ok[0]:
-            return None, None
-        mu = self.predict_drt(tau=tau, x=x, sign=sign)
-        # utils.stats.std_normal_quantile (stats.py:108-116): the reference inverts a 2000-point table of the normal CDF
-        s_grid = np.linspace(0, 14, 2000)
-        cdf = 0.5 * (1 + erf(s_grid / np.sqrt(2)))
-        q = np.asarray(quantiles, dtype=float)
-        s_lo, s_hi = np.interp(np.abs(q - 0.5) + 0.5, cdf, s_grid) * np.sign(q - 0.5)
-        sigma = np.sqrt(var[0])
-        return mu + s_lo * sigma, mu + s_hi * sigma
-
-    def predict_z(self, frequencies, include_vz_offset=True, x=None, include_dop=True, include_drt=True,
-                  include_inductance=True, include_ohmic=True, include_cap=True):
-        """drt1d.predict_z (3500-3542): model impedance at arbitrary frequencies; the Z' / Z'' (and phasance) matrices of the
-        prediction grid are built on the device."""
-        from ..matrices import phasance
-        frequencies = np.asarray(frequencies, dtype=float)
-        fp = self._fitted_parameters(x)
-        ctx = self._context if self._context is not None else _ffi.get_context(self.device)
-        z = np.zeros(len(frequencies), dtype=complex)
-        if include_drt:
-            mode = _ffi.MODE_INTERP if self.integrate_method == 'interp' else _ffi.MODE_TRAPZ
-            lookups = None
-            if mode == _ffi.MODE_INTERP:
-                lookups = self._lookups(ctx)['z']
-            tpl = mat1d.impedance_matrix_is_toeplitz(frequencies, self.basis_tau, self.frequency_precision)
-            a_re, a_im = ctx.impedance_matrix(frequencies, self.basis_tau, self.tau_epsilon, mode=mode, toeplitz=tpl,
-                                              lookups=lookups)
-            xd = fp['x']
-            if self.series_neg:
-                nt = len(self.basis_tau)
-                xd = xd[:nt] - xd[nt:]
-            z += (a_re + 1j * a_im) @ xd
-        if include_ohmic:
-            z += fp.get('R_inf', 0)
-        if include_inductance:
-            z += fp.get('inductance', 0) * 2j * np.pi * frequencies
-        if include_cap:
-            z += fp.get('C_inv', 0) * (2j * np.pi * frequencies) ** -1
-        if fp.get('x_dop') is not None and include_dop:
-            z += phasance.construct_phasor_z_matrix(frequencies, self.basis_nu, 'gaussian', self.nu_epsilon,
-                                                    device=self.device) @ fp['x_dop']
-        if include_vz_offset and fp.get('vz_offset', 0) != 0:
-            # drt1d.py:3537-3540: EIS predictions of a hybrid fit carry the fitted offset, faded outside the overlap
-            z *= (1 - fp['vz_offset'] * self._eis_vz_strength(frequencies, fp.get('vz_offset_eps', 1)))
-        return z
-
-    def predict_dop(self, nu=None, x=None, normalize=False, normalize_tau=None, order=0, return_nu=False,
-                    normalize_quantiles=(0, 1), include_ideal=True):
-        """drt1d.predict_dop (3273-3345) for the gaussian nu basis: distribution of phasances on a nu grid, optionally
-        normalised by the phasor scale of the data's tau range, with the ideal elements (R_inf at nu = 0, inductance at
-        nu = 1, C_inv at nu = -1) added as upstream does."""
-        from ..matrices import basis, phasance
-        if order != 0:
-            raise NotImplementedError("only order 0 is built")
-        if nu is None:
-            nu = np.unique(np.concatenate([self.basis_nu, np.linspace(-1, 1, 1001)]))
-            nu = np.unique(np.concatenate([nu, np.array([-1, 0, 1])]))
-        else:
-            nu = np.sort(nu)
-        fp = self._fitted_parameters(x)
-        dop = basis.construct_func_eval_matrix(self.basis_nu, nu, 'gaussian', epsilon=self.nu_epsilon, order=0) @ fp['x_dop']
-        area = np.sqrt(np.pi) / self.nu_epsilon
-        if normalize:
-            if normalize_tau is None:
-                pr = self._prep
-                normalize_tau = np.array(pp.get_tau_lim(pr['frequencies'], pr.get('sample_times'), pr.get('step_times')))
-            norm = phasance.phasor_scale_vector(nu, normalize_tau, normalize_quantiles) / area
-        else:
-            norm = 1
-        dop = dop / norm
-        if include_ideal:
-            for value, key in ((0, 'R_inf'), (1, 'inductance'), (-1, 'C_inv')):
-                idx = np.where(nu == value)
-                ideal = self.fit_parameters[key]
-                if normalize:
-                    ideal = ideal / (norm[idx] * area)
-                dop[idx] += ideal
-        return (nu, dop) if return_nu else dop
-
-    def predict_v_baseline(self, times, x_vb=None):
-        """drt1d.predict_v_baseline (3471-3478): polynomial (+ sqrt) baseline in data units."""
-        from . import background
-        fp = self.fit_parameters
-        if 'v_baseline' not in fp:
-            return np.zeros(len(times))
-        vb_mat = background.get_baseline_matrix(times, int(self.fit_kwargs.get('v_baseline_deg', 0)), normalize=False,
-                                                sqrt=bool(self.fit_kwargs.get('v_baseline_sqrt', False)))
-        return vb_mat @ (fp['v_baseline'] if x_vb is None else x_vb)
-
-    def predict_response(self, times=None, input_signal=None, step_times=None, step_sizes=None, op_mode=None,
-                         offset_steps=None, step_offset_size=None, include_dop=True, include_drt=True, include_ohmic=True,
-                         include_cap=True, smooth_inf_response=None, x=None, include_vz_offset=True, v_baseline=None):
-        """drt1d.predict_response (3363-3469; no background model): voltage response of the fitted model to the fitted
-        (or given) current steps at the fit times or any other times; response / phasance matrices built on the device."""
-        from ..matrices import phasance
-        if (op_mode or self.chrono_mode) != 'galv':
-            raise ValueError('only galvanostatic predictions are built')
-        prep = self._prep
-        use_fit_times = times is None
-        times = np.asarray(prep['sample_times'] if times is None else times, dtype=float)
-        offset_steps = self.fit_kwargs['offset_steps'] if offset_steps is None else offset_steps
-        step_offset_size = self.fit_kwargs['step_offset_size'] if step_offset_size is None else step_offset_size
-        smooth = self.fit_kwargs['smooth_inf_response'] if smooth_inf_response is None else smooth_inf_response
-        if input_signal is not None and step_times is not None:
-            raise ValueError('Either input_signal OR (step_times and step_sizes) should be provided; '
-                             'received input_signal and step_times')
-        if step_times is not None and step_sizes is None:
-            raise ValueError('If input signal steps are provided, both step_times and step_sizes must be provided; '
-                             'received step_times only')
-        if input_signal is None and step_times is None:
-            step_times, step_sizes = prep['step_times'], prep['step_sizes']
-            raw_input = prep.get('raw_input_signal')
-        elif step_times is not None:
-            raw_input = pp.generate_model_signal(times, step_times, step_sizes, None, 'ideal')
-        else:
-            raw_input = np.asarray(input_signal, dtype=float)
-            step_times, step_sizes, _ = pp.process_input_signal(times, raw_input, self.step_model, offset_steps, step_offset_size)
-        fp = self._fitted_parameters(x)
-        ctx = self._context if self._context is not None else _ffi.get_context(self.device)
-        response = np.zeros(len(times))
-        if include_drt:
-            mode = _ffi.MODE_INTERP if self.integrate_method == 'interp' else _ffi.MODE_TRAPZ
-            lookup = self._lookups(ctx)['response'] if mode == _ffi.MODE_INTERP else None
-            a, _ = ctx.response_matrix(times, self.basis_tau, step_times, step_sizes, self.tau_epsilon, mode=mode, lookup=lookup,
-                                       layered=False)
-            xd = fp['x']
-            if self.series_neg:
-                nt = len(self.basis_tau)
-                xd = xd[:nt] - xd[nt:]
-            response += a @ xd
-        if include_ohmic:
-            response += mat1d.construct_ohmic_response_vector(times, self.step_model, step_times, step_sizes, None, raw_input,
-                                                              smooth) * fp.get('R_inf', 0)
-        if include_cap and fp.get('C_inv', 0) != 0:
-            response += fp['C_inv'] * mat1d.construct_capacitance_response_vector(times, self.step_model, step_times,
-                                                                                 step_sizes, None)
-        if fp.get('x_dop') is not None and include_dop:
-            rm_dop, _ = phasance.construct_phasor_v_matrix(times, self.basis_nu, 'gaussian', self.nu_epsilon, self.step_model,
-                                                           step_times, step_sizes, device=self.device)
-            response += rm_dop @ fp['x_dop']
-        if include_vz_offset and fp.get('vz_offset', 0) != 0:
-            # chrono half of _get_vz_strength_vec relative to the FIT's frequencies (drt1d.py:6200-6213)
-            nonconsec = prep['nonconsec_step_times']
-            deltas = pp.get_time_since_step(times, nonconsec, prestep_value=-1)
-            eis_tau_max = np.max(1 / (2 * np.pi * prep['frequencies']))
-            cs = np.ones(len(deltas))
-            far = deltas >= eis_tau_max
-            cs[far] = np.exp(-(fp.get('vz_offset_eps', 1) * np.log(deltas[far] / eis_tau_max)) ** 2)
-            cs[deltas == -1] = 0
-            response *= (1 + fp['vz_offset'] * cs)
-        response += self.predict_v_baseline(times) if v_baseline is None else v_baseline
-        return response
-
-    def _eis_vz_strength(self, frequencies, vz_offset_eps):
-        """EIS half of DRT._get_vz_strength_vec (drt1d.py:6173-6226) relative to the FIT's sample times."""
-        prep = self._prep
-        deltas = pp.get_time_since_step(prep['sample_times'], prep['nonconsec_step_times'], prestep_value=-1)
-        chrono_tau_min = np.min(deltas[deltas > 0])
-        f_inv = 1 / (2 * np.pi * frequencies)
-        es = np.ones(len(frequencies))
-        fast = f_inv <= chrono_tau_min
-        es[fast] = np.exp(-(vz_offset_eps * np.log(f_inv[fast] / chrono_tau_min)) ** 2)
-        return es
 
     def evaluate_rss(self, weights=None, x=None):
         """drt1d.evaluate_rss (drt1d.py:4433-4455) -> qphb.evaluate_rss (qphb.py:1347-1352)."""

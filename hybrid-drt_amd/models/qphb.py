@@ -79,6 +79,8 @@ def solve_convex_opt(wrv, wrm, l2_matrix, l1v, nonneg, special_params, init_vals
     res = ctx.qp_batch(P[0], q, h)
     if res['status'][0] == _ffi.QP_SINGULAR:
         raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+    if res['status'][0] == _ffi.QP_ABORTED:
+        raise RuntimeError("hipdrt: the QP's workgroups were not co-resident (device shared with another process?)")
     return {'x': res['x'][0], 'primal objective': float(res['pcost'][0]), 'status': _STATUS[int(res['status'][0])],
             'iterations': int(res['iterations'][0])}
 

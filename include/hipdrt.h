@@ -29,6 +29,8 @@ extern "C" {
 #define HIPDRT_QP_MAXITER 1     /* maxiters reached (cvxopt status 'unknown')                      */
 #define HIPDRT_QP_SINGULAR_LATE 2 /* Cholesky breakdown after iteration 0: cvxopt returns current x */
 #define HIPDRT_QP_SINGULAR (-1) /* breakdown at the start point: cvxopt raises ValueError          */
+#define HIPDRT_QP_ABORTED (-2)  /* a large problem split over several workgroups gave up waiting for its partners (the
+                                   device was not exclusively ours); the result is not valid           */
 
 #define HIPDRT_MODE_INTERP 0    /* integrate_method='interp' (drtbase.py:155)  */
 #define HIPDRT_MODE_TRAPZ 1     /* integrate_method='trapz'  (drtbase.py:159)  */

@@ -453,53 +453,6 @@ def run_resolve_group(cvxopt, name, n_obs=16, batch_size=7, overlap=2):
     print(f"resolve_group_{name}: {n_obs} obs, {len(log)} batches, qp iterations {out['qp_iterations'].tolist()}")
 
 
-def run_predict(DRT, freq_g, z_g):
-    """evaluation of fitted models (drt1d.py:3043-3062, 3500-3542, 3552-3571): predict_drt, predict_z on a grid other than
-    the fit's, predict_r_p, for an EIS fit, an EIS + DOP fit and a joint fit with DOP (upstream's series_neg evaluation
-    path raises in get_drt_params, so it is not a parity case)"""
-    from hipdrt import synth
-    base = dict(fit_inductance=True, fit_capacitance=False, fit_ohmic=True)
-    meas = synth.hybrid_measurement(seed=0)
-    f_pred = np.logspace(5.5, -0.5, 37)
-    out = dict(f_pred=f_pred)
-    cases = {"eis": (dict(base, fit_dop=False), (None, None, None, freq_g, z_g), {}),
-             "eis_dop": (dict(base, fit_dop=True), (None, None, None, freq_g, z_g), {}),
-             "hybrid_dop": (dict(base, fit_dop=True), meas, {}),
-             "chrono": (dict(base, fit_dop=False), meas[:3] + (None, None), {})}
-    for tag, (ctor, data, kw) in cases.items():
-        with _quiet():
-            drt = DRT(**ctor)
-            if data[0] is None:
-                drt.fit_eis(data[3], data[4], **kw)
-            elif data[3] is None:
-                drt.fit_chrono(*data[:3], **kw)
-            else:
-                drt.fit_hybrid(*data, **kw)
-            tau = drt.get_tau_eval(20)
-            out[f"{tag}_tau"] = tau
-            out[f"{tag}_gamma"] = drt.predict_drt(tau=tau, sign=0 if kw.get("series_neg") else 1)
-            out[f"{tag}_gamma_norm"] = drt.predict_drt(tau=tau, normalize=True, sign=0 if kw.get("series_neg") else 1)
-            out[f"{tag}_z"] = drt.predict_z(f_pred)
-            out[f"{tag}_z_noL"] = drt.predict_z(f_pred, include_inductance=False, include_vz_offset=False)
-            out[f"{tag}_rp"] = drt.predict_r_p()
-            out[f"{tag}_rp_abs"] = drt.predict_r_p(absolute=True)
-            lo, hi = drt.predict_drt_ci(tau=tau)
-            out[f"{tag}_ci_lo"], out[f"{tag}_ci_hi"] = lo, hi
-            out[f"{tag}_dist_var_ext"] = np.diag(drt.estimate_distribution_cov(tau=tau, extend_var=True))
-            if ctor.get("fit_dop"):
-                out[f"{tag}_dop_nu"], out[f"{tag}_dop"] = drt.predict_dop(return_nu=True)
-                out[f"{tag}_dop_norm"] = drt.predict_dop(normalize=True)
-                out[f"{tag}_dop_coarse"] = drt.predict_dop(nu=np.linspace(-1, 1, 21), include_ideal=False)
-            if data[0] is not None:
-                t_pred = np.concatenate([data[0][::7], [data[0][-1] * 1.5]])
-                out[f"{tag}_v_fit"] = drt.predict_response()
-                out[f"{tag}_t_pred"] = t_pred
-                out[f"{tag}_v_pred"] = drt.predict_response(times=t_pred)
-                out[f"{tag}_v_pred_parts"] = drt.predict_response(times=t_pred, include_dop=False, include_vz_offset=False)
-    np.savez_compressed(os.path.join(OUT, "refrun_predict.npz"), **out)
-    print("refrun_predict.npz:", {k: np.shape(v) for k, v in out.items() if k.endswith("_z")})
-
-
 DECIMATE_CASES = [     # (record, keywords of preprocessing.downsample_data)
     ("one_step", dict(method='decimate', prestep_samples=10)),
     ("one_step", dict(method='decimate', prestep_samples=7, decimation_interval=25, decimation_factor=1.5)),
@@ -547,24 +500,6 @@ def run_decimate(DRT, cvxopt):
                                                              decimation_factor=1.5, decimation_max_period=0.05)))
 
 
-def run_kk(DRT, freq_g, z_g):
-    """DRT.kk_test (drt1d.py:1370-1491, models/kk.py): the reference's test spectrum with corrupted ends and two bad points
-    inside; flagged points, frequency limits, normalised residuals and the second (down-weighted) fit"""
-    z = z_g.copy()
-    z[:3] += np.array([0.04, -0.03 + 0.03j, 0.02j])          # high-frequency end
-    z[-2:] += np.array([0.05j, -0.06])                      # low-frequency end
-    z[30] += 0.03
-    z[45] -= 0.025j
-    with _quiet():
-        drt = DRT(fit_inductance=True, fit_capacitance=False, fit_ohmic=True, fit_dop=False)
-        out_idx, (f_min, f_max), (f_c, z_c) = drt.kk_test(freq_g, z, show_plot=False)
-        resid = drt.eval_kk_residuals()
-    np.savez_compressed(os.path.join(OUT, "refrun_kk.npz"), freq=freq_g, z=z, outlier_index=out_idx, f_min=f_min, f_max=f_max,
-                        f_clean=f_c, z_clean=z_c, residuals=resid, x=drt.fit_parameters["x"], basis_tau=drt.basis_tau,
-                        weights=drt.qphb_params["true_weights"], outer_iterations=len(drt.qphb_history))
-    print("refrun_kk.npz: outliers", out_idx.tolist(), "limits", f_min, f_max, "outer", len(drt.qphb_history))
-
-
 def run_posteriors(DRT, freq_g, z_g, default):
     from oracle.drt_oracle import get_basis_tau
     bt = get_basis_tau(freq_g)
@@ -581,16 +516,6 @@ def main():
     if "--only-decimate" in sys.argv:
         DRT, cvxopt = _boot_reference()
         run_decimate(DRT, cvxopt)
-        return
-    if "--only-kk" in sys.argv:
-        freq_g, z_g = extract_reference_test_vectors()
-        DRT, cvxopt = _boot_reference()
-        run_kk(DRT, freq_g, z_g)
-        return
-    if "--only-predict" in sys.argv:
-        freq_g, z_g = extract_reference_test_vectors()
-        DRT, cvxopt = _boot_reference()
-        run_predict(DRT, freq_g, z_g)
         return
     if "--only-resolve" in sys.argv:
         DRT, cvxopt = _boot_reference()
@@ -669,9 +594,7 @@ def main():
     run_resolve(DRT, cvxopt, "hybrid7_dop", True)
     run_resolve_group(cvxopt, "hybrid16")
     # (12) evaluation of fitted models
-    run_predict(DRT, freq_g, z_g)
     # (13) Kramers-Kronig test
-    run_kk(DRT, freq_g, z_g)
     # (14) progressive decimation of raw chrono records
     run_decimate(DRT, cvxopt)
 

@@ -756,61 +756,6 @@ def test_uniform_chrono_variance_shortcut_is_bit_identical():
     assert outs[0]["outer_iters"][0] == outs[1]["outer_iters"][0] == int(g["outer_iterations"])
 
 
-def test_predict_functions_match_reference_run():
-    """predict_drt / predict_z (on a frequency grid other than the fit's) / predict_r_p of fitted models"""
-    import os
-    from conftest import GOLDEN
-    from hipdrt.models import DRT
-    from hipdrt import synth
-    g = np.load(os.path.join(GOLDEN, "refrun_predict.npz"))
-    gg, _ = load_case("golden71x91_dop")
-    freq, z = gg["freq"], gg["z"]
-    meas = synth.hybrid_measurement(seed=0)
-    cases = {"eis": (dict(), (None, None, None, freq, z), {}), "eis_dop": (dict(fit_dop=True), (None, None, None, freq, z), {}),
-             "hybrid_dop": (dict(fit_dop=True), meas, {}), "chrono": (dict(), meas[:3] + (None, None), {})}
-    for tag, (ctor, data, kw) in cases.items():
-        drt = DRT(warn=False, **ctor)
-        if data[0] is None:
-            drt.fit_eis(data[3], data[4], **kw)
-        elif data[3] is None:
-            drt.fit_chrono(*data[:3], **kw)
-        else:
-            drt.fit_hybrid(*data, **kw)
-        if ctor.get("fit_dop"):
-            nu, dop = drt.predict_dop(return_nu=True)
-            np.testing.assert_array_equal(nu, g[f"{tag}_dop_nu"])
-            ds = np.abs(g[f"{tag}_dop"]).max()
-            np.testing.assert_allclose(dop, g[f"{tag}_dop"], rtol=1e-5, atol=1e-7 * ds, err_msg=tag)
-            np.testing.assert_allclose(drt.predict_dop(normalize=True), g[f"{tag}_dop_norm"], rtol=1e-5,
-                                       atol=1e-7 * np.abs(g[f"{tag}_dop_norm"]).max())
-            np.testing.assert_allclose(drt.predict_dop(nu=np.linspace(-1, 1, 21), include_ideal=False), g[f"{tag}_dop_coarse"],
-                                       rtol=1e-5, atol=1e-7 * ds)
-        if data[0] is not None:       # predict_response at the fit times, at other times, with parts switched off
-            vs = np.abs(g[f"{tag}_v_fit"]).max()
-            np.testing.assert_allclose(drt.predict_response(), g[f"{tag}_v_fit"], rtol=0, atol=1e-7 * vs, err_msg=tag)
-            np.testing.assert_allclose(drt.predict_response(times=g[f"{tag}_t_pred"]), g[f"{tag}_v_pred"], rtol=0, atol=1e-7 * vs)
-            np.testing.assert_allclose(drt.predict_response(times=g[f"{tag}_t_pred"], include_dop=False, include_vz_offset=False),
-                                       g[f"{tag}_v_pred_parts"], rtol=0, atol=1e-7 * vs)
-        sign = 0 if kw.get("series_neg") else 1
-        tau = drt.get_tau_eval(20)
-        np.testing.assert_allclose(tau, g[f"{tag}_tau"], rtol=1e-13)
-        gam = g[f"{tag}_gamma"]
-        np.testing.assert_allclose(drt.predict_drt(tau=tau, sign=sign), gam, rtol=1e-5, atol=1e-7 * np.abs(gam).max())
-        np.testing.assert_allclose(drt.predict_drt(tau=tau, sign=sign, normalize=True), g[f"{tag}_gamma_norm"], rtol=1e-5,
-                                   atol=1e-7 * np.abs(g[f"{tag}_gamma_norm"]).max())
-        np.testing.assert_allclose(drt.predict_z(g["f_pred"]), g[f"{tag}_z"], rtol=1e-6, atol=1e-8, err_msg=tag)
-        np.testing.assert_allclose(drt.predict_z(g["f_pred"], include_inductance=False, include_vz_offset=False),
-                                   g[f"{tag}_z_noL"], rtol=1e-6, atol=1e-8)
-        np.testing.assert_allclose(drt.predict_r_p(), g[f"{tag}_rp"], rtol=1e-6)
-        np.testing.assert_allclose(drt.predict_r_p(absolute=True), g[f"{tag}_rp_abs"], rtol=1e-6)
-        lo, hi = drt.predict_drt_ci(tau=tau)
-        band = np.abs(g[f"{tag}_ci_hi"] - g[f"{tag}_ci_lo"]).max()
-        np.testing.assert_allclose(lo, g[f"{tag}_ci_lo"], rtol=0, atol=1e-6 * band, err_msg=tag)
-        np.testing.assert_allclose(hi, g[f"{tag}_ci_hi"], rtol=0, atol=1e-6 * band)
-        var_ext, ok = drt.estimate_distribution_var_batch(tau=tau, extend_var=True)
-        np.testing.assert_allclose(var_ext[0], g[f"{tag}_dist_var_ext"], rtol=1e-5, atol=1e-9 * g[f"{tag}_dist_var_ext"].max())
-
-
 def test_parameter_variances_of_a_joint_fit():
     """diag(inv(P)) cs^2 for a prepared-plan fit against numpy on the downloaded P (estimate_param_cov, drt1d.py:4116-4138)"""
     from hipdrt.models import DRT

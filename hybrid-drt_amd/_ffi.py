@@ -352,8 +352,8 @@ class Context:
         return out
 
     def qp_profile(self, reset=True):
-        buf = (C.c_ulonglong * 16)()
-        _check(self._lib.hipdrt_qp_profile(self._h, buf, 16, int(reset)))
+        buf = (C.c_ulonglong * 48)()
+        _check(self._lib.hipdrt_qp_profile(self._h, buf, 48, int(reset)))
         return [int(v) for v in buf]
 
     def weighted_gram(self, A, w, b, l2=None, l1=None):

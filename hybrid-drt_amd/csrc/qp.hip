@@ -588,10 +588,10 @@ size_t qp_scratch_doubles(int n) {
 
 int qp_profile_read(unsigned long long* out, int n, int reset) {
 #ifdef HIPDRT_QP_PROFILE
-    unsigned long long h[16];
+    unsigned long long h[QP_PROF_SLOTS];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_qp_prof), sizeof(h)) != hipSuccess) return -1;
-    for (int i = 0; i < n && i < 16; ++i) out[i] = h[i];
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qp_prof), z, sizeof(z)); }
+    for (int i = 0; i < n; ++i) out[i] = i < QP_PROF_SLOTS ? h[i] : 0;
+    if (reset) { unsigned long long z[QP_PROF_SLOTS] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qp_prof), z, sizeof(z)); }
     return 1;
 #else
     for (int i = 0; i < n; ++i) out[i] = 0;
@@ -697,9 +697,10 @@ void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active
     hipLaunchKernelGGL(lpt_order_kernel, dim3(blocks), dim3(256), (size_t)B * sizeof(int), st, B, iters, active, order);
 }
 
-// which kernel serves n <= 528: the super-column kernel (default) or the 32-column one (HIPDRT_QP_KERNEL=resident)
+// which kernel serves n <= 528: the 32-column one (default) or the experimental 64-wide super-column kernel
+// (HIPDRT_QP_KERNEL=super; parity-green but slower so far: its diagonal-block chain is the critical path)
 static bool use_super() {
-    static const bool v = [] { const char* e = getenv("HIPDRT_QP_KERNEL"); return !(e && std::string(e) == "resident"); }();
+    static const bool v = [] { const char* e = getenv("HIPDRT_QP_KERNEL"); return e && std::string(e) == "super"; }();
     return v;
 }
 

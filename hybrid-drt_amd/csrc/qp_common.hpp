@@ -10,13 +10,19 @@ namespace hipdrt {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 #ifdef HIPDRT_QP_PROFILE
-__device__ unsigned long long g_qp_prof[16];
+static constexpr int QP_PROF_SLOTS = 48;
+__device__ unsigned long long g_qp_prof[QP_PROF_SLOTS];
 #define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime();
 #define PROF(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
     atomicAdd(&g_qp_prof[slot], _n - _pt); _pt = _n; } else { _pt = 0; } } while (0)
+// the same for lane 0 of any wavefront of workgroup 0 (role timelines of the super-column kernel, slots 16..)
+#define PROFW(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
+    atomicAdd(&g_qp_prof[slot], _n - _pt); _pt = _n; } else { _pt = 0; } } while (0)
 #else
+static constexpr int QP_PROF_SLOTS = 48;
 #define PROF_DECL
 #define PROF(slot)
+#define PROFW(slot)
 #endif
 
 static constexpr int NB = 32;     // Cholesky block
@@ -224,25 +230,26 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                     refresh = false;
                 }
             }
-            double t4[4] = {0.0, 0.0, 0.0, 0.0};
+            // (the element loops read everything they need first and store last: the state vectors are slices of one
+            // buffer, so a store in between would order every later load behind it -- one L2 round trip per statement)
+            double t4[4] = {0.0, 0.0, 0.0, 0.0}, zr[1] = {0.0};
 #pragma unroll
             FOR_E {
                 if (VALID) {
-                    double r = (kRecurPx ? px[i] : sm.dvec[i]) + qv[i];          // P x + q
-                    t4[0] += x[i] * r;                      // x'(Px+q)
-                    t4[1] += x[i] * qv[i];                  // x'q
-                    r -= z[i];                              // + G'z
-                    rx[i] = r;
+                    const double px_ = kRecurPx ? px[i] : sm.dvec[i], q_ = qv[i], x_ = x[i], z_ = z[i], s_ = s[i], h_ = hv[i];
+                    double r = px_ + q_;                    // P x + q
+                    t4[0] += x_ * r;                        // x'(Px+q)
+                    t4[1] += x_ * q_;                       // x'q
+                    r -= z_;                                // + G'z
                     t4[2] += r * r;
-                    const double rzz = s[i] - hv[i] - x[i]; // s + Gx - h
-                    rz[i] = rzz;
+                    const double rzz = s_ - h_ - x_;        // s + Gx - h
                     t4[3] += rzz * rzz;
+                    zr[0] += z_ * rzz;
+                    rx[i] = r;
+                    rz[i] = rzz;
                 }
             }
             red.sum(t4);
-            double zr[1] = {0.0};
-#pragma unroll
-            FOR_E if (VALID) zr[0] += z[i] * rz[i];
             red.sum(zr);
             const double f0 = 0.5 * (t4[0] + t4[1]);
             const double resx = sqrt(t4[2]), resz = sqrt(t4[3]);
@@ -259,7 +266,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             if (iters == a.opts.maxiters) { status = HIPDRT_QP_MAXITER; break; }
             if (iters == 0) {
 #pragma unroll
-                FOR_E if (VALID) { d[i] = sqrt(s[i] / z[i]); di[i] = 1.0 / d[i]; lm[i] = sqrt(s[i] * z[i]); }
+                FOR_E if (VALID) { const double s_ = s[i], z_ = z[i], d_ = sqrt(s_ / z_); d[i] = d_; di[i] = 1.0 / d_; lm[i] = sqrt(s_ * z_); }
             }
         }
         // ---- factor S = P + diag(di^2)  (di = 1 at the start point) --------------------------------------
@@ -274,12 +281,15 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                     if (start) {
                         sm.vec[i] = -qv[i] - hv[i];           // bx + Gs' bz with bx = -q, bz = h
                     } else {
-                        double t = (pc == 1) ? (-ws3[i] - lm[i] * lm[i]) : (-(lm[i] * lm[i]));
+                        const double lm_ = lm[i], rz_ = rz[i], d_ = d[i], di_ = di[i], rx_ = rx[i];
+                        double t = (pc == 1) ? (-ws3[i] - lm_ * lm_) : (-(lm_ * lm_));
                         t += sigma * mu;
-                        sv[i] = t / lm[i];
-                        const double bz = -rz[i] - d[i] * sv[i];
-                        zz[i] = bz * di[i];
-                        sm.vec[i] = -rx[i] - di[i] * zz[i];
+                        const double sv_ = t / lm_;
+                        const double bz = -rz_ - d_ * sv_;
+                        const double zz_ = bz * di_;
+                        sv[i] = sv_;
+                        zz[i] = zz_;
+                        sm.vec[i] = -rx_ - di_ * zz_;
                     }
                 }
             }
@@ -308,12 +318,14 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
                 FOR_E {
                     if (VALID) {
-                        x[i] = sm.vec[i];
-                        if (kRecurPx) px[i] = (-qv[i] - hv[i]) - x[i];     // (P + I) x = -q - h
-                        z[i] = -x[i] - hv[i];
-                        s[i] = -z[i];
-                        st[0] += s[i] * s[i]; st[1] += z[i] * z[i];
-                        mx[0] = fmax(mx[0], -s[i]); mx[1] = fmax(mx[1], -z[i]);
+                        const double x_ = sm.vec[i], q_ = qv[i], h_ = hv[i];
+                        const double z_ = -x_ - h_, s_ = -z_;
+                        st[0] += s_ * s_; st[1] += z_ * z_;
+                        mx[0] = fmax(mx[0], -s_); mx[1] = fmax(mx[1], -z_);
+                        x[i] = x_;
+                        if (kRecurPx) px[i] = (-q_ - h_) - x_;           // (P + I) x = -q - h
+                        z[i] = z_;
+                        s[i] = s_;
                     }
                 }
                 red.sum(st);
@@ -344,15 +356,19 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
                 FOR_E {
                     if (VALID) {
-                        dx[i] = sm.vec[i];
-                        dz[i] = -di[i] * dx[i] - zz[i];
-                        ds[i] = sv[i] - dz[i];
-                        dd[0] += ds[i] * dz[i];
-                        if (pc == 0) ws3[i] = ds[i] * dz[i];
-                        ds[i] /= lm[i];
-                        dz[i] /= lm[i];
-                        mx[0] = fmax(mx[0], -ds[i]);
-                        mx[1] = fmax(mx[1], -dz[i]);
+                        const double dx_ = sm.vec[i], di_ = di[i], zz_ = zz[i], sv_ = sv[i], lm_ = lm[i];
+                        double dz_ = -di_ * dx_ - zz_;
+                        double ds_ = sv_ - dz_;
+                        const double w3 = ds_ * dz_;
+                        dd[0] += w3;
+                        ds_ /= lm_;
+                        dz_ /= lm_;
+                        mx[0] = fmax(mx[0], -ds_);
+                        mx[1] = fmax(mx[1], -dz_);
+                        dx[i] = dx_;
+                        if (pc == 0) ws3[i] = w3;
+                        ds[i] = ds_;
+                        dz[i] = dz_;
                     }
                 }
                 red.sum(dd);
@@ -373,21 +389,29 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
         FOR_E {
             if (VALID) {
+                const double dx_ = dx[i], ds_ = ds[i], dz_ = dz[i], lm_ = lm[i], d_ = d[i], x_ = x[i];
+                double px_ = 0.0;
                 if (kRecurPx) {
-                    px[i] += step * ((-rx[i] - di[i] * zz[i]) - (di[i] * di[i]) * dx[i]);
-                    mm[0] = fmax(mm[0], fabs(step * dx[i]));
+                    const double rx_ = rx[i], di_ = di[i], zz_ = zz[i];
+                    px_ = px[i] + step * ((-rx_ - di_ * zz_) - (di_ * di_) * dx_);
+                    mm[0] = fmax(mm[0], fabs(step * dx_));
                 }
-                x[i] += step * dx[i];
-                mm[1] = fmax(mm[1], fabs(x[i]));
-                const double dss = (1.0 + step * ds[i]) * lm[i];
-                const double dzz = (1.0 + step * dz[i]) * lm[i];
+                const double xn = x_ + step * dx_;
+                mm[1] = fmax(mm[1], fabs(xn));
+                const double dss = (1.0 + step * ds_) * lm_;
+                const double dzz = (1.0 + step * dz_) * lm_;
                 const double sqs = sqrt(dss), sqz = sqrt(dzz);
-                d[i] = d[i] * sqs / sqz;
-                di[i] = 1.0 / d[i];
-                lm[i] = sqs * sqz;
-                s[i] = lm[i] * d[i];
-                z[i] = lm[i] * di[i];
-                g2[0] += lm[i] * lm[i];
+                const double dn = d_ * sqs / sqz;
+                const double din = 1.0 / dn;
+                const double lmn = sqs * sqz;
+                g2[0] += lmn * lmn;
+                if (kRecurPx) px[i] = px_;
+                x[i] = xn;
+                d[i] = dn;
+                di[i] = din;
+                lm[i] = lmn;
+                s[i] = lmn * dn;
+                z[i] = lmn * din;
             }
         }
         red.sum(g2);

@@ -40,6 +40,28 @@ static constexpr int SLD = 17;            // row stride of 16x16 LDS tiles
 static constexpr int STL = 16 * SLD;      // doubles per padded LDS tile (272)
 static constexpr int SUB = 3 * STL;       // doubles per inverse 32x32 block (Wa | Wba | Wb)
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// 16 bytes per lane from (wave-uniform base) + (per-lane byte offset), issued as ONE instruction the compiler neither
+// moves nor waits for: the rank-k loops below keep several half-chunks in flight and count vmcnt by hand (hipcc's own
+// schedule gathers all loads of an unrolled body at its top and drains them with vmcnt(0) at its bottom, so nothing
+// stays in flight across iterations).  Every use of the result must come after an explicit vm_wait<N>().
+static __device__ __forceinline__ v2d gload16(const char* sbase, unsigned voff) {
+    v2d d;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    return d;
+}
+template <int N>
+static __device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);      // register-only consumers (MFMA) must not be hoisted above the wait
+}
+static __device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
 struct SupSmem {
     double* red;     // [4][SNW][4]
     double* dsc;     // [16][SLD]      diagonal tile being factored
@@ -234,62 +256,48 @@ struct OpsSuper {
         const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
         const int tb = 4 * p;
         bool ok = true;
-        v4d e00 = sm.In[dtile(0, 0) * 64 + lane];
-        v4d x10, x20, x30, x21, x31, x32;
-        v4d e11, e21, e22, e31, e32, e33;
-        // ---- tile column 0
-        ok = cholinv16(e00, wtile(p, 0)) && ok;
-        if (ncol > 1) {
-            x10 = trsm_tile(wtile(p, 0), sm.In[dtile(1, 0) * 64 + lane], li, kq);
-            if (ncol > 2) x20 = trsm_tile(wtile(p, 0), sm.In[dtile(2, 0) * 64 + lane], li, kq);
-            if (ncol > 3) x30 = trsm_tile(wtile(p, 0), sm.In[dtile(3, 0) * 64 + lane], li, kq);
-            put_lt(ltile(1, 0), x10, li, kq);
-            if (ncol > 2) put_lt(ltile(2, 0), x20, li, kq);
-            if (ncol > 3) put_lt(ltile(3, 0), x30, li, kq);
+        PROF_DECL
+        // One ROLLED loop over the tile columns, every tile of the block living in LDS (In: register images, Lt: the
+        // solved tiles row-major as MFMA row operands): the 16x16 Gauss-Jordan is 12 kB of straight-line code, and four
+        // copies of it plus unrolled tile arithmetic made wavefront 0 instruction-fetch bound (88 k cycles per block).
+#pragma unroll 1
+        for (int c = 0; c < ncol; ++c) {
+            double* Wc = wtile(p, c);
+            ok = cholinv16(sm.In[dtile(c, c) * 64 + lane], Wc) && ok;
+            PROFW(44);
+            // tiles below the diagonal tile: X_ic = E_ic Wc'
+#pragma unroll 1
+            for (int i = c + 1; i < ncol; ++i) {
+                const v4d x = trsm_tile(Wc, sm.In[dtile(i, c) * 64 + lane], li, kq);
+                put_lt(ltile(i, c), x, li, kq);
+                sm.In[dtile(i, c) * 64 + lane] = x;
+            }
             __builtin_amdgcn_wave_barrier();
-            e11 = sm.In[dtile(1, 1) * 64 + lane];
-            syrk_tile(e11, sm.Lt + ltile(1, 0) * STL, x10, li, kq);
-            if (ncol > 2) {
-                e21 = sm.In[dtile(2, 1) * 64 + lane]; e22 = sm.In[dtile(2, 2) * 64 + lane];
-                syrk_tile(e21, sm.Lt + ltile(1, 0) * STL, x20, li, kq);
-                syrk_tile(e22, sm.Lt + ltile(2, 0) * STL, x20, li, kq);
+            // E_ij += X_ic X_jc'  for c < j <= i
+#pragma unroll 1
+            for (int i = c + 1; i < ncol; ++i) {
+                const v4d x = sm.In[dtile(i, c) * 64 + lane];
+#pragma unroll 1
+                for (int j = c + 1; j <= i; ++j) {
+                    v4d e = sm.In[dtile(i, j) * 64 + lane];
+                    syrk_tile(e, sm.Lt + ltile(j, c) * STL, x, li, kq);
+                    sm.In[dtile(i, j) * 64 + lane] = e;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            PROFW(45);
+        }
+        if (ncol > 2) {
+            // the tiles that couple the two 32x32 blocks of the super-column go to HBM for the triangular sweeps
+            store_tile(tb + 2, tb, sm.In[dtile(2, 0) * 64 + lane], fo);
+            store_tile(tb + 2, tb + 1, sm.In[dtile(2, 1) * 64 + lane], fo);
             if (ncol > 3) {
-                e31 = sm.In[dtile(3, 1) * 64 + lane]; e32 = sm.In[dtile(3, 2) * 64 + lane]; e33 = sm.In[dtile(3, 3) * 64 + lane];
-                syrk_tile(e31, sm.Lt + ltile(1, 0) * STL, x30, li, kq);
-                syrk_tile(e32, sm.Lt + ltile(2, 0) * STL, x30, li, kq);
-                syrk_tile(e33, sm.Lt + ltile(3, 0) * STL, x30, li, kq);
-            }
-            // ---- tile column 1
-            ok = cholinv16(e11, wtile(p, 1)) && ok;
-            if (ncol > 2) {
-                x21 = trsm_tile(wtile(p, 1), e21, li, kq);
-                if (ncol > 3) x31 = trsm_tile(wtile(p, 1), e31, li, kq);
-                put_lt(ltile(2, 1), x21, li, kq);
-                if (ncol > 3) put_lt(ltile(3, 1), x31, li, kq);
-                __builtin_amdgcn_wave_barrier();
-                syrk_tile(e22, sm.Lt + ltile(2, 1) * STL, x21, li, kq);
-                if (ncol > 3) {
-                    syrk_tile(e32, sm.Lt + ltile(2, 1) * STL, x31, li, kq);
-                    syrk_tile(e33, sm.Lt + ltile(3, 1) * STL, x31, li, kq);
-                }
-                // ---- tile column 2
-                ok = cholinv16(e22, wtile(p, 2)) && ok;
-                if (ncol > 3) {
-                    x32 = trsm_tile(wtile(p, 2), e32, li, kq);
-                    put_lt(ltile(3, 2), x32, li, kq);
-                    __builtin_amdgcn_wave_barrier();
-                    syrk_tile(e33, sm.Lt + ltile(3, 2) * STL, x32, li, kq);
-                    // ---- tile column 3
-                    ok = cholinv16(e33, wtile(p, 3)) && ok;
-                }
-                // the tiles that couple the two 32x32 blocks of the super-column go to HBM for the triangular sweeps
-                store_tile(tb + 2, tb, x20, fo);
-                store_tile(tb + 2, tb + 1, x21, fo);
-                if (ncol > 3) { store_tile(tb + 3, tb, x30, fo); store_tile(tb + 3, tb + 1, x31, fo); }
+                store_tile(tb + 3, tb, sm.In[dtile(3, 0) * 64 + lane], fo);
+                store_tile(tb + 3, tb + 1, sm.In[dtile(3, 1) * 64 + lane], fo);
             }
         }
         // lower-left tiles of the inverse 32x32 blocks: Wba = -Wb (L_ba Wa)
+        PROFW(45);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             if (2 * hb + 1 < ncol) {
@@ -315,6 +323,7 @@ struct OpsSuper {
                 for (int rg = 0; rg < 4; ++rg) { Wba[(kq + 4 * rg) * SLD + li] = 0.0; Wb[(kq + 4 * rg) * SLD + li] = 0.0; }
             }
         }
+        PROFW(46);
         if (fwd) {
             // fused forward substitution of the super-column's own 64 entries: y = M b per 32x32 block, the second block
             // after the first one's contribution through the coupling tiles
@@ -345,6 +354,7 @@ struct OpsSuper {
                 if (lane < 32) v[32 + lane] = yb;
             }
         }
+        PROFW(47);
         return ok;
     }
 
@@ -374,29 +384,36 @@ struct OpsSuper {
             const int epoch = p + 1;
             if (wv == 0) {
                 // ======== wavefront 0: the diagonal block =========================================================
+                PROF_DECL
                 const bool ok = chain(p, ncol, lane);
+                PROFW(16);
                 if (lane == 0) sm.flag[0] = ok ? 0 : 1;
                 __syncthreads();                                    // (A) inverse tiles, coupling tiles, y published
+                PROFW(17);
                 if (vflag[0]) return false;
+                __syncthreads();                                    // (B)
+                PROFW(18);
+                continue;
             } else if (wv == 1) {
                 // ======== wavefront 1: rank-k update of the next 64x64 diagonal block ================================
                 const int eb = tb + 4;
                 const int ne = (ntr - eb) < 4 ? (ntr - eb) : 4;     // its valid tile rows (<= 0: none)
                 v4d e[10];
-                const double2* pa[4];
+                const char* pa[4] = {nullptr, nullptr, nullptr, nullptr};
+                const unsigned voff = (unsigned)fo * 16u;
                 if (ne > 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
 #pragma unroll
                         for (int j = 0; j <= i; ++j)
                             e[dtile(i, j)] = (i < ne) ? init_tile(eb + i, eb + j, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
-                        pa[i] = tile2(i < ne ? eb + i : eb, 0) + fo;
+                        pa[i] = uniform_ptr(tile2(i < ne ? eb + i : eb, 0));
                     }
                 }
-                struct Fr { double2 a[4]; };
+                struct Fr { v2d a[4]; };
                 auto loadf = [&](Fr& f_, int k2) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) f_.a[i] = pa[i][k2 * 64];
+                    for (int i = 0; i < 4; ++i) f_.a[i] = gload16(pa[i] + (size_t)k2 * 1024, voff);
                 };
                 auto multf = [&](const Fr& f_) {
 #pragma unroll
@@ -409,19 +426,30 @@ struct OpsSuper {
 #pragma unroll
                         for (int j = 0; j <= i; ++j)
                             e[dtile(i, j)] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a[j].y, f_.a[i].y, e[dtile(i, j)], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 };
-                auto accumulate = [&](int k0, int k1) {             // half-chunks k0 .. k1-1 (an even count)
-                    Fr fa, fb;
-                    loadf(fa, k0);
-                    for (int k2 = k0; k2 < k1; k2 += 2) {
-                        loadf(fb, k2 + 1);
-                        multf(fa);
-                        if (k2 + 2 < k1) loadf(fa, k2 + 2);
-                        multf(fb);
+                auto accumulate = [&](int k0, int k1) {             // half-chunks k0 .. k1-1 (a multiple of 4)
+                    // hand-pipelined like the row wavefronts' loop: requests run three half-chunks ahead (4 loads per
+                    // step, so "this step's operands have arrived" is vmcnt(12)); indices past the end are clamped
+                    Fr f0, f1, f2, f3;
+                    const int kl = k1 - 1;
+                    auto ld = [&](Fr& f_, int k2) { loadf(f_, k2 < kl ? k2 : kl); };
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    ld(f0, k0); ld(f1, k0 + 1); ld(f2, k0 + 2);
+                    for (int k2 = k0; k2 < k1; k2 += 4) {
+                        ld(f3, k2 + 3); vm_wait<12>(); multf(f0);
+                        ld(f0, k2 + 4); vm_wait<12>(); multf(f1);
+                        ld(f1, k2 + 5); vm_wait<12>(); multf(f2);
+                        ld(f2, k2 + 6); vm_wait<12>(); multf(f3);
                     }
+                    vm_wait<0>();
                 };
+                PROF_DECL
                 if (ne > 0 && nk2 > 0) accumulate(0, nk2);
+                PROFW(20);
                 __syncthreads();                                    // (A)
+                PROFW(21);
                 if (vflag[0]) return false;
                 if (ne > 0) {
                     // the four tile columns of this super-column, as soon as their owners have stored them
@@ -430,6 +458,7 @@ struct OpsSuper {
                         while (vflag[1 + i] != epoch && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(2);
                     if (spins >= (1 << 24)) vflag[0] = 2;           // never expected: give up instead of hanging
                     asm volatile("" ::: "memory");
+                    PROFW(22);
                     accumulate(nk2, nk2 + 8);
                     // non-existing rows of the block: identity diagonal, nothing else (they are never referenced)
 #pragma unroll
@@ -438,12 +467,19 @@ struct OpsSuper {
                         for (int j = 0; j <= i; ++j)
                             if (i < ne) sm.In[dtile(i, j) * 64 + lane] = e[dtile(i, j)];
                 }
+                PROFW(23);
+                __syncthreads();                                    // (B)
+                PROFW(24);
+                continue;
             } else {
                 // ======== wavefronts 2..7: the tile rows below the diagonal block ==================================
                 const int fr = tb + 4;
                 const int nsq = ntr - fr > 0 ? ntr - fr : 0;                 // rows of the square matrix below the block
                 const int nothers = nsq + nex;                               // ... followed by the appended rows
                 const int npass = nothers > SRW * SMAXT ? (nothers + SRW * SMAXT - 1) / (SRW * SMAXT) : 1;
+                PROF_DECL
+                const int pslot = wv == 2 ? 26 : (wv == 7 ? 32 : 38);     // profile build: wave 2, wave 7, the other four
+                (void)pslot;
 #pragma unroll 1
                 for (int ps = 0; ps < npass; ++ps) {
                     int T[SMAXT];
@@ -462,43 +498,61 @@ struct OpsSuper {
                         for (int ct = 0; ct < 4; ++ct)
                             acc[u][ct] = (act[u] && ct < ncol) ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
                     if (nk2 > 0 && act[0]) {
-                        const double2* pb[4];
-                        const double2* pa[SMAXT];
+                        // Operand ring, software-pipelined by hand: the A tiles (this wavefront's own rows, from HBM) are
+                        // requested THREE half-chunks ahead, the B tiles (the block's rows, shared by all wavefronts: L1 /
+                        // L2) one ahead.  Per step 4 B + 4 A loads are issued, B first, so "B of this step has arrived"
+                        // is vmcnt(12): A(k+2), B(k+1), A(k+3) may still be in flight.  Indices past the end are clamped
+                        // (a redundant load of the last half-chunk) so that the counts stay uniform.
+                        const char* rb[4];
+                        const char* ra[SMAXT];
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) pb[ct] = tile2(ct < ncol ? tb + ct : tb, 0) + fo;   // stand-in for padding
+                        for (int ct = 0; ct < 4; ++ct) rb[ct] = uniform_ptr(tile2(ct < ncol ? tb + ct : tb, 0));   // stand-in for padding
 #pragma unroll
-                        for (int u = 0; u < SMAXT; ++u) pa[u] = tile2(act[u] ? T[u] : tb, 0) + fo;
-                        struct Slab { double2 b[4], a[SMAXT]; };
-                        auto load = [&](Slab& s_, int k2) {          // k2 = half-chunk index (8 columns)
-                            const int o = k2 * 64;
+                        for (int u = 0; u < SMAXT; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
+                        const unsigned voff = (unsigned)fo * 16u;
+                        struct SlA { v2d a[SMAXT]; };
+                        struct SlB { v2d b[4]; };
+                        const int klast = nk2 - 1;
+                        auto loadA = [&](SlA& s_, int k2) {
+                            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
 #pragma unroll
-                            for (int ct = 0; ct < 4; ++ct) s_.b[ct] = pb[ct][o];
-#pragma unroll
-                            for (int u = 0; u < SMAXT; ++u) s_.a[u] = pa[u][o];
+                            for (int u = 0; u < SMAXT; ++u) s_.a[u] = gload16(ra[u] + o, voff);
                         };
-                        auto mult = [&](const Slab& s_) {
+                        auto loadB = [&](SlB& s_, int k2) {
+                            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) s_.b[ct] = gload16(rb[ct] + o, voff);
+                        };
+                        auto mult = [&](const SlA& a_, const SlB& b_) {
 #pragma unroll
                             for (int u = 0; u < SMAXT; ++u)
 #pragma unroll
                                 for (int ct = 0; ct < 4; ++ct)
-                                    acc[u][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b[ct].x, s_.a[u].x, acc[u][ct], 0, 0, 0);
+                                    acc[u][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b[ct].x, a_.a[u].x, acc[u][ct], 0, 0, 0);
 #pragma unroll
                             for (int u = 0; u < SMAXT; ++u)
 #pragma unroll
                                 for (int ct = 0; ct < 4; ++ct)
-                                    acc[u][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b[ct].y, s_.a[u].y, acc[u][ct], 0, 0, 0);
+                                    acc[u][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b[ct].y, a_.a[u].y, acc[u][ct], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
                         };
-                        Slab sa, sb;
-                        load(sa, 0);
-                        for (int k2 = 0; k2 < nk2; k2 += 2) {
-                            load(sb, k2 + 1);
-                            mult(sa);
-                            if (k2 + 2 < nk2) load(sa, k2 + 2);
-                            mult(sb);
+                        SlA a0, a1, a2, a3;
+                        SlB b0, b1;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+                        __builtin_amdgcn_sched_barrier(0);
+                        loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
+                        for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 8p: a multiple of 4
+                            loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<12>(); mult(a0, b0);
+                            loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<12>(); mult(a1, b1);
+                            loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<12>(); mult(a2, b0);
+                            loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<12>(); mult(a3, b1);
                         }
+                        vm_wait<0>();                               // the clamped requests past the end
                     }
+                    PROFW(pslot);                                   // initial tiles + rank-k update
                     if (ps == 0) {
                         __syncthreads();                            // (A) published by wavefront 0
+                        PROFW(pslot + 1);
                         if (vflag[0]) return false;
                     }
                     // ---- (2) panel solve from registers, right-looking over the tile columns; row slot 0 first: in pass
@@ -559,6 +613,7 @@ struct OpsSuper {
                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row's four tiles have reached L2
                                 if (lane == 0) vflag[1 + (wv - 2)] = epoch;
                             }
+                            if (grp == 0) PROFW(pslot + 2); else PROFW(pslot + 3);
                             if (fwd) {
 #pragma unroll
                                 for (int u = 0; u < SMAXT; ++u) {
@@ -575,6 +630,10 @@ struct OpsSuper {
                 }
             }
             __syncthreads();                                        // (B) super-column visible to everyone
+#ifdef HIPDRT_QP_PROFILE
+            if (wv >= 2 && (threadIdx.x & 63) == 0 && blockIdx.x == 0)
+                atomicAdd(&g_qp_prof[(wv == 2 ? 26 : (wv == 7 ? 32 : 38)) + 4], 1ull);   // (rows' wait at B is 18/24's mirror)
+#endif
         }
         return true;
     }

@@ -36,6 +36,16 @@ if prof[10]:
     tot = prof[10]
     print("in-kernel ticks of WG0:", {n: prof[i] for i, n in enumerate(names)}, "factorizations:", prof[11])
     print("diagonal chain: cholinv1", prof[12], "l21+d2", prof[14], "cholinv2", prof[15]); print("shares:", {n: round(prof[i] / tot, 3) for i, n in enumerate(names)})
+if prof[10] and any(prof[16:44]):
+    # role timelines of the super-column kernel (qp_super.hpp), ticks summed over all factorisations of WG0
+    f = lambda i: round(prof[i] / tot, 3)
+    print("super-column kernel, shares of WG0's total:")
+    print("  total ticks", tot, "per factorisation", tot // max(prof[11], 1))
+    print("  wave0 chain", f(16), "wait A", f(17), "A->B", f(18))
+    print("    inside the chain: cholinv16 x4", f(44), "tile solves / updates", f(45), "Wba + stores", f(46), "fused forward", f(47))
+    print("  wave1 rank-k", f(20), "wait A", f(21), "wait rows", f(22), "last 4 chunks + stage", f(23), "wait B", f(24))
+    for name, b0 in (("wave2", 26), ("wave7", 32), ("waves3-6 (sum of 4)", 38)):
+        print(f"  {name} rank-k", f(b0), "wait A", f(b0 + 1), "solve row 0 + publish", f(b0 + 2), "solve rows 1-3", f(b0 + 3))
 from oracle.coneqp import coneqp_boxlow
 r = coneqp_boxlow(P, q, h)
 print("oracle iters", r["iterations"], "max rel err", np.max(np.abs(res["x"][0] - r["x"])) / np.abs(r["x"]).max())

@@ -827,6 +827,7 @@ static GramL2 plan_l2(const hipdrt_plan* p, double l2_lambda_0, const double* de
     GramL2 g{};
     g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1;
     g.sym = p->prepared ? 0 : p->toeplitz_m;      // caller-supplied matrices are not assumed bitwise symmetric
+    g.toep = p->toeplitz_m;                       // log-uniform tau grid (the hyper kernel relies on the same structure)
     for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = l2_lambda_0 * derivative_weights[k]; }
     g.s = p->s.d(); g.rho = p->rho.d();
     if (p->prepared && p->desc.dop_size > 0) {

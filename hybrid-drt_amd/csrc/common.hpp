@@ -112,6 +112,7 @@ struct GramL2 {
     int ns;
     int use_rho;
     int sym;               // penalty matrices are bitwise symmetric (Toeplitz build): read them along rows
+    int toep;              // the DRT block (indices >= ns) of every mk is symmetric Toeplitz: mk[i][j] = mk[ns][ns + |i - j|]
     // x_dop block (qphb.py:92-100): entries with both indices in [dop_start, dop_start + dop_size) are scaled by
     // dop_dfac[k] * dop_rho[b][k] instead
     int dop_start, dop_size;

@@ -118,6 +118,12 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
     // over the slab buffers, so the kernel needs 20 kB of LDS and eight workgroups fit a CU
     double (*sqI)[GT] = reinterpret_cast<double (*)[GT]>(sI);
     double (*sqJ)[GT] = reinterpret_cast<double (*)[GT]>(sJ);
+    // On a log-uniform tau grid the DRT block of every penalty matrix is symmetric Toeplitz, M_k[i][j] = t_k[|i - j|]
+    // with t_k = its first row: the tile needs the 127 differences around i0 - j0 only, staged behind the sqrt tables,
+    // and no dense matrix is read in the epilogue (three 2 MB matrices per spectrum and outer iteration otherwise).
+    constexpr int TW = 2 * GT;                                      // window slots per order (127 used)
+    double (*tw)[TW] = reinterpret_cast<double (*)[TW]>(sI + 3 * GT);
+    const int dbase = i0 - j0 - (GT - 1);                           // difference of window slot 0
     if (g.s) {
         __syncthreads();   // last slab consumed
         const double* sb_ = g.s + (size_t)b * 3 * n;
@@ -125,6 +131,15 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
             const int k = e / GT, c = e % GT;
             sqI[k][c] = (i0 + c < n) ? sqrt(sb_[k * n + i0 + c]) : 0.0;
             sqJ[k][c] = (j0 + c < n) ? sqrt(sb_[k * n + j0 + c]) : 0.0;
+        }
+        if (g.toep) {
+            const int nd = n - g.ns;                                // size of the DRT block
+            for (int e = tid; e < 3 * TW; e += 256) {
+                const int k = e / TW, sl = e % TW;
+                int dd = dbase + sl;
+                dd = dd < 0 ? -dd : dd;
+                tw[k][sl] = (g.dfac[k] > 0.0 && dd < nd) ? g.mk[k][(size_t)g.ns * g.ldm + g.ns + dd] : 0.0;
+            }
         }
         __syncthreads();
     }
@@ -161,9 +176,14 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
                             if (g.dfac[k] > 0.0) {
                                 // (i, j) = (lane&15, lane>>4 + 4r): reading the mirror element keeps the wave's
                                 // addresses contiguous when the matrices are bitwise symmetric
-                                double mv = g.sym ? g.mk[k][(size_t)j * g.ldm + i] : g.mk[k][(size_t)i * g.ldm + j];
-                                if (i >= g.ns && j >= g.ns) mv *= fac[k];
-                                else if (DOP && i >= dop_lo && i < dop_hi && j >= dop_lo && j < dop_hi) mv *= dfac2[k];
+                                double mv;
+                                if (g.toep && i >= g.ns && j >= g.ns) {
+                                    mv = tw[k][(i - j) - dbase] * fac[k];
+                                } else {
+                                    mv = g.sym ? g.mk[k][(size_t)j * g.ldm + i] : g.mk[k][(size_t)i * g.ldm + j];
+                                    if (i >= g.ns && j >= g.ns) mv *= fac[k];
+                                    else if (DOP && i >= dop_lo && i < dop_hi && j >= dop_lo && j < dop_hi) mv *= dfac2[k];
+                                }
                                 l2 += (sqI[k][i - i0] * mv) * sqJ[k][j - j0];
                             }
                         }

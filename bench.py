@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: DRT fits/sec, 256 freq x 512 tau, batched (BASELINE.json), one process per GPU.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config auto|c3|c4]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-A step = one full QPHB fit (DRT._qphb_fit_core: scaling, initial-weights QP, hyper-parameter loop to
-convergence, final q) of `--batch` synthetic 2-ZARC spectra per GPU (BASELINE configs[2]: 1024 spectra, shared
-256-point frequency grid, 512-point tau grid), inputs resident in HBM before the timed region.  Weak scaling:
-every rank fits its own `--batch` spectra (rank r: seeds r*batch ...); the lookup tables are built by rank 0 and
-broadcast over RCCL.  Rank 0 prints ONE JSON line.
+Workloads (`--config`, default `auto` = c3 on one GPU, c4 on several):
+  c3  BASELINE configs[2]: `--batch` (1024) synthetic 2-ZARC spectra per GPU, shared 256-point frequency grid, 512-point
+      tau grid.  A step = one full QPHB fit (DRT._qphb_fit_core: scaling, initial-weights QP, hyper-parameter loop to
+      convergence, final q) of the batch, inputs resident in HBM when the timed region starts.  Weak scaling over ranks.
+  c4  BASELINE configs[3]: ONE map of `--total` (10 000) spectra sharded over the ranks (interleaved shards, every rank
+      splits its share over `--inflight` plans), a step = upload + fit + download on every rank + one gather of the
+      results on rank 0, all inside the timed region.  Strong scaling.
+Rank 0 prints ONE JSON line.  `value` is always whole-job fits per second.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,30 +29,69 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # vendor dense FP64 matrix peak (the guide lists no FP64 row)
+QP_KERNEL = "qp_kernel_resident"          # as rocprofv3 prints it (hipdrt::qp_kernel_resident(hipdrt::QpArgs, int))
 
 
 def qp_algorithmic_flop(n, qp_iters_total, n_qp):
-    """per IPM iteration one Cholesky n^3/3 + two KKT solves (2 triangular solves each, 2n^2)
-    + one P x (2n^2); each QP adds the start-point factorisation + one solve."""
+    """per IPM iteration one Cholesky n^3/3 + two KKT solves of 2 n^2 each; every QP adds the start-point
+    factorisation with one solve."""
     fact = (qp_iters_total + n_qp) * (n ** 3 / 3.0)
-    solves = (2 * qp_iters_total + n_qp) * (2 * 2.0 * n * n)
-    matvec = (qp_iters_total + n_qp) * (2.0 * n * n)
-    return fact + solves + matvec
+    solves = (2 * qp_iters_total + n_qp) * (2.0 * n * n)
+    return fact + solves
 
 
-def cpu_baseline(freq, tau, z, seconds_budget=20.0, ref_structure_budget=12.0):
-    """The oracle (CPU restatement, checker) timed on this host, one BLAS thread, bounded sample.  Two numbers
-    (SURVEY.md 8d): the optimised restatement (structure='fast': elementwise scalings, G = -I specialisation) is the
-    reported baseline; 'reference_structure' mirrors the reference's own dense diag products (the O(n^3) work per
-    outer iteration that hybrid-drt actually does) on a smaller sample."""
-    from oracle import drt_oracle as orc
-    try:
+def source_hash():
+    """sha256 over the library's sources: stamps PMC traffic figures (profiles/qp_traffic.json) with the code they were
+    measured on -- a figure from other sources is reported as null, not silently carried along."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "hybrid-drt_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".hpp")) or name == "Makefile":
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    with open(os.path.join(ROOT, "include", "hipdrt.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ---- CPU baseline (the oracle = CPU restatement, used here as the thing timed beside the GPU; checker otherwise) --------
+_POOL = {}
+
+
+def _pool_init(freq, tau, z):
+    try:                            # (again in every forked worker: the BLAS re-creates its thread pool after a fork)
         from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
+        _POOL["limit"] = threadpool_limits(limits=1)
     except Exception:           # pragma: no cover
-        limiter = None
+        pass
+    if "drt" in _POOL:              # forked worker: the parent's prepared oracle came along
+        return
+    from oracle import drt_oracle as orc
     drt = orc.OracleDRT(fixed_basis_tau=tau)
     drt.prepare(freq)
+    _POOL.update(drt=drt, freq=freq, z=z)
+
+
+def _pool_work(args):
+    first, stride, budget = args
+    drt, freq, z = _POOL["drt"], _POOL["freq"], _POOL["z"]
+    done, t0, i = 0, time.perf_counter(), first
+    while time.perf_counter() - t0 < budget:
+        drt.fit_eis(freq, z[i % len(z)], structure='fast')
+        done += 1
+        i += stride
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(freq, tau, z, seconds_budget=20.0, ref_structure_budget=10.0, procs=None):
+    """The oracle timed on this host BEFORE the GPU is touched (the pool forks): (i) one process, one BLAS thread;
+    (ii) all host cores: a process pool over spectra, one BLAS thread each -- `cores` = the processes actually used;
+    (iii) 'reference_structure' mirrors the reference's own dense diag products (the O(n^3) work per outer iteration that
+    hybrid-drt itself does) on a smaller sample, one process."""
+    import multiprocessing as mp
+    _pool_init(freq, tau, z)
+    drt = _POOL["drt"]
 
     def timed(structure, budget):
         done, t0 = 0, time.perf_counter()
@@ -61,11 +104,27 @@ def cpu_baseline(freq, tau, z, seconds_budget=20.0, ref_structure_budget=12.0):
 
     done, dt = timed('fast', seconds_budget)
     rdone, rdt = timed('reference', ref_structure_budget)
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
+    ncpu = os.cpu_count() or 1
+    procs = ncpu if not procs else min(procs, ncpu)
+    allc = None
+    try:
+        ctx = mp.get_context("fork")            # nothing GPU-side exists yet in this process; children never touch it
+        t0 = time.perf_counter()
+        with ctx.Pool(procs, initializer=_pool_init, initargs=(freq, tau, z)) as pool:
+            t_up = time.perf_counter() - t0
+            parts = pool.map(_pool_work, [(i, procs, seconds_budget) for i in range(procs)], chunksize=1)
+        fits = sum(p[0] for p in parts)
+        wall = max(p[1] for p in parts)
+        allc = dict(value=fits / wall, unit="fits/s", cores=procs, kind="port",
+                    sample=f"{fits} fits of the batch's spectra in {wall:.1f} s: {procs} worker processes (one per host "
+                           f"cpu of {ncpu}), one BLAS thread each, every worker looping over its own stride of the batch; "
+                           f"pool start-up {t_up:.1f} s not counted")
+    except Exception as e:          # noqa: BLE001 -- a box that cannot fork that many workers still reports the 1-core leg
+        allc = dict(value=None, unit="fits/s", cores=0, kind="port", sample=f"process pool failed: {e!r}")
     return dict(value=done / dt, unit="fits/s", cores=1, kind="port",
                 sample=f"first {done} of the batch's spectra (256x512, full QPHB loop), oracle/drt_oracle.py "
-                       f"structure='fast', 1 BLAS thread, {dt:.1f} s on {os.cpu_count()} host cpus",
+                       f"structure='fast', 1 process, 1 BLAS thread, {dt:.1f} s",
+                all_cores=allc,
                 reference_structure=dict(value=rdone / rdt, unit="fits/s", cores=1,
                                          sample=f"first {rdone} spectra, structure='reference' (the reference's dense "
                                                 f"diag products restated one-for-one), 1 BLAS thread, {rdt:.1f} s"))
@@ -76,29 +135,51 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="spectra per GPU per step")
+    ap.add_argument("--config", choices=("auto", "c3", "c4"), default="auto",
+                    help="c3 = configs[2] (1024 spectra per GPU, weak), c4 = configs[3] (one 10 000-spectrum map sharded "
+                         "over the ranks, strong); auto = c3 on one GPU, c4 on several")
+    ap.add_argument("--batch", type=int, default=1024, help="c3: spectra per GPU per step")
+    ap.add_argument("--total", type=int, default=10000, help="c4: spectra of the whole map")
+    ap.add_argument("--shard", choices=("block", "interleave", "lpt"), default="interleave", help="c4: shard scheme")
     ap.add_argument("--inflight", type=int, default=4,
-                    help="batches kept in flight per GPU (each on its own plan + HIP stream); steps are dealt "
-                         "round-robin to them, so the low-occupancy tail of one step overlaps the next step")
+                    help="batches kept in flight per GPU (each on its own plan + HIP stream); c3: steps are dealt "
+                         "round-robin to them; c4: every rank's share is split over them")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the all-cores CPU leg (0 = all cpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix-build", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the single-spectrum and config-5 timings")
     args = ap.parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    config = args.config if args.config != "auto" else ("c3" if world_env == 1 else "c4")
 
     lib = os.path.join(ROOT, "hybrid-drt_amd", "libhipdrt.so")
     if not os.path.exists(lib) and "HIPDRT_LIB" not in os.environ:      # fresh checkout: build the (git-ignored) library once
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             import __graft_entry__
-            __graft_entry__.build()
+            __graft_entry__.build()                  # the Makefile moves the finished file into place atomically
         else:
             for _ in range(1200):
                 if os.path.exists(lib):
                     break
                 time.sleep(0.5)
-            time.sleep(2.0)
-    import torch
+            else:
+                raise SystemExit("bench.py: libhipdrt.so did not appear (did rank 0's build fail?)")
+
     from hipdrt import synth
+    cfg = synth.config_c2()
+    freq, tau = cfg["freq"], cfg["tau"]
+    rank_env = int(os.environ.get("RANK", "0"))
+
+    # ---- CPU legs first: the process pool forks, so it must run before anything in this process has opened the GPU ----
+    cpu = None
+    if rank_env == 0 and world_env == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(freq, tau, synth.zarc2_batch(freq, 64, first_seed=0), procs=args.cpu_procs)
+
+    import threading
+    import torch
+    from hipdrt import _ffi
     from hipdrt.mapping import dist as hd
+    from hipdrt.mapping.drtmd import shard_indices
     from hipdrt.models import DRT
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -109,18 +190,27 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    cfg = synth.config_c2()
-    freq, tau = cfg["freq"], cfg["tau"]
-    B = args.batch
-    z = synth.zarc2_batch(freq, B, first_seed=rank * B)
+    if config == "c3":
+        B = args.batch
+        z = synth.zarc2_batch(freq, B, first_seed=rank * B)
+        nfl = max(1, min(args.inflight, max(args.steps, 1)))
+        chunks = [np.arange(B)] * nfl                        # every plan holds the whole batch
+        job_fits = world * B
+    else:
+        total = args.total
+        mine = shard_indices(total, world, rank, args.shard)
+        z_all = None
+        # every rank generates its own rows only (seed = global observation index)
+        z = np.concatenate([synth.zarc2_batch(freq, 1, first_seed=int(i)) for i in mine]) if len(mine) else \
+            np.zeros((0, len(freq)), dtype=complex)
+        nfl = max(1, min(args.inflight, max(len(mine), 1)))
+        chunks = np.array_split(np.arange(len(mine)), nfl)
+        B = len(mine)
+        job_fits = total
 
-    import threading
-    from hipdrt import _ffi
-    nfl = max(1, min(args.inflight, max(args.steps, 1)))
-    # one DRT + plan + HIP stream per in-flight batch; all hold the same resident inputs (a step = one full fit
-    # of `B` spectra; which plan runs it does not change the work)
+    # one DRT + plan + HIP stream per in-flight batch
     drts = [DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local)) for _ in range(nfl)]
-    plans = [d.stage_batch(freq, z) for d in drts]         # lookups + matrices built, spectra resident in HBM
+    plans = [d.stage_batch(freq, z[c]) for d, c in zip(drts, chunks)]     # lookups + matrices built, spectra resident
     drt, plan = drts[0], plans[0]
     if world > 1:                                         # rank 0's tables -> everyone (one RCCL broadcast)
         zr, zi = hd.broadcast_arrays([plan.get("lut_z_re"), plan.get("lut_z_im")], src=0)
@@ -132,92 +222,164 @@ def main():
             d.fit_staged()
 
     stats = [dict(qp_ms=0.0, qp_launch=0, phase={"gram": 0.0, "qp": 0.0, "hyper": 0.0}) for _ in range(nfl)]
+    results = [None] * nfl
 
-    def worker(i, nsteps):
+    def note(i):
+        tms, launches = plans[i].timings()
+        stats[i]["qp_ms"] += tms["qp"]
+        stats[i]["qp_launch"] += launches["qp"]
+        for k in stats[i]["phase"]:
+            stats[i]["phase"][k] += tms[k]
+
+    def worker_resident(i, nsteps):                       # c3: inputs resident, results stay on the device
         for _ in range(nsteps):
             drts[i].fit_staged()                          # returns after the plan's stream has drained
-            tms, launches = plans[i].timings()
-            stats[i]["qp_ms"] += tms["qp"]
-            stats[i]["qp_launch"] += launches["qp"]
-            for k in stats[i]["phase"]:
-                stats[i]["phase"][k] += tms[k]
+            note(i)
 
-    def timed(nfl_used):
-        share = [args.steps // nfl_used + (1 if i < args.steps % nfl_used else 0) for i in range(nfl_used)]
-        hd.barrier()
+    def worker_transfers(i, nsteps):                      # upload + fit + download per step (c4; c3's second leg)
+        for _ in range(nsteps):
+            plans[i].upload(z[chunks[i]])
+            drts[i].fit_staged()
+            results[i] = drts[i].collect_staged()
+            note(i)
+
+    def sync_all():
         torch.cuda.synchronize()
         for p_ in plans:
             p_.ctx.synchronize()
+
+    def timed_c3(nfl_used, worker):
+        share = [args.steps // nfl_used + (1 if i < args.steps % nfl_used else 0) for i in range(nfl_used)]
+        hd.barrier()
+        sync_all()
         t0 = time.perf_counter()
         threads = [threading.Thread(target=worker, args=(i, share[i])) for i in range(nfl_used)]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
-        for p_ in plans:
-            p_.ctx.synchronize()
-        torch.cuda.synchronize()
+        sync_all()
         hd.barrier()
         return hd.max_over_ranks(time.perf_counter() - t0)
 
-    elapsed = timed(nfl)
-    qp_ms = sum(s_["qp_ms"] for s_ in stats)
-    qp_launch = sum(s_["qp_launch"] for s_ in stats)
-    phase = {k: sum(s_["phase"][k] for s_ in stats) for k in ("gram", "qp", "hyper")}
-    # the same K steps strictly one after the other (one batch in flight), for reference
-    single_elapsed = None
-    if nfl > 1:
-        for s_ in stats:
-            s_.update(qp_ms=0.0, qp_launch=0, phase={"gram": 0.0, "qp": 0.0, "hyper": 0.0})
-        single_elapsed = timed(1)
-        qp_ms, qp_launch = stats[0]["qp_ms"], stats[0]["qp_launch"]      # roofline from the un-overlapped launches
+    counts = [len(shard_indices(args.total, world, r, args.shard)) for r in range(world)] if config == "c4" else None
+
+    def timed_c4():
+        hd.barrier()
+        sync_all()
+        t0 = time.perf_counter()
+        gathered = None
+        for _ in range(args.steps):
+            threads = [threading.Thread(target=worker_transfers, args=(i, 1)) for i in range(nfl)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if B:
+                part = np.concatenate([np.concatenate([r_["fit_x"], r_["R_inf"][:, None], r_["inductance"][:, None],
+                                                       r_["status"][:, None].astype(float)], axis=1) for r_ in results])
+            else:
+                part = np.zeros((0, len(tau) + 3))
+            gathered = hd.gather_rows(part, counts, dst=0)          # ONE collective per step
+        sync_all()
+        hd.barrier()
+        return hd.max_over_ranks(time.perf_counter() - t0), gathered
+
+    reset = lambda: [s_.update(qp_ms=0.0, qp_launch=0, phase={"gram": 0.0, "qp": 0.0, "hyper": 0.0}) for s_ in stats]  # noqa: E731
+    single_elapsed = transfer_elapsed = None
+    if config == "c3":
+        elapsed = timed_c3(nfl, worker_resident)
+        reset()
+        transfer_elapsed = timed_c3(nfl, worker_transfers)          # same steps with upload and download inside
+        reset()
+        single_elapsed = timed_c3(1, worker_resident)               # one batch in flight: un-overlapped launches
+        qp_ms, qp_launch = stats[0]["qp_ms"], stats[0]["qp_launch"]
         phase = dict(stats[0]["phase"])
+        steps_in_stats = args.steps
+        res = drt.collect_staged()
+    else:
+        elapsed, gathered = timed_c4()
+        if rank == 0:
+            assert gathered.shape == (args.total, len(tau) + 3) and np.isfinite(gathered).all()
+        qp_ms = sum(s_["qp_ms"] for s_ in stats)
+        qp_launch = sum(s_["qp_launch"] for s_ in stats)
+        phase = {k: sum(s_["phase"][k] for s_ in stats) for k in ("gram", "qp", "hyper")}
+        steps_in_stats = args.steps
+        res = results[0]
 
-    res = drt.collect_staged()
-    n = plan.n
-    n_qp = res["outer_iters"].astype(np.int64) + 1
-    flop_step = float(qp_algorithmic_flop(n, res["qp_iters_total"].astype(np.int64), n_qp).sum())
-    launches_step = qp_launch / max(args.steps, 1)
-    flop_per_launch = flop_step / launches_step
-    avg_launch_s = qp_ms / qp_launch / 1e3
-    achieved = flop_per_launch / avg_launch_s / 1e12
-
+    n, m = plan.n, plan.m
     out = None
     if rank == 0:
-        traffic = None
+        n_qp = res["outer_iters"].astype(np.int64) + 1
+        flop_batch = float(qp_algorithmic_flop(n, res["qp_iters_total"].astype(np.int64), n_qp).sum())   # one plan's batch
+        launches_batch = qp_launch / max(steps_in_stats, 1) / (1 if config == "c3" else nfl)
+        flop_per_launch = flop_batch / launches_batch
+        avg_launch_s = qp_ms / max(qp_launch, 1) / 1e3
+        achieved = flop_per_launch / avg_launch_s / 1e12
+        traffic, traffic_note = None, "no PMC figure committed"
         pmc = os.path.join(ROOT, "profiles", "qp_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and config == "c3":
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("source_hash") == source_hash() and rec.get("kernel") == QP_KERNEL:
+                    traffic, traffic_note = rec.get("hbm_bytes_per_launch"), "rocprofv3 --pmc passes on these sources (profiles/qp_traffic.json)"
+                else:
+                    traffic_note = "profiles/qp_traffic.json was measured on other sources or another kernel: not reported"
             except Exception:
-                traffic = None
-        value = world * B * args.steps / elapsed
+                traffic_note = "profiles/qp_traffic.json unreadable"
+        value = job_fits * args.steps / elapsed
+        nb = len(res["outer_iters"])
+        outer_sum = float(res["outer_iters"].sum())
+        gram_s = phase["gram"] / steps_in_stats / 1e3 / (1 if config == "c3" else nfl)
+        hyper_s = phase["hyper"] / steps_in_stats / 1e3 / (1 if config == "c3" else nfl)
+        gram_flop = (outer_sum + nb) * m * n * n            # lower triangle of A'WA: m n^2 per spectrum and QP
         out = {
             "metric": "DRT fits/sec (256 freq x 512 tau, batched)", "value": value, "unit": "fits/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if config == "c3" else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: {B} synthetic 2-ZARC spectra per GPU, shared "
-                                   f"256-point frequency grid x 512-point tau grid, full QPHB loop "
-                                   f"(DRT.fit_eis defaults, interp lookups)",
+            "config": {"workload": (f"BASELINE configs[2]: {B} synthetic 2-ZARC spectra per GPU, shared 256-point frequency "
+                                    f"grid x 512-point tau grid, full QPHB loop (DRT.fit_eis defaults, interp lookups), "
+                                    f"inputs resident in HBM") if config == "c3" else
+                                   (f"BASELINE configs[3]: one map of {args.total} synthetic 2-ZARC spectra (256 x 512) "
+                                    f"sharded over {world} rank(s) ({args.shard} shards), per step upload + full QPHB "
+                                    f"loop + download on every rank and one gather on rank 0"),
                        "batch_per_gpu": B, "nf": 256, "ntau": 512, "n_unknowns": n,
-                       "sharding": f"{world} rank(s) x {B} independent spectra, no data-path collective",
+                       "sharding": (f"{world} rank(s) x {B} independent spectra, no data-path collective" if config == "c3"
+                                    else f"{args.total} spectra over {world} rank(s), {counts} per rank, one all_gather "
+                                         f"of {len(tau) + 3} doubles per spectrum"),
                        "batches_in_flight_per_gpu": nfl,
                        "converged_fraction": float((res["status"] == 0).mean()),
                        "mean_outer_iterations": float(res["outer_iters"].mean()),
                        "mean_ipm_iterations_per_fit": float(res["qp_iters_total"].mean())},
-            "roofline": {"bound": "mfma", "kernel": "qp_kernel (batched coneqp: Cholesky + KKT solves)",
+            "roofline": {"bound": "mfma", "kernel": QP_KERNEL,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
-                         "launches_per_step": launches_step,
-                         # the same launch against the other roof: PMC bytes (profiles/qp_traffic.json) / HIP-event time
+                         "launches_per_step": launches_batch,
+                         "flop_convention": "SURVEY 8d: n^3/3 + 2*2*n^2 per IPM iteration, n^3/3 + 2 n^2 per start point",
+                         # the same launch against the other roof: PMC bytes / HIP-event time
                          "traffic_GBps": None if traffic is None else traffic / avg_launch_s / 1e9,
                          "traffic_frac_of_hbm_peak": None if traffic is None else traffic / avg_launch_s / 8e12},
-            "phase_ms_per_step": {k: v / args.steps for k, v in phase.items()},
+            "roofline_gram": {"bound": "mfma", "kernel": "gram_kernel", "ms_per_step": gram_s * 1e3,
+                              "achieved": gram_flop / max(gram_s, 1e-12) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": gram_flop / max(gram_s, 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                              "note": "m n^2 flop per spectrum and QP (lower triangle only; SURVEY's 2 m n^2 counts the "
+                                      "mirrored half as well: double this fraction for that convention)"},
+            "roofline_hyper": {"bound": "hbm", "kernel": "hyper_kernel", "ms_per_step": hyper_s * 1e3,
+                               "achieved": outer_sum * (m * n + m * m) * 8 / max(hyper_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": outer_sum * (m * n + m * m) * 8 / max(hyper_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                               "note": "algorithmic bytes = (m n + m^2) 8 per spectrum and outer iteration (the two "
+                                       "matrix-vector products of estimate_weights); the matrices are shared by the "
+                                       "batch and stay in L2 / Infinity Cache"},
+            "phase_ms_per_step": {k: v / steps_in_stats / (1 if config == "c3" else nfl) for k, v in phase.items()},
             "single_stream": None if single_elapsed is None else {
                 "value": world * B * args.steps / single_elapsed, "ms_per_step": single_elapsed / args.steps * 1e3,
                 "note": "same K steps with one batch in flight; roofline / phase timings are taken from this run"},
+            "with_transfers": None if transfer_elapsed is None else {
+                "value": world * B * args.steps / transfer_elapsed, "ms_per_step": transfer_elapsed / args.steps * 1e3,
+                "note": "same K steps with the upload of the spectra and the download of all results inside every step"},
         }
         if not args.no_matrix_build:
             # secondary roofline (north_star): batched Z'/Z'' build with per-spectrum frequency grids
@@ -242,8 +404,10 @@ def main():
             # 256 x 512, configs[4] one joint chrono + EIS fit with DOP (512 f + 4096 t x 1024 tau); wall time of the
             # second call (plans and lookup tables warm), inputs handed over as host arrays
             other = {}
+            z1 = synth.zarc2_batch(freq, 1, first_seed=0)
+            drt.fit_eis_batch(freq, z1)
             t0 = time.perf_counter()
-            one = drt.fit_eis_batch(freq, z[:1])
+            one = drt.fit_eis_batch(freq, z1)
             other["config1_single_spectrum_256x512"] = {"seconds": time.perf_counter() - t0,
                                                         "outer_iterations": int(one["outer_iters"][0])}
             meas = synth.hybrid_measurement(seed=0, n_pre=96, n_post=4000, nf=512)
@@ -257,10 +421,12 @@ def main():
                 "qp_seconds": tm5["qp"] / 1e3, "rows": int(d5.qphb_params["rm"].shape[0]),
                 "unknowns": int(d5.qphb_params["rm"].shape[1]), "outer_iterations": int(d5.qphb_params["outer_iterations"])}
             out["other_configs"] = other
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(freq, tau, z)
-            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-            out["cpu_baseline"]["gpu_over_reference_structure"] = value / out["cpu_baseline"]["reference_structure"]["value"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            cpu["gpu_over_cpu_core"] = value / cpu["value"]
+            if cpu["all_cores"] and cpu["all_cores"]["value"]:
+                cpu["gpu_over_all_cores"] = value / cpu["all_cores"]["value"]
+            cpu["gpu_over_reference_structure"] = value / cpu["reference_structure"]["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -104,6 +104,7 @@ SIGNATURES = {
     "hipdrt_plan_get_p_matrix": [_vp, C.c_int, _dp],
     "hipdrt_plan_distribution_var": [_vp, _dp, C.c_int, _dp, _ip],
     "hipdrt_plan_llh_terms": [_vp, _dp, _dp],
+    "hipdrt_plan_obs_llh_terms": [_vp, _dp, _dp],
     "hipdrt_plan_set_state": [_vp, _dp, _dp, _dp, _dp],
     "hipdrt_plan_continue": [_vp, C.POINTER(FitOpts), C.c_double, C.c_int],
     "hipdrt_plan_param_var": [_vp, _dp, _ip],
@@ -441,9 +442,12 @@ class Plan:
     def fit(self):
         _check(self._lib.hipdrt_plan_fit(self._h))
 
-    def llh_terms(self):
+    def llh_terms(self, stored=False):
+        """(rss, sum(log w)) per spectrum; stored=False: weights re-estimated from the current x (PFRT steps),
+        stored=True: the fit's own est_weights (DRT.evaluate_rss() / evaluate_llh() defaults)."""
         rss, slw = np.empty(self.batch), np.empty(self.batch)
-        _check(self._lib.hipdrt_plan_llh_terms(self._h, _p(rss), _p(slw)))
+        fn = self._lib.hipdrt_plan_obs_llh_terms if stored else self._lib.hipdrt_plan_llh_terms
+        _check(fn(self._h, _p(rss), _p(slw)))
         return rss, slw
 
     def set_state(self, x=None, rho=None, s=None, weights=None):

@@ -1020,7 +1020,13 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     return HIPDRT_OK;
 }
 
-int hipdrt_plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) {
+static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored);
+
+int hipdrt_plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) { return plan_llh_terms(p, rss, sum_log_w, 0); }
+
+int hipdrt_plan_obs_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) { return plan_llh_terms(p, rss, sum_log_w, 1); }
+
+static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored) {
     HIPDRT_REQUIRE(p && rss && sum_log_w, "NULL pointer");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
@@ -1028,7 +1034,7 @@ int hipdrt_plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) {
     const size_t bb = (size_t)p->B * sizeof(double);
     DevBuf d1, d2;
     HIPDRT_CHECK(d1.alloc(bb)); HIPDRT_CHECK(d2.alloc(bb));
-    TRY(launch_llh(st, p->state(), p->B, d1.d(), d2.d()));
+    TRY(launch_llh(st, p->state(), p->B, d1.d(), d2.d(), stored));
     LAUNCH_OK();
     HIPDRT_CHECK(hipMemcpyAsync(rss, d1.p, bb, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipMemcpyAsync(sum_log_w, d2.p, bb, hipMemcpyDeviceToHost, st));

@@ -720,7 +720,9 @@ int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage, int
 // Ingredients of DRT.evaluate_llh(weights=estimate_weights(x), x) (drt1d.py:4457-4496, qphb.py:1347-1377) as the PFRT
 // driver evaluates it after every step (drt1d.py:2618-2622): weights re-estimated from the current x alone
 // (est_weights=None), then rss = x'(WR)'(WR)x - 2 (Wy)'(WR)x + (Wy)'(Wy) and sum(log w).  grid = B.
-__global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict__ rss, double* __restrict__ slw) {
+// stored != 0: the weights are the fit's own est_weights instead (DRT.evaluate_llh() / evaluate_rss() with their default
+// arguments, which is what DRTMD.fit_observation records per observation, drtmd.py:259-260).
+__global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict__ rss, double* __restrict__ slw, int stored) {
     extern __shared__ double sm[];
     __shared__ double red[HNW];
     const int b = blockIdx.x, tid = threadIdx.x, n = st.n, m = st.m;
@@ -735,14 +737,19 @@ __global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict
     __syncthreads();
     for (int i = tid; i < m; i += HT) { const double r = yh[i] - rv[i]; r2[i] = r * r; }
     __syncthreads();
-    rows_matvec(st.vmm, m, m, m, r2, sh);
+    if (!stored) rows_matvec(st.vmm, m, m, m, r2, sh);
     __syncthreads();
     const double vf = st.var_floor[b];
     double a = 0.0, c2 = 0.0, d = 0.0, lw = 0.0;
     for (int i = tid; i < m; i += HT) {
-        double v = sh[i];
-        if (v < vf) v = vf;
-        const double w = fmax(1.0 / sqrt(v), 1e-10);
+        double w;
+        if (stored) {
+            w = st.est_w[(size_t)b * m + i];
+        } else {
+            double v = sh[i];
+            if (v < vf) v = vf;
+            w = fmax(1.0 / sqrt(v), 1e-10);
+        }
         const double wy = w * yh[i], wr = w * rv[i];
         a += wy * wy; c2 += wr * wy; d += wr * wr; lw += log(w);
     }
@@ -750,10 +757,10 @@ __global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict
     if (tid == 0) { rss[b] = a - 2.0 * c2 + d; slw[b] = lw; }
 }
 
-int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw) {
+int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw, int stored) {
     const size_t lds = (size_t)(st.n + 3 * st.m) * sizeof(double);
     if (int rc = set_lds(reinterpret_cast<const void*>(llh_kernel), lds)) return rc;
-    hipLaunchKernelGGL(llh_kernel, dim3(B), dim3(HT), lds, s, st, rss, slw);
+    hipLaunchKernelGGL(llh_kernel, dim3(B), dim3(HT), lds, s, st, rss, slw, stored);
     return 0;
 }
 

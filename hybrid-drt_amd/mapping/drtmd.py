@@ -10,23 +10,136 @@ def shard_bounds(num_obs, world_size, rank):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def fit_observations(drt, frequencies, z_obs, tau_supergrid=None, drt_var=False, **fit_kw):
+def difficulty_proxy(z_obs):
+    """Cheap stand-in for how many outer iterations a spectrum will take, known before any fit: the relative roughness of
+    the spectrum (second differences along frequency against its span).  Noisier spectra run longer hyper-parameter
+    loops (25 ... 50 outer iterations at C2 size), smooth ones converge early."""
+    z = np.asarray(z_obs)
+    d2 = np.abs(np.diff(z, n=2, axis=1)).mean(axis=1)
+    span = np.abs(z - z.mean(axis=1, keepdims=True)).max(axis=1)
+    return d2 / np.maximum(span, 1e-300)
+
+
+def shard_indices(num_obs, world_size, rank, scheme='interleave', cost=None):
+    """Observation indices owned by `rank`.
+    'block'      contiguous blocks (shard_bounds);
+    'interleave' rank r takes r, r + W, r + 2W, ... : neighbouring observations of a map (similar difficulty) are dealt
+                 to different ranks, and every rank gets ceil/floor(num_obs / W) of them;
+    'lpt'        longest-processing-time-first on `cost` (one value per observation, e.g. difficulty_proxy): observations
+                 sorted by descending cost, dealt in a serpentine so that the per-rank cost sums stay level and the counts
+                 differ by at most one.
+    The union over ranks is a permutation of range(num_obs) for every scheme."""
+    if scheme == 'block':
+        a, b = shard_bounds(num_obs, world_size, rank)
+        return np.arange(a, b)
+    if scheme == 'interleave':
+        return np.arange(rank, num_obs, world_size)
+    if scheme == 'lpt':
+        if cost is None:
+            raise ValueError("scheme 'lpt' needs one cost per observation")
+        order = np.argsort(-np.asarray(cost, dtype=float), kind='stable')
+        pos = np.arange(num_obs)
+        rnd, lane = pos // world_size, pos % world_size
+        owner = np.where(rnd % 2 == 0, lane, world_size - 1 - lane)     # serpentine: 0..W-1, W-1..0, ...
+        return np.sort(order[owner == rank])
+    raise ValueError(f"unknown sharding scheme {scheme!r}")
+
+
+def fit_observations(drt, frequencies, z_obs, tau_supergrid=None, drt_var=False, ignore_errors=True, llh_kw=None,
+                     **fit_kw):
     """Fit every observation (rows of z_obs) and scatter the coefficients into supergrid slots like
-    DRTMD.fit_observation does (drtmd.py:263-275): returns obs_x (B, len(supergrid)), obs_special dict,
-    and the raw result dict.  With ``drt_var=True`` the result dict also carries ``obs_drt_var`` (B, len(supergrid)),
-    the diagonal of estimate_distribution_cov(tau=tau_supergrid, extend_var=True) of every observation
-    (drtmd.py:278-279), and ``obs_drt_var_ok``."""
+    DRTMD.fit_observation does (drtmd.py:245-301): returns obs_x (B, len(supergrid)), obs_special dict, and the raw
+    result dict, which also carries what the reference keeps per observation:
+      obs_llh, obs_rss       DRT.evaluate_llh(**llh_kw) / evaluate_rss() of every fit (drtmd.py:259-260);
+      obs_tau_indices        (left, right) supergrid slots of the basis grid (drtmd.py:262-267);
+      obs_fit_status         True where the fit succeeded; obs_fit_errors: None or the exception the reference would have
+                             raised for that observation (cvxopt's ValueError at a singular start point), which
+                             ``ignore_errors=False`` raises for the first failed observation as upstream does
+                             (drtmd.py:292-301);
+      obs_drt_var(+_ok)      with ``drt_var=True``: diagonal of estimate_distribution_cov(tau=tau_supergrid,
+                             extend_var=True) (drtmd.py:278-279)."""
     res = drt.fit_eis_batch(frequencies, z_obs, **fit_kw)
+    num = z_obs.shape[0]
     basis_tau = res['basis_tau']
     if tau_supergrid is None:
         tau_supergrid = basis_tau
     tau_supergrid = np.asarray(tau_supergrid)
     left = int(np.argmin(np.abs(np.log(tau_supergrid) - np.log(basis_tau[0]))))
     right = left + len(basis_tau)
-    obs_x = np.zeros((z_obs.shape[0], len(tau_supergrid)))
-    obs_x[:, left:right] = res['fit_x']
-    obs_special = {'R_inf': res['R_inf'], 'inductance': res['inductance']}
+    ok = np.asarray(res['status']) >= 0
+    errors = [None if good else ValueError("Rank(A) < p or Rank([P; A; G]) < n") for good in ok]
+    if not ignore_errors and not ok.all():
+        bad = int(np.flatnonzero(~ok)[0])
+        print(f"Error encountered at obs_index {bad}")
+        raise errors[bad]
+    obs_x = np.zeros((num, len(tau_supergrid)))
+    obs_x[:, left:right] = np.where(ok[:, None], res['fit_x'], 0.0)
+    obs_special = {'R_inf': np.where(ok, res['R_inf'], 0.0), 'inductance': np.where(ok, res['inductance'], 0.0)}
+    llh, rss = drt.evaluate_obs_llh_rss_batch(**(llh_kw or {}))
+    res['obs_llh'], res['obs_rss'] = np.where(ok, llh, 0.0), np.where(ok, rss, 0.0)
+    res['obs_tau_indices'] = (left, right)
+    res['obs_fit_status'], res['obs_fit_errors'] = ok, errors
     if drt_var:
         res['obs_drt_var'], res['obs_drt_var_ok'] = drt.estimate_distribution_var_batch(tau=tau_supergrid,
                                                                                        extend_var=True)
+    return obs_x, obs_special, res
+
+
+_GATHER_KEYS = ('obs_llh', 'obs_rss', 'outer_iters', 'qp_iters_total', 'status')
+
+
+def fit_observations_sharded(drt, frequencies, z_obs, rank=None, world=None, tau_supergrid=None, scheme='interleave',
+                             drt_var=False, dst=0, fit=fit_observations, **fit_kw):
+    """BASELINE configs[3]: the observations of one map sharded over the ranks of a node (one process per GPU), every
+    rank fitting its share in one device batch, the results gathered on rank `dst` with ONE collective.
+
+    Every rank calls this with the same (frequencies, z_obs) -- or at least with its own rows valid -- and its own `drt`.
+    Returns on `dst` the same triple as fit_observations for ALL observations in their original order (result dict
+    reduced to the per-observation arrays obs_llh, obs_rss, outer_iters, qp_iters_total, status [, obs_drt_var]); None
+    elsewhere.  `scheme`: see shard_indices ('lpt' uses difficulty_proxy(z_obs)).  `fit` is the per-rank fit function
+    (the CPU tests inject a stand-in)."""
+    from . import dist as hd
+    if rank is None or world is None:
+        import torch.distributed as tdist
+        rank = tdist.get_rank() if tdist.is_initialized() else 0
+        world = tdist.get_world_size() if tdist.is_initialized() else 1
+    z_obs = np.asarray(z_obs)
+    num = z_obs.shape[0]
+    cost = difficulty_proxy(z_obs) if scheme == 'lpt' else None
+    owned = [shard_indices(num, world, r, scheme, cost) for r in range(world)]
+    mine = owned[rank]
+    if len(mine):
+        obs_x, obs_special, res = fit(drt, frequencies, z_obs[mine], tau_supergrid=tau_supergrid, drt_var=drt_var, **fit_kw)
+        cols = [obs_x, obs_special['R_inf'][:, None], obs_special['inductance'][:, None]]
+        cols += [np.asarray(res[k], dtype=float)[:, None] for k in _GATHER_KEYS]
+        if drt_var:
+            cols += [res['obs_drt_var'], np.asarray(res['obs_drt_var_ok'], dtype=float)[:, None]]
+        packed = np.concatenate(cols, axis=1)
+    else:
+        packed = None
+    # ranks without observations still take part in the collective: the row width comes from a rank that has some
+    width = hd.max_over_ranks(0 if packed is None else packed.shape[1])
+    if packed is None:
+        packed = np.zeros((0, int(width)))
+    counts = [len(o) for o in owned]
+    full = hd.gather_rows(packed, counts, dst=dst)
+    if rank != dst:
+        return None
+    order = np.concatenate(owned) if world > 1 else mine
+    out = np.empty_like(full)
+    out[order] = full                                    # back to the original observation order
+    # row = [obs_x (nsup) | R_inf | inductance | _GATHER_KEYS | obs_drt_var (nsup) | ok]  (the last two with drt_var)
+    nsup = (out.shape[1] - 2 - len(_GATHER_KEYS) - (1 if drt_var else 0)) // (2 if drt_var else 1)
+    obs_x = out[:, :nsup]
+    pos = nsup
+    obs_special = {'R_inf': out[:, pos], 'inductance': out[:, pos + 1]}
+    pos += 2
+    res = {}
+    for k in _GATHER_KEYS:
+        res[k] = out[:, pos] if k in ('obs_llh', 'obs_rss') else out[:, pos].astype(np.int64)
+        pos += 1
+    if drt_var:
+        res['obs_drt_var'] = out[:, pos:pos + nsup]
+        res['obs_drt_var_ok'] = out[:, pos + nsup] > 0.5
+    res['obs_fit_status'] = res['status'] >= 0
     return obs_x, obs_special, res

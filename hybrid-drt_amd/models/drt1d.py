@@ -159,6 +159,30 @@ class DRT(PreparedFitMixin):
         return o, hypers, kw
 
     # ---- the fits ------------------------------------------------------------------------------------------
+    def _qphb_fit_core(self, times, i_signal, v_signal, frequencies, z, **kw):
+        """DRT._qphb_fit_core(times, i_signal, v_signal, frequencies, z, **fit_kw) (drt1d.py:102-137), the call
+        DRTMD.fit_observation makes as ``drt1d._qphb_fit_core(*chrono_data, *eis_data, **fit_kw)`` (drtmd.py:253): which
+        data are None selects the EIS, chrono or joint fit, with the keyword names of _qphb_fit_core itself."""
+        has_chrono = times is not None
+        has_eis = frequencies is not None
+        if not has_chrono and not has_eis:
+            raise ValueError('At least one of (times, i_signal, v_signal) and (frequencies, z) must be provided')
+        if has_chrono and (i_signal is None or v_signal is None):
+            raise ValueError('times, i_signal and v_signal must be provided together')     # utils.validation.check_chrono_data
+        if has_eis and z is None:
+            raise ValueError('frequencies and z must be provided together')                # utils.validation.check_eis_data
+        if not has_chrono:
+            return self.fit_eis(frequencies, z, **kw)
+        if not has_eis:
+            kw = dict(kw)
+            for core, own in (('chrono_error_structure', 'error_structure'), ('chrono_vmm_epsilon', 'vmm_epsilon')):
+                if core in kw:
+                    kw[own] = kw.pop(core)
+            for eis_only in ('eis_error_structure', 'eis_vmm_epsilon', 'eis_reim_cor'):
+                kw.pop(eis_only, None)
+            return self.fit_chrono(times, i_signal, v_signal, **kw)
+        return self.fit_hybrid(times, i_signal, v_signal, frequencies, z, **kw)
+
     def fit_eis(self, frequencies, z, **kw):
         """DRT.fit_eis (drt1d.py:1215-1241) -> _qphb_fit_core (102-1104) for one spectrum."""
         frequencies = np.asarray(frequencies, dtype=float)
@@ -295,6 +319,19 @@ class DRT(PreparedFitMixin):
             out.append(self.continue_from_init(weight_factor=multiplier ** i, xtol=xtol, max_iter=max_iter,
                                                history_of=history_of))
         return out
+
+    def evaluate_obs_llh_rss_batch(self, marginalize_weights=True, alpha_0=2, beta_0=1):
+        """(DRT.evaluate_llh(), DRT.evaluate_rss()) with their default arguments (weights = the fit's est_weights, x = the
+        last iterate; drt1d.py:4433-4496) for every spectrum of the last fitted batch -- what DRTMD.fit_observation stores
+        as obs_llh / obs_rss (drtmd.py:259-260).  Residuals and both sums on the device."""
+        from scipy.special import loggamma
+        rss, slw = self._plan.llh_terms(stored=True)
+        if marginalize_weights:
+            alpha_n = alpha_0 - 1 + self._plan.m / 2
+            llh = alpha_0 * np.log(beta_0) - alpha_n * np.log(beta_0 + 0.5 * rss) + loggamma(alpha_n) - loggamma(alpha_0)
+        else:
+            llh = -0.5 * rss
+        return llh + slw, rss
 
     def evaluate_step_llh_batch(self, alpha_0=2, beta_0=1):
         """evaluate_llh(weights=estimate_weights(x), x) (drt1d.py:2618-2622) for the current x of every spectrum of

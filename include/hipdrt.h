@@ -252,6 +252,10 @@ int hipdrt_plan_get_history(hipdrt_plan* plan, double* hist_x, double* hist_rho,
  * (drt1d.py:2618-2622): out rss[B] = weighted residual sum of squares, sum_log_w[B] = sum(log(weights)).
  * llh = a0 ln b0 - an ln(b0 + rss/2) + lgamma(an) - lgamma(a0) + sum_log_w with an = a0 - 1 + m/2.                 */
 int hipdrt_plan_llh_terms(hipdrt_plan* plan, double* rss, double* sum_log_w);
+/* The same two sums with the fit's own est_weights (qphb_params['est_weights']) as the weights: DRT.evaluate_rss() and
+ * DRT.evaluate_llh() with their default arguments (hybdrt/models/drt1d.py:4433-4496), which DRTMD.fit_observation
+ * records for every observation as obs_rss / obs_llh (hybdrt/mapping/drtmd.py:259-260).                              */
+int hipdrt_plan_obs_llh_terms(hipdrt_plan* plan, double* rss, double* sum_log_w);
 
 /* Overwrite parts of the fitted batch's state on the device (NULL = keep): x[B][n] (also becomes the previous iterate),
  * rho[B][3], s[B][3][n], weights[B][m].  The inputs of drt1d._continue_from_init (x_init, rho_vector, s_vectors, weights). */

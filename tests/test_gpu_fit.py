@@ -173,6 +173,84 @@ def test_distribution_variance_vs_reference_fixture():
     # llh / rss of the single fit (host arithmetic on the downloaded state)
     assert drt.evaluate_rss() == pytest.approx(float(g["rss"]), rel=1e-6)
     assert drt.evaluate_llh() == pytest.approx(float(g["llh"]), rel=1e-7)
+    # the same two numbers from the device (what the batch driver records per observation, drtmd.py:259-260)
+    llh, rss = drt.evaluate_obs_llh_rss_batch()
+    assert rss[0] == pytest.approx(float(g["rss"]), rel=1e-6) and llh[0] == pytest.approx(float(g["llh"]), rel=1e-7)
+    assert rss[0] == pytest.approx(drt.evaluate_rss(), rel=1e-9)
+
+
+def test_fit_observations_records_what_drtmd_records():
+    """mapping.fit_observations: obs_llh / obs_rss per observation equal the single-fit evaluate_llh() / evaluate_rss(),
+    tau indices, fit status; a spectrum whose QP breaks down at its start point (all-NaN data) is flagged and zeroed
+    instead of taking the batch down, and ignore_errors=False raises the error the reference's QP raises"""
+    from hipdrt import synth
+    from hipdrt.mapping import fit_observations
+    from hipdrt.models import DRT
+    freq = np.logspace(6, -1, 71)
+    z = synth.zarc2_batch(freq, 6, first_seed=300)
+    supergrid = np.logspace(-9, 3, 121)
+    drt = DRT(tau_supergrid=supergrid)
+    obs_x, obs_special, res = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True)
+    assert res["obs_tau_indices"] == (12, 104) and res["obs_fit_status"].all() and res["obs_fit_errors"] == [None] * 6
+    assert res["obs_drt_var"].shape == (6, 121) and res["obs_drt_var_ok"].all()
+    one = DRT(tau_supergrid=supergrid)
+    for b in (0, 5):
+        one.fit_eis(freq, z[b])
+        assert res["obs_llh"][b] == pytest.approx(one.evaluate_llh(), rel=1e-9)
+        assert res["obs_rss"][b] == pytest.approx(one.evaluate_rss(), rel=1e-9)
+    zbad = z.copy()
+    zbad[2] = np.nan
+    obs_x, obs_special, res = fit_observations(drt, freq, zbad, tau_supergrid=supergrid)
+    assert res["obs_fit_status"].tolist() == [True, True, False, True, True, True]
+    assert isinstance(res["obs_fit_errors"][2], ValueError) and not obs_x[2].any() and res["obs_llh"][2] == 0
+    with pytest.raises(ValueError):
+        fit_observations(drt, freq, zbad, tau_supergrid=supergrid, ignore_errors=False)
+
+
+def test_qphb_fit_core_as_drtmd_calls_it():
+    """DRTMD.fit_observation's call, verbatim: drt1d._qphb_fit_core(*chrono_data, *eis_data, **fit_kw) with
+    chrono_data = (None, None, None) for an EIS observation (drtmd.py:253), (None, None) eis_data for a chrono one"""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    g = load("refrun_golden71x91.npz")
+    chrono_data, eis_data = (None, None, None), (g["freq"], g["z"])
+    fit_kw = dict(nonneg=True, eis_error_structure=None, max_iter=50)
+    drt1d = DRT()
+    drt1d._qphb_fit_core(*chrono_data, *eis_data, **fit_kw)
+    ref = DRT()
+    ref.fit_eis(g["freq"], g["z"])
+    np.testing.assert_array_equal(drt1d.fit_parameters["x"], ref.fit_parameters["x"])
+    assert drt1d.fit_type == "qphb_eis"
+    meas = synth.hybrid_measurement(seed=0)
+    hyb, hyb_ref = DRT(warn=False), DRT(warn=False)
+    hyb._qphb_fit_core(*meas[:3], *meas[3:], max_iter=6)
+    hyb_ref.fit_hybrid(*meas, max_iter=6)
+    np.testing.assert_array_equal(hyb.fit_parameters["x"], hyb_ref.fit_parameters["x"])
+    chr_, chr_ref = DRT(warn=False), DRT(warn=False)
+    chr_._qphb_fit_core(*meas[:3], None, None, chrono_error_structure='uniform', max_iter=6)
+    chr_ref.fit_chrono(*meas[:3], max_iter=6)
+    np.testing.assert_array_equal(chr_.fit_parameters["x"], chr_ref.fit_parameters["x"])
+    with pytest.raises(ValueError):
+        DRT()._qphb_fit_core(None, None, None, None, None)
+
+
+def test_vector_weight_factor_in_a_batch():
+    """a vector-valued weight_factor (one factor per data row, drt1d.py:889-901) with more than one spectrum in the plan: every
+    member equals the same spectrum fitted alone with that vector (the C side once read capacity * m doubles from the
+    m-vector)"""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    freq = np.logspace(6, -1, 71)
+    z = synth.zarc2_batch(freq, 5, first_seed=500)
+    wf = np.ones(2 * len(freq))
+    wf[[3, 40, 3 + 71, 40 + 71]] = 1e-10
+    batch = DRT().fit_eis_batch(freq, z, weight_factor=wf)
+    for b in (0, 4):
+        one = DRT().fit_eis_batch(freq, z[b:b + 1], weight_factor=wf)
+        np.testing.assert_array_equal(batch["x"][b], one["x"][0])
+        assert batch["outer_iters"][b] == one["outer_iters"][0]
+    plain = DRT().fit_eis_batch(freq, z)
+    assert np.abs(plain["x"] - batch["x"]).max() > 0
 
 
 def test_distribution_variance_batch_256x512():
@@ -399,3 +477,31 @@ def test_full_size_equivariance_properties():
     np.testing.assert_array_equal(res2["coefficient_scale"], (res["coefficient_scale"] * factor)[perm])
 
 
+
+
+@pytest.mark.timeout(1200)
+def test_config4_ten_thousand_spectra_through_the_sharded_driver():
+    """BASELINE configs[3] on one GPU: 10 000 spectra (256 x 512) through mapping.fit_observations_sharded (world 1), i.e.
+    the function every rank runs on a multi-GPU node.  Size-independent properties for all of them -- finite, strictly
+    interior, outer iterations within [2, 50], converged fraction, llh / rss recorded -- and eight sampled spectra against
+    the CPU checker (same outer and interior-point iteration counts, coefficients within 1e-7 of the peak)."""
+    from hipdrt import synth
+    from hipdrt.mapping import fit_observations_sharded
+    from hipdrt.models import DRT
+    from oracle import drt_oracle as orc
+    c2 = synth.config_c2()
+    B = 10000
+    z = synth.zarc2_batch(c2["freq"], B)
+    drt = DRT(fixed_basis_tau=c2["tau"])
+    obs_x, obs_special, res = fit_observations_sharded(drt, c2["freq"], z, rank=0, world=1, scheme='lpt')
+    assert obs_x.shape == (B, 512) and np.isfinite(obs_x).all() and (obs_x > 0).all()
+    assert res["outer_iters"].min() >= 2 and res["outer_iters"].max() <= 50
+    assert np.isin(res["status"], (0, 1)).all() and (res["status"] == 0).mean() > 0.85 and res["obs_fit_status"].all()
+    assert np.isfinite(res["obs_llh"]).all() and (res["obs_rss"] > 0).all()
+    for b in (0, 1, 777, 2048, 4999, 5000, 8191, 9999):
+        od = orc.OracleDRT(fixed_basis_tau=c2["tau"])
+        ofp = od.fit_eis(c2["freq"], z[b], keep_history=True)
+        assert res["outer_iters"][b] == od.qphb_params["outer_iterations"], b
+        assert res["qp_iters_total"][b] == sum(l["iterations"] for l in od.qp_log), b
+        close_to_peak(obs_x[b], ofp["x"])
+        np.testing.assert_allclose(obs_special["R_inf"][b], ofp["R_inf"], rtol=1e-7)

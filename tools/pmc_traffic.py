@@ -24,6 +24,8 @@ def fold(path, counter, kernel):
 def main():
     fetch_csv, write_csv = sys.argv[1], sys.argv[2]
     kernel = sys.argv[3] if len(sys.argv) > 3 else "qp_kernel_resident"
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_hash
     fetch_kb, nf = fold(fetch_csv, "FETCH_SIZE", kernel)
     write_kb, nw = fold(write_csv, "WRITE_SIZE", kernel)
     if nf == 0 or nw == 0:
@@ -32,6 +34,7 @@ def main():
     write_b = write_kb * 1024.0 / nw
     out = {
         "kernel": kernel,
+        "source_hash": source_hash(),      # bench.py reports this figure only while the library's sources are these
         "launches": nf,
         "fetch_size_kb_sum": fetch_kb,
         "write_size_kb_sum": write_kb,

@@ -41,6 +41,28 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// 16 bytes per lane from (wave-uniform base) + (per-lane byte offset), issued as ONE instruction the compiler neither
+// moves nor waits for: the rank-k loops below keep several half-chunks in flight and count vmcnt by hand (hipcc's own
+// schedule gathers all loads of an unrolled body at its top and drains them with vmcnt(0) at its bottom, so nothing
+// stays in flight across iterations).  Every use of the result must come after an explicit vm_wait<N>().
+static __device__ __forceinline__ v2d gload16(const char* sbase, unsigned voff) {
+    v2d d;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    return d;
+}
+template <int N>
+static __device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);      // register-only consumers (MFMA) must not be hoisted above the wait
+}
+static __device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_d(double v) {     // quad_perm 0x00-0xFF, row_ror:n = 0x120 + n
     const int lo = __double2loint(v), hi = __double2hiint(v);
@@ -206,6 +228,9 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     const double resz0 = fmax(1.0, sqrt(nq[1]));
 
     PROF_DECL
+#ifdef HIPDRT_QP_PROFILE
+    const unsigned long long _rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz: slot 13 / slot 10 gives the shader clock
+#endif
     int status = HIPDRT_QP_MAXITER, iters = 0;
     double pcost = 0.0, gap = 0.0;
 
@@ -425,13 +450,16 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     }
 
     PROF(10);
+#ifdef HIPDRT_QP_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_qp_prof[13], __builtin_amdgcn_s_memrealtime() - _rt0);
+#endif
     if (leader) {
 #pragma unroll
         FOR_E if (VALID) a.x[(size_t)b * n + i] = x[i];
     }
     if (tid == 0 && leader) {
 #ifdef HIPDRT_QP_PROFILE
-        if (b == 0) atomicAdd(&g_qp_prof[11], (unsigned long long)(iters + 1));
+        if (blockIdx.x == 0) atomicAdd(&g_qp_prof[11], (unsigned long long)(iters + 1));      // the workgroup the tick counters follow
 #endif
         if (a.iters) a.iters[b] = iters;
         if (a.pcost) a.pcost[b] = pcost;

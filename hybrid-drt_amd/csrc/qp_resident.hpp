@@ -279,15 +279,19 @@ struct OpsResident {
                     e11 = init_tile(R2, R2, ntr, fo, li, kq);      e21 = init_tile(R3, R2, ntr, fo, li, kq);
                     e22 = init_tile(R3, R3, ntr, fo, li, kq);
                     if (jb > 0) {
-                        const double2* q0 = tile2(tb, 0) + fo;
-                        const double2* q1 = tile2(tb + 1, 0) + fo;
-                        const double2* q2 = tile2(R2, 0) + fo;
-                        const double2* q3 = tile2(v3 ? R3 : R2, 0) + fo;
-                        struct Frag { double2 b0a, b0b, b1a, b1b, a2a, a2b, a3a, a3b; };
-                        auto loadf = [&](Frag& f_, int c) {
-                            const int o = c * (TSZ / 2);
-                            f_.b0a = q0[o]; f_.b0b = q0[o + 64]; f_.b1a = q1[o]; f_.b1b = q1[o + 64];
-                            f_.a2a = q2[o]; f_.a2b = q2[o + 64]; f_.a3a = q3[o]; f_.a3b = q3[o + 64];
+                        // hand-pipelined operand ring (qp_common.hpp: gload16 / vm_wait): half-chunks of 8 columns, the
+                        // four operand tiles requested three half-chunks ahead (4 loads per step -> vmcnt(12))
+                        const char* q0 = uniform_ptr(tile2(tb, 0));
+                        const char* q1 = uniform_ptr(tile2(tb + 1, 0));
+                        const char* q2 = uniform_ptr(tile2(R2, 0));
+                        const char* q3 = uniform_ptr(tile2(v3 ? R3 : R2, 0));
+                        const unsigned voff = (unsigned)fo * 16u;
+                        struct Frag { v2d b0, b1, a2, a3; };
+                        const int nk2 = 2 * nc, klast = nk2 - 1;
+                        auto loadf = [&](Frag& f_, int k2) {
+                            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+                            f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
+                            f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
                         };
 #define HIPDRT_STEP7(B0, B1, A2, A3)                                                                    \
                         p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);               \
@@ -298,20 +302,22 @@ struct OpsResident {
                         e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);               \
                         e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);
                         auto multf = [&](const Frag& f_) {
-                            HIPDRT_STEP7(f_.b0a.x, f_.b1a.x, f_.a2a.x, f_.a3a.x)
-                            HIPDRT_STEP7(f_.b0a.y, f_.b1a.y, f_.a2a.y, f_.a3a.y)
-                            HIPDRT_STEP7(f_.b0b.x, f_.b1b.x, f_.a2b.x, f_.a3b.x)
-                            HIPDRT_STEP7(f_.b0b.y, f_.b1b.y, f_.a2b.y, f_.a3b.y)
+                            HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
+                            HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
+                            __builtin_amdgcn_sched_barrier(0);
                         };
 #undef HIPDRT_STEP7
-                        Frag fa, fb;
-                        loadf(fa, 0);
-                        for (int c = 0; c < nc; c += 2) {
-                            loadf(fb, c + 1);
-                            multf(fa);
-                            if (c + 2 < nc) loadf(fa, c + 2);
-                            multf(fb);
+                        Frag f0, f1, f2, f3;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+                        __builtin_amdgcn_sched_barrier(0);
+                        loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
+                        for (int k2 = 0; k2 < nk2; k2 += 4) {           // nk2 = 4 jb: a multiple of 4
+                            loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
+                            loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
+                            loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
+                            loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
                         }
+                        vm_wait<0>();
                         if (!v3) {
                             // R3 is pure padding (its operand was a stand-in): no panel tiles, identity diagonal
                             p30 = (v4d){0, 0, 0, 0}; p31 = (v4d){0, 0, 0, 0}; e21 = (v4d){0, 0, 0, 0};
@@ -405,45 +411,58 @@ struct OpsResident {
                         for (int ct = 0; ct < 2; ++ct)
                             acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
                     if (jb > 0 && act[0]) {
-                        const double2* pb0 = tile2(tb, 0) + fo;
-                        const double2* pb1 = tile2(two ? tb + 1 : tb, 0) + fo;   // stand-in when the row is padding
-                        const double2* pa[RMAXT];
+                        // Hand-pipelined operand ring (qp_common.hpp: gload16 / vm_wait), half-chunks of 8 columns: the A
+                        // tiles (this wavefront's own rows, from HBM) are requested THREE half-chunks ahead, the B tiles
+                        // (the block's two tile rows, shared by all wavefronts: L1 / L2) one ahead.  Per step 2 B + 4 A loads,
+                        // B first, so "B of this step has arrived" is vmcnt(10): A(k+2), B(k+1), A(k+3) may still be in
+                        // flight.  Indices past the end are clamped (a redundant load) so that the counts stay uniform.
+                        const char* rb0 = uniform_ptr(tile2(tb, 0));
+                        const char* rb1 = uniform_ptr(tile2(two ? tb + 1 : tb, 0));      // stand-in when the row is padding
+                        const char* ra[RMAXT];
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) pa[u] = tile2(act[u] ? T[u] : tb, 0) + fo;
-                        struct Slab { double2 b0a, b0b, b1a, b1b, aa[RMAXT], ab[RMAXT]; };
-                        auto load = [&](Slab& s_, int c) {          // c = k-chunk index (16 columns)
-                            const int o = c * (TSZ / 2);
-                            s_.b0a = pb0[o]; s_.b0b = pb0[o + 64];
-                            s_.b1a = pb1[o]; s_.b1b = pb1[o + 64];
+                        for (int u = 0; u < RMAXT; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
+                        const unsigned voff = (unsigned)fo * 16u;
+                        struct SlA { v2d a[RMAXT]; };
+                        struct SlB { v2d b0, b1; };
+                        const int nk2 = 2 * nc, klast = nk2 - 1;
+                        auto loadA = [&](SlA& s_, int k2) {
+                            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
 #pragma unroll
-                            for (int u = 0; u < RMAXT; ++u) { s_.aa[u] = pa[u][o]; s_.ab[u] = pa[u][o + 64]; }
+                            for (int u = 0; u < RMAXT; ++u) s_.a[u] = gload16(ra[u] + o, voff);
                         };
-                        auto mult = [&](const Slab& s_) {
+                        auto loadB = [&](SlB& s_, int k2) {
+                            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+                            s_.b0 = gload16(rb0 + o, voff); s_.b1 = gload16(rb1 + o, voff);
+                        };
+                        auto mult = [&](const SlA& a_, const SlB& b_) {
 #pragma unroll
                             for (int u = 0; u < RMAXT; ++u) {
                                 if (act[u]) {
-                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0a.x, s_.aa[u].x, acc[u][0], 0, 0, 0);
-                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0a.y, s_.aa[u].y, acc[u][0], 0, 0, 0);
-                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0b.x, s_.ab[u].x, acc[u][0], 0, 0, 0);
-                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0b.y, s_.ab[u].y, acc[u][0], 0, 0, 0);
-                                    if (two) {
-                                        acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1a.x, s_.aa[u].x, acc[u][1], 0, 0, 0);
-                                        acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1a.y, s_.aa[u].y, acc[u][1], 0, 0, 0);
-                                        acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1b.x, s_.ab[u].x, acc[u][1], 0, 0, 0);
-                                        acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1b.y, s_.ab[u].y, acc[u][1], 0, 0, 0);
-                                    }
+                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b0.x, a_.a[u].x, acc[u][0], 0, 0, 0);
+                                    if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b1.x, a_.a[u].x, acc[u][1], 0, 0, 0);
                                 }
                             }
+#pragma unroll
+                            for (int u = 0; u < RMAXT; ++u) {
+                                if (act[u]) {
+                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b0.y, a_.a[u].y, acc[u][0], 0, 0, 0);
+                                    if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b1.y, a_.a[u].y, acc[u][1], 0, 0, 0);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         };
-                        // ping-pong prefetch over the 2*jb finished 16-column chunks (always an even count)
-                        Slab sa, sb;
-                        load(sa, 0);
-                        for (int c = 0; c < nc; c += 2) {
-                            load(sb, c + 1);
-                            mult(sa);
-                            if (c + 2 < nc) load(sa, c + 2);
-                            mult(sb);
+                        SlA a0, a1, a2, a3;
+                        SlB b0, b1;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+                        __builtin_amdgcn_sched_barrier(0);
+                        loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
+                        for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 4 jb: a multiple of 4
+                            loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<10>(); mult(a0, b0);
+                            loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<10>(); mult(a1, b1);
+                            loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<10>(); mult(a2, b0);
+                            loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<10>(); mult(a3, b1);
                         }
+                        vm_wait<0>();
                     }
                     if (ps == 0) {
                         __syncthreads();                            // (A) W1, L21, W2 published by wavefront 0

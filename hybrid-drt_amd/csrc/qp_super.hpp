@@ -40,28 +40,6 @@ static constexpr int SLD = 17;            // row stride of 16x16 LDS tiles
 static constexpr int STL = 16 * SLD;      // doubles per padded LDS tile (272)
 static constexpr int SUB = 3 * STL;       // doubles per inverse 32x32 block (Wa | Wba | Wb)
 
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-// 16 bytes per lane from (wave-uniform base) + (per-lane byte offset), issued as ONE instruction the compiler neither
-// moves nor waits for: the rank-k loops below keep several half-chunks in flight and count vmcnt by hand (hipcc's own
-// schedule gathers all loads of an unrolled body at its top and drains them with vmcnt(0) at its bottom, so nothing
-// stays in flight across iterations).  Every use of the result must come after an explicit vm_wait<N>().
-static __device__ __forceinline__ v2d gload16(const char* sbase, unsigned voff) {
-    v2d d;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
-    return d;
-}
-template <int N>
-static __device__ __forceinline__ void vm_wait() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);      // register-only consumers (MFMA) must not be hoisted above the wait
-}
-static __device__ __forceinline__ const char* uniform_ptr(const void* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const char*)(((unsigned long long)hi << 32) | lo);
-}
-
 struct SupSmem {
     double* red;     // [4][SNW][4]
     double* dsc;     // [16][SLD]      diagonal tile being factored

@@ -39,7 +39,7 @@ struct hipdrt_plan {
     // per spectrum
     DevBuf z_re, z_im, rv, w, est_w, x, x_in, q, s, rho, xmx, coef_scale, var_floor;
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
-    DevBuf P, L, Ptmp, qpstate, Ppk, order, vmm_base, qp_gstate, qp_gsync, qp_gvec;
+    DevBuf L, Ptmp, qpstate, Ppk, order, vmm_base;
     // history
     int hist_b = -1, hist_cap = 0;
     DevBuf hist_x, hist_w, hist_rho, hist_qp, hist_rows;
@@ -452,13 +452,6 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     a.Ppk = dPpk.d(); a.ppk_stride = p_batched ? (long long)qp_ppk_doubles(n) : 0; a.nchp = qp_nchp(n);
     HIPDRT_CHECK(dstate.alloc((size_t)B * qp_state_doubles(n) * sizeof(double)));
     a.state = dstate.d(); a.state_ld = qp_state_ld(n); a.state_stride = (long long)qp_state_doubles(n);
-    DevBuf dgstate, dgsync, dgvec;
-    if (qp_group_size(B, n) > 1) {
-        HIPDRT_CHECK(dgstate.alloc((size_t)qp_group_slots() * qp_state_doubles(n) * sizeof(double)));
-        HIPDRT_CHECK(dgsync.alloc((size_t)B * sizeof(int)));
-        HIPDRT_CHECK(dgvec.alloc((size_t)B * qp_state_ld(n) * sizeof(double)));
-        a.gstate = dgstate.d(); a.gsync = dgsync.i(); a.gvec = dgvec.d();
-    }
     a.opts = opts ? *opts : default_qp_opts();
     TRY(launch_qp(st, a));
     HIPDRT_CHECK(hipMemcpyAsync(x, dx.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -561,13 +554,6 @@ static int plan_alloc_batch(hipdrt_plan* p) {
     for (DevBuf* ib : {&p->active, &p->outer_iters, &p->fit_status, &p->qp_iters_total, &p->qp_status, &p->qp_iters})
         HIPDRT_CHECK(ib->alloc(cap * sizeof(int)));
     HIPDRT_CHECK(p->n_active.alloc(sizeof(int)));
-    if (!qp_packed_only(n)) {
-        HIPDRT_CHECK(p->P.alloc(cap * n * p->ldp * sizeof(double)));
-        // scratch for running one large problem on several workgroups (qp.hip: qp_kernel_group)
-        HIPDRT_CHECK(p->qp_gstate.alloc((size_t)qp_group_slots() * qp_state_doubles(n) * sizeof(double)));
-        HIPDRT_CHECK(p->qp_gsync.alloc(cap * sizeof(int)));
-        HIPDRT_CHECK(p->qp_gvec.alloc(cap * qp_state_ld(n) * sizeof(double)));
-    }
     HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
     HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
@@ -890,12 +876,11 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
     qa.iters_accum = p->qp_iters_total.i(); qa.opts = p->opts.qp;
     qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);
-    qa.gstate = p->qp_gstate.d(); qa.gsync = p->qp_gsync.i(); qa.gvec = p->qp_gvec.d();
 
     // ---- initialize_weights (qphb.py:1609-1681): one un-weighted, weakly penalised QP; P is the same for
     //      every spectrum (weights = 1, s = s_0, rho = rho_0), only q differs -------------------------------
     tm.mark(1);
-    double* const Prow = qp_packed_only(n) ? nullptr : p->P.d();   // row-major P only for the multi-pass QP kernel
+    double* const Prow = nullptr;             // the QP reads P through its packed tile copy only (Ppk)
     const long long pstr = (long long)n * p->ldp, pkstr = (long long)qp_ppk_doubles(n);
     const int nc = p->prepared ? p->desc.num_chrono : 0;
     const bool separately = p->prepared && p->desc.init_weights_separately && nc > 0 && nc < m;
@@ -1090,8 +1075,7 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
     qa.iters_accum = p->qp_iters_total.i(); qa.opts = opts->qp;
     qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);
-    qa.gstate = p->qp_gstate.d(); qa.gsync = p->qp_gsync.i(); qa.gvec = p->qp_gvec.d();
-    double* const Prow = qp_packed_only(n) ? nullptr : p->P.d();
+    double* const Prow = nullptr;
     qa.P = Prow; qa.p_stride = (long long)n * p->ldp; qa.active = p->active.i();
     qa.Ppk = p->Ppk.d(); qa.ppk_stride = (long long)qp_ppk_doubles(n); qa.nchp = qp_nchp(n);
     for (int it = 0; it < opts->max_iter; ++it) {
@@ -1184,7 +1168,7 @@ static int plan_quadratic_forms(hipdrt_plan* p, const double* basis_eval, int ne
                                 int* status) {
     HIPDRT_REQUIRE(p->B > 0, "no fitted batch in the plan");
     HIPDRT_REQUIRE(neval >= 1, "neval >= 1");
-    HIPDRT_REQUIRE(qp_packed_only(p->n), "posterior variance is only built for n <= 528 unknowns");
+    HIPDRT_REQUIRE(p->n <= 2048, "posterior variance: n <= 2048");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
     const int n = p->n, m = p->m, B = p->B;

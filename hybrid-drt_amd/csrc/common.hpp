@@ -119,8 +119,6 @@ struct GramL2 {
     const double* dop_rho; // [B][3]
     double dop_dfac[3];    // dop_l2_lambda_0 * dop_derivative_weight[k]
 };
-// true when the QP for n unknowns runs on the kernel that reads P only through its packed tile copy (Ppk)
-bool qp_packed_only(int n);
 // a_stride: doubles between the response matrices of consecutive problems (0 = one shared matrix)
 void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const GramL2& g,
                     double* P, int ldp, long long p_stride, const int* active, double* Ppk = nullptr,
@@ -218,16 +216,8 @@ struct QpArgs {
     int state_ld;
     long long state_stride;
     hipdrt_qp_opts opts;
-    // optional: scratch for splitting one large problem (n > 528) over several workgroups when there are far fewer
-    // problems than CUs -- gstate: IPM iterates for qp_group_slots() workgroups, gsync: one barrier counter per problem
-    double* gstate = nullptr;
-    int* gsync = nullptr;
-    double* gvec = nullptr;        // [B][state_ld] meeting point of the split P x
 };
 int launch_qp(hipStream_t st, const QpArgs& a);
-// workgroups per problem launch_qp would use for B problems of n unknowns (1 = no grouping), and the scratch to provide
-int qp_group_size(int B, int n);
-inline int qp_group_slots() { return 256; }
 // posterior variance on an evaluation grid (qp_resident.hpp: cov_kernel_resident); Bex = evaluation rows as packed tiles
 int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long ppk_stride, const double* Bex, int nex,
                     double* L, long long l_stride, double* out, long long out_stride, int* status);

@@ -42,8 +42,13 @@ static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
 static constexpr int DLD = 17;           // row stride of the 16x16 LDS scratch blocks
 
-struct ResSmem {
-    double* U;       // [NP][PLD]   inverse diagonal blocks
+// GU = the inverse diagonal blocks U live in GLOBAL memory (per-problem scratch behind the factor, L2 resident) instead of
+// LDS: the only structure of this kernel whose size grows with n^1 x 33, i.e. what limits the LDS-resident form to
+// n <= 528.  With U outside, the same kernel serves every n <= 2048 (LDS then holds the two n-vectors and the small
+// fixed buffers: 39 kB).
+template <bool GU>
+struct ResSmemT {
+    double* U;       // [NP][PLD]   inverse diagonal blocks (LDS, or global when GU)
     double* vec;     // [NP + 32]
     double* dvec;    // [NP + 32]
     double* red;     // [4][RNW][4]
@@ -53,7 +58,7 @@ struct ResSmem {
     int* flag;       // [4]
 
     // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
-    static constexpr int VEC = 528 + 16 + 32;      // RNP_MAX + 16 + 32: NP <= 544
+    static constexpr int VEC = GU ? 2048 + 32 + 32 : 528 + 16 + 32;      // NP + 32 (NP <= 544, or <= 2080 with U outside)
     static constexpr int FIXED = 4 * (512 / 64) * 4 + 2 * 16 * 17 + 8 + 512 + 2 * VEC;   // doubles before U
     __device__ __forceinline__ void carve(double* smem) {
         red = smem;
@@ -67,8 +72,11 @@ struct ResSmem {
     }
 };
 
-struct OpsResident {
-    double* L; int nch; int n; ResSmem sm;                             // nch = tiles per tile-row (NP/16)
+using ResSmem = ResSmemT<false>;
+
+template <bool GU>
+struct OpsResidentT {
+    double* L; int nch; int n; ResSmemT<GU> sm;                        // nch = tiles per tile-row (NP/16)
     const double* Ppk; int nchp;                                       // P in L's tile layout (lower tiles)
     // Optional extra tile rows appended below the square matrix (tile rows nch .. nch+nex-1 of L, source tiles
     // Bex[nex][nchp][256]): the factorisation treats them as more panel rows, so they come out as Bex * L^-T --
@@ -607,6 +615,20 @@ struct OpsResident {
                             }
                         }
                     }
+                    if (GU) {
+                        // more tile rows below than the register buffers hold (n > 528): the rest straight from memory
+                        for (int tt = (wv - 1) + FT * UW; tt < tbelow; tt += UW) {
+                            const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;
+                            double pv = 0.0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { const double2 t_ = p[q * 64]; pv += t_.x * ya[q] + t_.y * yb[q]; }
+                            pv = quad_sum(pv);
+                            if (l4 == 0) {
+                                const int row = (tb + 2 + tt) * 16 + g4;
+                                if (row < n) vec[row] -= pv;
+                            }
+                        }
+                    }
                 }
                 fpre(B_, jb + 2);
                 lds_barrier();
@@ -699,6 +721,18 @@ struct OpsResident {
                             double s2 = B_.t[u][1].x * x0 + B_.t[u][3].x * x1;     // column 16c + 8 + l4
                             double s3 = B_.t[u][1].y * x0 + B_.t[u][3].y * x1;     // column 16c + 12 + l4
                             const double f = colsum4(s0, s1, s2, s3, lane);   // column 16c + l4 + 4*(lane>>4)
+                            if ((lane & 12) == 0) vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
+                        }
+                    }
+                    if (GU) {
+                        // more finished chunks than the register buffers hold (n > 528): the rest straight from memory
+                        for (int c = (wv - 1) + BC * UW; c < nc; c += UW) {
+                            const double2* p0 = tile2(tb, c) + lane;
+                            const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
+                            const double2 t0 = p0[0], t1 = p0[64], t2 = p1[0], t3 = p1[64];
+                            const double s0 = t0.x * x0 + t2.x * x1, s1 = t0.y * x0 + t2.y * x1;
+                            const double s2 = t1.x * x0 + t3.x * x1, s3 = t1.y * x0 + t3.y * x1;
+                            const double f = colsum4(s0, s1, s2, s3, lane);
                             if ((lane & 12) == 0) vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
                         }
                     }
@@ -820,15 +854,22 @@ struct CovArgs {
     int* status;                                         // [B]: 0 ok, -1 P not positive definite
 };
 
+// where U lives when it is not in LDS: behind the factor in the per-problem scratch (NP^2 doubles of tiles, then NP x 33)
+template <bool GU>
+__device__ __forceinline__ double* resident_u_ptr(double* Lb, int NP) { return Lb + (size_t)NP * NP; }
+
+template <bool GU>
 __global__ __launch_bounds__(RT) void cov_kernel_resident(CovArgs a, int NP) {
     const int b = blockIdx.x;
     extern __shared__ double smem[];
-    OpsResident ops;
+    OpsResidentT<GU> ops;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk + (size_t)b * a.ppk_stride; ops.nchp = a.nchp;
     ops.nex = a.nex; ops.Bex = a.Bex; ops.fwd = false;
-    constexpr int VEC = ResSmem::VEC;
+    constexpr int VEC = ResSmemT<GU>::VEC;
     ops.sm.carve(smem);
+    // with U outside LDS it sits behind the (nch + nex) x nch tiles of this spectrum's scratch
+    if (GU) ops.sm.U = ops.L + (size_t)(NP / 16 + a.nex) * (NP / 16) * TSZ;
     for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
     for (int i = threadIdx.x; i < VEC; i += RT) { ops.sm.vec[i] = 0.0; ops.sm.dvec[i] = 0.0; }   // no diagonal shift
     __syncthreads();
@@ -853,25 +894,34 @@ __global__ __launch_bounds__(RT) void cov_kernel_resident(CovArgs a, int NP) {
     }
 }
 
+template <bool GU>
 __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
     const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
     if (a.active && !a.active[b]) return;
     extern __shared__ double smem[];
-    OpsResident ops;
+    OpsResidentT<GU> ops;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk ? a.Ppk + (size_t)b * a.ppk_stride : nullptr; ops.nchp = a.nchp;
     ops.sm.carve(smem);
+    if (GU) ops.sm.U = resident_u_ptr<GU>(ops.L, NP);
     // zero U (the upper-right quarter of every inverse block stays zero) and the padding of vec (read by the
     // updates of the last, partial block)
     for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
     for (int i = threadIdx.x; i < NP + 32; i += RT) ops.sm.vec[i] = 0.0;
     __syncthreads();
     IpmSmem is{ops.sm.vec, ops.sm.dvec, ops.sm.red};
-    ipm_solve<RT, (RNP_MAX + RT - 1) / RT>(a, b, ops, is);
+    ipm_solve<RT, GU ? 2048 / RT : (RNP_MAX + RT - 1) / RT>(a, b, ops, is);
 }
 
+// LDS bytes: everything for n <= 528, only the fixed part when U lives in global memory
 static size_t resident_lds_bytes(int NP) {
     return ((size_t)NP * PLD + ResSmem::FIXED) * sizeof(double);
+}
+static size_t resident_gu_lds_bytes() { return (size_t)ResSmemT<true>::FIXED * sizeof(double); }
+// per-problem scratch doubles of the U-outside form: the tile-packed factor (NP^2) followed by U (NP x 33)
+static size_t resident_gu_doubles(int n) {
+    const size_t NP = (size_t)round_up(n, 32);
+    return NP * NP + NP * PLD;
 }
 
 // scratch doubles per problem for the tile-packed factor: (NP/16)^2 tiles of 256 doubles

@@ -236,10 +236,10 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* plan, int b, double* p);
  * normalisation), i.e. what DRTMD.fit_observation stores as obs_drt_var (hybdrt/mapping/drtmd.py:278-279) before its
  * extend_var post-processing.  basis_eval[neval][ntau] = basis.construct_func_eval_matrix(ln basis_tau, ln tau_eval).
  * For every fitted spectrum: final P (calculate_pq state), P = L L' on the device, out[b][i] = |L^-1 b_i|^2 * cs_b^2.
- * status[b] (may be NULL): 0 ok, -1 P not positive definite (the reference's LinAlgError -> None).  n <= 528 only. */
+ * status[b] (may be NULL): 0 ok, -1 P not positive definite (the reference's LinAlgError -> None).  n <= 2048. */
 int hipdrt_plan_distribution_var(hipdrt_plan* plan, const double* basis_eval, int neval, double* out, int* status);
 /* same machinery with the identity as evaluation rows: out[b][i] = diag(inv(P_b))_i * cs_b^2, the parameter variances
- * np.diag(DRT.estimate_param_cov()) (hybdrt/models/drt1d.py:4116-4138) of every fitted spectrum.  n <= 528 only.     */
+ * np.diag(DRT.estimate_param_cov()) (hybdrt/models/drt1d.py:4116-4138) of every fitted spectrum.  n <= 2048.          */
 int hipdrt_plan_param_var(hipdrt_plan* plan, double* out, int* status);
 
 /* per-outer-iteration history of spectrum b recorded when record_history was enabled before the fit:

@@ -1,4 +1,4 @@
-"""Throughput of batched fits that take the prepared-plan route: EIS + DOP at the config-2 grid (n = 564, multi-pass QP
+"""Throughput of batched fits that take the prepared-plan route: EIS + DOP at the config-2 grid (n = 564, tile-packed QP kernel with its inverse diagonal blocks in global memory
 kernel) and joint chrono + EIS fits.  python tools/probe_dop_batch.py [B]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""Diagnostic: one large QP (n > 528, multi-pass kernel) -- wall time per interior-point iteration and, with
+"""Diagnostic: one large QP (n > 528: tile-packed kernel, inverse diagonal blocks in global memory) -- wall time per interior-point iteration and, with
 HIPDRT_LIB=.../libhipdrt_prof.so, the in-kernel phase breakdown.  python tools/probe_qp_large.py [n] [B]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

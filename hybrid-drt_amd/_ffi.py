@@ -85,6 +85,7 @@ SIGNATURES = {
     "hipdrt_eis_var_matrix": [_vp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp],
     "hipdrt_qp_batch": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.POINTER(QpOpts), _dp, _ip, _dp, _ip],
     "hipdrt_qp_profile": [_vp, C.POINTER(C.c_ulonglong), C.c_int, C.c_int],
+    "hipdrt_debug_qp_occupancy": [_vp, C.c_int, C.c_int],
     "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -462,6 +462,11 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     return HIPDRT_OK;
 }
 
+int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n) {
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return -1;
+    return qp_occupancy(threads, n);
+}
+
 int hipdrt_qp_profile(hipdrt_ctx* ctx, unsigned long long* cycles, int n, int reset) {
     HIPDRT_REQUIRE(ctx && cycles, "NULL pointer");
     HIPDRT_CHECK(hipSetDevice(ctx->device));

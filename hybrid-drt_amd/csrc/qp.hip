@@ -21,7 +21,12 @@ size_t qp_scratch_ld(int n) { return (size_t)round_up(n, 16); }
 // doubles of factor scratch per problem: the tile-packed factor (the wider super-column layout up to n = 528), beyond
 // n = 528 followed by the inverse diagonal blocks
 size_t qp_scratch_doubles(int n) {
-    if (n <= RNP_MAX) { const size_t r = resident_l_doubles(n), s_ = super_l_doubles(n); return r > s_ ? r : s_; }
+    if (n <= RNP_MAX) {
+        size_t r = resident_l_doubles(n);
+        const size_t s_ = super_l_doubles(n), g_ = resident_gu_doubles(n);
+        if (s_ > r) r = s_;
+        return g_ > r ? g_ : r;           // (the U-outside form is also used for small n by the two-per-CU experiment)
+    }
     return resident_gu_doubles(n);
 }
 
@@ -146,6 +151,21 @@ int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long p
 size_t dist_var_scratch_doubles(int n, int nex) {
     const size_t nch = (size_t)round_up(n, 64) / 16;      // the super-column layout (the wider of the two)
     return (nch + (size_t)nex) * nch * TSZ + (n > RNP_MAX ? (size_t)round_up(n, 32) * PLD : 0);   // + U when it lives outside LDS
+}
+
+// diagnostic (tools/): resident workgroups per CU the runtime reports for the coneqp kernel of n unknowns
+int qp_occupancy(int threads, int n) {
+    const int NP = round_up(n, 32);
+    int nb = -1;
+    hipError_t e;
+    if (threads != 512) return -1;
+    if (n > RNP_MAX) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<true, 512>, 512, resident_gu_lds_bytes(512));
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_resident<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(NP));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<false, 512>, 512, resident_lds_bytes(NP));
+    }
+    return e == hipSuccess ? nb : -1;
 }
 
 int launch_qp(hipStream_t st, const QpArgs& a) {

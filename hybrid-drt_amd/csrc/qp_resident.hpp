@@ -46,7 +46,7 @@ static constexpr int DLD = 17;           // row stride of the 16x16 LDS scratch 
 // LDS: the only structure of this kernel whose size grows with n^1 x 33, i.e. what limits the LDS-resident form to
 // n <= 528.  With U outside, the same kernel serves every n <= 2048 (LDS then holds the two n-vectors and the small
 // fixed buffers: 39 kB).
-template <bool GU>
+template <bool GU, int RTT = 512>
 struct ResSmemT {
     double* U;       // [NP][PLD]   inverse diagonal blocks (LDS, or global when GU)
     double* vec;     // [NP + 32]
@@ -59,10 +59,10 @@ struct ResSmemT {
 
     // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
     static constexpr int VEC = GU ? 2048 + 32 + 32 : 528 + 16 + 32;      // NP + 32 (NP <= 544, or <= 2080 with U outside)
-    static constexpr int FIXED = 4 * (512 / 64) * 4 + 2 * 16 * 17 + 8 + 512 + 2 * VEC;   // doubles before U
+    static constexpr int FIXED = 4 * (RTT / 64) * 4 + 2 * 16 * 17 + 8 + 512 + 2 * VEC;   // doubles before U
     __device__ __forceinline__ void carve(double* smem) {
         red = smem;
-        t21 = red + 4 * (512 / 64) * 4;
+        t21 = red + 4 * (RTT / 64) * 4;
         dsc = t21 + 16 * 17;
         flag = reinterpret_cast<int*>(dsc + 16 * 17);
         img = dsc + 16 * 17 + 8;
@@ -74,9 +74,14 @@ struct ResSmemT {
 
 using ResSmem = ResSmemT<false>;
 
-template <bool GU>
+// RTT = threads per workgroup.  512 (8 wavefronts: chain, look-ahead, six row wavefronts; one workgroup per CU) is what
+// is built.  256 (chain, look-ahead, two row wavefronts, U in global memory, two workgroups per CU so that one's sequential
+// phases overlap the other's matrix work) compiles to 256 VGPRs and is parity-green, but measured 12.5 ms per launch against
+// 10.6: both workgroups put their row wavefronts on the same two SIMDs and every block column needs three to four passes.
+template <bool GU, int RTT = 512>
 struct OpsResidentT {
-    double* L; int nch; int n; ResSmemT<GU> sm;                        // nch = tiles per tile-row (NP/16)
+    static constexpr int RT = RTT, RNW = RTT / 64;                     // (shadow the namespace-level defaults)
+    double* L; int nch; int n; ResSmemT<GU, RTT> sm;                   // nch = tiles per tile-row (NP/16)
     const double* Ppk; int nchp;                                       // P in L's tile layout (lower tiles)
     // Optional extra tile rows appended below the square matrix (tile rows nch .. nch+nex-1 of L, source tiles
     // Bex[nex][nchp][256]): the factorisation treats them as more panel rows, so they come out as Bex * L^-T --
@@ -422,7 +427,7 @@ struct OpsResidentT {
                         // Hand-pipelined operand ring (qp_common.hpp: gload16 / vm_wait), half-chunks of 8 columns: the A
                         // tiles (this wavefront's own rows, from HBM) are requested THREE half-chunks ahead, the B tiles
                         // (the block's two tile rows, shared by all wavefronts: L1 / L2) one ahead.  Per step 2 B + 4 A loads,
-                        // B first, so "B of this step has arrived" is vmcnt(10): A(k+2), B(k+1), A(k+3) may still be in
+                        // B first, so "B of this step has arrived" is vmcnt(2 RMAXT + 2): A(k+2), B(k+1), A(k+3) may still be in
                         // flight.  Indices past the end are clamped (a redundant load) so that the counts stay uniform.
                         const char* rb0 = uniform_ptr(tile2(tb, 0));
                         const char* rb1 = uniform_ptr(tile2(two ? tb + 1 : tb, 0));      // stand-in when the row is padding
@@ -465,10 +470,10 @@ struct OpsResidentT {
                         __builtin_amdgcn_sched_barrier(0);
                         loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
                         for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 4 jb: a multiple of 4
-                            loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<10>(); mult(a0, b0);
-                            loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<10>(); mult(a1, b1);
-                            loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<10>(); mult(a2, b0);
-                            loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<10>(); mult(a3, b1);
+                            loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RMAXT + 2>(); mult(a0, b0);
+                            loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * RMAXT + 2>(); mult(a1, b1);
+                            loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RMAXT + 2>(); mult(a2, b0);
+                            loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<2 * RMAXT + 2>(); mult(a3, b1);
                         }
                         vm_wait<0>();
                     }
@@ -544,8 +549,8 @@ struct OpsResidentT {
         double* vec = sm.vec;
         const double* U = sm.U;
         constexpr int UW = RNW - 1;                 // updater wavefronts
-        constexpr int FT = (31 + UW - 1) / UW;      // forward: tiles per updater wavefront
-        constexpr int BC = (32 + UW - 1) / UW;      // backward: chunks per updater wavefront
+        constexpr int FT = (31 + UW - 1) / UW < 5 ? (31 + UW - 1) / UW : 5;      // forward: buffered tiles per updater wavefront
+        constexpr int BC = (32 + UW - 1) / UW < 5 ? (32 + UW - 1) / UW : 5;      // backward: buffered chunks per updater wavefront
         PROF_DECL
         // Two roles, two code paths with matching barrier sequences (per block: one barrier after the diagonal step,
         // one after the update).  The barriers order LDS traffic only, so the updaters' operand tiles -- fetched TWO
@@ -615,8 +620,9 @@ struct OpsResidentT {
                             }
                         }
                     }
-                    if (GU) {
-                        // more tile rows below than the register buffers hold (n > 528): the rest straight from memory
+                    {
+                        // more tile rows below than the register buffers hold (n > 528, or fewer wavefronts): the rest
+                        // straight from memory
                         for (int tt = (wv - 1) + FT * UW; tt < tbelow; tt += UW) {
                             const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;
                             double pv = 0.0;
@@ -652,8 +658,8 @@ struct OpsResidentT {
         double* vec = sm.vec;
         const double* U = sm.U;
         constexpr int UW = RNW - 1;                 // updater wavefronts
-        constexpr int FT = (31 + UW - 1) / UW;      // forward: tiles per updater wavefront
-        constexpr int BC = (32 + UW - 1) / UW;      // backward: chunks per updater wavefront
+        constexpr int FT = (31 + UW - 1) / UW < 5 ? (31 + UW - 1) / UW : 5;      // forward: buffered tiles per updater wavefront
+        constexpr int BC = (32 + UW - 1) / UW < 5 ? (32 + UW - 1) / UW : 5;      // backward: buffered chunks per updater wavefront
         PROF_DECL
         // Two roles, two code paths with matching barrier sequences (per block: one barrier after the diagonal step,
         // one after the update).  The barriers order LDS traffic only, so the updaters' operand tiles -- fetched TWO
@@ -724,8 +730,9 @@ struct OpsResidentT {
                             if ((lane & 12) == 0) vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
                         }
                     }
-                    if (GU) {
-                        // more finished chunks than the register buffers hold (n > 528): the rest straight from memory
+                    {
+                        // more finished chunks than the register buffers hold (n > 528, or fewer wavefronts): the rest
+                        // straight from memory
                         for (int c = (wv - 1) + BC * UW; c < nc; c += UW) {
                             const double2* p0 = tile2(tb, c) + lane;
                             const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
@@ -858,15 +865,16 @@ struct CovArgs {
 template <bool GU>
 __device__ __forceinline__ double* resident_u_ptr(double* Lb, int NP) { return Lb + (size_t)NP * NP; }
 
-template <bool GU>
-__global__ __launch_bounds__(RT) void cov_kernel_resident(CovArgs a, int NP) {
+template <bool GU, int RTT = 512>
+__global__ __launch_bounds__(RTT) void cov_kernel_resident(CovArgs a, int NP) {
+    constexpr int RT = RTT, RNW = RTT / 64;
     const int b = blockIdx.x;
     extern __shared__ double smem[];
-    OpsResidentT<GU> ops;
+    OpsResidentT<GU, RTT> ops;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk + (size_t)b * a.ppk_stride; ops.nchp = a.nchp;
     ops.nex = a.nex; ops.Bex = a.Bex; ops.fwd = false;
-    constexpr int VEC = ResSmemT<GU>::VEC;
+    constexpr int VEC = ResSmemT<GU, RTT>::VEC;
     ops.sm.carve(smem);
     // with U outside LDS it sits behind the (nch + nex) x nch tiles of this spectrum's scratch
     if (GU) ops.sm.U = ops.L + (size_t)(NP / 16 + a.nex) * (NP / 16) * TSZ;
@@ -894,12 +902,15 @@ __global__ __launch_bounds__(RT) void cov_kernel_resident(CovArgs a, int NP) {
     }
 }
 
-template <bool GU>
-__global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
+// (the second launch-bound argument is waves per SIMD: 2 in both forms, i.e. one 512-thread or two 256-thread workgroups per
+// CU and at most 256 registers per lane; without it hipcc gives the 256-thread form 393 registers and one workgroup per CU)
+template <bool GU, int RTT = 512>
+__global__ __launch_bounds__(RTT, 2) void qp_kernel_resident(QpArgs a, int NP) {
+    constexpr int RT = RTT;
     const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
     if (a.active && !a.active[b]) return;
     extern __shared__ double smem[];
-    OpsResidentT<GU> ops;
+    OpsResidentT<GU, RTT> ops;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk ? a.Ppk + (size_t)b * a.ppk_stride : nullptr; ops.nchp = a.nchp;
     ops.sm.carve(smem);
@@ -917,7 +928,7 @@ __global__ __launch_bounds__(RT) void qp_kernel_resident(QpArgs a, int NP) {
 static size_t resident_lds_bytes(int NP) {
     return ((size_t)NP * PLD + ResSmem::FIXED) * sizeof(double);
 }
-static size_t resident_gu_lds_bytes() { return (size_t)ResSmemT<true>::FIXED * sizeof(double); }
+static size_t resident_gu_lds_bytes() { return (size_t)ResSmemT<true, 512>::FIXED * sizeof(double); }
 // per-problem scratch doubles of the U-outside form: the tile-packed factor (NP^2) followed by U (NP x 33)
 static size_t resident_gu_doubles(int n) {
     const size_t NP = (size_t)round_up(n, 32);

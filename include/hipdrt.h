@@ -150,6 +150,8 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
 /* diagnostic: in-kernel phase cycle counters of qp_kernel (workgroup 0 only), non-zero only in a build with
  * -DHIPDRT_QP_PROFILE (make PROFILE=1); slots documented in csrc/qp.hip.  Never used in timed runs.        */
 int hipdrt_qp_profile(hipdrt_ctx* ctx, unsigned long long* cycles, int n, int reset);
+/* diagnostic: workgroups per CU the runtime reports for the coneqp kernel of n unknowns (threads = 512)          */
+int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n);
 
 /* P = (W A)'(W A) + L2, q = -(W A)'(W b) + l1 of qphb.solve_convex_opt (qphb.py:465-466) for B weight
  * vectors over one shared A[m][n]:  w[B][m], b[B][m], l2[B or 1][n][n], l1[n] -> P[B][n][n], q[B][n]   */

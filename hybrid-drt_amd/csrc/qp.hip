@@ -160,7 +160,7 @@ int qp_occupancy(int threads, int n) {
     hipError_t e;
     if (threads != 512) return -1;
     if (n > RNP_MAX) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<true, 512>, 512, resident_gu_lds_bytes(512));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<true, 512>, 512, resident_gu_lds_bytes());
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_resident<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(NP));
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<false, 512>, 512, resident_lds_bytes(NP));

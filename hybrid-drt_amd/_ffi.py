@@ -57,6 +57,12 @@ class PreparedDesc(C.Structure):
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
+class IterateState(C.Structure):
+    """hipdrt_iterate_state (include/hipdrt.h): the arrays iterate_qphb takes; NULL keeps the device value"""
+    _fields_ = [(name, C.POINTER(C.c_double)) for name in
+                ("x_in", "s_vectors", "rho", "dop_rho", "weights", "est_weights", "xmx_norms", "dop_xmx_norms")]
+
+
 _vp = C.c_void_p
 
 # name -> argtypes (all return int unless listed in _RESTYPES).  Mirrors include/hipdrt.h one-to-one;
@@ -108,6 +114,7 @@ SIGNATURES = {
     "hipdrt_plan_obs_llh_terms": [_vp, _dp, _dp],
     "hipdrt_plan_set_state": [_vp, _dp, _dp, _dp, _dp],
     "hipdrt_plan_continue": [_vp, C.POINTER(FitOpts), C.c_double, C.c_int],
+    "hipdrt_plan_iterate": [_vp, C.POINTER(IterateState), _ip, _ip, _ip, _dp],
     "hipdrt_plan_param_var": [_vp, _dp, _ip],
     "hipdrt_plan_record_history": [_vp, C.c_int],
     "hipdrt_plan_get_history": [_vp, _dp, _dp, _dp, _ip, C.c_int, _ip],
@@ -558,6 +565,29 @@ class PreparedPlan(Plan):
         _check(self._lib.hipdrt_plan_upload_prepared(self._h, rzv.shape[0], int(batched), _p(rzm), _p(rzv)))
         self.batch = self.B = rzv.shape[0]
         self.rm_batched = batched
+
+    def iterate(self, x_in=None, s_vectors=None, rho=None, dop_rho=None, weights=None, est_weights=None,
+                xmx_norms=None, dop_xmx_norms=None):
+        """hipdrt_plan_iterate: one qphb.iterate_qphb on every staged measurement; arrays are (B, ...) or None to keep
+        what the device holds.  Returns dict(converged, qp_status, qp_iters, primal_objective), each (B,)."""
+        B, n, m = self.batch, self.n, self.m
+        shapes = dict(x_in=(B, n), s_vectors=(B, 3, n), rho=(B, 3), dop_rho=(B, 3), weights=(B, m),
+                      est_weights=(B, m), xmx_norms=(B, 3), dop_xmx_norms=(B, 3))
+        given = dict(x_in=x_in, s_vectors=s_vectors, rho=rho, dop_rho=dop_rho, weights=weights,
+                     est_weights=est_weights, xmx_norms=xmx_norms, dop_xmx_norms=dop_xmx_norms)
+        st, keep = IterateState(), []
+        for name, arr in given.items():
+            if arr is None:
+                continue
+            a = _f64(arr)
+            if a.shape != shapes[name]:
+                raise ValueError(f"{name}: expected shape {shapes[name]}, got {a.shape}")
+            keep.append(a)
+            setattr(st, name, _p(a))
+        conv, status, iters = (np.empty(B, dtype=np.int32) for _ in range(3))
+        pobj = np.empty(B)
+        _check(self._lib.hipdrt_plan_iterate(self._h, C.byref(st), _pi(conv), _pi(status), _pi(iters), _p(pobj)))
+        return dict(converged=conv.astype(bool), qp_status=status, qp_iters=iters, primal_objective=pobj)
 
     def get(self, which):
         B = self.batch

@@ -25,6 +25,7 @@ struct hipdrt_plan {
     hipdrt_fit_opts opts{};
     // prepared-matrix plans (hipdrt_plan_create_prepared)
     int prepared = 0;
+    int prepped = 0;           // launch_prep has run on the staged batch (hipdrt_plan_iterate runs it once)
     hipdrt_prepared_desc desc{};
     long long rm_stride = 0;
     DevBuf vz_strength, dop_rho, dop_xmx, hist_dop_rho, outlier_t;
@@ -706,6 +707,7 @@ int hipdrt_plan_upload_prepared(hipdrt_plan* p, int B, int rm_batched, const dou
     HIPDRT_CHECK(hipStreamSynchronize(st));
     p->rm_stride = rm_batched ? (long long)m * p->ldrm : 0;
     p->B = B;
+    p->prepped = 0;
     return HIPDRT_OK;
 }
 
@@ -867,6 +869,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     if (p->hist_b >= 0) HIPDRT_CHECK(hipMemsetAsync(p->hist_rows.p, 0, sizeof(int), st));
     launch_prep(st, fs, B);
     LAUNCH_OK();
+    p->prepped = 1;
 
     // initialize_weights runs with iw_l2_lambda_0 and the DOP / DRT ratio kept (drt1d.py:640-646)
     const double dop_l2 = p->prepared ? p->desc.dop_l2_lambda_0 : 0.0;
@@ -1049,6 +1052,20 @@ int hipdrt_plan_set_state(hipdrt_plan* p, const double* x, const double* rho, co
     return HIPDRT_OK;
 }
 
+// QP arguments of the outer loop: one P per spectrum in the packed tile layout, the loop's constraint vector
+static QpArgs loop_qp_args(hipdrt_plan* p, const hipdrt_qp_opts& qpo) {
+    const int n = p->n;
+    QpArgs qa{};
+    qa.B = p->B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
+    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n);
+    qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
+    qa.iters_accum = p->qp_iters_total.i(); qa.opts = qpo;
+    qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);
+    qa.P = nullptr; qa.p_stride = (long long)n * p->ldp; qa.active = p->active.i();
+    qa.Ppk = p->Ppk.d(); qa.ppk_stride = (long long)qp_ppk_doubles(n); qa.nchp = qp_nchp(n);
+    return qa;
+}
+
 // drt1d._continue_from_init (hybdrt/models/drt1d.py:1270-1365) for the fitted batch: the same outer loop re-entered from
 // the state on the device (x, s, rho, weights; est_weights, xmx norms and data scale stay) with updated hyper-parameters.
 int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double weight_factor, int min_iter) {
@@ -1074,15 +1091,8 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
         HIPDRT_CHECK(hipStreamSynchronize(st));
     }
     GramL2 g = plan_l2(p, opts->l2_lambda_0, opts->derivative_weights, 0.0);
-    QpArgs qa{};
-    qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
-    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n);
-    qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
-    qa.iters_accum = p->qp_iters_total.i(); qa.opts = opts->qp;
-    qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);
+    QpArgs qa = loop_qp_args(p, opts->qp);
     double* const Prow = nullptr;
-    qa.P = Prow; qa.p_stride = (long long)n * p->ldp; qa.active = p->active.i();
-    qa.Ppk = p->Ppk.d(); qa.ppk_stride = (long long)qp_ppk_doubles(n); qa.nchp = qp_nchp(n);
     for (int it = 0; it < opts->max_iter; ++it) {
         tm.mark(1);
         HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
@@ -1110,6 +1120,70 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     LAUNCH_OK();
     tm.mark(-1);
     HIPDRT_CHECK(hipStreamSynchronize(st));
+    tm.collect(p->t_ms, p->launches);
+    return HIPDRT_OK;
+}
+
+// qphb.iterate_qphb (hybdrt/models/qphb.py:606-972) for every staged measurement of a prepared plan: the QP on
+// (weights, s_vectors, rho) as given, then the s / rho / DOP hyper-parameter pass, estimate_weights and is_converged
+// against x_in.  What _qphb_fit_core does around the call (xmx norms of the first iteration, data rescaling, the
+// vz_offset column; drt1d.py:903-979) is not part of it.
+int hipdrt_plan_iterate(hipdrt_plan* p, const hipdrt_iterate_state* in, int* converged, int* qp_status, int* qp_iters,
+                        double* primal_objective) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_REQUIRE(p->prepared, "hipdrt_plan_iterate works on prepared plans (the caller's rm, rv as iterate_qphb takes them)");
+    HIPDRT_REQUIRE(p->B >= 1, "no measurements staged (call hipdrt_plan_upload_prepared)");
+    HIPDRT_REQUIRE(!p->has_weight_factors(), "weight factors belong to _qphb_fit_core, not to iterate_qphb");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const int B = p->B, n = p->n, m = p->m;
+    FitState fs = p->state();
+    fs.continue_mode = 2; fs.min_iter = 1;
+    fs.opts.max_iter = 2;                      // never "stopped at max_iter": fit_status 0 <=> converged
+    if (!p->prepped) {                         // variance floor of estimate_weights + default state (qphb.py:1569)
+        launch_prep(st, fs, B);
+        LAUNCH_OK();
+        p->prepped = 1;
+    }
+    if (in) {
+        const size_t b = (size_t)B;
+        struct { const double* src; void* dst; size_t cnt; } cp[] = {
+            {in->x_in, p->x_in.p, b * n}, {in->x_in, p->x.p, b * n}, {in->s_vectors, p->s.p, b * 3 * n},
+            {in->rho, p->rho.p, b * 3}, {in->dop_rho, p->dop_rho.p, b * 3}, {in->weights, p->w.p, b * m},
+            {in->est_weights, p->est_w.p, b * m}, {in->xmx_norms, p->xmx.p, b * 3},
+            {in->dop_xmx_norms, p->dop_xmx.p, b * 3}};
+        for (auto& c : cp)
+            if (c.src) HIPDRT_CHECK(hipMemcpyAsync(c.dst, c.src, c.cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    PhaseTimer tm(st);
+    tm.mark(4);
+    {
+        std::vector<int> ones(B, 1);
+        HIPDRT_CHECK(hipMemcpyAsync(p->active.p, ones.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
+        HIPDRT_CHECK(hipStreamSynchronize(st));         // `ones` and the caller's arrays may go once this returns
+    }
+    const GramL2 g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, p->desc.dop_l2_lambda_0);
+    QpArgs qa = loop_qp_args(p, p->opts.qp);
+    tm.mark(1);
+    launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, nullptr, p->ldp, (long long)n * p->ldp, p->active.i(),
+                   p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n), p->rm_stride);
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i(), p->rm_stride);
+    LAUNCH_OK();
+    tm.mark(2);
+    TRY(launch_qp(st, qa));
+    tm.mark(3);
+    TRY(launch_hyper(st, fs, B, 0));
+    LAUNCH_OK();
+    tm.mark(-1);
+    std::vector<int> act(B);
+    HIPDRT_CHECK(hipMemcpyAsync(act.data(), p->active.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (qp_status) HIPDRT_CHECK(hipMemcpyAsync(qp_status, p->qp_status.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (qp_iters) HIPDRT_CHECK(hipMemcpyAsync(qp_iters, p->qp_iters.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (primal_objective)
+        HIPDRT_CHECK(hipMemcpyAsync(primal_objective, p->pcost.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    if (converged) for (int b = 0; b < B; ++b) converged[b] = act[b] == 0;
     tm.collect(p->t_ms, p->launches);
     return HIPDRT_OK;
 }

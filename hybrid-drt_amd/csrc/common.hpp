@@ -138,7 +138,8 @@ void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, 
 struct FitState {
     int nf, m, n, ns, ldrm, ldm;
     int toeplitz_m;        // penalty blocks are symmetric Toeplitz (uniform ln-tau grid): first column suffices
-    int continue_mode;     // warm restart (_continue_from_init): xmx norms stay frozen
+    int continue_mode;     // 1: warm restart (_continue_from_init): xmx norms stay frozen, no rescaling;
+                           // 2: a bare iterate_qphb (hipdrt_plan_iterate): as 1 and no vz_offset column rewrite
     int min_iter;          // a spectrum may only stop once it has done this many outer iterations (fit: 1)
     double basis_area;     // area of one tau basis function (sqrt(pi) / epsilon): predict_r_p of update_scale
     hipdrt_fit_opts opts;

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             st.hist_dop_rho[(size_t)it * 3 + tid] = st.dop_rho[(size_t)b * 3 + tid];
         if (tid == 0) { st.hist_qp[it + 1] = st.qp_iters[b]; st.hist_rows[0] = it + 1; }
     }
-    if (st.prepared && st.desc.vz_index >= 0) {
+    if (st.prepared && st.desc.vz_index >= 0 && st.continue_mode != 2) {
         // drt1d.py:973-979: the vz_offset column becomes the current prediction of the matrix without the baseline and
         // offset columns (rzm_vz was copied while the offset column was still zero), impedance rows negated, times the
         // strength vector.  The weights above were estimated with the previous column, as in iterate_qphb.

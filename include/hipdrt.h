@@ -312,6 +312,28 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* des
  * is initialize_weights', which is what remove_outliers thresholds, drt1d.py:817-833).                                  */
 int hipdrt_plan_upload_prepared(hipdrt_plan* plan, int B, int rm_batched, const double* rzm, const double* rzv);
 
+/* One qphb.iterate_qphb (hybdrt/models/qphb.py:606-972) on every staged measurement of a prepared plan -- the body of
+ * _qphb_fit_core's loop as the reference exposes it: solve the QP built from (weights, s_vectors, rho_vector, dop_rho_vector),
+ * update s_vectors / rho_vector (733-817) and the DOP pair (822-933) from the new x with the given xmx norms, re-estimate the
+ * weights against est_weights (936), and test is_converged(x_in, x) (967-970).  A NULL member keeps the value on the device
+ * (defaults after hipdrt_plan_upload_prepared: x 1e-6, s = s_0, rho = rho_0, weights = est_weights... = 1, norms 1; after
+ * hipdrt_plan_fit: the fit's), so repeated calls with in = NULL continue from their own results.  Not included: what
+ * _qphb_fit_core does around the call (xmx norms of the first iteration, update_scale, the vz_offset column, weight factors).
+ * Results through hipdrt_plan_download (x, weights, rho, s_vectors) and hipdrt_plan_get("dop_rho"); the optional
+ * outputs [B]: is_converged, and of the QP its status (HIPDRT_QP_*), iteration count and 'primal objective'. */
+typedef struct {
+    const double* x_in;           /* [B][n]    */
+    const double* s_vectors;      /* [B][3][n] */
+    const double* rho;            /* [B][3]    */
+    const double* dop_rho;        /* [B][3]    */
+    const double* weights;        /* [B][m]    */
+    const double* est_weights;    /* [B][m]    */
+    const double* xmx_norms;      /* [B][3]    */
+    const double* dop_xmx_norms;  /* [B][3]    */
+} hipdrt_iterate_state;
+int hipdrt_plan_iterate(hipdrt_plan* plan, const hipdrt_iterate_state* in, int* converged, int* qp_status, int* qp_iters,
+                        double* primal_objective);
+
 /* Weight factors of _qphb_fit_core (hybdrt/models/drt1d.py:887-901, 990-1000): every outer iteration solves its QP with
  * weights * row_factors (chrono_weight_factor on the chrono rows, eis_weight_factor on the impedance rows; NULL = 1),
  * from the second iteration on also * weight_factor; estimate_weights keeps working on the unscaled weights.  After the

@@ -1,0 +1,157 @@
+"""GPU: qphb.iterate_qphb (hybdrt/models/qphb.py:606-972) as one device pass -- hipdrt_plan_iterate behind the reference's
+signature -- against the reference-run fixtures (first pass of a recorded fit) and the oracle's restatement (chained passes)."""
+import numpy as np
+import pytest
+
+from oracle import drt_oracle as orc
+from hybrid_util import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(name):
+    g, special = load_case(name)
+    hyp = orc.get_default_hypers()
+    dop = None
+    if "x_dop" in special:
+        hyp.update(orc.get_default_dop_hypers())
+        a = special["x_dop"]["index"]
+        dop = (a, a + special["x_dop"]["size"])
+    ns = int(sum(v["size"] for v in special.values()))
+    pen = {f"m{k}": g[f"m{k}"] for k in range(3)}
+    return g, special, hyp, dop, ns, pen
+
+
+def _start_state(g, hyp, n, dop):
+    """what _qphb_fit_core hands to its first iterate_qphb (drt1d.py:616-623, 860-875)"""
+    return dict(x=np.zeros(n) + 1e-6, s=[np.ones(n) * hyp["s_0"][k] for k in range(3)],
+                rho=hyp["rho_0"].astype(float).copy(),
+                dop_rho=None if dop is None else hyp["dop_rho_0"].astype(float).copy(),
+                weights=g["init_weights"].copy(), xmx=np.ones(3), dop_xmx=None if dop is None else np.ones(3))
+
+
+def _ours(qphb, st, g, special, hyp, pen, history=None, rv=None):
+    return qphb.iterate_qphb(st["x"], np.array(st["s"]), st["rho"], st["dop_rho"], g["rv"] if rv is None else rv,
+                             st["weights"], g["est_weights"], None, g["rm"], g["vmm"], pen, "integral",
+                             g["l1_lambda_vector"], hyp, True, st["xmx"], st["dop_xmx"], None, None, None, True, special,
+                             1e-2, 1, history)
+
+
+@pytest.mark.parametrize("name", ["golden71x91_dop", "hybrid_s0"])
+def test_first_pass_reproduces_the_recorded_reference_iteration(name):
+    from hipdrt.models import qphb
+    g, special, hyp, dop, ns, pen = _problem(name)
+    if "vz_offset" in special:
+        pytest.skip("the recorded first pass ran on the matrix before the vz_offset rewrite")
+    n = g["rm"].shape[1]
+    st = _start_state(g, hyp, n, dop)
+    history = []
+    x, s, rho, dop_rho, w, outlier_t, out_tvt, cvx, conv = _ours(qphb, st, g, special, hyp, pen, history)
+    np.testing.assert_allclose(x, g["hist_x"][0], rtol=1e-6, atol=2e-7)
+    np.testing.assert_allclose(rho, g["hist_rho"][0], rtol=1e-6)
+    np.testing.assert_allclose(w, g["hist_weights"][0], rtol=1e-6)
+    if dop is not None:
+        np.testing.assert_allclose(dop_rho, g["hist_dop_rho"][0], rtol=1e-6)
+    else:
+        assert dop_rho is None
+    assert cvx["iterations"] == int(g["qp_iterations"][1]) and cvx["status"] == "optimal"
+    assert conv is False and out_tvt is None and np.all(outlier_t == 1)
+    assert len(history) == 1 and history[0]["fun"] == cvx["primal objective"]
+    np.testing.assert_array_equal(history[0]["x"], x)
+
+
+@pytest.mark.parametrize("name", ["golden71x91_dop", "hybrid_s0", "hybrid_s0_dop"])
+def test_chained_passes_follow_the_oracle(name):
+    """Four passes, each fed the oracle's state (so a deviation cannot hide in the next pass's inputs); xmx norms taken
+    after the first pass as _qphb_fit_core does (drt1d.py:946-960)"""
+    from hipdrt.models import qphb
+    g, special, hyp, dop, ns, pen = _problem(name)
+    n = g["rm"].shape[1]
+    plist = [pen[f"m{k}"] for k in range(3)]
+    st = _start_state(g, hyp, n, dop)
+    for it in range(4):
+        ours = _ours(qphb, st, g, special, hyp, pen)
+        s_in = [v.copy() for v in st["s"]]          # the oracle updates s in place, like the reference
+        x, s, rho, dop_rho, w, cvx, conv = orc.iterate_qphb_general(
+            st["x"], s_in, st["rho"], st["dop_rho"], g["rv"], st["weights"], g["est_weights"], g["rm"], g["vmm"], plist,
+            g["l1_lambda_vector"], hyp, st["xmx"], st["dop_xmx"], True, special, ns, dop, 1e-2)
+        np.testing.assert_allclose(ours[0], x, rtol=1e-6, atol=2e-7)
+        np.testing.assert_allclose(ours[1], np.array(s), rtol=1e-5, atol=1e-10)
+        np.testing.assert_allclose(ours[2], rho, rtol=1e-6)
+        np.testing.assert_allclose(ours[4], w, rtol=1e-6)
+        if dop is not None:
+            np.testing.assert_allclose(ours[3], dop_rho, rtol=1e-6)
+        assert ours[7]["iterations"] == cvx["iterations"]
+        np.testing.assert_allclose(ours[7]["primal objective"], cvx["primal objective"], rtol=1e-8)
+        assert ours[8] == conv
+        st.update(x=x, s=s, rho=rho, dop_rho=dop_rho, weights=w)
+        if it == 0:
+            xd = x[ns:]
+            st["xmx"] = np.array([xd @ plist[k][ns:, ns:] @ xd for k in range(3)])
+            if dop is not None:
+                xp = x[dop[0]:dop[1]]
+                st["dop_xmx"] = np.array([xp @ plist[k][dop[0]:dop[1], dop[0]:dop[1]] @ xp for k in range(3)])
+
+
+def test_batched_pass_and_device_resident_chaining():
+    """(B, ...) arguments give B independent passes in one call; PreparedPlan.iterate with no arrays continues from the
+    state the device holds and lands where the host-fed chain lands"""
+    from hipdrt.models import qphb
+    g, special, hyp, dop, ns, pen = _problem("golden71x91_dop")
+    m, n = g["rm"].shape
+    st = _start_state(g, hyp, n, dop)
+    B = 3
+    rv = np.stack([g["rv"], 0.5 * g["rv"], g["rv"]])
+    tile = lambda a, r: np.tile(np.asarray(a, dtype=float), (B,) + (1,) * r)
+    args = dict(x=tile(st["x"], 1), s=tile(np.array(st["s"]), 2), rho=tile(st["rho"], 1), dop_rho=tile(st["dop_rho"], 1),
+                weights=tile(st["weights"], 1), xmx=tile(st["xmx"], 1), dop_xmx=tile(st["dop_xmx"], 1))
+    out = qphb.iterate_qphb(args["x"], args["s"], args["rho"], args["dop_rho"], rv, args["weights"],
+                            tile(g["est_weights"], 1), None, g["rm"], g["vmm"], pen, "integral", g["l1_lambda_vector"],
+                            hyp, True, args["xmx"], args["dop_xmx"], None, None, None, True, special, 1e-2, 1, None)
+    single = _ours(qphb, st, g, special, hyp, pen)
+    np.testing.assert_array_equal(out[0][0], out[0][2])
+    np.testing.assert_array_equal(out[0][0], single[0])
+    np.testing.assert_array_equal(out[1][0], single[1])
+    np.testing.assert_array_equal(out[4][0], single[4])
+    assert not np.allclose(out[0][1], out[0][0])
+    half = _ours(qphb, st, g, special, hyp, pen, rv=0.5 * g["rv"])
+    np.testing.assert_array_equal(out[0][1], half[0])
+    assert out[8].shape == (B,) and len(out[7]) == B
+
+    # device-resident chain: first pass with arrays, two more without
+    plan = qphb._iter_plan["plan"]
+    plan.upload(g["rm"], g["rv"][None])
+    one = lambda a: None if a is None else np.asarray(a, dtype=float)[None]
+    plan.iterate(x_in=one(st["x"]), s_vectors=one(np.array(st["s"])), rho=one(st["rho"]), dop_rho=one(st["dop_rho"]),
+                 weights=one(st["weights"]), est_weights=one(g["est_weights"]), xmx_norms=one(st["xmx"]),
+                 dop_xmx_norms=one(st["dop_xmx"]))
+    for _ in range(2):
+        res = plan.iterate()
+    dev = plan.download(s_vectors=True)
+    cur = dict(st)
+    for _ in range(3):
+        r = _ours(qphb, cur, g, special, hyp, pen)
+        cur.update(x=r[0], s=list(r[1]), rho=r[2], dop_rho=r[3], weights=r[4])
+    np.testing.assert_array_equal(dev["x"][0], cur["x"])
+    np.testing.assert_array_equal(dev["weights"][0], cur["weights"])
+    np.testing.assert_array_equal(dev["rho"][0], cur["rho"])
+    assert res["qp_status"][0] == 0
+
+
+def test_unbuilt_branches_and_bad_shapes_are_refused():
+    from hipdrt.models import qphb
+    g, special, hyp, dop, ns, pen = _problem("golden71x91_dop")
+    n = g["rm"].shape[1]
+    st = _start_state(g, hyp, n, dop)
+    base = [st["x"], np.array(st["s"]), st["rho"], st["dop_rho"], g["rv"], st["weights"], g["est_weights"], None, g["rm"],
+            g["vmm"], pen, "integral", g["l1_lambda_vector"], hyp, True, st["xmx"], st["dop_xmx"], None, None, None, True,
+            special, 1e-2, 1, None]
+    for pos, val in ((11, "discrete"), (17, [0]), (19, True), (23, 2)):
+        bad = list(base)
+        bad[pos] = val
+        with pytest.raises(NotImplementedError):
+            qphb.iterate_qphb(*bad)
+    bad = list(base)
+    bad[0] = st["x"][:-1]
+    with pytest.raises(ValueError):
+        qphb.iterate_qphb(*bad)

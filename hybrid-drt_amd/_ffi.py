@@ -361,8 +361,8 @@ class Context:
         return out
 
     def qp_profile(self, reset=True):
-        buf = (C.c_ulonglong * 48)()
-        _check(self._lib.hipdrt_qp_profile(self._h, buf, 48, int(reset)))
+        buf = (C.c_ulonglong * 64)()        # 0..47 the QP kernel's phases, 48..63 hyper_kernel's (PROFILE=1 builds)
+        _check(self._lib.hipdrt_qp_profile(self._h, buf, 64, int(reset)))
         return [int(v) for v in buf]
 
     def weighted_gram(self, A, w, b, l2=None, l1=None):

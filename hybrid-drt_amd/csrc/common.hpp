@@ -232,6 +232,7 @@ size_t qp_scratch_doubles(int n);
 inline int qp_state_ld(int n) { return round_up(n, 32) + 32; }
 inline size_t qp_state_doubles(int n) { return (size_t)17 * qp_state_ld(n); }
 int qp_profile_read(unsigned long long* out, int n, int reset);
+int hyper_profile_read(unsigned long long* out, int n, int reset);   // slots 48.. of hipdrt_qp_profile (hyper.hip)
 int qp_occupancy(int threads, int n);
 
 }  // namespace hipdrt

@@ -14,6 +14,36 @@
 
 namespace hipdrt {
 
+// PROFILE=1 builds: shader-clock ticks per phase of hyper_kernel's workgroup 0 (slots 48.. of hipdrt_qp_profile)
+#ifdef HIPDRT_QP_PROFILE
+__device__ unsigned long long g_hyper_prof[16];
+struct HProf {
+    unsigned long long t;
+    __device__ __forceinline__ void start() { t = clock64(); }
+    __device__ __forceinline__ void mark(int slot) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long n_ = clock64(); atomicAdd(&g_hyper_prof[slot], n_ - t); t = n_; }
+    }
+};
+#define HPROF_START() HProf hp_; hp_.start()
+#define HPROF(slot) hp_.mark(slot)
+#define HPROF_COUNT(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_hyper_prof[slot], 1ull); } while (0)
+#else
+#define HPROF_COUNT(slot) do {} while (0)
+#define HPROF_START() do {} while (0)
+#define HPROF(slot) do {} while (0)
+#endif
+int hyper_profile_read(unsigned long long* out, int n, int reset) {
+#ifdef HIPDRT_QP_PROFILE
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hyper_prof), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 16; ++i) out[i] = h[i];
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hyper_prof), z, sizeof(z)); }
+#else
+    for (int i = 0; i < n && i < 16; ++i) out[i] = 0;
+#endif
+    return 0;
+}
+
 static constexpr int HT = 512;
 static constexpr int HNW = HT / 64;
 
@@ -195,15 +225,22 @@ __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld
 }
 
 // same for a symmetric Toeplitz matrix given by its mirrored first column (LDS, c[d] valid for -(nd-1) <= d <= nd-1):
-// y[i] = sum_j c[i - j] v[j]
+// y[i] = sum_j c[i - j] v[j].  One row per thread: v[j] is a broadcast read, c[i - j] runs over consecutive addresses
+// across the lanes, nothing is reduced across lanes; four partial sums (j mod 4) keep the adds independent.
 __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, int nd, const double* __restrict__ v,
                                                 double* __restrict__ out) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = wv; i < nd; i += HNW) {
-        double s = 0.0;
-        for (int j = lane; j < nd; j += 64) s += c[i - j] * v[j];
-        s = hw_sum(s);
-        if (lane == 0) out[i] = s;
+    for (int i = threadIdx.x; i < nd; i += HT) {
+        const double* ci = c + i;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = 0;
+        for (; j + 3 < nd; j += 4) {
+            s0 += ci[-j] * v[j];
+            s1 += ci[-j - 1] * v[j + 1];
+            s2 += ci[-j - 2] * v[j + 2];
+            s3 += ci[-j - 3] * v[j + 3];
+        }
+        for (; j < nd; ++j) s0 += ci[-j] * v[j];
+        out[i] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -217,8 +254,10 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* V,
     const int m = st.m, n = st.n, tid = threadIdx.x;
     const double* rv = st.rv + (size_t)b * m;
     const double op = st.opts.outlier_p;
+    HPROF_START();
     rows_matvec(st.rm + (size_t)b * st.rm_stride, st.ldrm, m, n, xs, tmp);        // rm @ x
     __syncthreads();
+    HPROF(8);
     for (int i = tid; i < m; i += HT) {
         const double r = tmp[i] - rv[i];
         if (op > 0.0) tmp3[i] = r;
@@ -239,6 +278,7 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* V,
         rows_matvec(V, m, m, m, tmp, tmp2);
     }
     __syncthreads();
+    HPROF(9);
     if (op > 0.0) {
         const double s2pi = sqrt(2.0 * 3.141592653589793);
         for (int i = tid; i < m; i += HT) {
@@ -346,6 +386,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
     __shared__ double red[HNW];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!st.active[b]) return;
+    HPROF_START();
     const int n = st.n, m = st.m, ns = st.ns, nd = n - ns;
     double* xs = sm;              // [n]   new x
     double* bsum = xs + n;        // [nd]  off-diagonal row sums of gamma @ diag(sqrt s)
@@ -382,6 +423,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         xh[i] = sg * sqrt(fabs(v));
     }
     __syncthreads();
+    HPROF(0);
 
     // solve_s + solve_rho (qphb.py:320-356, 385-405) of one derivative order on one block of x: the DRT coefficients
     // (with the G matrix for k = 0) or the x_dop block (qphb.py:822-933, no G matrix)
@@ -407,41 +449,51 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
             __syncthreads();
             const double* ck = ctp + k * cw + (nd - 1);      // ck[i - j]
             const double* c1 = ctp + cw + (nd - 1);
+            // one row per thread (see toeplitz_matvec): the column index is uniform across the wavefront
             double lmax = 0.0;
-            for (int i = wv; i < nd; i += HNW) {
+            for (int i = tid; i < nd; i += HT) {
                 const double xi = xd[i], xr = reff * xi;      // rho_k_eff * x_i (1 under eff_hp, qphb.py:747-750)
-                const int jd = i & ~63;                        // the 64-column chunk that holds the diagonal
-                double s0 = 0.0;
+                const double* cki = ck + i;
+                double s0 = 0.0, s1 = 0.0;
                 if (use_g) {
                     const double xhs = xh[i] / sig2;
-                    for (int j0 = 0; j0 < nd; j0 += 64) {
-                        const int j = j0 + lane;
-                        if (j < nd) {
-                            double gu = xr * (ck[i - j] * vs[j]) + xhs * (c1[i - j] * vh[j]);
-                            if (j0 == jd && j == i) gu = 0.0;
-                            s0 += gu;
-                            lmax = fmax(lmax, fabs(gu));
-                        }
+                    const double* c1i = c1 + i;
+                    double m0 = 0.0, m1 = 0.0;
+                    int j = 0;
+                    for (; j + 1 < nd; j += 2) {
+                        double g0 = xr * (cki[-j] * vs[j]) + xhs * (c1i[-j] * vh[j]);
+                        double g1 = xr * (cki[-j - 1] * vs[j + 1]) + xhs * (c1i[-j - 1] * vh[j + 1]);
+                        g0 = (j == i) ? 0.0 : g0;
+                        g1 = (j + 1 == i) ? 0.0 : g1;
+                        s0 += g0; s1 += g1;
+                        m0 = fmax(m0, fabs(g0)); m1 = fmax(m1, fabs(g1));
                     }
-                    s0 = hw_sum(s0);
-                    if (lane == 0) {
-                        bsum[i] = s0;
-                        gdia[i] = ((xr * ck[0]) * xi + ((xh[i] * c1[0]) * xh[i]) / sig2) + beta;
+                    if (j < nd && j != i) {
+                        const double g0 = xr * (cki[-j] * vs[j]) + xhs * (c1i[-j] * vh[j]);
+                        s0 += g0; m0 = fmax(m0, fabs(g0));
                     }
+                    lmax = fmax(lmax, fmax(m0, m1));
+                    bsum[i] = s0 + s1;
+                    gdia[i] = ((xr * ck[0]) * xi + ((xh[i] * c1[0]) * xh[i]) / sig2) + beta;
                 } else {
-                    double mx0 = 0.0;
-                    for (int j0 = 0; j0 < nd; j0 += 64) {
-                        const int j = j0 + lane;
-                        if (j < nd) {
-                            double t0 = ck[i - j] * vs[j];
-                            if (j0 == jd && j == i) t0 = 0.0;
-                            s0 += t0;
-                            mx0 = fmax(mx0, fabs(t0));
-                        }
+                    double s2 = 0.0, s3 = 0.0, m0 = 0.0, m1 = 0.0;
+                    int j = 0;
+                    for (; j + 3 < nd; j += 4) {
+                        double t0 = cki[-j] * vs[j], t1 = cki[-j - 1] * vs[j + 1];
+                        double t2 = cki[-j - 2] * vs[j + 2], t3 = cki[-j - 3] * vs[j + 3];
+                        t0 = (j == i) ? 0.0 : t0;
+                        t1 = (j + 1 == i) ? 0.0 : t1;
+                        t2 = (j + 2 == i) ? 0.0 : t2;
+                        t3 = (j + 3 == i) ? 0.0 : t3;
+                        s0 += t0; s1 += t1; s2 += t2; s3 += t3;
+                        m0 = fmax(m0, fmax(fabs(t0), fabs(t1)));
+                        m1 = fmax(m1, fmax(fabs(t2), fabs(t3)));
                     }
-                    s0 = hw_sum(s0);
-                    lmax = fmax(lmax, fabs(xr) * mx0);
-                    if (lane == 0) { bsum[i] = xr * s0; gdia[i] = (xr * ck[0]) * xi + beta; }
+                    for (; j < nd; ++j)
+                        if (j != i) { const double t0 = cki[-j] * vs[j]; s0 += t0; m0 = fmax(m0, fabs(t0)); }
+                    lmax = fmax(lmax, fabs(xr) * fmax(m0, m1));
+                    bsum[i] = xr * ((s0 + s1) + (s2 + s3));
+                    gdia[i] = (xr * ck[0]) * xi + beta;
                 }
             }
             gmax = hw_max(lmax);
@@ -503,6 +555,7 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         update_block(k, xs + ns, n - ns, ns, st.toeplitz_m != 0, k == 0, st.opts.s_alpha[k], st.opts.s_0[k],
                      st.opts.sigma_ds[k], st.opts.rho_alpha[k], st.opts.rho_0[k], st.rho + (size_t)b * 3,
                      st.xmx + (size_t)b * 3, st.opts.eff_hp ? 1.0 : st.rho[(size_t)b * 3 + k]);
+        HPROF(1 + k);
     }
     if (st.prepared && st.desc.dop_size > 0) {
         for (int k = 0; k < 3; ++k) {
@@ -540,10 +593,12 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         }
     }
 
+    HPROF(4);
     // weights
     double* wg = st.w + (size_t)b * m;
     double* tmp3 = ctp + 3 * cw;       // [2][m], only present (and only touched) when outlier_p is set
     estimate_weights_dev(st, b, st.vmm, xs, tmp, tmp2, tmp3, tmp3 + m, st.est_w + (size_t)b * m, wg);
+    HPROF(5);
 
     // convergence (qphb.py:597-603, 969-970)
     double* xin = st.x_in + (size_t)b * n;
@@ -603,6 +658,8 @@ __global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
         }
         if (tid == 0) { st.coef_scale[b] /= sf; st.var_floor[b] *= sf * sf; }
     }
+    HPROF(6);
+    HPROF_COUNT(15);
     if (tid == 0) {
         st.outer_iters[b] = it + 1;
         if (stop) { st.active[b] = 0; st.fit_status[b] = 0; }

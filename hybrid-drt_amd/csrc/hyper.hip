@@ -183,7 +183,10 @@ __global__ __launch_bounds__(HT) void prep_prepared_kernel(FitState st) {
 }
 
 // y[i] = sum_j M[i][j] * v[j] for the rows owned by this wavefront; v in LDS; result to LDS out.  Four rows per
-// pass with 16-byte loads (the row loads of a pass are independent, so they are all in flight together).
+// pass with 16-byte loads, MV_UC column chunks of 128 requested before the first product: 4 * MV_UC independent loads
+// in flight per lane (one L2 round trip per 512 columns instead of one per chunk; more would not fit 128 VGPRs).  Columns past the end are
+// loaded from a clamped address and left out of the sum, so the per-lane order of additions is the plain loop's.
+static constexpr int MV_UC = 4;
 __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld, int nrow, int ncol,
                                             const double* __restrict__ v, double* __restrict__ out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -194,16 +197,29 @@ __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld
             const double* r2 = M + (size_t)(i0 + 2 < nrow ? i0 + 2 : i0) * ld;
             const double* r3 = M + (size_t)(i0 + 3 < nrow ? i0 + 3 : i0) * ld;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            for (int j = 2 * lane; j < ncol; j += 128) {
-                const double2 a0 = *reinterpret_cast<const double2*>(r0 + j);
-                const double2 a1 = *reinterpret_cast<const double2*>(r1 + j);
-                const double2 a2 = *reinterpret_cast<const double2*>(r2 + j);
-                const double2 a3 = *reinterpret_cast<const double2*>(r3 + j);
-                const double vx = v[j], vy = v[j + 1];
-                s0 += a0.x * vx + a0.y * vy;
-                s1 += a1.x * vx + a1.y * vy;
-                s2 += a2.x * vx + a2.y * vy;
-                s3 += a3.x * vx + a3.y * vy;
+            for (int base = 0; base < ncol; base += 128 * MV_UC) {
+                const int jb = base + 2 * lane;
+                double2 a0[MV_UC], a1[MV_UC], a2[MV_UC], a3[MV_UC];
+#pragma unroll
+                for (int c = 0; c < MV_UC; ++c) {
+                    if (base + 128 * c >= ncol) break;               // the whole chunk lies past the end (uniform)
+                    const int j = jb + 128 * c, jj = j < ncol ? j : ncol - 2;
+                    a0[c] = *reinterpret_cast<const double2*>(r0 + jj);
+                    a1[c] = *reinterpret_cast<const double2*>(r1 + jj);
+                    a2[c] = *reinterpret_cast<const double2*>(r2 + jj);
+                    a3[c] = *reinterpret_cast<const double2*>(r3 + jj);
+                }
+#pragma unroll
+                for (int c = 0; c < MV_UC; ++c) {
+                    const int j = jb + 128 * c;
+                    if (j < ncol) {
+                        const double vx = v[j], vy = v[j + 1];
+                        s0 += a0[c].x * vx + a0[c].y * vy;
+                        s1 += a1[c].x * vx + a1[c].y * vy;
+                        s2 += a2[c].x * vx + a2[c].y * vy;
+                        s3 += a3[c].x * vx + a3[c].y * vy;
+                    }
+                }
             }
             s0 = hw_sum(s0); s1 = hw_sum(s1); s2 = hw_sum(s2); s3 = hw_sum(s3);
             if (lane == 0) {
@@ -381,7 +397,7 @@ void launch_vmm_exclude_self(hipStream_t s, const double* vmm, int m, double* ou
 // ---------------------------------------------------------------------------------------------------------
 // hyper-parameter update + weights + convergence for one outer iteration.  grid = B
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HT) void hyper_kernel(FitState st, int it) {
+__global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {     // <= 128 VGPRs: two workgroups per CU
     extern __shared__ double sm[];
     __shared__ double red[HNW];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

@@ -9,6 +9,7 @@
 // n <= 2048: inverse diagonal blocks in LDS up to n = 528, in global memory beyond.  This file holds the launchers.
 #include <mutex>
 #include <cstdlib>
+#include <cstdio>
 
 #include "qp_common.hpp"
 #include "qp_resident.hpp"
@@ -92,7 +93,8 @@ static int launch_qp_super(hipStream_t st, const QpArgs& a) {
 static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
     const int NP = round_up(a.n, 32);
     if (!a.Ppk) { set_error("qp resident: packed copy of P missing"); return HIPDRT_E_INVALID; }
-    const bool gu = a.n > RNP_MAX;          // inverse diagonal blocks in global memory: any n <= 2048
+    static const bool force_gu = getenv("HIPDRT_QP_GU") != nullptr;      // experiments: the U-outside form for small n too
+    const bool gu = a.n > RNP_MAX || force_gu;          // inverse diagonal blocks in global memory: any n <= 2048
     const size_t lds = gu ? resident_gu_lds_bytes() : resident_lds_bytes(NP);
     const void* fn = gu ? reinterpret_cast<const void*>(qp_kernel_resident<true>) : reinterpret_cast<const void*>(qp_kernel_resident<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

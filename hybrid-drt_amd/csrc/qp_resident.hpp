@@ -37,7 +37,19 @@ namespace hipdrt {
 
 static constexpr int RT = 512;           // threads
 static constexpr int RNW = RT / 64;      // 8 wavefronts
-static constexpr int RMAXT = 4;          // tile rows per wavefront and pass
+#ifndef HIPDRT_QP_RMAXT
+#define HIPDRT_QP_RMAXT 4
+#endif
+#ifndef HIPDRT_QP_SWEEPCAP
+#define HIPDRT_QP_SWEEPCAP 5
+#endif
+#ifndef HIPDRT_QP_LADEPTH
+#define HIPDRT_QP_LADEPTH 4
+#endif
+#ifndef HIPDRT_QP_MINWAVES
+#define HIPDRT_QP_MINWAVES 2
+#endif
+static constexpr int RMAXT = HIPDRT_QP_RMAXT;   // tile rows per wavefront and pass
 static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
 static constexpr int DLD = 17;           // row stride of the 16x16 LDS scratch blocks
@@ -78,6 +90,11 @@ using ResSmem = ResSmemT<false>;
 // is built.  256 (chain, look-ahead, two row wavefronts, U in global memory, two workgroups per CU so that one's sequential
 // phases overlap the other's matrix work) compiles to 256 VGPRs and is parity-green, but measured 12.5 ms per launch against
 // 10.6: both workgroups put their row wavefronts on the same two SIMDs and every block column needs three to four passes.
+// Two 512-THREAD workgroups per CU (128 VGPRs each: `make VARIANT=two EXTRA="-DHIPDRT_QP_RMAXT=2 -DHIPDRT_QP_MINWAVES=4
+// -DHIPDRT_QP_SWEEPCAP=2 -DHIPDRT_QP_LADEPTH=2"`, run with HIPDRT_QP_GU=1 so that U lives in global memory and LDS admits
+// two) is parity-green as well -- the ~200 spilled registers stay outside the operand rings -- and measured 14.7 ms per
+// launch against 11.3 for one workgroup per CU in the same U-outside form (10.65 with U in LDS): halving every wavefront's
+// rows per pass, ring depth and sweep buffers costs more than the second workgroup's overlap returns.
 template <bool GU, int RTT = 512>
 struct OpsResidentT {
     static constexpr int RT = RTT, RNW = RTT / 64;                     // (shadow the namespace-level defaults)
@@ -320,9 +337,17 @@ struct OpsResidentT {
                             __builtin_amdgcn_sched_barrier(0);
                         };
 #undef HIPDRT_STEP7
-                        Frag f0, f1, f2, f3;
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
                         __builtin_amdgcn_sched_barrier(0);
+#if HIPDRT_QP_LADEPTH == 2
+                        Frag f0, f1;                                     // (two-per-CU experiment: half the registers)
+                        loadf(f0, 0);
+                        for (int k2 = 0; k2 < nk2; k2 += 2) {
+                            loadf(f1, k2 + 1); vm_wait<4>(); multf(f0);
+                            loadf(f0, k2 + 2); vm_wait<4>(); multf(f1);
+                        }
+#else
+                        Frag f0, f1, f2, f3;
                         loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
                         for (int k2 = 0; k2 < nk2; k2 += 4) {           // nk2 = 4 jb: a multiple of 4
                             loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
@@ -330,6 +355,7 @@ struct OpsResidentT {
                             loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
                             loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
                         }
+#endif
                         vm_wait<0>();
                         if (!v3) {
                             // R3 is pure padding (its operand was a stand-in): no panel tiles, identity diagonal
@@ -549,8 +575,8 @@ struct OpsResidentT {
         double* vec = sm.vec;
         const double* U = sm.U;
         constexpr int UW = RNW - 1;                 // updater wavefronts
-        constexpr int FT = (31 + UW - 1) / UW < 5 ? (31 + UW - 1) / UW : 5;      // forward: buffered tiles per updater wavefront
-        constexpr int BC = (32 + UW - 1) / UW < 5 ? (32 + UW - 1) / UW : 5;      // backward: buffered chunks per updater wavefront
+        constexpr int FT = (31 + UW - 1) / UW < HIPDRT_QP_SWEEPCAP ? (31 + UW - 1) / UW : HIPDRT_QP_SWEEPCAP;      // forward: buffered tiles per updater wavefront
+        constexpr int BC = (32 + UW - 1) / UW < HIPDRT_QP_SWEEPCAP ? (32 + UW - 1) / UW : HIPDRT_QP_SWEEPCAP;      // backward: buffered chunks per updater wavefront
         PROF_DECL
         // Two roles, two code paths with matching barrier sequences (per block: one barrier after the diagonal step,
         // one after the update).  The barriers order LDS traffic only, so the updaters' operand tiles -- fetched TWO
@@ -658,8 +684,8 @@ struct OpsResidentT {
         double* vec = sm.vec;
         const double* U = sm.U;
         constexpr int UW = RNW - 1;                 // updater wavefronts
-        constexpr int FT = (31 + UW - 1) / UW < 5 ? (31 + UW - 1) / UW : 5;      // forward: buffered tiles per updater wavefront
-        constexpr int BC = (32 + UW - 1) / UW < 5 ? (32 + UW - 1) / UW : 5;      // backward: buffered chunks per updater wavefront
+        constexpr int FT = (31 + UW - 1) / UW < HIPDRT_QP_SWEEPCAP ? (31 + UW - 1) / UW : HIPDRT_QP_SWEEPCAP;      // forward: buffered tiles per updater wavefront
+        constexpr int BC = (32 + UW - 1) / UW < HIPDRT_QP_SWEEPCAP ? (32 + UW - 1) / UW : HIPDRT_QP_SWEEPCAP;      // backward: buffered chunks per updater wavefront
         PROF_DECL
         // Two roles, two code paths with matching barrier sequences (per block: one barrier after the diagonal step,
         // one after the update).  The barriers order LDS traffic only, so the updaters' operand tiles -- fetched TWO
@@ -905,7 +931,7 @@ __global__ __launch_bounds__(RTT) void cov_kernel_resident(CovArgs a, int NP) {
 // (the second launch-bound argument is waves per SIMD: 2 in both forms, i.e. one 512-thread or two 256-thread workgroups per
 // CU and at most 256 registers per lane; without it hipcc gives the 256-thread form 393 registers and one workgroup per CU)
 template <bool GU, int RTT = 512>
-__global__ __launch_bounds__(RTT, 2) void qp_kernel_resident(QpArgs a, int NP) {
+__global__ __launch_bounds__(RTT, HIPDRT_QP_MINWAVES) void qp_kernel_resident(QpArgs a, int NP) {
     constexpr int RT = RTT;
     const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
     if (a.active && !a.active[b]) return;
@@ -921,14 +947,15 @@ __global__ __launch_bounds__(RTT, 2) void qp_kernel_resident(QpArgs a, int NP) {
     for (int i = threadIdx.x; i < NP + 32; i += RT) ops.sm.vec[i] = 0.0;
     __syncthreads();
     IpmSmem is{ops.sm.vec, ops.sm.dvec, ops.sm.red};
-    ipm_solve<RT, GU ? 2048 / RT : (RNP_MAX + RT - 1) / RT>(a, b, ops, is);
+    ipm_solve<RT, GU ? (2048 + RT - 1) / RT : (RNP_MAX + RT - 1) / RT>(a, b, ops, is);
 }
 
 // LDS bytes: everything for n <= 528, only the fixed part when U lives in global memory
 static size_t resident_lds_bytes(int NP) {
     return ((size_t)NP * PLD + ResSmem::FIXED) * sizeof(double);
 }
-static size_t resident_gu_lds_bytes() { return (size_t)ResSmemT<true, 512>::FIXED * sizeof(double); }
+template <int RTT = 512>
+static size_t resident_gu_lds_bytes() { return (size_t)ResSmemT<true, RTT>::FIXED * sizeof(double); }
 // per-problem scratch doubles of the U-outside form: the tile-packed factor (NP^2) followed by U (NP x 33)
 static size_t resident_gu_doubles(int n) {
     const size_t NP = (size_t)round_up(n, 32);

@@ -491,9 +491,23 @@ struct OpsResidentT {
                             __builtin_amdgcn_sched_barrier(0);
                         };
                         SlA a0, a1, a2, a3;
-                        SlB b0, b1;
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
                         __builtin_amdgcn_sched_barrier(0);
+#ifdef HIPDRT_QP_BRING4
+                        // (experiment, -DHIPDRT_QP_BRING4) B three half-chunks ahead like A: loads return in order, so with B one
+                        // step ahead every A issued before it has to be back a step early (an effective lead of two steps).
+                        // Measured 10.61 vs 10.66 ms per launch at the cost of 8 spilled registers: the operand stream is
+                        // not what the row wavefronts wait for, so the default keeps the two-slot B ring.
+                        SlB b0, b1, b2, b3;
+                        loadB(b0, 0); loadA(a0, 0); loadB(b1, 1); loadA(a1, 1); loadB(b2, 2); loadA(a2, 2);
+                        for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 4 jb: a multiple of 4
+                            loadB(b3, k2 + 3); loadA(a3, k2 + 3); vm_wait<3 * (RMAXT + 2)>(); mult(a0, b0);
+                            loadB(b0, k2 + 4); loadA(a0, k2 + 4); vm_wait<3 * (RMAXT + 2)>(); mult(a1, b1);
+                            loadB(b1, k2 + 5); loadA(a1, k2 + 5); vm_wait<3 * (RMAXT + 2)>(); mult(a2, b2);
+                            loadB(b2, k2 + 6); loadA(a2, k2 + 6); vm_wait<3 * (RMAXT + 2)>(); mult(a3, b3);
+                        }
+#else
+                        SlB b0, b1;
                         loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
                         for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 4 jb: a multiple of 4
                             loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RMAXT + 2>(); mult(a0, b0);
@@ -501,6 +515,7 @@ struct OpsResidentT {
                             loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RMAXT + 2>(); mult(a2, b0);
                             loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<2 * RMAXT + 2>(); mult(a3, b1);
                         }
+#endif
                         vm_wait<0>();
                     }
                     if (ps == 0) {

@@ -68,17 +68,21 @@ struct ResSmemT {
     double* dsc;     // [16][DLD]   diagonal block being factored
     double* img;     // [2][64][4]  register images of -D21', -D22' of the next diagonal block
     int* flag;       // [4]
+    unsigned char* sched;   // [nblk][SROW] owner wavefront of every tile row below a block column (build_schedule)
 
     // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
     static constexpr int VEC = GU ? 2048 + 32 + 32 : 528 + 16 + 32;      // NP + 32 (NP <= 544, or <= 2080 with U outside)
-    static constexpr int FIXED = 4 * (RTT / 64) * 4 + 2 * 16 * 17 + 8 + 512 + 2 * VEC;   // doubles before U
+    static constexpr int SROW = GU ? 128 : 32;                           // table row: tile rows below a block column (<= 124 | 29)
+    static constexpr int SCHED = GU ? 64 * 128 / 8 : 17 * 32 / 8 + 4;    // doubles: nblk <= 64 | 17 rows of SROW bytes
+    static constexpr int FIXED = 4 * (RTT / 64) * 4 + 2 * 16 * 17 + 8 + 512 + SCHED + 2 * VEC;   // doubles before U
     __device__ __forceinline__ void carve(double* smem) {
         red = smem;
         t21 = red + 4 * (RTT / 64) * 4;
         dsc = t21 + 16 * 17;
         flag = reinterpret_cast<int*>(dsc + 16 * 17);
         img = dsc + 16 * 17 + 8;
-        vec = img + 512;
+        sched = reinterpret_cast<unsigned char*>(img + 512);
+        vec = img + 512 + SCHED;
         dvec = vec + VEC;
         U = dvec + VEC;
     }
@@ -108,6 +112,55 @@ struct OpsResidentT {
     // a block column's tiles sit in registers): the predictor's forward sweep costs no pass over L in HBM.
     static constexpr bool kFusedForward = true;
     bool fwd = true;
+
+    // Which row wavefront owns which tile row below block column jb.  The rank-k phase is bound by the busiest SIMD's FP64
+    // MFMA pipe: wavefront w sits on SIMD w % 4, the look-ahead wavefront (1) carries a fixed 14 MFMAs per half-chunk
+    // whatever the number of rows left, and a plain round-robin gives its SIMD partner (5) as many rows as everyone else
+    // (sum over the block columns of the busiest SIMD at n = 514: 657k cycles, 417k if perfectly balanced).  The table gives
+    // every row to the least-loaded SIMD instead -- one thread per block column, once per launch; results do not depend on
+    // who computes a row.  Only for the plain factorisation (no appended rows) with 8 wavefronts.
+    bool balanced = false;
+    __device__ __forceinline__ void build_schedule() {
+        balanced = (RNW == 8) && nex == 0;
+        if (!balanced) return;
+        const int ntr = (n + 15) >> 4, nblk = (n + NB - 1) / NB;
+        constexpr int SROW = ResSmemT<GU, RTT>::SROW;
+        for (int jb = threadIdx.x; jb < nblk; jb += RT) {
+            const int tb = 2 * jb, nk2 = 4 * jb;
+            const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;
+            const int c = 4 * nk2 + 12;                               // MFMAs of one row: rank-k + triangular solve
+            // no more passes than the round-robin needs: a wavefront's rows beyond its first RMAXT are streamed after
+            // barrier (A), i.e. in series with the diagonal chain
+            const int cap = RMAXT * (nsq > 6 * RMAXT ? (nsq + 6 * RMAXT - 1) / (6 * RMAXT) : 1);
+#ifndef HIPDRT_QP_CHAINLOAD
+#define HIPDRT_QP_CHAINLOAD 150
+#endif
+#ifndef HIPDRT_QP_LALOAD
+#define HIPDRT_QP_LALOAD 14
+#endif
+            // SIMD 0 also runs the diagonal chain (~21k cycles per block column = ~300 MFMA slots of FP64 vector work that a
+            // partner's FP64 MFMAs slow down by 40 %, profiles/r02d_chain_partner.txt): wavefront 4 is charged with it
+            int l0 = HIPDRT_QP_CHAINLOAD, l1 = (tb + 2 < ntr) ? HIPDRT_QP_LALOAD * nk2 + 24 : 0, l2 = 0, l3 = 0;      // MFMAs per SIMD
+            int c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;                          // rows per wavefront
+            for (int r = 0; r < nsq; ++r) {
+                // candidate of each SIMD: its row wavefront with fewer rows (SIMD 0: 4, SIMD 1: 5, SIMD 2: 2|6, SIMD 3: 3|7)
+                const int w2 = c2 <= c6 ? 2 : 6, n2 = c2 <= c6 ? c2 : c6;
+                const int w3 = c3 <= c7 ? 3 : 7, n3 = c3 <= c7 ? c3 : c7;
+                int best = -1, bl = 0x7fffffff;
+                if (c4 < cap && l0 < bl) { best = 4; bl = l0; }
+                if (n2 < cap && l2 < bl) { best = w2; bl = l2; }
+                if (n3 < cap && l3 < bl) { best = w3; bl = l3; }
+                if (c5 < cap && l1 < bl) { best = 5; bl = l1; }
+                sm.sched[jb * SROW + r] = (unsigned char)best;
+                if (best == 4) { ++c4; l0 += c; }
+                else if (best == 5) { ++c5; l1 += c; }
+                else if (best == 2) { ++c2; l2 += c; }
+                else if (best == 6) { ++c6; l2 += c; }
+                else if (best == 3) { ++c3; l3 += c; }
+                else { ++c7; l3 += c; }
+            }
+        }
+    }
 
     // tile (t, c) starts at ((t*nch + c) * TSZ) doubles; returned in double2 units
     __device__ __forceinline__ const double2* tile2(int t, int c) const {
@@ -431,16 +484,37 @@ struct OpsResidentT {
                 const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;   // rows of the square matrix below R3
                 const int nothers = nsq + nex;                               // ... followed by the appended rows
                 const bool two = (tb + 1) < ntr;                             // second tile column is not pure padding
-                const int npass = nothers > OW * RMAXT ? (nothers + OW * RMAXT - 1) / (OW * RMAXT) : 1;
+                int npass = nothers > OW * RMAXT ? (nothers + OW * RMAXT - 1) / (OW * RMAXT) : 1;
+                // balanced schedule (build_schedule): bit r of (m0, m1) = tile row tb + 4 + r is this wavefront's
+                unsigned long long m0 = 0, m1 = 0;
+                if (balanced) {
+                    constexpr int SROW = ResSmemT<GU, RTT>::SROW;
+                    const unsigned char* row = sm.sched + jb * SROW;
+                    m0 = __ballot(lane < nsq && row[lane] == wv);
+                    if (SROW > 64) m1 = __ballot(lane + 64 < nsq && row[lane + 64] == wv);
+                    const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);
+                    npass = mine > RMAXT ? (mine + RMAXT - 1) / RMAXT : 1;
+                }
 #pragma unroll 1
                 for (int ps = 0; ps < npass; ++ps) {
                     int T[RMAXT];
                     bool act[RMAXT];
+                    if (balanced) {
 #pragma unroll
-                    for (int u = 0; u < RMAXT; ++u) {
-                        const int slot = (wv - 2) + u * OW + ps * OW * RMAXT;
-                        T[u] = slot < nsq ? tb + 4 + slot : nch + (slot - nsq);
-                        act[u] = slot < nothers;
+                        for (int u = 0; u < RMAXT; ++u) {
+                            int r = -1;
+                            if (m0) { r = __builtin_ctzll(m0); m0 &= m0 - 1; }
+                            else if (m1) { r = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+                            T[u] = r >= 0 ? tb + 4 + r : nch;
+                            act[u] = r >= 0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < RMAXT; ++u) {
+                            const int slot = (wv - 2) + u * OW + ps * OW * RMAXT;
+                            T[u] = slot < nsq ? tb + 4 + slot : nch + (slot - nsq);
+                            act[u] = slot < nothers;
+                        }
                     }
                     // ---- (1) accT = -(S' tile) + sum_c L(Cc, c) L(T, c)' --------------------------------------
                     v4d acc[RMAXT][2];
@@ -956,6 +1030,7 @@ __global__ __launch_bounds__(RTT, HIPDRT_QP_MINWAVES) void qp_kernel_resident(Qp
     ops.Ppk = a.Ppk ? a.Ppk + (size_t)b * a.ppk_stride : nullptr; ops.nchp = a.nchp;
     ops.sm.carve(smem);
     if (GU) ops.sm.U = resident_u_ptr<GU>(ops.L, NP);
+    ops.build_schedule();
     // zero U (the upper-right quarter of every inverse block stays zero) and the padding of vec (read by the
     // updates of the last, partial block)
     for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;

@@ -102,6 +102,31 @@ def test_impedance_interp_batched_frequency_grids(ctx):
         np.testing.assert_allclose(a_im[b], o_im, rtol=RTOL, atol=1e-300)
 
 
+def test_impedance_interp_irregular_tables(ctx):
+    """The general build's interpolation must be numpy's for ANY increasing table: knots jittered off the uniform grid (the
+    arithmetic bin is then off by one and the search runs), an odd number of knots, different abscissae for Z' and Z'',
+    abscissae beyond both table ends, odd tau count -- and the same table on both sides (one shared bin search)."""
+    from hipdrt.matrices import mat1d
+    rng = np.random.default_rng(11)
+    ng = 1999
+    def table(lim):
+        x = np.linspace(-lim, lim, ng)
+        x[1:-1] += rng.uniform(-0.45, 0.45, ng - 2) * (x[1] - x[0])          # still increasing, visibly non-uniform
+        return x, np.cumsum(rng.standard_normal(ng)) * 0.01 + np.sin(x)
+    t_re, t_im = table(6.2), table(12.4)
+    tau = np.logspace(-6, 3, 75)
+    freq = np.sort(10 ** rng.uniform(-4, 8, size=(4, 41)), axis=1)[:, ::-1].copy()      # ln(omega tau) in [-21, 26]
+    for grids in ((t_re, t_im), (t_im, t_im)):
+        a_re, a_im = mat1d.construct_impedance_matrices(freq, tau, 1.0, 'interp', interpolate_grids=grids)
+        for b in range(freq.shape[0]):
+            x = np.log(2 * np.pi * freq[b])[:, None] + np.log(tau)[None, :]
+            for got, (xp, fp) in ((a_re[b], grids[0]), (a_im[b], grids[1])):
+                want = np.interp(x, xp, fp)
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-13 * np.abs(fp).max())
+                outside = (x < xp[0]) | (x > xp[-1])
+                assert outside.any() and np.array_equal(got[outside], want[outside])      # table ends: copies, bit-exact
+
+
 @pytest.mark.parametrize("name", ["refrun_trapz_32x64.npz", "refrun_trapz_71x91_toeplitz.npz"])
 def test_impedance_trapz_vs_reference_fixture(ctx, name):
     from hipdrt.matrices import mat1d

@@ -41,7 +41,7 @@ static constexpr int RNW = RT / 64;      // 8 wavefronts
 #define HIPDRT_QP_RMAXT 4
 #endif
 #ifndef HIPDRT_QP_SWEEPCAP
-#define HIPDRT_QP_SWEEPCAP 5
+#define HIPDRT_QP_SWEEPCAP 5     // (vm_wait_tiles covers counts up to 5)
 #endif
 #ifndef HIPDRT_QP_LADEPTH
 #define HIPDRT_QP_LADEPTH 4
@@ -263,6 +263,18 @@ struct OpsResidentT {
         p_ += __shfl_xor(p_, 16, 64);
         p_ += __shfl_xor(p_, 32, 64);
         if (kq == 0) sm.vec[T * 16 + li] -= p_;
+    }
+
+    // s_waitcnt vmcnt(4 k) for a wave-uniform k <= 5: the sweeps leave the k tiles (4 loads each) of the next block in flight
+    static __device__ __forceinline__ void vm_wait_tiles(int k) {
+        switch (k) {
+            case 0: vm_wait<0>(); break;
+            case 1: vm_wait<4>(); break;
+            case 2: vm_wait<8>(); break;
+            case 3: vm_wait<12>(); break;
+            case 4: vm_wait<16>(); break;
+            default: vm_wait<20>(); break;
+        }
     }
 
     // operand fragments of a tile held in its register image (rg <-> column kq + 4 rg): k-half h = (x[2h], x[2h+1])
@@ -697,25 +709,33 @@ struct OpsResidentT {
             //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane -> row lane/4,
             //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
             const int l4 = lane & 3, g4 = lane >> 2;
-            struct Buf { double2 t[FT > BC ? FT : BC][4]; };
+            struct Buf { v2d t[FT > BC ? FT : BC][4]; };
+            const unsigned voff = (unsigned)lane * 16u;
             // ---- forward: L y = b -------------------------------------------------------------------------
+            // The operand tiles are requested TWO blocks ahead with gload16 (qp_common.hpp) and retired with a counted wait:
+            // left to hipcc, every use waits for vmcnt(0..3), i.e. also for the block requested one step ago, and a sweep
+            // step (~1.6k cycles of work) is then as long as a memory round trip.  The wait before block jb's tiles are used
+            // allows exactly the loads of block jb+1 to stay in flight (vm_wait_tiles: a uniform switch over the tile count).
+            auto fcount = [&](int jb) {                 // tiles this wavefront requests for block jb
+                const int tbelow = jb < nblk ? ntr - (2 * jb + 2) : 0;
+                const int k = tbelow - (wv - 1) > 0 ? (tbelow - (wv - 1) + UW - 1) / UW : 0;
+                return k < FT ? k : FT;
+            };
             auto fpre = [&](Buf& B_, int jb) {          // tiles (tb+2+tt, 2jb..2jb+1): [tile][chunk*2 + half]
-                if (jb < nblk) {
-                    const int tb = 2 * jb, tbelow = ntr - (tb + 2);
+                const int tb = 2 * jb, nv = fcount(jb);
 #pragma unroll
-                    for (int u = 0; u < FT; ++u) {
-                        const int tt = (wv - 1) + u * UW;
-                        if (tt < tbelow) {
-                            const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;   // chunks 2jb, 2jb+1 are adjacent
+                for (int u = 0; u < FT; ++u) {
+                    if (u < nv) {
+                        const char* p = uniform_ptr(tile2(tb + 2 + (wv - 1) + u * UW, 2 * jb));   // chunks 2jb, 2jb+1 are adjacent
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) B_.t[u][q] = p[q * 64];
-                        }
+                        for (int q = 0; q < 4; ++q) B_.t[u][q] = gload16(p + q * 1024, voff);
                     }
                 }
             };
             auto fstep = [&](Buf& B_, int jb) {
                 const int j0 = jb * NB, tb = 2 * jb, tbelow = ntr - (tb + 2);
                 lds_barrier();
+                vm_wait_tiles(fcount(jb + 1));                      // this block's tiles are in; the next block's may be in flight
                 if (tbelow > 0) {
                     // q = 2*chunk + half: lane holds columns 8q + l4 and 8q + l4 + 4 of tile row g4
                     double ya[4], yb[4];
@@ -762,6 +782,7 @@ struct OpsResidentT {
                     fstep(fa, jb);
                     if (jb + 1 < nblk) fstep(fb, jb + 1);
                 }
+                vm_wait<0>();
             }
         }
     }
@@ -806,21 +827,26 @@ struct OpsResidentT {
             //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane -> row lane/4,
             //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
             const int l4 = lane & 3, g4 = lane >> 2;
-            struct Buf { double2 t[FT > BC ? FT : BC][4]; };
+            struct Buf { v2d t[FT > BC ? FT : BC][4]; };
+            const unsigned voff = (unsigned)lane * 16u;
             // ---- backward: L' x = y -----------------------------------------------------------------------
+            // (operand tiles two blocks ahead, counted waits: see forward())
+            auto bcount = [&](int jb) {                 // chunks this wavefront requests for block jb
+                const int nc = jb > 0 ? 2 * jb : 0;
+                const int k = nc - (wv - 1) > 0 ? (nc - (wv - 1) + UW - 1) / UW : 0;
+                return k < BC ? k : BC;
+            };
             auto bpre = [&](Buf& B_, int jb) {          // tiles (tb..tb+1, c): [chunk][tile*2 + half]
-                if (jb >= 0) {
-                    const int tb = 2 * jb, nc = 2 * jb;
-                    const bool two = (tb + 1) < ntr;
+                const int tb = 2 * jb, nv = bcount(jb);
+                const bool two = (tb + 1) < ntr;
 #pragma unroll
-                    for (int u = 0; u < BC; ++u) {
+                for (int u = 0; u < BC; ++u) {
+                    if (u < nv) {
                         const int c = (wv - 1) + u * UW;
-                        if (c < nc) {
-                            const double2* p0 = tile2(tb, c) + lane;
-                            const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
-                            B_.t[u][0] = p0[0]; B_.t[u][1] = p0[64];
-                            B_.t[u][2] = p1[0]; B_.t[u][3] = p1[64];
-                        }
+                        const char* p0 = uniform_ptr(tile2(tb, c));
+                        const char* p1 = uniform_ptr(tile2(two ? tb + 1 : tb, c));
+                        B_.t[u][0] = gload16(p0, voff); B_.t[u][1] = gload16(p0 + 1024, voff);
+                        B_.t[u][2] = gload16(p1, voff); B_.t[u][3] = gload16(p1 + 1024, voff);
                     }
                 }
             };
@@ -828,6 +854,7 @@ struct OpsResidentT {
                 const int j0 = jb * NB, tb = 2 * jb, nc = 2 * jb;
                 const bool two = (tb + 1) < ntr;                    // second tile-row of the block holds valid rows
                 lds_barrier();
+                vm_wait_tiles(bcount(jb - 1));
                 if (nc > 0) {
                     // x of the block: row g4 of tile tb and of tile tb+1 (zero padding beyond n)
                     const double x0 = vec[j0 + g4];
@@ -870,6 +897,7 @@ struct OpsResidentT {
                     bstep(ba, jb);
                     if (jb - 1 >= 0) bstep(bb, jb - 1);
                 }
+                vm_wait<0>();
             }
         }
     }

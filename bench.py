@@ -209,8 +209,20 @@ def main():
         job_fits = total
 
     # one DRT + plan + HIP stream per in-flight batch
-    drts = [DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local)) for _ in range(nfl)]
-    plans = [d.stage_batch(freq, z[c]) for d, c in zip(drts, chunks)]     # lookups + matrices built, spectra resident
+    if config == "c3":
+        drts = [DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local)) for _ in range(nfl)]
+        plans = [d.stage_batch(freq, z[c]) for d, c in zip(drts, chunks)]     # lookups + matrices built, spectra resident
+    else:
+        # c4 goes through the product's own driver (mapping.fit_observations_sharded: shard -> `nfl` batches side by side
+        # on sibling plans -> one gather); this first call builds the sibling plans
+        from hipdrt.mapping.drtmd import drt_siblings, fit_observations_sharded
+        z_all = np.zeros((total, len(freq)), dtype=complex)
+        z_all[mine] = z                                   # every rank holds its own rows only
+        drt0 = DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local))
+        fit_observations_sharded(drt0, freq, z_all, rank=rank, world=world, scheme=args.shard, inflight=nfl)
+        drts = drt_siblings(drt0, nfl) if len(mine) >= 2 * nfl else [drt0]
+        nfl = len(drts)
+        plans = [d._plan for d in drts]
     drt, plan = drts[0], plans[0]
     if world > 1:                                         # rank 0's tables -> everyone (one RCCL broadcast)
         zr, zi = hd.broadcast_arrays([plan.get("lut_z_re"), plan.get("lut_z_im")], src=0)
@@ -218,8 +230,10 @@ def main():
             p_.set_lookup(zr, zi)
 
     for d in drts:
-        for _ in range(args.warmup):
+        for _ in range(args.warmup if config == "c3" else 0):
             d.fit_staged()
+    for _ in range(args.warmup if config == "c4" else 0):
+        fit_observations_sharded(drt, freq, z_all, rank=rank, world=world, scheme=args.shard, inflight=nfl)
 
     stats = [dict(qp_ms=0.0, qp_launch=0, phase={"gram": 0.0, "qp": 0.0, "hyper": 0.0}) for _ in range(nfl)]
     results = [None] * nfl
@@ -270,17 +284,10 @@ def main():
         t0 = time.perf_counter()
         gathered = None
         for _ in range(args.steps):
-            threads = [threading.Thread(target=worker_transfers, args=(i, 1)) for i in range(nfl)]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            if B:
-                part = np.concatenate([np.concatenate([r_["fit_x"], r_["R_inf"][:, None], r_["inductance"][:, None],
-                                                       r_["status"][:, None].astype(float)], axis=1) for r_ in results])
-            else:
-                part = np.zeros((0, len(tau) + 3))
-            gathered = hd.gather_rows(part, counts, dst=0)          # ONE collective per step
+            # upload, fit, llh / rss, download on every rank and ONE gather, all inside the product's driver
+            gathered = fit_observations_sharded(drt, freq, z_all, rank=rank, world=world, scheme=args.shard, inflight=nfl)
+            for i in range(nfl):
+                note(i)
         sync_all()
         hd.barrier()
         return hd.max_over_ranks(time.perf_counter() - t0), gathered
@@ -299,20 +306,23 @@ def main():
         res = drt.collect_staged()
     else:
         elapsed, gathered = timed_c4()
-        if rank == 0:
-            assert gathered.shape == (args.total, len(tau) + 3) and np.isfinite(gathered).all()
         qp_ms = sum(s_["qp_ms"] for s_ in stats)
         qp_launch = sum(s_["qp_launch"] for s_ in stats)
         phase = {k: sum(s_["phase"][k] for s_ in stats) for k in ("gram", "qp", "hyper")}
         steps_in_stats = args.steps
-        res = results[0]
+        res = None
+        if rank == 0:
+            obs_x, obs_special, res_all = gathered
+            assert obs_x.shape == (args.total, len(tau)) and np.isfinite(obs_x).all() and res_all["obs_fit_status"].all()
+            res = {k: res_all[k][mine] for k in ("outer_iters", "qp_iters_total", "status")}     # this rank's share
 
     n, m = plan.n, plan.m
     out = None
     if rank == 0:
         n_qp = res["outer_iters"].astype(np.int64) + 1
         flop_batch = float(qp_algorithmic_flop(n, res["qp_iters_total"].astype(np.int64), n_qp).sum())   # one plan's batch
-        launches_batch = qp_launch / max(steps_in_stats, 1) / (1 if config == "c3" else nfl)
+        # c3: `res` is one plan's batch; c4: this rank's whole share, whose launches are spread over its plans
+        launches_batch = qp_launch / max(steps_in_stats, 1)
         flop_per_launch = flop_batch / launches_batch
         avg_launch_s = qp_ms / max(qp_launch, 1) / 1e3
         achieved = flop_per_launch / avg_launch_s / 1e12
@@ -330,8 +340,9 @@ def main():
         value = job_fits * args.steps / elapsed
         nb = len(res["outer_iters"])
         outer_sum = float(res["outer_iters"].sum())
-        gram_s = phase["gram"] / steps_in_stats / 1e3 / (1 if config == "c3" else nfl)
-        hyper_s = phase["hyper"] / steps_in_stats / 1e3 / (1 if config == "c3" else nfl)
+        # (c4: `res` is the rank's whole share, so the times are summed over its plans as if they ran one after the other)
+        gram_s = phase["gram"] / steps_in_stats / 1e3
+        hyper_s = phase["hyper"] / steps_in_stats / 1e3
         gram_flop = (outer_sum + nb) * m * n * n            # lower triangle of A'WA: m n^2 per spectrum and QP
         out = {
             "metric": "DRT fits/sec (256 freq x 512 tau, batched)", "value": value, "unit": "fits/s",
@@ -343,8 +354,9 @@ def main():
                                     f"grid x 512-point tau grid, full QPHB loop (DRT.fit_eis defaults, interp lookups), "
                                     f"inputs resident in HBM") if config == "c3" else
                                    (f"BASELINE configs[3]: one map of {args.total} synthetic 2-ZARC spectra (256 x 512) "
-                                    f"sharded over {world} rank(s) ({args.shard} shards), per step upload + full QPHB "
-                                    f"loop + download on every rank and one gather on rank 0"),
+                                    f"sharded over {world} rank(s) ({args.shard} shards) by mapping.fit_observations_sharded: "
+                                    f"per step upload + full QPHB loop + llh / rss + download on every rank and one "
+                                    f"gather on rank 0"),
                        "batch_per_gpu": B, "nf": 256, "ntau": 512, "n_unknowns": n,
                        "sharding": (f"{world} rank(s) x {B} independent spectra, no data-path collective" if config == "c3"
                                     else f"{args.total} spectra over {world} rank(s), {counts} per rank, one all_gather "
@@ -361,7 +373,10 @@ def main():
                          "flop_convention": "SURVEY 8d: n^3/3 + 2*2*n^2 per IPM iteration, n^3/3 + 2 n^2 per start point",
                          # the same launch against the other roof: PMC bytes / HIP-event time
                          "traffic_GBps": None if traffic is None else traffic / avg_launch_s / 1e9,
-                         "traffic_frac_of_hbm_peak": None if traffic is None else traffic / avg_launch_s / 8e12},
+                         "traffic_frac_of_hbm_peak": None if traffic is None else traffic / avg_launch_s / 8e12,
+                         "note": None if config == "c3" else
+                         "c4: launch times are HIP-event intervals on streams that share the GPU with the other plans in "
+                         "flight, i.e. inflated by the overlap; the kernel's roofline figure is the c3 line's"},
             "roofline_gram": {"bound": "mfma", "kernel": "gram_kernel", "ms_per_step": gram_s * 1e3,
                               "achieved": gram_flop / max(gram_s, 1e-12) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": gram_flop / max(gram_s, 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,

@@ -45,8 +45,70 @@ def shard_indices(num_obs, world_size, rank, scheme='interleave', cost=None):
     raise ValueError(f"unknown sharding scheme {scheme!r}")
 
 
+_NOT_PER_OBS = ('basis_tau', 'timings_ms', 'launches', 'obs_tau_indices', 'obs_fit_errors')
+
+
+def drt_siblings(drt, count):
+    """`count` DRT objects with the configuration of `drt` (itself first), each sibling with its own hipdrt context (HIP
+    stream) and plan, so that their device loops run side by side; cached on `drt`."""
+    import copy
+    from .. import _ffi
+    sibs = getattr(drt, '_siblings', None) or [drt]
+    while len(sibs) < count:
+        c = copy.copy(drt)                     # configuration only: the arrays it refers to are read-only
+        c._plan = c._plan_key = c._last_batch = None
+        c._context = _ffi.Context(drt.device)
+        c._siblings = None
+        sibs.append(c)
+    drt._siblings = sibs
+    return sibs[:count]
+
+
+def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid, drt_var, ignore_errors, llh_kw, fit_kw):
+    """The observations in `inflight` contiguous chunks, each chunk one device batch on its own sibling plan, the host
+    threads overlapping their device loops: spectra finish after 4 ... 50 outer iterations, so one batch alone leaves
+    CUs idle in its tail, several side by side fill them ('batches in flight')."""
+    import threading
+    num = z_obs.shape[0]
+    chunks = [c for c in np.array_split(np.arange(num), inflight) if len(c)]
+    sibs = drt_siblings(drt, len(chunks))
+    outs, errs = [None] * len(chunks), [None] * len(chunks)
+
+    def work(i):
+        try:
+            outs[i] = fit_observations(sibs[i], frequencies, z_obs[chunks[i]], tau_supergrid=tau_supergrid, drt_var=drt_var,
+                                       ignore_errors=True, llh_kw=llh_kw, **fit_kw)
+        except BaseException as exc:            # re-raised in the caller's thread
+            errs[i] = exc
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(chunks))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for exc in errs:
+        if exc is not None:
+            raise exc
+    obs_x = np.concatenate([o[0] for o in outs])
+    obs_special = {k: np.concatenate([o[1][k] for o in outs]) for k in outs[0][1]}
+    res = {}
+    for k, v in outs[0][2].items():
+        if k in _NOT_PER_OBS:
+            res[k] = v
+        elif isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == len(chunks[0]):
+            res[k] = np.concatenate([o[2][k] for o in outs])
+        else:
+            res[k] = v
+    res['obs_fit_errors'] = [e for o in outs for e in o[2]['obs_fit_errors']]
+    if not ignore_errors and not res['obs_fit_status'].all():
+        bad = int(np.flatnonzero(~res['obs_fit_status'])[0])
+        print(f"Error encountered at obs_index {bad}")
+        raise res['obs_fit_errors'][bad]
+    return obs_x, obs_special, res
+
+
 def fit_observations(drt, frequencies, z_obs, tau_supergrid=None, drt_var=False, ignore_errors=True, llh_kw=None,
-                     **fit_kw):
+                     inflight=1, **fit_kw):
     """Fit every observation (rows of z_obs) and scatter the coefficients into supergrid slots like
     DRTMD.fit_observation does (drtmd.py:245-301): returns obs_x (B, len(supergrid)), obs_special dict, and the raw
     result dict, which also carries what the reference keeps per observation:
@@ -57,7 +119,13 @@ def fit_observations(drt, frequencies, z_obs, tau_supergrid=None, drt_var=False,
                              ``ignore_errors=False`` raises for the first failed observation as upstream does
                              (drtmd.py:292-301);
       obs_drt_var(+_ok)      with ``drt_var=True``: diagonal of estimate_distribution_cov(tau=tau_supergrid,
-                             extend_var=True) (drtmd.py:278-279)."""
+                             extend_var=True) (drtmd.py:278-279).
+    ``inflight`` > 1 fits the observations as that many batches side by side (sibling plans of `drt`, one host thread
+    each): same results, in the same order, at the throughput of several batches in flight."""
+    z_obs = np.asarray(z_obs)
+    if inflight > 1 and z_obs.shape[0] >= 2 * inflight:
+        return _fit_observations_inflight(drt, frequencies, z_obs, int(inflight), tau_supergrid, drt_var, ignore_errors,
+                                          llh_kw, fit_kw)
     res = drt.fit_eis_batch(frequencies, z_obs, **fit_kw)
     num = z_obs.shape[0]
     basis_tau = res['basis_tau']
@@ -89,7 +157,7 @@ _GATHER_KEYS = ('obs_llh', 'obs_rss', 'outer_iters', 'qp_iters_total', 'status')
 
 
 def fit_observations_sharded(drt, frequencies, z_obs, rank=None, world=None, tau_supergrid=None, scheme='interleave',
-                             drt_var=False, dst=0, fit=fit_observations, **fit_kw):
+                             drt_var=False, dst=0, fit=fit_observations, inflight=1, **fit_kw):
     """BASELINE configs[3]: the observations of one map sharded over the ranks of a node (one process per GPU), every
     rank fitting its share in one device batch, the results gathered on rank `dst` with ONE collective.
 
@@ -97,7 +165,7 @@ def fit_observations_sharded(drt, frequencies, z_obs, rank=None, world=None, tau
     Returns on `dst` the same triple as fit_observations for ALL observations in their original order (result dict
     reduced to the per-observation arrays obs_llh, obs_rss, outer_iters, qp_iters_total, status [, obs_drt_var]); None
     elsewhere.  `scheme`: see shard_indices ('lpt' uses difficulty_proxy(z_obs)).  `fit` is the per-rank fit function
-    (the CPU tests inject a stand-in)."""
+    (the CPU tests inject a stand-in); `inflight` > 1 is handed to it (batches side by side on every rank)."""
     from . import dist as hd
     if rank is None or world is None:
         import torch.distributed as tdist
@@ -109,6 +177,8 @@ def fit_observations_sharded(drt, frequencies, z_obs, rank=None, world=None, tau
     owned = [shard_indices(num, world, r, scheme, cost) for r in range(world)]
     mine = owned[rank]
     if len(mine):
+        if inflight > 1:
+            fit_kw = dict(fit_kw, inflight=inflight)
         obs_x, obs_special, res = fit(drt, frequencies, z_obs[mine], tau_supergrid=tau_supergrid, drt_var=drt_var, **fit_kw)
         cols = [obs_x, obs_special['R_inf'][:, None], obs_special['inductance'][:, None]]
         cols += [np.asarray(res[k], dtype=float)[:, None] for k in _GATHER_KEYS]

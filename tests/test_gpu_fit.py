@@ -207,6 +207,36 @@ def test_fit_observations_records_what_drtmd_records():
         fit_observations(drt, freq, zbad, tau_supergrid=supergrid, ignore_errors=False)
 
 
+def test_fit_observations_in_flight_is_the_same_fit():
+    """inflight=k: the observations as k batches side by side on sibling plans (own HIP streams, host threads) -- every
+    per-observation result bit-identical to the one-batch call and in the same order, error capture included"""
+    from hipdrt import synth
+    from hipdrt.mapping import fit_observations
+    from hipdrt.models import DRT
+    freq = np.logspace(6, -1, 71)
+    z = synth.zarc2_batch(freq, 23, first_seed=500)
+    z[7] = np.nan
+    supergrid = np.logspace(-9, 3, 121)
+    drt = DRT(tau_supergrid=supergrid)
+    x1, sp1, r1 = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True)
+    x3, sp3, r3 = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True, inflight=3)
+    assert len(drt._siblings) == 3 and drt._siblings[0] is drt
+    np.testing.assert_array_equal(x1, x3)
+    for k in sp1:
+        np.testing.assert_array_equal(sp1[k], sp3[k])
+    for k in ("obs_llh", "obs_rss", "outer_iters", "qp_iters_total", "status", "x", "weights", "s_vectors", "obs_drt_var",
+              "obs_drt_var_ok", "obs_fit_status"):
+        np.testing.assert_array_equal(r1[k], r3[k], err_msg=k)
+    assert r3["obs_tau_indices"] == r1["obs_tau_indices"] and len(r3["obs_fit_errors"]) == 23
+    assert isinstance(r3["obs_fit_errors"][7], ValueError) and r3["obs_fit_status"].sum() == 22
+    with pytest.raises(ValueError):
+        fit_observations(drt, freq, z, tau_supergrid=supergrid, ignore_errors=False, inflight=3)
+    # second call: the sibling plans are reused
+    plans = [d._plan for d in drt._siblings]
+    fit_observations(drt, freq, z, tau_supergrid=supergrid, inflight=3)
+    assert [d._plan for d in drt._siblings] == plans
+
+
 def test_qphb_fit_core_as_drtmd_calls_it():
     """DRTMD.fit_observation's call, verbatim: drt1d._qphb_fit_core(*chrono_data, *eis_data, **fit_kw) with
     chrono_data = (None, None, None) for an EIS observation (drtmd.py:253), (None, None) eis_data for a chrono one"""

@@ -140,6 +140,8 @@ def main():
                          "over the ranks, strong); auto = c3 on one GPU, c4 on several")
     ap.add_argument("--batch", type=int, default=1024, help="c3: spectra per GPU per step")
     ap.add_argument("--total", type=int, default=10000, help="c4: spectra of the whole map")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' lets several "
+                                                    "ranks share one GPU for a functional check of the N > 1 path")
     ap.add_argument("--shard", choices=("block", "interleave", "lpt"), default="interleave", help="c4: shard scheme")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batches kept in flight per GPU (each on its own plan + HIP stream); c3: steps are dealt "
@@ -185,8 +187,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.backend == "gloo":
+        local %= torch.cuda.device_count()               # functional check: ranks may share a GPU
     torch.cuda.set_device(local)
-    rank, world, local = hd.init_from_env(device=local)
+    rank, world, _ = hd.init_from_env(backend=args.backend, device=local)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 

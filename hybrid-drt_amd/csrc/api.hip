@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 #include "common.hpp"
 #include <vector>
@@ -95,7 +96,7 @@ int hipdrt_create(int device, hipdrt_ctx** out) {
         return HIPDRT_E_NODEVICE;
     }
     HIPDRT_REQUIRE(device >= 0 && device < count, "device index out of range");
-    HIPDRT_CHECK(hipSetDevice(device));
+    HIPDRT_CHECK(hipSetDevice(device)); (void)hipGetLastError();
     hipDeviceProp_t prop;
     HIPDRT_CHECK(hipGetDeviceProperties(&prop, device));
     std::string arch = prop.gcnArchName;
@@ -114,11 +115,19 @@ int hipdrt_create(int device, hipdrt_ctx** out) {
     return HIPDRT_OK;
 }
 
-int hipdrt_destroy(hipdrt_ctx* ctx) {
-    if (!ctx) return HIPDRT_OK;
+static std::mutex g_life;          // context / plan creation and destruction (any thread, e.g. a garbage collector's)
+
+static void free_ctx(hipdrt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int hipdrt_destroy(hipdrt_ctx* ctx) {
+    if (!ctx) return HIPDRT_OK;
+    std::lock_guard<std::mutex> lk(g_life);
+    if (ctx->plans > 0) { ctx->released = true; return HIPDRT_OK; }     // the last plan's destruction frees it
+    free_ctx(ctx);
     return HIPDRT_OK;
 }
 
@@ -144,7 +153,7 @@ int hipdrt_impedance_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, 
                             const double* wt_im, double* z_re, double* z_im) {
     HIPDRT_REQUIRE(ctx && wt_re && wt_im && z_re && z_im, "NULL pointer");
     HIPDRT_REQUIRE(ngrid >= 2 && ny >= 2 && ny <= 6000, "ngrid >= 2, 2 <= ny <= 6000");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dwr, dwi, dzr, dzi;
     const size_t gb = (size_t)ngrid * sizeof(double);
@@ -162,7 +171,7 @@ int hipdrt_phasor_z_matrix(hipdrt_ctx* ctx, const double* freq, int nf, const do
                            double* zm_re, double* zm_im) {
     HIPDRT_REQUIRE(ctx && freq && basis_nu && zm_re && zm_im, "NULL pointer");
     HIPDRT_REQUIRE(nf >= 1 && n_nu >= 1 && nu_epsilon > 0.0, "nf, n_nu >= 1, nu_epsilon > 0");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf df, dn, dr, di;
     TRY(upload(df, freq, (size_t)nf * sizeof(double), st));
@@ -181,7 +190,7 @@ int hipdrt_phasor_v_matrix(hipdrt_ctx* ctx, const double* times, int nt, const d
                            const double* step_times, const double* step_sizes, int nsteps, double* rm, double* layered) {
     HIPDRT_REQUIRE(ctx && times && basis_nu && step_times && step_sizes && rm, "NULL pointer");
     HIPDRT_REQUIRE(nt >= 1 && n_nu >= 1 && nsteps >= 1 && nu_epsilon > 0.0, "nt, n_nu, nsteps >= 1, nu_epsilon > 0");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dt, dn, ds, da, dr, dl;
     TRY(upload(dt, times, (size_t)nt * sizeof(double), st));
@@ -203,7 +212,7 @@ int hipdrt_chrono_var_matrix(hipdrt_ctx* ctx, const double* tt, int nt, const in
                              int uniform, double* vmm) {
     HIPDRT_REQUIRE(ctx && tt && seg && vmm, "NULL pointer");
     HIPDRT_REQUIRE(nt >= 1 && nseg >= 1, "nt >= 1, nseg >= 1");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dtt, dseg, dv;
     TRY(upload(dtt, tt, (size_t)nt * sizeof(double), st));
@@ -219,7 +228,7 @@ int hipdrt_chrono_var_matrix(hipdrt_ctx* ctx, const double* tt, int nt, const in
 int hipdrt_response_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, const double* td, double* v) {
     HIPDRT_REQUIRE(ctx && td && v, "NULL pointer");
     HIPDRT_REQUIRE(ngrid >= 2 && ny >= 2 && ny <= 6000, "ngrid >= 2, 2 <= ny <= 6000");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dtd, dv;
     const size_t gb = (size_t)ngrid * sizeof(double);
@@ -244,7 +253,7 @@ int hipdrt_response_matrix(hipdrt_ctx* ctx, const double* times, int nt, const d
     } else {
         HIPDRT_REQUIRE(ny >= 2 && ny <= 6000, "2 <= ny <= 6000");
     }
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dt, dtau, dst, dsa, lut3, da, dl;
     TRY(upload(dt, times, (size_t)nt * sizeof(double), st));
@@ -300,7 +309,7 @@ static int impedance_matrix_common(hipdrt_ctx* ctx, int B, int freq_batched, con
         HIPDRT_REQUIRE(log_wt_re && z_re && log_wt_im && z_im && ngrid >= 2 && ngrid <= 3400,
                        "interp needs lookups with 2 <= ngrid <= 3400");
     else HIPDRT_REQUIRE(ny >= 2 && ny <= 6000, "2 <= ny <= 6000");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dfreq, dtau, lut6, cr;
     TRY(upload(dfreq, freq, (size_t)(freq_batched ? B : 1) * nf * sizeof(double), st));
@@ -338,7 +347,7 @@ int hipdrt_impedance_matrix(hipdrt_ctx* ctx, int B, int freq_batched, const doub
                             double* a_im) {
     HIPDRT_REQUIRE(ctx && a_re && a_im, "NULL pointer");
     HIPDRT_REQUIRE(B >= 1 && nf >= 1 && ntau >= 1, "B, nf, ntau >= 1");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     DevBuf dre, dim;
     const size_t bytes = (size_t)B * nf * ntau * sizeof(double);
     HIPDRT_CHECK(dre.alloc(bytes)); HIPDRT_CHECK(dim.alloc(bytes));
@@ -355,7 +364,7 @@ int hipdrt_nonuniform_gaussian_filter1d(hipdrt_ctx* ctx, const double* y, int n,
                                         double* out) {
     HIPDRT_REQUIRE(ctx && y && sigma && seg && filtered && nodes && node_delta && weights && woff && radius && out, "NULL pointer");
     HIPDRT_REQUIRE(n >= 1 && nseg >= 1 && K >= 1 && nweights >= 1, "n, nseg, K, nweights >= 1");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     // sample -> segment map (or -1 for an unfiltered segment)
     std::vector<int> seg_of(n, -1);
@@ -386,7 +395,7 @@ int hipdrt_penalty_matrices(hipdrt_ctx* ctx, const double* ln_tau, int n, double
                             double* m1, double* m2) {
     HIPDRT_REQUIRE(ctx && ln_tau && m0 && m1 && m2, "NULL pointer");
     HIPDRT_REQUIRE(n >= 1, "n >= 1");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dl, d0, d1, d2;
     const size_t bytes = (size_t)n * n * sizeof(double);
@@ -405,7 +414,7 @@ int hipdrt_eis_var_matrix(hipdrt_ctx* ctx, const double* freq, int nf, double vm
                           int uniform, double* vmm) {
     HIPDRT_REQUIRE(ctx && freq && vmm, "NULL pointer");
     HIPDRT_REQUIRE(nf >= 1, "nf >= 1");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf df, dv;
     const size_t bytes = (size_t)4 * nf * nf * sizeof(double);
@@ -424,7 +433,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
                     const double* h, const hipdrt_qp_opts* opts, double* x, int* iters, double* pcost, int* status) {
     HIPDRT_REQUIRE(ctx && P && q && h && x && status, "NULL pointer");
     HIPDRT_REQUIRE(B >= 1 && n >= 1 && n <= 2048, "B >= 1, 1 <= n <= 2048");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dP, dq, dh, dL, dx, dit, dpc, dst, dstate, dPpk;
     const int ldl = (int)qp_scratch_ld(n);
@@ -470,7 +479,7 @@ int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n) {
 
 int hipdrt_qp_profile(hipdrt_ctx* ctx, unsigned long long* cycles, int n, int reset) {
     HIPDRT_REQUIRE(ctx && cycles, "NULL pointer");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     HIPDRT_CHECK(hipStreamSynchronize(ctx->stream));
     return qp_profile_read(cycles, n, reset) < 0 ? HIPDRT_E_HIP : HIPDRT_OK;
 }
@@ -479,7 +488,7 @@ int hipdrt_weighted_gram(hipdrt_ctx* ctx, int B, int m, int n, const double* A, 
                          int l2_batched, const double* l2, const double* l1, double* P, double* q) {
     HIPDRT_REQUIRE(ctx && A && w && b && P && q, "NULL pointer");
     HIPDRT_REQUIRE(B >= 1 && m >= 1 && n >= 1, "B, m, n >= 1");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     DevBuf dA, dw, db, dl2, dl1, dP, dq;
     TRY(upload(dA, A, (size_t)m * n * sizeof(double), st));
@@ -583,7 +592,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     if (mode == HIPDRT_MODE_INTERP)
         HIPDRT_REQUIRE(wt_re && wt_im && log_wt_re && log_wt_im && ngrid >= 2 && ngrid <= 3400, "interp lookups");
     HIPDRT_REQUIRE(ny >= 2 && ny <= 6000, "2 <= ny <= 6000");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     std::unique_ptr<hipdrt_plan> p(new hipdrt_plan());
     p->ctx = ctx;
@@ -642,6 +651,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     launch_make_h(st, p->h.d(), n, ns, p->opts.nonneg);
     LAUNCH_OK();
     HIPDRT_CHECK(hipStreamSynchronize(st));
+    { std::lock_guard<std::mutex> lk(g_life); ++ctx->plans; }
     *out = p.release();
     return HIPDRT_OK;
 }
@@ -659,7 +669,7 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, 
     HIPDRT_REQUIRE(d->vb_size >= 0 && d->vb_start >= 0 && d->vb_start + d->vb_size <= d->ns, "v_baseline columns");
     HIPDRT_REQUIRE(d->num_chrono >= 0 && d->num_chrono <= d->m, "num_chrono");
     HIPDRT_REQUIRE(!(opts && opts->update_scale) || d->basis_area > 0.0, "update_scale needs desc.basis_area");
-    HIPDRT_CHECK(hipSetDevice(ctx->device));
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
     std::unique_ptr<hipdrt_plan> p(new hipdrt_plan());
     p->ctx = ctx;
@@ -685,6 +695,7 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, 
     HIPDRT_CHECK(p->dop_rho.alloc((size_t)capacity * 3 * sizeof(double)));
     HIPDRT_CHECK(p->dop_xmx.alloc((size_t)capacity * 3 * sizeof(double)));
     HIPDRT_CHECK(hipStreamSynchronize(st));
+    { std::lock_guard<std::mutex> lk(g_life); ++ctx->plans; }
     *out = p.release();
     return HIPDRT_OK;
 }
@@ -694,7 +705,7 @@ int hipdrt_plan_upload_prepared(hipdrt_plan* p, int B, int rm_batched, const dou
     HIPDRT_REQUIRE(p->prepared, "not a prepared plan");
     HIPDRT_REQUIRE(B >= 1 && B <= p->capacity, "1 <= B <= capacity");
     HIPDRT_REQUIRE(rm_batched || p->desc.vz_index < 0, "a vz_offset column needs one response matrix per measurement");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const int n = p->n, m = p->m;
     const size_t nmat = rm_batched ? (size_t)B : 1;
@@ -714,7 +725,7 @@ int hipdrt_plan_upload_prepared(hipdrt_plan* p, int B, int rm_batched, const dou
 int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const double* row_factors, int batched) {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(weight_factor > 0.0, "weight_factor > 0");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     p->weight_factor = weight_factor;
     p->wrow_batched = (batched & 1) ? 1 : 0;
@@ -732,7 +743,7 @@ int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const d
 
 int hipdrt_plan_set_init_h(hipdrt_plan* p, const double* h_init) {
     HIPDRT_REQUIRE(p, "plan is NULL");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     if (!h_init) { p->h_init.release(); return HIPDRT_OK; }
     TRY(upload(p->h_init, h_init, (size_t)p->n * sizeof(double), p->ctx->stream));
     HIPDRT_CHECK(hipStreamSynchronize(p->ctx->stream));
@@ -740,7 +751,12 @@ int hipdrt_plan_set_init_h(hipdrt_plan* p, const double* h_init) {
 }
 
 int hipdrt_plan_destroy(hipdrt_plan* plan) {
-    if (plan) { (void)hipSetDevice(plan->ctx->device); delete plan; }
+    if (!plan) return HIPDRT_OK;
+    std::lock_guard<std::mutex> lk(g_life);
+    hipdrt_ctx* ctx = plan->ctx;
+    (void)hipSetDevice(ctx->device);
+    delete plan;
+    if (--ctx->plans == 0 && ctx->released) free_ctx(ctx);
     return HIPDRT_OK;
 }
 
@@ -761,7 +777,7 @@ static int copy_strided(double* out, const double* dev, int rows, int cols, int 
 
 int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long count) {
     HIPDRT_REQUIRE(p && which && out, "NULL pointer");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const std::string w = which;
     const double* src = nullptr; int rows = 0, cols = 0, ld = 0;
@@ -791,7 +807,7 @@ int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long co
 int hipdrt_plan_set_lookup(hipdrt_plan* p, const double* z_re, const double* z_im) {
     HIPDRT_REQUIRE(p && z_re && z_im, "NULL pointer");
     HIPDRT_REQUIRE(p->mode == HIPDRT_MODE_INTERP, "plan is not in interp mode");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const size_t gb = (size_t)p->ngrid * sizeof(double);
     HIPDRT_CHECK(hipMemcpyAsync(p->lut6.d() + p->ngrid, z_re, gb, hipMemcpyHostToDevice, st));
@@ -805,7 +821,7 @@ int hipdrt_plan_upload(hipdrt_plan* p, int B, const double* z_re, const double* 
     HIPDRT_REQUIRE(p && z_re && z_im, "NULL pointer");
     HIPDRT_REQUIRE(!p->prepared, "prepared plans take hipdrt_plan_upload_prepared");
     HIPDRT_REQUIRE(B >= 1 && B <= p->capacity, "1 <= B <= capacity");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const size_t bytes = (size_t)B * p->nf * sizeof(double);
     HIPDRT_CHECK(hipMemcpyAsync(p->z_re.p, z_re, bytes, hipMemcpyHostToDevice, st));
@@ -860,7 +876,7 @@ struct PhaseTimer {
 int hipdrt_plan_fit(hipdrt_plan* p) {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no spectra staged (call hipdrt_plan_upload)");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const int B = p->B, n = p->n, m = p->m;
     FitState fs = p->state();
@@ -1022,7 +1038,7 @@ int hipdrt_plan_obs_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) { 
 static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored) {
     HIPDRT_REQUIRE(p && rss && sum_log_w, "NULL pointer");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const size_t bb = (size_t)p->B * sizeof(double);
     DevBuf d1, d2;
@@ -1038,7 +1054,7 @@ static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int st
 int hipdrt_plan_set_state(hipdrt_plan* p, const double* x, const double* rho, const double* s, const double* weights) {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const size_t B = p->B, n = p->n, m = p->m;
     if (x) {
@@ -1075,7 +1091,7 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     // rejected calls must leave the finished fit as it is: every check comes before the first write
     HIPDRT_REQUIRE(!p->prepared, "warm restarts are not available on prepared plans");
     HIPDRT_REQUIRE(!p->has_weight_factors(), "warm restarts take their weight_factor argument; clear the plan's weight factors");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const int B = p->B, n = p->n, m = p->m;
     TRY(plan_hist_reserve(p, opts->max_iter));
@@ -1134,7 +1150,7 @@ int hipdrt_plan_iterate(hipdrt_plan* p, const hipdrt_iterate_state* in, int* con
     HIPDRT_REQUIRE(p->prepared, "hipdrt_plan_iterate works on prepared plans (the caller's rm, rv as iterate_qphb takes them)");
     HIPDRT_REQUIRE(p->B >= 1, "no measurements staged (call hipdrt_plan_upload_prepared)");
     HIPDRT_REQUIRE(!p->has_weight_factors(), "weight factors belong to _qphb_fit_core, not to iterate_qphb");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const int B = p->B, n = p->n, m = p->m;
     FitState fs = p->state();
@@ -1200,7 +1216,7 @@ int hipdrt_plan_download(hipdrt_plan* p, double* x, double* fit_x, double* r_inf
                          int* qp_iters_total, int* status) {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "nothing fitted");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     const int B = p->B, n = p->n, m = p->m, ns = p->ns, ntau = p->ntau;
     std::vector<double> hx((size_t)B * n), hcs(B);
     HIPDRT_CHECK(hipMemcpy(hx.data(), p->x.p, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1228,7 +1244,7 @@ int hipdrt_plan_download(hipdrt_plan* p, double* x, double* fit_x, double* r_inf
 int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
     HIPDRT_REQUIRE(p && out, "NULL pointer");
     HIPDRT_REQUIRE(b >= 0 && b < p->B, "spectrum index out of range");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const int n = p->n, m = p->m;
     GramL2 g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, p->prepared ? p->desc.dop_l2_lambda_0 : 0.0);
@@ -1248,7 +1264,7 @@ static int plan_quadratic_forms(hipdrt_plan* p, const double* basis_eval, int ne
     HIPDRT_REQUIRE(p->B > 0, "no fitted batch in the plan");
     HIPDRT_REQUIRE(neval >= 1, "neval >= 1");
     HIPDRT_REQUIRE(p->n <= 2048, "posterior variance: n <= 2048");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const int n = p->n, m = p->m, B = p->B;
     const int nex = (neval + 15) / 16, nchp = qp_nchp(n);
@@ -1318,7 +1334,7 @@ static int plan_hist_reserve(hipdrt_plan* p, int rows) {
 
 int hipdrt_plan_record_history(hipdrt_plan* p, int b) {
     HIPDRT_REQUIRE(p, "plan is NULL");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     p->hist_b = b;
     return plan_hist_reserve(p, p->opts.max_iter);
 }
@@ -1327,7 +1343,7 @@ int hipdrt_plan_get_history(hipdrt_plan* p, double* hist_x, double* hist_rho, do
                             int max_rows, int* rows) {
     HIPDRT_REQUIRE(p && rows, "NULL pointer");
     HIPDRT_REQUIRE(p->hist_b >= 0 && p->hist_cap > 0, "history recording was not enabled");
-    HIPDRT_CHECK(hipSetDevice(p->ctx->device));
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     int r = 0;
     HIPDRT_CHECK(hipMemcpy(&r, p->hist_rows.p, sizeof(int), hipMemcpyDeviceToHost));
     if (r > max_rows) r = max_rows;

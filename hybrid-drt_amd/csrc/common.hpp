@@ -66,6 +66,10 @@ struct hipdrt_ctx {
     int num_cu = 0;
     size_t hbm_bytes = 0;
     std::string arch;
+    // lifetime: plans refer to their context, and a garbage collector may release the two in either order -- a released
+    // context lives on until its last plan is destroyed
+    int plans = 0;
+    bool released = false;
 };
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ---------------------------------

@@ -53,15 +53,15 @@ def drt_siblings(drt, count):
     stream) and plan, so that their device loops run side by side; cached on `drt`."""
     import copy
     from .. import _ffi
-    sibs = getattr(drt, '_siblings', None) or [drt]
-    while len(sibs) < count:
+    clones = getattr(drt, '_sibling_clones', None) or []     # (the clones only: no reference cycle through `drt`)
+    while len(clones) < count - 1:
         c = copy.copy(drt)                     # configuration only: the arrays it refers to are read-only
         c._plan = c._plan_key = c._last_batch = None
         c._context = _ffi.Context(drt.device)
-        c._siblings = None
-        sibs.append(c)
-    drt._siblings = sibs
-    return sibs[:count]
+        c._sibling_clones = None
+        clones.append(c)
+    drt._sibling_clones = clones
+    return ([drt] + clones)[:count]
 
 
 def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid, drt_var, ignore_errors, llh_kw, fit_kw):

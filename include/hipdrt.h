@@ -40,7 +40,7 @@ typedef struct hipdrt_plan hipdrt_plan;
 
 /* ---- context -------------------------------------------------------------------------------------- */
 int hipdrt_create(int device, hipdrt_ctx** out);
-int hipdrt_destroy(hipdrt_ctx* ctx);
+int hipdrt_destroy(hipdrt_ctx* ctx);   /* with plans still alive on it the context is freed by the last hipdrt_plan_destroy */
 const char* hipdrt_last_error(void);
 /* HIP stream the ctx launches on (so callers can record events / order other work): returns hipStream_t */
 void* hipdrt_stream(hipdrt_ctx* ctx);

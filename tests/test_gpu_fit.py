@@ -220,7 +220,8 @@ def test_fit_observations_in_flight_is_the_same_fit():
     drt = DRT(tau_supergrid=supergrid)
     x1, sp1, r1 = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True)
     x3, sp3, r3 = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True, inflight=3)
-    assert len(drt._siblings) == 3 and drt._siblings[0] is drt
+    from hipdrt.mapping.drtmd import drt_siblings
+    assert len(drt._sibling_clones) == 2 and drt_siblings(drt, 3)[0] is drt
     np.testing.assert_array_equal(x1, x3)
     for k in sp1:
         np.testing.assert_array_equal(sp1[k], sp3[k])
@@ -232,9 +233,30 @@ def test_fit_observations_in_flight_is_the_same_fit():
     with pytest.raises(ValueError):
         fit_observations(drt, freq, z, tau_supergrid=supergrid, ignore_errors=False, inflight=3)
     # second call: the sibling plans are reused
-    plans = [d._plan for d in drt._siblings]
+    plans = [d._plan for d in drt_siblings(drt, 3)]
     fit_observations(drt, freq, z, tau_supergrid=supergrid, inflight=3)
-    assert [d._plan for d in drt._siblings] == plans
+    assert [d._plan for d in drt_siblings(drt, 3)] == plans
+
+
+def test_context_released_before_its_plan():
+    """A garbage collector may release a context before the plans created on it (reference cycles): the context then
+    lives on until its last plan is destroyed, the plan stays usable, and no stale HIP error is left behind for the next
+    call on this thread to trip over"""
+    from hipdrt import _ffi, synth
+    from hipdrt.models import DRT
+    freq = np.logspace(6, -1, 71)
+    z = synth.zarc2_batch(freq, 4, first_seed=700)
+    d = DRT(context=_ffi.Context(0))
+    ref = d.fit_eis_batch(freq, z)
+    d._context.close()                      # released while the plan is alive
+    d._context = None
+    again = d._plan
+    again.upload(z)
+    again.fit()                             # the plan still has its stream
+    np.testing.assert_array_equal(again.download()["x"], ref["x"])
+    again.close()                           # ... and takes the context with it
+    other = DRT().fit_eis_batch(freq, z)    # default context, same thread: must not see an error from the calls above
+    np.testing.assert_array_equal(other["x"], ref["x"])
 
 
 def test_qphb_fit_core_as_drtmd_calls_it():

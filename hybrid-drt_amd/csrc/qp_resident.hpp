@@ -197,18 +197,21 @@ struct OpsResidentT {
 #pragma unroll
         for (int c = 0; c < 16; ++c) { a[c] = D[r * DLD + c]; w[c] = (c == r) ? 1.0 : 0.0; }
         bool ok = true;
+        double myrinv = 1.0;                             // 1 / L_rr of this lane's row: its scaling is applied once, at the end
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const double piv = bcast_lane(a[c], c);
             if (!(piv > 0.0)) ok = false;
             const double rinv = rsqrt(piv);              // 1 / L_cc
             const double lrc = a[c] * rinv;              // L_rc for r >= c
-            const double lm = (r > c) ? lrc : 0.0;       // row operation  row_r -= L_rc * row_c  below the pivot only
-            const double sc = (r == c) ? rinv : 1.0;     // the pivot row itself is scaled
+            // row operation  row_r -= L_rc * (row_c / L_cc)  below the pivot only.  The pivot row is read here for the last time,
+            // so it stays unscaled in its registers (the factor 1 / L_cc goes into the multiplier) and every row is scaled by
+            // its own 1 / L_rr after the last step: one FMA per element and step instead of two multiplies and an FMA
+            const double lmr = (r > c) ? lrc * rinv : 0.0;
+            myrinv = (r == c) ? rinv : myrinv;
 #pragma unroll
             for (int j = 0; j <= c; ++j) {
-                const double wcj = bcast_lane(w[j], c) * rinv;
-                w[j] = w[j] * sc - lm * wcj;
+                w[j] -= lmr * bcast_lane(w[j], c);
                 asm volatile("" : "+v"(w[j]));           // pinned: see below
             }
             // the updates are pinned here (opaque use): left to itself the optimiser sinks them to their first use and
@@ -223,7 +226,7 @@ struct OpsResidentT {
         }
         if (lane < 16) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) sm.U[(size_t)(r0 + r) * PLD + c0 + j] = (j <= r) ? w[j] : 0.0;
+            for (int j = 0; j < 16; ++j) sm.U[(size_t)(r0 + r) * PLD + c0 + j] = (j <= r) ? w[j] * myrinv : 0.0;
         }
         __builtin_amdgcn_wave_barrier();
         return ok;

@@ -143,9 +143,10 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' lets several "
                                                     "ranks share one GPU for a functional check of the N > 1 path")
     ap.add_argument("--shard", choices=("block", "interleave", "lpt"), default="interleave", help="c4: shard scheme")
-    ap.add_argument("--inflight", type=int, default=4,
-                    help="batches kept in flight per GPU (each on its own plan + HIP stream); c3: steps are dealt "
-                         "round-robin to them; c4: every rank's share is split over them")
+    ap.add_argument("--inflight", type=lambda v: v if v == "auto" else int(v), default=None,
+                    help="batches kept in flight per GPU (each on its own plan + HIP stream); c3 (default 4): steps are dealt "
+                         "round-robin to them; c4 (default auto = mapping.auto_inflight(share)): every rank's share is split "
+                         "over them")
     ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the all-cores CPU leg (0 = all cpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix-build", action="store_true")
@@ -197,7 +198,7 @@ def main():
     if config == "c3":
         B = args.batch
         z = synth.zarc2_batch(freq, B, first_seed=rank * B)
-        nfl = max(1, min(args.inflight, max(args.steps, 1)))
+        nfl = max(1, min(4 if args.inflight in (None, "auto") else args.inflight, max(args.steps, 1)))
         chunks = [np.arange(B)] * nfl                        # every plan holds the whole batch
         job_fits = world * B
     else:
@@ -207,7 +208,9 @@ def main():
         # every rank generates its own rows only (seed = global observation index)
         z = np.concatenate([synth.zarc2_batch(freq, 1, first_seed=int(i)) for i in mine]) if len(mine) else \
             np.zeros((0, len(freq)), dtype=complex)
-        nfl = max(1, min(args.inflight, max(len(mine), 1)))
+        from hipdrt.mapping.drtmd import auto_inflight
+        nfl = auto_inflight(len(mine)) if args.inflight in (None, "auto") else args.inflight
+        nfl = max(1, min(nfl, max(len(mine), 1)))
         chunks = np.array_split(np.arange(len(mine)), nfl)
         B = len(mine)
         job_fits = total

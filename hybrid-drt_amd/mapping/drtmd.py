@@ -48,6 +48,13 @@ def shard_indices(num_obs, world_size, rank, scheme='interleave', cost=None):
 _NOT_PER_OBS = ('basis_tau', 'timings_ms', 'launches', 'obs_tau_indices', 'obs_fit_errors')
 
 
+def auto_inflight(num_obs):
+    """Batches in flight that served `num_obs` C2-size observations best on one MI355X (tools/probe_inflight.py, fits/s with
+    1 / 2 / 3 / 4 batches: 1250 obs. 1631 / 1814 / 1718 / 1473; 2500: 1792 / 1954 / 1971 / 1738; 10 000: 1994 / 2035 / 2053 /
+    1986): a batch should keep more than ~500 spectra, and more than three host threads get in each other's way."""
+    return 1 if num_obs < 512 else (2 if num_obs < 2000 else 3)
+
+
 def drt_siblings(drt, count):
     """`count` DRT objects with the configuration of `drt` (itself first), each sibling with its own hipdrt context (HIP
     stream) and plan, so that their device loops run side by side; cached on `drt`."""
@@ -121,8 +128,10 @@ def fit_observations(drt, frequencies, z_obs, tau_supergrid=None, drt_var=False,
       obs_drt_var(+_ok)      with ``drt_var=True``: diagonal of estimate_distribution_cov(tau=tau_supergrid,
                              extend_var=True) (drtmd.py:278-279).
     ``inflight`` > 1 fits the observations as that many batches side by side (sibling plans of `drt`, one host thread
-    each): same results, in the same order, at the throughput of several batches in flight."""
+    each): same results, in the same order, at the throughput of several batches in flight; 'auto' = auto_inflight(number
+    of observations).  (Afterwards `drt` itself holds the first batch only.)"""
     z_obs = np.asarray(z_obs)
+    inflight = auto_inflight(z_obs.shape[0]) if inflight == 'auto' else int(inflight)
     if inflight > 1 and z_obs.shape[0] >= 2 * inflight:
         return _fit_observations_inflight(drt, frequencies, z_obs, int(inflight), tau_supergrid, drt_var, ignore_errors,
                                           llh_kw, fit_kw)
@@ -177,7 +186,7 @@ def fit_observations_sharded(drt, frequencies, z_obs, rank=None, world=None, tau
     owned = [shard_indices(num, world, r, scheme, cost) for r in range(world)]
     mine = owned[rank]
     if len(mine):
-        if inflight > 1:
+        if inflight != 1:
             fit_kw = dict(fit_kw, inflight=inflight)
         obs_x, obs_special, res = fit(drt, frequencies, z_obs[mine], tau_supergrid=tau_supergrid, drt_var=drt_var, **fit_kw)
         cols = [obs_x, obs_special['R_inf'][:, None], obs_special['inductance'][:, None]]

@@ -86,3 +86,13 @@ def test_inflight_error_capture_and_reraising(monkeypatch):
     monkeypatch.setattr(drtmd, "drt_siblings", lambda drt, count: [fakes[0], Boom(), fakes[2]][:count])
     with pytest.raises(RuntimeError, match="device lost"):         # a worker thread's exception surfaces in the caller
         drtmd.fit_observations(fakes[0], freq, _data(12), inflight=3)
+
+
+def test_auto_inflight_rule(monkeypatch):
+    from hipdrt.mapping import drtmd
+    assert [drtmd.auto_inflight(n) for n in (1, 511, 512, 1999, 2000, 10000)] == [1, 1, 2, 2, 3, 3]
+    fakes = [_FakeDRT() for _ in range(3)]
+    monkeypatch.setattr(drtmd, "drt_siblings", lambda drt, count: fakes[:count])
+    freq = np.logspace(3, 0, 9)
+    drtmd.fit_observations(fakes[0], freq, _data(600), inflight='auto')
+    assert [len(f.calls) for f in fakes] == [1, 1, 0] and [f.calls[0][1] for f in fakes[:2]] == [300, 300]

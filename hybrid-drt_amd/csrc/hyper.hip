@@ -241,22 +241,28 @@ __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld
 }
 
 // same for a symmetric Toeplitz matrix given by its mirrored first column (LDS, c[d] valid for -(nd-1) <= d <= nd-1):
-// y[i] = sum_j c[i - j] v[j].  One row per thread: v[j] is a broadcast read, c[i - j] runs over consecutive addresses
-// across the lanes, nothing is reduced across lanes; four partial sums (j mod 4) keep the adds independent.
+// y[i] = sum_j c[i - j] v[j].  Two adjacent rows per thread: v[j] is a broadcast read, c[i - j] runs over consecutive
+// addresses across the lanes, nothing is reduced across lanes, and row i+1's operand at column j+1 is row i's at column j
+// (kept in a register) -- one LDS read per product instead of two.  Four partial sums per row (j mod 4), as before.
 __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, int nd, const double* __restrict__ v,
                                                 double* __restrict__ out) {
-    for (int i = threadIdx.x; i < nd; i += HT) {
-        const double* ci = c + i;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int p = threadIdx.x; 2 * p < nd; p += HT) {
+        const int ia = 2 * p;
+        const bool hb = ia + 1 < nd;
+        const double* ca = c + ia;                 // ca[-j] = c[ia - j]
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        double prev = hb ? ca[1] : ca[0];          // c[ib - 0]
         int j = 0;
         for (; j + 3 < nd; j += 4) {
-            s0 += ci[-j] * v[j];
-            s1 += ci[-j - 1] * v[j + 1];
-            s2 += ci[-j - 2] * v[j + 2];
-            s3 += ci[-j - 3] * v[j + 3];
+            const double c0 = ca[-j], c1 = ca[-j - 1], c2 = ca[-j - 2], c3 = ca[-j - 3];
+            const double v0 = v[j], v1 = v[j + 1], v2 = v[j + 2], v3 = v[j + 3];
+            a0 += c0 * v0; a1 += c1 * v1; a2 += c2 * v2; a3 += c3 * v3;
+            b0 += prev * v0; b1 += c0 * v1; b2 += c1 * v2; b3 += c2 * v3;
+            prev = c3;
         }
-        for (; j < nd; ++j) s0 += ci[-j] * v[j];
-        out[i] = (s0 + s1) + (s2 + s3);
+        for (; j < nd; ++j) { const double c0 = ca[-j]; a0 += c0 * v[j]; b0 += prev * v[j]; prev = c0; }
+        out[ia] = (a0 + a1) + (a2 + a3);
+        if (hb) out[ia + 1] = (b0 + b1) + (b2 + b3);
     }
 }
 
@@ -465,54 +471,92 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
             __syncthreads();
             const double* ck = ctp + k * cw + (nd - 1);      // ck[i - j]
             const double* c1 = ctp + cw + (nd - 1);
-            // one row per thread (see toeplitz_matvec): the column index is uniform across the wavefront
+            // the row sums leave out j = i: for their duration the lag-0 entries of the Toeplitz columns are zero in LDS (a
+            // product with zero adds nothing and cannot raise the maximum) instead of two selects per product
+            const double ck00 = ck[0], c100 = c1[0];
+            __syncthreads();
+            if (tid == 0) { ctp[k * cw + (nd - 1)] = 0.0; if (use_g) ctp[cw + (nd - 1)] = 0.0; }
+            __syncthreads();
+            // two adjacent rows per thread (see toeplitz_matvec): the column index is uniform across the wavefront and row
+            // i+1 reuses row i's Toeplitz operands one column later; per row the same sums in the same order as one row per
+            // thread gave
             double lmax = 0.0;
-            for (int i = tid; i < nd; i += HT) {
-                const double xi = xd[i], xr = reff * xi;      // rho_k_eff * x_i (1 under eff_hp, qphb.py:747-750)
-                const double* cki = ck + i;
-                double s0 = 0.0, s1 = 0.0;
+            for (int p = tid; 2 * p < nd; p += HT) {
+                const int ia = 2 * p, ib = ia + 1;
+                const bool hb = ib < nd;
+                const double xia = xd[ia], xra = reff * xia;                 // rho_k_eff * x_i (1 under eff_hp, qphb.py:747-750)
+                const double xib = hb ? xd[ib] : 0.0, xrb = reff * xib;
+                const double* cka = ck + ia;
                 if (use_g) {
-                    const double xhs = xh[i] / sig2;
-                    const double* c1i = c1 + i;
-                    double m0 = 0.0, m1 = 0.0;
+                    const double xhsa = xh[ia] / sig2, xhsb = hb ? xh[ib] / sig2 : 0.0;
+                    const double* c1a = c1 + ia;
+                    double sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0, ma0 = 0.0, ma1 = 0.0, mb0 = 0.0, mb1 = 0.0;
+                    double pk = hb ? cka[1] : cka[0], p1 = hb ? c1a[1] : c1a[0];
                     int j = 0;
                     for (; j + 1 < nd; j += 2) {
-                        double g0 = xr * (cki[-j] * vs[j]) + xhs * (c1i[-j] * vh[j]);
-                        double g1 = xr * (cki[-j - 1] * vs[j + 1]) + xhs * (c1i[-j - 1] * vh[j + 1]);
-                        g0 = (j == i) ? 0.0 : g0;
-                        g1 = (j + 1 == i) ? 0.0 : g1;
-                        s0 += g0; s1 += g1;
-                        m0 = fmax(m0, fabs(g0)); m1 = fmax(m1, fabs(g1));
+                        const double k0 = cka[-j], k1 = cka[-j - 1], q0 = c1a[-j], q1 = c1a[-j - 1];
+                        const double v0 = vs[j], v1 = vs[j + 1], h0 = vh[j], h1 = vh[j + 1];
+                        const double ga0 = xra * (k0 * v0) + xhsa * (q0 * h0);
+                        const double ga1 = xra * (k1 * v1) + xhsa * (q1 * h1);
+                        const double gb0 = xrb * (pk * v0) + xhsb * (p1 * h0);
+                        const double gb1 = xrb * (k0 * v1) + xhsb * (q0 * h1);
+                        pk = k1; p1 = q1;
+                        sa0 += ga0; sa1 += ga1; sb0 += gb0; sb1 += gb1;
+                        ma0 = fmax(ma0, fabs(ga0)); ma1 = fmax(ma1, fabs(ga1));
+                        mb0 = fmax(mb0, fabs(gb0)); mb1 = fmax(mb1, fabs(gb1));
                     }
-                    if (j < nd && j != i) {
-                        const double g0 = xr * (cki[-j] * vs[j]) + xhs * (c1i[-j] * vh[j]);
-                        s0 += g0; m0 = fmax(m0, fabs(g0));
+                    if (j < nd) {
+                        const double ga0 = xra * (cka[-j] * vs[j]) + xhsa * (c1a[-j] * vh[j]);
+                        const double gb0 = xrb * (pk * vs[j]) + xhsb * (p1 * vh[j]);
+                        sa0 += ga0; ma0 = fmax(ma0, fabs(ga0));
+                        sb0 += gb0; mb0 = fmax(mb0, fabs(gb0));
                     }
-                    lmax = fmax(lmax, fmax(m0, m1));
-                    bsum[i] = s0 + s1;
-                    gdia[i] = ((xr * ck[0]) * xi + ((xh[i] * c1[0]) * xh[i]) / sig2) + beta;
+                    lmax = fmax(lmax, fmax(ma0, ma1));
+                    bsum[ia] = sa0 + sa1;
+                    gdia[ia] = ((xra * ck00) * xia + ((xh[ia] * c100) * xh[ia]) / sig2) + beta;
+                    if (hb) {
+                        lmax = fmax(lmax, fmax(mb0, mb1));
+                        bsum[ib] = sb0 + sb1;
+                        gdia[ib] = ((xrb * ck00) * xib + ((xh[ib] * c100) * xh[ib]) / sig2) + beta;
+                    }
                 } else {
-                    double s2 = 0.0, s3 = 0.0, m0 = 0.0, m1 = 0.0;
+                    double sa0 = 0.0, sa1 = 0.0, sa2 = 0.0, sa3 = 0.0, sb0 = 0.0, sb1 = 0.0, sb2 = 0.0, sb3 = 0.0;
+                    double ma0 = 0.0, ma1 = 0.0, mb0 = 0.0, mb1 = 0.0;
+                    double pk = hb ? cka[1] : cka[0];
                     int j = 0;
                     for (; j + 3 < nd; j += 4) {
-                        double t0 = cki[-j] * vs[j], t1 = cki[-j - 1] * vs[j + 1];
-                        double t2 = cki[-j - 2] * vs[j + 2], t3 = cki[-j - 3] * vs[j + 3];
-                        t0 = (j == i) ? 0.0 : t0;
-                        t1 = (j + 1 == i) ? 0.0 : t1;
-                        t2 = (j + 2 == i) ? 0.0 : t2;
-                        t3 = (j + 3 == i) ? 0.0 : t3;
-                        s0 += t0; s1 += t1; s2 += t2; s3 += t3;
-                        m0 = fmax(m0, fmax(fabs(t0), fabs(t1)));
-                        m1 = fmax(m1, fmax(fabs(t2), fabs(t3)));
+                        const double k0 = cka[-j], k1 = cka[-j - 1], k2 = cka[-j - 2], k3 = cka[-j - 3];
+                        const double v0 = vs[j], v1 = vs[j + 1], v2 = vs[j + 2], v3 = vs[j + 3];
+                        const double ta0 = k0 * v0, ta1 = k1 * v1, ta2 = k2 * v2, ta3 = k3 * v3;
+                        const double tb0 = pk * v0, tb1 = k0 * v1, tb2 = k1 * v2, tb3 = k2 * v3;
+                        pk = k3;
+                        sa0 += ta0; sa1 += ta1; sa2 += ta2; sa3 += ta3;
+                        sb0 += tb0; sb1 += tb1; sb2 += tb2; sb3 += tb3;
+                        ma0 = fmax(ma0, fmax(fabs(ta0), fabs(ta1)));
+                        ma1 = fmax(ma1, fmax(fabs(ta2), fabs(ta3)));
+                        mb0 = fmax(mb0, fmax(fabs(tb0), fabs(tb1)));
+                        mb1 = fmax(mb1, fmax(fabs(tb2), fabs(tb3)));
                     }
-                    for (; j < nd; ++j)
-                        if (j != i) { const double t0 = cki[-j] * vs[j]; s0 += t0; m0 = fmax(m0, fabs(t0)); }
-                    lmax = fmax(lmax, fabs(xr) * fmax(m0, m1));
-                    bsum[i] = xr * ((s0 + s1) + (s2 + s3));
-                    gdia[i] = (xr * ck[0]) * xi + beta;
+                    for (; j < nd; ++j) {
+                        const double k0 = cka[-j];
+                        const double ta0 = k0 * vs[j], tb0 = pk * vs[j];
+                        pk = k0;
+                        sa0 += ta0; ma0 = fmax(ma0, fabs(ta0));
+                        sb0 += tb0; mb0 = fmax(mb0, fabs(tb0));
+                    }
+                    lmax = fmax(lmax, fabs(xra) * fmax(ma0, ma1));
+                    bsum[ia] = xra * ((sa0 + sa1) + (sa2 + sa3));
+                    gdia[ia] = (xra * ck00) * xia + beta;
+                    if (hb) {
+                        lmax = fmax(lmax, fabs(xrb) * fmax(mb0, mb1));
+                        bsum[ib] = xrb * ((sb0 + sb1) + (sb2 + sb3));
+                        gdia[ib] = (xrb * ck00) * xib + beta;
+                    }
                 }
             }
             gmax = hw_max(lmax);
+            __syncthreads();
+            if (tid == 0) { ctp[k * cw + (nd - 1)] = ck00; if (use_g) ctp[cw + (nd - 1)] = c100; }
         } else
         for (int i = wv; i < nd; i += HNW) {
             const double* row = Mk + (size_t)i * st.ldm;

@@ -391,14 +391,18 @@ struct OpsResidentT {
                             f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
                             f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
                         };
+                        // (R3 pure padding -- the last block of a matrix whose size is 1..16 past a multiple of 32, e.g. n = 514:
+                        // four of the seven tiles are not needed, and in that block column this wavefront is the critical path)
 #define HIPDRT_STEP7(B0, B1, A2, A3)                                                                    \
                         p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);               \
                         p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);               \
-                        p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);               \
-                        p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);               \
                         e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);               \
-                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);               \
-                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);
+                        if (v3) {                                                                       \
+                            p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);           \
+                            p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);           \
+                            e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);           \
+                            e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);           \
+                        }
                         auto multf = [&](const Frag& f_) {
                             HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
                             HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)

@@ -333,7 +333,7 @@ struct OpsResidentT {
                 PROF(15);
                 if (lane == 0) sm.flag[0] = ok ? 0 : 1;
                 __syncthreads();                                    // (A) W1, L21, W2 published
-                PROF(1);
+                PROF2(1, 16 + (jb < 31 ? jb : 31));                 // (slots 16..: the wait at (A) by block column)
                 if (sm.flag[0]) return false;
                 // lower-left block of the inverse for the solves: W21 = -W2 (L21 W1)
                 v4d y = (v4d){0, 0, 0, 0};

@@ -36,6 +36,9 @@ if prof[10]:
     tot = prof[10]
     print("in-kernel ticks of WG0:", {n: prof[i] for i, n in enumerate(names)}, "factorizations:", prof[11])
     print("diagonal chain: cholinv1", prof[12], "l21+d2", prof[14], "cholinv2", prof[15]); print("shares:", {n: round(prof[i] / tot, 3) for i, n in enumerate(names)})
+if prof[10] and not any(prof[44:48]) and any(prof[16:48]):
+    nf = max(prof[11], 1)
+    print("wavefront 0's wait at barrier (A) by block column, ticks per factorisation:", [int(v / nf) for v in prof[16:48] if v])
 if prof[10] and prof[13]:
     print("shader clock while WG0 ran: %.2f GHz (s_memtime ticks / 100 MHz s_memrealtime ticks)" % (prof[10] / prof[13] * 0.1))
 if prof[10] and any(prof[16:44]):

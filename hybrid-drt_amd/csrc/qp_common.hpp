@@ -104,6 +104,15 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// A value that is the same in every lane (the result of a block reduction) moved to scalar registers: the IPM's scalars
+// (gap, mu, sigma, step, costs, norms) live across the factorisation and the solves, where vector registers are scarce
+__device__ __forceinline__ double uni(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+
 // wavefront sum / max, every lane gets the result: DPP quad permutes and row rotations inside the 16-lane rows,
 // v_readlane across the four rows (no LDS crossbar)
 __device__ __forceinline__ double wsum(double v) {
@@ -228,8 +237,8 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
     FOR_E if (VALID) { nq[0] += qv[i] * qv[i]; nq[1] += hv[i] * hv[i]; }
     red.sum(nq);
-    const double resx0 = fmax(1.0, sqrt(nq[0]));
-    const double resz0 = fmax(1.0, sqrt(nq[1]));
+    const double resx0 = uni(fmax(1.0, sqrt(nq[0])));
+    const double resz0 = uni(fmax(1.0, sqrt(nq[1])));
 
     PROF_DECL
 #ifdef HIPDRT_QP_PROFILE
@@ -282,7 +291,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             red.sum(zr);
             const double f0 = 0.5 * (t4[0] + t4[1]);
             const double resx = sqrt(t4[2]), resz = sqrt(t4[3]);
-            pcost = f0;
+            pcost = uni(f0);
             const double dcost = f0 + zr[0] - gap;
             bool has_rel = false;
             double relgap = 0.0;
@@ -299,7 +308,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             }
         }
         // ---- factor S = P + diag(di^2)  (di = 1 at the start point) --------------------------------------
-        const double mu = gap / (double)n;
+        const double mu = uni(gap / (double)n);
         double sigma = 0.0, step = 1.0;
         const int nsolve = start ? 1 : 2;
         // right-hand side of KKT solve pc (sigma = 0 for the predictor, so its rhs is known before the factorisation)
@@ -364,7 +373,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
                     FOR_E if (VALID) mm[0] = fmax(mm[0], fabs(x[i]));
                     red.max(mm);
-                    drift = mm[0];
+                    drift = uni(mm[0]);
                 }
                 const double nrms = sqrt(st[0]), nrmz = sqrt(st[1]);
                 if (mx[0] >= -1e-8 * fmax(nrms, 1.0)) {
@@ -379,7 +388,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
 #pragma unroll
                 FOR_E if (VALID) gp[0] += s[i] * z[i];
                 red.sum(gp);
-                gap = gp[0];
+                gap = uni(gp[0]);
             } else {
                 double dd[1] = {0.0}, mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
@@ -404,11 +413,11 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 red.max(mx);
                 const double t = fmax(0.0, fmax(mx[0], mx[1]));
                 if (t == 0.0) step = 1.0;
-                else if (pc == 0) step = fmin(1.0, 1.0 / t);
-                else step = fmin(1.0, 0.99 / t);
+                else if (pc == 0) step = uni(fmin(1.0, 1.0 / t));
+                else step = uni(fmin(1.0, 0.99 / t));
                 if (pc == 0) {
                     const double sg = fmin(1.0, fmax(0.0, 1.0 - step + dd[0] / gap * (step * step)));
-                    sigma = sg * sg * sg;
+                    sigma = uni(sg * sg * sg);
                 }
             }
         }
@@ -444,11 +453,11 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             }
         }
         red.sum(g2);
-        gap = g2[0];
+        gap = uni(g2[0]);
         if (kRecurPx) {
             red.max(mm);
-            drift += mm[0];
-            if (drift > kDriftTol * mm[1]) { refresh = true; drift = mm[1]; }
+            drift = uni(drift + mm[0]);
+            if (drift > kDriftTol * mm[1]) { refresh = true; drift = uni(mm[1]); }
         }
         ++iters;
     }

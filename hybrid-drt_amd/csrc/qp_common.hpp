@@ -75,14 +75,28 @@ __device__ __forceinline__ double dpp_mov_d(double v) {     // quad_perm 0x00-0x
 }
 // Column sums of a tile held as lane = 4*row + l4 with four values per lane (columns l4, l4+4, l4+8, l4+12):
 // the sum over the 16 rows of value v ends up in the lanes of 16-lane row v (lane>>4 == v).  Rows 4-apart are
-// combined with DPP row rotations, the four 16-lane rows with a halving exchange (3 cross-lane moves, not 16).
+// combined with DPP row rotations, the four 16-lane rows with a halving exchange (3 swaps, not 16 moves).
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper 32-lane (odd 16-lane) rows of the first operand with
+// the lower (even) rows of the second: (a', b') = swap(a, b), and a' + b' is at once "lower lanes: a summed over both halves,
+// upper lanes: b summed over both halves" -- the halving exchange of a cross-lane reduction in two VALU instructions per
+// double, no select and no LDS crossbar (ds_bpermute) round trip.  Same operands per addition as the shuffle form had.
+__device__ __forceinline__ double swap_add32(double a, double b) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+
 __device__ __forceinline__ double colsum4(double s0, double s1, double s2, double s3, int lane) {
     s0 += dpp_mov_d<0x128>(s0); s1 += dpp_mov_d<0x128>(s1); s2 += dpp_mov_d<0x128>(s2); s3 += dpp_mov_d<0x128>(s3);
     s0 += dpp_mov_d<0x124>(s0); s1 += dpp_mov_d<0x124>(s1); s2 += dpp_mov_d<0x124>(s2); s3 += dpp_mov_d<0x124>(s3);
-    const bool hi5 = (lane & 32) != 0, hi4 = (lane & 16) != 0;
-    const double k0 = (hi5 ? s2 : s0) + __shfl_xor(hi5 ? s0 : s2, 32, 64);
-    const double k1 = (hi5 ? s3 : s1) + __shfl_xor(hi5 ? s1 : s3, 32, 64);
-    return (hi4 ? k1 : k0) + __shfl_xor(hi4 ? k0 : k1, 16, 64);
+    const double k0 = swap_add32(s0, s2);        // lanes 0-31: value 0 over both halves, lanes 32-63: value 2
+    const double k1 = swap_add32(s1, s3);
+    return swap_add16(k0, k1);                   // 16-lane row v holds the sum of value v
 }
 
 // sum over the 4 lanes of a quad (lane ^ 1, lane ^ 2) with DPP quad permutes: VALU speed, no LDS crossbar

@@ -263,8 +263,8 @@ struct OpsResidentT {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
             p_ += x1[rg] * sm.vec[j0 + kq + 4 * rg] + x2[rg] * sm.vec[j0 + 16 + kq + 4 * rg];
-        p_ += __shfl_xor(p_, 16, 64);
-        p_ += __shfl_xor(p_, 32, 64);
+        p_ = swap_add16(p_, p_);                 // p + its neighbour 16 lanes away, in every lane
+        p_ = swap_add32(p_, p_);
         if (kq == 0) sm.vec[T * 16 + li] -= p_;
     }
 

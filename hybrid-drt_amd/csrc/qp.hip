@@ -13,23 +13,13 @@
 
 #include "qp_common.hpp"
 #include "qp_resident.hpp"
-#include "qp_super.hpp"
 
 namespace hipdrt {
 
 size_t qp_scratch_ld(int n) { return (size_t)round_up(n, 16); }
 
-// doubles of factor scratch per problem: the tile-packed factor (the wider super-column layout up to n = 528), beyond
-// n = 528 followed by the inverse diagonal blocks
-size_t qp_scratch_doubles(int n) {
-    if (n <= RNP_MAX) {
-        size_t r = resident_l_doubles(n);
-        const size_t s_ = super_l_doubles(n), g_ = resident_gu_doubles(n);
-        if (s_ > r) r = s_;
-        return g_ > r ? g_ : r;           // (the U-outside form is also used for small n by the two-per-CU experiment)
-    }
-    return resident_gu_doubles(n);
-}
+// doubles of factor scratch per problem: the tile-packed factor, beyond n = 528 followed by the inverse diagonal blocks
+size_t qp_scratch_doubles(int n) { return n <= RNP_MAX ? resident_l_doubles(n) : resident_gu_doubles(n); }
 
 int qp_profile_read(unsigned long long* out, int n, int reset) {
 #ifdef HIPDRT_QP_PROFILE
@@ -70,31 +60,10 @@ void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active
     hipLaunchKernelGGL(lpt_order_kernel, dim3(blocks), dim3(256), (size_t)B * sizeof(int), st, B, iters, active, order);
 }
 
-// which kernel serves n <= 528: the 32-column one (default) or the experimental 64-wide super-column kernel
-// (HIPDRT_QP_KERNEL=super; parity-green but slower so far: its diagonal-block chain is the critical path)
-static bool use_super() {
-    static const bool v = [] { const char* e = getenv("HIPDRT_QP_KERNEL"); return e && std::string(e) == "super"; }();
-    return v;
-}
-
-static int launch_qp_super(hipStream_t st, const QpArgs& a) {
-    const int NP64 = round_up(a.n, 64);
-    if (!a.Ppk) { set_error("qp super: packed copy of P missing"); return HIPDRT_E_INVALID; }
-    const size_t lds = super_lds_bytes(a.n);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_super),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(qp super): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
-    hipLaunchKernelGGL(qp_kernel_super, dim3(a.B), dim3(ST), lds, st, a, NP64);
-    e = hipGetLastError();
-    if (e != hipSuccess) { set_error(std::string("qp launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
-    return HIPDRT_OK;
-}
-
 static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
     const int NP = round_up(a.n, 32);
     if (!a.Ppk) { set_error("qp resident: packed copy of P missing"); return HIPDRT_E_INVALID; }
-    static const bool force_gu = getenv("HIPDRT_QP_GU") != nullptr;      // experiments: the U-outside form for small n too
-    const bool gu = a.n > RNP_MAX || force_gu;          // inverse diagonal blocks in global memory: any n <= 2048
+    const bool gu = a.n > RNP_MAX;                      // inverse diagonal blocks in global memory: any n <= 2048
     const size_t lds = gu ? resident_gu_lds_bytes() : resident_lds_bytes(NP);
     const void* fn = gu ? reinterpret_cast<const void*>(qp_kernel_resident<true>) : reinterpret_cast<const void*>(qp_kernel_resident<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -123,19 +92,6 @@ int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long p
         if (e != hipSuccess) { set_error(std::string("cov launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
         return HIPDRT_OK;
     }
-    if (use_super()) {
-        const size_t lds = super_lds_bytes(n);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_kernel_super),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(cov): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
-        CovArgs a;
-        a.B = B; a.n = n; a.Ppk = Ppk; a.ppk_stride = ppk_stride; a.nchp = qp_nchp(n); a.Bex = Bex; a.nex = nex;
-        a.L = L; a.l_stride = l_stride; a.out = out; a.out_stride = out_stride; a.status = status;
-        hipLaunchKernelGGL(cov_kernel_super, dim3(B), dim3(ST), lds, st, a, round_up(n, 64));
-        e = hipGetLastError();
-        if (e != hipSuccess) { set_error(std::string("cov launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
-        return HIPDRT_OK;
-    }
     const int NP = round_up(n, 32);
     const size_t lds = resident_lds_bytes(NP);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_kernel_resident<false>),
@@ -152,7 +108,7 @@ int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long p
 
 // doubles of factor scratch per spectrum for the posterior-variance kernel: (nch + nex) x nch tiles
 size_t dist_var_scratch_doubles(int n, int nex) {
-    const size_t nch = (size_t)round_up(n, 64) / 16;      // the super-column layout (the wider of the two)
+    const size_t nch = (size_t)round_up(n, 32) / 16;
     return (nch + (size_t)nex) * nch * TSZ + (n > RNP_MAX ? (size_t)round_up(n, 32) * PLD : 0);   // + U when it lives outside LDS
 }
 
@@ -173,7 +129,7 @@ int qp_occupancy(int threads, int n) {
 
 int launch_qp(hipStream_t st, const QpArgs& a) {
     if (a.n > 2048) { set_error("qp: n > 2048 not supported"); return HIPDRT_E_INVALID; }
-    return (a.n <= RNP_MAX && use_super()) ? launch_qp_super(st, a) : launch_qp_resident(st, a);
+    return launch_qp_resident(st, a);
 }
 
 }  // namespace hipdrt

@@ -18,7 +18,7 @@ __device__ unsigned long long g_qp_prof[QP_PROF_SLOTS];
 // the same interval into two slots (a total and a per-block-column breakdown)
 #define PROF2(slot, slot2) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
     atomicAdd(&g_qp_prof[slot], _n - _pt); atomicAdd(&g_qp_prof[slot2], _n - _pt); _pt = _n; } else { _pt = 0; } } while (0)
-// the same for lane 0 of any wavefront of workgroup 0 (role timelines of the super-column kernel, slots 16..)
+// the same for lane 0 of any wavefront of workgroup 0 (per-wavefront role timelines, slots 16..)
 #define PROFW(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
     atomicAdd(&g_qp_prof[slot], _n - _pt); _pt = _n; } else { _pt = 0; } } while (0)
 #else

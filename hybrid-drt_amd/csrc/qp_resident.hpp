@@ -49,6 +49,9 @@ static constexpr int RNW = RT / 64;      // 8 wavefronts
 #ifndef HIPDRT_QP_MINWAVES
 #define HIPDRT_QP_MINWAVES 2
 #endif
+#ifndef HIPDRT_QP_PREFETCH
+#define HIPDRT_QP_PREFETCH 1     // source tiles of block column jb + 1 requested before barrier (B) of column jb
+#endif
 static constexpr int RMAXT = HIPDRT_QP_RMAXT;   // tile rows per wavefront and pass
 static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
@@ -232,18 +235,25 @@ struct OpsResidentT {
         return ok;
     }
 
-    // accumulator image of -(S tile (T, Cc))': lane (li, kq) register rg <-> row li, column kq + 4 rg
-    __device__ __forceinline__ v4d init_tile(int T, int Cc, int ntr, int fo, int li, int kq) const {
-        v4d a_ = (v4d){0, 0, 0, 0};
+    // accumulator image of -(S tile (T, Cc))': lane (li, kq) register rg <-> row li, column kq + 4 rg.  In two steps so that
+    // the loads can be issued a block column ahead (factor(): the source tiles of column jb + 1 are requested before barrier
+    // (B) of column jb and travel while the stores drain): tile_src() = the two 16-byte halves as they lie in memory,
+    // tile_image() = negation + diagonal shift.
+    struct TileSrc { double2 d0, d1; };
+    __device__ __forceinline__ TileSrc tile_src(int T, int Cc, int ntr, int fo) const {
+        TileSrc r_;
+        r_.d0 = make_double2(0.0, 0.0); r_.d1 = r_.d0;
         if (T >= nch) {
             const double2* tile = reinterpret_cast<const double2*>(Bex + ((size_t)(T - nch) * nchp + Cc) * 256);
-            const double2 d0 = tile[fo], d1 = tile[64 + fo];
-            a_ = (v4d){-d0.x, -d0.y, -d1.x, -d1.y};
+            r_.d0 = tile[fo]; r_.d1 = tile[64 + fo];
         } else if (T < ntr) {
             const double2* tile = reinterpret_cast<const double2*>(Ppk + ((size_t)T * nchp + Cc) * 256);
-            const double2 d0 = tile[fo], d1 = tile[64 + fo];
-            a_ = (v4d){-d0.x, -d0.y, -d1.x, -d1.y};
+            r_.d0 = tile[fo]; r_.d1 = tile[64 + fo];
         }
+        return r_;
+    }
+    __device__ __forceinline__ v4d tile_image(const TileSrc& r_, int T, int Cc, int li, int kq) const {
+        v4d a_ = (v4d){-r_.d0.x, -r_.d0.y, -r_.d1.x, -r_.d1.y};
         if (T == Cc) {
             // diagonal shift; identity beyond n
             const int row = T * 16 + li;
@@ -253,6 +263,9 @@ struct OpsResidentT {
                 if (kq + 4 * rg == li) a_[rg] -= dg;
         }
         return a_;
+    }
+    __device__ __forceinline__ v4d init_tile(int T, int Cc, int ntr, int fo, int li, int kq) const {
+        return tile_image(tile_src(T, Cc, ntr, fo), T, Cc, li, kq);
     }
 
     // -----------------------------------------------------------------------------------------------------
@@ -281,164 +294,428 @@ struct OpsResidentT {
     }
 
     // operand fragments of a tile held in its register image (rg <-> column kq + 4 rg): k-half h = (x[2h], x[2h+1])
+    //
+    // One loop over the block columns PER ROLE (the barrier sequences of the three loops match: (A), (A2) when the forward
+    // substitution is fused, (B)): state carried from one block column to the next -- the source tiles requested a column
+    // ahead -- is then live in its own role's loop only and costs the other roles no registers.
     __device__ __forceinline__ bool factor() {
         const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int li = lane & 15, kq = lane >> 4;
-        const int fo = li * 4 + kq;              // this lane's double2 inside a 1 KB half tile
-        const int nblk = (n + NB - 1) / NB;
         const int ntr = (n + 15) >> 4;           // tile rows that hold valid rows
-        double* U = sm.U;
-        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);        // register images of -D21', -D22' of the next block
-        v4d* const img22 = img21 + 64;
-        // Roles.  Wavefront 0: factor + invert the diagonal block (no global traffic at all).  Wavefront 1: the two tile
-        // rows of the NEXT diagonal block -- their panel tiles in this block column plus, one column ahead, the rank-k
-        // update of the next diagonal block, which it hands to wavefront 0 through LDS.  Wavefronts 2..7: all rows below.
-        // So the sequential diagonal work of column j+1 overlaps everybody else's rank-k update of column j+1.
         if (wv == 1) {
             // prologue: diagonal block of column 0 straight from P
+            const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+            v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
             const v4d d11 = init_tile(0, 0, ntr, fo, li, kq);
             const v4d d21 = init_tile(1, 0, ntr, fo, li, kq);
             const v4d d22 = init_tile(1, 1, ntr, fo, li, kq);
             stage_dsc(d11);
             img21[lane] = d21;
-            img22[lane] = d22;
+            img21[64 + lane] = d22;
         }
         __syncthreads();
+        if (wv == 0) return factor_chain();
+        if (wv == 1) return factor_lookahead();
+        return factor_rows(wv);
+    }
+
+    // ======== wavefront 0: factor + invert the diagonal blocks (no global traffic at all) ============================
+    __device__ __forceinline__ bool factor_chain() {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int nblk = (n + NB - 1) / NB;
+        double* U = sm.U;
+        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);        // register images of -D21', -D22' of the next block
+        v4d* const img22 = img21 + 64;
+        for (int jb = 0; jb < nblk; ++jb) {
+            const int j0 = jb * NB;
+            PROF_DECL
+            bool ok = cholinv16_dsc(j0, 0);
+            PROF(12);
+            // L21' = W1 * C21'  (image = -C21', operand -W1)
+            const v4d d21 = img21[lane];
+            v4d d22 = img22[lane];
+            v4d x21 = (v4d){0, 0, 0, 0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                x21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + li) * PLD + 4 * s_ + kq], d21[s_], x21, 0, 0, 0);
+            // lane (li, kq) holds L21[li][kq + 4 rg]
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) sm.t21[li * DLD + kq + 4 * rg] = x21[rg];
+            __builtin_amdgcn_wave_barrier();
+            // -D2' += L21 * L21'
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq], x21[s_], d22, 0, 0, 0);
+            PROF(14);
+            ok = cholinv16(d22, j0 + 16, 16) && ok;
+            PROF(15);
+            if (lane == 0) sm.flag[0] = ok ? 0 : 1;
+            __syncthreads();                                    // (A) W1, L21, W2 published
+            PROF2(1, 16 + (jb < 31 ? jb : 31));                 // (slots 16..: the wait at (A) by block column)
+            if (sm.flag[0]) return false;
+            // lower-left block of the inverse for the solves: W21 = -W2 (L21 W1)
+            v4d y = (v4d){0, 0, 0, 0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                y = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq],
+                                                         U[(size_t)(j0 + 4 * s_ + kq) * PLD + li], y, 0, 0, 0);
+            v4d w21 = (v4d){0, 0, 0, 0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq], y[s_], w21, 0, 0, 0);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
+            if (fwd) {
+                // fused forward substitution: y_j = M_j b_j (b_j has received every earlier column's update)
+                __builtin_amdgcn_wave_barrier();
+                const int r = lane & 31;
+                const double* Mr = U + (size_t)(j0 + r) * PLD;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; c += 4) {
+                    s0 += Mr[c] * sm.vec[j0 + c];
+                    s1 += Mr[c + 1] * sm.vec[j0 + c + 1];
+                    s2 += Mr[c + 2] * sm.vec[j0 + c + 2];
+                    s3 += Mr[c + 3] * sm.vec[j0 + c + 3];
+                }
+                const double yv = (s0 + s1) + (s2 + s3);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < NB) sm.vec[j0 + lane] = yv;
+                lds_barrier();                                  // (A2) y_j published
+            }
+            PROF(3);
+            __syncthreads();                                    // (B) block column visible to everyone
+            PROF(4);
+        }
+        return true;
+    }
+
+    // ======== wavefront 1: the two tile rows R2 = tb+2, R3 = tb+3 of the NEXT diagonal block ==========================
+    // their panel tiles in this block column plus, one column ahead, the rank-k update of the next diagonal block, which it
+    // hands to wavefront 0 through LDS: the sequential diagonal work of column j+1 overlaps everybody else's rank-k update
+    // of column j+1.
+    __device__ __forceinline__ bool factor_lookahead() {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;              // this lane's double2 inside a 1 KB half tile
+        const int nblk = (n + NB - 1) / NB;
+        const int ntr = (n + 15) >> 4;
+        double* U = sm.U;
+        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
+        v4d* const img22 = img21 + 64;
+        // source tiles of the NEXT block column, requested before barrier (B) (tile_src): (R2|R3, tb|tb+1), (R2,R2), (R3,R2), (R3,R3)
+        TileSrc pre[7];
+        bool have_pre = false;
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
             const int tb = j0 >> 4;                 // first tile-row of the block
             const int nc = 2 * jb;                  // finished 16-column chunks
-            PROF_DECL
-            if (wv == 0) {
-                // ======== wavefront 0: the diagonal block =====================================================
-                bool ok = cholinv16_dsc(j0, 0);
-                PROF(12);
-                // L21' = W1 * C21'  (image = -C21', operand -W1)
-                const v4d d21 = img21[lane];
-                v4d d22 = img22[lane];
-                v4d x21 = (v4d){0, 0, 0, 0};
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_)
-                    x21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + li) * PLD + 4 * s_ + kq], d21[s_], x21, 0, 0, 0);
-                // lane (li, kq) holds L21[li][kq + 4 rg]
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) sm.t21[li * DLD + kq + 4 * rg] = x21[rg];
-                __builtin_amdgcn_wave_barrier();
-                // -D2' += L21 * L21'
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_)
-                    d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq], x21[s_], d22, 0, 0, 0);
-                PROF(14);
-                ok = cholinv16(d22, j0 + 16, 16) && ok;
-                PROF(15);
-                if (lane == 0) sm.flag[0] = ok ? 0 : 1;
-                __syncthreads();                                    // (A) W1, L21, W2 published
-                PROF2(1, 16 + (jb < 31 ? jb : 31));                 // (slots 16..: the wait at (A) by block column)
-                if (sm.flag[0]) return false;
-                // lower-left block of the inverse for the solves: W21 = -W2 (L21 W1)
-                v4d y = (v4d){0, 0, 0, 0};
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_)
-                    y = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq],
-                                                             U[(size_t)(j0 + 4 * s_ + kq) * PLD + li], y, 0, 0, 0);
-                v4d w21 = (v4d){0, 0, 0, 0};
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_)
-                    w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq], y[s_], w21, 0, 0, 0);
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
-                if (fwd) {
-                    // fused forward substitution: y_j = M_j b_j (b_j has received every earlier column's update)
-                    __builtin_amdgcn_wave_barrier();
-                    const int r = lane & 31;
-                    const double* Mr = U + (size_t)(j0 + r) * PLD;
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NB; c += 4) {
-                        s0 += Mr[c] * sm.vec[j0 + c];
-                        s1 += Mr[c + 1] * sm.vec[j0 + c + 1];
-                        s2 += Mr[c + 2] * sm.vec[j0 + c + 2];
-                        s3 += Mr[c + 3] * sm.vec[j0 + c + 3];
-                    }
-                    const double y = (s0 + s1) + (s2 + s3);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < NB) sm.vec[j0 + lane] = y;
-                    lds_barrier();                                  // (A2) y_j published
-                }
-                PROF(3);
-            } else if (wv == 1) {
-                // ======== wavefront 1: the tile rows R2 = tb+2, R3 = tb+3 of the next diagonal block ============
-                const int R2 = tb + 2, R3 = tb + 3;
-                const bool v2 = R2 < ntr, v3 = R3 < ntr;
-                v4d p20, p21, p30, p31, e11, e21, e22;   // panel tiles (R2|R3, 2jb|2jb+1) and the next diagonal block
-                if (v2) {
+            const int R2 = tb + 2, R3 = tb + 3;
+            const bool v2 = R2 < ntr, v3 = R3 < ntr;
+            v4d p20, p21, p30, p31, e11, e21, e22;   // panel tiles (R2|R3, 2jb|2jb+1) and the next diagonal block
+            if (v2) {
+                if (have_pre) {
+                    p20 = tile_image(pre[0], R2, tb, li, kq);      p21 = tile_image(pre[1], R2, tb + 1, li, kq);
+                    p30 = tile_image(pre[2], R3, tb, li, kq);      p31 = tile_image(pre[3], R3, tb + 1, li, kq);
+                    e11 = tile_image(pre[4], R2, R2, li, kq);      e21 = tile_image(pre[5], R3, R2, li, kq);
+                    e22 = tile_image(pre[6], R3, R3, li, kq);
+                } else {
                     p20 = init_tile(R2, tb, ntr, fo, li, kq);      p21 = init_tile(R2, tb + 1, ntr, fo, li, kq);
                     p30 = init_tile(R3, tb, ntr, fo, li, kq);      p31 = init_tile(R3, tb + 1, ntr, fo, li, kq);
                     e11 = init_tile(R2, R2, ntr, fo, li, kq);      e21 = init_tile(R3, R2, ntr, fo, li, kq);
                     e22 = init_tile(R3, R3, ntr, fo, li, kq);
-                    if (jb > 0) {
-                        // hand-pipelined operand ring (qp_common.hpp: gload16 / vm_wait): half-chunks of 8 columns, the
-                        // four operand tiles requested three half-chunks ahead (4 loads per step -> vmcnt(12))
-                        const char* q0 = uniform_ptr(tile2(tb, 0));
-                        const char* q1 = uniform_ptr(tile2(tb + 1, 0));
-                        const char* q2 = uniform_ptr(tile2(R2, 0));
-                        const char* q3 = uniform_ptr(tile2(v3 ? R3 : R2, 0));
-                        const unsigned voff = (unsigned)fo * 16u;
-                        struct Frag { v2d b0, b1, a2, a3; };
-                        const int nk2 = 2 * nc, klast = nk2 - 1;
-                        auto loadf = [&](Frag& f_, int k2) {
-                            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-                            f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
-                            f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
-                        };
-                        // (R3 pure padding -- the last block of a matrix whose size is 1..16 past a multiple of 32, e.g. n = 514:
-                        // four of the seven tiles are not needed, and in that block column this wavefront is the critical path)
+                }
+                if (jb > 0) {
+                    // hand-pipelined operand ring (qp_common.hpp: gload16 / vm_wait): half-chunks of 8 columns, the
+                    // four operand tiles requested three half-chunks ahead (4 loads per step -> vmcnt(12))
+                    const char* q0 = uniform_ptr(tile2(tb, 0));
+                    const char* q1 = uniform_ptr(tile2(tb + 1, 0));
+                    const char* q2 = uniform_ptr(tile2(R2, 0));
+                    const char* q3 = uniform_ptr(tile2(v3 ? R3 : R2, 0));
+                    const unsigned voff = (unsigned)fo * 16u;
+                    struct Frag { v2d b0, b1, a2, a3; };
+                    const int nk2 = 2 * nc, klast = nk2 - 1;
+                    auto loadf = [&](Frag& f_, int k2) {
+                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+                        f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
+                        f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
+                    };
+                    // (R3 pure padding -- the last block of a matrix whose size is 1..16 past a multiple of 32, e.g. n = 514:
+                    // four of the seven tiles are not needed, and in that block column this wavefront is the critical path)
 #define HIPDRT_STEP7(B0, B1, A2, A3)                                                                    \
-                        p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);               \
-                        p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);               \
-                        e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);               \
-                        if (v3) {                                                                       \
-                            p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);           \
-                            p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);           \
-                            e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);           \
-                            e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);           \
-                        }
-                        auto multf = [&](const Frag& f_) {
-                            HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
-                            HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
-                            __builtin_amdgcn_sched_barrier(0);
-                        };
-#undef HIPDRT_STEP7
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+                    p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);               \
+                    p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);               \
+                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);               \
+                    if (v3) {                                                                       \
+                        p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);           \
+                        p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);           \
+                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);           \
+                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);           \
+                    }
+                    auto multf = [&](const Frag& f_) {
+                        HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
+                        HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
                         __builtin_amdgcn_sched_barrier(0);
+                    };
+#undef HIPDRT_STEP7
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+                    __builtin_amdgcn_sched_barrier(0);
 #if HIPDRT_QP_LADEPTH == 2
-                        Frag f0, f1;                                     // (two-per-CU experiment: half the registers)
-                        loadf(f0, 0);
-                        for (int k2 = 0; k2 < nk2; k2 += 2) {
-                            loadf(f1, k2 + 1); vm_wait<4>(); multf(f0);
-                            loadf(f0, k2 + 2); vm_wait<4>(); multf(f1);
-                        }
+                    Frag f0, f1;                                     // (two-per-CU experiment: half the registers)
+                    loadf(f0, 0);
+                    for (int k2 = 0; k2 < nk2; k2 += 2) {
+                        loadf(f1, k2 + 1); vm_wait<4>(); multf(f0);
+                        loadf(f0, k2 + 2); vm_wait<4>(); multf(f1);
+                    }
 #else
-                        Frag f0, f1, f2, f3;
-                        loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
-                        for (int k2 = 0; k2 < nk2; k2 += 4) {           // nk2 = 4 jb: a multiple of 4
-                            loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
-                            loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
-                            loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
-                            loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
-                        }
+                    Frag f0, f1, f2, f3;
+                    loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
+                    for (int k2 = 0; k2 < nk2; k2 += 4) {           // nk2 = 4 jb: a multiple of 4
+                        loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
+                        loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
+                        loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
+                        loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
+                    }
 #endif
-                        vm_wait<0>();
-                        if (!v3) {
-                            // R3 is pure padding (its operand was a stand-in): no panel tiles, identity diagonal
-                            p30 = (v4d){0, 0, 0, 0}; p31 = (v4d){0, 0, 0, 0}; e21 = (v4d){0, 0, 0, 0};
-                            e22 = init_tile(R3, R3, ntr, fo, li, kq);
-                        }
+                    vm_wait<0>();
+                    if (!v3) {
+                        // R3 is pure padding (its operand was a stand-in): no panel tiles, identity diagonal
+                        p30 = (v4d){0, 0, 0, 0}; p31 = (v4d){0, 0, 0, 0}; e21 = (v4d){0, 0, 0, 0};
+                        e22 = init_tile(R3, R3, ntr, fo, li, kq);
                     }
                 }
-                __syncthreads();                                    // (A)
-                if (sm.flag[0]) return false;
-                if (v2) {
+            }
+            __syncthreads();                                    // (A)
+            if (sm.flag[0]) return false;
+            have_pre = false;
+            if (v2) {
+                double wn1[4], l21[4], wn2[4];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    wn1[s_] = -U[(size_t)(j0 + li) * PLD + 4 * s_ + kq];
+                    l21[s_] = sm.t21[li * DLD + 4 * s_ + kq];
+                    wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
+                }
+                v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    x20 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p20[s_], x20, 0, 0, 0);
+                    x30 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p30[s_], x30, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x20[s_], p21, 0, 0, 0);
+                    p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x30[s_], p31, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    x21_ = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p21[s_], x21_, 0, 0, 0);
+                    x31 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p31[s_], x31, 0, 0, 0);
+                }
+                {
+                    double2* d0 = const_cast<double2*>(tile2(R2, 2 * jb)) + fo;
+                    d0[0] = make_double2(x20[0], x20[1]);   d0[64] = make_double2(x20[2], x20[3]);
+                    d0[128] = make_double2(x21_[0], x21_[1]); d0[192] = make_double2(x21_[2], x21_[3]);
+                }
+                if (v3) {
+                    double2* d0 = const_cast<double2*>(tile2(R3, 2 * jb)) + fo;
+                    d0[0] = make_double2(x30[0], x30[1]);   d0[64] = make_double2(x30[2], x30[3]);
+                    d0[128] = make_double2(x31[0], x31[1]); d0[192] = make_double2(x31[2], x31[3]);
+                }
+#if HIPDRT_QP_PREFETCH
+                // next column's source tiles (rows tb+4, tb+5): in flight while the stores above drain
+                if (R2 + 2 < ntr) {
+                    const int N2 = R2 + 2, N3 = R3 + 2;
+                    pre[0] = tile_src(N2, R2, ntr, fo); pre[1] = tile_src(N2, R3, ntr, fo);
+                    pre[2] = tile_src(N3, R2, ntr, fo); pre[3] = tile_src(N3, R3, ntr, fo);
+                    pre[4] = tile_src(N2, N2, ntr, fo); pre[5] = tile_src(N3, N2, ntr, fo);
+                    pre[6] = tile_src(N3, N3, ntr, fo);
+                    have_pre = true;
+                }
+#endif
+                // the two chunks just produced complete the next diagonal block: a tile's register image is its own
+                // operand fragment (register s <-> k-step s)
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x20[s_], e11, 0, 0, 0);
+                    e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x30[s_], e21, 0, 0, 0);
+                    e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x30[s_], x30[s_], e22, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x21_[s_], e11, 0, 0, 0);
+                    e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x31[s_], e21, 0, 0, 0);
+                    e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x31[s_], x31[s_], e22, 0, 0, 0);
+                }
+                stage_dsc(e11);
+                img21[lane] = e21;
+                img22[lane] = e22;
+                if (fwd) {
+                    lds_barrier();                              // (A2)
+                    fwd_update(x20, x21_, R2, j0, li, kq);
+                    if (v3) fwd_update(x30, x31, R3, j0, li, kq);
+                }
+            } else if (fwd) {
+                lds_barrier();                                  // (A2)
+            }
+            __syncthreads();                                    // (B) block column visible to everyone
+        }
+        return true;
+    }
+
+    // ======== wavefronts 2..7: the rows below ==========================================================================
+    // rows of pass 0 of block column jb for this wavefront (balanced schedule: the first RMAXT set bits of its mask)
+    __device__ __forceinline__ void first_rows(int jb, int wv, int lane, int ntr, int (&T)[RMAXT], bool (&act)[RMAXT]) const {
+        constexpr int OW = RNW - 2;
+        const int tb = 2 * jb;
+        const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;
+        const int nothers = nsq + nex;
+        if (balanced) {
+            constexpr int SROW = ResSmemT<GU, RTT>::SROW;
+            const unsigned char* row = sm.sched + jb * SROW;
+            unsigned long long m0 = __ballot(lane < nsq && row[lane] == wv), m1 = 0;
+            if (SROW > 64) m1 = __ballot(lane + 64 < nsq && row[lane + 64] == wv);
+#pragma unroll
+            for (int u = 0; u < RMAXT; ++u) {
+                int r = -1;
+                if (m0) { r = __builtin_ctzll(m0); m0 &= m0 - 1; }
+                else if (m1) { r = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+                T[u] = r >= 0 ? tb + 4 + r : nch;
+                act[u] = r >= 0;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < RMAXT; ++u) {
+                const int slot = (wv - 2) + u * OW;
+                T[u] = slot < nsq ? tb + 4 + slot : nch + (slot - nsq);
+                act[u] = slot < nothers;
+            }
+        }
+    }
+
+    __device__ __forceinline__ bool factor_rows(int wv) {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;              // this lane's double2 inside a 1 KB half tile
+        const int nblk = (n + NB - 1) / NB;
+        const int ntr = (n + 15) >> 4;
+        double* U = sm.U;
+        constexpr int OW = RNW - 2;                       // wavefronts in this role
+        // source tiles of pass 0 of the NEXT block column, requested before barrier (B) (tile_src)
+        TileSrc pre[RMAXT][2];
+        bool have_pre = false;
+        for (int jb = 0; jb < nblk; ++jb) {
+            const int j0 = jb * NB;
+            const int tb = j0 >> 4;                 // first tile-row of the block
+            const int nc = 2 * jb;                  // finished 16-column chunks
+            const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;   // rows of the square matrix below R3
+            const int nothers = nsq + nex;                               // ... followed by the appended rows
+            const bool two = (tb + 1) < ntr;                             // second tile column is not pure padding
+            int npass = nothers > OW * RMAXT ? (nothers + OW * RMAXT - 1) / (OW * RMAXT) : 1;
+            // balanced schedule (build_schedule): bit r of (m0, m1) = tile row tb + 4 + r is this wavefront's
+            unsigned long long m0 = 0, m1 = 0;
+            if (balanced) {
+                constexpr int SROW = ResSmemT<GU, RTT>::SROW;
+                const unsigned char* row = sm.sched + jb * SROW;
+                m0 = __ballot(lane < nsq && row[lane] == wv);
+                if (SROW > 64) m1 = __ballot(lane + 64 < nsq && row[lane + 64] == wv);
+                const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);
+                npass = mine > RMAXT ? (mine + RMAXT - 1) / RMAXT : 1;
+            }
+#pragma unroll 1
+            for (int ps = 0; ps < npass; ++ps) {
+                int T[RMAXT];
+                bool act[RMAXT];
+                if (balanced) {
+#pragma unroll
+                    for (int u = 0; u < RMAXT; ++u) {
+                        int r = -1;
+                        if (m0) { r = __builtin_ctzll(m0); m0 &= m0 - 1; }
+                        else if (m1) { r = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+                        T[u] = r >= 0 ? tb + 4 + r : nch;
+                        act[u] = r >= 0;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RMAXT; ++u) {
+                        const int slot = (wv - 2) + u * OW + ps * OW * RMAXT;
+                        T[u] = slot < nsq ? tb + 4 + slot : nch + (slot - nsq);
+                        act[u] = slot < nothers;
+                    }
+                }
+                // ---- (1) accT = -(S' tile) + sum_c L(Cc, c) L(T, c)' --------------------------------------
+                v4d acc[RMAXT][2];
+                if (ps == 0 && have_pre) {
+#pragma unroll
+                    for (int u = 0; u < RMAXT; ++u)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[u][ct] = act[u] ? tile_image(pre[u][ct], T[u], tb + ct, li, kq) : (v4d){0, 0, 0, 0};
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RMAXT; ++u)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                }
+                if (jb > 0 && act[0]) {
+                    // Hand-pipelined operand ring (qp_common.hpp: gload16 / vm_wait), half-chunks of 8 columns: the A
+                    // tiles (this wavefront's own rows, from HBM) are requested THREE half-chunks ahead, the B tiles
+                    // (the block's two tile rows, shared by all wavefronts: L1 / L2) one ahead.  Per step 2 B + 4 A loads,
+                    // B first, so "B of this step has arrived" is vmcnt(2 RMAXT + 2): A(k+2), B(k+1), A(k+3) may still be in
+                    // flight.  Indices past the end are clamped (a redundant load) so that the counts stay uniform.
+                    const char* rb0 = uniform_ptr(tile2(tb, 0));
+                    const char* rb1 = uniform_ptr(tile2(two ? tb + 1 : tb, 0));      // stand-in when the row is padding
+                    const char* ra[RMAXT];
+#pragma unroll
+                    for (int u = 0; u < RMAXT; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
+                    const unsigned voff = (unsigned)fo * 16u;
+                    struct SlA { v2d a[RMAXT]; };
+                    struct SlB { v2d b0, b1; };
+                    const int nk2 = 2 * nc, klast = nk2 - 1;
+                    auto loadA = [&](SlA& s_, int k2) {
+                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+#pragma unroll
+                        for (int u = 0; u < RMAXT; ++u) s_.a[u] = gload16(ra[u] + o, voff);
+                    };
+                    auto loadB = [&](SlB& s_, int k2) {
+                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+                        s_.b0 = gload16(rb0 + o, voff); s_.b1 = gload16(rb1 + o, voff);
+                    };
+                    auto mult = [&](const SlA& a_, const SlB& b_) {
+#pragma unroll
+                        for (int u = 0; u < RMAXT; ++u) {
+                            if (act[u]) {
+                                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b0.x, a_.a[u].x, acc[u][0], 0, 0, 0);
+                                if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b1.x, a_.a[u].x, acc[u][1], 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < RMAXT; ++u) {
+                            if (act[u]) {
+                                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b0.y, a_.a[u].y, acc[u][0], 0, 0, 0);
+                                if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b1.y, a_.a[u].y, acc[u][1], 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    SlA a0, a1, a2, a3;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+                    __builtin_amdgcn_sched_barrier(0);
+                    SlB b0, b1;
+                    loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
+                    for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 4 jb: a multiple of 4
+                        loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RMAXT + 2>(); mult(a0, b0);
+                        loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * RMAXT + 2>(); mult(a1, b1);
+                        loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RMAXT + 2>(); mult(a2, b0);
+                        loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<2 * RMAXT + 2>(); mult(a3, b1);
+                    }
+                    vm_wait<0>();
+                }
+                if (ps == 0) {
+                    __syncthreads();                            // (A) W1, L21, W2 published by wavefront 0
+                    if (sm.flag[0]) return false;
+                    have_pre = false;
+                }
+                // ---- (3) X1' = W1 C1', C2' -= L21 X1', X2' = W2 C2' on the matrix pipe, from registers -----
+                if (act[0]) {
                     double wn1[4], l21[4], wn2[4];
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_) {
@@ -446,226 +723,62 @@ struct OpsResidentT {
                         l21[s_] = sm.t21[li * DLD + 4 * s_ + kq];
                         wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
                     }
-                    v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
+                    v4d x1[RMAXT], x2[RMAXT];
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        x20 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p20[s_], x20, 0, 0, 0);
-                        x30 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p30[s_], x30, 0, 0, 0);
-                    }
+                    for (int u = 0; u < RMAXT; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x20[s_], p21, 0, 0, 0);
-                        p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x30[s_], p31, 0, 0, 0);
-                    }
+                    for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        x21_ = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p21[s_], x21_, 0, 0, 0);
-                        x31 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p31[s_], x31, 0, 0, 0);
-                    }
-                    {
-                        double2* d0 = const_cast<double2*>(tile2(R2, 2 * jb)) + fo;
-                        d0[0] = make_double2(x20[0], x20[1]);   d0[64] = make_double2(x20[2], x20[3]);
-                        d0[128] = make_double2(x21_[0], x21_[1]); d0[192] = make_double2(x21_[2], x21_[3]);
-                    }
-                    if (v3) {
-                        double2* d0 = const_cast<double2*>(tile2(R3, 2 * jb)) + fo;
-                        d0[0] = make_double2(x30[0], x30[1]);   d0[64] = make_double2(x30[2], x30[3]);
-                        d0[128] = make_double2(x31[0], x31[1]); d0[192] = make_double2(x31[2], x31[3]);
-                    }
-                    // the two chunks just produced complete the next diagonal block: a tile's register image is its own
-                    // operand fragment (register s <-> k-step s)
+                        for (int u = 0; u < RMAXT; ++u)
+                            x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x20[s_], e11, 0, 0, 0);
-                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x30[s_], e21, 0, 0, 0);
-                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x30[s_], x30[s_], e22, 0, 0, 0);
-                    }
+                    for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x21_[s_], e11, 0, 0, 0);
-                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x31[s_], e21, 0, 0, 0);
-                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x31[s_], x31[s_], e22, 0, 0, 0);
-                    }
-                    stage_dsc(e11);
-                    img21[lane] = e21;
-                    img22[lane] = e22;
-                    if (fwd) {
-                        lds_barrier();                              // (A2)
-                        fwd_update(x20, x21_, R2, j0, li, kq);
-                        if (v3) fwd_update(x30, x31, R3, j0, li, kq);
-                    }
-                } else if (fwd) {
-                    lds_barrier();                                  // (A2)
-                }
-            } else {
-                // ======== wavefronts 2..7: the rows below ======================================================
-                constexpr int OW = RNW - 2;                       // wavefronts in this role
-                const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;   // rows of the square matrix below R3
-                const int nothers = nsq + nex;                               // ... followed by the appended rows
-                const bool two = (tb + 1) < ntr;                             // second tile column is not pure padding
-                int npass = nothers > OW * RMAXT ? (nothers + OW * RMAXT - 1) / (OW * RMAXT) : 1;
-                // balanced schedule (build_schedule): bit r of (m0, m1) = tile row tb + 4 + r is this wavefront's
-                unsigned long long m0 = 0, m1 = 0;
-                if (balanced) {
-                    constexpr int SROW = ResSmemT<GU, RTT>::SROW;
-                    const unsigned char* row = sm.sched + jb * SROW;
-                    m0 = __ballot(lane < nsq && row[lane] == wv);
-                    if (SROW > 64) m1 = __ballot(lane + 64 < nsq && row[lane + 64] == wv);
-                    const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);
-                    npass = mine > RMAXT ? (mine + RMAXT - 1) / RMAXT : 1;
-                }
-#pragma unroll 1
-                for (int ps = 0; ps < npass; ++ps) {
-                    int T[RMAXT];
-                    bool act[RMAXT];
-                    if (balanced) {
+                        for (int u = 0; u < RMAXT; ++u)
+                            acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) {
-                            int r = -1;
-                            if (m0) { r = __builtin_ctzll(m0); m0 &= m0 - 1; }
-                            else if (m1) { r = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
-                            T[u] = r >= 0 ? tb + 4 + r : nch;
-                            act[u] = r >= 0;
-                        }
-                    } else {
+                    for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) {
-                            const int slot = (wv - 2) + u * OW + ps * OW * RMAXT;
-                            T[u] = slot < nsq ? tb + 4 + slot : nch + (slot - nsq);
-                            act[u] = slot < nothers;
+                        for (int u = 0; u < RMAXT; ++u)
+                            x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
+                    // ---- (4) tiles straight from registers: two contiguous 1 KB stores per tile ------------
+#pragma unroll
+                    for (int u = 0; u < RMAXT; ++u) {
+                        if (act[u]) {
+                            double2* d0 = const_cast<double2*>(tile2(T[u], 2 * jb)) + fo;
+                            d0[0] = make_double2(x1[u][0], x1[u][1]);
+                            d0[64] = make_double2(x1[u][2], x1[u][3]);
+                            d0[128] = make_double2(x2[u][0], x2[u][1]);
+                            d0[192] = make_double2(x2[u][2], x2[u][3]);
                         }
                     }
-                    // ---- (1) accT = -(S' tile) + sum_c L(Cc, c) L(T, c)' --------------------------------------
-                    v4d acc[RMAXT][2];
+#if HIPDRT_QP_PREFETCH
+                    if (ps == npass - 1 && jb + 1 < nblk) {
+                        // the source tiles of the next block column's first pass: in flight while the stores above drain
+                        int Tn[RMAXT];
+                        bool an[RMAXT];
+                        first_rows(jb + 1, wv, lane, ntr, Tn, an);
+                        if (an[0]) {
 #pragma unroll
-                    for (int u = 0; u < RMAXT; ++u)
+                            for (int u = 0; u < RMAXT; ++u)
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-                            acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
-                    if (jb > 0 && act[0]) {
-                        // Hand-pipelined operand ring (qp_common.hpp: gload16 / vm_wait), half-chunks of 8 columns: the A
-                        // tiles (this wavefront's own rows, from HBM) are requested THREE half-chunks ahead, the B tiles
-                        // (the block's two tile rows, shared by all wavefronts: L1 / L2) one ahead.  Per step 2 B + 4 A loads,
-                        // B first, so "B of this step has arrived" is vmcnt(2 RMAXT + 2): A(k+2), B(k+1), A(k+3) may still be in
-                        // flight.  Indices past the end are clamped (a redundant load) so that the counts stay uniform.
-                        const char* rb0 = uniform_ptr(tile2(tb, 0));
-                        const char* rb1 = uniform_ptr(tile2(two ? tb + 1 : tb, 0));      // stand-in when the row is padding
-                        const char* ra[RMAXT];
-#pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
-                        const unsigned voff = (unsigned)fo * 16u;
-                        struct SlA { v2d a[RMAXT]; };
-                        struct SlB { v2d b0, b1; };
-                        const int nk2 = 2 * nc, klast = nk2 - 1;
-                        auto loadA = [&](SlA& s_, int k2) {
-                            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-#pragma unroll
-                            for (int u = 0; u < RMAXT; ++u) s_.a[u] = gload16(ra[u] + o, voff);
-                        };
-                        auto loadB = [&](SlB& s_, int k2) {
-                            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-                            s_.b0 = gload16(rb0 + o, voff); s_.b1 = gload16(rb1 + o, voff);
-                        };
-                        auto mult = [&](const SlA& a_, const SlB& b_) {
-#pragma unroll
-                            for (int u = 0; u < RMAXT; ++u) {
-                                if (act[u]) {
-                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b0.x, a_.a[u].x, acc[u][0], 0, 0, 0);
-                                    if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b1.x, a_.a[u].x, acc[u][1], 0, 0, 0);
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < RMAXT; ++u) {
-                                if (act[u]) {
-                                    acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b0.y, a_.a[u].y, acc[u][0], 0, 0, 0);
-                                    if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b1.y, a_.a[u].y, acc[u][1], 0, 0, 0);
-                                }
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        };
-                        SlA a0, a1, a2, a3;
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
-                        __builtin_amdgcn_sched_barrier(0);
-#ifdef HIPDRT_QP_BRING4
-                        // (experiment, -DHIPDRT_QP_BRING4) B three half-chunks ahead like A: loads return in order, so with B one
-                        // step ahead every A issued before it has to be back a step early (an effective lead of two steps).
-                        // Measured 10.61 vs 10.66 ms per launch at the cost of 8 spilled registers: the operand stream is
-                        // not what the row wavefronts wait for, so the default keeps the two-slot B ring.
-                        SlB b0, b1, b2, b3;
-                        loadB(b0, 0); loadA(a0, 0); loadB(b1, 1); loadA(a1, 1); loadB(b2, 2); loadA(a2, 2);
-                        for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 4 jb: a multiple of 4
-                            loadB(b3, k2 + 3); loadA(a3, k2 + 3); vm_wait<3 * (RMAXT + 2)>(); mult(a0, b0);
-                            loadB(b0, k2 + 4); loadA(a0, k2 + 4); vm_wait<3 * (RMAXT + 2)>(); mult(a1, b1);
-                            loadB(b1, k2 + 5); loadA(a1, k2 + 5); vm_wait<3 * (RMAXT + 2)>(); mult(a2, b2);
-                            loadB(b2, k2 + 6); loadA(a2, k2 + 6); vm_wait<3 * (RMAXT + 2)>(); mult(a3, b3);
+                                for (int ct = 0; ct < 2; ++ct)
+                                    if (an[u]) pre[u][ct] = tile_src(Tn[u], tb + 2 + ct, ntr, fo);
+                            have_pre = true;
                         }
-#else
-                        SlB b0, b1;
-                        loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
-                        for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 4 jb: a multiple of 4
-                            loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RMAXT + 2>(); mult(a0, b0);
-                            loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * RMAXT + 2>(); mult(a1, b1);
-                            loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RMAXT + 2>(); mult(a2, b0);
-                            loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<2 * RMAXT + 2>(); mult(a3, b1);
-                        }
+                    }
 #endif
-                        vm_wait<0>();
+                    if (fwd) {
+                        if (ps == 0) lds_barrier();             // (A2) y_j published by wavefront 0
+#pragma unroll
+                        for (int u = 0; u < RMAXT; ++u)
+                            if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0, li, kq);
                     }
-                    if (ps == 0) {
-                        __syncthreads();                            // (A) W1, L21, W2 published by wavefront 0
-                        if (sm.flag[0]) return false;
-                    }
-                    // ---- (3) X1' = W1 C1', C2' -= L21 X1', X2' = W2 C2' on the matrix pipe, from registers -----
-                    if (act[0]) {
-                        double wn1[4], l21[4], wn2[4];
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_) {
-                            wn1[s_] = -U[(size_t)(j0 + li) * PLD + 4 * s_ + kq];
-                            l21[s_] = sm.t21[li * DLD + 4 * s_ + kq];
-                            wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
-                        }
-                        v4d x1[RMAXT], x2[RMAXT];
-#pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RMAXT; ++u)
-                                x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RMAXT; ++u)
-                                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RMAXT; ++u)
-                                x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
-                        // ---- (4) tiles straight from registers: two contiguous 1 KB stores per tile ------------
-#pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) {
-                            if (act[u]) {
-                                double2* d0 = const_cast<double2*>(tile2(T[u], 2 * jb)) + fo;
-                                d0[0] = make_double2(x1[u][0], x1[u][1]);
-                                d0[64] = make_double2(x1[u][2], x1[u][3]);
-                                d0[128] = make_double2(x2[u][0], x2[u][1]);
-                                d0[192] = make_double2(x2[u][2], x2[u][3]);
-                            }
-                        }
-                        if (fwd) {
-                            if (ps == 0) lds_barrier();             // (A2) y_j published by wavefront 0
-#pragma unroll
-                            for (int u = 0; u < RMAXT; ++u)
-                                if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0, li, kq);
-                        }
-                    } else if (fwd && ps == 0) {
-                        lds_barrier();                              // (A2)
-                    }
+                } else if (fwd && ps == 0) {
+                    lds_barrier();                              // (A2)
                 }
             }
             __syncthreads();                                        // (B) block column visible to everyone
-            PROF(4);
         }
         return true;
     }

@@ -281,10 +281,13 @@ def main():
         nfl = len(drts)
         plans = [d._plan for d in drts]
     drt, plan = drts[0], plans[0]
-    if world > 1:                                         # rank 0's tables -> everyone (one RCCL broadcast)
-        zr, zi = hd.broadcast_arrays([plan.get("lut_z_re"), plan.get("lut_z_im")], src=0)
-        for p_ in plans:
-            p_.set_lookup(zr, zi)
+    if plan is None:
+        raise SystemExit(f"bench.py: rank {rank} has no observations to fit ({job_fits} spectra over {world} ranks)")
+    if world > 1 and config == "c3":
+        # rank 0's lookup tables -> everyone, one RCCL broadcast (c4: mapping.fit_observations_sharded does this itself)
+        from hipdrt.mapping.drtmd import share_lookup_tables
+        for d in drts:
+            share_lookup_tables(d, rank, world, src=0)
 
     for d in drts:
         for _ in range(args.warmup if config == "c3" else 0):

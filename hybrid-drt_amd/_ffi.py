@@ -112,6 +112,7 @@ SIGNATURES = {
     "hipdrt_plan_distribution_var": [_vp, _dp, C.c_int, _dp, _ip],
     "hipdrt_plan_llh_terms": [_vp, _dp, _dp],
     "hipdrt_plan_obs_llh_terms": [_vp, _dp, _dp],
+    "hipdrt_plan_obs_llh_terms_w": [_vp, C.c_int, C.c_double, _dp, _dp],
     "hipdrt_plan_set_state": [_vp, _dp, _dp, _dp, _dp],
     "hipdrt_plan_continue": [_vp, C.POINTER(FitOpts), C.c_double, C.c_int],
     "hipdrt_plan_iterate": [_vp, C.POINTER(IterateState), _ip, _ip, _ip, _dp],
@@ -450,12 +451,21 @@ class Plan:
     def fit(self):
         _check(self._lib.hipdrt_plan_fit(self._h))
 
-    def llh_terms(self, stored=False):
+    def llh_terms(self, stored=False, weights=None):
         """(rss, sum(log w)) per spectrum; stored=False: weights re-estimated from the current x (PFRT steps),
-        stored=True: the fit's own est_weights (DRT.evaluate_rss() / evaluate_llh() defaults)."""
+        stored=True: the `weights` argument of DRT.evaluate_rss() / evaluate_llh(): None = the fit's own est_weights,
+        'uniform' = per-domain means of them (DRTMD's default), a positive scalar = that weight for every row."""
         rss, slw = np.empty(self.batch), np.empty(self.batch)
-        fn = self._lib.hipdrt_plan_obs_llh_terms if stored else self._lib.hipdrt_plan_llh_terms
-        _check(fn(self._h, _p(rss), _p(slw)))
+        if not stored:
+            _check(self._lib.hipdrt_plan_llh_terms(self._h, _p(rss), _p(slw)))
+        elif weights is None:
+            _check(self._lib.hipdrt_plan_obs_llh_terms(self._h, _p(rss), _p(slw)))
+        elif isinstance(weights, str):
+            if weights != 'uniform':
+                raise ValueError(f"weights must be None, 'uniform' or a scalar, got {weights!r}")
+            _check(self._lib.hipdrt_plan_obs_llh_terms_w(self._h, 2, 1.0, _p(rss), _p(slw)))
+        else:
+            _check(self._lib.hipdrt_plan_obs_llh_terms_w(self._h, 3, float(weights), _p(rss), _p(slw)))
         return rss, slw
 
     def set_state(self, x=None, rho=None, s=None, weights=None):

@@ -1029,13 +1029,20 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     return HIPDRT_OK;
 }
 
-static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored);
+static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored, double scalar_w = 1.0);
 
 int hipdrt_plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) { return plan_llh_terms(p, rss, sum_log_w, 0); }
 
 int hipdrt_plan_obs_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) { return plan_llh_terms(p, rss, sum_log_w, 1); }
 
-static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored) {
+int hipdrt_plan_obs_llh_terms_w(hipdrt_plan* p, int weights_mode, double scalar_weight, double* rss, double* sum_log_w) {
+    HIPDRT_REQUIRE(weights_mode == HIPDRT_LLH_W_EST || weights_mode == HIPDRT_LLH_W_UNIFORM || weights_mode == HIPDRT_LLH_W_SCALAR,
+                   "weights_mode");
+    HIPDRT_REQUIRE(weights_mode != HIPDRT_LLH_W_SCALAR || scalar_weight > 0.0, "scalar weight must be positive");
+    return plan_llh_terms(p, rss, sum_log_w, weights_mode, scalar_weight);
+}
+
+static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored, double scalar_w) {
     HIPDRT_REQUIRE(p && rss && sum_log_w, "NULL pointer");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
@@ -1043,7 +1050,7 @@ static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int st
     const size_t bb = (size_t)p->B * sizeof(double);
     DevBuf d1, d2;
     HIPDRT_CHECK(d1.alloc(bb)); HIPDRT_CHECK(d2.alloc(bb));
-    TRY(launch_llh(st, p->state(), p->B, d1.d(), d2.d(), stored));
+    TRY(launch_llh(st, p->state(), p->B, d1.d(), d2.d(), stored, scalar_w));
     LAUNCH_OK();
     HIPDRT_CHECK(hipMemcpyAsync(rss, d1.p, bb, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipMemcpyAsync(sum_log_w, d2.p, bb, hipMemcpyDeviceToHost, st));

@@ -188,7 +188,7 @@ int launch_hyper(hipStream_t s, const FitState& st, int B, int it);
 void launch_scale_weights(hipStream_t s, const FitState& st, int B, double factor);
 void launch_scale_rows(hipStream_t s, int B, int m, const double* w, const double* rows, int batched, double factor,
                        const int* active, double* out);
-int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw, int stored = 0);
+int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw, int stored = 0, double scalar_w = 1.0);
 void launch_assemble_rm(hipStream_t s, const FitState& st, const double* a_re, const double* a_im, const double* freq,
                         double* rm, int idx_rinf, int idx_induc);
 void launch_special_penalty(hipStream_t s, double* m0, double* m1, double* m2, int ld, int idx_rinf, int idx_induc,

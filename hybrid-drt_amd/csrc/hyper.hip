@@ -837,9 +837,12 @@ int launch_init_weights(hipStream_t s, const FitState& st, int B, int stage, int
 // Ingredients of DRT.evaluate_llh(weights=estimate_weights(x), x) (drt1d.py:4457-4496, qphb.py:1347-1377) as the PFRT
 // driver evaluates it after every step (drt1d.py:2618-2622): weights re-estimated from the current x alone
 // (est_weights=None), then rss = x'(WR)'(WR)x - 2 (Wy)'(WR)x + (Wy)'(Wy) and sum(log w).  grid = B.
-// stored != 0: the weights are the fit's own est_weights instead (DRT.evaluate_llh() / evaluate_rss() with their default
-// arguments, which is what DRTMD.fit_observation records per observation, drtmd.py:259-260).
-__global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict__ rss, double* __restrict__ slw, int stored) {
+// stored = 1: the weights are the fit's own est_weights instead (DRT.evaluate_llh() / evaluate_rss() with weights=None);
+// stored = 2: weights='uniform' (drt1d.py:4436-4441, 4465-4470): within each domain -- chrono rows [0, num_chrono), impedance
+// rows after them -- every weight is the mean of that domain's est_weights, which is what DRTMD.fit_observation records per
+// observation with its default llh_kw / rss_kw (drtmd.py:129-131, 259-260); stored = 3: one scalar weight for every row.
+__global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict__ rss, double* __restrict__ slw, int stored,
+                                                 double scalar_w) {
     extern __shared__ double sm[];
     __shared__ double red[HNW];
     const int b = blockIdx.x, tid = threadIdx.x, n = st.n, m = st.m;
@@ -857,11 +860,25 @@ __global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict
     if (!stored) rows_matvec(st.vmm, m, m, m, r2, sh);
     __syncthreads();
     const double vf = st.var_floor[b];
+    const int nchr = st.prepared ? st.desc.num_chrono : 0;
+    double wmean_c = scalar_w, wmean_e = scalar_w;
+    if (stored == 2) {
+        double sc = 0.0, se = 0.0;
+        for (int i = tid; i < m; i += HT) {
+            const double w = st.est_w[(size_t)b * m + i];
+            if (i < nchr) sc += w; else se += w;
+        }
+        sc = blk_sum(sc, red); se = blk_sum(se, red);
+        wmean_c = nchr > 0 ? sc / (double)nchr : 0.0;
+        wmean_e = m > nchr ? se / (double)(m - nchr) : 0.0;
+    }
     double a = 0.0, c2 = 0.0, d = 0.0, lw = 0.0;
     for (int i = tid; i < m; i += HT) {
         double w;
-        if (stored) {
+        if (stored == 1) {
             w = st.est_w[(size_t)b * m + i];
+        } else if (stored >= 2) {
+            w = i < nchr ? wmean_c : wmean_e;
         } else {
             double v = sh[i];
             if (v < vf) v = vf;
@@ -874,10 +891,10 @@ __global__ __launch_bounds__(HT) void llh_kernel(FitState st, double* __restrict
     if (tid == 0) { rss[b] = a - 2.0 * c2 + d; slw[b] = lw; }
 }
 
-int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw, int stored) {
+int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw, int stored, double scalar_w) {
     const size_t lds = (size_t)(st.n + 3 * st.m) * sizeof(double);
     if (int rc = set_lds(reinterpret_cast<const void*>(llh_kernel), lds)) return rc;
-    hipLaunchKernelGGL(llh_kernel, dim3(B), dim3(HT), lds, s, st, rss, slw, stored);
+    hipLaunchKernelGGL(llh_kernel, dim3(B), dim3(HT), lds, s, st, rss, slw, stored, scalar_w);
     return 0;
 }
 

@@ -52,8 +52,9 @@ def broadcast_arrays(arrays, src=0):
 
 
 def gather_rows(local, counts, dst=0):
-    """Gather per-rank result blocks (arrays whose first axis is the local spectrum count) to `dst`;
-    counts[r] = rows owned by rank r.  Returns the concatenated array on dst, None elsewhere."""
+    """Gather per-rank result blocks (arrays whose first axis is the local spectrum count) to `dst` with ONE collective
+    (a gather: only `dst` receives; blocks padded to the largest count); counts[r] = rows owned by rank r.  Returns the
+    concatenated array on dst, None elsewhere."""
     local = np.ascontiguousarray(local, dtype=np.float64)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
@@ -63,8 +64,8 @@ def gather_rows(local, counts, dst=0):
     pad = max(counts)
     buf = torch.zeros(pad * width, dtype=torch.float64, device=_dev())
     buf[:local.size] = torch.from_numpy(local.ravel()).to(_dev())
-    gathered = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(gathered, buf)          # one collective; B*(n+m+8)*8 bytes total (tens of MB at 10k spectra)
+    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, gathered, dst=dst)     # B*(n+8)*8 bytes in all (tens of MB at 10k spectra), to one rank only
     if rank != dst:
         return None
     parts = [g.cpu().numpy()[:counts[r] * width].reshape((counts[r],) + tail) for r, g in enumerate(gathered)]

@@ -71,7 +71,7 @@ def drt_siblings(drt, count):
     return ([drt] + clones)[:count]
 
 
-def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid, drt_var, ignore_errors, llh_kw, fit_kw):
+def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid, drt_var, ignore_errors, llh_kw, rss_kw, fit_kw):
     """The observations in `inflight` contiguous chunks, each chunk one device batch on its own sibling plan, the host
     threads overlapping their device loops: spectra finish after 4 ... 50 outer iterations, so one batch alone leaves
     CUs idle in its tail, several side by side fill them ('batches in flight')."""
@@ -84,7 +84,7 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
     def work(i):
         try:
             outs[i] = fit_observations(sibs[i], frequencies, z_obs[chunks[i]], tau_supergrid=tau_supergrid, drt_var=drt_var,
-                                       ignore_errors=True, llh_kw=llh_kw, **fit_kw)
+                                       ignore_errors=True, llh_kw=llh_kw, rss_kw=rss_kw, **fit_kw)
         except BaseException as exc:            # re-raised in the caller's thread
             errs[i] = exc
 
@@ -107,34 +107,149 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
         else:
             res[k] = v
     res['obs_fit_errors'] = [e for o in outs for e in o[2]['obs_fit_errors']]
-    if not ignore_errors and not res['obs_fit_status'].all():
-        bad = int(np.flatnonzero(~res['obs_fit_status'])[0])
-        print(f"Error encountered at obs_index {bad}")
-        raise res['obs_fit_errors'][bad]
+    _raise_first_error(res, ignore_errors)
     return obs_x, obs_special, res
 
 
-def fit_observations(drt, frequencies, z_obs, tau_supergrid=None, drt_var=False, ignore_errors=True, llh_kw=None,
-                     inflight=1, **fit_kw):
-    """Fit every observation (rows of z_obs) and scatter the coefficients into supergrid slots like
-    DRTMD.fit_observation does (drtmd.py:245-301): returns obs_x (B, len(supergrid)), obs_special dict, and the raw
-    result dict, which also carries what the reference keeps per observation:
-      obs_llh, obs_rss       DRT.evaluate_llh(**llh_kw) / evaluate_rss() of every fit (drtmd.py:259-260);
+def _raise_first_error(res, ignore_errors):
+    """fit_observation's error contract (drtmd.py:292-301): without ignore_errors the first failed observation raises"""
+    if not ignore_errors and not np.all(res['obs_fit_status']):
+        bad = int(np.flatnonzero(~np.asarray(res['obs_fit_status']))[0])
+        print(f"Error encountered at obs_index {bad}")
+        raise res['obs_fit_errors'][bad]
+
+
+def _metric_kw(llh_kw, rss_kw):
+    """DRTMD.__init__ (drtmd.py:121-134): both keyword sets default to normalize=True, weights='uniform'"""
+    llh_kw, rss_kw = dict(llh_kw or {}), dict(rss_kw or {})
+    for kw in (llh_kw, rss_kw):
+        kw.setdefault('normalize', True)
+        kw.setdefault('weights', 'uniform')
+    return llh_kw, rss_kw
+
+
+def _supergrid_slots(tau_supergrid, basis_tau):
+    """drtmd.py:262-267 (utils.array.nearest_index on both ends of the basis grid)"""
+    left = int(np.argmin(np.abs(np.log(tau_supergrid) - np.log(basis_tau[0]))))
+    right = int(np.argmin(np.abs(np.log(tau_supergrid) - np.log(basis_tau[-1])))) + 1
+    return left, right
+
+
+def observation_groups(observations):
+    """Observations that can share one device plan: same data type (EIS / chrono / joint), same frequency grid, same sample
+    times and current signal -- hence the same matrices and the same slice of the tau supergrid.  Returns a list of
+    (kind, [observation indices]) in order of first appearance."""
+    groups, order = {}, []
+    for k, (chrono, eis) in enumerate(observations):
+        has_c = chrono is not None and chrono[0] is not None
+        has_e = eis is not None and eis[0] is not None
+        if not (has_c or has_e):
+            raise ValueError(f'observation {k} has neither chrono nor EIS data')
+        key = ('hybrid' if has_c and has_e else 'eis' if has_e else 'chrono',)
+        if has_c:
+            key += (np.asarray(chrono[0], dtype=float).tobytes(), np.asarray(chrono[1], dtype=float).tobytes())
+        if has_e:
+            key += (np.asarray(eis[0], dtype=float).tobytes(),)
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(k)
+    return [(key[0], groups[key]) for key in order]
+
+
+def fit_observation_list(drt, observations, tau_supergrid, drt_var=False, ignore_errors=False, llh_kw=None, rss_kw=None,
+                         **fit_kw):
+    """DRTMD.fit_observations (drtmd.py:245-319) for ANY mix of observations, each given as DRTMD.add_observation takes it:
+    (chrono_data, eis_data) with chrono_data = (times, i_signal, v_signal) or None and eis_data = (frequencies, z) or None.
+    Observations are grouped by (data type, sampling grids) on the host (observation_groups); every group is ONE device
+    batch -- an EIS plan (fit_eis_batch) or a prepared-matrix plan (joint / chrono fits) -- whose results are scattered
+    into the observation's own slice of the tau supergrid.  Returns (obs_x, obs_special, res) like fit_observations, with
+    per observation: obs_tau_indices (list of (left, right)), obs_group (index into res['groups']), obs_llh, obs_rss,
+    obs_fit_status / obs_fit_errors, outer_iters, qp_iters_total, status [, obs_drt_var, obs_drt_var_ok]."""
+    tau_supergrid = np.asarray(tau_supergrid, dtype=float)
+    num = len(observations)
+    llh_kw, rss_kw = _metric_kw(llh_kw, rss_kw)
+    obs_x = np.zeros((num, len(tau_supergrid)))
+    obs_special = {}
+    res = dict(obs_llh=np.zeros(num), obs_rss=np.zeros(num), obs_tau_indices=[None] * num, obs_group=np.zeros(num, dtype=int),
+               obs_fit_status=np.zeros(num, dtype=bool), obs_fit_errors=[None] * num, outer_iters=np.zeros(num, dtype=np.int64),
+               qp_iters_total=np.zeros(num, dtype=np.int64), status=np.zeros(num, dtype=np.int64), groups=[])
+    if drt_var:
+        res['obs_drt_var'] = np.zeros((num, len(tau_supergrid)))
+        res['obs_drt_var_ok'] = np.zeros(num, dtype=bool)
+    for g, (kind, idx) in enumerate(observation_groups(observations)):
+        idx = np.asarray(idx)
+        if kind == 'eis':
+            freq = np.asarray(observations[idx[0]][1][0], dtype=float)
+            out = drt.fit_eis_batch(freq, np.array([observations[k][1][1] for k in idx]), **fit_kw)
+            special_keys = [key for key in ('R_inf', 'inductance') if key in out]
+        else:
+            meas = []
+            for k in idx:
+                chrono, eis = observations[k]
+                eis = eis if (eis is not None and eis[0] is not None) else (None, None)
+                meas.append((chrono[0], chrono[1], chrono[2], eis[0], eis[1]))
+            out = drt._fit_prepared_batch(meas, fit_kw)
+            special_keys = [key for key in drt.special_qp_params if key in out]
+        basis_tau = out['basis_tau']
+        left, right = _supergrid_slots(tau_supergrid, basis_tau)
+        ok = np.asarray(out['status']) >= 0
+        obs_x[idx, left:right] = np.where(ok[:, None], out['fit_x'], 0.0)
+        for key in special_keys:
+            val = np.asarray(out[key], dtype=float)
+            if key not in obs_special:          # (initialize_obs_special / the "key is new" branch of drtmd.py:281-285)
+                obs_special[key] = np.zeros((num,) + val.shape[1:])
+            obs_special[key][idx] = np.where(ok.reshape((-1,) + (1,) * (val.ndim - 1)), val, 0.0)
+        llh, rss = drt.evaluate_obs_llh_rss_batch(llh_kw=llh_kw, rss_kw=rss_kw)
+        res['obs_llh'][idx], res['obs_rss'][idx] = np.where(ok, llh, 0.0), np.where(ok, rss, 0.0)
+        res['obs_fit_status'][idx] = ok
+        res['obs_group'][idx] = g
+        for key in ('outer_iters', 'qp_iters_total', 'status'):
+            res[key][idx] = out[key]
+        for j, k in enumerate(idx):
+            res['obs_tau_indices'][k] = (left, right)
+            if not ok[j]:
+                res['obs_fit_errors'][k] = ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+        if drt_var:
+            var, vok = drt.estimate_distribution_var_batch(tau=tau_supergrid, extend_var=True)
+            vok = np.asarray(vok, dtype=bool) & ok
+            res['obs_drt_var'][idx] = np.where(vok[:, None], var, 0.0)
+            res['obs_drt_var_ok'][idx] = vok
+        res['groups'].append(dict(kind=kind, indices=idx, basis_tau=basis_tau, tau_indices=(left, right)))
+    _raise_first_error(res, ignore_errors)
+    return obs_x, obs_special, res
+
+
+def fit_observations(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_var=False, ignore_errors=False, llh_kw=None,
+                     rss_kw=None, inflight=1, observations=None, **fit_kw):
+    """Fit every observation and scatter the coefficients into supergrid slots like DRTMD.fit_observation does
+    (drtmd.py:245-301): returns obs_x (B, len(supergrid)), obs_special dict, and the raw result dict, which also
+    carries what the reference keeps per observation:
+      obs_llh, obs_rss       DRT.evaluate_llh(**llh_kw) / evaluate_rss(**rss_kw) of every fit (drtmd.py:259-260), both
+                             keyword sets with DRTMD's defaults normalize=True, weights='uniform' (drtmd.py:121-134);
       obs_tau_indices        (left, right) supergrid slots of the basis grid (drtmd.py:262-267);
       obs_fit_status         True where the fit succeeded; obs_fit_errors: None or the exception the reference would have
-                             raised for that observation (cvxopt's ValueError at a singular start point), which
-                             ``ignore_errors=False`` raises for the first failed observation as upstream does
-                             (drtmd.py:292-301);
+                             raised for that observation (cvxopt's ValueError at a singular start point).  As upstream
+                             (``ignore_errors=False``, drtmd.py:245, 292-301) the first failed observation raises;
+                             with ``ignore_errors=True`` failed observations keep zeros everywhere;
       obs_drt_var(+_ok)      with ``drt_var=True``: diagonal of estimate_distribution_cov(tau=tau_supergrid,
                              extend_var=True) (drtmd.py:278-279).
-    ``inflight`` > 1 fits the observations as that many batches side by side (sibling plans of `drt`, one host thread
-    each): same results, in the same order, at the throughput of several batches in flight; 'auto' = auto_inflight(number
-    of observations).  (Afterwards `drt` itself holds the first batch only.)"""
+    Two call forms: ``(frequencies, z_obs)`` = impedance spectra on one shared frequency grid (rows of z_obs), or
+    ``observations=[(chrono_data, eis_data), ...]`` = any mix of data types and grids (fit_observation_list; needs
+    `tau_supergrid`).  ``inflight`` > 1 (shared-grid form) fits the observations as that many batches side by side
+    (sibling plans of `drt`, one host thread each): same results, in the same order, at the throughput of several batches
+    in flight; 'auto' = auto_inflight(number of observations).  (Afterwards `drt` itself holds the first batch only.)"""
+    if observations is not None:
+        if tau_supergrid is None:
+            raise ValueError('a heterogeneous observation list needs tau_supergrid')
+        return fit_observation_list(drt, observations, tau_supergrid, drt_var=drt_var, ignore_errors=ignore_errors,
+                                    llh_kw=llh_kw, rss_kw=rss_kw, **fit_kw)
     z_obs = np.asarray(z_obs)
     inflight = auto_inflight(z_obs.shape[0]) if inflight == 'auto' else int(inflight)
     if inflight > 1 and z_obs.shape[0] >= 2 * inflight:
         return _fit_observations_inflight(drt, frequencies, z_obs, int(inflight), tau_supergrid, drt_var, ignore_errors,
-                                          llh_kw, fit_kw)
+                                          llh_kw, rss_kw, fit_kw)
+    llh_kw, rss_kw = _metric_kw(llh_kw, rss_kw)
     res = drt.fit_eis_batch(frequencies, z_obs, **fit_kw)
     num = z_obs.shape[0]
     basis_tau = res['basis_tau']
@@ -145,52 +260,101 @@ def fit_observations(drt, frequencies, z_obs, tau_supergrid=None, drt_var=False,
     right = left + len(basis_tau)
     ok = np.asarray(res['status']) >= 0
     errors = [None if good else ValueError("Rank(A) < p or Rank([P; A; G]) < n") for good in ok]
-    if not ignore_errors and not ok.all():
-        bad = int(np.flatnonzero(~ok)[0])
-        print(f"Error encountered at obs_index {bad}")
-        raise errors[bad]
+    res['obs_fit_status'], res['obs_fit_errors'] = ok, errors
+    _raise_first_error(res, ignore_errors)
     obs_x = np.zeros((num, len(tau_supergrid)))
     obs_x[:, left:right] = np.where(ok[:, None], res['fit_x'], 0.0)
     obs_special = {'R_inf': np.where(ok, res['R_inf'], 0.0), 'inductance': np.where(ok, res['inductance'], 0.0)}
-    llh, rss = drt.evaluate_obs_llh_rss_batch(**(llh_kw or {}))
+    llh, rss = drt.evaluate_obs_llh_rss_batch(llh_kw=llh_kw, rss_kw=rss_kw)
     res['obs_llh'], res['obs_rss'] = np.where(ok, llh, 0.0), np.where(ok, rss, 0.0)
     res['obs_tau_indices'] = (left, right)
-    res['obs_fit_status'], res['obs_fit_errors'] = ok, errors
     if drt_var:
-        res['obs_drt_var'], res['obs_drt_var_ok'] = drt.estimate_distribution_var_batch(tau=tau_supergrid,
-                                                                                       extend_var=True)
+        var, vok = drt.estimate_distribution_var_batch(tau=tau_supergrid, extend_var=True)
+        vok = np.asarray(vok, dtype=bool) & ok
+        res['obs_drt_var'], res['obs_drt_var_ok'] = np.where(vok[:, None], var, 0.0), vok     # (failed fits keep zeros)
     return obs_x, obs_special, res
 
 
 _GATHER_KEYS = ('obs_llh', 'obs_rss', 'outer_iters', 'qp_iters_total', 'status')
 
 
-def fit_observations_sharded(drt, frequencies, z_obs, rank=None, world=None, tau_supergrid=None, scheme='interleave',
-                             drt_var=False, dst=0, fit=fit_observations, inflight=1, **fit_kw):
-    """BASELINE configs[3]: the observations of one map sharded over the ranks of a node (one process per GPU), every
-    rank fitting its share in one device batch, the results gathered on rank `dst` with ONE collective.
+def share_lookup_tables(drt, rank, world, src=0):
+    """SURVEY 8e / north_star: the lookup tables of the shared tau basis (impedance Z', Z'' and the chrono response, 3 x
+    2000 doubles) are built once, on rank `src`, and broadcast to the other ranks (RCCL over xGMI on a GPU node) -- ONE
+    collective; every rank's plans then take their tables from the broadcast instead of rebuilding them."""
+    from . import dist as hd
+    if world <= 1 or drt.tau_epsilon is None or drt.integrate_method != 'interp':
+        return False
+    shapes = [(len(drt._wt_re),), (len(drt._wt_im),), (2000,)]
+    if rank == src:
+        z_re, z_im, resp = drt.lookup_tables()
+    else:
+        z_re, z_im, resp = (np.zeros(shp) for shp in shapes)
+    z_re, z_im, resp = hd.broadcast_arrays([z_re, z_im, resp], src=src)
+    if rank != src:
+        drt.install_lookup_tables(z_re, z_im, resp)
+    return True
 
-    Every rank calls this with the same (frequencies, z_obs) -- or at least with its own rows valid -- and its own `drt`.
-    Returns on `dst` the same triple as fit_observations for ALL observations in their original order (result dict
-    reduced to the per-observation arrays obs_llh, obs_rss, outer_iters, qp_iters_total, status [, obs_drt_var]); None
-    elsewhere.  `scheme`: see shard_indices ('lpt' uses difficulty_proxy(z_obs)).  `fit` is the per-rank fit function
-    (the CPU tests inject a stand-in); `inflight` > 1 is handed to it (batches side by side on every rank)."""
+
+def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world=None, tau_supergrid=None, scheme='interleave',
+                             drt_var=False, dst=0, fit=fit_observations, inflight=1, observations=None, ignore_errors=False,
+                             **fit_kw):
+    """BASELINE configs[3]: the observations of one map sharded over the ranks of a node (one process per GPU), every
+    rank fitting its share as device batches, the results gathered on rank `dst` with ONE collective; before that, ONE
+    broadcast of rank `dst`'s lookup tables (share_lookup_tables).
+
+    Every rank calls this with the same (frequencies, z_obs) -- or at least with its own rows valid -- or the same
+    ``observations`` list (any mix of data types and grids, see fit_observations), and its own `drt`.  Returns on `dst` the
+    same triple as fit_observations for ALL observations in their original order (result dict reduced to the
+    per-observation arrays obs_llh, obs_rss, outer_iters, qp_iters_total, status [, obs_tau_indices, obs_drt_var]); None
+    elsewhere.  `scheme`: see shard_indices ('lpt' uses difficulty_proxy(z_obs); shared-grid form only).  `fit` is the
+    per-rank fit function (the CPU tests inject a stand-in); `inflight` > 1 is handed to it (batches side by side on every
+    rank).  Every rank fits with ignore_errors=True, so that all of them reach the collective; a failed observation then
+    raises on `dst`, after the gather, unless ``ignore_errors``."""
     from . import dist as hd
     if rank is None or world is None:
         import torch.distributed as tdist
         rank = tdist.get_rank() if tdist.is_initialized() else 0
         world = tdist.get_world_size() if tdist.is_initialized() else 1
-    z_obs = np.asarray(z_obs)
-    num = z_obs.shape[0]
-    cost = difficulty_proxy(z_obs) if scheme == 'lpt' else None
+    general = observations is not None
+    if general:
+        num = len(observations)
+        if scheme == 'lpt':
+            raise ValueError("scheme 'lpt' needs the shared-grid form (one z_obs array)")
+        cost = None
+    else:
+        z_obs = np.asarray(z_obs)
+        num = z_obs.shape[0]
+        cost = difficulty_proxy(z_obs) if scheme == 'lpt' else None
     owned = [shard_indices(num, world, r, scheme, cost) for r in range(world)]
     mine = owned[rank]
+    if fit is fit_observations:
+        share_lookup_tables(drt, rank, world, src=dst)
+    # special-parameter columns: the union over the whole map, in a fixed order, so that every rank packs the same row
+    special_keys = ['R_inf', 'inductance']
+    if general:
+        kinds = {kind for kind, _ in observation_groups(observations)}
+        if kinds - {'eis'}:
+            special_keys = ['v_baseline', 'vz_offset', 'R_inf', 'inductance']
+    nsup = None
     if len(mine):
+        kw = dict(fit_kw, ignore_errors=True)
         if inflight != 1:
-            fit_kw = dict(fit_kw, inflight=inflight)
-        obs_x, obs_special, res = fit(drt, frequencies, z_obs[mine], tau_supergrid=tau_supergrid, drt_var=drt_var, **fit_kw)
-        cols = [obs_x, obs_special['R_inf'][:, None], obs_special['inductance'][:, None]]
+            kw['inflight'] = inflight
+        if general:
+            obs_x, obs_special, res = fit(drt, tau_supergrid=tau_supergrid, drt_var=drt_var,
+                                          observations=[observations[k] for k in mine], **kw)
+        else:
+            obs_x, obs_special, res = fit(drt, frequencies, z_obs[mine], tau_supergrid=tau_supergrid, drt_var=drt_var, **kw)
+        nsup = obs_x.shape[1]
+        cols = [obs_x]
+        for key in special_keys:
+            val = obs_special.get(key)
+            cols.append(np.zeros((len(mine), 1)) if val is None else np.asarray(val, dtype=float).reshape(len(mine), -1)[:, :1])
         cols += [np.asarray(res[k], dtype=float)[:, None] for k in _GATHER_KEYS]
+        ti = res.get('obs_tau_indices', (0, nsup))
+        ti = np.array(ti, dtype=float) if isinstance(ti, list) else np.tile(np.array(ti, dtype=float), (len(mine), 1))
+        cols.append(ti)
         if drt_var:
             cols += [res['obs_drt_var'], np.asarray(res['obs_drt_var_ok'], dtype=float)[:, None]]
         packed = np.concatenate(cols, axis=1)
@@ -207,18 +371,25 @@ def fit_observations_sharded(drt, frequencies, z_obs, rank=None, world=None, tau
     order = np.concatenate(owned) if world > 1 else mine
     out = np.empty_like(full)
     out[order] = full                                    # back to the original observation order
-    # row = [obs_x (nsup) | R_inf | inductance | _GATHER_KEYS | obs_drt_var (nsup) | ok]  (the last two with drt_var)
-    nsup = (out.shape[1] - 2 - len(_GATHER_KEYS) - (1 if drt_var else 0)) // (2 if drt_var else 1)
+    # row = [obs_x (nsup) | specials | _GATHER_KEYS | left, right | obs_drt_var (nsup) | ok]  (the last two with drt_var)
+    fixed = len(special_keys) + len(_GATHER_KEYS) + 2 + (1 if drt_var else 0)
+    nsup = (out.shape[1] - fixed) // (2 if drt_var else 1)
     obs_x = out[:, :nsup]
     pos = nsup
-    obs_special = {'R_inf': out[:, pos], 'inductance': out[:, pos + 1]}
-    pos += 2
+    obs_special = {}
+    for key in special_keys:
+        obs_special[key] = out[:, pos]
+        pos += 1
     res = {}
     for k in _GATHER_KEYS:
         res[k] = out[:, pos] if k in ('obs_llh', 'obs_rss') else out[:, pos].astype(np.int64)
         pos += 1
+    res['obs_tau_indices'] = [(int(a_), int(b_)) for a_, b_ in out[:, pos:pos + 2]]
+    pos += 2
     if drt_var:
         res['obs_drt_var'] = out[:, pos:pos + nsup]
         res['obs_drt_var_ok'] = out[:, pos + nsup] > 0.5
     res['obs_fit_status'] = res['status'] >= 0
+    res['obs_fit_errors'] = [None if good else ValueError("Rank(A) < p or Rank([P; A; G]) < n") for good in res['obs_fit_status']]
+    _raise_first_error(res, ignore_errors)
     return obs_x, obs_special, res

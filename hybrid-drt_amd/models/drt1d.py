@@ -117,7 +117,28 @@ class DRT(PreparedFitMixin):
                                opts=opts, capacity=capacity)
         self._plan_key = key
         self.basis_tau = basis_tau
+        if getattr(self, '_luts_installed', False) and getattr(self, '_lut_key', None) == float(self.tau_epsilon):
+            (_, z_re), (_, z_im) = self._luts['z']          # tables received from another rank (install_lookup_tables)
+            self._plan.set_lookup(z_re, z_im)
         return self._plan
+
+    def lookup_tables(self):
+        """(z_re, z_im, response) ordinates of the three lookup tables of this instance's epsilon (drtbase.py:138-156),
+        built on the device (PreparedFitMixin._lookups)."""
+        ctx = self._context if self._context is not None else _ffi.get_context(self.device)
+        luts = self._lookups(ctx)
+        return luts['z'][0][1], luts['z'][1][1], luts['response'][1]
+
+    def install_lookup_tables(self, z_re, z_im, response):
+        """Use tables built elsewhere (rank 0 of a sharded map, mapping.share_lookup_tables) instead of building them:
+        prepared-matrix fits read them from here, EIS plans receive them right after they are created."""
+        td = np.logspace(-6, 2, 2000)
+        self._luts = dict(z=((np.log(self._wt_re), np.asarray(z_re, dtype=float)), (np.log(self._wt_im), np.asarray(z_im, dtype=float))),
+                          response=(np.log(td), np.asarray(response, dtype=float)))
+        self._lut_key = float(self.tau_epsilon)
+        self._luts_installed = True
+        if self._plan is not None and hasattr(self._plan, 'set_lookup'):
+            self._plan.set_lookup(z_re, z_im)
 
     def _make_opts(self, fit_kw):
         kw = dict(_FIT_KW_DEFAULTS)
@@ -320,18 +341,41 @@ class DRT(PreparedFitMixin):
                                                history_of=history_of))
         return out
 
-    def evaluate_obs_llh_rss_batch(self, marginalize_weights=True, alpha_0=2, beta_0=1):
-        """(DRT.evaluate_llh(), DRT.evaluate_rss()) with their default arguments (weights = the fit's est_weights, x = the
-        last iterate; drt1d.py:4433-4496) for every spectrum of the last fitted batch -- what DRTMD.fit_observation stores
-        as obs_llh / obs_rss (drtmd.py:259-260).  Residuals and both sums on the device."""
+    def evaluate_obs_llh_rss_batch(self, llh_kw=None, rss_kw=None):
+        """(DRT.evaluate_llh(**llh_kw), DRT.evaluate_rss(**rss_kw)) (drt1d.py:4433-4496; x = the last iterate) for every
+        spectrum of the last fitted batch -- what DRTMD.fit_observation stores as obs_llh / obs_rss (drtmd.py:259-260).
+        Keys as upstream: ``weights`` (None = the fit's est_weights, 'uniform' = per-domain means of them, a scalar),
+        ``normalize`` (divide by the number of data rows), and for the likelihood ``marginalize_weights``, ``alpha_0``,
+        ``beta_0``.  Residuals and all sums on the device."""
         from scipy.special import loggamma
-        rss, slw = self._plan.llh_terms(stored=True)
-        if marginalize_weights:
-            alpha_n = alpha_0 - 1 + self._plan.m / 2
-            llh = alpha_0 * np.log(beta_0) - alpha_n * np.log(beta_0 + 0.5 * rss) + loggamma(alpha_n) - loggamma(alpha_0)
+        llh_kw, rss_kw = dict(llh_kw or {}), dict(rss_kw or {})
+        bad = (set(llh_kw) - {'weights', 'normalize', 'marginalize_weights', 'alpha_0', 'beta_0', 'subtract_background'}) | \
+              (set(rss_kw) - {'weights', 'normalize'})
+        if bad:
+            raise TypeError(f"unexpected keyword(s) {sorted(bad)}")
+        m = self._plan.m
+        terms = {}
+
+        def sums(weights):
+            key = weights if (weights is None or isinstance(weights, str)) else float(weights)
+            if key not in terms:
+                terms[key] = self._plan.llh_terms(stored=True, weights=weights)
+            return terms[key]
+
+        rss_l, slw = sums(llh_kw.get('weights'))
+        alpha_0, beta_0 = llh_kw.get('alpha_0', 2), llh_kw.get('beta_0', 1)
+        if llh_kw.get('marginalize_weights', True):
+            alpha_n = alpha_0 - 1 + m / 2
+            llh = alpha_0 * np.log(beta_0) - alpha_n * np.log(beta_0 + 0.5 * rss_l) + loggamma(alpha_n) - loggamma(alpha_0)
         else:
-            llh = -0.5 * rss
-        return llh + slw, rss
+            llh = -0.5 * rss_l
+        llh = llh + slw
+        if llh_kw.get('normalize', False):
+            llh = llh / m
+        rss = sums(rss_kw.get('weights'))[0].copy()
+        if rss_kw.get('normalize', False):
+            rss /= m
+        return llh, rss
 
     def evaluate_step_llh_batch(self, alpha_0=2, beta_0=1):
         """evaluate_llh(weights=estimate_weights(x), x) (drt1d.py:2618-2622) for the current x of every spectrum of
@@ -396,7 +440,7 @@ class DRT(PreparedFitMixin):
             var, status = self._plan.distribution_var(bm, self._last_batch)
         if extend_var:
             if prepared:
-                pr = self._prep
+                pr = preps[0]                       # (the members of a prepared batch share their sampling grids)
                 t_left, t_right = pp.get_tau_lim(pr['frequencies'], pr.get('sample_times'), pr.get('nonconsec_step_times'))
             else:
                 t_left, t_right = 1 / (2 * np.pi * np.max(self.f_fit)), 1 / (2 * np.pi * np.min(self.f_fit))
@@ -428,18 +472,40 @@ class DRT(PreparedFitMixin):
 
     series_neg = False
 
-    def evaluate_rss(self, weights=None, x=None):
+    def _llh_weights(self, weights):
+        """the `weights` argument of evaluate_rss / evaluate_llh (drt1d.py:4434-4443, 4459-4472)"""
+        est = self.qphb_params['est_weights']
+        if weights is None:
+            return est
+        if isinstance(weights, str):
+            if weights != 'uniform':
+                raise ValueError(f"weights must be None, 'uniform', a scalar or an array, got {weights!r}")
+            nc = int(self.qphb_params.get('num_chrono', 0) or 0)
+            w = np.empty(len(est))
+            if nc:
+                w[:nc] = np.mean(est[:nc])
+            w[nc:] = np.mean(est[nc:])
+            return w
+        if np.isscalar(weights):
+            return np.ones_like(est) * weights
+        w = np.asarray(weights, dtype=float)
+        if w.shape != est.shape:
+            raise ValueError('Expected weights array of shape {}, but received shape {}'.format(est.shape, w.shape))
+        return w
+
+    def evaluate_rss(self, weights=None, x=None, normalize=False):
         """drt1d.evaluate_rss (drt1d.py:4433-4455) -> qphb.evaluate_rss (qphb.py:1347-1352)."""
-        w = self.qphb_params['est_weights'] if weights is None else np.asarray(weights, dtype=float)
+        w = self._llh_weights(weights)
         x = self.qphb_history[-1]['x'] if x is None else x
         rm, rv = self.qphb_params['rm'], self.qphb_params['rv']
         wrm, wrv = w[:, None] * rm, w * rv
-        return x @ wrm.T @ wrm @ x - 2 * wrv.T @ wrm @ x + wrv.T @ wrv
+        rss = x @ wrm.T @ wrm @ x - 2 * wrv.T @ wrm @ x + wrv.T @ wrv
+        return rss / len(rv) if normalize else rss
 
-    def evaluate_llh(self, weights=None, x=None, marginalize_weights=True, alpha_0=2, beta_0=1):
+    def evaluate_llh(self, weights=None, x=None, marginalize_weights=True, alpha_0=2, beta_0=1, normalize=False):
         """drt1d.evaluate_llh (drt1d.py:4457-4496) -> qphb.evaluate_llh (qphb.py:1355-1377)."""
         from scipy.special import loggamma
-        w = self.qphb_params['est_weights'] if weights is None else np.asarray(weights, dtype=float)
+        w = self._llh_weights(weights)
         rss = self.evaluate_rss(w, x)
         if marginalize_weights:
             alpha_n = alpha_0 - 1 + len(w) / 2
@@ -447,7 +513,8 @@ class DRT(PreparedFitMixin):
             llh = alpha_0 * np.log(beta_0) - alpha_n * np.log(beta_n) + loggamma(alpha_n) - loggamma(alpha_0)
         else:
             llh = -0.5 * rss
-        return llh + np.sum(np.log(w))
+        llh = llh + np.sum(np.log(w))
+        return llh / len(w) if normalize else llh
 
     def _fit(self, frequencies, z_batch, kw, history_of):
         self.stage_batch(frequencies, z_batch, history_of=history_of, **kw)

@@ -258,6 +258,15 @@ int hipdrt_plan_llh_terms(hipdrt_plan* plan, double* rss, double* sum_log_w);
  * DRT.evaluate_llh() with their default arguments (hybdrt/models/drt1d.py:4433-4496), which DRTMD.fit_observation
  * records for every observation as obs_rss / obs_llh (hybdrt/mapping/drtmd.py:259-260).                              */
 int hipdrt_plan_obs_llh_terms(hipdrt_plan* plan, double* rss, double* sum_log_w);
+/* The same two sums for the other forms of the `weights` argument of DRT.evaluate_rss / evaluate_llh
+ * (hybdrt/models/drt1d.py:4434-4443, 4459-4472): HIPDRT_LLH_W_EST = None (the fit's est_weights, as above),
+ * HIPDRT_LLH_W_UNIFORM = "uniform" (within each domain -- chrono rows, impedance rows -- every weight is the mean of that
+ * domain's est_weights: DRTMD's default llh_kw / rss_kw, hybdrt/mapping/drtmd.py:129-131), HIPDRT_LLH_W_SCALAR = one scalar
+ * weight for every row.  `normalize=True` (division by the number of rows) is left to the caller.                     */
+#define HIPDRT_LLH_W_EST 1
+#define HIPDRT_LLH_W_UNIFORM 2
+#define HIPDRT_LLH_W_SCALAR 3
+int hipdrt_plan_obs_llh_terms_w(hipdrt_plan* plan, int weights_mode, double scalar_weight, double* rss, double* sum_log_w);
 
 /* Overwrite parts of the fitted batch's state on the device (NULL = keep): x[B][n] (also becomes the previous iterate),
  * rho[B][3], s[B][3][n], weights[B][m].  The inputs of drt1d._continue_from_init (x_init, rho_vector, s_vectors, weights). */

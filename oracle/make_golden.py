@@ -453,6 +453,46 @@ def run_resolve_group(cvxopt, name, n_obs=16, batch_size=7, overlap=2):
     print(f"resolve_group_{name}: {n_obs} obs, {len(log)} batches, qp iterations {out['qp_iterations'].tolist()}")
 
 
+def mixed_map_observations(n_obs=16):
+    """The 16-observation map of the heterogeneous batch-driver test (tests/test_gpu_mapping.py), as DRTMD.add_observation
+    takes it: (chrono_data | None, eis_data) per observation.  Three groups, interleaved: joint chrono + EIS measurements
+    (k % 3 == 0), impedance spectra on a 41-point grid 1e5 .. 1 Hz (k % 3 == 1) and on a 36-point grid 1e4 .. 0.1 Hz
+    (k % 3 == 2): different data types, different frequency ranges, hence different slices of the tau supergrid."""
+    from hipdrt import synth
+    fa, fb = np.logspace(5, 0, 41), np.logspace(4, -1, 36)
+    obs = []
+    for k in range(n_obs):
+        if k % 3 == 0:
+            m = synth.hybrid_measurement(seed=200 + k, jitter=True, n_post=100, nf=31)
+            obs.append(((m[0], m[1], m[2]), (m[3], m[4])))
+        else:
+            f = fa if k % 3 == 1 else fb
+            obs.append((None, (f, synth.zarc2_spectrum(f, 300 + k, jitter=True))))
+    return obs
+
+
+def run_drtmd_mixed(n_obs=16):
+    """the reference's own DRTMD (mapping/drtmd.py:186-329, 1136-1158) on a map that mixes data types and frequency ranges:
+    what fit_all records per observation -- obs_x in supergrid slots, every special parameter, obs_llh / obs_rss (with
+    DRTMD's default llh_kw / rss_kw: weights='uniform', normalize=True), obs_tau_indices, obs_drt_var."""
+    from hybdrt.mapping.drtmd import DRTMD
+    sup = np.logspace(-8, 4, 121)
+    obs = mixed_map_observations(n_obs)
+    with _quiet():
+        dmd = DRTMD(tau_supergrid=sup, psi_dim_names=['T'], print_progress=False, warn=False)
+        for k, (chrono, eis) in enumerate(obs):
+            dmd.add_observation(np.array([float(k)]), chrono, eis, group_id='g')
+        dmd.fit_all()
+    assert dmd.obs_fit_status.all()
+    out = dict(n_obs=n_obs, tau_supergrid=sup, obs_x=dmd.obs_x, obs_llh=dmd.obs_llh, obs_rss=dmd.obs_rss,
+               obs_tau_indices=np.array(dmd.obs_tau_indices), obs_drt_var=dmd.obs_drt_var,
+               special_names=np.array(list(dmd.obs_special.keys())))
+    for key, val in dmd.obs_special.items():
+        out["special_" + key] = np.asarray(val)
+    np.savez_compressed(os.path.join(OUT, "refrun_drtmd_mixed16.npz"), **out)
+    print(f"drtmd_mixed16: {n_obs} obs, specials {list(dmd.obs_special)}, tau slices {sorted(set(map(tuple, dmd.obs_tau_indices)))}")
+
+
 DECIMATE_CASES = [     # (record, keywords of preprocessing.downsample_data)
     ("one_step", dict(method='decimate', prestep_samples=10)),
     ("one_step", dict(method='decimate', prestep_samples=7, decimation_interval=25, decimation_factor=1.5)),
@@ -557,6 +597,10 @@ def main():
         run_resolve(DRT, cvxopt, "hybrid7_dop", True)
         run_resolve_group(cvxopt, "hybrid16")
         return
+    if "--only-drtmd" in sys.argv:
+        _boot_reference()
+        run_drtmd_mixed()
+        return
     if "--only-hybrid" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()
         DRT, cvxopt = _boot_reference()
@@ -627,6 +671,7 @@ def main():
     run_resolve(DRT, cvxopt, "hybrid7", False)
     run_resolve(DRT, cvxopt, "hybrid7_dop", True)
     run_resolve_group(cvxopt, "hybrid16")
+    run_drtmd_mixed()
     # (12) evaluation of fitted models
     # (13) Kramers-Kronig test
     # (14) progressive decimation of raw chrono records

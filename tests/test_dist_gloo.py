@@ -51,9 +51,25 @@ def test_sharded_batch_plumbing_world2():
     mp.spawn(_worker, args=(2, port, 7), nprocs=2, join=True)
 
 
-def _fake_fit(drt, frequencies, z_obs, tau_supergrid=None, drt_var=False, **kw):
+def _fake_fit(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_var=False, observations=None, **kw):
     """stand-in for mapping.fit_observations with the same return structure: every output is a deterministic function of
     the observation's own data, so the gathered result can be checked against a single-process evaluation"""
+    if observations is not None:
+        # heterogeneous form: (chrono_data | None, (frequencies, z)); spectra of different lengths -> different tau slices
+        num, nsup = len(observations), 12
+        obs_x = np.zeros((num, nsup))
+        ti, rinf, vb = [], np.zeros(num), np.zeros(num)
+        for k, (chrono, (f, z)) in enumerate(observations):
+            left = len(f) % 3
+            obs_x[k, left:left + 8] = z.real.sum() * np.arange(1.0, 9.0)
+            ti.append((left, left + 8))
+            rinf[k] = z.real[0]
+            vb[k] = 0.0 if chrono is None else float(np.sum(chrono[2]))
+        zs = np.array([z.sum() for _, (f, z) in observations])
+        res = {"obs_llh": -np.abs(zs), "obs_rss": np.abs(zs) ** 2,
+               "outer_iters": np.array([len(f) + int(chrono is not None) for chrono, (f, z) in observations]) % 5 + 2,
+               "qp_iters_total": np.arange(num) * 0 + 7, "status": np.zeros(num, dtype=np.int64), "obs_tau_indices": ti}
+        return obs_x, {"v_baseline": vb, "vz_offset": vb * 0.5, "R_inf": rinf, "inductance": rinf * 2}, res
     num, nsup = z_obs.shape[0], 12
     obs_x = np.outer(z_obs.real.sum(1), np.arange(1.0, nsup + 1))
     special = {"R_inf": z_obs.real[:, 0].copy(), "inductance": z_obs.imag[:, -1].copy()}
@@ -91,6 +107,44 @@ def _sharded_worker(rank, world, port, total, scheme, drt_var):
         assert out is None
     hd.barrier()
     dist.destroy_process_group()
+
+
+def _sharded_general_worker(rank, world, port, total):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from hipdrt import synth
+    from hipdrt.mapping import dist as hd
+    from hipdrt.mapping.drtmd import fit_observations_sharded
+    hd.init_from_env(backend="gloo")
+    obs = []
+    for k in range(total):
+        f = np.logspace(3, 0, 14 + k % 3)
+        z = synth.zarc2_spectrum(f, k)
+        obs.append(((np.arange(5.0), np.ones(5), np.arange(5.0) * (k + 1)) if k % 4 == 0 else None, (f, z)))
+    out = fit_observations_sharded(None, observations=obs, tau_supergrid=np.logspace(-3, 1, 12), fit=_fake_fit)
+    if rank == 0:
+        obs_x, special, res = out
+        ex, es, er = _fake_fit(None, observations=obs)
+        np.testing.assert_array_equal(obs_x, ex)
+        assert set(special) == set(es)
+        for k in es:
+            np.testing.assert_array_equal(special[k], es[k])
+        for k in ("obs_llh", "obs_rss", "outer_iters", "qp_iters_total", "status"):
+            np.testing.assert_array_equal(res[k], er[k], err_msg=k)
+        assert res["obs_tau_indices"] == er["obs_tau_indices"]
+    else:
+        assert out is None
+    hd.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_observations_sharded_world2_heterogeneous_observations():
+    """the observation-list form (any mix of data types and grids) through the sharded driver: per-observation tau slices
+    and the union of the special parameters travel through the one gather"""
+    mp.spawn(_sharded_general_worker, args=(2, _free_port(), 11), nprocs=2, join=True)
 
 
 def test_fit_observations_sharded_world2_every_scheme():

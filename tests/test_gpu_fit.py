@@ -196,15 +196,25 @@ def test_fit_observations_records_what_drtmd_records():
     one = DRT(tau_supergrid=supergrid)
     for b in (0, 5):
         one.fit_eis(freq, z[b])
-        assert res["obs_llh"][b] == pytest.approx(one.evaluate_llh(), rel=1e-9)
-        assert res["obs_rss"][b] == pytest.approx(one.evaluate_rss(), rel=1e-9)
+        # DRTMD's defaults (drtmd.py:121-134): weights='uniform', normalize=True on both
+        assert res["obs_llh"][b] == pytest.approx(one.evaluate_llh(weights='uniform', normalize=True), rel=1e-9)
+        assert res["obs_rss"][b] == pytest.approx(one.evaluate_rss(weights='uniform', normalize=True), rel=1e-9)
+    # the other forms of the metric keywords (DRT.evaluate_llh / evaluate_rss arguments), device sums vs the host mirror
+    _, _, res2 = fit_observations(drt, freq, z, tau_supergrid=supergrid, llh_kw=dict(weights=None, normalize=False),
+                                  rss_kw=dict(weights=0.5, normalize=False))
+    one.fit_eis(freq, z[3])
+    assert res2["obs_llh"][3] == pytest.approx(one.evaluate_llh(), rel=1e-9)
+    assert res2["obs_rss"][3] == pytest.approx(one.evaluate_rss(weights=0.5), rel=1e-9)
+    with pytest.raises(TypeError):
+        fit_observations(drt, freq, z, tau_supergrid=supergrid, llh_kw=dict(wieghts=None))
     zbad = z.copy()
     zbad[2] = np.nan
-    obs_x, obs_special, res = fit_observations(drt, freq, zbad, tau_supergrid=supergrid)
+    obs_x, obs_special, res = fit_observations(drt, freq, zbad, tau_supergrid=supergrid, drt_var=True, ignore_errors=True)
     assert res["obs_fit_status"].tolist() == [True, True, False, True, True, True]
     assert isinstance(res["obs_fit_errors"][2], ValueError) and not obs_x[2].any() and res["obs_llh"][2] == 0
-    with pytest.raises(ValueError):
-        fit_observations(drt, freq, zbad, tau_supergrid=supergrid, ignore_errors=False)
+    assert not res["obs_drt_var"][2].any() and not res["obs_drt_var_ok"][2]      # (the reference leaves zeros)
+    with pytest.raises(ValueError):                # upstream default (drtmd.py:245): the first failed observation raises
+        fit_observations(drt, freq, zbad, tau_supergrid=supergrid)
 
 
 def test_fit_observations_in_flight_is_the_same_fit():
@@ -218,8 +228,8 @@ def test_fit_observations_in_flight_is_the_same_fit():
     z[7] = np.nan
     supergrid = np.logspace(-9, 3, 121)
     drt = DRT(tau_supergrid=supergrid)
-    x1, sp1, r1 = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True)
-    x3, sp3, r3 = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True, inflight=3)
+    x1, sp1, r1 = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True, ignore_errors=True)
+    x3, sp3, r3 = fit_observations(drt, freq, z, tau_supergrid=supergrid, drt_var=True, inflight=3, ignore_errors=True)
     from hipdrt.mapping.drtmd import drt_siblings
     assert len(drt._sibling_clones) == 2 and drt_siblings(drt, 3)[0] is drt
     np.testing.assert_array_equal(x1, x3)
@@ -234,7 +244,7 @@ def test_fit_observations_in_flight_is_the_same_fit():
         fit_observations(drt, freq, z, tau_supergrid=supergrid, ignore_errors=False, inflight=3)
     # second call: the sibling plans are reused
     plans = [d._plan for d in drt_siblings(drt, 3)]
-    fit_observations(drt, freq, z, tau_supergrid=supergrid, inflight=3)
+    fit_observations(drt, freq, z, tau_supergrid=supergrid, inflight=3, ignore_errors=True)
     assert [d._plan for d in drt_siblings(drt, 3)] == plans
 
 

@@ -1,0 +1,102 @@
+"""The batch driver on a heterogeneous map: DRTMD.fit_observations (hybdrt/mapping/drtmd.py:245-319) fits any
+mix of EIS / chrono / joint observations, each on its own frequency range and its own slice of the tau supergrid.  The fixture
+tests/golden/refrun_drtmd_mixed16.npz is the REFERENCE's own DRTMD run (oracle/make_golden.py: run_drtmd_mixed) on the
+16-observation map rebuilt below from the same seeds."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def mixed_map_observations(n_obs=16):
+    """as oracle/make_golden.py: mixed_map_observations (the fixture's inputs; hipdrt.synth is seeded)"""
+    from hipdrt import synth
+    fa, fb = np.logspace(5, 0, 41), np.logspace(4, -1, 36)
+    obs = []
+    for k in range(n_obs):
+        if k % 3 == 0:
+            m = synth.hybrid_measurement(seed=200 + k, jitter=True, n_post=100, nf=31)
+            obs.append(((m[0], m[1], m[2]), (m[3], m[4])))
+        else:
+            f = fa if k % 3 == 1 else fb
+            obs.append((None, (f, synth.zarc2_spectrum(f, 300 + k, jitter=True))))
+    return obs
+
+
+def _check_against_reference(g, obs_x, obs_special, res, drt_var):
+    peak = np.abs(g["obs_x"]).max(axis=1, keepdims=True)
+    np.testing.assert_allclose(obs_x / peak, g["obs_x"] / peak, rtol=0, atol=2e-6)
+    assert [tuple(t) for t in res["obs_tau_indices"]] == [tuple(t) for t in g["obs_tau_indices"].tolist()]
+    assert set(obs_special) == set(str(k) for k in g["special_names"])
+    for key in obs_special:
+        ref = g["special_" + key].reshape(len(obs_x), -1)[:, 0]
+        np.testing.assert_allclose(np.asarray(obs_special[key]).reshape(len(obs_x), -1)[:, 0], ref, rtol=2e-5,
+                                   atol=2e-6 * max(np.abs(ref).max(), 1e-300), err_msg=key)
+    # DRTMD's default metrics: weights='uniform', normalize=True (drtmd.py:121-134)
+    np.testing.assert_allclose(res["obs_llh"], g["obs_llh"], rtol=1e-5)
+    np.testing.assert_allclose(res["obs_rss"], g["obs_rss"], rtol=1e-4)
+    if drt_var:
+        vmax = g["obs_drt_var"].max(axis=1, keepdims=True)
+        np.testing.assert_allclose(res["obs_drt_var"] / vmax, g["obs_drt_var"] / vmax, rtol=0, atol=1e-4)
+
+
+def test_mixed_map_matches_the_reference_drtmd():
+    """16 observations, three groups (joint chrono + EIS; EIS on 1e5..1 Hz; EIS on 1e4..0.1 Hz), interleaved: grouped on the
+    host, one device plan per group, scattered into each observation's own supergrid slice"""
+    from hipdrt.mapping import fit_observations
+    from hipdrt.mapping.drtmd import observation_groups
+    from hipdrt.models import DRT
+    g = np.load(os.path.join(GOLDEN, "refrun_drtmd_mixed16.npz"))
+    obs = mixed_map_observations(int(g["n_obs"]))
+    groups = observation_groups(obs)
+    assert [kind for kind, _ in groups] == ["hybrid", "eis", "eis"] and [len(i) for _, i in groups] == [6, 5, 5]
+    drt = DRT(tau_supergrid=g["tau_supergrid"], warn=False)
+    obs_x, obs_special, res = fit_observations(drt, observations=obs, tau_supergrid=g["tau_supergrid"], drt_var=True, nonneg=True)
+    assert res["obs_fit_status"].all() and len(res["groups"]) == 3
+    assert len({tuple(t) for t in res["obs_tau_indices"]}) == 3          # three different slices of the supergrid
+    _check_against_reference(g, obs_x, obs_special, res, drt_var=True)
+
+
+def test_mixed_map_through_the_sharded_driver():
+    """the same map through fit_observations_sharded (world 1 = what every rank of a node runs on its shard): identical to
+    the direct call"""
+    from hipdrt.mapping import fit_observations, fit_observations_sharded
+    from hipdrt.models import DRT
+    g = np.load(os.path.join(GOLDEN, "refrun_drtmd_mixed16.npz"))
+    obs = mixed_map_observations(int(g["n_obs"]))
+    drt = DRT(tau_supergrid=g["tau_supergrid"], warn=False)
+    direct = fit_observations(drt, observations=obs, tau_supergrid=g["tau_supergrid"], nonneg=True)
+    obs_x, obs_special, res = fit_observations_sharded(DRT(tau_supergrid=g["tau_supergrid"], warn=False), observations=obs,
+                                                       rank=0, world=1, tau_supergrid=g["tau_supergrid"], nonneg=True)
+    np.testing.assert_array_equal(obs_x, direct[0])
+    for key in direct[1]:
+        np.testing.assert_array_equal(obs_special[key], np.asarray(direct[1][key]).reshape(len(obs), -1)[:, 0], err_msg=key)
+    for key in ("obs_llh", "obs_rss", "outer_iters", "status"):
+        np.testing.assert_array_equal(res[key], direct[2][key], err_msg=key)
+    assert res["obs_tau_indices"] == direct[2]["obs_tau_indices"]
+    _check_against_reference(g, obs_x, obs_special, res, drt_var=False)
+
+
+def test_lookup_tables_travel_between_instances():
+    """share_lookup_tables' two halves on one rank: tables taken from one DRT (lookup_tables) and installed into another
+    (install_lookup_tables) give bit-identical fits, for an EIS plan and for a prepared-matrix plan"""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    freq = np.logspace(5, 0, 41)
+    z = synth.zarc2_batch(freq, 3, first_seed=40)
+    a = DRT(warn=False)
+    ra = a.fit_eis_batch(freq, z)
+    b = DRT(warn=False)
+    b.install_lookup_tables(*a.lookup_tables())
+    rb = b.fit_eis_batch(freq, z)
+    np.testing.assert_array_equal(ra["x"], rb["x"])
+    m = synth.hybrid_measurement(seed=3, n_post=100, nf=31)
+    fa = DRT(warn=False).fit_hybrid(*m)
+    c = DRT(warn=False)
+    c.install_lookup_tables(*a.lookup_tables())
+    fc = c.fit_hybrid(*m)
+    np.testing.assert_array_equal(fa["x"], fc["x"])

@@ -74,11 +74,11 @@ def test_inflight_error_capture_and_reraising(monkeypatch):
     freq = np.logspace(3, 0, 9)
     z = _data(12)
     z[7] = np.nan                                                  # falls into the second chunk
-    obs_x, special, res = drtmd.fit_observations(fakes[0], freq, z, inflight=3)
+    obs_x, special, res = drtmd.fit_observations(fakes[0], freq, z, inflight=3, ignore_errors=True)
     assert res["obs_fit_status"].tolist() == [True] * 7 + [False] + [True] * 4
     assert isinstance(res["obs_fit_errors"][7], ValueError) and not obs_x[7].any()
-    with pytest.raises(ValueError):
-        drtmd.fit_observations(fakes[0], freq, z, inflight=3, ignore_errors=False)
+    with pytest.raises(ValueError):                # the reference's default (drtmd.py:245): raise at the first failure
+        drtmd.fit_observations(fakes[0], freq, z, inflight=3)
 
     class Boom(_FakeDRT):
         def fit_eis_batch(self, *a, **k):

@@ -41,7 +41,8 @@ struct hipdrt_plan {
     // per spectrum
     DevBuf z_re, z_im, rv, w, est_w, x, x_in, q, s, rho, xmx, coef_scale, var_floor;
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
-    DevBuf L, Ptmp, qpstate, Ppk, order, vmm_base;
+    DevBuf L, Ptmp, qpstate, Ppk, order, vmm_base, gsync;
+    int qp_G = 0;           // workgroups per QP (qp_group_size at the plan's capacity): 0 = the batch kernel
     // history
     int hist_b = -1, hist_cap = 0;
     DevBuf hist_x, hist_w, hist_rho, hist_qp, hist_rows;
@@ -432,11 +433,12 @@ static hipdrt_qp_opts default_qp_opts() { return hipdrt_qp_opts{1e-7, 1e-6, 1e-7
 int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* P, const double* q, int h_batched,
                     const double* h, const hipdrt_qp_opts* opts, double* x, int* iters, double* pcost, int* status) {
     HIPDRT_REQUIRE(ctx && P && q && h && x && status, "NULL pointer");
-    HIPDRT_REQUIRE(B >= 1 && n >= 1 && n <= 2048, "B >= 1, 1 <= n <= 2048");
+    HIPDRT_REQUIRE(B >= 1 && n >= 1 && n <= 4096, "B >= 1, 1 <= n <= 4096");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     hipStream_t st = ctx->stream;
-    DevBuf dP, dq, dh, dL, dx, dit, dpc, dst, dstate, dPpk;
+    DevBuf dP, dq, dh, dL, dx, dit, dpc, dst, dstate, dPpk, dgs;
     const int ldl = (int)qp_scratch_ld(n);
+    const int G = qp_group_size(B, n);           // 0: one workgroup per problem; >= 1: that many workgroups per problem
     // device copy of P with an even leading dimension (16-byte row-pair loads in the kernels), pad column zeroed
     const int ldp = round_up(n, 2);
     const size_t nmat = (size_t)(p_batched ? B : 1);
@@ -446,7 +448,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
                                   (size_t)n * sizeof(double), nmat * n, hipMemcpyHostToDevice, st));
     TRY(upload(dq, q, (size_t)B * n * sizeof(double), st));
     TRY(upload(dh, h, (size_t)(h_batched ? B : 1) * n * sizeof(double), st));
-    HIPDRT_CHECK(dL.alloc((size_t)B * qp_scratch_doubles(n) * sizeof(double)));
+    HIPDRT_CHECK(dL.alloc((size_t)B * qp_scratch_doubles(n, G) * sizeof(double)));
     HIPDRT_CHECK(dx.alloc((size_t)B * n * sizeof(double)));
     HIPDRT_CHECK(dit.alloc((size_t)B * sizeof(int)));
     HIPDRT_CHECK(dpc.alloc((size_t)B * sizeof(double)));
@@ -454,13 +456,18 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     QpArgs a{};
     a.B = B; a.n = n; a.P = dP.d(); a.p_stride = p_batched ? (long long)n * ldp : 0; a.ldp = ldp;
     a.q = dq.d(); a.h = dh.d(); a.h_stride = h_batched ? n : 0;
-    a.L = dL.d(); a.ldl = ldl; a.l_stride = (long long)qp_scratch_doubles(n);
+    a.L = dL.d(); a.ldl = ldl; a.l_stride = (long long)qp_scratch_doubles(n, G);
     a.x = dx.d(); a.iters = dit.i(); a.pcost = dpc.d(); a.status = dst.i();
     a.active = nullptr; a.iters_accum = nullptr;
+    a.G = G;
+    if (G >= 1) {
+        HIPDRT_CHECK(dgs.alloc((size_t)B * qp_gsync_ints() * sizeof(int)));
+        a.gsync = dgs.i();
+    }
     HIPDRT_CHECK(dPpk.alloc(nmat * qp_ppk_doubles(n) * sizeof(double)));
     launch_pack_p(st, (int)nmat, n, dP.d(), ldp, (long long)n * ldp, dPpk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
     a.Ppk = dPpk.d(); a.ppk_stride = p_batched ? (long long)qp_ppk_doubles(n) : 0; a.nchp = qp_nchp(n);
-    HIPDRT_CHECK(dstate.alloc((size_t)B * qp_state_doubles(n) * sizeof(double)));
+    HIPDRT_CHECK(dstate.alloc((size_t)B * (G > 1 ? G : 1) * qp_state_doubles(n) * sizeof(double)));
     a.state = dstate.d(); a.state_ld = qp_state_ld(n); a.state_stride = (long long)qp_state_doubles(n);
     a.opts = opts ? *opts : default_qp_opts();
     TRY(launch_qp(st, a));
@@ -469,6 +476,11 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     if (pcost) HIPDRT_CHECK(hipMemcpyAsync(pcost, dpc.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipMemcpyAsync(status, dst.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+int hipdrt_debug_qp_group(int members) {
+    qp_debug_force_group(members);
     return HIPDRT_OK;
 }
 
@@ -569,9 +581,12 @@ static int plan_alloc_batch(hipdrt_plan* p) {
     for (DevBuf* ib : {&p->active, &p->outer_iters, &p->fit_status, &p->qp_iters_total, &p->qp_status, &p->qp_iters})
         HIPDRT_CHECK(ib->alloc(cap * sizeof(int)));
     HIPDRT_CHECK(p->n_active.alloc(sizeof(int)));
-    HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n) * sizeof(double)));
+    p->qp_G = qp_group_size(p->capacity, n);
+    HIPDRT_REQUIRE(p->qp_G >= 0, "n too large for the QP kernels");
+    HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n, p->qp_G) * sizeof(double)));
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
-    HIPDRT_CHECK(p->qpstate.alloc(cap * qp_state_doubles(n) * sizeof(double)));
+    HIPDRT_CHECK(p->qpstate.alloc(cap * (p->qp_G > 1 ? p->qp_G : 1) * qp_state_doubles(n) * sizeof(double)));
+    if (p->qp_G >= 1) HIPDRT_CHECK(p->gsync.alloc(cap * qp_gsync_ints() * sizeof(int)));
     HIPDRT_CHECK(p->Ppk.alloc(cap * qp_ppk_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->order.alloc(cap * sizeof(int)));
     if (p->opts.outlier_p > 0.0) {
@@ -605,7 +620,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     if (p->opts.fit_inductance) p->idx_induc = ns++;
     p->ns = ns; p->n = ns + ntau; p->m = 2 * nf;
     const int n = p->n, m = p->m;
-    HIPDRT_REQUIRE(n <= 2048, "ns + ntau <= 2048");
+    HIPDRT_REQUIRE(n <= 4096, "ns + ntau <= 4096");
     p->ldrm = round_up(n, 2); p->ldm = round_up(n, 2); p->ldp = round_up(n, 2); p->ldl = (int)qp_scratch_ld(n);
 
     std::vector<double> ln_tau(ntau);
@@ -661,7 +676,7 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, 
                                 const double* vz_strength, const hipdrt_fit_opts* opts, int capacity, hipdrt_plan** out) {
     HIPDRT_REQUIRE(ctx && d && m0 && m1 && m2 && vmm && h && l1 && out, "NULL pointer");
     HIPDRT_REQUIRE(d->m >= 2 && d->n >= 2 && d->ns >= 0 && d->ns < d->n && capacity >= 1, "m, n >= 2, 0 <= ns < n, capacity >= 1");
-    HIPDRT_REQUIRE(d->n <= 2048, "n <= 2048");
+    HIPDRT_REQUIRE(d->n <= 4096, "n <= 4096");
     HIPDRT_REQUIRE(d->dop_size >= 0 && (d->dop_size == 0 || (d->dop_start >= 0 && d->dop_start + d->dop_size <= d->ns)),
                    "the x_dop block must lie inside the special parameters");
     HIPDRT_REQUIRE(d->dop_size <= d->n - d->ns, "x_dop block larger than the DRT block");
@@ -896,7 +911,8 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
 
     QpArgs qa{};
     qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
-    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n);
+    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n, p->qp_G);
+    qa.G = p->qp_G; qa.gsync = p->gsync.i();
     qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
     qa.iters_accum = p->qp_iters_total.i(); qa.opts = p->opts.qp;
     qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);
@@ -1080,7 +1096,8 @@ static QpArgs loop_qp_args(hipdrt_plan* p, const hipdrt_qp_opts& qpo) {
     const int n = p->n;
     QpArgs qa{};
     qa.B = p->B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
-    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n);
+    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n, p->qp_G);
+    qa.G = p->qp_G; qa.gsync = p->gsync.i();
     qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
     qa.iters_accum = p->qp_iters_total.i(); qa.opts = qpo;
     qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);

@@ -217,12 +217,22 @@ struct QpArgs {
     const int* active;    // [B] or null: skip problems with active[b]==0
     const int* order = nullptr;   // [B] or null: workgroup i solves problem order[i] (longest-first dispatch)
     int* iters_accum;     // [B] or null: += iterations
-    double* state;        // scratch [B][17][state_ld] for the IPM iterates
+    double* state;        // scratch [B * max(G, 1)][17][state_ld] for the IPM iterates (one copy per member of a group)
     int state_ld;
     long long state_stride;
     hipdrt_qp_opts opts;
+    // G >= 1: the group kernel (qp_group.hpp), every problem on G co-resident workgroups (qp_group_size picks G when the
+    // buffers are sized); 0: the batch kernel, one workgroup per problem
+    int G = 0;
+    int* gsync = nullptr; // [B][qp_gsync_ints()] global sync words of the groups (zeroed by the launcher)
+    int redo_aborted = 0; // group kernel: only the problems whose status is HIPDRT_QP_ABORTED (second pass of launch_qp)
 };
 int launch_qp(hipStream_t st, const QpArgs& a);
+// workgroups per problem for a launch of B problems of n unknowns: 0 = batch kernel (one workgroup per problem, n <= 2048),
+// >= 1 = group kernel with that many members (few problems, or n > 2048); -1 = n not supported
+int qp_group_size(int B, int n);
+void qp_debug_force_group(int members);
+size_t qp_gsync_ints();
 // posterior variance on an evaluation grid (qp_resident.hpp: cov_kernel_resident); Bex = evaluation rows as packed tiles
 int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long ppk_stride, const double* Bex, int nex,
                     double* L, long long l_stride, double* out, long long out_stride, int* status);
@@ -232,7 +242,7 @@ void launch_pack_rows(hipStream_t st, int nrow, int ncol, int col_offset, const 
 // order[] = problem indices sorted by descending iteration count of the previous solve (inactive ones last)
 void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active, int* order);
 size_t qp_scratch_ld(int n);
-size_t qp_scratch_doubles(int n);
+size_t qp_scratch_doubles(int n, int G = 0);
 inline int qp_state_ld(int n) { return round_up(n, 32) + 32; }
 inline size_t qp_state_doubles(int n) { return (size_t)17 * qp_state_ld(n); }
 int qp_profile_read(unsigned long long* out, int n, int reset);

@@ -13,13 +13,56 @@
 
 #include "qp_common.hpp"
 #include "qp_resident.hpp"
+#include "qp_group.hpp"
 
 namespace hipdrt {
 
 size_t qp_scratch_ld(int n) { return (size_t)round_up(n, 16); }
 
 // doubles of factor scratch per problem: the tile-packed factor, beyond n = 528 followed by the inverse diagonal blocks
-size_t qp_scratch_doubles(int n) { return n <= RNP_MAX ? resident_l_doubles(n) : resident_gu_doubles(n); }
+// (group kernel: one copy of those per member)
+size_t qp_scratch_doubles(int n, int G) {
+    if (G >= 1) return group_scratch_doubles(n, G);
+    return n <= RNP_MAX ? resident_l_doubles(n) : resident_gu_doubles(n);
+}
+size_t qp_gsync_ints() { return GRP_WORDS; }
+
+static int device_cus() {
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return cus;
+}
+
+// One problem per workgroup keeps the chip full from a few hundred problems on.  Below that -- a single spectrum, one joint
+// fit, the handful of coupled QPs of resolve_group -- most CUs would idle, and beyond n = 2048 the one-workgroup kernel does
+// not reach: such launches go to the group kernel.  Members per problem: one per two block rows (a member's fixed cost is
+// its redundant chain wavefront; the look-ahead tiles are accumulated by one member per block column), all members of a
+// problem on one XCD (32 CUs) with up to eight problems side by side.
+static int g_force_group = -1;           // hipdrt_debug_qp_group (tests)
+void qp_debug_force_group(int members) { g_force_group = members; }
+
+int qp_group_size(int B, int n) {
+    if (n > GRP_NMAX) return -1;
+    if (g_force_group == 0 && n <= 2048) return 0;
+    if (g_force_group >= 1) {
+        int G = g_force_group;
+        const int ntr = (n + 15) / 16, rounds = (B + 7) / 8;
+        if (G > 32 / rounds) G = 32 / rounds;
+        if (G > ntr / 2) G = ntr / 2;        // (at least one block row per member)
+        return G >= 1 ? G : 1;
+    }
+    const bool few = B * 16 <= device_cus();              // <= 16 problems on a 256-CU part
+    if (n <= 2048 && !(few && n > 256)) return 0;       // (small n: a block column is all chain, nothing to share)
+    const int ntr = (n + 15) / 16, rounds = (B + 7) / 8;
+    int G = ntr / 4;                                       // two block rows (pairs of tile rows) per member
+    if (G > 32 / rounds) G = 32 / rounds;
+    if (G > GRP_MAXG) G = GRP_MAXG;
+    return G >= 2 ? G : 1;
+}
 
 int qp_profile_read(unsigned long long* out, int n, int reset) {
 #ifdef HIPDRT_QP_PROFILE
@@ -127,9 +170,69 @@ int qp_occupancy(int threads, int n) {
     return e == hipSuccess ? nb : -1;
 }
 
+// The group kernel's members wait for each other, so a group launch must become fully resident.  Two group launches from
+// different streams could each occupy part of the CUs and wait for the rest: they are chained through one event per device
+// (stream-ordered; other kernels still overlap freely).  Every wait inside the kernel is bounded on top of that.
+static int launch_qp_group(hipStream_t st, const QpArgs& a, int G) {
+    const int NP = round_up(a.n, 32);
+    if (!a.Ppk || !a.gsync) { set_error("qp group: packed copy of P or sync words missing"); return HIPDRT_E_INVALID; }
+    const size_t lds = group_lds_bytes(NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_group), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(qp group): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    e = hipMemsetAsync(a.gsync, 0, (size_t)a.B * GRP_WORDS * sizeof(int), st);
+    if (e != hipSuccess) { set_error(std::string("qp group sync reset: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    const int blocks = 8 * G * ((a.B + 7) / 8);
+    static std::mutex mtx;
+    static hipEvent_t last[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mtx);
+    hipEvent_t& ev = last[dev & 63];
+    if (G > 1) {
+        if (ev) {
+            e = hipStreamWaitEvent(st, ev, 0);
+            if (e != hipSuccess) { set_error(std::string("qp group chain: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+        } else {
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) { ev = nullptr; set_error(std::string("qp group event: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+        }
+    }
+    hipLaunchKernelGGL(qp_kernel_group, dim3(blocks), dim3(512), lds, st, a, NP, G);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("qp group launch: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    if (G > 1) {
+        e = hipEventRecord(ev, st);
+        if (e != hipSuccess) { set_error(std::string("qp group record: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    }
+    return HIPDRT_OK;
+}
+
+// process-wide: set once a group launch has found its members spread over several XCDs (the placement the fence-free
+// hand-offs rely on does not hold on this device / driver): from then on every group runs with one member
+static bool g_group_spread = false;
+
 int launch_qp(hipStream_t st, const QpArgs& a) {
-    if (a.n > 2048) { set_error("qp: n > 2048 not supported"); return HIPDRT_E_INVALID; }
-    return launch_qp_resident(st, a);
+    if (a.n > GRP_NMAX) { set_error("qp: n > 4096 not supported"); return HIPDRT_E_INVALID; }
+    if (a.G < 1) {
+        if (a.n > 2048) { set_error("qp: n > 2048 needs the group kernel's buffers (QpArgs.G >= 1)"); return HIPDRT_E_INVALID; }
+        return launch_qp_resident(st, a);
+    }
+    const int G = g_group_spread ? 1 : a.G;
+    int rc = launch_qp_group(st, a, G);
+    if (rc != HIPDRT_OK || G == 1) return rc;
+    // did every group find its members on one XCD?  (one short synchronisation per group launch: these are the launches of
+    // single fits, tens of microseconds against milliseconds of kernel)
+    std::vector<int> stt((size_t)a.B);
+    hipError_t e = hipMemcpyAsync(stt.data(), a.status, (size_t)a.B * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error(std::string("qp group status: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    bool spread = false;
+    for (int b = 0; b < a.B; ++b) spread = spread || stt[(size_t)b] == HIPDRT_QP_ABORTED;
+    if (!spread) return HIPDRT_OK;
+    g_group_spread = true;
+    QpArgs again = a;
+    again.redo_aborted = 1;                  // the spread groups once more, one member each (they had changed nothing)
+    return launch_qp_group(st, again, 1);
 }
 
 }  // namespace hipdrt

@@ -209,6 +209,10 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     // slot / leader: several workgroups may run the same problem redundantly (qp.hip, workgroup groups); each then keeps
     // its own copy of the iterates and only the leader writes the results
     constexpr int NW = THREADS / 64;
+    // element loops: fully unrolled up to 4 elements per thread (reads first, stores last: all loads of a statement in flight
+    // together); beyond that (the group kernel, n <= 4096: 8 per thread) in pairs -- eight elements' worth of operands at once
+    // would not fit the register file next to the factorisation's rings
+    constexpr int EUNR = EPT <= 4 ? EPT : 2;
     const int n = a.n;
     const unsigned tid = threadIdx.x;      // unsigned indices: SGPR base + 32-bit VGPR offset addressing, no per-vector
                                            // 64-bit address registers kept alive across the whole kernel
@@ -228,7 +232,8 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     constexpr bool kRecurPx = true;
 #endif
     constexpr double kDriftTol = 8.0;
-    double drift = 0.0;
+    constexpr double kCancUlps = 64.0;
+    double drift = 0.0, canc = 0.0;
     bool refresh = false;
 
     // The O(n) iterates live in a per-problem global scratch (L1/L2 resident, 16 vectors), element i touched
@@ -244,11 +249,11 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     double* const px = SV(16);      // P x, carried along by the recurrence below
 #define FOR_E for (unsigned e_ = 0, i = opaque_u32(tid); e_ < (unsigned)EPT; ++e_, i += THREADS)
 #define VALID (i < (unsigned)n)
-#pragma unroll
+#pragma unroll EUNR
     FOR_E if (VALID) { qv[i] = qg[i]; hv[i] = hg[i]; x[i] = z[i] = 0.0; s[i] = lm[i] = 1.0; d[i] = di[i] = 1.0; }
 
     double nq[2] = {0.0, 0.0};
-#pragma unroll
+#pragma unroll EUNR
     FOR_E if (VALID) { nq[0] += qv[i] * qv[i]; nq[1] += hv[i] * hv[i]; }
     red.sum(nq);
     const double resx0 = uni(fmax(1.0, sqrt(nq[0])));
@@ -267,9 +272,10 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     for (;;) {
         if (!start) {
             // ---- residuals, costs, stopping test ----------------------------------------------------------
-            if (!kRecurPx || refresh) {
+            const bool direct = !kRecurPx || refresh;       // this pass's P x is a direct product
+            if (direct) {
                 __syncthreads();
-#pragma unroll
+#pragma unroll EUNR
                 FOR_E if (VALID) sm.vec[i] = x[i];
                 __syncthreads();
                 { PROF_DECL
@@ -277,15 +283,16 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 __syncthreads();
                 PROF(9); }
                 if (kRecurPx) {
-#pragma unroll
+#pragma unroll EUNR
                     FOR_E if (VALID) px[i] = sm.dvec[i];
                     refresh = false;
+                    canc = 0.0;
                 }
             }
             // (the element loops read everything they need first and store last: the state vectors are slices of one
             // buffer, so a store in between would order every later load behind it -- one L2 round trip per statement)
             double t4[4] = {0.0, 0.0, 0.0, 0.0}, zr[1] = {0.0};
-#pragma unroll
+#pragma unroll EUNR
             FOR_E {
                 if (VALID) {
                     const double px_ = kRecurPx ? px[i] : sm.dvec[i], q_ = qv[i], x_ = x[i], z_ = z[i], s_ = s[i], h_ = hv[i];
@@ -314,10 +321,22 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             const double pres = resz / resz0, dres = resx / resx0;
             const bool conv = pres <= a.opts.feastol && dres <= a.opts.feastol &&
                               (gap <= a.opts.abstol || (has_rel && relgap <= a.opts.reltol));
+            // The drift rule does not see cancellation in r - D dx when di^2 is huge (active constraints late in the iteration),
+            // nor the residual of the Cholesky solve on such an S.  `canc` sums, since the last direct product, the largest
+            // magnitude that went into an element of the recurrence (step (|r| + di^2 |dx|)): each update loses at most a few
+            // ulps of that, so kCancUlps eps sqrt(n) canc bounds what the carried residual norm can be off by.  A verdict --
+            // "optimal", or the last test at maxiters -- taken on a carried P x whose bound exceeds 5 % of the dual
+            // feasibility threshold is repeated once on P x itself, as cvxopt forms it in every iteration; if the direct
+            // residual does not pass, the iteration simply goes on from the corrected P x.
+            if ((conv || iters == a.opts.maxiters) && !direct &&
+                kCancUlps * 1.1102230246251565e-16 * sqrt((double)n) * canc > 0.05 * a.opts.feastol * resx0) {
+                refresh = true;
+                continue;
+            }
             if (conv) { status = HIPDRT_QP_OPTIMAL; break; }
             if (iters == a.opts.maxiters) { status = HIPDRT_QP_MAXITER; break; }
             if (iters == 0) {
-#pragma unroll
+#pragma unroll EUNR
                 FOR_E if (VALID) { const double s_ = s[i], z_ = z[i], d_ = sqrt(s_ / z_); d[i] = d_; di[i] = 1.0 / d_; lm[i] = sqrt(s_ * z_); }
             }
         }
@@ -327,7 +346,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
         const int nsolve = start ? 1 : 2;
         // right-hand side of KKT solve pc (sigma = 0 for the predictor, so its rhs is known before the factorisation)
         auto set_rhs = [&](int pc) {
-#pragma unroll
+#pragma unroll EUNR
             FOR_E {
                 if (VALID) {
                     if (start) {
@@ -347,7 +366,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             }
         };
         __syncthreads();
-#pragma unroll
+#pragma unroll EUNR
         FOR_E if (VALID) sm.dvec[i] = di[i] * di[i];
         if (Ops::kFusedForward) set_rhs(0);     // the factorisation also forward-substitutes the first rhs
         __syncthreads();
@@ -367,7 +386,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             }
             if (start) {
                 double st[2] = {0.0, 0.0}, mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
+#pragma unroll EUNR
                 FOR_E {
                     if (VALID) {
                         const double x_ = sm.vec[i], q_ = qv[i], h_ = hv[i];
@@ -383,29 +402,30 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 red.sum(st);
                 red.max(mx);
                 if (kRecurPx) {
-                    double mm[1] = {0.0};
-#pragma unroll
-                    FOR_E if (VALID) mm[0] = fmax(mm[0], fabs(x[i]));
+                    double mm[2] = {0.0, 0.0};
+#pragma unroll EUNR
+                    FOR_E if (VALID) { const double ax = fabs(x[i]); mm[0] = fmax(mm[0], ax); mm[1] = fmax(mm[1], fabs(qv[i] + hv[i]) + ax); }
                     red.max(mm);
                     drift = uni(mm[0]);
+                    canc = uni(mm[1]);
                 }
                 const double nrms = sqrt(st[0]), nrmz = sqrt(st[1]);
                 if (mx[0] >= -1e-8 * fmax(nrms, 1.0)) {
-#pragma unroll
+#pragma unroll EUNR
                     FOR_E if (VALID) s[i] += 1.0 + mx[0];
                 }
                 if (mx[1] >= -1e-8 * fmax(nrmz, 1.0)) {
-#pragma unroll
+#pragma unroll EUNR
                     FOR_E if (VALID) z[i] += 1.0 + mx[1];
                 }
                 double gp[1] = {0.0};
-#pragma unroll
+#pragma unroll EUNR
                 FOR_E if (VALID) gp[0] += s[i] * z[i];
                 red.sum(gp);
                 gap = uni(gp[0]);
             } else {
                 double dd[1] = {0.0}, mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
+#pragma unroll EUNR
                 FOR_E {
                     if (VALID) {
                         const double dx_ = sm.vec[i], di_ = di[i], zz_ = zz[i], sv_ = sv[i], lm_ = lm[i];
@@ -437,16 +457,18 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
         }
         if (start) { start = false; continue; }
         // ---- update ---------------------------------------------------------------------------------------
-        double g2[1] = {0.0}, mm[2] = {0.0, 0.0};
-#pragma unroll
+        double g2[1] = {0.0}, mm[3] = {0.0, 0.0, 0.0};
+#pragma unroll EUNR
         FOR_E {
             if (VALID) {
                 const double dx_ = dx[i], ds_ = ds[i], dz_ = dz[i], lm_ = lm[i], d_ = d[i], x_ = x[i];
                 double px_ = 0.0;
                 if (kRecurPx) {
                     const double rx_ = rx[i], di_ = di[i], zz_ = zz[i];
-                    px_ = px[i] + step * ((-rx_ - di_ * zz_) - (di_ * di_) * dx_);
+                    const double r_ = -rx_ - di_ * zz_, t_ = (di_ * di_) * dx_;
+                    px_ = px[i] + step * (r_ - t_);
                     mm[0] = fmax(mm[0], fabs(step * dx_));
+                    mm[2] = fmax(mm[2], step * (fabs(r_) + fabs(t_)));
                 }
                 const double xn = x_ + step * dx_;
                 mm[1] = fmax(mm[1], fabs(xn));
@@ -471,6 +493,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
         if (kRecurPx) {
             red.max(mm);
             drift = uni(drift + mm[0]);
+            canc = uni(canc + mm[2]);
             if (drift > kDriftTol * mm[1]) { refresh = true; drift = uni(mm[1]); }
         }
         ++iters;
@@ -481,7 +504,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_qp_prof[13], __builtin_amdgcn_s_memrealtime() - _rt0);
 #endif
     if (leader) {
-#pragma unroll
+#pragma unroll EUNR
         FOR_E if (VALID) a.x[(size_t)b * n + i] = x[i];
     }
     if (tid == 0 && leader) {

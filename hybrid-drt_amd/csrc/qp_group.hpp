@@ -6,30 +6,37 @@
 // factorisation of ONE problem -- the tile-packed left-looking blocked Cholesky of qp_resident.hpp, same tile layout, same
 // per-tile arithmetic -- is shared by G workgroups:
 //
-//  * Tile row T belongs to member T % G for the whole factorisation, and inside the member to one row wavefront (static
-//    table, build_owner): a wavefront only re-reads tiles it stored itself.  The diagonal chain (wavefront 0) and the
-//    look-ahead rows (wavefront 1: the two tile rows of the next diagonal block) are computed REDUNDANTLY by every member
-//    from identical inputs, hence bit-identical: the only data that crosses between members are the finished tiles of the two
-//    rows that become look-ahead rows next, published by their owner through one progress word per tile row in global
-//    memory (rowprog[T] = factorisation count * 256 + block columns complete).
+//  * Tile rows belong to members in pairs (block row jb = tile rows 2 jb, 2 jb + 1 -> member jb % G) for the whole
+//    factorisation, and inside the member to one row wavefront (static table, build_owner): a wavefront only re-reads tiles
+//    it stored itself.
+//  * The diagonal chain (wavefront 0: factor + invert the 32 x 32 diagonal block) runs REDUNDANTLY in every member, from
+//    identical inputs, hence bit-identical: no member ever waits for another one's chain.
+//  * The look-ahead tiles (the seven accumulators that become the next diagonal block and its panel rows: inner dimension
+//    = every finished block column) are accumulated by ONE member per block column -- the owner of those two tile rows, all
+//    seven working wavefronts on a slice of the inner dimension each -- and published: 14 KB in labuf[jb] + the laprog
+//    word.  Every member's wavefront 1 fetches them while its chain still works on the current block, then does the last
+//    rank-32 update, the panel solve and the staging of the next diagonal block itself (redundantly, identical bits).  This
+//    publication is the only data that crosses between members inside a factorisation, and the only wait on another member.
 //  * Inside a member there is no barrier at the end of a block column: the hand-offs between its wavefronts go through
-//    progress bytes in LDS (rowdone[T], same meaning) and a "diagonal block staged" word, so a member's store drain overlaps
-//    its next rank-k update.  Two workgroup barriers per block column remain: (A) inverse diagonal blocks published, (A2)
-//    forward-substituted right-hand-side block published.
+//    progress bytes in LDS (rowdone[T]) and a "diagonal block staged" word, so a member's store drain overlaps its next
+//    rank-k update.  Two workgroup barriers per block column remain: (A) inverse diagonal blocks published, (A2) the L21
+//    scratch block may be rewritten.
 //  * Everything else -- the O(n) interior-point vectors, the triangular sweeps, P x -- every member does redundantly on its
 //    own copy (own state slot, own inverse diagonal blocks U), reading the shared factor: no communication, and the members
 //    stay in lockstep because they compute the same bits.  Two group barriers per factorisation: before it (everybody has
-//    finished sweeping the old factor) and after it (every tile is in memory; followed by an agent-scope acquire, i.e. an L1
-//    invalidate, so that the sweeps' plain loads see the other members' tiles).
-//  * Visibility inside the factorisation without fences: the members of a group sit on ONE XCD (blocks b and b + 8 share an
-//    XCD under the round-robin dispatch; checked at run time through HW_REG_XCC_ID -- a group that is spread over several
-//    XCDs reports HIPDRT_QP_ABORTED and the launcher repeats that problem with G = 1), so the XCD's L2 is the point of
-//    coherence: stores are complete (s_waitcnt vmcnt(0)) before the progress word is written, and every load of a tile
-//    another member may have written is an `sc1` load, which bypasses the CU's L1 (MI355X_MICROARCH.md, inter-workgroup
-//    visibility).  Tiles a wavefront wrote itself are read with plain loads.
+//    finished sweeping the old factor; followed by an L1 invalidate) and after it (every tile is in memory; L1 invalidate).
+//  * Visibility: the members of a group sit on ONE XCD (blocks b and b + 8 share an XCD under the round-robin dispatch;
+//    checked at run time through HW_REG_XCC_ID -- a group that is spread over several XCDs reports HIPDRT_QP_ABORTED and the
+//    launcher repeats that problem with G = 1), so the XCD's L2 is the point of coherence.  Stores are complete (s_waitcnt
+//    vmcnt(0)) before a progress word is written.  Tiles of L are read with plain loads: a CU reads a tile for the first
+//    time in a factorisation only after the tile is final (see "operand rings"), so its L1 cannot hold a stale copy; the
+//    look-ahead accumulators are read with sc1 loads (L1 bypass).
 //  * Every wait on another member is bounded (kSpinLimit): a protocol error or a member that never became resident traps the
 //    launch instead of hanging the device.  Group launches of one device are chained through an event (qp.hip) so that two
 //    of them cannot each occupy part of the CUs and wait for the rest.
+//  * The result does not depend on G (who owns a row does not change its arithmetic; the look-ahead slices are cut by
+//    wavefront, not by member).  Against the batch kernel it differs by rounding: there the predictor's forward substitution
+//    is fused into the factorisation and the look-ahead tiles are summed in one pass.
 //
 // G = 1 is the same kernel without the global words: the single-workgroup form for n up to 4096.
 #pragma once
@@ -40,19 +47,41 @@ namespace hipdrt {
 static constexpr int GRP_NMAX = 4096;                  // unknowns
 static constexpr int GRP_OWN = 512;                    // tile rows incl. appended ones the tables cover
 static constexpr int GRP_MAXG = 32;                    // members (CUs of one XCD)
+static constexpr int GRP_RMAXT = 2;                    // tile rows per row wavefront and pass: a member has few rows, and a short
+                                                       // pass leaves registers for an eight-slot operand ring (below)
 static constexpr int GRP_WORDS = 16 + GRP_OWN;         // ints of global sync state per problem
-// words: [0] members arrived at the start, [1] OR of (1 << XCC id), [2] barrier counter, [16 + T] rowprog[T]
+// words: [0] members arrived at the start, [1] OR of (1 << XCC id), [2] barrier counter, [3] laprog: factorisation count * 256
+// + block columns whose look-ahead accumulators are in labuf (written by the owner of the column's look-ahead rows)
 
-// 16 bytes per lane that bypass the CU's vector L1 (another CU of the XCD may have written them)
+// 16 bytes per lane that bypass the CU's vector L1 (written by another CU of the XCD in THIS factorisation after this CU may
+// have read the same addresses: the look-ahead accumulators, whose slots are reused from one factorisation to the next)
 static __device__ __forceinline__ v2d gload16_sc1(const char* sbase, unsigned voff) {
     v2d d;
     asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
     return d;
 }
+// an int / a byte of LDS read NOW (polls of progress words: a volatile C++ load would be a FLAT instruction, which counts in
+// vmcnt as well and returns out of order with the hand-counted loads).  The value goes through readfirstlane: the spin loops
+// around these stay scalar branches -- a loop whose exit depends on a vector register runs under EXEC masking, and
+// hand-issued loads after such a loop were observed to fault.
+static __device__ __forceinline__ int lds_peek32(const void* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+static __device__ __forceinline__ int lds_peek8(const void* p) {
+    int v;
+    asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
 
-struct OpsGroup : OpsResidentT<true, 512, 4> {
-    using Base = OpsResidentT<true, 512, 4>;
+struct OpsGroup : OpsResidentT<true, 512> {
+    using Base = OpsResidentT<true, 512>;
     static constexpr int RT = 512, RNW = 8;
+    // The predictor's forward substitution is NOT fused into the factorisation here: a member only touches its own rows'
+    // tiles, but every member needs the whole substituted vector for its (redundant) interior-point step; the predictor
+    // solve is a full forward + backward sweep over the finished factor instead.
+    static constexpr bool kFusedForward = false;
     static constexpr int kSpinLimit = 1 << 24;
     int G = 1, g = 0;                      // members of the group, this member
     int* gs = nullptr;                     // global sync words of the problem (GRP_WORDS)
@@ -60,11 +89,15 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
     unsigned char* owner = nullptr;        // LDS [GRP_OWN]: row wavefront (2..7) owning tile row T in THIS member, 0 = not mine
     volatile unsigned char* rowdone = nullptr;   // LDS [GRP_OWN]: block columns of tile row T complete in memory (own member's rows
                                                  // and the look-ahead rows this member computes itself)
+    double* latile = nullptr;              // LDS [6][256]: the look-ahead tiles computed by wavefronts 2..7 (register images)
+    int* lacnt = nullptr;                  // LDS: look-ahead tiles delivered in this factorisation (6 per block column this member owns)
+    double* labuf = nullptr;               // global [block columns][7][256]: look-ahead accumulators published by their owner
 
     __device__ __forceinline__ void trap_if(bool c) const { if (c) __builtin_trap(); }
 
     // ---- group barrier: every member's stores complete, then one arrival per member on a monotonic counter -------------
     __device__ __forceinline__ void group_sync() {
+        PROF_DECL
         __syncthreads();                                   // (s_waitcnt vmcnt(0) in every wavefront: this member's stores are in L2)
         if (G > 1) {
             ++gepoch;
@@ -81,45 +114,49 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
             }
             __syncthreads();
         }
+        PROF(4);
     }
 
-    // rows of this member, dealt to its row wavefronts from the bottom up by weighted round-robin (qp_resident.hpp: SIMD 0 / 1
-    // also run the chain / the look-ahead wavefront, so wavefronts 4 / 5 get smaller shares)
+    // Tile rows belong to members in PAIRS (the two tile rows of a block row: member (T / 2) % G), so that the two look-ahead
+    // rows of a block column have one owner.  Inside the member they are dealt to the row wavefronts from the bottom up,
+    // round-robin in an order that fills the four SIMDs evenly (wavefront w runs on SIMD w % 4; SIMD 0 / 1 also carry the
+    // chain / the look-ahead wavefront, which use the matrix pipe little, so wavefronts 4 and 5 come first): the rows still
+    // active at any block column are a prefix of that deal.
+    __device__ __forceinline__ bool mine(int T) const { return (T >> 1) % G == g; }
     __device__ __forceinline__ void build_owner() {
         if (threadIdx.x != 0) return;
         const int ntr = (n + 15) >> 4;
-        int cnt[6] = {0, 0, 0, 0, 0, 0};
-        const int wt[6] = {22, 22, 28, 10, 22, 22};
+        const unsigned char order[6] = {4, 5, 2, 3, 6, 7};
+        int k = 0;
         for (int T = ntr - 1; T >= 0; --T) {
-            if (T % G != g) { owner[T] = 0; continue; }
-            int best = 0;
-            for (int w = 1; w < 6; ++w)
-                if ((cnt[w] + 1) * wt[best] < (cnt[best] + 1) * wt[w]) best = w;
-            ++cnt[best];
-            owner[T] = (unsigned char)(best + 2);
+            if (!mine(T)) { owner[T] = 0; continue; }
+            owner[T] = order[k];
+            k = k == 5 ? 0 : k + 1;
         }
+    }
+    // the member that accumulates the look-ahead tiles of block column jb (rows 2 jb + 2, 2 jb + 3: its own rows)
+    __device__ __forceinline__ bool la_owner(int jb) const { return (jb + 1) % G == g; }
+    // does this member own a tile row below the look-ahead rows of block column jb?  (first pair >= jb + 2 that is its own)
+    __device__ __forceinline__ bool has_rows_below(int jb, int ntr) const {
+        const int p0 = jb + 2, d = ((g - p0) % G + G) % G;
+        return 2 * (p0 + d) < ntr;
     }
 
     // ---- progress words ----------------------------------------------------------------------------------------------------
     __device__ __forceinline__ int prog_value(int jb) const { return fidx * 256 + jb; }
-    // tile row T complete through block column jb - 1 (published by its owner; local rows through LDS)
+    // tile row T of THIS member complete through block column jb - 1 (set by the row wavefront that stores it)
     __device__ __forceinline__ void wait_row(int T, int jb) const {
         int spins = 0;
-        if (T % G == g || G == 1) {
-            while (rowdone[T] < jb) { __builtin_amdgcn_s_sleep(1); trap_if(++spins > kSpinLimit); }
-        } else {
-            const int want = prog_value(jb);
-            while (__hip_atomic_load(&gs[16 + T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                trap_if(++spins > kSpinLimit);
-            }
-        }
+        while (lds_peek8((const void*)(rowdone + T)) < jb) { __builtin_amdgcn_s_sleep(1); trap_if(++spins > kSpinLimit); }
         asm volatile("" ::: "memory");
     }
     // rows tb, tb + 1 of the current diagonal block: stored by this member's own look-ahead wavefront
     __device__ __forceinline__ void wait_diag_rows(int tb, bool two, int jb) const {
         int spins = 0;
-        while (rowdone[tb] < jb || (two && rowdone[tb + 1] < jb)) { __builtin_amdgcn_s_sleep(1); trap_if(++spins > kSpinLimit); }
+        while (lds_peek8((const void*)(rowdone + tb)) < jb || (two && lds_peek8((const void*)(rowdone + tb + 1)) < jb)) {
+            __builtin_amdgcn_s_sleep(1);
+            trap_if(++spins > kSpinLimit);
+        }
         asm volatile("" ::: "memory");
     }
 
@@ -149,6 +186,184 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
         return __builtin_popcountll(k.m0) + __builtin_popcountll(k.m1) + __builtin_popcountll(k.m2) + __builtin_popcountll(k.m3);
     }
 
+    // ---- the look-ahead tiles ------------------------------------------------------------------------------------------------
+    // The seven tiles wavefront 1 of the batch kernel accumulates in one loop -- (R2|R3, tb|tb+1) and the next diagonal block
+    // (R2,R2), (R3,R2), (R3,R3), over the whole inner dimension -- are the critical path of a block column here, and computed
+    // by every member they would cost each member 14 MFMAs per half-chunk whatever the group size (measured: a group of 16
+    // no faster than one of 8).  Only the member that OWNS rows R2, R3 accumulates them (la_owner), one tile per wavefront
+    // 1..7 (same order of summation as the batch kernel: same bits), wavefronts 2..7 hand theirs to wavefront 1 through LDS,
+    // and wavefront 1 publishes the seven raw accumulators in labuf[jb] + the laprog word.  Every member's wavefront 1
+    // fetches them (sc1 loads: the XCD's L2) while its chain wavefront still factors the current diagonal block, and does the
+    // last rank-32 update, the panel solve and the staging itself after barrier (A) -- redundantly, from identical bits.
+    // ---- operand rings -------------------------------------------------------------------------------------------------------
+    // Every rank-k loop of this kernel streams its operands through an eight-slot register ring, one half-chunk (1 KB per
+    // operand) per slot, requested SEVEN slots ahead with hand-issued loads and counted waits (qp_resident.hpp, gload16 /
+    // vm_wait).  The loads are plain, L1-cached ones although most of the B operand (rows tb, tb+1) was stored by another
+    // member: this CU reads a tile of L for the first time in a factorisation only after the tile is final (its rows were
+    // waited for by the member that published the look-ahead accumulators this member fetched before it passed barrier (A)
+    // of the previous block column), and group_sync() invalidated the L1 after the previous factor's sweeps -- so no stale
+    // line can be hit, and the six row wavefronts of a member, which walk the same B chunks, share them through the L1.
+    // (An earlier form staged the shared rows through LDS with LDS-DMA loads and a software barrier per four half-chunks
+    // among the seven wavefronts: 3.9k cycles per super-step of which 1.1k matrix work -- DESIGN.md section 7.)
+    //
+    // Registers written by a hand-issued load stay allocated until the load has landed only if something reads them after
+    // the wait: slots past the end of the inner dimension are re-reads of the last chunk, and are "consumed" by an empty asm.
+
+    // rows of this pass: acc[u][c] += chunk(T[u], k) chunk(tb + c, k)' over the finished block columns
+    __device__ __forceinline__ void ring_rows(int jb, int ntr, int lane, const int (&T)[GRP_RMAXT], const bool (&act)[GRP_RMAXT],
+                                              v4d (&acc)[GRP_RMAXT][2]) const {
+        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+        const int tb = 2 * jb, nk2 = 4 * jb, klast = nk2 - 1;
+        const bool two = tb + 1 < ntr;
+        const char* rb0 = uniform_ptr(tile2(tb, 0));
+        const char* rb1 = uniform_ptr(tile2(two ? tb + 1 : tb, 0));
+        const char* ra[GRP_RMAXT];
+#pragma unroll
+        for (int u = 0; u < GRP_RMAXT; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
+        const unsigned voff = (unsigned)fo * 16u;
+        struct Sl { v2d b0, b1, a[GRP_RMAXT]; };
+        auto load = [&](Sl& s_, int k2) {
+            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+            s_.b0 = gload16(uniform_ptr(rb0 + o), voff); s_.b1 = gload16(uniform_ptr(rb1 + o), voff);
+#pragma unroll
+            for (int u = 0; u < GRP_RMAXT; ++u) s_.a[u] = gload16(uniform_ptr(ra[u] + o), voff);
+        };
+        auto mult = [&](const Sl& s_, int k2) {
+            if (k2 < nk2) {
+#pragma unroll
+                for (int u = 0; u < GRP_RMAXT; ++u) {
+                    if (act[u]) {
+                        acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0.x, s_.a[u].x, acc[u][0], 0, 0, 0);
+                        if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1.x, s_.a[u].x, acc[u][1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GRP_RMAXT; ++u) {
+                    if (act[u]) {
+                        acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0.y, s_.a[u].y, acc[u][0], 0, 0, 0);
+                        if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1.y, s_.a[u].y, acc[u][1], 0, 0, 0);
+                    }
+                }
+            } else {
+                asm volatile("" :: "v"(s_.b0), "v"(s_.b1));
+#pragma unroll
+                for (int u = 0; u < GRP_RMAXT; ++u) asm volatile("" :: "v"(s_.a[u]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int LPS = 2 + GRP_RMAXT;                  // loads per slot
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // the newest two chunks of rows tb, tb+1 were stored by this member's look-ahead wavefront in the previous block
+        // column: wait for them just before the first request that reaches that far
+        bool gated = false;
+        if (6 >= nk2 - 4) { wait_diag_rows(tb, two, jb); gated = true; }
+        Sl r0, r1, r2, r3, r4, r5, r6, r7;
+        load(r0, 0); load(r1, 1); load(r2, 2); load(r3, 3); load(r4, 4); load(r5, 5); load(r6, 6);
+        for (int kb = 0; kb < nk2; kb += 8) {
+            if (!gated && kb + 14 >= nk2 - 4) { wait_diag_rows(tb, two, jb); gated = true; }
+            load(r7, kb + 7);  vm_wait<7 * LPS>(); mult(r0, kb);
+            load(r0, kb + 8);  vm_wait<7 * LPS>(); mult(r1, kb + 1);
+            load(r1, kb + 9);  vm_wait<7 * LPS>(); mult(r2, kb + 2);
+            load(r2, kb + 10); vm_wait<7 * LPS>(); mult(r3, kb + 3);
+            load(r3, kb + 11); vm_wait<7 * LPS>(); mult(r4, kb + 4);
+            load(r4, kb + 12); vm_wait<7 * LPS>(); mult(r5, kb + 5);
+            load(r5, kb + 13); vm_wait<7 * LPS>(); mult(r6, kb + 6);
+            load(r6, kb + 14); vm_wait<7 * LPS>(); mult(r7, kb + 7);
+        }
+        vm_wait<0>();
+        mult(r0, nk2); mult(r1, nk2); mult(r2, nk2); mult(r3, nk2); mult(r4, nk2); mult(r5, nk2); mult(r6, nk2);   // (pins)
+    }
+
+    // The look-ahead accumulators in the owner of rows R2, R3: the seven tiles are products of chunks of FOUR tile rows (tb,
+    // tb+1, R2, R3), so the inner dimension is cut into seven contiguous slices, one per wavefront 1..7, and each wavefront
+    // accumulates all seven tiles over its slice -- every operand chunk is requested once per member (one tile per wavefront
+    // over the whole inner dimension asked for 14 KB per half-chunk instead of 4, at the ~20 bytes per cycle a single CU
+    // draws from beyond its L2: 44k cycles per block column with every other member waiting).  The partial sums are then
+    // added up in LDS in wavefront order (la_reduce): a fixed order, independent of the group size.
+    struct LaAcc { v4d p20, p21, p30, p31, e11, e21, e22; };
+    __device__ __forceinline__ void ring_la_slice(int jb, int ntr, int lane, int w, LaAcc& A) const {
+        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+        const int tb = 2 * jb, nk2 = 4 * jb;
+        const bool v3 = tb + 3 < ntr;
+        // rows R2, R3 (this member's own): every tile their row wavefronts ever stored is in memory
+        wait_row(tb + 2, jb);
+        if (v3) wait_row(tb + 3, jb);
+        const int k0 = (w - 1) * nk2 / 7, k1 = w * nk2 / 7, klast = k1 - 1;      // this wavefront's half-chunks
+        if (k1 <= k0) return;
+        const char* r0p = uniform_ptr(tile2(tb, 0));
+        const char* r1p = uniform_ptr(tile2(tb + 1, 0));
+        const char* r2p = uniform_ptr(tile2(tb + 2, 0));
+        const char* r3p = uniform_ptr(tile2(v3 ? tb + 3 : tb + 2, 0));          // (padding row: its tiles are replaced by the caller)
+        const unsigned voff = (unsigned)fo * 16u;
+        struct Sl { v2d c0, c1, c2, c3; };
+        auto load = [&](Sl& s_, int k2) {
+            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+            s_.c0 = gload16(uniform_ptr(r0p + o), voff); s_.c1 = gload16(uniform_ptr(r1p + o), voff);
+            s_.c2 = gload16(uniform_ptr(r2p + o), voff); s_.c3 = gload16(uniform_ptr(r3p + o), voff);
+        };
+        auto mult = [&](const Sl& s_, int k2) {
+            if (k2 < k1) {
+                A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c0.x, s_.c2.x, A.p20, 0, 0, 0);
+                A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c1.x, s_.c2.x, A.p21, 0, 0, 0);
+                A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c0.x, s_.c3.x, A.p30, 0, 0, 0);
+                A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c1.x, s_.c3.x, A.p31, 0, 0, 0);
+                A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c2.x, s_.c2.x, A.e11, 0, 0, 0);
+                A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c2.x, s_.c3.x, A.e21, 0, 0, 0);
+                A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c3.x, s_.c3.x, A.e22, 0, 0, 0);
+                A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c0.y, s_.c2.y, A.p20, 0, 0, 0);
+                A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c1.y, s_.c2.y, A.p21, 0, 0, 0);
+                A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c0.y, s_.c3.y, A.p30, 0, 0, 0);
+                A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c1.y, s_.c3.y, A.p31, 0, 0, 0);
+                A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c2.y, s_.c2.y, A.e11, 0, 0, 0);
+                A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c2.y, s_.c3.y, A.e21, 0, 0, 0);
+                A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c3.y, s_.c3.y, A.e22, 0, 0, 0);
+            } else {
+                asm volatile("" :: "v"(s_.c0), "v"(s_.c1), "v"(s_.c2), "v"(s_.c3));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // the newest two chunks of rows tb, tb+1 (half-chunks nk2-4 ..) come from this member's wavefront 1, stored in the
+        // previous block column: only a slice that reaches them waits
+        if (k1 > nk2 - 4) wait_diag_rows(tb, true, jb);
+        constexpr int NS = 8;
+        Sl r[NS];
+#pragma unroll
+        for (int i_ = 0; i_ < NS - 1; ++i_) load(r[i_], k0 + i_);
+        for (int kb = k0; kb < k1; kb += NS) {
+#pragma unroll
+            for (int i_ = 0; i_ < NS; ++i_) {
+                load(r[(i_ + NS - 1) % NS], kb + i_ + NS - 1);
+                vm_wait<4 * (NS - 1)>();
+                mult(r[i_], kb + i_);
+            }
+        }
+        vm_wait<0>();
+#pragma unroll
+        for (int i_ = 0; i_ < NS; ++i_) mult(r[i_], k1);       // (pins)
+    }
+    // Partial sums -> LDS, added in wavefront order 1, 2, .. 7 (wavefront 1 starts from the source tiles).  `base` = 7 x the
+    // block columns this member accumulated before this one: lacnt counts the additions of the whole factorisation.
+    __device__ __forceinline__ void la_reduce(int lane, int w, int base, const LaAcc& A, const LaAcc* init) const {
+        for (int spins = 0; lds_peek32(lacnt) < base + (w - 1);) {
+            __builtin_amdgcn_s_sleep(1);
+            trap_if(++spins > kSpinLimit);
+        }
+        asm volatile("" ::: "memory");
+        v4d* lt = reinterpret_cast<v4d*>(latile) + lane;
+        if (init) {
+            lt[0] = init->p20 + A.p20;   lt[64] = init->p21 + A.p21;   lt[128] = init->p30 + A.p30;  lt[192] = init->p31 + A.p31;
+            lt[256] = init->e11 + A.e11; lt[320] = init->e21 + A.e21; lt[384] = init->e22 + A.e22;
+        } else {
+            lt[0] += A.p20;   lt[64] += A.p21;  lt[128] += A.p30; lt[192] += A.p31;
+            lt[256] += A.e11; lt[320] += A.e21; lt[384] += A.e22;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(lacnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
     // =========================================================================================================================
     __device__ __forceinline__ bool factor() {
         const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,7 +371,7 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
         ++fidx;
         group_sync();                            // every member has finished sweeping the previous factor: its tiles may go
         for (int i = tid; i < GRP_OWN; i += RT) rowdone[i] = 0;
-        if (tid == 0) sm.flag[1] = 0;
+        if (tid == 0) { sm.flag[1] = 0; *lacnt = 0; }
         if (wv == 1) {
             // prologue: diagonal block of column 0 straight from P
             const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
@@ -187,11 +402,13 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
         v4d* const img22 = img21 + 64;
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
-            for (int spins = 0; *(volatile int*)&sm.flag[1] < jb;) {                    // diagonal block jb staged
+            PROF_DECL
+            for (int spins = 0; lds_peek32(&sm.flag[1]) < jb;) {                        // diagonal block jb staged
                 __builtin_amdgcn_s_sleep(1);
                 trap_if(++spins > kSpinLimit);
             }
             asm volatile("" ::: "memory");
+            PROF(2);
             bool ok = cholinv16_dsc(j0, 0);
             const v4d d21 = img21[lane];
             v4d d22 = img22[lane];
@@ -214,8 +431,10 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
             for (int s_ = 0; s_ < 4; ++s_)
                 d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq], x21[s_], d22, 0, 0, 0);
             ok = cholinv16(d22, j0 + 16, 16) && ok;
+            PROF(12);
             if (lane == 0) sm.flag[0] = ok ? 0 : 1;
             __syncthreads();                                    // (A) W1, L21, W2 published
+            PROF(1);
             if (sm.flag[0]) return false;
             // lower-left block of the inverse for the solves: W21 = -W2 (L21 W1)
             v4d y = (v4d){0, 0, 0, 0};
@@ -229,23 +448,10 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
                 w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq], y[s_], w21, 0, 0, 0);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
-            // fused forward substitution: y_j = M_j b_j (b_j has received every earlier column's update)
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (U lives in global memory: the row of W21 just stored is read back)
-            const int r = lane & 31;
-            const double* Mr = U + (size_t)(j0 + r) * PLD;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int c = 0; c < NB; c += 4) {
-                s0 += Mr[c] * sm.vec[j0 + c];
-                s1 += Mr[c + 1] * sm.vec[j0 + c + 1];
-                s2 += Mr[c + 2] * sm.vec[j0 + c + 2];
-                s3 += Mr[c + 3] * sm.vec[j0 + c + 3];
-            }
-            const double yv = (s0 + s1) + (s2 + s3);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < NB) sm.vec[j0 + lane] = yv;
-            lds_barrier();                                      // (A2) y_j published
+            // (A2): separates this block column's readers of the L21 scratch block from its next writer (in the batch kernel
+            // it also publishes the forward-substituted right-hand-side block)
+            lds_barrier();                                      // (A2)
+            PROF(3);
         }
         return true;
     }
@@ -259,86 +465,90 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
         double* U = sm.U;
         v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
         v4d* const img22 = img21 + 64;
-        TileSrc pre[7];
-        bool have_pre = false;
+        int laown = 0;                               // block columns whose look-ahead tiles this member accumulated
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
             const int tb = j0 >> 4;
-            const int nc = 2 * jb;
             const int R2 = tb + 2, R3 = tb + 3;
             const bool v2 = R2 < ntr, v3 = R3 < ntr;
+            PROF_DECL
             if (jb > 0) {
                 // the tiles this wavefront stored in the previous column (rows tb, tb+1 now) are in memory: tell the row wavefronts
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane < 2) rowdone[tb + lane] = (unsigned char)jb;
             }
+            PROFW(20);
             v4d p20, p21, p30, p31, e11, e21, e22;
             if (v2) {
-                if (have_pre) {
-                    p20 = tile_image(pre[0], R2, tb, li, kq);      p21 = tile_image(pre[1], R2, tb + 1, li, kq);
-                    p30 = tile_image(pre[2], R3, tb, li, kq);      p31 = tile_image(pre[3], R3, tb + 1, li, kq);
-                    e11 = tile_image(pre[4], R2, R2, li, kq);      e21 = tile_image(pre[5], R3, R2, li, kq);
-                    e22 = tile_image(pre[6], R3, R3, li, kq);
-                } else {
+                if (jb == 0) {
                     p20 = init_tile(R2, tb, ntr, fo, li, kq);      p21 = init_tile(R2, tb + 1, ntr, fo, li, kq);
                     p30 = init_tile(R3, tb, ntr, fo, li, kq);      p31 = init_tile(R3, tb + 1, ntr, fo, li, kq);
                     e11 = init_tile(R2, R2, ntr, fo, li, kq);      e21 = init_tile(R3, R2, ntr, fo, li, kq);
                     e22 = init_tile(R3, R3, ntr, fo, li, kq);
-                }
-                if (jb > 0) {
-                    // operand ring as in qp_resident.hpp; every tile may have been written by another member: sc1 loads
-                    const char* q0 = uniform_ptr(tile2(tb, 0));
-                    const char* q1 = uniform_ptr(tile2(tb + 1, 0));
-                    const char* q2 = uniform_ptr(tile2(R2, 0));
-                    const char* q3 = uniform_ptr(tile2(v3 ? R3 : R2, 0));
-                    const unsigned voff = (unsigned)fo * 16u;
-                    struct Frag { v2d b0, b1, a2, a3; };
-                    const int nk2 = 2 * nc, klast = nk2 - 1;
-                    auto loadf = [&](Frag& f_, int k2) {
-                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-                        f_.b0 = gload16_sc1(q0 + o, voff); f_.b1 = gload16_sc1(q1 + o, voff);
-                        f_.a2 = gload16_sc1(q2 + o, voff); f_.a3 = gload16_sc1(q3 + o, voff);
-                    };
-#define HIPDRT_STEP7(B0, B1, A2, A3)                                                                    \
-                    p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);               \
-                    p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);               \
-                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);               \
-                    if (v3) {                                                                       \
-                        p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);           \
-                        p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);           \
-                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);           \
-                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);           \
+                } else {
+                    const bool la = la_owner(jb);
+                    if (la) {
+                        // this wavefront's slice of the inner dimension on top of the source tiles, then the other six wavefronts'
+                        LaAcc I_, A_;
+                        A_.p20 = A_.p21 = A_.p30 = A_.p31 = A_.e11 = A_.e21 = A_.e22 = (v4d){0, 0, 0, 0};
+                        ring_la_slice(jb, ntr, lane, 1, A_);
+                        __builtin_amdgcn_sched_barrier(0);           // (the source tiles only after the ring's registers are free)
+                        I_.p20 = init_tile(R2, tb, ntr, fo, li, kq);      I_.p21 = init_tile(R2, tb + 1, ntr, fo, li, kq);
+                        I_.p30 = init_tile(R3, tb, ntr, fo, li, kq);      I_.p31 = init_tile(R3, tb + 1, ntr, fo, li, kq);
+                        I_.e11 = init_tile(R2, R2, ntr, fo, li, kq);      I_.e21 = init_tile(R3, R2, ntr, fo, li, kq);
+                        I_.e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                        la_reduce(lane, 1, 7 * laown, A_, &I_);
+                        PROFW(21);
+                        ++laown;
+                        for (int spins = 0; lds_peek32(lacnt) < 7 * laown;) {
+                            __builtin_amdgcn_s_sleep(1);
+                            trap_if(++spins > kSpinLimit);
+                        }
+                        asm volatile("" ::: "memory");
+                        PROFW(22);
+                        const v4d* lt = reinterpret_cast<const v4d*>(latile) + lane;
+                        p20 = lt[0]; p21 = lt[64]; p30 = lt[128]; p31 = lt[192]; e11 = lt[256]; e21 = lt[320]; e22 = lt[384];
+                        if (G > 1) {
+                            // publish the seven raw accumulators (register images) for the other members
+                            v4d* dst = reinterpret_cast<v4d*>(labuf + (size_t)jb * 7 * 256) + lane;
+                            dst[0] = p20; dst[64] = p21; dst[128] = p30; dst[192] = p31; dst[256] = e11; dst[320] = e21; dst[384] = e22;
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (lane == 0) __hip_atomic_store(&gs[3], prog_value(jb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    } else {
+                        // the owner's accumulators
+                        PROFW(21);
+                        const int want = prog_value(jb + 1);
+                        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&gs[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want;) {
+                            __builtin_amdgcn_s_sleep(1);
+                            trap_if(++spins > kSpinLimit);
+                        }
+                        asm volatile("" ::: "memory");
+                        PROFW(22);
+                        const char* src = uniform_ptr(labuf + (size_t)jb * 7 * 256);
+                        const unsigned vo = (unsigned)lane * 32u;
+                        v2d t_[14];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) {
+                            t_[2 * q] = gload16_sc1(src + q * 2048, vo);
+                            t_[2 * q + 1] = gload16_sc1(src + q * 2048 + 16, vo);
+                        }
+                        vm_wait<0>();
+#pragma unroll
+                        for (int q = 0; q < 14; ++q) asm volatile("" : "+v"(t_[q]));
+                        auto cat = [&](int q) { return (v4d){t_[2 * q].x, t_[2 * q].y, t_[2 * q + 1].x, t_[2 * q + 1].y}; };
+                        p20 = cat(0); p21 = cat(1); p30 = cat(2); p31 = cat(3); e11 = cat(4); e21 = cat(5); e22 = cat(6);
                     }
-                    auto multf = [&](const Frag& f_) {
-                        HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
-                        HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-#undef HIPDRT_STEP7
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the newest two chunks (half-chunks nk2-4 ..) of rows R2, R3 were stored by their owners (possibly other
-                    // members) in the previous block column: wait for them just before the first request that reaches that far
-                    if (nk2 == 4) { wait_row(R2, jb); if (v3) wait_row(R3, jb); }
-                    Frag f0, f1, f2, f3;
-                    loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
-                    for (int k2 = 0; k2 < nk2; k2 += 4) {
-                        if (k2 == nk2 - 8) { wait_row(R2, jb); if (v3) wait_row(R3, jb); }
-                        loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
-                        loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
-                        loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
-                        loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
-                    }
-                    vm_wait<0>();
                     if (!v3) {
+                        // R3 is pure padding: no panel tiles, identity diagonal
                         p30 = (v4d){0, 0, 0, 0}; p31 = (v4d){0, 0, 0, 0}; e21 = (v4d){0, 0, 0, 0};
                         e22 = init_tile(R3, R3, ntr, fo, li, kq);
                     }
                 }
             }
             __syncthreads();                                    // (A)
+            PROFW(23);
             if (sm.flag[0]) return false;
-            have_pre = false;
             if (v2) {
                 double wn1[4], l21[4], wn2[4];
 #pragma unroll
@@ -392,21 +602,11 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
                 img22[lane] = e22;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) *(volatile int*)&sm.flag[1] = jb + 1;      // diagonal block jb + 1 staged: the chain may start
-                // next column's source tiles (rows tb+4, tb+5), requested a column ahead
-                if (R2 + 2 < ntr) {
-                    const int N2 = R2 + 2, N3 = R3 + 2;
-                    pre[0] = tile_src(N2, R2, ntr, fo); pre[1] = tile_src(N2, R3, ntr, fo);
-                    pre[2] = tile_src(N3, R2, ntr, fo); pre[3] = tile_src(N3, R3, ntr, fo);
-                    pre[4] = tile_src(N2, N2, ntr, fo); pre[5] = tile_src(N3, N2, ntr, fo);
-                    pre[6] = tile_src(N3, N3, ntr, fo);
-                    have_pre = true;
-                }
                 lds_barrier();                                  // (A2)
-                fwd_update(x20, x21_, R2, j0, li, kq);
-                if (v3) fwd_update(x30, x31, R3, j0, li, kq);
             } else {
                 lds_barrier();                                  // (A2)
             }
+            PROFW(24);
         }
         return true;
     }
@@ -418,114 +618,56 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
         const int nblk = (n + NB - 1) / NB;
         const int ntr = (n + 15) >> 4;
         double* U = sm.U;
-        TileSrc pre[RMAXT][2];
-        bool have_pre = false;
+        int laown = 0;                               // block columns whose look-ahead tiles this member accumulated
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
             const int tb = j0 >> 4;
-            const int nc = 2 * jb;
-            const bool two = (tb + 1) < ntr;
             RowMask mask = my_rows(jb, wv, lane, ntr);
+            PROF_DECL
             if (jb > 0) {
                 // everything this wavefront stored in the previous block column is in memory (the wait also covers the source
-                // tiles requested after those stores).  The only rows anybody else reads next are tb + 2 and tb + 3 -- the
-                // look-ahead wavefronts' rows from now on: their owner publishes them, to its own member through LDS and to
-                // the other members through the global progress word
+                // tiles requested after those stores).  The only rows another wavefront reads next are tb + 2 and tb + 3 -- the
+                // look-ahead rows from now on, read by the wavefronts of this same member (their owner): tell them
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane < 2) {
                     const int T = tb + 2 + lane;
-                    if (T < ntr && owner[T] == wv) {
-                        rowdone[T] = (unsigned char)jb;
-                        if (G > 1) __hip_atomic_store(&gs[16 + T], prog_value(jb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    if (T < ntr && owner[T] == wv) rowdone[T] = (unsigned char)jb;
                 }
             }
+            if (wv == 2) PROFW(26);
+            // this wavefront's look-ahead tile first (in the owner of the look-ahead rows: everybody else waits for them)
+            if (jb > 0 && tb + 2 < ntr && la_owner(jb)) {
+                LaAcc A_;
+                A_.p20 = A_.p21 = A_.p30 = A_.p31 = A_.e11 = A_.e21 = A_.e22 = (v4d){0, 0, 0, 0};
+                ring_la_slice(jb, ntr, lane, wv, A_);
+                la_reduce(lane, wv, 7 * laown, A_, nullptr);
+                ++laown;
+            }
+            if (wv == 2) PROFW(27);
             const int mine = count_rows(mask);
-            const int npass = mine > RMAXT ? (mine + RMAXT - 1) / RMAXT : 1;
+            const int npass = mine > GRP_RMAXT ? (mine + GRP_RMAXT - 1) / GRP_RMAXT : 1;
 #pragma unroll 1
             for (int ps = 0; ps < npass; ++ps) {
-                int T[RMAXT];
-                bool act[RMAXT];
+                int T[GRP_RMAXT];
+                bool act[GRP_RMAXT];
 #pragma unroll
-                for (int u = 0; u < RMAXT; ++u) {
+                for (int u = 0; u < GRP_RMAXT; ++u) {
                     const int t_ = pop_row(mask, tb);
                     T[u] = t_ >= 0 ? t_ : nch;
                     act[u] = t_ >= 0;
                 }
-                v4d acc[RMAXT][2];
-                if (ps == 0 && have_pre) {
+                v4d acc[GRP_RMAXT][2];
 #pragma unroll
-                    for (int u = 0; u < RMAXT; ++u)
+                for (int u = 0; u < GRP_RMAXT; ++u)
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-                            acc[u][ct] = act[u] ? tile_image(pre[u][ct], T[u], tb + ct, li, kq) : (v4d){0, 0, 0, 0};
-                } else {
-#pragma unroll
-                    for (int u = 0; u < RMAXT; ++u)
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-                            acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
-                }
-                if (jb > 0 && act[0]) {
-                    // operand ring as in qp_resident.hpp.  A tiles = this wavefront's own rows (plain loads: it stored them
-                    // itself); B tiles = rows tb, tb+1, whose older chunks their owner -- possibly another member -- stored
-                    // when they were ordinary rows: sc1 loads
-                    const char* rb0 = uniform_ptr(tile2(tb, 0));
-                    const char* rb1 = uniform_ptr(tile2(two ? tb + 1 : tb, 0));
-                    const char* ra[RMAXT];
-#pragma unroll
-                    for (int u = 0; u < RMAXT; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
-                    const unsigned voff = (unsigned)fo * 16u;
-                    struct SlA { v2d a[RMAXT]; };
-                    struct SlB { v2d b0, b1; };
-                    const int nk2 = 2 * nc, klast = nk2 - 1;
-                    auto loadA = [&](SlA& s_, int k2) {
-                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-#pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) s_.a[u] = act[u] ? gload16(ra[u] + o, voff) : gload16_sc1(ra[u] + o, voff);
-                    };
-                    auto loadB = [&](SlB& s_, int k2) {
-                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-                        s_.b0 = gload16_sc1(rb0 + o, voff); s_.b1 = gload16_sc1(rb1 + o, voff);
-                    };
-                    auto mult = [&](const SlA& a_, const SlB& b_) {
-#pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) {
-                            if (act[u]) {
-                                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b0.x, a_.a[u].x, acc[u][0], 0, 0, 0);
-                                if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b1.x, a_.a[u].x, acc[u][1], 0, 0, 0);
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) {
-                            if (act[u]) {
-                                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b0.y, a_.a[u].y, acc[u][0], 0, 0, 0);
-                                if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b1.y, a_.a[u].y, acc[u][1], 0, 0, 0);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-                    SlA a0, a1, a2, a3;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the newest two chunks of rows tb, tb+1 were stored by this member's look-ahead wavefront in the previous
-                    // block column: wait for them just before the first request that reaches that far
-                    if (nk2 == 4) wait_diag_rows(tb, two, jb);
-                    SlB b0, b1;
-                    loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
-                    for (int k2 = 0; k2 < nk2; k2 += 4) {
-                        if (k2 == nk2 - 8) wait_diag_rows(tb, two, jb);
-                        loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RMAXT + 2>(); mult(a0, b0);
-                        loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * RMAXT + 2>(); mult(a1, b1);
-                        loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RMAXT + 2>(); mult(a2, b0);
-                        loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<2 * RMAXT + 2>(); mult(a3, b1);
-                    }
-                    vm_wait<0>();
-                }
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                if (jb > 0 && act[0]) ring_rows(jb, ntr, lane, T, act, acc);
                 if (ps == 0) {
+                    if (wv == 2) PROFW(28);
                     __syncthreads();                            // (A) W1, L21, W2 published by wavefront 0
+                    if (wv == 2) PROFW(29);
                     if (sm.flag[0]) return false;
-                    have_pre = false;
                 }
                 if (act[0]) {
                     double wn1[4], l21[4], wn2[4];
@@ -543,26 +685,26 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
                         const double2 h0 = t_[0], h1 = t_[64];
                         l21[0] = h0.x; l21[1] = h0.y; l21[2] = h1.x; l21[3] = h1.y;
                     }
-                    v4d x1[RMAXT], x2[RMAXT];
+                    v4d x1[GRP_RMAXT], x2[GRP_RMAXT];
 #pragma unroll
-                    for (int u = 0; u < RMAXT; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
+                    for (int u = 0; u < GRP_RMAXT; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u)
+                        for (int u = 0; u < GRP_RMAXT; ++u)
                             x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u)
+                        for (int u = 0; u < GRP_RMAXT; ++u)
                             acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                        for (int u = 0; u < RMAXT; ++u)
+                        for (int u = 0; u < GRP_RMAXT; ++u)
                             x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < RMAXT; ++u) {
+                    for (int u = 0; u < GRP_RMAXT; ++u) {
                         if (act[u]) {
                             double2* d0 = const_cast<double2*>(tile2(T[u], 2 * jb)) + fo;
                             d0[0] = make_double2(x1[u][0], x1[u][1]);
@@ -571,42 +713,27 @@ struct OpsGroup : OpsResidentT<true, 512, 4> {
                             d0[192] = make_double2(x2[u][2], x2[u][3]);
                         }
                     }
-                    if (ps == npass - 1 && jb + 1 < nblk) {
-                        // the source tiles of the next block column's first pass, requested a column ahead
-                        RowMask nx = my_rows(jb + 1, wv, lane, ntr);
-                        int Tn[RMAXT];
-#pragma unroll
-                        for (int u = 0; u < RMAXT; ++u) Tn[u] = pop_row(nx, tb + 2);
-                        if (Tn[0] >= 0) {
-#pragma unroll
-                            for (int u = 0; u < RMAXT; ++u)
-#pragma unroll
-                                for (int ct = 0; ct < 2; ++ct)
-                                    if (Tn[u] >= 0) pre[u][ct] = tile_src(Tn[u], tb + 2 + ct, ntr, fo);
-                            have_pre = true;
-                        }
-                    }
-                    if (ps == 0) lds_barrier();                 // (A2) y_j published by wavefront 0
-#pragma unroll
-                    for (int u = 0; u < RMAXT; ++u)
-                        if (act[u]) fwd_update(x1[u], x2[u], T[u], j0, li, kq);
+                    if (ps == 0) lds_barrier();                 // (A2)
                 } else if (ps == 0) {
                     lds_barrier();                              // (A2)
                 }
             }
+            if (wv == 2) PROFW(30);
         }
         return true;
     }
 };
 
 // LDS of the group kernel (doubles): the fixed buffers of qp_resident.hpp, the two byte tables, the two n-vectors
-static constexpr int GRP_FIXED = 4 * 8 * 4 + 2 * 16 * 17 + 8 + 512 + 2 * GRP_OWN / 8;
+static constexpr int GRP_FIXED = 4 * 8 * 4 + 2 * 16 * 17 + 8 + 512 + 2 * GRP_OWN / 8 + 7 * 256 + 8;
 static size_t group_lds_bytes(int NP) { return (size_t)(GRP_FIXED + 2 * (NP + 64)) * sizeof(double); }
 
-// per-problem scratch doubles: the tile-packed factor followed by one copy of U per member
+// per-problem scratch doubles: the tile-packed factor, one copy of U per member, the look-ahead accumulators of every block
+// column (7 tiles each; a column's slot is written once per factorisation, so no member can overwrite what a slower one
+// has not fetched yet)
 static size_t group_scratch_doubles(int n, int G) {
     const size_t NP = (size_t)round_up(n, 32);
-    return NP * NP + (size_t)G * NP * PLD;
+    return NP * NP + (size_t)G * NP * PLD + (NP / NB) * 7 * 256;
 }
 
 // grid: block 8 (r G + g) + s = member g of problem 8 r + s -- the members of a problem are 8 blocks apart, i.e. on one XCD
@@ -617,6 +744,7 @@ __global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int 
     const int b = 8 * (rg / G) + s_, g = rg % G;
     if (b >= a.B) return;
     if (a.active && !a.active[b]) return;
+    if (a.redo_aborted && a.status[b] != HIPDRT_QP_ABORTED) return;
     extern __shared__ double smem[];
     OpsGroup ops;
     ops.G = G; ops.g = g;
@@ -631,15 +759,18 @@ __global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int 
     ops.sm.img = ops.sm.dsc + 16 * 17 + 8;
     ops.owner = reinterpret_cast<unsigned char*>(ops.sm.img + 512);
     ops.rowdone = ops.owner + GRP_OWN;
-    ops.sm.vec = ops.sm.img + 512 + 2 * GRP_OWN / 8;
+    ops.latile = ops.sm.img + 512 + 2 * GRP_OWN / 8;
+    ops.lacnt = reinterpret_cast<int*>(ops.latile + 7 * 256);
+    ops.sm.vec = ops.latile + 7 * 256 + 8;
     ops.sm.dvec = ops.sm.vec + NP + 64;
     ops.sm.U = ops.L + (size_t)NP * NP + (size_t)g * NP * PLD;          // this member's own inverse diagonal blocks
+    ops.labuf = ops.L + (size_t)NP * NP + (size_t)G * NP * PLD;
     ops.build_owner();
     for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
     for (int i = threadIdx.x; i < NP + 64; i += RT) { ops.sm.vec[i] = 0.0; ops.sm.dvec[i] = 0.0; }
     // ---- rendezvous: all members resident, all on one XCD -------------------------------------------------------------------
     if (G > 1) {
-        __shared__ int xcc_mask;
+        int& xcc_mask = ops.sm.flag[2];
         if (threadIdx.x == 0) {
             const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;      // HW_REG_XCC_ID[3:0]
             __hip_atomic_fetch_or(&ops.gs[1], 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -49,6 +49,9 @@ static constexpr int RNW = RT / 64;      // 8 wavefronts
 #ifndef HIPDRT_QP_MINWAVES
 #define HIPDRT_QP_MINWAVES 2
 #endif
+#ifndef HIPDRT_QP_OVR
+#define HIPDRT_QP_OVR 0
+#endif
 #ifndef HIPDRT_QP_PREFETCH
 #define HIPDRT_QP_PREFETCH 1     // source tiles of block column jb + 1 requested before barrier (B) of column jb
 #endif
@@ -876,17 +879,34 @@ struct OpsResidentT {
                         }
                     }
                     {
-                        // more tile rows below than the register buffers hold (n > 528, or fewer wavefronts): the rest
-                        // straight from memory
-                        for (int tt = (wv - 1) + FT * UW; tt < tbelow; tt += UW) {
-                            const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;
-                            double pv = 0.0;
+                        // more tile rows below than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
+                        // from memory, four tile rows per round -- their sixteen loads are requested together, so a round costs
+                        // one memory round trip instead of four
+                        constexpr int OVR = (GU && HIPDRT_QP_OVR) ? 4 : 1;       // (n <= 528 never gets here: no registers spent on it)
+                        for (int tt0 = (wv - 1) + FT * UW; tt0 < tbelow; tt0 += OVR * UW) {
+                            double2 t_[OVR][4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) { const double2 t_ = p[q * 64]; pv += t_.x * ya[q] + t_.y * yb[q]; }
-                            pv = quad_sum(pv);
-                            if (l4 == 0) {
-                                const int row = (tb + 2 + tt) * 16 + g4;
-                                if (row < n) vec[row] -= pv;
+                            for (int j = 0; j < OVR; ++j) {
+                                const int tt = tt0 + j * UW;
+                                if (tt < tbelow) {
+                                    const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) t_[j][q] = p[q * 64];
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < OVR; ++j) {
+                                const int tt = tt0 + j * UW;
+                                if (tt < tbelow) {
+                                    double pv = 0.0;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) pv += t_[j][q].x * ya[q] + t_[j][q].y * yb[q];
+                                    pv = quad_sum(pv);
+                                    if (l4 == 0) {
+                                        const int row = (tb + 2 + tt) * 16 + g4;
+                                        if (row < n) vec[row] -= pv;
+                                    }
+                                }
                             }
                         }
                     }
@@ -993,16 +1013,30 @@ struct OpsResidentT {
                         }
                     }
                     {
-                        // more finished chunks than the register buffers hold (n > 528, or fewer wavefronts): the rest
-                        // straight from memory
-                        for (int c = (wv - 1) + BC * UW; c < nc; c += UW) {
-                            const double2* p0 = tile2(tb, c) + lane;
-                            const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
-                            const double2 t0 = p0[0], t1 = p0[64], t2 = p1[0], t3 = p1[64];
-                            const double s0 = t0.x * x0 + t2.x * x1, s1 = t0.y * x0 + t2.y * x1;
-                            const double s2 = t1.x * x0 + t3.x * x1, s3 = t1.y * x0 + t3.y * x1;
-                            const double f = colsum4(s0, s1, s2, s3, lane);
-                            if ((lane & 12) == 0) vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
+                        // more finished chunks than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
+                        // from memory, four chunks per round (sixteen loads requested together: one round trip per round)
+                        constexpr int OVR = (GU && HIPDRT_QP_OVR) ? 4 : 1;
+                        for (int c0 = (wv - 1) + BC * UW; c0 < nc; c0 += OVR * UW) {
+                            double2 t_[OVR][4];
+#pragma unroll
+                            for (int j = 0; j < OVR; ++j) {
+                                const int c = c0 + j * UW;
+                                if (c < nc) {
+                                    const double2* p0 = tile2(tb, c) + lane;
+                                    const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
+                                    t_[j][0] = p0[0]; t_[j][1] = p0[64]; t_[j][2] = p1[0]; t_[j][3] = p1[64];
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < OVR; ++j) {
+                                const int c = c0 + j * UW;
+                                if (c < nc) {
+                                    const double s0 = t_[j][0].x * x0 + t_[j][2].x * x1, s1 = t_[j][0].y * x0 + t_[j][2].y * x1;
+                                    const double s2 = t_[j][1].x * x0 + t_[j][3].x * x1, s3 = t_[j][1].y * x0 + t_[j][3].y * x1;
+                                    const double f = colsum4(s0, s1, s2, s3, lane);
+                                    if ((lane & 12) == 0) vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
+                                }
+                            }
                         }
                     }
                 }

@@ -194,3 +194,79 @@ def test_concurrent_large_launches_from_two_streams():
         assert not t.is_alive(), "QP launches hung"
     np.testing.assert_array_equal(out[0]["x"], out[1]["x"])
     assert np.all(out[0]["status"] == 0)
+
+
+def _random_qp(n, rng):
+    A = rng.standard_normal((n + 50, n)) / np.sqrt(n)
+    xt = np.maximum(rng.standard_normal(n), 0)
+    return A.T @ A + 1e-3 * np.eye(n), -A.T @ (A @ xt)
+
+
+@pytest.mark.parametrize("n,B", [(514, 1), (514, 8), (1078, 1), (1078, 2), (2049, 1), (2500, 2), (3598, 1), (4096, 1)])
+def test_group_kernel_few_large_problems(n, B):
+    """Few problems, or n > 2048: every problem on several co-resident workgroups (qp_group.hpp).  Against the CPU checker:
+    same iteration count, x within 1e-9 of the peak (n <= 2500); the result does not depend on the number of problems in the
+    launch (hence not on the group size either)."""
+    from hipdrt import _ffi
+    from oracle.coneqp import coneqp_boxlow
+    rng = np.random.default_rng(7 * n + B)
+    ctx = _ffi.get_context()
+    Ps, qs = zip(*[_random_qp(n, rng) for _ in range(B)])
+    Ps, qs = np.array(Ps), np.array(qs)
+    h = np.zeros(n)
+    h[:3] = 1000.0
+    res = ctx.qp_batch(Ps, qs, h)
+    assert np.all(res["status"] == 0) and np.all(np.isfinite(res["x"]))
+    assert np.all(res["x"][:, 3:] > -1e-9)
+    if n <= 2500:
+        r = coneqp_boxlow(Ps[0], qs[0], h)
+        assert r["iterations"] == res["iterations"][0]
+        np.testing.assert_allclose(res["x"][0], r["x"], rtol=0, atol=1e-9 * np.abs(r["x"]).max())
+    else:
+        # KKT residual of the returned point instead of a (slow) CPU solve: P x + q - z = 0, z >= 0, z (x + h) ~ 0
+        for b in range(B):
+            x = res["x"][b]
+            z = Ps[b] @ x + qs[b]
+            assert z.min() > -1e-6 * np.abs(qs[b]).max() and np.abs(z * (x + h)).max() < 1e-5 * np.abs(qs[b]).max()
+    # the same first problem alone / in a launch of another size: bit-identical
+    more = ctx.qp_batch(np.concatenate([Ps[:1]] * 3), np.concatenate([qs[:1]] * 3), h)
+    for b in range(3):
+        np.testing.assert_array_equal(more["x"][b], res["x"][0])
+    assert more["iterations"].tolist() == [int(res["iterations"][0])] * 3
+
+
+def test_group_kernel_result_independent_of_group_size():
+    """The same problems on 1, 3, 8 and 16 workgroups each (debug switch of the C-ABI): identical bits whatever the group size
+    (the rows' arithmetic does not depend on who owns them); against the batch kernel (one workgroup per problem, forward
+    substitution fused into the factorisation, hence another summation order): same iteration counts, x within 1e-12 of the
+    peak"""
+    from hipdrt import _ffi
+    rng = np.random.default_rng(99)
+    ctx = _ffi.get_context()
+    n = 600
+    Ps, qs = zip(*[_random_qp(n, rng) for _ in range(3)])
+    Ps, qs = np.array(Ps), np.array(qs)
+    h = np.zeros(n)
+    try:
+        ctx.debug_qp_group(0)                         # batch kernel
+        ref = ctx.qp_batch(Ps, qs, h)
+        outs = []
+        for G in (1, 3, 8, 16):
+            ctx.debug_qp_group(G)
+            outs.append(ctx.qp_batch(Ps, qs, h))
+    finally:
+        ctx.debug_qp_group(-1)                        # automatic choice again
+    for o in outs:
+        assert o["iterations"].tolist() == ref["iterations"].tolist()
+        np.testing.assert_allclose(o["x"], ref["x"], rtol=0, atol=1e-12 * np.abs(ref["x"]).max())
+        np.testing.assert_array_equal(o["x"], outs[0]["x"])
+
+
+def test_group_kernel_reports_breakdown():
+    from hipdrt import _ffi
+    ctx = _ffi.get_context()
+    n = 1500
+    P = np.eye(n)
+    P[700, 700] = -5.0
+    res = ctx.qp_batch(P[None], np.ones((1, n)), np.zeros(n))
+    assert res["status"][0] < 0

@@ -33,6 +33,10 @@
 #pragma once
 #include "qp_common.hpp"
 
+#ifndef HIPDRT_QP_CHOLINV_MFMA
+#define HIPDRT_QP_CHOLINV_MFMA 1      // 0: the register-only Gauss-Jordan by rows (sixteen pivot steps)
+#endif
+
 namespace hipdrt {
 
 static constexpr int RT = 512;           // threads
@@ -196,6 +200,75 @@ struct OpsResidentT {
         return cholinv16_dsc(r0, c0);
     }
     __device__ __forceinline__ bool cholinv16_dsc(int r0, int c0) const {
+#if HIPDRT_QP_CHOLINV_MFMA
+        return cholinv16_blocked(r0, c0);
+#else
+        return cholinv16_rows(r0, c0);
+#endif
+    }
+    // The same in four block steps of four pivots on the matrix pipe: forward elimination of [D | I] to [L' | W], the two
+    // halves kept as two MFMA accumulators (lane (li, kq) register rg <-> row kq + 4 rg, column li).  Step k reads its 4 x 4
+    // diagonal block (ten v_readlane pairs), factors and inverts it in uniform arithmetic (every lane the same values: four
+    // dependent rsqrt instead of sixteen pivots with a cross-lane broadcast per update), and then needs
+    //     X = Wkk D[block k, :]      (the scaled pivot rows; by symmetry also the panel L[:, block k] transposed)
+    //     Y = Wkk W[block k, :]      (rows 4k .. 4k+3 of the result)
+    //     D -= L[:, block k] X,  W -= L[:, block k] Y   for the rows below the block
+    // -- four v_mfma_f64_16x16x4: register k of an accumulator IS the B operand "rows of block k", and register 0 of X is at
+    // once B operand (X) and, negated and masked to the rows below, A operand (the panel), so nothing moves between lanes.
+    __device__ __forceinline__ bool cholinv16_blocked(int r0, int c0) const {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const double* D = sm.dsc;
+        v4d aA, aW;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int i = kq + 4 * rg;
+            aA[rg] = D[(i > li ? i : li) * DLD + (i > li ? li : i)];      // lower triangle mirrored
+            aW[rg] = (i == li) ? 1.0 : 0.0;
+        }
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double tA = aA[k], tW = aW[k];
+            // element (a, b) of the diagonal block: row 4k + a, column 4k + b -> lane (li = 4k + b, kq = a)
+            auto dg = [&](int a_, int b_) { return bcast_lane(tA, 4 * k + b_ + 16 * a_); };
+            const double d00 = dg(0, 0), d10 = dg(1, 0), d20 = dg(2, 0), d30 = dg(3, 0);
+            const double d11 = dg(1, 1), d21 = dg(2, 1), d31 = dg(3, 1), d22 = dg(2, 2), d32 = dg(3, 2), d33 = dg(3, 3);
+            const double i0 = rsqrt(d00);
+            const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+            const double p1 = d11 - l10 * l10;
+            const double i1 = rsqrt(p1);
+            const double l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
+            const double p2 = d22 - l20 * l20 - l21 * l21;
+            const double i2 = rsqrt(p2);
+            const double l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+            const double p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+            const double i3 = rsqrt(p3);
+            if (!(d00 > 0.0) || !(p1 > 0.0) || !(p2 > 0.0) || !(p3 > 0.0)) ok = false;
+            // Wkk = inverse of the 4 x 4 factor
+            const double w10 = -(l10 * i0) * i1;
+            const double w21 = -(l21 * i1) * i2, w20 = -(l20 * i0 + l21 * w10) * i2;
+            const double w32 = -(l32 * i2) * i3, w31 = -(l31 * i1 + l32 * w21) * i3, w30 = -(l30 * i0 + l31 * w10 + l32 * w20) * i3;
+            // A operand: row li (< 4) of Wkk, inner index kq
+            const double r0_ = kq == 0 ? i0 : 0.0;
+            const double r1_ = kq == 0 ? w10 : kq == 1 ? i1 : 0.0;
+            const double r2_ = kq == 0 ? w20 : kq == 1 ? w21 : kq == 2 ? i2 : 0.0;
+            const double r3_ = kq == 0 ? w30 : kq == 1 ? w31 : kq == 2 ? w32 : i3;
+            const double wsel = li == 0 ? r0_ : li == 1 ? r1_ : li == 2 ? r2_ : li == 3 ? r3_ : 0.0;
+            const v4d z4 = (v4d){0, 0, 0, 0};
+            const v4d X = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, tA, z4, 0, 0, 0);
+            const v4d Y = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, tW, z4, 0, 0, 0);
+            // rows 4k .. 4k+3 of the inverse: Y[0] at lane (li, kq) = W[4k + kq][li]
+            sm.U[(size_t)(r0 + 4 * k + kq) * PLD + c0 + li] = (li <= 4 * k + kq) ? Y[0] : 0.0;
+            if (k < 3) {
+                const double pan = (li > 4 * k + 3) ? -X[0] : 0.0;      // -L[li][4k + kq] below the block, nothing above
+                aA = __builtin_amdgcn_mfma_f64_16x16x4f64(pan, X[0], aA, 0, 0, 0);
+                aW = __builtin_amdgcn_mfma_f64_16x16x4f64(pan, Y[0], aW, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        return ok;
+    }
+    __device__ __forceinline__ bool cholinv16_rows(int r0, int c0) const {
         const int lane = fresh_lane(), li = lane & 15;
         const double* D = sm.dsc;
         const int r = li;

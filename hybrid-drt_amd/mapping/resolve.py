@@ -2,7 +2,7 @@
 
 The single fits' P matrices sit on the block diagonal of one large QP; a second-derivative Gaussian filter across the
 observation index couples equal coefficients of neighbouring observations.  The assembly is O((nr nc)^2) bookkeeping on
-the host exactly as in the reference; the QP itself (n = nr * nc up to 2048 unknowns, same coneqp trajectory) is solved
+the host exactly as in the reference; the QP itself (n = nr * nc up to 4096 unknowns, same coneqp trajectory) is solved
 by the device kernel behind ``hipdrt_qp_batch``.  Like the reference, this needs hybrid fits: the data-dependent unknowns
 ``v_baseline`` and ``vz_offset`` are eliminated first (resolve.py:23-24)."""
 from copy import deepcopy

@@ -365,7 +365,7 @@ def run_hybrid_cases(DRT, cvxopt, freq_g, z_g):
     run_hybrid_case(DRT, cvxopt, "hybrid_cap", meas_c, dict(capb, fit_dop=False), {})
 
 
-def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7):
+def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7, basis_tau=None, store_p=True):
     """survey 8f rank 2: mapping/resolve.py:189-341 -- coherent re-optimisation of neighbouring observations (block
     diagonal P of the single fits + a smoothness penalty across observations).  The reference only supports hybrid
     fits here (get_offset_pq indexes v_baseline / vz_offset unconditionally).  Saves what resolve consumes from every
@@ -373,6 +373,8 @@ def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7):
     from hipdrt import synth
     from hybdrt.mapping import resolve
     base = dict(fit_inductance=True, fit_capacitance=False, fit_ohmic=True, fit_dop=fit_dop)
+    if basis_tau is not None:
+        base["fixed_basis_tau"] = basis_tau
     drts = []
     with _quiet():
         for s_ in range(n_obs):
@@ -408,6 +410,13 @@ def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7):
     if fit_dop:
         out.update(x_dop=np.array([d.fit_parameters["x_dop"] for d in drts]),
                    dop_scale_vector=np.array([d.dop_scale_vector for d in drts]))
+    if not store_p:
+        # large grids: the single fits' P matrices (n_obs x n x n doubles) stay out of the repository; the fixture keeps the
+        # fitted coefficients (the device test fits the same synthetic cells itself and compares them first), P's diagonal
+        # and the resolved result
+        out["p_diag"] = np.array([np.diag(p_) for p_ in out.pop("p_matrix")])
+        out["x_fit"] = np.array([d.fit_parameters["x"] for d in drts])
+        out["basis_tau"] = np.asarray(basis_tau)
     np.savez_compressed(os.path.join(OUT, f"refrun_resolve_{name}.npz"), **out)
     print(f"resolve_{name}: {n_obs} obs x {x_opt.shape[1]} params, qp iterations {out['qp_iterations'].tolist()}")
 
@@ -596,6 +605,12 @@ def main():
         run_resolve(DRT, cvxopt, "hybrid7", False)
         run_resolve(DRT, cvxopt, "hybrid7_dop", True)
         run_resolve_group(cvxopt, "hybrid16")
+        return
+    if "--only-resolve-c2grid" in sys.argv:
+        # 7 joint fits on the 512-point tau grid of BASELINE configs[2]: a coupled QP of 7 x 514 = 3598 unknowns
+        from hipdrt import synth
+        DRT, cvxopt = _boot_reference()
+        run_resolve(DRT, cvxopt, "c2grid", False, basis_tau=synth.config_c2()["tau"], store_p=False)
         return
     if "--only-drtmd" in sys.argv:
         _boot_reference()

@@ -162,3 +162,53 @@ def test_batch_fits_feed_resolve_like_single_fits():
     np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=1e-5 * np.abs(g["x_opt"]).max())
     np.testing.assert_allclose(fits[3].fit_parameters["p_matrix"], g["p_matrix"][3], rtol=1e-5,
                                atol=1e-7 * np.abs(g["p_matrix"][3]).max())
+
+
+@pytest.mark.gpu
+def test_device_resolve_c2grid_3598_unknowns():
+    """Seven joint fits on the 512-point tau grid of BASELINE configs[2] -> one coupled QP of 7 x 514 = 3598 unknowns: beyond
+    the 2048 a single workgroup serves, i.e. the group kernel (one problem on 32 workgroups).  Two checkers:
+    (1) the CPU restatement of resolve + coneqp on the SAME inputs (the device fits' own P, q): identical iteration count,
+        x within 1e-7 of the peak -- the trajectory test at this size;
+    (2) the reference's own run (refrun_resolve_c2grid.npz: hybdrt fits of the same synthetic cells + hybdrt resolve): same
+        iteration count, assembled q / diag P / h and the resolved coefficients within the tolerance the single fits allow
+        (51 basis points per decade: two of the seven fits stop at max_iter = 50 in the reference and on the device alike, and
+        there the device fit agrees with the reference's to 4e-7 of the peak instead of 1e-11, measured; the fixture keeps
+        the reference's fitted coefficients for that comparison instead of its 7 x 516 x 516 P matrices)."""
+    from hipdrt.models import DRT
+    from hipdrt.mapping import resolve
+    from hipdrt import synth
+    from oracle import resolve_oracle as ro
+    g = np.load(os.path.join(GOLDEN, "refrun_resolve_c2grid.npz"))
+    nt, nobs = int(g["ntau"]), int(g["n_obs"])
+    assert nt == 512 and nobs * (nt + 2) == 3598
+    drts = []
+    for s_ in range(nobs):
+        d = DRT(fixed_basis_tau=g["basis_tau"], warn=False)
+        d.fit_hybrid(*synth.hybrid_measurement(seed=s_, jitter=True, n_post=120, nf=31))
+        drts.append(d)
+    np.testing.assert_allclose([d.coefficient_scale for d in drts], g["coefficient_scale"], rtol=1e-12)
+    x_fit = np.array([d.fit_parameters["x"] for d in drts])
+    np.testing.assert_allclose(x_fit, g["x_fit"], rtol=0, atol=5e-6 * np.abs(g["x_fit"]).max())
+    x, match = resolve.resolve_observations(drts, [(0, nt)] * nobs, True)
+    assert match == (0, nt) and x.shape == (nobs, nt + 2)
+    its = resolve.resolve_observations.last_qp["iterations"]
+    # (1) same inputs on the CPU
+    special = drts[0].special_qp_params
+    obs = [dict(p_matrix=d.fit_parameters["p_matrix"], q_vector=d.fit_parameters["q_vector"],
+                v_baseline=d.fit_parameters["v_baseline"], vz_offset=d.fit_parameters["vz_offset"],
+                R_inf=d.fit_parameters["R_inf"], coefficient_scale=d.coefficient_scale,
+                response_signal_scale=d.response_signal_scale, scaled_response_offset=d.scaled_response_offset,
+                v_baseline_scale=d.v_baseline_scale) for d in drts]
+    xo, res, (P, q, h) = ro.resolve_observations(obs, special)
+    assert P.shape == (3598, 3598)
+    assert its == res["iterations"]
+    np.testing.assert_allclose(x, xo, rtol=0, atol=1e-7 * np.abs(xo).max())
+    # (2) the reference's run
+    assert its == int(g["qp_iterations"][0])
+    np.testing.assert_array_equal(h, g["qp0_h"])
+    np.testing.assert_allclose(np.diag(P), g["qp0_P_diag"], rtol=3e-4)
+    np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=2e-6 * np.abs(g["x_opt"]).max())
+    x2, _ = resolve.resolve_observations(drts, [(0, nt)] * nobs, True, sigma=2, lambda_psi=10)
+    assert resolve.resolve_observations.last_qp["iterations"] == int(g["qp_iterations"][1])
+    np.testing.assert_allclose(x2, g["x_opt_sigma2_lambda10"], rtol=0, atol=2e-6 * np.abs(g["x_opt"]).max())

@@ -54,7 +54,7 @@ def _c2_mode():
 
 def _c2_one(i):
     od, freq, z = globals()["_C2"]
-    od.fit_eis(freq, z[i], structure='fast')
+    od.fit_eis(freq, z[i], structure='fast', keep_history=True)
     return (od.qphb_params["x_scaled"].copy(), int(od.qphb_params["outer_iterations"]),
             int(sum(l["iterations"] for l in od.qp_log)))
 

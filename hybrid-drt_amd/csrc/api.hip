@@ -41,6 +41,7 @@ struct hipdrt_plan {
     // per spectrum
     DevBuf z_re, z_im, rv, w, est_w, x, x_in, q, s, rho, xmx, coef_scale, var_floor;
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
+    DevBuf premv;          // [3][capacity][m]: hyper-parameter step of few, large fits (hyper.hip, premv_kernel)
     DevBuf L, Ptmp, qpstate, Ppk, order, vmm_base, gsync;
     int qp_G = 0;           // workgroups per QP (qp_group_size at the plan's capacity): 0 = the batch kernel
     // history
@@ -70,6 +71,7 @@ struct hipdrt_plan {
         st.hist_b = hist_b; st.hist_cap = hist_cap;
         st.hist_x = hist_x.d(); st.hist_w = hist_w.d(); st.hist_rho = hist_rho.d();
         st.hist_qp = hist_qp.i(); st.hist_rows = hist_rows.i();
+        st.premv = nullptr;
         return st;
     }
 };
@@ -861,6 +863,17 @@ static GramL2 plan_l2(const hipdrt_plan* p, double l2_lambda_0, const double* de
     return g;
 }
 
+// hyper-parameter step of one outer iteration.  Few fits with large matrices: their matrix-vector products are spread over
+// many workgroups first (premv_kernel), else the one workgroup per fit of hyper_kernel would stream them through one CU each.
+static int plan_hyper(hipdrt_plan* p, hipStream_t st, const FitState& fs_in, int B, int it) {
+    FitState fs = fs_in;
+    if (B * 8 <= device_cus() && (size_t)p->m * p->n >= ((size_t)1 << 20) && !(p->opts.outlier_p > 0.0)) {
+        if (!p->premv.p) HIPDRT_CHECK(p->premv.alloc(3 * (size_t)p->capacity * p->m * sizeof(double)));
+        fs.premv = p->premv.d();
+    }
+    return launch_hyper(st, fs, B, it);
+}
+
 namespace {
 struct PhaseTimer {
     hipStream_t st;
@@ -1016,7 +1029,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
         }
         TRY(launch_qp(st, qa));
         tm.mark(3);
-        TRY(launch_hyper(st, fs, B, it));
+        TRY(plan_hyper(p, st, fs, B, it));
         LAUNCH_OK();
         int n_active = 0;
         HIPDRT_CHECK(hipMemcpyAsync(&n_active, p->n_active.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1148,7 +1161,7 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
         }
         TRY(launch_qp(st, qa));
         tm.mark(3);
-        TRY(launch_hyper(st, fs, B, it));
+        TRY(plan_hyper(p, st, fs, B, it));
         LAUNCH_OK();
         int n_active = 0;
         HIPDRT_CHECK(hipMemcpyAsync(&n_active, p->n_active.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1213,7 +1226,7 @@ int hipdrt_plan_iterate(hipdrt_plan* p, const hipdrt_iterate_state* in, int* con
     tm.mark(2);
     TRY(launch_qp(st, qa));
     tm.mark(3);
-    TRY(launch_hyper(st, fs, B, 0));
+    TRY(plan_hyper(p, st, fs, B, 0));
     LAUNCH_OK();
     tm.mark(-1);
     std::vector<int> act(B);

@@ -170,6 +170,9 @@ struct FitState {
     double *coef_scale, *var_floor;   // [B]
     int *active, *outer_iters, *fit_status, *qp_iters_total, *qp_status, *qp_iters;   // [B]
     int* n_active;               // [1]
+    // few, large fits: the three matrix-vector products of an outer iteration (rm @ x, vmm @ resid^2, rm @ x for the
+    // vz_offset column) computed by a many-workgroup kernel before hyper_kernel, which then only reads them ([3][B][m], or null)
+    double* premv;
     // optional history of one spectrum
     int hist_b, hist_cap;
     double *hist_x, *hist_w, *hist_rho;
@@ -185,6 +188,7 @@ void launch_weight_method(hipStream_t s, const FitState& st, int B, double fixed
                           double* wfac);
 void launch_vmm_exclude_self(hipStream_t s, const double* vmm, int m, double* out);
 int launch_hyper(hipStream_t s, const FitState& st, int B, int it);
+int device_cus();      // compute units of the current device (qp.hip)
 void launch_scale_weights(hipStream_t s, const FitState& st, int B, double factor);
 void launch_scale_rows(hipStream_t s, int B, int m, const double* w, const double* rows, int batched, double factor,
                        const int* active, double* out);

@@ -272,12 +272,16 @@ __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, in
 // s_hat = sqrt(t) o V (sqrt(t) o r^2) + (1 - t) o r^2).  Result written to w_out[m] (global).
 __device__ void estimate_weights_dev(const FitState& st, int b, const double* V, const double* xs, double* tmp, double* tmp2,
                                      double* tmp3, double* tmp4, const double* est_w, double* w_out, int r0 = 0, int r1 = -1,
-                                     double vf_range = -1.0) {
+                                     double vf_range = -1.0, const double* pre = nullptr) {
     const int m = st.m, n = st.n, tid = threadIdx.x;
     const double* rv = st.rv + (size_t)b * m;
     const double op = st.opts.outlier_p;
     HPROF_START();
-    rows_matvec(st.rm + (size_t)b * st.rm_stride, st.ldrm, m, n, xs, tmp);        // rm @ x
+    // (pre: both products of this call were computed by premv_kernel, same arithmetic per row)
+    const double* pre1 = pre ? pre + (size_t)b * m : nullptr;
+    const double* pre2 = pre ? pre + ((size_t)gridDim.x + b) * m : nullptr;
+    if (pre1) { for (int i = tid; i < m; i += HT) tmp[i] = pre1[i]; }
+    else rows_matvec(st.rm + (size_t)b * st.rm_stride, st.ldrm, m, n, xs, tmp);        // rm @ x
     __syncthreads();
     HPROF(8);
     for (int i = tid; i < m; i += HT) {
@@ -289,7 +293,15 @@ __device__ void estimate_weights_dev(const FitState& st, int b, const double* V,
     // V @ resid**2.  A uniform chrono block (error_structure='uniform': every chrono row of V is the same vector, zero on the
     // impedance columns) needs one row only -- same arithmetic per row, so the same bits, without streaming nc x m entries
     const int ncu = (st.prepared && st.desc.chrono_vmm_uniform && V == st.vmm && op <= 0.0) ? st.desc.num_chrono : 0;
-    if (ncu > 0) {
+    if (pre2) {
+        for (int i = tid; i < m; i += HT) if (i == 0 || i >= ncu) tmp2[i] = pre2[i];
+        __syncthreads();
+        if (ncu > 0) {
+            const double s0 = tmp2[0];
+            __syncthreads();
+            for (int i = 1 + tid; i < ncu; i += HT) tmp2[i] = s0;
+        }
+    } else if (ncu > 0) {
         rows_matvec(V, m, 1, m, tmp, tmp2);
         if (ncu < m) rows_matvec(V + (size_t)ncu * m, m, m - ncu, m, tmp, tmp2 + ncu);
         __syncthreads();
@@ -401,6 +413,50 @@ void launch_vmm_exclude_self(hipStream_t s, const double* vmm, int m, double* ou
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Few, large fits (one joint fit of BASELINE configs[4]: rm is 5120 x 1078, vmm 5120 x 5120): hyper_kernel is one workgroup
+// per fit, and its three matrix-vector products would stream ~130 MB through ONE CU per outer iteration (2.6 of its
+// 4.5 ms).  Here the same products, row slab by row slab on many workgroups, with rows_matvec itself -- the same
+// arithmetic per row, hence the same bits -- into premv[3][B][m]: phase 0  rm @ x and (vz_offset fits) rm @ x with the
+// baseline / offset entries zeroed; phase 1  vmm @ (rm x - rv)^2 (uniform chrono block: row 0 stands for the block).
+// grid = (row slabs, B)
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int PREMV_ROWS = 32;      // rows per workgroup (4 per wavefront and pass)
+__global__ __launch_bounds__(HT) void premv_kernel(FitState st, int phase, int B) {
+    extern __shared__ double sm[];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (!st.active[b] || st.qp_status[b] < 0) return;
+    const int n = st.n, m = st.m;
+    const int r0 = blockIdx.x * PREMV_ROWS, r1 = r0 + PREMV_ROWS < m ? r0 + PREMV_ROWS : m;
+    double* y1 = st.premv + (size_t)b * m;
+    double* y2 = st.premv + ((size_t)B + b) * m;
+    double* y3 = st.premv + (2 * (size_t)B + b) * m;
+    if (phase == 0) {
+        double* xs = sm;
+        const double* xg = st.x + (size_t)b * n;
+        for (int i = tid; i < n; i += HT) xs[i] = xg[i];
+        __syncthreads();
+        rows_matvec(st.rm + (size_t)b * st.rm_stride + (size_t)r0 * st.ldrm, st.ldrm, r1 - r0, n, xs, y1 + r0);
+        if (st.prepared && st.desc.vz_index >= 0 && st.continue_mode != 2) {
+            __syncthreads();
+            const int vz = st.desc.vz_index;
+            for (int i = tid; i < n; i += HT)
+                if (i == vz || (i >= st.desc.vb_start && i < st.desc.vb_start + st.desc.vb_size)) xs[i] = 0.0;
+            __syncthreads();
+            rows_matvec(st.rm_rw + (size_t)b * st.rm_stride + (size_t)r0 * st.ldrm, st.ldrm, r1 - r0, n, xs, y3 + r0);
+        }
+    } else {
+        double* r2 = sm;
+        const double* rv = st.rv + (size_t)b * m;
+        for (int i = tid; i < m; i += HT) { const double r = y1[i] - rv[i]; r2[i] = r * r; }
+        __syncthreads();
+        const int ncu = (st.prepared && st.desc.chrono_vmm_uniform) ? st.desc.num_chrono : 0;
+        if (ncu > 0 && r0 == 0) rows_matvec(st.vmm, m, 1, m, r2, y2);
+        const int a0 = r0 > ncu ? r0 : ncu;
+        if (a0 < r1) rows_matvec(st.vmm + (size_t)a0 * m, m, r1 - a0, m, r2, y2 + a0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // hyper-parameter update + weights + convergence for one outer iteration.  grid = B
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {     // <= 128 VGPRs: two workgroups per CU
@@ -420,7 +476,9 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
     double* tmp2 = tmp + tl;      // [max(m, nd)]
     // [3][2 nd - 1] first columns of the Toeplitz penalty blocks (uniform ln-tau grids), mirrored around index nd - 1
     // so that entry (i, j) is cx[i - j + nd - 1] without an absolute value
-    double* ctp = tmp2 + tl;
+    // (toeplitz_m == 2, large joint fits: they start inside the second m-vector, behind the nd entries the Toeplitz phases use
+    // of it -- the weights phase, which needs all m, comes after the last use of the columns)
+    double* ctp = st.toeplitz_m == 2 ? tmp2 + nd : tmp2 + tl;
     const int cw = 2 * nd - 1;
     const bool tpl = st.toeplitz_m != 0;
     if (tpl) {
@@ -657,7 +715,7 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
     // weights
     double* wg = st.w + (size_t)b * m;
     double* tmp3 = ctp + 3 * cw;       // [2][m], only present (and only touched) when outlier_p is set
-    estimate_weights_dev(st, b, st.vmm, xs, tmp, tmp2, tmp3, tmp3 + m, st.est_w + (size_t)b * m, wg);
+    estimate_weights_dev(st, b, st.vmm, xs, tmp, tmp2, tmp3, tmp3 + m, st.est_w + (size_t)b * m, wg, 0, -1, -1.0, st.premv);
     HPROF(5);
 
     // convergence (qphb.py:597-603, 969-970)
@@ -694,7 +752,8 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
             if (i == vz || (i >= st.desc.vb_start && i < st.desc.vb_start + st.desc.vb_size)) xs[i] = 0.0;
         __syncthreads();
         double* rmb = st.rm_rw + (size_t)b * st.rm_stride;
-        rows_matvec(rmb, st.ldrm, m, n, xs, tmp);
+        if (st.premv) { for (int i = tid; i < m; i += HT) tmp[i] = st.premv[(2 * (size_t)gridDim.x + b) * m + i]; }
+        else rows_matvec(rmb, st.ldrm, m, n, xs, tmp);
         __syncthreads();
         for (int i = tid; i < m; i += HT)
             rmb[(size_t)i * st.ldrm + vz] = (i < st.desc.num_chrono ? tmp[i] : -tmp[i]) * st.vz_strength[i];
@@ -932,13 +991,25 @@ int launch_hyper(hipStream_t s, const FitState& st_in, int B, int it) {
     const size_t extra = st.opts.outlier_p > 0.0 ? 2 * (size_t)st.m * sizeof(double) : 0;
     size_t lds = hyper_lds_bytes(st.n, st.m, st.ns) + extra;
     if (lds > kLdsLimit && st.toeplitz_m && extra == 0) {
-        // large joint fits (config 5: m = 5120, n = 1078): no room for the mirrored Toeplitz columns next to the
-        // m-vectors; the general row-streaming form of the same updates reads the penalty blocks from L2 instead
-        st.toeplitz_m = 0;
-        lds -= 3 * (size_t)(2 * (st.n - st.ns) - 1) * sizeof(double);
+        // large joint fits (config 5: m = 5120, n = 1078): no room for the mirrored Toeplitz columns NEXT to the two
+        // m-vectors -- they share the second one's space (see hyper_kernel); if even that does not fit, the general
+        // row-streaming form of the same updates reads the penalty blocks from L2 instead
+        const size_t nd = (size_t)(st.n - st.ns), tl = (size_t)st.m > nd ? (size_t)st.m : nd, cols = 3 * (2 * nd - 1);
+        const size_t second = tl > nd + cols ? tl : nd + cols;
+        const size_t compact = ((size_t)st.n + 4 * nd + tl + second) * sizeof(double);
+        if (compact <= kLdsLimit) { st.toeplitz_m = 2; lds = compact; }
+        else { st.toeplitz_m = 0; lds -= cols * sizeof(double); }
     }
     if (lds > kLdsLimit) { set_error("hyper-parameter kernel: problem too large for LDS (m, n)"); return HIPDRT_E_INVALID; }
     if (int rc = set_lds(reinterpret_cast<const void*>(hyper_kernel), lds)) return rc;
+    if (st.premv && st.opts.outlier_p <= 0.0) {
+        const size_t l0 = (size_t)st.n * sizeof(double), l1 = (size_t)st.m * sizeof(double);
+        const dim3 grid((st.m + PREMV_ROWS - 1) / PREMV_ROWS, B);
+        hipLaunchKernelGGL(premv_kernel, grid, dim3(HT), l0, s, st, 0, B);
+        hipLaunchKernelGGL(premv_kernel, grid, dim3(HT), l1, s, st, 1, B);
+    } else {
+        st.premv = nullptr;
+    }
     hipLaunchKernelGGL(hyper_kernel, dim3(B), dim3(HT), lds, s, st, it);
     return 0;
 }

@@ -27,7 +27,7 @@ size_t qp_scratch_doubles(int n, int G) {
 }
 size_t qp_gsync_ints() { return GRP_WORDS; }
 
-static int device_cus() {
+int device_cus() {
     static const int cus = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess ||

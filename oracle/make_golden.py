@@ -549,15 +549,16 @@ def run_decimate(DRT, cvxopt):
                                                              decimation_factor=1.5, decimation_max_period=0.05)))
 
 
-def run_config5(DRT, cvxopt, K=12):
+def run_config5(DRT, cvxopt, K=12, v_noise=2e-5, name="refrun_config5_full"):
     """BASELINE configs[4] at FULL size through the reference itself: fit_hybrid with the distribution of phasances, 512
     frequencies + 4096 time samples x 1024 tau (m = 5120 rows, n = 1078 unknowns), the first K outer iterations.  The
     workload is synth.hybrid_measurement(seed=0, n_pre=96, n_post=4000, nf=512, v_noise=2e-5): with 20 uV of voltage noise
     the reference's outer iteration is contractive (step sizes 0.11, 0.03, 0.02, ... 0.01; oracle/probe_c5.py), so the
     iterates are reproducible to rounding and can be pinned tightly -- with the 2 uV of the other fixtures the loop
-    wanders (steps grow again after the sixth iteration) and any two implementations drift apart."""
+    wanders (steps grow again after the sixth iteration) and any two implementations drift apart.  The second fixture
+    (refrun_config5_2uV: v_noise = 2e-6, the bench's own workload, K = 6) pins the iterations before that happens."""
     from hipdrt import synth
-    meas = synth.hybrid_measurement(seed=0, n_pre=96, n_post=4000, nf=512, v_noise=2e-5)
+    meas = synth.hybrid_measurement(seed=0, n_pre=96, n_post=4000, nf=512, v_noise=v_noise)
     log = []
     cvxopt.solvers.options["_oracle_log"] = log
     with _quiet():
@@ -566,17 +567,17 @@ def run_config5(DRT, cvxopt, K=12):
         drt.fit_hybrid(*meas, max_iter=K)
     cvxopt.solvers.options["_oracle_log"] = None
     fp, qp = drt.fit_parameters, drt.qphb_params
-    out = dict(K=K, v_noise=2e-5, qp_iterations=np.array([l["iterations"] for l in log]),
+    out = dict(K=K, v_noise=v_noise, qp_iterations=np.array([l["iterations"] for l in log]),
                hist_x=np.array([h["x"] for h in drt.qphb_history]),
                hist_rho=np.array([h["rho_vector"] for h in drt.qphb_history]),
                hist_dop_rho=np.array([h["dop_rho_vector"] for h in drt.qphb_history]),
                x=fp["x"], x_dop=fp["x_dop"], R_inf=fp["R_inf"], inductance=fp["inductance"], v_baseline=fp["v_baseline"],
                vz_offset=fp["vz_offset"], coefficient_scale=drt.coefficient_scale, rm_shape=np.array(qp["rm"].shape),
                rv=qp["rv"], est_weights=qp["est_weights"], xmx_norms=qp["xmx_norms"], dop_xmx_norms=qp["dop_xmx_norms"])
-    np.savez_compressed(os.path.join(OUT, "refrun_config5_full.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     hx = out["hist_x"]
     steps = np.abs(np.diff(hx, axis=0)).max(axis=1) / np.abs(hx[1:]).max(axis=1)
-    print(f"config5_full: m x n = {qp['rm'].shape}, qp_iters={out['qp_iterations'].tolist()}, steps {np.round(steps, 3).tolist()}")
+    print(f"{name}: m x n = {qp['rm'].shape}, qp_iters={out['qp_iterations'].tolist()}, steps {np.round(steps, 3).tolist()}")
 
 
 def run_posteriors(DRT, freq_g, z_g, default):
@@ -595,6 +596,10 @@ def main():
     if "--only-config5" in sys.argv:
         DRT, cvxopt = _boot_reference()
         run_config5(DRT, cvxopt)
+        return
+    if "--only-config5-2uV" in sys.argv:
+        DRT, cvxopt = _boot_reference()
+        run_config5(DRT, cvxopt, K=int(os.environ.get("C5_K", "6")), v_noise=2e-6, name="refrun_config5_2uV")
         return
     if "--only-decimate" in sys.argv:
         DRT, cvxopt = _boot_reference()

@@ -34,6 +34,6 @@ for G in groups:
     x = np.asarray(d5.cvx_result["x"])
     if ref5 is None:
         ref5 = x.copy()
-    print(f"configs[4] group {G}: {t5:.3f} s wall, device loop {tm['total'] / 1e3:.3f} s (qp {tm['qp'] / 1e3:.3f}), outer "
+    print(f"configs[4] group {G}: {t5:.3f} s wall, device loop {tm['total'] / 1e3:.3f} s (qp {tm['qp'] / 1e3:.3f}, gram {tm['gram'] / 1e3:.3f}, hyper {tm['hyper'] / 1e3:.3f}), outer "
           f"{int(d5.qphb_params['outer_iterations'])}, max |dx|/peak vs first {np.abs(x - ref5).max() / np.abs(ref5).max():.1e}", flush=True)
 ctx.debug_qp_group(-1)

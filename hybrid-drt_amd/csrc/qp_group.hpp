@@ -51,7 +51,9 @@ static constexpr int GRP_RMAXT = 2;                    // tile rows per row wave
                                                        // pass leaves registers for an eight-slot operand ring (below)
 static constexpr int GRP_WORDS = 16 + GRP_OWN;         // ints of global sync state per problem
 // words: [0] members arrived at the start, [1] OR of (1 << XCC id), [2] barrier counter, [3] laprog: factorisation count * 256
-// + block columns whose look-ahead accumulators are in labuf (written by the owner of the column's look-ahead rows)
+// + block columns whose look-ahead accumulators are in labuf (written by the owner of the column's look-ahead rows),
+// [16 + T] rowprog: factorisation count * 256 + block columns of tile row T complete in memory (written by T's owner when T
+// becomes a look-ahead row: the member that accumulates the next look-ahead block reads T as an operand)
 
 // 16 bytes per lane that bypass the CU's vector L1 (written by another CU of the XCD in THIS factorisation after this CU may
 // have read the same addresses: the look-ahead accumulators, whose slots are reused from one factorisation to the next)
@@ -275,21 +277,45 @@ struct OpsGroup : OpsResidentT<true, 512> {
         mult(r0, nk2); mult(r1, nk2); mult(r2, nk2); mult(r3, nk2); mult(r4, nk2); mult(r5, nk2); mult(r6, nk2);   // (pins)
     }
 
-    // The look-ahead accumulators in the owner of rows R2, R3: the seven tiles are products of chunks of FOUR tile rows (tb,
-    // tb+1, R2, R3), so the inner dimension is cut into seven contiguous slices, one per wavefront 1..7, and each wavefront
-    // accumulates all seven tiles over its slice -- every operand chunk is requested once per member (one tile per wavefront
-    // over the whole inner dimension asked for 14 KB per half-chunk instead of 4, at the ~20 bytes per cycle a single CU
-    // draws from beyond its L2: 44k cycles per block column with every other member waiting).  The partial sums are then
-    // added up in LDS in wavefront order (la_reduce): a fixed order, independent of the group size.
+    // The look-ahead accumulators of block column jbn (tile rows R2 = 2 jbn + 2, R3 = R2 + 1 against rows tbn = 2 jbn, tbn + 1
+    // and themselves), in the member that owns R2, R3.  The seven tiles are products of chunks of FOUR tile rows, and a
+    // single CU draws only ~20 bytes per cycle from beyond its L2, so (a) every operand chunk is requested once per member:
+    // the inner dimension is cut into contiguous slices, one per row wavefront 2..7, each accumulating all seven tiles over
+    // its slice, the partial sums added up in LDS in wavefront order (la_reduce: a fixed order, independent of the group
+    // size); and (b) the bulk of it happens ONE BLOCK COLUMN EARLY: during block column jbn - 1 the owner accumulates the
+    // "old range" -- block columns 0 .. jbn - 3, half-chunks [0, 4 (jbn - 2)) -- which needs nothing of the two newest
+    // columns; when column jbn starts only its "new range" (the eight half-chunks of block columns jbn - 2, jbn - 1) is
+    // left, one 32-load step of wavefront 1 (la_new_range), and every other member gets the accumulators while its chain
+    // still works on the diagonal block.  (Accumulated within block column jbn itself, the seven-tile loop was what every
+    // member waited for: 29 k of 46 k cycles per block column at n = 1078.  With the old range reaching up to column
+    // jbn - 2 the owners serialise: each needs the previous owner's newest stores before it can start, 51 k per column.)
     struct LaAcc { v4d p20, p21, p30, p31, e11, e21, e22; };
-    __device__ __forceinline__ void ring_la_slice(int jb, int ntr, int lane, int w, LaAcc& A) const {
+    // old range of la(jbn), slice of row wavefront w = 2..7; called during block column jbn - 1 >= 1
+    __device__ __forceinline__ void ring_la_slice(int jbn, int ntr, int lane, int w, LaAcc& A) const {
         const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
-        const int tb = 2 * jb, nk2 = 4 * jb;
+        const int jb = jbn;                                  // (names as in the formulas above)
+        const int tb = 2 * jb, nk2 = 4 * (jb - 2);
         const bool v3 = tb + 3 < ntr;
-        // rows R2, R3 (this member's own): every tile their row wavefronts ever stored is in memory
-        wait_row(tb + 2, jb);
-        if (v3) wait_row(tb + 3, jb);
-        const int k0 = (w - 1) * nk2 / 7, k1 = w * nk2 / 7, klast = k1 - 1;      // this wavefront's half-chunks
+        // rows R2, R3 (this member's own), complete through block column jbn - 3: their row wavefronts said so
+        wait_row(tb + 2, jb - 2);
+        if (v3) wait_row(tb + 3, jb - 2);
+        // rows tbn, tbn + 1: the look-ahead rows of the column in progress, another member's in general -- through block
+        // column jbn - 3 their owner published them a whole block column ago
+        if (mine(tb)) {
+            wait_row(tb, jb - 2);
+            wait_row(tb + 1, jb - 2);
+        } else {
+            const int want = prog_value(jb - 2);
+            for (int spins = 0;; ) {
+                const int a_ = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&gs[16 + tb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const int b_ = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&gs[16 + tb + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (a_ >= want && b_ >= want) break;
+                __builtin_amdgcn_s_sleep(1);
+                trap_if(++spins > kSpinLimit);
+            }
+            asm volatile("" ::: "memory");
+        }
+        const int k0 = (w - 2) * nk2 / 6, k1 = (w - 1) * nk2 / 6, klast = k1 - 1;      // this wavefront's half-chunks
         if (k1 <= k0) return;
         const char* r0p = uniform_ptr(tile2(tb, 0));
         const char* r1p = uniform_ptr(tile2(tb + 1, 0));
@@ -325,9 +351,6 @@ struct OpsGroup : OpsResidentT<true, 512> {
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // the newest two chunks of rows tb, tb+1 (half-chunks nk2-4 ..) come from this member's wavefront 1, stored in the
-        // previous block column: only a slice that reaches them waits
-        if (k1 > nk2 - 4) wait_diag_rows(tb, true, jb);
         constexpr int NS = 8;
         Sl r[NS];
 #pragma unroll
@@ -344,8 +367,64 @@ struct OpsGroup : OpsResidentT<true, 512> {
 #pragma unroll
         for (int i_ = 0; i_ < NS; ++i_) mult(r[i_], k1);       // (pins)
     }
-    // Partial sums -> LDS, added in wavefront order 1, 2, .. 7 (wavefront 1 starts from the source tiles).  `base` = 7 x the
-    // block columns this member accumulated before this one: lacnt counts the additions of the whole factorisation.
+    // new range of la(jb) on top of the totals (wavefront 1 of the owner, at the start of block column jb): the half-chunks
+    // of block columns jb - 2 and jb - 1.  The newest tiles this member stored itself a moment ago (rows tb, tb+1: this
+    // wavefront's panel store; R2, R3: its row wavefronts'); those of rows tb, tb+1 in column jb - 2 their owner stored before
+    // it published the look-ahead accumulators this member fetched in the previous block column.
+    // four half-chunks of the four rows: sixteen loads in flight, then 56 MFMAs
+    struct LaChunk4 { v2d c[4][4]; };
+    __device__ __forceinline__ void la_load4(LaChunk4& q, const char* const (&rp)[4], int k0, unsigned voff) const {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q.c[h][r] = gload16(uniform_ptr(rp[r] + (size_t)(k0 + h) * 1024), voff);
+    }
+    static __device__ __forceinline__ void la_mult4(const LaChunk4& q, LaAcc& A) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].x, q.c[h][2].x, A.p20, 0, 0, 0);
+            A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].x, q.c[h][2].x, A.p21, 0, 0, 0);
+            A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].x, q.c[h][3].x, A.p30, 0, 0, 0);
+            A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].x, q.c[h][3].x, A.p31, 0, 0, 0);
+            A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].x, q.c[h][2].x, A.e11, 0, 0, 0);
+            A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].x, q.c[h][3].x, A.e21, 0, 0, 0);
+            A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][3].x, q.c[h][3].x, A.e22, 0, 0, 0);
+            A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].y, q.c[h][2].y, A.p20, 0, 0, 0);
+            A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].y, q.c[h][2].y, A.p21, 0, 0, 0);
+            A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].y, q.c[h][3].y, A.p30, 0, 0, 0);
+            A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].y, q.c[h][3].y, A.p31, 0, 0, 0);
+            A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].y, q.c[h][2].y, A.e11, 0, 0, 0);
+            A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].y, q.c[h][3].y, A.e21, 0, 0, 0);
+            A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][3].y, q.c[h][3].y, A.e22, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void la_new_range(int jb, int ntr, int lane, LaAcc& A) const {
+        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+        const int tb = 2 * jb;
+        const bool v3 = tb + 3 < ntr;
+        wait_row(tb + 2, jb);
+        if (v3) wait_row(tb + 3, jb);
+        wait_diag_rows(tb, true, jb);
+        const char* const rp[4] = {uniform_ptr(tile2(tb, 0)), uniform_ptr(tile2(tb + 1, 0)), uniform_ptr(tile2(tb + 2, 0)),
+                                   uniform_ptr(tile2(v3 ? tb + 3 : tb + 2, 0))};
+        const unsigned voff = (unsigned)fo * 16u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // block column jb - 2 first (same order of summation as one pass over the inner dimension), then block column jb - 1
+        // through the same sixteen registers (both in flight at once spills: this wavefront also carries the seven
+        // accumulators through the panel solve)
+        LaChunk4 qa;
+#pragma unroll 1
+        for (int c_ = jb >= 2 ? jb - 2 : 0; c_ < jb; ++c_) {
+            la_load4(qa, rp, 4 * c_, voff);
+            vm_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            la_mult4(qa, A);
+        }
+    }
+    // Old-range partial sums -> LDS, in wavefront order: wavefront 1 writes the source tiles (init), wavefronts 2 .. 7 add
+    // theirs.  `base` = 7 x the old ranges this member accumulated before this one: lacnt counts the whole factorisation's.
     __device__ __forceinline__ void la_reduce(int lane, int w, int base, const LaAcc& A, const LaAcc* init) const {
         for (int spins = 0; lds_peek32(lacnt) < base + (w - 1);) {
             __builtin_amdgcn_s_sleep(1);
@@ -487,27 +566,44 @@ struct OpsGroup : OpsResidentT<true, 512> {
                     e22 = init_tile(R3, R3, ntr, fo, li, kq);
                 } else {
                     const bool la = la_owner(jb);
+                    // (order: this member's finished old-range totals out of LDS first -- the buffer is about to be reused --,
+                    // then the source tiles of the NEXT look-ahead block into it if this member accumulates that one, so that its
+                    // row wavefronts never wait for what follows: the new range and the publication, or the owner's accumulators)
+                    LaAcc T_;
                     if (la) {
-                        // this wavefront's slice of the inner dimension on top of the source tiles, then the other six wavefronts'
-                        LaAcc I_, A_;
-                        A_.p20 = A_.p21 = A_.p30 = A_.p31 = A_.e11 = A_.e21 = A_.e22 = (v4d){0, 0, 0, 0};
-                        ring_la_slice(jb, ntr, lane, 1, A_);
-                        __builtin_amdgcn_sched_barrier(0);           // (the source tiles only after the ring's registers are free)
-                        I_.p20 = init_tile(R2, tb, ntr, fo, li, kq);      I_.p21 = init_tile(R2, tb + 1, ntr, fo, li, kq);
-                        I_.p30 = init_tile(R3, tb, ntr, fo, li, kq);      I_.p31 = init_tile(R3, tb + 1, ntr, fo, li, kq);
-                        I_.e11 = init_tile(R2, R2, ntr, fo, li, kq);      I_.e21 = init_tile(R3, R2, ntr, fo, li, kq);
-                        I_.e22 = init_tile(R3, R3, ntr, fo, li, kq);
-                        la_reduce(lane, 1, 7 * laown, A_, &I_);
-                        PROFW(21);
-                        ++laown;
-                        for (int spins = 0; lds_peek32(lacnt) < 7 * laown;) {
-                            __builtin_amdgcn_s_sleep(1);
-                            trap_if(++spins > kSpinLimit);
+                        // the old range was summed up in LDS during the previous block column (jb < 3: there is none, the
+                        // totals are the source tiles); the new range on top of it
+                        if (jb >= 3) {
+                            for (int spins = 0; lds_peek32(lacnt) < 7 * laown;) {
+                                __builtin_amdgcn_s_sleep(1);
+                                trap_if(++spins > kSpinLimit);
+                            }
+                            asm volatile("" ::: "memory");
+                            const v4d* lt = reinterpret_cast<const v4d*>(latile) + lane;
+                            T_.p20 = lt[0]; T_.p21 = lt[64]; T_.p30 = lt[128]; T_.p31 = lt[192];
+                            T_.e11 = lt[256]; T_.e21 = lt[320]; T_.e22 = lt[384];
+                        } else {
+                            T_.p20 = init_tile(R2, tb, ntr, fo, li, kq);      T_.p21 = init_tile(R2, tb + 1, ntr, fo, li, kq);
+                            T_.p30 = init_tile(R3, tb, ntr, fo, li, kq);      T_.p31 = init_tile(R3, tb + 1, ntr, fo, li, kq);
+                            T_.e11 = init_tile(R2, R2, ntr, fo, li, kq);      T_.e21 = init_tile(R3, R2, ntr, fo, li, kq);
+                            T_.e22 = init_tile(R3, R3, ntr, fo, li, kq);
                         }
-                        asm volatile("" ::: "memory");
+                    }
+                    if (jb >= 2 && tb + 4 < ntr && la_owner(jb + 1)) {
+                        LaAcc I_, Z_;
+                        Z_.p20 = Z_.p21 = Z_.p30 = Z_.p31 = Z_.e11 = Z_.e21 = Z_.e22 = (v4d){0, 0, 0, 0};
+                        I_.p20 = init_tile(R2 + 2, tb + 2, ntr, fo, li, kq);   I_.p21 = init_tile(R2 + 2, tb + 3, ntr, fo, li, kq);
+                        I_.p30 = init_tile(R3 + 2, tb + 2, ntr, fo, li, kq);   I_.p31 = init_tile(R3 + 2, tb + 3, ntr, fo, li, kq);
+                        I_.e11 = init_tile(R2 + 2, R2 + 2, ntr, fo, li, kq);   I_.e21 = init_tile(R3 + 2, R2 + 2, ntr, fo, li, kq);
+                        I_.e22 = init_tile(R3 + 2, R3 + 2, ntr, fo, li, kq);
+                        la_reduce(lane, 1, 7 * laown, Z_, &I_);
+                        ++laown;
+                    }
+                    if (la) {
+                        PROFW(21);
+                        la_new_range(jb, ntr, lane, T_);
                         PROFW(22);
-                        const v4d* lt = reinterpret_cast<const v4d*>(latile) + lane;
-                        p20 = lt[0]; p21 = lt[64]; p30 = lt[128]; p31 = lt[192]; e11 = lt[256]; e21 = lt[320]; e22 = lt[384];
+                        p20 = T_.p20; p21 = T_.p21; p30 = T_.p30; p31 = T_.p31; e11 = T_.e11; e21 = T_.e21; e22 = T_.e22;
                         if (G > 1) {
                             // publish the seven raw accumulators (register images) for the other members
                             v4d* dst = reinterpret_cast<v4d*>(labuf + (size_t)jb * 7 * 256) + lane;
@@ -626,20 +722,25 @@ struct OpsGroup : OpsResidentT<true, 512> {
             PROF_DECL
             if (jb > 0) {
                 // everything this wavefront stored in the previous block column is in memory (the wait also covers the source
-                // tiles requested after those stores).  The only rows another wavefront reads next are tb + 2 and tb + 3 -- the
-                // look-ahead rows from now on, read by the wavefronts of this same member (their owner): tell them
+                // tiles requested after those stores).  The rows somebody else reads next: tb + 2, tb + 3 (the look-ahead rows
+                // from now on: wavefront 1 of this member, and the member that accumulates the NEXT look-ahead block, through
+                // the global word) and tb + 4, tb + 5 (this member's own old-range pass below)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane < 2) {
+                if (lane < 4) {
                     const int T = tb + 2 + lane;
-                    if (T < ntr && owner[T] == wv) rowdone[T] = (unsigned char)jb;
+                    if (T < ntr && owner[T] == wv) {
+                        rowdone[T] = (unsigned char)jb;
+                        if (G > 1) __hip_atomic_store(&gs[16 + T], prog_value(jb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             if (wv == 2) PROFW(26);
-            // this wavefront's look-ahead tile first (in the owner of the look-ahead rows: everybody else waits for them)
-            if (jb > 0 && tb + 2 < ntr && la_owner(jb)) {
+            // the old range of the NEXT block column's look-ahead accumulators, if this member owns those rows: this
+            // wavefront's slice, added to the sums in LDS (ring_la_slice)
+            if (jb >= 2 && tb + 4 < ntr && la_owner(jb + 1)) {
                 LaAcc A_;
                 A_.p20 = A_.p21 = A_.p30 = A_.p31 = A_.e11 = A_.e21 = A_.e22 = (v4d){0, 0, 0, 0};
-                ring_la_slice(jb, ntr, lane, wv, A_);
+                ring_la_slice(jb + 1, ntr, lane, wv, A_);
                 la_reduce(lane, wv, 7 * laown, A_, nullptr);
                 ++laown;
             }

@@ -35,6 +35,9 @@ for G in [int(a) for a in sys.argv[3:]] or [1, 2, 4, 8, -1]:
               "clock %.2f GHz" % (prof[10] / max(prof[13], 1) * 0.1))
         w = {20: "w1 drain+publish", 21: "w1 own tile", 22: "w1 wait tiles", 23: "w1 wait (A)", 24: "w1 (A)->(A2)",
              26: "w2 drain+publish", 27: "w2 la tile", 28: "w2 own rows", 29: "w2 wait (A)", 30: "w2 (A)->end"}
+        if prof[31] or prof[33]:
+            print("  wavefront 1 of WG0 as look-ahead owner, k cycles per factorisation: source tiles + segments %d, wait for own row stores %d, new range %d, publish %d"
+                  % (prof[31] // nf // 1000, prof[32] // nf // 1000, prof[33] // nf // 1000, prof[34] // nf // 1000))
         if prof[36]:
             print("  wavefront 2's staged loop: %d super-steps per factorisation; cycles per super-step: wait loads %d, barrier %d, issue %d, compute %d"
                   % (prof[36] // nf, prof[32] // prof[36], prof[33] // prof[36], prof[34] // prof[36], prof[35] // prof[36]))

@@ -86,12 +86,28 @@ def _pool_init(freq, tau, z):
 def _pool_work(args):
     first, stride, budget = args
     drt, freq, z = _POOL["drt"], _POOL["freq"], _POOL["z"]
-    done, t0, i = 0, time.perf_counter(), first
+    done, t0, c0, i = 0, time.perf_counter(), time.process_time(), first
     while time.perf_counter() - t0 < budget:
         drt.fit_eis(freq, z[i % len(z)], structure='fast')
         done += 1
         i += stride
-    return done, time.perf_counter() - t0, _blas_threads()
+    # (CPU seconds this worker was actually given, next to its wall time: a quota or an oversubscribed host shows up here)
+    return done, time.perf_counter() - t0, _blas_threads(), time.process_time() - c0
+
+
+def cgroup_cpu_limit():
+    """CPU bandwidth limit of this container in cores (cgroup v2 cpu.max or v1 cfs quota), or None when unlimited / unknown"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
 
 
 def host_cores():
@@ -120,7 +136,7 @@ def host_cores():
     return min(physical, logical), logical
 
 
-def cpu_baseline(freq, tau, z, seconds_budget=15.0, ref_structure_budget=8.0, procs=None, pool_budget=8.0):
+def cpu_baseline(freq, tau, z, seconds_budget=15.0, ref_structure_budget=8.0, procs=None, pool_budget=6.0):
     """The oracle timed on this host BEFORE the GPU is touched (the pool forks): (i) one process, one BLAS thread;
     (ii) the whole host: process pools over spectra, one single-threaded worker each, swept over
     {physical cores / 2, physical cores, logical cpus} workers -- the best is reported with its count and every point of
@@ -143,7 +159,7 @@ def cpu_baseline(freq, tau, z, seconds_budget=15.0, ref_structure_budget=8.0, pr
     rdone, rdt = timed('reference', ref_structure_budget)
     one_core = done / dt
     physical, logical = host_cores()
-    counts = sorted({max(1, physical // 2), physical, logical}) if not procs else [min(procs, logical)]
+    counts = sorted({min(8, logical), min(32, logical), max(1, physical // 2), physical, logical}) if not procs else [min(procs, logical)]
     sweep, allc = [], None
     ctx = mp.get_context("fork")            # nothing GPU-side exists yet in this process; children never touch it
     for n_workers in counts:
@@ -156,6 +172,7 @@ def cpu_baseline(freq, tau, z, seconds_budget=15.0, ref_structure_budget=8.0, pr
             wall = max(p[1] for p in parts)
             sweep.append(dict(workers=n_workers, value=fits / wall, fits=fits, seconds=wall, pool_startup_s=t_up,
                               per_worker_vs_one_core=fits / wall / n_workers / one_core,
+                              cpu_seconds_over_wall=sum(p[3] for p in parts) / sum(p[1] for p in parts),
                               worker_blas_threads=sorted({p[2] for p in parts})))
         except Exception as e:          # noqa: BLE001 -- a box that cannot fork that many workers still reports the rest
             sweep.append(dict(workers=n_workers, value=None, error=repr(e)))
@@ -163,12 +180,16 @@ def cpu_baseline(freq, tau, z, seconds_budget=15.0, ref_structure_budget=8.0, pr
     if good:
         best = max(good, key=lambda s_: s_["value"])
         allc = dict(value=best["value"], unit="fits/s", cores=best["workers"], kind="port",
-                    physical_cores=physical, logical_cpus=logical, sweep=sweep,
+                    physical_cores=physical, logical_cpus=logical, cgroup_cpu_limit=cgroup_cpu_limit(), sweep=sweep,
                     efficiency_vs_cores=best["value"] / (min(best["workers"], physical) * one_core),
                     sample=f"{best['fits']} fits of the batch's spectra in {best['seconds']:.1f} s: {best['workers']} forked worker "
                            f"processes, BLAS threads per worker {best['worker_blas_threads']} (OMP/OPENBLAS/MKL_NUM_THREADS=1 set "
                            f"before numpy was imported), every worker looping over its own stride of the batch; host has "
-                           f"{physical} physical cores / {logical} logical cpus; pool start-up not counted")
+                           f"{physical} physical cores / {logical} logical cpus; pool start-up not counted; per sweep point "
+                           f"`cpu_seconds_over_wall` = CPU time the workers were given / their wall time (1.0 = every worker had "
+                           f"a core to itself the whole time: then the loss against workers x the 1-core figure is contention "
+                           f"for caches and memory bandwidth -- a fit streams its 2 MB P and L through several O(n^2) numpy passes "
+                           f"per interior-point iteration --, not scheduling)")
     else:
         allc = dict(value=None, unit="fits/s", cores=0, kind="port", sweep=sweep, sample="every process pool failed")
     return dict(value=one_core, unit="fits/s", cores=1, kind="port",

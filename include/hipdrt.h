@@ -29,8 +29,9 @@ extern "C" {
 #define HIPDRT_QP_MAXITER 1     /* maxiters reached (cvxopt status 'unknown')                      */
 #define HIPDRT_QP_SINGULAR_LATE 2 /* Cholesky breakdown after iteration 0: cvxopt returns current x */
 #define HIPDRT_QP_SINGULAR (-1) /* breakdown at the start point: cvxopt raises ValueError          */
-#define HIPDRT_QP_ABORTED (-2)  /* a large problem split over several workgroups gave up waiting for its partners (the
-                                   device was not exclusively ours); the result is not valid           */
+#define HIPDRT_QP_ABORTED (-2)  /* internal to the several-workgroups-per-problem kernel: the workgroups of this problem were
+                                   not placed on one XCD; the launcher repeats such a problem on one workgroup before it
+                                   returns, so a caller sees this only if that repeat could not run     */
 
 #define HIPDRT_MODE_INTERP 0    /* integrate_method='interp' (drtbase.py:155)  */
 #define HIPDRT_MODE_TRAPZ 1     /* integrate_method='trapz'  (drtbase.py:159)  */
@@ -142,7 +143,9 @@ typedef struct {
 /* cvxopt.solvers.qp(P, q, G=-I, h) as called from qphb.solve_convex_opt (hybdrt/models/qphb.py:512-519):
  * B independent problems min 1/2 x'Px + q'x s.t. -x <= h, solved with coneqp's trajectory.
  * P[B or 1][n][n] (p_batched selects; only the lower triangle is read), q[B][n], h[B or 1][n].
- * out: x[B][n], iters[B], pcost[B] ('primal objective'), status[B]                                    */
+ * out: x[B][n], iters[B], pcost[B] ('primal objective'), status[B]
+ * n <= 4096.  Many problems: one workgroup each (n <= 2048).  Few problems (B <= #CUs / 16, n > 256) or n > 2048: every
+ * problem on up to 32 co-resident workgroups of one XCD; same iteration counts, x equal to rounding.   */
 int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* P, const double* q,
                     int h_batched, const double* h, const hipdrt_qp_opts* opts,
                     double* x, int* iters, double* pcost, int* status);

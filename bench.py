@@ -159,7 +159,15 @@ def cpu_baseline(freq, tau, z, seconds_budget=15.0, ref_structure_budget=8.0, pr
     rdone, rdt = timed('reference', ref_structure_budget)
     one_core = done / dt
     physical, logical = host_cores()
-    counts = sorted({min(8, logical), min(32, logical), max(1, physical // 2), physical, logical}) if not procs else [min(procs, logical)]
+    quota = cgroup_cpu_limit()                       # CPU bandwidth this container may use, in cores (None = no limit)
+    if procs:
+        counts = [min(procs, logical)]
+    elif quota and quota < physical:
+        # a container with a CPU quota: more runnable workers than the quota only take turns -- sweep around the quota
+        q = max(1, int(round(quota)))
+        counts = sorted({max(1, q // 2), q, min(2 * q, logical), min(4 * q, logical)})
+    else:
+        counts = sorted({min(8, logical), min(32, logical), max(1, physical // 2), physical, logical})
     sweep, allc = [], None
     ctx = mp.get_context("fork")            # nothing GPU-side exists yet in this process; children never touch it
     for n_workers in counts:
@@ -179,13 +187,15 @@ def cpu_baseline(freq, tau, z, seconds_budget=15.0, ref_structure_budget=8.0, pr
     good = [s_ for s_ in sweep if s_.get("value")]
     if good:
         best = max(good, key=lambda s_: s_["value"])
-        allc = dict(value=best["value"], unit="fits/s", cores=best["workers"], kind="port",
-                    physical_cores=physical, logical_cpus=logical, cgroup_cpu_limit=cgroup_cpu_limit(), sweep=sweep,
-                    efficiency_vs_cores=best["value"] / (min(best["workers"], physical) * one_core),
+        eff_cores = min(best["workers"], physical, quota) if quota else min(best["workers"], physical)
+        allc = dict(value=best["value"], unit="fits/s", cores=best["workers"], kind="port", cores_available=eff_cores,
+                    physical_cores=physical, logical_cpus=logical, cgroup_cpu_limit=quota, sweep=sweep,
+                    efficiency_vs_cores=best["value"] / (eff_cores * one_core),
                     sample=f"{best['fits']} fits of the batch's spectra in {best['seconds']:.1f} s: {best['workers']} forked worker "
                            f"processes, BLAS threads per worker {best['worker_blas_threads']} (OMP/OPENBLAS/MKL_NUM_THREADS=1 set "
                            f"before numpy was imported), every worker looping over its own stride of the batch; host has "
-                           f"{physical} physical cores / {logical} logical cpus; pool start-up not counted; per sweep point "
+                           f"{physical} physical cores / {logical} logical cpus, cgroup CPU limit {quota} cores (`cores_available` = what "
+                           f"the best pool could actually use; `efficiency_vs_cores` is against that); pool start-up not counted; per sweep point "
                            f"`cpu_seconds_over_wall` = CPU time the workers were given / their wall time (1.0 = every worker had "
                            f"a core to itself the whole time: then the loss against workers x the 1-core figure is contention "
                            f"for caches and memory bandwidth -- a fit streams its 2 MB P and L through several O(n^2) numpy passes "

@@ -43,7 +43,21 @@ struct hipdrt_plan {
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
     DevBuf premv;          // [3][capacity][m]: hyper-parameter step of few, large fits (hyper.hip, premv_kernel)
     DevBuf L, Ptmp, qpstate, Ppk, order, vmm_base, gsync;
-    int qp_G = 0;           // workgroups per QP (qp_group_size at the plan's capacity): 0 = the batch kernel
+    int qp_G = 0;           // workgroups per QP when the plan is full (qp_group_size at its capacity): 0 = the batch kernel
+    // The kernel is chosen per fit from the number of spectra actually staged: a plan sized for a thousand spectra that is
+    // handed one or a handful runs them on several workgroups each, inside the scratch it already has.
+    void qp_layout(int B, QpArgs& qa) const {
+        int G = qp_group_size(B, n);
+        const size_t have_l = L.bytes / sizeof(double), have_s = qpstate.bytes / sizeof(double);
+        if (G >= 1 && G != qp_G) {
+            const bool fits = gsync.p && (size_t)B * qp_scratch_doubles(n, G) <= have_l &&
+                              (size_t)B * G * qp_state_doubles(n) <= have_s && (size_t)B * qp_gsync_ints() * sizeof(int) <= gsync.bytes;
+            if (!fits) G = qp_G;
+        } else if (G < 1) {
+            G = qp_G;            // (a plan created for few spectra keeps its group layout when it is full)
+        }
+        qa.G = G; qa.gsync = gsync.i(); qa.l_stride = (long long)qp_scratch_doubles(n, G);
+    }
     // history
     int hist_b = -1, hist_cap = 0;
     DevBuf hist_x, hist_w, hist_rho, hist_qp, hist_rows;
@@ -588,7 +602,7 @@ static int plan_alloc_batch(hipdrt_plan* p) {
     HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n, p->qp_G) * sizeof(double)));
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));
     HIPDRT_CHECK(p->qpstate.alloc(cap * (p->qp_G > 1 ? p->qp_G : 1) * qp_state_doubles(n) * sizeof(double)));
-    if (p->qp_G >= 1) HIPDRT_CHECK(p->gsync.alloc(cap * qp_gsync_ints() * sizeof(int)));
+    HIPDRT_CHECK(p->gsync.alloc(cap * qp_gsync_ints() * sizeof(int)));
     HIPDRT_CHECK(p->Ppk.alloc(cap * qp_ppk_doubles(n) * sizeof(double)));
     HIPDRT_CHECK(p->order.alloc(cap * sizeof(int)));
     if (p->opts.outlier_p > 0.0) {
@@ -924,8 +938,8 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
 
     QpArgs qa{};
     qa.B = B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
-    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n, p->qp_G);
-    qa.G = p->qp_G; qa.gsync = p->gsync.i();
+    qa.L = p->L.d(); qa.ldl = p->ldl;
+    p->qp_layout(B, qa);
     qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
     qa.iters_accum = p->qp_iters_total.i(); qa.opts = p->opts.qp;
     qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);
@@ -1109,8 +1123,8 @@ static QpArgs loop_qp_args(hipdrt_plan* p, const hipdrt_qp_opts& qpo) {
     const int n = p->n;
     QpArgs qa{};
     qa.B = p->B; qa.n = n; qa.ldp = p->ldp; qa.q = p->q.d(); qa.h = p->h.d(); qa.h_stride = 0;
-    qa.L = p->L.d(); qa.ldl = p->ldl; qa.l_stride = (long long)qp_scratch_doubles(n, p->qp_G);
-    qa.G = p->qp_G; qa.gsync = p->gsync.i();
+    qa.L = p->L.d(); qa.ldl = p->ldl;
+    p->qp_layout(p->B, qa);
     qa.x = p->x.d(); qa.iters = p->qp_iters.i(); qa.pcost = p->pcost.d(); qa.status = p->qp_status.i();
     qa.iters_accum = p->qp_iters_total.i(); qa.opts = qpo;
     qa.state = p->qpstate.d(); qa.state_ld = qp_state_ld(n); qa.state_stride = (long long)qp_state_doubles(n);

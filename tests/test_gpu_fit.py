@@ -567,3 +567,21 @@ def test_config4_ten_thousand_spectra_through_the_sharded_driver():
         assert res["qp_iters_total"][b] == sum(l["iterations"] for l in od.qp_log), b
         close_to_peak(obs_x[b], ofp["x"])
         np.testing.assert_allclose(obs_special["R_inf"][b], ofp["R_inf"], rtol=1e-7)
+
+
+def test_kernel_choice_follows_the_staged_batch_not_the_plan_capacity():
+    """A plan sized for 40 spectra that is then handed ONE runs that fit on the several-workgroups kernel, inside the scratch it
+    already has: the same bits as a fresh single-spectrum plan gives (both few-problem launches; C2 grid, n = 514), the same
+    iteration counts as the spectrum had inside the batch of 40 (one workgroup per problem there), x equal to rounding."""
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    c2 = synth.config_c2()
+    z = synth.zarc2_batch(c2["freq"], 40, first_seed=900)
+    big = DRT(fixed_basis_tau=c2["tau"])
+    res40 = big.fit_eis_batch(c2["freq"], z)
+    res1 = big.fit_eis_batch(c2["freq"], z[7:8])             # same plan, one spectrum staged
+    fresh = DRT(fixed_basis_tau=c2["tau"]).fit_eis_batch(c2["freq"], z[7:8])
+    np.testing.assert_array_equal(res1["x"], fresh["x"])
+    assert res1["outer_iters"][0] == fresh["outer_iters"][0] == res40["outer_iters"][7]
+    assert res1["qp_iters_total"][0] == res40["qp_iters_total"][7]
+    close_to_peak(res1["x"][0], res40["x"][7], tol=1e-10)

@@ -781,7 +781,9 @@ def test_parameter_variances_of_a_joint_fit():
     var, ok = drt.estimate_param_var_batch()
     assert ok[0]
     ref = np.diag(np.linalg.inv(fp["p_matrix"])) * drt.coefficient_scale ** 2
-    np.testing.assert_allclose(var[0], ref, rtol=1e-6)@pytest.mark.gpu
+    np.testing.assert_allclose(var[0], ref, rtol=1e-6)
+
+
 def test_config5_bench_workload_first_outer_iterations():
     """The bench's own configs[4] workload (2 uV of voltage noise) against the reference itself, for the
     outer iterations in which the reference is still reproducible: tests/golden/refrun_config5_2uV.npz (oracle/make_golden.py
@@ -808,6 +810,3 @@ def test_config5_bench_workload_first_outer_iterations():
     np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in drt.qphb_history]), g["hist_dop_rho"], rtol=1e-5)
     np.testing.assert_allclose(fp["x"], g["x"], rtol=0, atol=1e-6 * np.abs(g["x"]).max())
     np.testing.assert_allclose(fp["x_dop"], g["x_dop"], rtol=0, atol=1e-6 * np.abs(g["x_dop"]).max())
-
-
-

@@ -955,7 +955,7 @@ struct OpsResidentT {
                         // more tile rows below than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
                         // from memory, four tile rows per round -- their sixteen loads are requested together, so a round costs
                         // one memory round trip instead of four
-                        constexpr int OVR = (GU && HIPDRT_QP_OVR) ? 4 : 1;       // (n <= 528 never gets here: no registers spent on it)
+                        constexpr int OVR = (GU && HIPDRT_QP_OVR > 1) ? HIPDRT_QP_OVR : 1;       // (n <= 528 never gets here: no registers spent on it)
                         for (int tt0 = (wv - 1) + FT * UW; tt0 < tbelow; tt0 += OVR * UW) {
                             double2 t_[OVR][4];
 #pragma unroll
@@ -1088,7 +1088,7 @@ struct OpsResidentT {
                     {
                         // more finished chunks than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
                         // from memory, four chunks per round (sixteen loads requested together: one round trip per round)
-                        constexpr int OVR = (GU && HIPDRT_QP_OVR) ? 4 : 1;
+                        constexpr int OVR = (GU && HIPDRT_QP_OVR > 1) ? HIPDRT_QP_OVR : 1;
                         for (int c0 = (wv - 1) + BC * UW; c0 < nc; c0 += OVR * UW) {
                             double2 t_[OVR][4];
 #pragma unroll

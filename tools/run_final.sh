@@ -4,3 +4,5 @@ bash tools/collect_profiles.sh $T
 timeout 900 python bench.py --config c4 --no-cpu-baseline --no-other-configs > $O/bench_${T}_c4.json 2> $O/bench_${T}_c4.err; tail -1 $O/bench_${T}_c4.json | cut -c1-300
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --backend gloo --config c4 --total 2000 --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > $O/bench_${T}_gloo2.json 2> $O/bench_${T}_gloo2.err; tail -1 $O/bench_${T}_gloo2.json | cut -c1-400
 timeout 600 python tools/probe_single.py 0 -1 2>&1 | grep -v "Extension modules" > $O/${T}_single.txt; cat $O/${T}_single.txt
+bash tools/pmc_sq_collect.sh $T > /dev/null 2>&1; tail -25 $O/${T}_pmc_sq_summary.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -881,22 +881,33 @@ struct OpsResidentT {
         if (wv == 0) {
             // ======== wavefront 0: multiply by the inverse 32x32 diagonal blocks ================================
             const int r = lane & 31;
+            // U in global memory (GU): this lane's row of the NEXT inverse block is requested while the updaters work on the
+            // current one (32 strided 8-byte loads per lane, an L2 round trip that used to sit on the sweep's critical path)
+            double mr[NB];
+            if (GU) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) mr[c] = U[(size_t)r * PLD + c];
+            }
             for (int jb = 0; jb < nblk; ++jb) {          // forward: y = M b (upper-right 16x16 of M is zero)
                 const int j0 = jb * NB;
                 const double* Mr = U + (size_t)(j0 + r) * PLD;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
                 for (int c = 0; c < NB; c += 4) {
-                    s0 += Mr[c] * vec[j0 + c];
-                    s1 += Mr[c + 1] * vec[j0 + c + 1];
-                    s2 += Mr[c + 2] * vec[j0 + c + 2];
-                    s3 += Mr[c + 3] * vec[j0 + c + 3];
+                    s0 += (GU ? mr[c] : Mr[c]) * vec[j0 + c];
+                    s1 += (GU ? mr[c + 1] : Mr[c + 1]) * vec[j0 + c + 1];
+                    s2 += (GU ? mr[c + 2] : Mr[c + 2]) * vec[j0 + c + 2];
+                    s3 += (GU ? mr[c + 3] : Mr[c + 3]) * vec[j0 + c + 3];
                 }
                 const double y = (s0 + s1) + (s2 + s3);
                 __builtin_amdgcn_wave_barrier();
                 if (lane < NB) vec[j0 + lane] = y;
                 lds_barrier();
                 PROF(5);
+                if (GU && jb + 1 < nblk) {
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) mr[c] = Mr[(size_t)NB * PLD + c];
+                }
                 lds_barrier();
                 PROF(6);
             }
@@ -1016,22 +1027,31 @@ struct OpsResidentT {
         if (wv == 0) {
             // ======== wavefront 0: multiply by the inverse 32x32 diagonal blocks ================================
             const int r = lane & 31;
+            double mc[NB];                               // (GU: this lane's column of the next block, one block ahead: see forward())
+            if (GU) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) mc[q] = U[((size_t)(nblk - 1) * NB + q) * PLD + r];
+            }
             for (int jb = nblk - 1; jb >= 0; --jb) {     // backward: x = M' y, lane = column of M
                 const int j0 = jb * NB;
                 const double* Mc = U + (size_t)j0 * PLD + r;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
                 for (int q = 0; q < NB; q += 4) {
-                    s0 += Mc[(size_t)q * PLD] * vec[j0 + q];
-                    s1 += Mc[(size_t)(q + 1) * PLD] * vec[j0 + q + 1];
-                    s2 += Mc[(size_t)(q + 2) * PLD] * vec[j0 + q + 2];
-                    s3 += Mc[(size_t)(q + 3) * PLD] * vec[j0 + q + 3];
+                    s0 += (GU ? mc[q] : Mc[(size_t)q * PLD]) * vec[j0 + q];
+                    s1 += (GU ? mc[q + 1] : Mc[(size_t)(q + 1) * PLD]) * vec[j0 + q + 1];
+                    s2 += (GU ? mc[q + 2] : Mc[(size_t)(q + 2) * PLD]) * vec[j0 + q + 2];
+                    s3 += (GU ? mc[q + 3] : Mc[(size_t)(q + 3) * PLD]) * vec[j0 + q + 3];
                 }
                 const double xv = (s0 + s1) + (s2 + s3);
                 __builtin_amdgcn_wave_barrier();
                 if (lane < NB) vec[j0 + lane] = xv;
                 lds_barrier();
                 PROF(7);
+                if (GU && jb > 0) {
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) mc[q] = U[((size_t)(j0 - NB) + q) * PLD + r];
+                }
                 lds_barrier();
                 PROF(8);
             }

@@ -64,6 +64,14 @@ int qp_group_size(int B, int n) {
     return G >= 2 ? G : 1;
 }
 
+#ifdef HIPDRT_GRP_TIMELINE
+}  // namespace hipdrt
+extern "C" int hipdrt_debug_group_timeline(unsigned long long* out) {      // [32 members][8 wavefronts][10 stamps] + [32] owner flags
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hipdrt::g_grp_tl), sizeof(unsigned long long) * (32 * 8 * 10 + 32)) == hipSuccess ? 0 : -1;
+}
+namespace hipdrt {
+#endif
+
 int qp_profile_read(unsigned long long* out, int n, int reset) {
 #ifdef HIPDRT_QP_PROFILE
     unsigned long long h[QP_PROF_SLOTS];

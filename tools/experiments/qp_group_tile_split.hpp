@@ -1,3 +1,13 @@
+// EXPERIMENT (not built into the library): qp_group.hpp with (a) the new range of the look-ahead accumulators cut by TILE over the
+// owner's seven wavefronts (la_tile_new), (b) the old-range sums in LDS pipelined by tile (one counter per tile), (c) a row's two
+// tile columns split between the wavefront that owns the row and an idle helper wavefront (ring_rows_col).  Parity-green (59 tests
+// of test_gpu_qp.py; (c) is bit-identical to the built kernel by construction).  Measured against the built kernel: (a) takes the
+// owner's publication from 18 k to 12.8 k cycles after its column top, (b) the old-range hand-overs from 1.6 k to ~0.4 k per
+// wavefront -- and nothing end to end (configs[1] 76.0 / 77.8 ms against 75.5, configs[4] 0.85 / 0.95 s against 0.85), because the
+// time of a block column is not there: tools/probe_timeline.py (profiles/r03_group_timeline.txt) shows the rank-k ring of a
+// single row at 300-440 cycles per half-chunk whether it issues four MFMAs or two -- three to four 1 KB loads per half-chunk at
+// ~100 cycles each per wavefront; prefetching the rows into L2 by idle wavefronts (also tried) changes nothing either --, and the
+// member that accumulates the next old range arrives 15-25 k cycles late at its barrier (A), i.e. late as the NEXT owner.
 // coneqp for FEW, possibly LARGE problems: one problem on G co-resident workgroups ("members"), n <= 4096.
 //
 // The batch kernel (qp_resident.hpp) gives every problem one workgroup = one CU: the right shape for a thousand problems,
@@ -45,16 +55,16 @@
 namespace hipdrt {
 
 #ifdef HIPDRT_GRP_TIMELINE
-// diagnostic (-DHIPDRT_GRP_TIMELINE=<block column>, tools/probe_timeline.py): s_memtime stamps of one block column of the third
-// factorisation, every member, every wavefront -> g_grp_tl[member][wavefront][10] (+ [2560 + member] = owner of the look-ahead rows)
 __device__ unsigned long long g_grp_tl[32 * 8 * 10 + 32];
+// diagnostic (PROFILE builds, -DHIPDRT_GRP_TIMELINE=<block column>): absolute s_memtime stamps of one block column of the third
+// factorisation in every member, printed by lane 0 of wavefronts 1 and 2 at the end of the column
 #define TS_DECL unsigned long long ts_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const bool ts_on_ = (fidx == 3 && jb == HIPDRT_GRP_TIMELINE);
 #define TS(e) do { if (ts_on_) ts_[e] = __builtin_amdgcn_s_memtime(); } while (0)
-#define TS_PRINT() do { if (ts_on_ && (threadIdx.x & 63) == 0 && g < 32) { const int w_ = threadIdx.x >> 6; for (int e_ = 0; e_ < 10; ++e_) g_grp_tl[(g * 8 + w_) * 10 + e_] = ts_[e_]; if (w_ == 1) g_grp_tl[2560 + g] = la_owner(jb); } } while (0)
+#define TS_PRINT(tag) do { if (ts_on_ && (threadIdx.x & 63) == 0 && g < 32) { const int w_ = threadIdx.x >> 6; for (int e_ = 0; e_ < 10; ++e_) g_grp_tl[(g * 8 + w_) * 10 + e_] = ts_[e_]; if (w_ == 1) g_grp_tl[2560 + g] = la_owner(jb); } } while (0)
 #else
 #define TS_DECL
 #define TS(e)
-#define TS_PRINT()
+#define TS_PRINT(tag)
 #endif
 
 static constexpr int GRP_NMAX = 4096;                  // unknowns
@@ -106,6 +116,10 @@ struct OpsGroup : OpsResidentT<true, 512> {
                                                  // and the look-ahead rows this member computes itself)
     double* latile = nullptr;              // LDS [6][256]: the look-ahead tiles computed by wavefronts 2..7 (register images)
     int* lacnt = nullptr;                  // LDS: look-ahead tiles delivered in this factorisation (6 per block column this member owns)
+    double* latile2 = nullptr;             // LDS [7][256]: the row wavefronts' tiles of a new range
+    double* rowx = nullptr;                // LDS [2][GRP_RMAXT][256]: second-column accumulators handed from a helper wavefront to the
+                                           // wavefront that owns the row (wavefront 2 helps 4, 3 helps 5)
+    int* lacnt2 = nullptr;                 // LDS: parts added to latile2 in this factorisation (6 per block column this member owns)
     double* labuf = nullptr;               // global [block columns][7][256]: look-ahead accumulators published by their owner
 
     __device__ __forceinline__ void trap_if(bool c) const { if (c) __builtin_trap(); }
@@ -227,7 +241,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
     // rows of this pass: acc[u][c] += chunk(T[u], k) chunk(tb + c, k)' over the finished block columns
     __device__ __forceinline__ void ring_rows(int jb, int ntr, int lane, const int (&T)[GRP_RMAXT], const bool (&act)[GRP_RMAXT],
                                               v4d (&acc)[GRP_RMAXT][2]) const {
-        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+        const int li = fresh_lane() & 15, kq = fresh_lane() >> 4, fo = li * 4 + kq;
         const int tb = 2 * jb, nk2 = 4 * jb, klast = nk2 - 1;
         const bool two = tb + 1 < ntr;
         const char* rb0 = uniform_ptr(tile2(tb, 0));
@@ -290,6 +304,63 @@ struct OpsGroup : OpsResidentT<true, 512> {
         mult(r0, nk2); mult(r1, nk2); mult(r2, nk2); mult(r3, nk2); mult(r4, nk2); mult(r5, nk2); mult(r6, nk2);   // (pins)
     }
 
+    // One tile column of the same: acc[u] += chunk(T[u], k) chunk(tb + col, k)'.  A member with fewer rows than row wavefronts
+    // splits a row's two tiles between the wavefront that owns the row (column 0) and an idle helper (column 1): two MFMAs per
+    // half-chunk and wavefront instead of four on one -- the loop is bound by the matrix pipe of ONE SIMD (440 cycles per
+    // half-chunk measured with one row, everybody else waiting at barrier (A)).  Same arithmetic per tile: same bits.
+    __device__ __forceinline__ void ring_rows_col(int jb, int ntr, int lane, int col, const int (&T)[GRP_RMAXT],
+                                                  const bool (&act)[GRP_RMAXT], v4d (&acc)[GRP_RMAXT]) const {
+        const int li = fresh_lane() & 15, kq = fresh_lane() >> 4, fo = li * 4 + kq;
+        const int tb = 2 * jb, nk2 = 4 * jb, klast = nk2 - 1;
+        const char* rb = uniform_ptr(tile2(tb + col, 0));
+        const char* ra[GRP_RMAXT];
+#pragma unroll
+        for (int u = 0; u < GRP_RMAXT; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
+        const unsigned voff = (unsigned)fo * 16u;
+        struct Sl { v2d b, a[GRP_RMAXT]; };
+        auto load = [&](Sl& s_, int k2) {
+            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+            s_.b = gload16(uniform_ptr(rb + o), voff);
+#pragma unroll
+            for (int u = 0; u < GRP_RMAXT; ++u) s_.a[u] = gload16(uniform_ptr(ra[u] + o), voff);
+        };
+        auto mult = [&](const Sl& s_, int k2) {
+            if (k2 < nk2) {
+#pragma unroll
+                for (int u = 0; u < GRP_RMAXT; ++u)
+                    if (act[u]) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b.x, s_.a[u].x, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < GRP_RMAXT; ++u)
+                    if (act[u]) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b.y, s_.a[u].y, acc[u], 0, 0, 0);
+            } else {
+                asm volatile("" :: "v"(s_.b));
+#pragma unroll
+                for (int u = 0; u < GRP_RMAXT; ++u) asm volatile("" :: "v"(s_.a[u]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int LPS = 1 + GRP_RMAXT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bool gated = false;
+        if (6 >= nk2 - 4) { wait_diag_rows(tb, true, jb); gated = true; }
+        Sl r0, r1, r2, r3, r4, r5, r6, r7;
+        load(r0, 0); load(r1, 1); load(r2, 2); load(r3, 3); load(r4, 4); load(r5, 5); load(r6, 6);
+        for (int kb = 0; kb < nk2; kb += 8) {
+            if (!gated && kb + 14 >= nk2 - 4) { wait_diag_rows(tb, true, jb); gated = true; }
+            load(r7, kb + 7);  vm_wait<7 * LPS>(); mult(r0, kb);
+            load(r0, kb + 8);  vm_wait<7 * LPS>(); mult(r1, kb + 1);
+            load(r1, kb + 9);  vm_wait<7 * LPS>(); mult(r2, kb + 2);
+            load(r2, kb + 10); vm_wait<7 * LPS>(); mult(r3, kb + 3);
+            load(r3, kb + 11); vm_wait<7 * LPS>(); mult(r4, kb + 4);
+            load(r4, kb + 12); vm_wait<7 * LPS>(); mult(r5, kb + 5);
+            load(r5, kb + 13); vm_wait<7 * LPS>(); mult(r6, kb + 6);
+            load(r6, kb + 14); vm_wait<7 * LPS>(); mult(r7, kb + 7);
+        }
+        vm_wait<0>();
+        mult(r0, nk2); mult(r1, nk2); mult(r2, nk2); mult(r3, nk2); mult(r4, nk2); mult(r5, nk2); mult(r6, nk2);   // (pins)
+    }
+
     // The look-ahead accumulators of block column jbn (tile rows R2 = 2 jbn + 2, R3 = R2 + 1 against rows tbn = 2 jbn, tbn + 1
     // and themselves), in the member that owns R2, R3.  The seven tiles are products of chunks of FOUR tile rows, and a
     // single CU draws only ~20 bytes per cycle from beyond its L2, so (a) every operand chunk is requested once per member:
@@ -305,7 +376,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
     struct LaAcc { v4d p20, p21, p30, p31, e11, e21, e22; };
     // old range of la(jbn), slice of row wavefront w = 2..7; called during block column jbn - 1 >= 1
     __device__ __forceinline__ void ring_la_slice(int jbn, int ntr, int lane, int w, LaAcc& A) const {
-        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+        const int li = fresh_lane() & 15, kq = fresh_lane() >> 4, fo = li * 4 + kq;
         const int jb = jbn;                                  // (names as in the formulas above)
         const int tb = 2 * jb, nk2 = 4 * (jb - 2);
         const bool v3 = tb + 3 < ntr;
@@ -380,80 +451,74 @@ struct OpsGroup : OpsResidentT<true, 512> {
 #pragma unroll
         for (int i_ = 0; i_ < NS; ++i_) mult(r[i_], k1);       // (pins)
     }
-    // new range of la(jb) on top of the totals (wavefront 1 of the owner, at the start of block column jb): the half-chunks
-    // of block columns jb - 2 and jb - 1.  The newest tiles this member stored itself a moment ago (rows tb, tb+1: this
-    // wavefront's panel store; R2, R3: its row wavefronts'); those of rows tb, tb+1 in column jb - 2 their owner stored before
-    // it published the look-ahead accumulators this member fetched in the previous block column.
-    // four half-chunks of the four rows: sixteen loads in flight, then 56 MFMAs
-    struct LaChunk4 { v2d c[4][4]; };
-    __device__ __forceinline__ void la_load4(LaChunk4& q, const char* const (&rp)[4], int k0, unsigned voff) const {
-#pragma unroll
-        for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) q.c[h][r] = gload16(uniform_ptr(rp[r] + (size_t)(k0 + h) * 1024), voff);
-    }
-    static __device__ __forceinline__ void la_mult4(const LaChunk4& q, LaAcc& A) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].x, q.c[h][2].x, A.p20, 0, 0, 0);
-            A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].x, q.c[h][2].x, A.p21, 0, 0, 0);
-            A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].x, q.c[h][3].x, A.p30, 0, 0, 0);
-            A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].x, q.c[h][3].x, A.p31, 0, 0, 0);
-            A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].x, q.c[h][2].x, A.e11, 0, 0, 0);
-            A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].x, q.c[h][3].x, A.e21, 0, 0, 0);
-            A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][3].x, q.c[h][3].x, A.e22, 0, 0, 0);
-            A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].y, q.c[h][2].y, A.p20, 0, 0, 0);
-            A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].y, q.c[h][2].y, A.p21, 0, 0, 0);
-            A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].y, q.c[h][3].y, A.p30, 0, 0, 0);
-            A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].y, q.c[h][3].y, A.p31, 0, 0, 0);
-            A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].y, q.c[h][2].y, A.e11, 0, 0, 0);
-            A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].y, q.c[h][3].y, A.e21, 0, 0, 0);
-            A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][3].y, q.c[h][3].y, A.e22, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __device__ __forceinline__ void la_new_range(int jb, int ntr, int lane, LaAcc& A) const {
-        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+    // New range of la(jb) (the owner of the look-ahead rows, at the start of block column jb): the eight half-chunks of block
+    // columns jb - 2 and jb - 1 (four at jb = 1).  Short enough that operand sharing does not matter, so here the work is cut
+    // by TILE: wavefront w = 1..7 accumulates tile w - 1 over the whole new range (one load round trip of at most sixteen
+    // chunks, sixteen MFMAs) and drops it into its own slot of latile2 -- no ordered accumulation in LDS (measured at 1.6 k
+    // cycles per wavefront and hand-over when the range was cut by half-chunk: the six additions took as long as the two
+    // load round trips + 112 MFMAs on one wavefront they replaced).  Wavefront 1 adds totals + new range per tile.  The newest
+    // tiles this member stored itself a moment ago (rows tb, tb+1: wavefront 1's panel store; R2, R3: the row wavefronts');
+    // those of rows tb, tb+1 in column jb - 2 their owner stored before it published the look-ahead accumulators this member
+    // fetched in the previous block column.
+    __device__ __forceinline__ v4d la_tile_new(int jb, int ntr, int lane, int tile) const {
+        const int li = fresh_lane() & 15, kq = fresh_lane() >> 4, fo = li * 4 + kq;
         const int tb = 2 * jb;
         const bool v3 = tb + 3 < ntr;
         wait_row(tb + 2, jb);
         if (v3) wait_row(tb + 3, jb);
         wait_diag_rows(tb, true, jb);
-        const char* const rp[4] = {uniform_ptr(tile2(tb, 0)), uniform_ptr(tile2(tb + 1, 0)), uniform_ptr(tile2(tb + 2, 0)),
-                                   uniform_ptr(tile2(v3 ? tb + 3 : tb + 2, 0))};
+        // operand rows of the seven tiles (offsets from tb): p20 (0,2) p21 (1,2) p30 (0,3) p31 (1,3) e11 (2,2) e21 (2,3) e22 (3,3)
+        const int xr = tile == 0 || tile == 2 ? 0 : tile == 1 || tile == 3 ? 1 : 2 + (tile == 6 ? 1 : 0);
+        const int yr = tile == 0 || tile == 1 || tile == 4 ? 2 : 3;
+        const int r3 = v3 ? 3 : 2;                                         // (padding row: its tiles are replaced by the caller)
+        const char* xp = uniform_ptr(tile2(tb + (xr == 3 ? r3 : xr), 0));
+        const char* yp = uniform_ptr(tile2(tb + (yr == 3 ? r3 : yr), 0));
         const unsigned voff = (unsigned)fo * 16u;
+        const int k0 = jb >= 2 ? 4 * (jb - 2) : 0;
+        const bool eight = jb >= 2;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // block column jb - 2 first (same order of summation as one pass over the inner dimension), then block column jb - 1
-        // through the same sixteen registers (both in flight at once spills: this wavefront also carries the seven
-        // accumulators through the panel solve)
-        LaChunk4 qa;
-#pragma unroll 1
-        for (int c_ = jb >= 2 ? jb - 2 : 0; c_ < jb; ++c_) {
-            la_load4(qa, rp, 4 * c_, voff);
-            vm_wait<0>();
-            __builtin_amdgcn_sched_barrier(0);
-            la_mult4(qa, A);
+        v2d x[8], y[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int k = eight ? k0 + h : k0 + (h & 3);                   // (jb = 1: four half-chunks, requested twice, used once)
+            x[h] = gload16(uniform_ptr(xp + (size_t)k * 1024), voff);
+            y[h] = gload16(uniform_ptr(yp + (size_t)k * 1024), voff);
         }
+        vm_wait<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            if (h < 4 || eight) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[h].x, y[h].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[h].y, y[h].y, acc, 0, 0, 0);
+            } else {
+                asm volatile("" :: "v"(x[h]), "v"(y[h]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        return acc;
     }
-    // Old-range partial sums -> LDS, in wavefront order: wavefront 1 writes the source tiles (init), wavefronts 2 .. 7 add
-    // theirs.  `base` = 7 x the old ranges this member accumulated before this one: lacnt counts the whole factorisation's.
+    // Old-range partial sums -> LDS, per tile in wavefront order: wavefront 1 writes the source tiles (init), wavefronts 2 .. 7
+    // add theirs -- a fixed order whatever the group size.  Pipelined by tile: every tile has its own counter (lacnt[2 + t]
+    // counts the additions to tile t over the whole factorisation), a wavefront walks the tiles in order and only waits for
+    // its predecessor ON THAT TILE, so wavefront w + 1 is one tile behind wavefront w instead of seven (one counter for all
+    // seven tiles: 1.6 k cycles per hand-over, 10 k per old range, measured).  `base` = 7 x the old ranges this member
+    // accumulated before this one.
     __device__ __forceinline__ void la_reduce(int lane, int w, int base, const LaAcc& A, const LaAcc* init) const {
-        for (int spins = 0; lds_peek32(lacnt) < base + (w - 1);) {
-            __builtin_amdgcn_s_sleep(1);
-            trap_if(++spins > kSpinLimit);
-        }
-        asm volatile("" ::: "memory");
         v4d* lt = reinterpret_cast<v4d*>(latile) + lane;
-        if (init) {
-            lt[0] = init->p20 + A.p20;   lt[64] = init->p21 + A.p21;   lt[128] = init->p30 + A.p30;  lt[192] = init->p31 + A.p31;
-            lt[256] = init->e11 + A.e11; lt[320] = init->e21 + A.e21; lt[384] = init->e22 + A.e22;
-        } else {
-            lt[0] += A.p20;   lt[64] += A.p21;  lt[128] += A.p30; lt[192] += A.p31;
-            lt[256] += A.e11; lt[320] += A.e21; lt[384] += A.e22;
+        const v4d* a_ = &A.p20;
+        const v4d* i_ = init ? &init->p20 : nullptr;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            for (int spins = 0; lds_peek32(lacnt + 2 + t) < base + (w - 1);) trap_if(++spins > kSpinLimit);
+            asm volatile("" ::: "memory");
+            if (i_) lt[64 * t] = i_[t] + a_[t];
+            else lt[64 * t] += a_[t];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(lacnt + 2 + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(lacnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
     // =========================================================================================================================
@@ -463,7 +528,8 @@ struct OpsGroup : OpsResidentT<true, 512> {
         ++fidx;
         group_sync();                            // every member has finished sweeping the previous factor: its tiles may go
         for (int i = tid; i < GRP_OWN; i += RT) rowdone[i] = 0;
-        if (tid == 0) { sm.flag[1] = 0; *lacnt = 0; }
+        if (tid < 16) lacnt[tid] = 0;              // (lacnt, lacnt2, the seven per-tile counters)
+        if (tid == 0) sm.flag[1] = 0;
         if (wv == 1) {
             // prologue: diagonal block of column 0 straight from P
             const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
@@ -548,11 +614,10 @@ struct OpsGroup : OpsResidentT<true, 512> {
             for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
             // (A2): separates this block column's readers of the L21 scratch block from its next writer (in the batch kernel
             // it also publishes the forward-substituted right-hand-side block)
-            TS(8);
-            lds_barrier();                                      // (A2)
+            TS(8); lds_barrier();                                      // (A2)
             PROF(3);
             TS(7);
-            TS_PRINT();
+            TS_PRINT("w0");
         }
         return true;
     }
@@ -567,6 +632,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
         v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
         v4d* const img22 = img21 + 64;
         int laown = 0;                               // block columns whose look-ahead tiles this member accumulated
+        int laown2 = 0;                              // block columns whose look-ahead rows this member owned (new ranges summed)
         for (int jb = 0; jb < nblk; ++jb) {
             const int j0 = jb * NB;
             const int tb = j0 >> 4;
@@ -598,7 +664,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
                         // the old range was summed up in LDS during the previous block column (jb < 3: there is none, the
                         // totals are the source tiles); the new range on top of it
                         if (jb >= 3) {
-                            for (int spins = 0; lds_peek32(lacnt) < 7 * laown;) {
+                            for (int spins = 0; lds_peek32(lacnt + 8) < 7 * laown;) {     // (the last tile's counter: the others are ahead)
                                 __builtin_amdgcn_s_sleep(1);
                                 trap_if(++spins > kSpinLimit);
                             }
@@ -626,7 +692,20 @@ struct OpsGroup : OpsResidentT<true, 512> {
                     if (la) {
                         PROFW(21);
                         TS(1);
-                        la_new_range(jb, ntr, lane, T_);
+                        // the new range: this wavefront's own tile, the row wavefronts' six out of their LDS slots
+                        const v4d n0 = la_tile_new(jb, ntr, lane, 0);
+                        TS(2);
+                        ++laown2;
+                        for (int spins = 0; lds_peek32(lacnt2) < 6 * laown2;) {
+                            __builtin_amdgcn_s_sleep(1);
+                            trap_if(++spins > kSpinLimit);
+                        }
+                        asm volatile("" ::: "memory");
+                        {
+                            const v4d* l2 = reinterpret_cast<const v4d*>(latile2) + lane;
+                            T_.p20 += n0;      T_.p21 += l2[64];  T_.p30 += l2[128]; T_.p31 += l2[192];
+                            T_.e11 += l2[256]; T_.e21 += l2[320]; T_.e22 += l2[384];
+                        }
                         PROFW(22);
                         TS(3);
                         p20 = T_.p20; p21 = T_.p21; p30 = T_.p30; p31 = T_.p31; e11 = T_.e11; e21 = T_.e21; e22 = T_.e22;
@@ -730,13 +809,13 @@ struct OpsGroup : OpsResidentT<true, 512> {
                 img22[lane] = e22;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) *(volatile int*)&sm.flag[1] = jb + 1;      // diagonal block jb + 1 staged: the chain may start
-                lds_barrier();                                  // (A2)
+                TS(8); lds_barrier();                                  // (A2)
             } else {
-                lds_barrier();                                  // (A2)
+                TS(8); lds_barrier();                                  // (A2)
             }
             PROFW(24);
             TS(7);
-            TS_PRINT();
+            TS_PRINT("w1");
         }
         return true;
     }
@@ -772,6 +851,16 @@ struct OpsGroup : OpsResidentT<true, 512> {
             }
             if (wv == 2) PROFW(26);
             TS(1);
+            // this member owns the look-ahead rows of THIS block column: this wavefront's tile of their new range first -- every
+            // other member is waiting for it (la_tile_new)
+            if (jb >= 1 && tb + 2 < ntr && la_owner(jb)) {
+                const v4d nt_ = la_tile_new(jb, ntr, lane, wv - 1);
+                TS(2);
+                reinterpret_cast<v4d*>(latile2)[(wv - 1) * 64 + lane] = nt_;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(lacnt2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            TS(3);
             // the old range of the NEXT block column's look-ahead accumulators, if this member owns those rows: this
             // wavefront's slice, added to the sums in LDS (ring_la_slice)
             if (jb >= 2 && tb + 4 < ntr && la_owner(jb + 1)) {
@@ -785,6 +874,20 @@ struct OpsGroup : OpsResidentT<true, 512> {
             TS(4);
             const int mine = count_rows(mask);
             const int npass = mine > GRP_RMAXT ? (mine + GRP_RMAXT - 1) / GRP_RMAXT : 1;
+            // Helper pairs (wavefront 2 helps 4, 3 helps 5: the deal gives 4 and 5 their rows first, see build_owner): a row
+            // wavefront with no rows in this block column takes the SECOND tile column of its partner's first pass
+            // (ring_rows_col), hands the accumulators over through LDS before barrier (A); the partner computes the first
+            // column only and picks them up behind the barrier.
+            const bool two_cols = jb > 0 && tb + 1 < ntr;
+            const int partner = wv == 2 ? 4 : wv == 3 ? 5 : wv == 4 ? 2 : wv == 5 ? 3 : 0;
+            bool helping = false, helped = false;
+            RowMask pm = mask;
+            if (two_cols && partner) {
+                pm = my_rows(jb, partner, lane, ntr);
+                const int theirs = count_rows(pm);
+                helping = wv <= 3 && mine == 0 && theirs > 0;
+                helped = wv >= 4 && mine > 0 && theirs == 0;
+            }
 #pragma unroll 1
             for (int ps = 0; ps < npass; ++ps) {
                 int T[GRP_RMAXT];
@@ -796,13 +899,37 @@ struct OpsGroup : OpsResidentT<true, 512> {
                     act[u] = t_ >= 0;
                 }
                 v4d acc[GRP_RMAXT][2];
+                const bool split = ps == 0 && (helping || helped);        // one tile column of the partner's / of this wavefront's rows
+                if (split) {
+                    int Tc[GRP_RMAXT];
+                    bool ac[GRP_RMAXT];
+                    v4d a1[GRP_RMAXT];
+                    const int col = helping ? 1 : 0;
 #pragma unroll
-                for (int u = 0; u < GRP_RMAXT; ++u)
+                    for (int u = 0; u < GRP_RMAXT; ++u) {
+                        if (helping) { const int t_ = pop_row(pm, tb); Tc[u] = t_ >= 0 ? t_ : nch; ac[u] = t_ >= 0; }
+                        else { Tc[u] = T[u]; ac[u] = act[u]; }
+                        a1[u] = ac[u] ? init_tile(Tc[u], tb + col, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                    }
+                    TS(9);
+                    ring_rows_col(jb, ntr, lane, col, Tc, ac, a1);
+                    if (helping) {
+                        v4d* dst = reinterpret_cast<v4d*>(rowx) + (size_t)(partner - 4) * GRP_RMAXT * 64 + lane;
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-                        acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
-                TS(9);
-                if (jb > 0 && act[0]) ring_rows(jb, ntr, lane, T, act, acc);
+                        for (int u = 0; u < GRP_RMAXT; ++u) { dst[u * 64] = a1[u]; acc[u][0] = acc[u][1] = (v4d){0, 0, 0, 0}; }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < GRP_RMAXT; ++u) { acc[u][0] = a1[u]; acc[u][1] = (v4d){0, 0, 0, 0}; }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < GRP_RMAXT; ++u)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                    TS(9);
+                    if (jb > 0 && act[0]) ring_rows(jb, ntr, lane, T, act, acc);
+                }
                 if (ps == 0) {
                     if (wv == 2) PROFW(28);
                     TS(5);
@@ -810,6 +937,11 @@ struct OpsGroup : OpsResidentT<true, 512> {
                     if (wv == 2) PROFW(29);
                     TS(6);
                     if (sm.flag[0]) return false;
+                    if (helped) {
+                        const v4d* src = reinterpret_cast<const v4d*>(rowx) + (size_t)(wv - 4) * GRP_RMAXT * 64 + lane;
+#pragma unroll
+                        for (int u = 0; u < GRP_RMAXT; ++u) acc[u][1] = src[u * 64];
+                    }
                 }
                 if (act[0]) {
                     double wn1[4], l21[4], wn2[4];
@@ -855,21 +987,21 @@ struct OpsGroup : OpsResidentT<true, 512> {
                             d0[192] = make_double2(x2[u][2], x2[u][3]);
                         }
                     }
-                    if (ps == 0) lds_barrier();                 // (A2)
+                    if (ps == 0) { TS(8); lds_barrier(); }                 // (A2)
                 } else if (ps == 0) {
-                    lds_barrier();                              // (A2)
+                    TS(8); lds_barrier();                              // (A2)
                 }
             }
             if (wv == 2) PROFW(30);
             TS(7);
-            TS_PRINT();
+            TS_PRINT(wv == 2 ? "w2" : wv == 3 ? "w3" : wv == 4 ? "w4" : wv == 5 ? "w5" : wv == 6 ? "w6" : "w7");
         }
         return true;
     }
 };
 
 // LDS of the group kernel (doubles): the fixed buffers of qp_resident.hpp, the two byte tables, the two n-vectors
-static constexpr int GRP_FIXED = 4 * 8 * 4 + 2 * 16 * 17 + 8 + 512 + 2 * GRP_OWN / 8 + 7 * 256 + 8;
+static constexpr int GRP_FIXED = 4 * 8 * 4 + 2 * 16 * 17 + 8 + 512 + 2 * GRP_OWN / 8 + 2 * 7 * 256 + 8 + 2 * GRP_RMAXT * 256;
 static size_t group_lds_bytes(int NP) { return (size_t)(GRP_FIXED + 2 * (NP + 64)) * sizeof(double); }
 
 // per-problem scratch doubles: the tile-packed factor, one copy of U per member, the look-ahead accumulators of every block
@@ -904,8 +1036,11 @@ __global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int 
     ops.owner = reinterpret_cast<unsigned char*>(ops.sm.img + 512);
     ops.rowdone = ops.owner + GRP_OWN;
     ops.latile = ops.sm.img + 512 + 2 * GRP_OWN / 8;
-    ops.lacnt = reinterpret_cast<int*>(ops.latile + 7 * 256);
-    ops.sm.vec = ops.latile + 7 * 256 + 8;
+    ops.latile2 = ops.latile + 7 * 256;
+    ops.lacnt = reinterpret_cast<int*>(ops.latile + 2 * 7 * 256);
+    ops.lacnt2 = ops.lacnt + 1;
+    ops.rowx = ops.latile + 2 * 7 * 256 + 8;
+    ops.sm.vec = ops.rowx + 2 * GRP_RMAXT * 256;
     ops.sm.dvec = ops.sm.vec + NP + 64;
     ops.sm.U = ops.L + (size_t)NP * NP + (size_t)g * NP * PLD;          // this member's own inverse diagonal blocks
     ops.labuf = ops.L + (size_t)NP * NP + (size_t)G * NP * PLD;

@@ -225,6 +225,9 @@ struct OpsGroup : OpsResidentT<true, 512> {
     // the wait: slots past the end of the inner dimension are re-reads of the last chunk, and are "consumed" by an empty asm.
 
     // rows of this pass: acc[u][c] += chunk(T[u], k) chunk(tb + c, k)' over the finished block columns
+    // (NR = rows actually present in this pass: a slot carries NR + 2 loads -- a wavefront pays ~100 cycles per 1 KB load, so the
+    // single-row case, the usual one once a member has fewer rows than wavefronts, does not request a second row it does not have)
+    template <int NR>
     __device__ __forceinline__ void ring_rows(int jb, int ntr, int lane, const int (&T)[GRP_RMAXT], const bool (&act)[GRP_RMAXT],
                                               v4d (&acc)[GRP_RMAXT][2]) const {
         const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
@@ -232,28 +235,28 @@ struct OpsGroup : OpsResidentT<true, 512> {
         const bool two = tb + 1 < ntr;
         const char* rb0 = uniform_ptr(tile2(tb, 0));
         const char* rb1 = uniform_ptr(tile2(two ? tb + 1 : tb, 0));
-        const char* ra[GRP_RMAXT];
+        const char* ra[NR];
 #pragma unroll
-        for (int u = 0; u < GRP_RMAXT; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
+        for (int u = 0; u < NR; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
         const unsigned voff = (unsigned)fo * 16u;
-        struct Sl { v2d b0, b1, a[GRP_RMAXT]; };
+        struct Sl { v2d b0, b1, a[NR]; };
         auto load = [&](Sl& s_, int k2) {
             const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
             s_.b0 = gload16(uniform_ptr(rb0 + o), voff); s_.b1 = gload16(uniform_ptr(rb1 + o), voff);
 #pragma unroll
-            for (int u = 0; u < GRP_RMAXT; ++u) s_.a[u] = gload16(uniform_ptr(ra[u] + o), voff);
+            for (int u = 0; u < NR; ++u) s_.a[u] = gload16(uniform_ptr(ra[u] + o), voff);
         };
         auto mult = [&](const Sl& s_, int k2) {
             if (k2 < nk2) {
 #pragma unroll
-                for (int u = 0; u < GRP_RMAXT; ++u) {
+                for (int u = 0; u < NR; ++u) {
                     if (act[u]) {
                         acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0.x, s_.a[u].x, acc[u][0], 0, 0, 0);
                         if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1.x, s_.a[u].x, acc[u][1], 0, 0, 0);
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < GRP_RMAXT; ++u) {
+                for (int u = 0; u < NR; ++u) {
                     if (act[u]) {
                         acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0.y, s_.a[u].y, acc[u][0], 0, 0, 0);
                         if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1.y, s_.a[u].y, acc[u][1], 0, 0, 0);
@@ -262,11 +265,11 @@ struct OpsGroup : OpsResidentT<true, 512> {
             } else {
                 asm volatile("" :: "v"(s_.b0), "v"(s_.b1));
 #pragma unroll
-                for (int u = 0; u < GRP_RMAXT; ++u) asm volatile("" :: "v"(s_.a[u]));
+                for (int u = 0; u < NR; ++u) asm volatile("" :: "v"(s_.a[u]));
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        constexpr int LPS = 2 + GRP_RMAXT;                  // loads per slot
+        constexpr int LPS = 2 + NR;                  // loads per slot
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         // the newest two chunks of rows tb, tb+1 were stored by this member's look-ahead wavefront in the previous block
@@ -802,7 +805,10 @@ struct OpsGroup : OpsResidentT<true, 512> {
                     for (int ct = 0; ct < 2; ++ct)
                         acc[u][ct] = act[u] ? init_tile(T[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
                 TS(9);
-                if (jb > 0 && act[0]) ring_rows(jb, ntr, lane, T, act, acc);
+                if (jb > 0 && act[0]) {
+                    if (act[GRP_RMAXT - 1]) ring_rows<GRP_RMAXT>(jb, ntr, lane, T, act, acc);
+                    else ring_rows<1>(jb, ntr, lane, T, act, acc);
+                }
                 if (ps == 0) {
                     if (wv == 2) PROFW(28);
                     TS(5);

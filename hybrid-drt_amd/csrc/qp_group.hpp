@@ -60,6 +60,16 @@ __device__ unsigned long long g_grp_tl[32 * 8 * 10 + 32];
 static constexpr int GRP_NMAX = 4096;                  // unknowns
 static constexpr int GRP_OWN = 512;                    // tile rows incl. appended ones the tables cover
 static constexpr int GRP_MAXG = 32;                    // members (CUs of one XCD)
+#ifndef HIPDRT_GRP_LA_RING
+#define HIPDRT_GRP_LA_RING 4
+#endif
+#ifndef HIPDRT_GRP_ROW_RING
+#define HIPDRT_GRP_ROW_RING 8
+#endif
+static constexpr int GRP_LA_RING = HIPDRT_GRP_LA_RING;  // slots of the old-range operand ring (ring_la_slice): a ring issues
+                                                        // ceil(len / slots) * slots + slots - 1 slots of loads whatever the length, a
+                                                        // slice is 4 .. 22 half-chunks long, and a wavefront pays ~100 cycles per load
+static constexpr int GRP_ROW_RING = HIPDRT_GRP_ROW_RING;  // slots of the rows' operand ring (ring_rows)
 static constexpr int GRP_RMAXT = 2;                    // tile rows per row wavefront and pass: a member has few rows, and a short
                                                        // pass leaves registers for an eight-slot operand ring (below)
 static constexpr int GRP_WORDS = 16 + GRP_OWN;         // ints of global sync state per problem
@@ -275,22 +285,23 @@ struct OpsGroup : OpsResidentT<true, 512> {
         // the newest two chunks of rows tb, tb+1 were stored by this member's look-ahead wavefront in the previous block
         // column: wait for them just before the first request that reaches that far
         bool gated = false;
-        if (6 >= nk2 - 4) { wait_diag_rows(tb, two, jb); gated = true; }
-        Sl r0, r1, r2, r3, r4, r5, r6, r7;
-        load(r0, 0); load(r1, 1); load(r2, 2); load(r3, 3); load(r4, 4); load(r5, 5); load(r6, 6);
-        for (int kb = 0; kb < nk2; kb += 8) {
-            if (!gated && kb + 14 >= nk2 - 4) { wait_diag_rows(tb, two, jb); gated = true; }
-            load(r7, kb + 7);  vm_wait<7 * LPS>(); mult(r0, kb);
-            load(r0, kb + 8);  vm_wait<7 * LPS>(); mult(r1, kb + 1);
-            load(r1, kb + 9);  vm_wait<7 * LPS>(); mult(r2, kb + 2);
-            load(r2, kb + 10); vm_wait<7 * LPS>(); mult(r3, kb + 3);
-            load(r3, kb + 11); vm_wait<7 * LPS>(); mult(r4, kb + 4);
-            load(r4, kb + 12); vm_wait<7 * LPS>(); mult(r5, kb + 5);
-            load(r5, kb + 13); vm_wait<7 * LPS>(); mult(r6, kb + 6);
-            load(r6, kb + 14); vm_wait<7 * LPS>(); mult(r7, kb + 7);
+        if (GRP_ROW_RING - 2 >= nk2 - 4) { wait_diag_rows(tb, two, jb); gated = true; }
+        constexpr int NS = GRP_ROW_RING;
+        Sl r[NS];
+#pragma unroll
+        for (int i_ = 0; i_ < NS - 1; ++i_) load(r[i_], i_);
+        for (int kb = 0; kb < nk2; kb += NS) {
+            if (!gated && kb + 2 * NS - 2 >= nk2 - 4) { wait_diag_rows(tb, two, jb); gated = true; }
+#pragma unroll
+            for (int i_ = 0; i_ < NS; ++i_) {
+                load(r[(i_ + NS - 1) % NS], kb + i_ + NS - 1);
+                vm_wait<(NS - 1) * LPS>();
+                mult(r[i_], kb + i_);
+            }
         }
         vm_wait<0>();
-        mult(r0, nk2); mult(r1, nk2); mult(r2, nk2); mult(r3, nk2); mult(r4, nk2); mult(r5, nk2); mult(r6, nk2);   // (pins)
+#pragma unroll
+        for (int i_ = 0; i_ < NS; ++i_) mult(r[i_], nk2);       // (pins)
     }
 
     // The look-ahead accumulators of block column jbn (tile rows R2 = 2 jbn + 2, R3 = R2 + 1 against rows tbn = 2 jbn, tbn + 1
@@ -367,7 +378,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int NS = 8;
+        constexpr int NS = GRP_LA_RING;
         Sl r[NS];
 #pragma unroll
         for (int i_ = 0; i_ < NS - 1; ++i_) load(r[i_], k0 + i_);

@@ -1,7 +1,8 @@
-# same-box A/B of the working library against variant libraries + GPU tests + the resolve probe
+# same-box A/B of the working library against variant libraries + bit comparison + QP tests
 cd $GRAFT_REPO_ROOT; O=gpurun_out; T=${1:-ab}; shift; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "Extension modules" | tail -8 > $O/${T}_pytest.txt
+timeout 300 python tools/dump_fit.py $O/dump_new.npz 2>&1 | grep -v "Extension modules" | tail -2 > $O/${T}_dump.txt
+HIPDRT_LIB=$PWD/$1 timeout 300 python tools/dump_fit.py $O/dump_old.npz 2>&1 | tail -1 >> $O/${T}_dump.txt
+python tools/dump_fit.py --cmp $O/dump_new.npz $O/dump_old.npz >> $O/${T}_dump.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_qp.py tests/test_gpu_fit.py -m gpu -x -q 2>&1 | tail -2 >> $O/${T}_dump.txt
 bash tools/ab_libs.sh "$@" > $O/${T}_ab.txt 2>&1
-timeout 600 python tools/probe_single.py 0 -1 2>&1 | grep -v "Extension modules" > $O/${T}_single.txt
-timeout 900 python tools/probe_resolve_c2grid.py 2>&1 | grep -v "Extension modules" > $O/${T}_resolve.txt
-cat $O/${T}_pytest.txt $O/${T}_ab.txt $O/${T}_single.txt $O/${T}_resolve.txt
+cat $O/${T}_dump.txt $O/${T}_ab.txt

@@ -1,0 +1,1092 @@
+// EXPERIMENT (not built into the library): qp_group.hpp with BOTH (a) the old range of the look-ahead accumulators in four
+// segments accumulated by members spread evenly around the ring (running sum handed on through global memory, per-tile
+// pipelined sums in LDS) and (b) a row's inner dimension in thirds over idle helper wavefronts (four-slot rings).  Parity-green
+// (59 tests of test_gpu_qp.py, results independent of the group size).  tools/probe_timeline.py at n = 1078 / 16 members / block
+// column 16: (a) alone removes the laggard -- every member passes barrier (A) at 36 k cycles, bound by the single-row rank-k
+// ring (26 k), 2.37 M cycles per factorisation against 2.30 M built; (a) + (b): rows done by 27 k, but the owner of the look-ahead
+// rows is 20-27 k behind the others again, configs[4] 0.83 s (= built), configs[1] 88 ms against 73 built (eight members: the
+// "evenly spread" helpers include the next owner).  Not understood well enough to ship; the measured facts are in DESIGN.md.
+// coneqp for FEW, possibly LARGE problems: one problem on G co-resident workgroups ("members"), n <= 4096.
+//
+// The batch kernel (qp_resident.hpp) gives every problem one workgroup = one CU: the right shape for a thousand problems,
+// the wrong one for a single spectrum (BASELINE configs[1]: 255 of 256 CUs idle), one joint fit (configs[4], n = 1078) or
+// a coupled multi-observation QP (mapping/resolve.py, n = 7 x 514 = 3598 > the 2048 the one-CU kernel serves).  Here the
+// factorisation of ONE problem -- the tile-packed left-looking blocked Cholesky of qp_resident.hpp, same tile layout, same
+// per-tile arithmetic -- is shared by G workgroups:
+//
+//  * Tile rows belong to members in pairs (block row jb = tile rows 2 jb, 2 jb + 1 -> member jb % G) for the whole
+//    factorisation, and inside the member to one row wavefront (static table, build_owner): a wavefront only re-reads tiles
+//    it stored itself.
+//  * The diagonal chain (wavefront 0: factor + invert the 32 x 32 diagonal block) runs REDUNDANTLY in every member, from
+//    identical inputs, hence bit-identical: no member ever waits for another one's chain.
+//  * The look-ahead tiles (the seven accumulators that become the next diagonal block and its panel rows: inner dimension
+//    = every finished block column) are accumulated by ONE member per block column -- the owner of those two tile rows, all
+//    seven working wavefronts on a slice of the inner dimension each -- and published: 14 KB in labuf[jb] + the laprog
+//    word.  Every member's wavefront 1 fetches them while its chain still works on the current block, then does the last
+//    rank-32 update, the panel solve and the staging of the next diagonal block itself (redundantly, identical bits).  This
+//    publication is the only data that crosses between members inside a factorisation, and the only wait on another member.
+//  * Inside a member there is no barrier at the end of a block column: the hand-offs between its wavefronts go through
+//    progress bytes in LDS (rowdone[T]) and a "diagonal block staged" word, so a member's store drain overlaps its next
+//    rank-k update.  Two workgroup barriers per block column remain: (A) inverse diagonal blocks published, (A2) the L21
+//    scratch block may be rewritten.
+//  * Everything else -- the O(n) interior-point vectors, the triangular sweeps, P x -- every member does redundantly on its
+//    own copy (own state slot, own inverse diagonal blocks U), reading the shared factor: no communication, and the members
+//    stay in lockstep because they compute the same bits.  Two group barriers per factorisation: before it (everybody has
+//    finished sweeping the old factor; followed by an L1 invalidate) and after it (every tile is in memory; L1 invalidate).
+//  * Visibility: the members of a group sit on ONE XCD (blocks b and b + 8 share an XCD under the round-robin dispatch;
+//    checked at run time through HW_REG_XCC_ID -- a group that is spread over several XCDs reports HIPDRT_QP_ABORTED and the
+//    launcher repeats that problem with G = 1), so the XCD's L2 is the point of coherence.  Stores are complete (s_waitcnt
+//    vmcnt(0)) before a progress word is written.  Tiles of L are read with plain loads: a CU reads a tile for the first
+//    time in a factorisation only after the tile is final (see "operand rings"), so its L1 cannot hold a stale copy; the
+//    look-ahead accumulators are read with sc1 loads (L1 bypass).
+//  * Every wait on another member is bounded (kSpinLimit): a protocol error or a member that never became resident traps the
+//    launch instead of hanging the device.  Group launches of one device are chained through an event (qp.hip) so that two
+//    of them cannot each occupy part of the CUs and wait for the rest.
+//  * The result does not depend on G (who owns a row does not change its arithmetic; the look-ahead slices are cut by
+//    wavefront, not by member).  Against the batch kernel it differs by rounding: there the predictor's forward substitution
+//    is fused into the factorisation and the look-ahead tiles are summed in one pass.
+//
+// G = 1 is the same kernel without the global words: the single-workgroup form for n up to 4096.
+#pragma once
+#include "qp_resident.hpp"
+
+namespace hipdrt {
+
+#ifdef HIPDRT_GRP_TIMELINE
+// diagnostic (-DHIPDRT_GRP_TIMELINE=<block column>, tools/probe_timeline.py): s_memtime stamps of one block column of the third
+// factorisation, every member, every wavefront -> g_grp_tl[member][wavefront][10] (+ [2560 + member] = owner of the look-ahead rows)
+__device__ unsigned long long g_grp_tl[32 * 8 * 10 + 32];
+#define TS_DECL unsigned long long ts_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const bool ts_on_ = (fidx == 3 && jb == HIPDRT_GRP_TIMELINE);
+#define TS(e) do { if (ts_on_) ts_[e] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TS_PRINT() do { if (ts_on_ && (threadIdx.x & 63) == 0 && g < 32) { const int w_ = threadIdx.x >> 6; for (int e_ = 0; e_ < 10; ++e_) g_grp_tl[(g * 8 + w_) * 10 + e_] = ts_[e_]; if (w_ == 1) g_grp_tl[2560 + g] = la_owner(jb); } } while (0)
+#else
+#define TS_DECL
+#define TS(e)
+#define TS_PRINT()
+#endif
+
+static constexpr int GRP_NMAX = 4096;                  // unknowns
+static constexpr int GRP_OWN = 512;                    // tile rows incl. appended ones the tables cover
+static constexpr int GRP_MAXG = 32;                    // members (CUs of one XCD)
+#ifndef HIPDRT_GRP_LA_RING
+#define HIPDRT_GRP_LA_RING 4
+#endif
+#ifndef HIPDRT_GRP_ROW_RING
+#define HIPDRT_GRP_ROW_RING 4
+#endif
+static constexpr int GRP_LA_RING = HIPDRT_GRP_LA_RING;  // slots of the old-range operand ring (ring_la_slice): a ring issues
+                                                        // ceil(len / slots) * slots + slots - 1 slots of loads whatever the length, a
+                                                        // slice is 4 .. 22 half-chunks long, and a wavefront pays ~100 cycles per load
+static constexpr int GRP_ROW_RING = HIPDRT_GRP_ROW_RING;  // slots of the rows' operand ring (ring_rows)
+static constexpr int GRP_RMAXT = 2;                    // tile rows per row wavefront and pass: a member has few rows, and a short
+                                                       // pass leaves registers for an eight-slot operand ring (below)
+static constexpr int GRP_LA_SEG = 4;                   // the old range of a look-ahead block is accumulated in this many segments
+static constexpr int GRP_NBLK = GRP_NMAX / 32;         // block columns
+static constexpr int GRP_WORDS = 16 + GRP_OWN + GRP_NBLK;   // ints of global sync state per problem
+// words: [0] members arrived at the start, [1] OR of (1 << XCC id), [2] barrier counter, [3] laprog: factorisation count * 256
+// + block columns whose look-ahead accumulators are in labuf (written by the owner of the column's look-ahead rows),
+// [16 + T] rowprog: factorisation count * 256 + block columns of tile row T complete in memory (written by T's owner when T
+// becomes a look-ahead row: the member that accumulates the next look-ahead block reads T as an operand)
+
+// 16 bytes per lane that bypass the CU's vector L1 (written by another CU of the XCD in THIS factorisation after this CU may
+// have read the same addresses: the look-ahead accumulators, whose slots are reused from one factorisation to the next)
+static __device__ __forceinline__ v2d gload16_sc1(const char* sbase, unsigned voff) {
+    v2d d;
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    return d;
+}
+// an int / a byte of LDS read NOW (polls of progress words: a volatile C++ load would be a FLAT instruction, which counts in
+// vmcnt as well and returns out of order with the hand-counted loads).  The value goes through readfirstlane: the spin loops
+// around these stay scalar branches -- a loop whose exit depends on a vector register runs under EXEC masking, and
+// hand-issued loads after such a loop were observed to fault.
+static __device__ __forceinline__ int lds_peek32(const void* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+static __device__ __forceinline__ int lds_peek8(const void* p) {
+    int v;
+    asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+struct OpsGroup : OpsResidentT<true, 512> {
+    using Base = OpsResidentT<true, 512>;
+    static constexpr int RT = 512, RNW = 8;
+    // The predictor's forward substitution is NOT fused into the factorisation here: a member only touches its own rows'
+    // tiles, but every member needs the whole substituted vector for its (redundant) interior-point step; the predictor
+    // solve is a full forward + backward sweep over the finished factor instead.
+    static constexpr bool kFusedForward = false;
+    static constexpr int kSpinLimit = 1 << 24;
+    int G = 1, g = 0;                      // members of the group, this member
+    int* gs = nullptr;                     // global sync words of the problem (GRP_WORDS)
+    int fidx = 0, gepoch = 0;              // factorisations started, group barriers passed (identical in every member)
+    unsigned char* owner = nullptr;        // LDS [GRP_OWN]: row wavefront (2..7) owning tile row T in THIS member, 0 = not mine
+    volatile unsigned char* rowdone = nullptr;   // LDS [GRP_OWN]: block columns of tile row T complete in memory (own member's rows
+                                                 // and the look-ahead rows this member computes itself)
+    double* latile = nullptr;              // LDS [6][256]: the look-ahead tiles computed by wavefronts 2..7 (register images)
+    int* lacnt = nullptr;                  // LDS: look-ahead tiles delivered in this factorisation (6 per block column this member owns)
+    double* rowx = nullptr;                // LDS [2 owners][2 thirds][GRP_RMAXT][2][256]: partial sums of a row handed from a helper
+                                           // wavefront to the wavefront that owns the row (ring_rows)
+    double* labuf = nullptr;               // global [block columns][7][256]: look-ahead accumulators published by their owner
+    double* laseg = nullptr;               // global [block columns][7][256]: running sum of the old range's segments (gs[16 + GRP_OWN + jb]
+                                           // counts the segments delivered: GRP_LA_SEG per factorisation)
+
+    __device__ __forceinline__ void trap_if(bool c) const { if (c) __builtin_trap(); }
+
+    // ---- group barrier: every member's stores complete, then one arrival per member on a monotonic counter -------------
+    __device__ __forceinline__ void group_sync() {
+        PROF_DECL
+        __syncthreads();                                   // (s_waitcnt vmcnt(0) in every wavefront: this member's stores are in L2)
+        if (G > 1) {
+            ++gepoch;
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(&gs[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int target = G * gepoch;
+                int spins = 0;
+                while (__hip_atomic_load(&gs[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(2);
+                    trap_if(++spins > kSpinLimit);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // L1 invalidate: plain loads below see the other members' data
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+        PROF(4);
+    }
+
+    // Tile rows belong to members in PAIRS (the two tile rows of a block row: member (T / 2) % G), so that the two look-ahead
+    // rows of a block column have one owner.  Inside the member they are dealt to the row wavefronts from the bottom up,
+    // round-robin in an order that fills the four SIMDs evenly (wavefront w runs on SIMD w % 4; SIMD 0 / 1 also carry the
+    // chain / the look-ahead wavefront, which use the matrix pipe little, so wavefronts 4 and 5 come first): the rows still
+    // active at any block column are a prefix of that deal.
+    __device__ __forceinline__ bool mine(int T) const { return (T >> 1) % G == g; }
+    __device__ __forceinline__ void build_owner() {
+        if (threadIdx.x != 0) return;
+        const int ntr = (n + 15) >> 4;
+        const unsigned char order[6] = {4, 5, 2, 3, 6, 7};
+        int k = 0;
+        for (int T = ntr - 1; T >= 0; --T) {
+            if (!mine(T)) { owner[T] = 0; continue; }
+            owner[T] = order[k];
+            k = k == 5 ? 0 : k + 1;
+        }
+    }
+    // the member that accumulates the look-ahead tiles of block column jb (rows 2 jb + 2, 2 jb + 3: its own rows)
+    __device__ __forceinline__ bool la_owner(int jb) const { return (jb + 1) % G == g; }
+    // does this member own a tile row below the look-ahead rows of block column jb?  (first pair >= jb + 2 that is its own)
+    __device__ __forceinline__ bool has_rows_below(int jb, int ntr) const {
+        const int p0 = jb + 2, d = ((g - p0) % G + G) % G;
+        return 2 * (p0 + d) < ntr;
+    }
+
+    // ---- progress words ----------------------------------------------------------------------------------------------------
+    __device__ __forceinline__ int prog_value(int jb) const { return fidx * 256 + jb; }
+    // tile row T of THIS member complete through block column jb - 1 (set by the row wavefront that stores it)
+    __device__ __forceinline__ void wait_row(int T, int jb) const {
+        int spins = 0;
+        while (lds_peek8((const void*)(rowdone + T)) < jb) { __builtin_amdgcn_s_sleep(1); trap_if(++spins > kSpinLimit); }
+        asm volatile("" ::: "memory");
+    }
+    // rows tb, tb + 1 of the current diagonal block: stored by this member's own look-ahead wavefront
+    __device__ __forceinline__ void wait_diag_rows(int tb, bool two, int jb) const {
+        int spins = 0;
+        while (lds_peek8((const void*)(rowdone + tb)) < jb || (two && lds_peek8((const void*)(rowdone + tb + 1)) < jb)) {
+            __builtin_amdgcn_s_sleep(1);
+            trap_if(++spins > kSpinLimit);
+        }
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- row masks: bit r = tile row tb + 4 + r (r < nsq) is this wavefront's ------------------------------------------------
+    struct RowMask { unsigned long long m0, m1, m2, m3; };
+    __device__ __forceinline__ RowMask my_rows(int jb, int wv, int lane, int ntr) const {
+        const int tb = 2 * jb;
+        const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;
+        auto word = [&](int w) -> unsigned long long {
+            if (64 * w >= nsq) return 0ull;
+            const int r = lane + 64 * w;
+            return __ballot(r < nsq && owner[r < nsq ? tb + 4 + r : 0] == wv);
+        };
+        RowMask k;
+        k.m0 = word(0); k.m1 = word(1); k.m2 = word(2); k.m3 = word(3);
+        return k;
+    }
+    __device__ __forceinline__ int pop_row(RowMask& k, int tb) const {
+        int r = -1;
+        if (k.m0) { r = __builtin_ctzll(k.m0); k.m0 &= k.m0 - 1; }
+        else if (k.m1) { r = 64 + __builtin_ctzll(k.m1); k.m1 &= k.m1 - 1; }
+        else if (k.m2) { r = 128 + __builtin_ctzll(k.m2); k.m2 &= k.m2 - 1; }
+        else if (k.m3) { r = 192 + __builtin_ctzll(k.m3); k.m3 &= k.m3 - 1; }
+        return r < 0 ? -1 : tb + 4 + r;
+    }
+    static __device__ __forceinline__ int count_rows(const RowMask& k) {
+        return __builtin_popcountll(k.m0) + __builtin_popcountll(k.m1) + __builtin_popcountll(k.m2) + __builtin_popcountll(k.m3);
+    }
+
+    // ---- the look-ahead tiles ------------------------------------------------------------------------------------------------
+    // The seven tiles wavefront 1 of the batch kernel accumulates in one loop -- (R2|R3, tb|tb+1) and the next diagonal block
+    // (R2,R2), (R3,R2), (R3,R3), over the whole inner dimension -- are the critical path of a block column here, and computed
+    // by every member they would cost each member 14 MFMAs per half-chunk whatever the group size (measured: a group of 16
+    // no faster than one of 8).  Only the member that OWNS rows R2, R3 accumulates them (la_owner), one tile per wavefront
+    // 1..7 (same order of summation as the batch kernel: same bits), wavefronts 2..7 hand theirs to wavefront 1 through LDS,
+    // and wavefront 1 publishes the seven raw accumulators in labuf[jb] + the laprog word.  Every member's wavefront 1
+    // fetches them (sc1 loads: the XCD's L2) while its chain wavefront still factors the current diagonal block, and does the
+    // last rank-32 update, the panel solve and the staging itself after barrier (A) -- redundantly, from identical bits.
+    // ---- operand rings -------------------------------------------------------------------------------------------------------
+    // Every rank-k loop of this kernel streams its operands through an eight-slot register ring, one half-chunk (1 KB per
+    // operand) per slot, requested SEVEN slots ahead with hand-issued loads and counted waits (qp_resident.hpp, gload16 /
+    // vm_wait).  The loads are plain, L1-cached ones although most of the B operand (rows tb, tb+1) was stored by another
+    // member: this CU reads a tile of L for the first time in a factorisation only after the tile is final (its rows were
+    // waited for by the member that published the look-ahead accumulators this member fetched before it passed barrier (A)
+    // of the previous block column), and group_sync() invalidated the L1 after the previous factor's sweeps -- so no stale
+    // line can be hit, and the six row wavefronts of a member, which walk the same B chunks, share them through the L1.
+    // (An earlier form staged the shared rows through LDS with LDS-DMA loads and a software barrier per four half-chunks
+    // among the seven wavefronts: 3.9k cycles per super-step of which 1.1k matrix work -- DESIGN.md section 7.)
+    //
+    // Registers written by a hand-issued load stay allocated until the load has landed only if something reads them after
+    // the wait: slots past the end of the inner dimension are re-reads of the last chunk, and are "consumed" by an empty asm.
+
+    // rows of this pass: acc[u][c] += chunk(T[u], k) chunk(tb + c, k)' over the finished block columns
+    // (NR = rows actually present in this pass: a slot carries NR + 2 loads -- a wavefront pays ~100 cycles per 1 KB load, so the
+    // single-row case, the usual one once a member has fewer rows than wavefronts, does not request a second row it does not have)
+    // Half-chunks [kA, kB) only.  The sum over the whole inner dimension is DEFINED in three thirds, ((S + P0) + P1) + P2 with S
+    // the source tile, P0 accumulated onto S and P1, P2 accumulated from zero and added in this order -- so that the thirds of a
+    // row can be computed by different wavefronts without changing a bit: with every member's look-ahead work off the critical
+    // path, a block column is as long as the rank-k update of ONE row on one wavefront (26 k cycles for 64 half-chunks at
+    // n = 1078: three loads per half-chunk at ~100 cycles each), and a member with fewer rows than row wavefronts has idle
+    // wavefronts to run the other thirds' load streams.  A wavefront that covers several thirds itself folds at the cuts.
+    //   owner of the rows: kA = 0, acc = source tiles on entry, running sum on exit;  helper: one third, acc = 0 on entry
+    template <int NR>
+    __device__ __forceinline__ void ring_rows(int jb, int ntr, int lane, const int (&T)[GRP_RMAXT], const bool (&act)[GRP_RMAXT],
+                                              v4d (&acc)[GRP_RMAXT][2], int kA, int kB) const {
+        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+        const int tb = 2 * jb, nk2 = 4 * jb, klast = kB - 1;
+        const int c1 = nk2 / 3, c2 = 2 * nk2 / 3;           // the cuts between the thirds
+        const bool two = tb + 1 < ntr;
+        v4d stash[NR][2];
+        bool stashed = false;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) { stash[u][0] = (v4d){0, 0, 0, 0}; stash[u][1] = (v4d){0, 0, 0, 0}; }
+        const char* rb0 = uniform_ptr(tile2(tb, 0));
+        const char* rb1 = uniform_ptr(tile2(two ? tb + 1 : tb, 0));
+        const char* ra[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tb, 0));
+        const unsigned voff = (unsigned)fo * 16u;
+        struct Sl { v2d b0, b1, a[NR]; };
+        auto load = [&](Sl& s_, int k2) {
+            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+            s_.b0 = gload16(uniform_ptr(rb0 + o), voff); s_.b1 = gload16(uniform_ptr(rb1 + o), voff);
+#pragma unroll
+            for (int u = 0; u < NR; ++u) s_.a[u] = gload16(uniform_ptr(ra[u] + o), voff);
+        };
+        auto mult = [&](const Sl& s_, int k2) {
+            if (k2 < kB) {
+                if (k2 > kA && (k2 == c1 || k2 == c2)) {
+                    // a cut inside this wavefront's range: the finished third joins the running sum, the next one starts from zero
+#pragma unroll
+                    for (int u = 0; u < NR; ++u)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            stash[u][c] = stashed ? stash[u][c] + acc[u][c] : acc[u][c];
+                            acc[u][c] = (v4d){0, 0, 0, 0};
+                        }
+                    stashed = true;
+                }
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    if (act[u]) {
+                        acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0.x, s_.a[u].x, acc[u][0], 0, 0, 0);
+                        if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1.x, s_.a[u].x, acc[u][1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    if (act[u]) {
+                        acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0.y, s_.a[u].y, acc[u][0], 0, 0, 0);
+                        if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1.y, s_.a[u].y, acc[u][1], 0, 0, 0);
+                    }
+                }
+            } else {
+                asm volatile("" :: "v"(s_.b0), "v"(s_.b1));
+#pragma unroll
+                for (int u = 0; u < NR; ++u) asm volatile("" :: "v"(s_.a[u]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int LPS = 2 + NR;                  // loads per slot
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // the newest two chunks of rows tb, tb+1 were stored by this member's look-ahead wavefront in the previous block
+        // column: wait for them just before the first request that reaches that far
+        bool gated = kB <= nk2 - 4;                  // (a range that does not reach them needs no wait)
+        if (!gated && kA + GRP_ROW_RING - 2 >= nk2 - 4) { wait_diag_rows(tb, two, jb); gated = true; }
+        constexpr int NS = GRP_ROW_RING;
+        Sl r[NS];
+#pragma unroll
+        for (int i_ = 0; i_ < NS - 1; ++i_) load(r[i_], kA + i_);
+        for (int kb = kA; kb < kB; kb += NS) {
+            if (!gated && kb + 2 * NS - 2 >= nk2 - 4) { wait_diag_rows(tb, two, jb); gated = true; }
+#pragma unroll
+            for (int i_ = 0; i_ < NS; ++i_) {
+                load(r[(i_ + NS - 1) % NS], kb + i_ + NS - 1);
+                vm_wait<(NS - 1) * LPS>();
+                mult(r[i_], kb + i_);
+            }
+        }
+        vm_wait<0>();
+#pragma unroll
+        for (int i_ = 0; i_ < NS; ++i_) mult(r[i_], kB);       // (pins)
+        if (stashed) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[u][c] = stash[u][c] + acc[u][c];
+        }
+    }
+
+    // The look-ahead accumulators of block column jbn (tile rows R2 = 2 jbn + 2, R3 = R2 + 1 against rows tbn = 2 jbn, tbn + 1
+    // and themselves), in the member that owns R2, R3.  The seven tiles are products of chunks of FOUR tile rows, and a
+    // single CU draws only ~20 bytes per cycle from beyond its L2, so (a) every operand chunk is requested once per member:
+    // the inner dimension is cut into contiguous slices, one per row wavefront 2..7, each accumulating all seven tiles over
+    // its slice, the partial sums added up in LDS in wavefront order (la_reduce: a fixed order, independent of the group
+    // size); and (b) the bulk of it happens ONE BLOCK COLUMN EARLY: during block column jbn - 1 the owner accumulates the
+    // "old range" -- block columns 0 .. jbn - 3, half-chunks [0, 4 (jbn - 2)) -- which needs nothing of the two newest
+    // columns; when column jbn starts only its "new range" (the eight half-chunks of block columns jbn - 2, jbn - 1) is
+    // left, one 32-load step of wavefront 1 (la_new_range), and every other member gets the accumulators while its chain
+    // still works on the diagonal block.  (Accumulated within block column jbn itself, the seven-tile loop was what every
+    // member waited for: 29 k of 46 k cycles per block column at n = 1078.  With the old range reaching up to column
+    // jbn - 2 the owners serialise: each needs the previous owner's newest stores before it can start, 51 k per column.)
+    struct LaAcc { v4d p20, p21, p30, p31, e11, e21, e22; };
+    // Segment s of the old range of la(jbn) is accumulated (during block column jbn - 1) by the member (s + 1) G / (SEG + 1)
+    // places behind the owner of the rows in the ring: spread evenly, so that the extra work does not land on the members that
+    // are about to become owners themselves -- whoever accumulates enters its next block column that much later, and a plain
+    // member has no slack to catch up before everybody waits for ITS publication (tools/probe_timeline.py: with the whole
+    // old range on the next owner it arrived 25 k cycles late at n = 1078).  With fewer members than segments a member takes
+    // several, one after the other.
+    __device__ __forceinline__ int la_segment_member(int jbn, int s_) const { return ((jbn + 1) + ((s_ + 1) * G) / (GRP_LA_SEG + 1)) % G; }
+    // tile row T complete through block column `cols` - 1: this member's own rows through LDS, another member's through its
+    // global word
+    __device__ __forceinline__ void wait_row_any(int T, int cols) const {
+        if (mine(T)) { wait_row(T, cols); return; }
+        const int want = prog_value(cols);
+        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&gs[16 + T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want;) {
+            __builtin_amdgcn_s_sleep(1);
+            trap_if(++spins > kSpinLimit);
+        }
+        asm volatile("" ::: "memory");
+    }
+    // segment `seg` of the old range of la(jbn), slice of row wavefront w = 2..7; called during block column jbn - 1 >= 2 by the
+    // member the segment is dealt to
+    __device__ __forceinline__ void ring_la_slice(int jbn, int ntr, int lane, int w, int seg, LaAcc& A) const {
+        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+        const int jb = jbn;                                  // (names as in the formulas above)
+        const int tb = 2 * jb, nk2 = 4 * (jb - 2);
+        const bool v3 = tb + 3 < ntr;
+        // all four operand rows complete through block column jbn - 3: their owners said so a whole block column ago
+        wait_row_any(tb, jb - 2);
+        wait_row_any(tb + 1, jb - 2);
+        wait_row_any(tb + 2, jb - 2);
+        if (v3) wait_row_any(tb + 3, jb - 2);
+        const int s0 = seg * nk2 / GRP_LA_SEG, ns_ = (seg + 1) * nk2 / GRP_LA_SEG - s0;
+        const int k0 = s0 + (w - 2) * ns_ / 6, k1 = s0 + (w - 1) * ns_ / 6, klast = k1 - 1;      // this wavefront's half-chunks
+        if (k1 <= k0) return;
+        const char* r0p = uniform_ptr(tile2(tb, 0));
+        const char* r1p = uniform_ptr(tile2(tb + 1, 0));
+        const char* r2p = uniform_ptr(tile2(tb + 2, 0));
+        const char* r3p = uniform_ptr(tile2(v3 ? tb + 3 : tb + 2, 0));          // (padding row: its tiles are replaced by the caller)
+        const unsigned voff = (unsigned)fo * 16u;
+        struct Sl { v2d c0, c1, c2, c3; };
+        auto load = [&](Sl& s_, int k2) {
+            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+            s_.c0 = gload16(uniform_ptr(r0p + o), voff); s_.c1 = gload16(uniform_ptr(r1p + o), voff);
+            s_.c2 = gload16(uniform_ptr(r2p + o), voff); s_.c3 = gload16(uniform_ptr(r3p + o), voff);
+        };
+        auto mult = [&](const Sl& s_, int k2) {
+            if (k2 < k1) {
+                A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c0.x, s_.c2.x, A.p20, 0, 0, 0);
+                A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c1.x, s_.c2.x, A.p21, 0, 0, 0);
+                A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c0.x, s_.c3.x, A.p30, 0, 0, 0);
+                A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c1.x, s_.c3.x, A.p31, 0, 0, 0);
+                A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c2.x, s_.c2.x, A.e11, 0, 0, 0);
+                A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c2.x, s_.c3.x, A.e21, 0, 0, 0);
+                A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c3.x, s_.c3.x, A.e22, 0, 0, 0);
+                A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c0.y, s_.c2.y, A.p20, 0, 0, 0);
+                A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c1.y, s_.c2.y, A.p21, 0, 0, 0);
+                A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c0.y, s_.c3.y, A.p30, 0, 0, 0);
+                A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c1.y, s_.c3.y, A.p31, 0, 0, 0);
+                A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c2.y, s_.c2.y, A.e11, 0, 0, 0);
+                A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c2.y, s_.c3.y, A.e21, 0, 0, 0);
+                A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.c3.y, s_.c3.y, A.e22, 0, 0, 0);
+            } else {
+                asm volatile("" :: "v"(s_.c0), "v"(s_.c1), "v"(s_.c2), "v"(s_.c3));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NS = GRP_LA_RING;
+        Sl r[NS];
+#pragma unroll
+        for (int i_ = 0; i_ < NS - 1; ++i_) load(r[i_], k0 + i_);
+        for (int kb = k0; kb < k1; kb += NS) {
+#pragma unroll
+            for (int i_ = 0; i_ < NS; ++i_) {
+                load(r[(i_ + NS - 1) % NS], kb + i_ + NS - 1);
+                vm_wait<4 * (NS - 1)>();
+                mult(r[i_], kb + i_);
+            }
+        }
+        vm_wait<0>();
+#pragma unroll
+        for (int i_ = 0; i_ < NS; ++i_) mult(r[i_], k1);       // (pins)
+    }
+    // new range of la(jb) on top of the totals (wavefront 1 of the owner, at the start of block column jb): the half-chunks
+    // of block columns jb - 2 and jb - 1.  The newest tiles this member stored itself a moment ago (rows tb, tb+1: this
+    // wavefront's panel store; R2, R3: its row wavefronts'); those of rows tb, tb+1 in column jb - 2 their owner stored before
+    // it published the look-ahead accumulators this member fetched in the previous block column.
+    // four half-chunks of the four rows: sixteen loads in flight, then 56 MFMAs
+    struct LaChunk4 { v2d c[4][4]; };
+    __device__ __forceinline__ void la_load4(LaChunk4& q, const char* const (&rp)[4], int k0, unsigned voff) const {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q.c[h][r] = gload16(uniform_ptr(rp[r] + (size_t)(k0 + h) * 1024), voff);
+    }
+    static __device__ __forceinline__ void la_mult4(const LaChunk4& q, LaAcc& A) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].x, q.c[h][2].x, A.p20, 0, 0, 0);
+            A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].x, q.c[h][2].x, A.p21, 0, 0, 0);
+            A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].x, q.c[h][3].x, A.p30, 0, 0, 0);
+            A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].x, q.c[h][3].x, A.p31, 0, 0, 0);
+            A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].x, q.c[h][2].x, A.e11, 0, 0, 0);
+            A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].x, q.c[h][3].x, A.e21, 0, 0, 0);
+            A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][3].x, q.c[h][3].x, A.e22, 0, 0, 0);
+            A.p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].y, q.c[h][2].y, A.p20, 0, 0, 0);
+            A.p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].y, q.c[h][2].y, A.p21, 0, 0, 0);
+            A.p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][0].y, q.c[h][3].y, A.p30, 0, 0, 0);
+            A.p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][1].y, q.c[h][3].y, A.p31, 0, 0, 0);
+            A.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].y, q.c[h][2].y, A.e11, 0, 0, 0);
+            A.e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][2].y, q.c[h][3].y, A.e21, 0, 0, 0);
+            A.e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(q.c[h][3].y, q.c[h][3].y, A.e22, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void la_new_range(int jb, int ntr, int lane, LaAcc& A) const {
+        const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+        const int tb = 2 * jb;
+        const bool v3 = tb + 3 < ntr;
+        wait_row(tb + 2, jb);
+        if (v3) wait_row(tb + 3, jb);
+        wait_diag_rows(tb, true, jb);
+        const char* const rp[4] = {uniform_ptr(tile2(tb, 0)), uniform_ptr(tile2(tb + 1, 0)), uniform_ptr(tile2(tb + 2, 0)),
+                                   uniform_ptr(tile2(v3 ? tb + 3 : tb + 2, 0))};
+        const unsigned voff = (unsigned)fo * 16u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // block column jb - 2 first (same order of summation as one pass over the inner dimension), then block column jb - 1
+        // through the same sixteen registers (both in flight at once spills: this wavefront also carries the seven
+        // accumulators through the panel solve)
+        LaChunk4 qa;
+#pragma unroll 1
+        for (int c_ = jb >= 2 ? jb - 2 : 0; c_ < jb; ++c_) {
+            la_load4(qa, rp, 4 * c_, voff);
+            vm_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            la_mult4(qa, A);
+        }
+    }
+    // One segment's partial sums -> LDS, per tile in wavefront order (2 writes, 3 .. 7 add: a fixed order whatever the group
+    // size), pipelined by tile: every tile has its own counter (lacnt[2 + t] counts the additions to tile t over the whole
+    // factorisation), a wavefront walks the tiles in order and only waits for its predecessor ON THAT TILE (one counter for
+    // all seven tiles: 1.6 k cycles per hand-over, measured).  Wavefront 7, the last one on every tile, puts the segment's sum
+    // on top of the running sum of the segments before it, ((P_0 + P_1) + P_2) + .., in global memory -- the member that holds
+    // segment seg - 1 delivered it, a chain of short hand-overs off everybody's critical path -- so that the owner of the rows
+    // fetches ONE buffer at the start of its block column.  `base` = 6 x the segments this member accumulated before.
+    __device__ __forceinline__ void la_reduce(int lane, int w, int base, const LaAcc& A, int jbn, int seg) const {
+        v4d* lt = reinterpret_cast<v4d*>(latile) + lane;
+        const v4d* a_ = &A.p20;
+        v2d t_[14];
+        if (w == 7 && seg > 0) {
+            const int want = GRP_LA_SEG * (fidx - 1) + seg;
+            for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&gs[16 + GRP_OWN + jbn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want;) {
+                __builtin_amdgcn_s_sleep(1);
+                trap_if(++spins > kSpinLimit);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* src = uniform_ptr(laseg + (size_t)jbn * 7 * 256);
+            const unsigned vo = (unsigned)lane * 32u;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                t_[2 * q] = gload16_sc1(src + q * 2048, vo);
+                t_[2 * q + 1] = gload16_sc1(src + q * 2048 + 16, vo);
+            }
+            vm_wait<0>();
+#pragma unroll
+            for (int q = 0; q < 14; ++q) asm volatile("" : "+v"(t_[q]));
+        }
+        v4d* dst = reinterpret_cast<v4d*>(laseg + (size_t)jbn * 7 * 256) + lane;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            for (int spins = 0; lds_peek32(lacnt + 2 + t) < base + (w - 2);) trap_if(++spins > kSpinLimit);
+            asm volatile("" ::: "memory");
+            if (w == 2) lt[64 * t] = a_[t];
+            else if (w < 7) lt[64 * t] += a_[t];
+            else {
+                const v4d p_ = lt[64 * t] + a_[t];
+                dst[64 * t] = seg > 0 ? (v4d){t_[2 * t].x, t_[2 * t].y, t_[2 * t + 1].x, t_[2 * t + 1].y} + p_ : p_;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(lacnt + 2 + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (w == 7) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&gs[16 + GRP_OWN + jbn], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // =========================================================================================================================
+    __device__ __forceinline__ bool factor() {
+        const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int ntr = (n + 15) >> 4;
+        ++fidx;
+        group_sync();                            // every member has finished sweeping the previous factor: its tiles may go
+        for (int i = tid; i < GRP_OWN; i += RT) rowdone[i] = 0;
+        if (tid < 16) lacnt[tid] = 0;              // (the per-tile counters of la_reduce)
+        if (tid == 0) sm.flag[1] = 0;
+        if (wv == 1) {
+            // prologue: diagonal block of column 0 straight from P
+            const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+            v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
+            const v4d d11 = init_tile(0, 0, ntr, fo, li, kq);
+            const v4d d21 = init_tile(1, 0, ntr, fo, li, kq);
+            const v4d d22 = init_tile(1, 1, ntr, fo, li, kq);
+            stage_dsc(d11);
+            img21[lane] = d21;
+            img21[64 + lane] = d22;
+        }
+        __syncthreads();
+        bool ok;
+        if (wv == 0) ok = factor_chain();
+        else if (wv == 1) ok = factor_lookahead();
+        else ok = factor_rows(wv);
+        if (ok) group_sync();                    // every tile of every member in memory (and this CU's L1 invalidated)
+        return ok;                               // (a failed factorisation left through barrier (A) in every wavefront of every member)
+    }
+
+    // ======== wavefront 0: factor + invert the diagonal blocks (redundantly in every member) =====================================
+    __device__ __forceinline__ bool factor_chain() {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;
+        const int nblk = (n + NB - 1) / NB;
+        double* U = sm.U;
+        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
+        v4d* const img22 = img21 + 64;
+        for (int jb = 0; jb < nblk; ++jb) {
+            const int j0 = jb * NB;
+            PROF_DECL
+            TS_DECL
+            TS(0);
+            for (int spins = 0; lds_peek32(&sm.flag[1]) < jb;) {                        // diagonal block jb staged
+                __builtin_amdgcn_s_sleep(1);
+                trap_if(++spins > kSpinLimit);
+            }
+            asm volatile("" ::: "memory");
+            PROF(2);
+            TS(1);
+            bool ok = cholinv16_dsc(j0, 0);
+            TS(2);
+            const v4d d21 = img21[lane];
+            v4d d22 = img22[lane];
+            v4d x21 = (v4d){0, 0, 0, 0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                x21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + li) * PLD + 4 * s_ + kq], d21[s_], x21, 0, 0, 0);
+            // L21: into the LDS scratch block for this block column's first pass, and as tile (tb + 1, 2 jb) of L (a slot nothing
+            // else uses) for later passes, which may run while this wavefront already factors the next diagonal block.  (Every
+            // member stores the same bits there.)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) sm.t21[li * DLD + kq + 4 * rg] = x21[rg];
+            {
+                double2* d0 = const_cast<double2*>(tile2(2 * jb + 1, 2 * jb)) + fo;
+                d0[0] = make_double2(x21[0], x21[1]);
+                d0[64] = make_double2(x21[2], x21[3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq], x21[s_], d22, 0, 0, 0);
+            ok = cholinv16(d22, j0 + 16, 16) && ok;
+            PROF(12);
+            TS(5);
+            if (lane == 0) sm.flag[0] = ok ? 0 : 1;
+            __syncthreads();                                    // (A) W1, L21, W2 published
+            PROF(1);
+            TS(6);
+            if (sm.flag[0]) return false;
+            // lower-left block of the inverse for the solves: W21 = -W2 (L21 W1)
+            v4d y = (v4d){0, 0, 0, 0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                y = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.t21[li * DLD + 4 * s_ + kq],
+                                                         U[(size_t)(j0 + 4 * s_ + kq) * PLD + li], y, 0, 0, 0);
+            v4d w21 = (v4d){0, 0, 0, 0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq], y[s_], w21, 0, 0, 0);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
+            // (A2): separates this block column's readers of the L21 scratch block from its next writer (in the batch kernel
+            // it also publishes the forward-substituted right-hand-side block)
+            TS(8);
+            lds_barrier();                                      // (A2)
+            PROF(3);
+            TS(7);
+            TS_PRINT();
+        }
+        return true;
+    }
+
+    // ======== wavefront 1: the two tile rows R2 = tb+2, R3 = tb+3 of the NEXT diagonal block (redundantly in every member) =======
+    __device__ __forceinline__ bool factor_lookahead() {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;
+        const int nblk = (n + NB - 1) / NB;
+        const int ntr = (n + 15) >> 4;
+        double* U = sm.U;
+        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
+        v4d* const img22 = img21 + 64;
+        for (int jb = 0; jb < nblk; ++jb) {
+            const int j0 = jb * NB;
+            const int tb = j0 >> 4;
+            const int R2 = tb + 2, R3 = tb + 3;
+            const bool v2 = R2 < ntr, v3 = R3 < ntr;
+            PROF_DECL
+            if (jb > 0) {
+                // the tiles this wavefront stored in the previous column (rows tb, tb+1 now) are in memory: tell the row wavefronts
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane < 2) rowdone[tb + lane] = (unsigned char)jb;
+            }
+            PROFW(20);
+            TS_DECL
+            TS(0);
+            v4d p20, p21, p30, p31, e11, e21, e22;
+            if (v2) {
+                if (jb == 0) {
+                    p20 = init_tile(R2, tb, ntr, fo, li, kq);      p21 = init_tile(R2, tb + 1, ntr, fo, li, kq);
+                    p30 = init_tile(R3, tb, ntr, fo, li, kq);      p31 = init_tile(R3, tb + 1, ntr, fo, li, kq);
+                    e11 = init_tile(R2, R2, ntr, fo, li, kq);      e21 = init_tile(R3, R2, ntr, fo, li, kq);
+                    e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                } else {
+                    const bool la = la_owner(jb);
+                    LaAcc T_;
+                    if (la) {
+                        // source tiles, plus the old range (jb >= 3): the running sum of its GRP_LA_SEG segments, accumulated during
+                        // the previous block column by members spread around the ring (la_segment_member)
+                        T_.p20 = init_tile(R2, tb, ntr, fo, li, kq);      T_.p21 = init_tile(R2, tb + 1, ntr, fo, li, kq);
+                        T_.p30 = init_tile(R3, tb, ntr, fo, li, kq);      T_.p31 = init_tile(R3, tb + 1, ntr, fo, li, kq);
+                        T_.e11 = init_tile(R2, R2, ntr, fo, li, kq);      T_.e21 = init_tile(R3, R2, ntr, fo, li, kq);
+                        T_.e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                        if (jb >= 3) {
+                            const int want = GRP_LA_SEG * fidx;
+                            for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&gs[16 + GRP_OWN + jb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want;) {
+                                __builtin_amdgcn_s_sleep(1);
+                                trap_if(++spins > kSpinLimit);
+                            }
+                            asm volatile("" ::: "memory");
+                            const unsigned vo = (unsigned)lane * 32u;
+                            const char* src = uniform_ptr(laseg + (size_t)jb * 7 * 256);
+                            v2d t_[14];
+#pragma unroll
+                            for (int q = 0; q < 7; ++q) {
+                                t_[2 * q] = gload16_sc1(src + q * 2048, vo);
+                                t_[2 * q + 1] = gload16_sc1(src + q * 2048 + 16, vo);
+                            }
+                            vm_wait<0>();
+#pragma unroll
+                            for (int q = 0; q < 14; ++q) asm volatile("" : "+v"(t_[q]));
+                            auto cat = [&](int q) { return (v4d){t_[2 * q].x, t_[2 * q].y, t_[2 * q + 1].x, t_[2 * q + 1].y}; };
+                            T_.p20 += cat(0); T_.p21 += cat(1); T_.p30 += cat(2); T_.p31 += cat(3);
+                            T_.e11 += cat(4); T_.e21 += cat(5); T_.e22 += cat(6);
+                        }
+                    }
+                    if (la) {
+                        PROFW(21);
+                        TS(1);
+                        la_new_range(jb, ntr, lane, T_);
+                        PROFW(22);
+                        TS(3);
+                        p20 = T_.p20; p21 = T_.p21; p30 = T_.p30; p31 = T_.p31; e11 = T_.e11; e21 = T_.e21; e22 = T_.e22;
+                        if (G > 1) {
+                            // publish the seven raw accumulators (register images) for the other members
+                            v4d* dst = reinterpret_cast<v4d*>(labuf + (size_t)jb * 7 * 256) + lane;
+                            dst[0] = p20; dst[64] = p21; dst[128] = p30; dst[192] = p31; dst[256] = e11; dst[320] = e21; dst[384] = e22;
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (lane == 0) __hip_atomic_store(&gs[3], prog_value(jb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        TS(4);
+                    } else {
+                        // the owner's accumulators
+                        PROFW(21);
+                        TS(1);
+                        const int want = prog_value(jb + 1);
+                        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&gs[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want;) {
+                            __builtin_amdgcn_s_sleep(1);
+                            trap_if(++spins > kSpinLimit);
+                        }
+                        asm volatile("" ::: "memory");
+                        PROFW(22);
+                        TS(3);
+                        const char* src = uniform_ptr(labuf + (size_t)jb * 7 * 256);
+                        const unsigned vo = (unsigned)lane * 32u;
+                        v2d t_[14];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) {
+                            t_[2 * q] = gload16_sc1(src + q * 2048, vo);
+                            t_[2 * q + 1] = gload16_sc1(src + q * 2048 + 16, vo);
+                        }
+                        vm_wait<0>();
+#pragma unroll
+                        for (int q = 0; q < 14; ++q) asm volatile("" : "+v"(t_[q]));
+                        auto cat = [&](int q) { return (v4d){t_[2 * q].x, t_[2 * q].y, t_[2 * q + 1].x, t_[2 * q + 1].y}; };
+                        p20 = cat(0); p21 = cat(1); p30 = cat(2); p31 = cat(3); e11 = cat(4); e21 = cat(5); e22 = cat(6);
+                        TS(4);
+                    }
+                    if (!v3) {
+                        // R3 is pure padding: no panel tiles, identity diagonal
+                        p30 = (v4d){0, 0, 0, 0}; p31 = (v4d){0, 0, 0, 0}; e21 = (v4d){0, 0, 0, 0};
+                        e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                    }
+                }
+            }
+            TS(5);
+            __syncthreads();                                    // (A)
+            PROFW(23);
+            TS(6);
+            if (sm.flag[0]) return false;
+            if (v2) {
+                double wn1[4], l21[4], wn2[4];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    wn1[s_] = -U[(size_t)(j0 + li) * PLD + 4 * s_ + kq];
+                    l21[s_] = sm.t21[li * DLD + 4 * s_ + kq];
+                    wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
+                }
+                v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    x20 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p20[s_], x20, 0, 0, 0);
+                    x30 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p30[s_], x30, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x20[s_], p21, 0, 0, 0);
+                    p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x30[s_], p31, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    x21_ = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p21[s_], x21_, 0, 0, 0);
+                    x31 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p31[s_], x31, 0, 0, 0);
+                }
+                // (every member stores the same bits into the shared factor: its own row wavefronts and its own next look-ahead
+                // pass read them back, and the sweeps read them after the group barrier)
+                {
+                    double2* d0 = const_cast<double2*>(tile2(R2, 2 * jb)) + fo;
+                    d0[0] = make_double2(x20[0], x20[1]);   d0[64] = make_double2(x20[2], x20[3]);
+                    d0[128] = make_double2(x21_[0], x21_[1]); d0[192] = make_double2(x21_[2], x21_[3]);
+                }
+                if (v3) {
+                    double2* d0 = const_cast<double2*>(tile2(R3, 2 * jb)) + fo;
+                    d0[0] = make_double2(x30[0], x30[1]);   d0[64] = make_double2(x30[2], x30[3]);
+                    d0[128] = make_double2(x31[0], x31[1]); d0[192] = make_double2(x31[2], x31[3]);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x20[s_], e11, 0, 0, 0);
+                    e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x30[s_], e21, 0, 0, 0);
+                    e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x30[s_], x30[s_], e22, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x21_[s_], e11, 0, 0, 0);
+                    e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x31[s_], e21, 0, 0, 0);
+                    e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x31[s_], x31[s_], e22, 0, 0, 0);
+                }
+                stage_dsc(e11);
+                img21[lane] = e21;
+                img22[lane] = e22;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) *(volatile int*)&sm.flag[1] = jb + 1;      // diagonal block jb + 1 staged: the chain may start
+                lds_barrier();                                  // (A2)
+            } else {
+                lds_barrier();                                  // (A2)
+            }
+            PROFW(24);
+            TS(7);
+            TS_PRINT();
+        }
+        return true;
+    }
+
+    // ======== wavefronts 2..7: this member's rows below =============================================================================
+    __device__ __forceinline__ bool factor_rows(int wv) {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;
+        const int nblk = (n + NB - 1) / NB;
+        const int ntr = (n + 15) >> 4;
+        double* U = sm.U;
+        int laown = 0;                               // old-range segments this member accumulated so far
+        for (int jb = 0; jb < nblk; ++jb) {
+            const int j0 = jb * NB;
+            const int tb = j0 >> 4;
+            RowMask mask = my_rows(jb, wv, lane, ntr);
+            PROF_DECL
+            TS_DECL
+            TS(0);
+            if (jb > 0) {
+                // everything this wavefront stored in the previous block column is in memory (the wait also covers the source
+                // tiles requested after those stores).  The rows somebody else reads next: tb + 2, tb + 3 (the look-ahead rows
+                // from now on: wavefront 1 of this member, and the member that accumulates the NEXT look-ahead block, through
+                // the global word) and tb + 4, tb + 5 (this member's own old-range pass below)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane < 6) {
+                    const int T = tb + 2 + lane;
+                    if (T < ntr && owner[T] == wv) {
+                        rowdone[T] = (unsigned char)jb;
+                        if (G > 1) __hip_atomic_store(&gs[16 + T], prog_value(jb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (wv == 2) PROFW(26);
+            TS(1);
+            // the old range of the NEXT block column's look-ahead accumulators: the segments dealt to this member
+            // (la_segment_member), this wavefront's slice of each, added to the segment's sum in LDS (ring_la_slice, la_reduce)
+            if (jb >= 2 && tb + 4 < ntr) {
+                const int jbn = jb + 1;
+#pragma unroll 1
+                for (int sg = 0; sg < GRP_LA_SEG; ++sg) {
+                    if (la_segment_member(jbn, sg) != g) continue;
+                    LaAcc A_;
+                    A_.p20 = A_.p21 = A_.p30 = A_.p31 = A_.e11 = A_.e21 = A_.e22 = (v4d){0, 0, 0, 0};
+                    ring_la_slice(jbn, ntr, lane, wv, sg, A_);
+                    la_reduce(lane, wv, 6 * laown, A_, jbn, sg);
+                    ++laown;
+                }
+            }
+            if (wv == 2) PROFW(27);
+            TS(4);
+            const int mine = count_rows(mask);
+            const int npass = mine > GRP_RMAXT ? (mine + GRP_RMAXT - 1) / GRP_RMAXT : 1;
+            // Helpers (ring_rows): the deal gives wavefronts 4 and 5 their rows first, then 2, 3, then 6, 7.  A wavefront with no
+            // rows in this block column takes a third of the inner dimension of its partner's first pass -- 6 (7) the last
+            // third of 4's (5's) rows, 2 (3) the middle third if 6 (7) is idle too -- and hands the partial sums over through
+            // LDS before barrier (A); the owner covers what is left and adds the thirds in order behind the barrier.
+            const int nk2r = 4 * jb, c1r = nk2r / 3, c2r = 2 * nk2r / 3;
+            int hfor = 0, hslice = 0;                       // helper: the wavefront whose rows it takes a third of, which third
+            int kBown = nk2r;                               // owner: the end of its own range
+            bool h1 = false, h2 = false;
+            RowMask pm = mask;
+            if (jb > 0) {
+                auto cnt = [&](int w_) { return count_rows(my_rows(jb, w_, lane, ntr)); };
+                if (wv == 6 || wv == 7) {
+                    if (mine == 0 && cnt(wv - 2) > 0) { hfor = wv - 2; hslice = 2; }
+                } else if (wv == 2 || wv == 3) {
+                    if (mine == 0 && cnt(wv + 4) == 0 && cnt(wv + 2) > 0) { hfor = wv + 2; hslice = 1; }
+                } else if (mine > 0) {                      // 4, 5
+                    h2 = cnt(wv + 2) == 0;
+                    h1 = h2 && cnt(wv - 2) == 0;
+                    kBown = h1 ? c1r : h2 ? c2r : nk2r;
+                }
+                if (hfor) pm = my_rows(jb, hfor, lane, ntr);
+            }
+#pragma unroll 1
+            for (int ps = 0; ps < npass; ++ps) {
+                int T[GRP_RMAXT];
+                bool act[GRP_RMAXT];
+#pragma unroll
+                for (int u = 0; u < GRP_RMAXT; ++u) {
+                    const int t_ = pop_row(mask, tb);
+                    T[u] = t_ >= 0 ? t_ : nch;
+                    act[u] = t_ >= 0;
+                }
+                v4d acc[GRP_RMAXT][2];
+                int Tc[GRP_RMAXT];
+                bool ac[GRP_RMAXT];
+                const bool helping = ps == 0 && hfor != 0;
+#pragma unroll
+                for (int u = 0; u < GRP_RMAXT; ++u) {
+                    if (helping) { const int t_ = pop_row(pm, tb); Tc[u] = t_ >= 0 ? t_ : nch; ac[u] = t_ >= 0; }
+                    else { Tc[u] = T[u]; ac[u] = act[u]; }
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[u][ct] = (ac[u] && !helping) ? init_tile(Tc[u], tb + ct, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                }
+                TS(9);
+                if (jb > 0 && ac[0]) {
+                    // (a helper: one third of the partner's first-pass rows from zero; the owner: from the source tiles up to the
+                    // first third a helper takes, everything in the later passes)
+                    const int ka_ = helping ? (hslice == 1 ? c1r : c2r) : 0;
+                    const int kb_ = helping ? (hslice == 1 ? c2r : nk2r) : (ps == 0 ? kBown : nk2r);
+                    if (ac[GRP_RMAXT - 1]) ring_rows<GRP_RMAXT>(jb, ntr, lane, Tc, ac, acc, ka_, kb_);
+                    else ring_rows<1>(jb, ntr, lane, Tc, ac, acc, ka_, kb_);
+                }
+                if (helping) {
+                    v4d* dst = reinterpret_cast<v4d*>(rowx) + (size_t)(((hfor - 4) * 2 + (hslice - 1)) * GRP_RMAXT * 2) * 64 + lane;
+#pragma unroll
+                    for (int u = 0; u < GRP_RMAXT; ++u) { dst[(2 * u) * 64] = acc[u][0]; dst[(2 * u + 1) * 64] = acc[u][1]; }
+                }
+                if (ps == 0) {
+                    if (wv == 2) PROFW(28);
+                    TS(5);
+                    __syncthreads();                            // (A) W1, L21, W2 published by wavefront 0
+                    if (wv == 2) PROFW(29);
+                    TS(6);
+                    if (sm.flag[0]) return false;
+                    if (h2) {
+                        // the helpers' thirds, in order
+                        const v4d* src = reinterpret_cast<const v4d*>(rowx) + (size_t)((wv - 4) * 2 * GRP_RMAXT * 2) * 64 + lane;
+                        if (h1) {
+#pragma unroll
+                            for (int u = 0; u < GRP_RMAXT; ++u) { acc[u][0] += src[(2 * u) * 64]; acc[u][1] += src[(2 * u + 1) * 64]; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < GRP_RMAXT; ++u) {
+                            acc[u][0] += src[(GRP_RMAXT * 2 + 2 * u) * 64];
+                            acc[u][1] += src[(GRP_RMAXT * 2 + 2 * u + 1) * 64];
+                        }
+                    }
+                }
+                if (act[0]) {
+                    double wn1[4], l21[4], wn2[4];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        wn1[s_] = -U[(size_t)(j0 + li) * PLD + 4 * s_ + kq];
+                        wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
+                    }
+                    if (ps == 0) {
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_) l21[s_] = sm.t21[li * DLD + 4 * s_ + kq];
+                    } else {
+                        // later passes: from the copy in L (the LDS block may already hold the next block's L21)
+                        const double2* t_ = tile2(tb + 1, 2 * jb) + fo;
+                        const double2 h0 = t_[0], h1 = t_[64];
+                        l21[0] = h0.x; l21[1] = h0.y; l21[2] = h1.x; l21[3] = h1.y;
+                    }
+                    v4d x1[GRP_RMAXT], x2[GRP_RMAXT];
+#pragma unroll
+                    for (int u = 0; u < GRP_RMAXT; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int u = 0; u < GRP_RMAXT; ++u)
+                            x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int u = 0; u < GRP_RMAXT; ++u)
+                            acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int u = 0; u < GRP_RMAXT; ++u)
+                            x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < GRP_RMAXT; ++u) {
+                        if (act[u]) {
+                            double2* d0 = const_cast<double2*>(tile2(T[u], 2 * jb)) + fo;
+                            d0[0] = make_double2(x1[u][0], x1[u][1]);
+                            d0[64] = make_double2(x1[u][2], x1[u][3]);
+                            d0[128] = make_double2(x2[u][0], x2[u][1]);
+                            d0[192] = make_double2(x2[u][2], x2[u][3]);
+                        }
+                    }
+                    if (ps == 0) lds_barrier();                 // (A2)
+                } else if (ps == 0) {
+                    lds_barrier();                              // (A2)
+                }
+            }
+            if (wv == 2) PROFW(30);
+            TS(7);
+            TS_PRINT();
+        }
+        return true;
+    }
+};
+
+// LDS of the group kernel (doubles): the fixed buffers of qp_resident.hpp, the two byte tables, the two n-vectors
+static constexpr int GRP_FIXED = 4 * 8 * 4 + 2 * 16 * 17 + 8 + 512 + 2 * GRP_OWN / 8 + 7 * 256 + 8 + 2 * 2 * GRP_RMAXT * 2 * 256;
+static size_t group_lds_bytes(int NP) { return (size_t)(GRP_FIXED + 2 * (NP + 64)) * sizeof(double); }
+
+// per-problem scratch doubles: the tile-packed factor, one copy of U per member, the look-ahead accumulators of every block
+// column (7 tiles each; a column's slot is written once per factorisation, so no member can overwrite what a slower one
+// has not fetched yet)
+static size_t group_scratch_doubles(int n, int G) {
+    const size_t NP = (size_t)round_up(n, 32);
+    return NP * NP + (size_t)G * NP * PLD + (NP / NB) * 2 * 7 * 256;
+}
+
+// grid: block 8 (r G + g) + s = member g of problem 8 r + s -- the members of a problem are 8 blocks apart, i.e. on one XCD
+// under the round-robin dispatch (checked below)
+__global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int G) {
+    constexpr int RT = 512;
+    const int s_ = blockIdx.x & 7, rg = blockIdx.x >> 3;
+    const int b = 8 * (rg / G) + s_, g = rg % G;
+    if (b >= a.B) return;
+    if (a.active && !a.active[b]) return;
+    if (a.redo_aborted && a.status[b] != HIPDRT_QP_ABORTED) return;
+    extern __shared__ double smem[];
+    OpsGroup ops;
+    ops.G = G; ops.g = g;
+    ops.gs = a.gsync + (size_t)b * GRP_WORDS;
+    ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
+    ops.Ppk = a.Ppk + (size_t)b * a.ppk_stride; ops.nchp = a.nchp;
+    // LDS carve (the pointers of the base class's layout struct are set by hand: n-vectors sized by this launch)
+    ops.sm.red = smem;
+    ops.sm.t21 = ops.sm.red + 4 * 8 * 4;
+    ops.sm.dsc = ops.sm.t21 + 16 * 17;
+    ops.sm.flag = reinterpret_cast<int*>(ops.sm.dsc + 16 * 17);
+    ops.sm.img = ops.sm.dsc + 16 * 17 + 8;
+    ops.owner = reinterpret_cast<unsigned char*>(ops.sm.img + 512);
+    ops.rowdone = ops.owner + GRP_OWN;
+    ops.latile = ops.sm.img + 512 + 2 * GRP_OWN / 8;
+    ops.lacnt = reinterpret_cast<int*>(ops.latile + 7 * 256);
+    ops.rowx = ops.latile + 7 * 256 + 8;
+    ops.sm.vec = ops.rowx + 2 * 2 * GRP_RMAXT * 2 * 256;
+    ops.sm.dvec = ops.sm.vec + NP + 64;
+    ops.sm.U = ops.L + (size_t)NP * NP + (size_t)g * NP * PLD;          // this member's own inverse diagonal blocks
+    ops.labuf = ops.L + (size_t)NP * NP + (size_t)G * NP * PLD;
+    ops.laseg = ops.labuf + (size_t)(NP / NB) * 7 * 256;
+    ops.build_owner();
+    for (int i = threadIdx.x; i < NP * PLD; i += RT) ops.sm.U[i] = 0.0;
+    for (int i = threadIdx.x; i < NP + 64; i += RT) { ops.sm.vec[i] = 0.0; ops.sm.dvec[i] = 0.0; }
+    // ---- rendezvous: all members resident, all on one XCD -------------------------------------------------------------------
+    if (G > 1) {
+        int& xcc_mask = ops.sm.flag[2];
+        if (threadIdx.x == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;      // HW_REG_XCC_ID[3:0]
+            __hip_atomic_fetch_or(&ops.gs[1], 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&ops.gs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(&ops.gs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > OpsGroup::kSpinLimit) __builtin_trap();
+            }
+            xcc_mask = __hip_atomic_load(&ops.gs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (__builtin_popcount(xcc_mask) != 1) {
+            // spread over several XCDs: the L2-coherence assumption does not hold -- every member leaves, the host repeats
+            // this problem on one workgroup
+            if (g == 0 && threadIdx.x == 0) a.status[b] = HIPDRT_QP_ABORTED;
+            return;
+        }
+    }
+    __syncthreads();
+    IpmSmem is{ops.sm.vec, ops.sm.dvec, ops.sm.red};
+    ipm_solve<RT, (GRP_NMAX + RT - 1) / RT>(a, b, ops, is, b * G + g, g == 0);
+}
+
+}  // namespace hipdrt

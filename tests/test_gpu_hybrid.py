@@ -193,12 +193,16 @@ def test_hyper_step_on_many_workgroups_is_bit_identical():
         assert (len(meas[0]) + 2 * len(meas[3])) * (len(tau) + 4) >= 1 << 20       # rows x columns of the response matrix
         many = DRT(fixed_basis_tau=tau, warn=False)
         r40 = many.fit_hybrid_batch(meas[0], [meas[1]] * 40, [meas[2]] * 40, meas[3], [meas[4]] * 40)
+        three = DRT(fixed_basis_tau=tau, warn=False)            # several fits per launch of the many-workgroup kernel
+        r3 = three.fit_hybrid_batch(meas[0], [meas[1]] * 3, [meas[2]] * 3, meas[3], [meas[4]] * 3)
     finally:
         ctx.debug_qp_group(-1)
-    assert r1["outer_iters"][0] == r40["outer_iters"][0] == r40["outer_iters"][39]
+    assert r1["outer_iters"][0] == r40["outer_iters"][0] == r40["outer_iters"][39] == r3["outer_iters"][2]
     for key in ("x", "vz_offset", "R_inf"):
         np.testing.assert_array_equal(r40[key][0], r1[key][0])
         np.testing.assert_array_equal(r40[key][39], r1[key][0])
+        np.testing.assert_array_equal(r3[key][1], r1[key][0])
+        np.testing.assert_array_equal(r3[key][2], r1[key][0])
 
 
 def test_joint_fits_are_scale_and_order_equivariant():

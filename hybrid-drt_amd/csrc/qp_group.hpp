@@ -64,7 +64,7 @@ static constexpr int GRP_MAXG = 32;                    // members (CUs of one XC
 #define HIPDRT_GRP_LA_RING 4
 #endif
 #ifndef HIPDRT_GRP_ROW_RING
-#define HIPDRT_GRP_ROW_RING 8
+#define HIPDRT_GRP_ROW_RING 4
 #endif
 static constexpr int GRP_LA_RING = HIPDRT_GRP_LA_RING;  // slots of the old-range operand ring (ring_la_slice): a ring issues
                                                         // ceil(len / slots) * slots + slots - 1 slots of loads whatever the length, a
@@ -256,6 +256,14 @@ struct OpsGroup : OpsResidentT<true, 512> {
 #pragma unroll
             for (int u = 0; u < NR; ++u) s_.a[u] = gload16(uniform_ptr(ra[u] + o), voff);
         };
+        // Two accumulators per tile: the products of the first four columns of a half-chunk go onto the source tile, those of
+        // the last four into a second accumulator from zero, added at the end -- with one row a wavefront has only two tiles, and a
+        // v_mfma_f64_16x16x4 that has to wait for the one two instructions back costs ~100 cycles instead of 64 (400 cycles per
+        // half-chunk measured for one row against 256 of issue).  The same for two rows, so that a tile's bits do not depend on
+        // how many rows its wavefront happened to have.
+        v4d accy[NR][2];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) { accy[u][0] = (v4d){0, 0, 0, 0}; accy[u][1] = (v4d){0, 0, 0, 0}; }
         auto mult = [&](const Sl& s_, int k2) {
             if (k2 < nk2) {
 #pragma unroll
@@ -268,8 +276,8 @@ struct OpsGroup : OpsResidentT<true, 512> {
 #pragma unroll
                 for (int u = 0; u < NR; ++u) {
                     if (act[u]) {
-                        acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0.y, s_.a[u].y, acc[u][0], 0, 0, 0);
-                        if (two) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1.y, s_.a[u].y, acc[u][1], 0, 0, 0);
+                        accy[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b0.y, s_.a[u].y, accy[u][0], 0, 0, 0);
+                        if (two) accy[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_.b1.y, s_.a[u].y, accy[u][1], 0, 0, 0);
                     }
                 }
             } else {
@@ -302,6 +310,8 @@ struct OpsGroup : OpsResidentT<true, 512> {
         vm_wait<0>();
 #pragma unroll
         for (int i_ = 0; i_ < NS; ++i_) mult(r[i_], nk2);       // (pins)
+#pragma unroll
+        for (int u = 0; u < NR; ++u) { acc[u][0] += accy[u][0]; acc[u][1] += accy[u][1]; }
     }
 
     // The look-ahead accumulators of block column jbn (tile rows R2 = 2 jbn + 2, R3 = R2 + 1 against rows tbn = 2 jbn, tbn + 1

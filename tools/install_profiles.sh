@@ -1,5 +1,6 @@
 #!/bin/bash
 # Move a freshly collected profile set from gpurun_out/ into profiles/ under tag $1, retiring the set tagged $2:
+# (new and old tags must differ: the old set is removed)
 #   bash tools/install_profiles.sh r02i r02h     (run in the repository root, after tools/collect_profiles.sh and pmc_sq_collect.sh)
 new="$1"; old="$2"
 for f in kernel_stats.csv kernel_stats_inflight1.csv pmc_fetch_size.csv pmc_write_size.csv pmc_sq_summary.txt; do

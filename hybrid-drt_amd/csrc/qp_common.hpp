@@ -45,6 +45,21 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// an int / a byte of LDS read NOW (polls of progress words: a volatile C++ load would be a FLAT instruction, which counts in
+// vmcnt as well and returns out of order with the hand-counted loads).  The value goes through readfirstlane: the spin loops
+// around these stay scalar branches -- a loop whose exit depends on a vector register runs under EXEC masking, and
+// hand-issued loads after such a loop were observed to fault.
+static __device__ __forceinline__ int lds_peek32(const void* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+static __device__ __forceinline__ int lds_peek8(const void* p) {
+    int v;
+    asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 // 16 bytes per lane from (wave-uniform base) + (per-lane byte offset), issued as ONE instruction the compiler neither
@@ -54,6 +69,13 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ v2d gload16(const char* sbase, unsigned voff) {
     v2d d;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    return d;
+}
+// the same from a per-lane 64-bit address plus an immediate byte offset (0 .. 4095), no scalar base pair
+template <int OFF>
+static __device__ __forceinline__ v2d gload16v(const void* p) {
+    v2d d;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory");
     return d;
 }
 template <int N>

@@ -85,20 +85,6 @@ static __device__ __forceinline__ v2d gload16_sc1(const char* sbase, unsigned vo
     asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
     return d;
 }
-// an int / a byte of LDS read NOW (polls of progress words: a volatile C++ load would be a FLAT instruction, which counts in
-// vmcnt as well and returns out of order with the hand-counted loads).  The value goes through readfirstlane: the spin loops
-// around these stay scalar branches -- a loop whose exit depends on a vector register runs under EXEC masking, and
-// hand-issued loads after such a loop were observed to fault.
-static __device__ __forceinline__ int lds_peek32(const void* p) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
-    return __builtin_amdgcn_readfirstlane(v);
-}
-static __device__ __forceinline__ int lds_peek8(const void* p) {
-    int v;
-    asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
-    return __builtin_amdgcn_readfirstlane(v);
-}
 
 struct OpsGroup : OpsResidentT<true, 512> {
     using Base = OpsResidentT<true, 512>;

@@ -860,24 +860,58 @@ struct OpsResidentT {
     }
 
     // -----------------------------------------------------------------------------------------------------
-    // vec := S^-1 vec.  Wavefront 0 multiplies by the inverse 32x32 diagonal blocks (LDS resident); wavefronts
-    // 1..7 apply the rank-32 updates.  The update operands (tiles of L in HBM) do not depend on the running
-    // solution, so they are fetched BEFORE the diagonal step of the same block and are in flight meanwhile.
+    // vec := S^-1 vec.  Two roles.  Wavefront 0 multiplies by the inverse 32x32 diagonal blocks (LDS resident) AND applies the
+    // urgent part of a block's rank-32 update itself -- the two tiles that touch the 32 entries its next diagonal step needs;
+    // wavefronts 1.. apply the rest of the update while wavefront 0 is already on the next block.  The sweep's chain is then
+    // diagonal step -> two tiles -> diagonal step on one wavefront, with ONE barrier per block: it publishes y_j to the others
+    // and separates block j's trailing update from block j + 1's.  Every entry still receives the blocks' contributions in the
+    // order 0, 1, 2, ..., each from one wavefront with the same arithmetic (fwd_tile / bwd_chunk): the sums are bit for bit
+    // those of the strictly sequential sweep (diagonal step, barrier, update of all rows, barrier) this replaces.
+    // The update operands (tiles of L in HBM) do not depend on the running solution: they are fetched TWO blocks ahead into
+    // alternating register buffers by hand-issued loads and retired with a counted wait (left to hipcc, every use waits for
+    // vmcnt(0..3), i.e. also for the block requested one step ago), behind the block's arithmetic, so that their issue cost
+    // (~100 cycles per 1 KB load and wavefront) is off the chain.  Wavefront 0's loads take a per-lane 64-bit address
+    // (gload16v): with a scalar base pair, as everywhere else, this role's prefetch faulted on the device with a pointer
+    // whose upper half was wrong -- the kernel sits at the scalar-register limit, cause not found.
     //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane  ->  row i = lane/4,
     //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
+    static constexpr int SW_TW = RNW - 1;                // trailing-update wavefronts
+    static constexpr int SW_FT = (29 + SW_TW - 1) / SW_TW < HIPDRT_QP_SWEEPCAP ? (29 + SW_TW - 1) / SW_TW : HIPDRT_QP_SWEEPCAP;   // forward: buffered tiles each
+    static constexpr int SW_BC = (30 + SW_TW - 1) / SW_TW < HIPDRT_QP_SWEEPCAP ? (30 + SW_TW - 1) / SW_TW : HIPDRT_QP_SWEEPCAP;   // backward: buffered chunks each
+    static constexpr int SW_NBUF = SW_FT > SW_BC ? SW_FT : SW_BC;
+    struct SweepBuf { v2d t[SW_NBUF][4]; };
+    struct UrgentBuf { v2d t[2][4]; };
+
+    // one tile row of the forward update: vec[rows of tile row T] -= L(T, 2jb..2jb+1) y_jb   (t: [chunk*2 + half])
+    __device__ __forceinline__ void fwd_tile(const v2d (&t)[4], const double (&ya)[4], const double (&yb)[4], int T, int l4, int g4) {
+        double pv = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pv += t[q].x * ya[q] + t[q].y * yb[q];
+        pv = quad_sum(pv);
+        if (l4 == 0) {
+            const int row = T * 16 + g4;
+            if (row < n) sm.vec[row] -= pv;
+        }
+    }
+    // one chunk of the backward update: vec[16c ..] -= L(tb..tb+1, c)' x_jb   (t: [tile*2 + half])
+    __device__ __forceinline__ void bwd_chunk(const v2d (&t)[4], double x0, double x1, int c, int lane, int l4) {
+        const double s0 = t[0].x * x0 + t[2].x * x1;     // column 16c + l4
+        const double s1 = t[0].y * x0 + t[2].y * x1;     // column 16c + l4 + 4
+        const double s2 = t[1].x * x0 + t[3].x * x1;     // column 16c + 8 + l4
+        const double s3 = t[1].y * x0 + t[3].y * x1;     // column 16c + 12 + l4
+        const double f = colsum4(s0, s1, s2, s3, lane);   // column 16c + l4 + 4*(lane>>4)
+        if ((lane & 12) == 0) sm.vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
+    }
+
     __device__ __forceinline__ void forward() {
         const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int nblk = (n + NB - 1) / NB;
         const int ntr = (n + 15) >> 4;
         double* vec = sm.vec;
         const double* U = sm.U;
-        constexpr int UW = RNW - 1;                 // updater wavefronts
-        constexpr int FT = (31 + UW - 1) / UW < HIPDRT_QP_SWEEPCAP ? (31 + UW - 1) / UW : HIPDRT_QP_SWEEPCAP;      // forward: buffered tiles per updater wavefront
-        constexpr int BC = (32 + UW - 1) / UW < HIPDRT_QP_SWEEPCAP ? (32 + UW - 1) / UW : HIPDRT_QP_SWEEPCAP;      // backward: buffered chunks per updater wavefront
         PROF_DECL
-        // Two roles, two code paths with matching barrier sequences (per block: one barrier after the diagonal step,
-        // one after the update).  The barriers order LDS traffic only, so the updaters' operand tiles -- fetched TWO
-        // blocks ahead into alternating register buffers -- stay in flight across them.
+        // Two code paths with matching barrier sequences: one barrier per block (behind the diagonal step) and one at the end.
+        // The barriers order LDS traffic only, so operand tiles stay in flight across them.
         if (wv == 0) {
             // ======== wavefront 0: multiply by the inverse 32x32 diagonal blocks ================================
             const int r = lane & 31;
@@ -888,9 +922,42 @@ struct OpsResidentT {
 #pragma unroll
                 for (int c = 0; c < NB; ++c) mr[c] = U[(size_t)r * PLD + c];
             }
-            for (int jb = 0; jb < nblk; ++jb) {          // forward: y = M b (upper-right 16x16 of M is zero)
+            const int l4 = lane & 3, g4 = lane >> 2;
+            auto ucount = [&](int jb) {                 // urgent tile rows of block jb: tb + 2, tb + 3 where they exist
+                const int k = jb < nblk ? ntr - (2 * jb + 2) : 0;
+                return k < 0 ? 0 : (k < 2 ? k : 2);
+            };
+            auto upre = [&](UrgentBuf& B_, int jb) {
+                const int nv = ucount(jb);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u < nv) {
+                        const double2* p = tile2(2 * jb + 2 + u, 2 * jb) + lane;   // chunks 2jb, 2jb+1 are adjacent
+                        B_.t[u][0] = gload16v<0>(p); B_.t[u][1] = gload16v<1024>(p);
+                        B_.t[u][2] = gload16v<2048>(p); B_.t[u][3] = gload16v<3072>(p);
+                    }
+                }
+            };
+            auto urgent = [&](UrgentBuf& B_, int jb) {  // b_(jb+1) -= L(jb+1, jb) y_jb, then the tiles of two blocks on
+                const int j0 = jb * NB, nv = ucount(jb);
+                vm_wait_tiles(ucount(jb + 1));
+                if (nv > 0) {
+                    double ya[4], yb[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { ya[q] = vec[j0 + 8 * q + l4]; yb[q] = vec[j0 + 8 * q + l4 + 4]; }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (u < nv) fwd_tile(B_.t[u], ya, yb, 2 * jb + 2 + u, l4, g4);
+                }
+                upre(B_, jb + 2);
+            };
+            UrgentBuf ua, ub;
+            upre(ua, 0);
+            upre(ub, 1);
+            auto dstep = [&](int jb) {                   // forward: y = M b (upper-right 16x16 of M is zero)
                 const int j0 = jb * NB;
                 const double* Mr = U + (size_t)(j0 + r) * PLD;
+                PROF(6);
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
                 for (int c = 0; c < NB; c += 4) {
@@ -908,39 +975,38 @@ struct OpsResidentT {
 #pragma unroll
                     for (int c = 0; c < NB; ++c) mr[c] = Mr[(size_t)NB * PLD + c];
                 }
-                lds_barrier();
-                PROF(6);
-            }
-        } else {
-            // ======== wavefronts 1..7: rank-32 updates ========================================================
-            //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane -> row lane/4,
-            //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
-            const int l4 = lane & 3, g4 = lane >> 2;
-            struct Buf { v2d t[FT > BC ? FT : BC][4]; };
-            const unsigned voff = (unsigned)lane * 16u;
-            // ---- forward: L y = b -------------------------------------------------------------------------
-            // The operand tiles are requested TWO blocks ahead with gload16 (qp_common.hpp) and retired with a counted wait:
-            // left to hipcc, every use waits for vmcnt(0..3), i.e. also for the block requested one step ago, and a sweep
-            // step (~1.6k cycles of work) is then as long as a memory round trip.  The wait before block jb's tiles are used
-            // allows exactly the loads of block jb+1 to stay in flight (vm_wait_tiles: a uniform switch over the tile count).
-            auto fcount = [&](int jb) {                 // tiles this wavefront requests for block jb
-                const int tbelow = jb < nblk ? ntr - (2 * jb + 2) : 0;
-                const int k = tbelow - (wv - 1) > 0 ? (tbelow - (wv - 1) + UW - 1) / UW : 0;
-                return k < FT ? k : FT;
             };
-            auto fpre = [&](Buf& B_, int jb) {          // tiles (tb+2+tt, 2jb..2jb+1): [tile][chunk*2 + half]
+            // (two blocks per trip, one buffer each: a buffer picked by the block's parity at run time would make hipcc copy
+            // the freshly requested registers at the merge -- before the data has arrived)
+            for (int jb = 0; jb < nblk; jb += 2) {
+                dstep(jb);
+                urgent(ua, jb);
+                if (jb + 1 < nblk) { dstep(jb + 1); urgent(ub, jb + 1); }
+            }
+            vm_wait<0>();
+            lds_barrier();
+        } else {
+            // ======== wavefronts 1..: the rest of the rank-32 updates ==========================================
+            const int l4 = lane & 3, g4 = lane >> 2, tw_ = wv - 1;
+            const unsigned voff = (unsigned)lane * 16u;
+            auto fcount = [&](int jb) {                 // tiles this wavefront requests for block jb (tile rows tb + 4 ..)
+                const int tbelow = jb < nblk ? ntr - (2 * jb + 4) : 0;
+                const int k = tbelow - tw_ > 0 ? (tbelow - tw_ + SW_TW - 1) / SW_TW : 0;
+                return k < SW_FT ? k : SW_FT;
+            };
+            auto fpre = [&](SweepBuf& B_, int jb) {     // tiles (tb+4+tt, 2jb..2jb+1): [tile][chunk*2 + half]
                 const int tb = 2 * jb, nv = fcount(jb);
 #pragma unroll
-                for (int u = 0; u < FT; ++u) {
+                for (int u = 0; u < SW_FT; ++u) {
                     if (u < nv) {
-                        const char* p = uniform_ptr(tile2(tb + 2 + (wv - 1) + u * UW, 2 * jb));   // chunks 2jb, 2jb+1 are adjacent
+                        const char* p = uniform_ptr(tile2(tb + 4 + tw_ + u * SW_TW, 2 * jb));   // chunks 2jb, 2jb+1 are adjacent
 #pragma unroll
                         for (int q = 0; q < 4; ++q) B_.t[u][q] = gload16(p + q * 1024, voff);
                     }
                 }
             };
-            auto fstep = [&](Buf& B_, int jb) {
-                const int j0 = jb * NB, tb = 2 * jb, tbelow = ntr - (tb + 2);
+            auto fstep = [&](SweepBuf& B_, int jb) {
+                const int j0 = jb * NB, tb = 2 * jb, tbelow = ntr - (tb + 4);
                 lds_barrier();
                 vm_wait_tiles(fcount(jb + 1));                      // this block's tiles are in; the next block's may be in flight
                 if (tbelow > 0) {
@@ -949,57 +1015,38 @@ struct OpsResidentT {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { ya[q] = vec[j0 + 8 * q + l4]; yb[q] = vec[j0 + 8 * q + l4 + 4]; }
 #pragma unroll
-                    for (int u = 0; u < FT; ++u) {
-                        const int tt = (wv - 1) + u * UW;
-                        if (tt < tbelow) {
-                            double pv = 0.0;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) pv += B_.t[u][q].x * ya[q] + B_.t[u][q].y * yb[q];
-                            pv = quad_sum(pv);
-                            if (l4 == 0) {
-                                const int row = (tb + 2 + tt) * 16 + g4;
-                                if (row < n) vec[row] -= pv;
-                            }
-                        }
+                    for (int u = 0; u < SW_FT; ++u) {
+                        const int tt = tw_ + u * SW_TW;
+                        if (tt < tbelow) fwd_tile(B_.t[u], ya, yb, tb + 4 + tt, l4, g4);
                     }
                     {
                         // more tile rows below than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
                         // from memory, four tile rows per round -- their sixteen loads are requested together, so a round costs
                         // one memory round trip instead of four
                         constexpr int OVR = (GU && HIPDRT_QP_OVR > 1) ? HIPDRT_QP_OVR : 1;       // (n <= 528 never gets here: no registers spent on it)
-                        for (int tt0 = (wv - 1) + FT * UW; tt0 < tbelow; tt0 += OVR * UW) {
-                            double2 t_[OVR][4];
+                        for (int tt0 = tw_ + SW_FT * SW_TW; tt0 < tbelow; tt0 += OVR * SW_TW) {
+                            v2d t_[OVR][4];
 #pragma unroll
                             for (int j = 0; j < OVR; ++j) {
-                                const int tt = tt0 + j * UW;
+                                const int tt = tt0 + j * SW_TW;
                                 if (tt < tbelow) {
-                                    const double2* p = tile2(tb + 2 + tt, 2 * jb) + lane;
+                                    const double2* p = tile2(tb + 4 + tt, 2 * jb) + lane;
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) t_[j][q] = p[q * 64];
+                                    for (int q = 0; q < 4; ++q) { const double2 d_ = p[q * 64]; t_[j][q] = (v2d){d_.x, d_.y}; }
                                 }
                             }
 #pragma unroll
                             for (int j = 0; j < OVR; ++j) {
-                                const int tt = tt0 + j * UW;
-                                if (tt < tbelow) {
-                                    double pv = 0.0;
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) pv += t_[j][q].x * ya[q] + t_[j][q].y * yb[q];
-                                    pv = quad_sum(pv);
-                                    if (l4 == 0) {
-                                        const int row = (tb + 2 + tt) * 16 + g4;
-                                        if (row < n) vec[row] -= pv;
-                                    }
-                                }
+                                const int tt = tt0 + j * SW_TW;
+                                if (tt < tbelow) fwd_tile(t_[j], ya, yb, tb + 4 + tt, l4, g4);
                             }
                         }
                     }
                 }
                 fpre(B_, jb + 2);
-                lds_barrier();
             };
             {
-                Buf fa, fb;
+                SweepBuf fa, fb;
                 fpre(fa, 0);
                 fpre(fb, 1);
                 for (int jb = 0; jb < nblk; jb += 2) {
@@ -1007,6 +1054,7 @@ struct OpsResidentT {
                     if (jb + 1 < nblk) fstep(fb, jb + 1);
                 }
                 vm_wait<0>();
+                lds_barrier();
             }
         }
     }
@@ -1017,13 +1065,8 @@ struct OpsResidentT {
         const int ntr = (n + 15) >> 4;
         double* vec = sm.vec;
         const double* U = sm.U;
-        constexpr int UW = RNW - 1;                 // updater wavefronts
-        constexpr int FT = (31 + UW - 1) / UW < HIPDRT_QP_SWEEPCAP ? (31 + UW - 1) / UW : HIPDRT_QP_SWEEPCAP;      // forward: buffered tiles per updater wavefront
-        constexpr int BC = (32 + UW - 1) / UW < HIPDRT_QP_SWEEPCAP ? (32 + UW - 1) / UW : HIPDRT_QP_SWEEPCAP;      // backward: buffered chunks per updater wavefront
         PROF_DECL
-        // Two roles, two code paths with matching barrier sequences (per block: one barrier after the diagonal step,
-        // one after the update).  The barriers order LDS traffic only, so the updaters' operand tiles -- fetched TWO
-        // blocks ahead into alternating register buffers -- stay in flight across them.
+        // (roles and barriers as in forward(); the urgent part of block jb's update are chunks 2jb - 2 and 2jb - 1)
         if (wv == 0) {
             // ======== wavefront 0: multiply by the inverse 32x32 diagonal blocks ================================
             const int r = lane & 31;
@@ -1032,9 +1075,41 @@ struct OpsResidentT {
 #pragma unroll
                 for (int q = 0; q < NB; ++q) mc[q] = U[((size_t)(nblk - 1) * NB + q) * PLD + r];
             }
-            for (int jb = nblk - 1; jb >= 0; --jb) {     // backward: x = M' y, lane = column of M
+            const int l4 = lane & 3, g4 = lane >> 2;
+            auto ucount = [&](int jb) { return jb > 0 ? 2 : 0; };
+            auto upre = [&](UrgentBuf& B_, int jb) {    // chunks 2jb - 2, 2jb - 1 of tile rows tb, tb + 1
+                if (jb > 0) {
+                    const int tb = 2 * jb;
+                    const bool two = (tb + 1) < ntr;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int c = 2 * jb - 2 + u;
+                        const double2* p0 = tile2(tb, c) + lane;
+                        const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
+                        B_.t[u][0] = gload16v<0>(p0); B_.t[u][1] = gload16v<1024>(p0);
+                        B_.t[u][2] = gload16v<0>(p1); B_.t[u][3] = gload16v<1024>(p1);
+                    }
+                }
+            };
+            auto urgent = [&](UrgentBuf& B_, int jb) {
+                const int j0 = jb * NB, tb = 2 * jb;
+                const bool two = (tb + 1) < ntr;                    // second tile-row of the block holds valid rows
+                vm_wait_tiles(ucount(jb - 1));
+                if (jb > 0) {
+                    const double x0 = vec[j0 + g4];
+                    const double x1 = two ? vec[j0 + 16 + g4] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) bwd_chunk(B_.t[u], x0, x1, 2 * jb - 2 + u, lane, l4);
+                }
+                upre(B_, jb - 2);
+            };
+            UrgentBuf ua, ub;
+            upre(ua, nblk - 1);
+            upre(ub, nblk - 2);
+            auto dstep = [&](int jb) {                   // backward: x = M' y, lane = column of M
                 const int j0 = jb * NB;
                 const double* Mc = U + (size_t)j0 * PLD + r;
+                PROF(8);
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
                 for (int q = 0; q < NB; q += 4) {
@@ -1052,30 +1127,30 @@ struct OpsResidentT {
 #pragma unroll
                     for (int q = 0; q < NB; ++q) mc[q] = U[((size_t)(j0 - NB) + q) * PLD + r];
                 }
-                lds_barrier();
-                PROF(8);
-            }
-        } else {
-            // ======== wavefronts 1..7: rank-32 updates ========================================================
-            //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane -> row lane/4,
-            //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
-            const int l4 = lane & 3, g4 = lane >> 2;
-            struct Buf { v2d t[FT > BC ? FT : BC][4]; };
-            const unsigned voff = (unsigned)lane * 16u;
-            // ---- backward: L' x = y -----------------------------------------------------------------------
-            // (operand tiles two blocks ahead, counted waits: see forward())
-            auto bcount = [&](int jb) {                 // chunks this wavefront requests for block jb
-                const int nc = jb > 0 ? 2 * jb : 0;
-                const int k = nc - (wv - 1) > 0 ? (nc - (wv - 1) + UW - 1) / UW : 0;
-                return k < BC ? k : BC;
             };
-            auto bpre = [&](Buf& B_, int jb) {          // tiles (tb..tb+1, c): [chunk][tile*2 + half]
+            for (int jb = nblk - 1; jb >= 0; jb -= 2) {
+                dstep(jb);
+                urgent(ua, jb);
+                if (jb - 1 >= 0) { dstep(jb - 1); urgent(ub, jb - 1); }
+            }
+            vm_wait<0>();
+            lds_barrier();
+        } else {
+            // ======== wavefronts 1..: the chunks further left ===================================================
+            const int l4 = lane & 3, g4 = lane >> 2, tw_ = wv - 1;
+            const unsigned voff = (unsigned)lane * 16u;
+            auto bcount = [&](int jb) {                 // chunks this wavefront requests for block jb (chunks 0 .. 2jb - 3)
+                const int nc = jb > 0 ? 2 * jb - 2 : 0;
+                const int k = nc - tw_ > 0 ? (nc - tw_ + SW_TW - 1) / SW_TW : 0;
+                return k < SW_BC ? k : SW_BC;
+            };
+            auto bpre = [&](SweepBuf& B_, int jb) {     // tiles (tb..tb+1, c): [chunk][tile*2 + half]
                 const int tb = 2 * jb, nv = bcount(jb);
                 const bool two = (tb + 1) < ntr;
 #pragma unroll
-                for (int u = 0; u < BC; ++u) {
+                for (int u = 0; u < SW_BC; ++u) {
                     if (u < nv) {
-                        const int c = (wv - 1) + u * UW;
+                        const int c = tw_ + u * SW_TW;
                         const char* p0 = uniform_ptr(tile2(tb, c));
                         const char* p1 = uniform_ptr(tile2(two ? tb + 1 : tb, c));
                         B_.t[u][0] = gload16(p0, voff); B_.t[u][1] = gload16(p0 + 1024, voff);
@@ -1083,8 +1158,8 @@ struct OpsResidentT {
                     }
                 }
             };
-            auto bstep = [&](Buf& B_, int jb) {
-                const int j0 = jb * NB, tb = 2 * jb, nc = 2 * jb;
+            auto bstep = [&](SweepBuf& B_, int jb) {
+                const int j0 = jb * NB, tb = 2 * jb, nc = 2 * jb - 2;
                 const bool two = (tb + 1) < ntr;                    // second tile-row of the block holds valid rows
                 lds_barrier();
                 vm_wait_tiles(bcount(jb - 1));
@@ -1093,51 +1168,39 @@ struct OpsResidentT {
                     const double x0 = vec[j0 + g4];
                     const double x1 = two ? vec[j0 + 16 + g4] : 0.0;
 #pragma unroll
-                    for (int u = 0; u < BC; ++u) {
-                        const int c = (wv - 1) + u * UW;
-                        if (c < nc) {
-                            // t[u][0..1] = tile tb halves 0,1 ; t[u][2..3] = tile tb+1 halves 0,1
-                            double s0 = B_.t[u][0].x * x0 + B_.t[u][2].x * x1;     // column 16c + l4
-                            double s1 = B_.t[u][0].y * x0 + B_.t[u][2].y * x1;     // column 16c + l4 + 4
-                            double s2 = B_.t[u][1].x * x0 + B_.t[u][3].x * x1;     // column 16c + 8 + l4
-                            double s3 = B_.t[u][1].y * x0 + B_.t[u][3].y * x1;     // column 16c + 12 + l4
-                            const double f = colsum4(s0, s1, s2, s3, lane);   // column 16c + l4 + 4*(lane>>4)
-                            if ((lane & 12) == 0) vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
-                        }
+                    for (int u = 0; u < SW_BC; ++u) {
+                        const int c = tw_ + u * SW_TW;
+                        if (c < nc) bwd_chunk(B_.t[u], x0, x1, c, lane, l4);
                     }
                     {
                         // more finished chunks than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
                         // from memory, four chunks per round (sixteen loads requested together: one round trip per round)
                         constexpr int OVR = (GU && HIPDRT_QP_OVR > 1) ? HIPDRT_QP_OVR : 1;
-                        for (int c0 = (wv - 1) + BC * UW; c0 < nc; c0 += OVR * UW) {
-                            double2 t_[OVR][4];
+                        for (int c0 = tw_ + SW_BC * SW_TW; c0 < nc; c0 += OVR * SW_TW) {
+                            v2d t_[OVR][4];
 #pragma unroll
                             for (int j = 0; j < OVR; ++j) {
-                                const int c = c0 + j * UW;
+                                const int c = c0 + j * SW_TW;
                                 if (c < nc) {
                                     const double2* p0 = tile2(tb, c) + lane;
                                     const double2* p1 = tile2(two ? tb + 1 : tb, c) + lane;
-                                    t_[j][0] = p0[0]; t_[j][1] = p0[64]; t_[j][2] = p1[0]; t_[j][3] = p1[64];
+                                    const double2 d0 = p0[0], d1 = p0[64], d2 = p1[0], d3 = p1[64];
+                                    t_[j][0] = (v2d){d0.x, d0.y}; t_[j][1] = (v2d){d1.x, d1.y};
+                                    t_[j][2] = (v2d){d2.x, d2.y}; t_[j][3] = (v2d){d3.x, d3.y};
                                 }
                             }
 #pragma unroll
                             for (int j = 0; j < OVR; ++j) {
-                                const int c = c0 + j * UW;
-                                if (c < nc) {
-                                    const double s0 = t_[j][0].x * x0 + t_[j][2].x * x1, s1 = t_[j][0].y * x0 + t_[j][2].y * x1;
-                                    const double s2 = t_[j][1].x * x0 + t_[j][3].x * x1, s3 = t_[j][1].y * x0 + t_[j][3].y * x1;
-                                    const double f = colsum4(s0, s1, s2, s3, lane);
-                                    if ((lane & 12) == 0) vec[c * 16 + l4 + 4 * (lane >> 4)] -= f;
-                                }
+                                const int c = c0 + j * SW_TW;
+                                if (c < nc) bwd_chunk(t_[j], x0, x1, c, lane, l4);
                             }
                         }
                     }
                 }
                 bpre(B_, jb - 2);
-                lds_barrier();
             };
             {
-                Buf ba, bb;
+                SweepBuf ba, bb;
                 bpre(ba, nblk - 1);
                 bpre(bb, nblk - 2);
                 for (int jb = nblk - 1; jb >= 0; jb -= 2) {
@@ -1145,6 +1208,7 @@ struct OpsResidentT {
                     if (jb - 1 >= 0) bstep(bb, jb - 1);
                 }
                 vm_wait<0>();
+                lds_barrier();
             }
         }
     }

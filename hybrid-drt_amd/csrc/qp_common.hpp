@@ -66,6 +66,10 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // moves nor waits for: the rank-k loops below keep several half-chunks in flight and count vmcnt by hand (hipcc's own
 // schedule gathers all loads of an unrolled body at its top and drains them with vmcnt(0) at its bottom, so nothing
 // stays in flight across iterations).  Every use of the result must come after an explicit vm_wait<N>().
+// HAZARD: hipcc does not insert wait states for inline asm.  gfx9 needs 5 between a VALU instruction that writes an SGPR
+// (v_readlane: every SGPR spill reload; v_readfirstlane) and a VMEM instruction that reads it -- a gload16 right behind a spill
+// reload of its base loads from a stale pointer (observed: faults on address 0).  tools/sgpr_hazard.py scans the assembly for
+// this, tests/test_isa_hazards.py runs it with every test run; where it cannot be avoided use gload16v (VGPR address).
 static __device__ __forceinline__ v2d gload16(const char* sbase, unsigned voff) {
     v2d d;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");

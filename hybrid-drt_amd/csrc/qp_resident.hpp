@@ -871,8 +871,9 @@ struct OpsResidentT {
     // alternating register buffers by hand-issued loads and retired with a counted wait (left to hipcc, every use waits for
     // vmcnt(0..3), i.e. also for the block requested one step ago), behind the block's arithmetic, so that their issue cost
     // (~100 cycles per 1 KB load and wavefront) is off the chain.  Wavefront 0's loads take a per-lane 64-bit address
-    // (gload16v): with a scalar base pair, as everywhere else, this role's prefetch faulted on the device with a pointer
-    // whose upper half was wrong -- the kernel sits at the scalar-register limit, cause not found.
+    // (gload16v): with a scalar base pair, as everywhere else, this role's prefetch faulted on the device -- at the kernel's
+    // scalar-register limit the bases are reloaded from VGPR lanes right in front of the loads, inside the 5 wait states gfx9
+    // wants between a VALU-written SGPR and a VMEM instruction reading it (qp_common.hpp: gload16; tools/sgpr_hazard.py).
     //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane  ->  row i = lane/4,
     //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
     static constexpr int SW_TW = RNW - 1;                // trailing-update wavefronts

@@ -1,0 +1,51 @@
+"""The coneqp kernels issue their operand loads by hand (inline asm `global_load_dwordx4 v, v, s[base]`), and hipcc's hazard
+recognizer does not look inside inline asm: a scalar base that was reloaded from a VGPR lane (SGPR spill) or produced by
+v_readfirstlane fewer than 5 wait states before such a load is read stale by the hardware (gfx9: "VALU writes SGPR -> VMEM reads
+that SGPR"), which showed up on the device as memory faults on address 0.  Compile the kernels to assembly here (no GPU needed)
+and check that no hand-issued load sits in that shadow (tools/sgpr_hazard.py)."""
+import importlib.util
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _scanner():
+    spec = importlib.util.spec_from_file_location("sgpr_hazard", os.path.join(ROOT, "tools", "sgpr_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_scanner_sees_a_planted_hazard():
+    mod = _scanner()
+    planted = """_ZN6hipdrt4testEv:
+	v_readlane_b32 s2, v248, 59
+	v_readlane_b32 s3, v248, 60
+	s_add_u32 s0, s2, 0x400
+	global_load_dwordx4 v[4:7], v88, s[2:3]
+	s_nop 4
+	global_load_dwordx4 v[8:11], v88, s[2:3]
+.Lfunc_end0:
+"""
+    found = mod.scan(planted)
+    assert len(found) == 2 and all(f[1].startswith("global_load_dwordx4 v[4:7]") for f in found)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hand_issued_loads_are_outside_the_sgpr_hazard_shadow(tmp_path):
+    mod = _scanner()
+    src = os.path.join(ROOT, "hybrid-drt_amd", "csrc", "qp.hip")
+    out = tmp_path / "qp.s"
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
+                    "-S", "--cuda-device-only", src, "-o", str(out)], check=True, cwd=os.path.dirname(src),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    assert "global_load_dwordx4" in txt and "qp_kernel_resident" in txt
+    found = mod.scan(txt)
+    assert not found, "hand-issued loads behind a VALU-written scalar base:\n" + "\n".join(
+        "%s | %s | s%d %d wait states" % (n[:50], l, s_, age) for n, l, s_, age in found[:10])

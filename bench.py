@@ -18,6 +18,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -46,18 +47,30 @@ def qp_algorithmic_flop(n, qp_iters_total, n_qp):
     return fact + solves
 
 
+def _code_only(name, text):
+    """source text without comments and with runs of white space collapsed: the stamp below should follow the CODE, not a
+    reworded comment (string literals in these sources hold no comment markers)"""
+    if name == "Makefile":
+        text = re.sub(r"#[^\n]*", "", text)
+    else:
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", " ", text).strip()
+
+
 def source_hash():
-    """sha256 over the library's sources: stamps PMC traffic figures (profiles/qp_traffic.json) with the code they were
-    measured on -- a figure from other sources is reported as null, not silently carried along."""
+    """sha256 over the library's sources (code only: comments and white space do not count): stamps PMC traffic figures
+    (profiles/qp_traffic.json) with the code they were measured on -- a figure from other sources is reported as null, not
+    silently carried along."""
     h = hashlib.sha256()
     src = os.path.join(ROOT, "hybrid-drt_amd", "csrc")
     for name in sorted(os.listdir(src)):
         if name.endswith((".hip", ".hpp")) or name == "Makefile":
-            with open(os.path.join(src, name), "rb") as f:
+            with open(os.path.join(src, name), "r", encoding="utf-8", errors="replace") as f:
                 h.update(name.encode())
-                h.update(f.read())
-    with open(os.path.join(ROOT, "include", "hipdrt.h"), "rb") as f:
-        h.update(f.read())
+                h.update(_code_only(name, f.read()).encode())
+    with open(os.path.join(ROOT, "include", "hipdrt.h"), "r", encoding="utf-8", errors="replace") as f:
+        h.update(_code_only("hipdrt.h", f.read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -25,8 +25,9 @@
 //    substitution chain and never fetch diagonal blocks from HBM (the diagonal-block tiles of L are not even
 //    written to HBM).
 //  * The predictor's forward substitution is fused into the factorisation (a block column's tiles update the
-//    right-hand side while they are still in registers).  Separate solves: per 32-block the mat-vec by wavefront 0;
-//    wavefronts 1..7 apply the rank-32 updates from tiles fetched two blocks ahead, across LDS-only barriers.
+//    right-hand side while they are still in registers).  Separate solves: per 32-block the mat-vec by wavefront 0, which
+//    also applies the two tiles of the rank-32 update its next step needs; wavefronts 1..7 apply the rest meanwhile (tiles
+//    fetched two blocks ahead, one LDS-only barrier per block: forward() / backward()).
 //  * P x from the packed lower tiles: every tile is read once and used for y_T += tile x_C and y_C += tile' x_T.
 //  * Optional extra tile rows appended below the matrix turn the same factorisation into a multi-right-hand-side
 //    triangular solve (posterior variance, cov_kernel_resident).

@@ -38,6 +38,52 @@ __global__ __launch_bounds__(1024) void mfma_cycles(double* out, WaveRec* rec, i
         r.xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;     // HW_REG_XCC_ID[3:0]
     }
 }
+// The same timed window with the accumulators PINNED in AccVGPRs by inline asm ("+a"): v_mfma_f64_16x16x4_f64 a[..], v, v, a[..].
+// The compiler-chosen AccVGPR form of mfma_loop below copies all 32 accumulator registers VGPR -> AccVGPR and back in EVERY
+// iteration (32 v_accvgpr_write + 32 v_accvgpr_read + s_nop 13 around 4 MFMAs: profiles/r04_mfma_agpr_disasm.txt), which is
+// what made that leg 2.4x slower -- not the register class.  Same launch geometry cases as mfma_cycles.
+template <int BOUND>
+__global__ __launch_bounds__(BOUND) void mfma_cycles_agpr(double* out, WaveRec* rec, int warm) {
+    v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    double x = threadIdx.x * 1e-3, y = 1.0 + threadIdx.x * 1e-4;
+#define AMFMA(A) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(A) : "v"(x), "v"(y))
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < warm; ++i) { AMFMA(a0); AMFMA(a1); AMFMA(a2); AMFMA(a3); }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 1000; ++i) { AMFMA(a0); AMFMA(a1); AMFMA(a2); AMFMA(a3); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < warm; ++i) { AMFMA(a0); AMFMA(a1); AMFMA(a2); AMFMA(a3); }
+#undef AMFMA
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+    if ((threadIdx.x & 63) == 0) {
+        WaveRec& r = rec[(blockIdx.x * blockDim.x + threadIdx.x) >> 6];
+        r.cyc = (unsigned)(c1 - c0); r.ticks = (unsigned)(t1 - t0); r.run0 = r0; r.run1 = r1;
+        r.hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((32 - 1) << 11));
+        r.xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;
+    }
+}
+// ... and with A / B operands in AccVGPRs too (gfx90a+: any MFMA source may be an AccVGPR), one dependent accumulator chain of
+// 2, 3 and 4 accumulators: how many independent tiles a wavefront needs in rotation to issue every 64 cycles.
+template <int NACC, bool ABAGPR>
+__global__ __launch_bounds__(256) void mfma_chain(double* out, unsigned* cyc) {
+    v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    double x = threadIdx.x * 1e-3, y = 1.0 + threadIdx.x * 1e-4;
+#define VMFMA(A) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(A) : "v"(x), "v"(y))
+#define GMFMA(A) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(A) : "a"(x), "a"(y))
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 4000; ++i) {
+        if (ABAGPR) { GMFMA(a0); if (NACC > 1) GMFMA(a1); if (NACC > 2) GMFMA(a2); if (NACC > 3) GMFMA(a3); }
+        else { VMFMA(a0); if (NACC > 1) VMFMA(a1); if (NACC > 2) VMFMA(a2); if (NACC > 3) VMFMA(a3); }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#undef VMFMA
+#undef GMFMA
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+    if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = (unsigned)(c1 - c0);
+}
 // Does other work on the same SIMD take time from the FP64 matrix pipe?  512-thread workgroups, wavefronts 0..3 (one per SIMD) run
 // the MFMA loop, wavefronts 4..7 (their SIMD partners) one of: nothing, 32-bit integer VALU, FP32 FMA, FP64 FMA, LDS reads.
 __global__ __launch_bounds__(512) void mfma_partner(double* out, unsigned* cyc, int kind, int iters) {
@@ -164,6 +210,49 @@ int main() {
                "(%.2f ms; events %.2f ms) | %d CUs used, at most %d wavefronts on one\n",
                c.what, sc / nw / 4000.0, cmin / 4000.0, cmax / 4000.0, sc / (st * 10e-9) * 1e-6, total_mfma * 2048 / span_s * 1e-12,
                span_s * 1e3, ms, ncu, maxper);
+    }
+    printf("accumulators pinned in AccVGPRs by inline asm (same in-kernel window; __launch_bounds__(256) = up to 512 registers per lane):\n");
+    {
+        struct Case2 { const char* what; int grid, block; } cases2[] = {
+            {"AGPR acc, all CUs x 4 wavefronts (1 per SIMD)", cus, 256},
+            {"AGPR acc, 2 x CUs x 4 wavefronts (2 per SIMD)", 2 * cus, 256},
+            {"AGPR acc, 8 workgroups x 4 wavefronts", 8, 256},
+        };
+        for (const Case2& c : cases2) {
+            const int nw = c.grid * c.block / 64;
+            const int warm = 40000 / (c.grid > cus ? 2 : 1);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(mfma_cycles_agpr<256>, dim3(c.grid), dim3(c.block), 0, 0, out, rec, warm);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(h, rec, sizeof(WaveRec) * nw, hipMemcpyDeviceToHost);
+            double sc = 0, st = 0, cmin = 1e30, cmax = 0;
+            unsigned long long r0 = ~0ull, r1 = 0;
+            for (int i = 0; i < nw; ++i) {
+                sc += h[i].cyc; st += h[i].ticks;
+                cmin = h[i].cyc < cmin ? h[i].cyc : cmin; cmax = h[i].cyc > cmax ? h[i].cyc : cmax;
+                r0 = h[i].run0 < r0 ? h[i].run0 : r0; r1 = h[i].run1 > r1 ? h[i].run1 : r1;
+            }
+            const double total_mfma = (double)nw * (2.0 * warm + 1000) * 4;
+            const double span_s = (double)(r1 - r0) * 10e-9;
+            printf("%-48s: window: %6.1f cycles per MFMA per wavefront (min %.1f max %.1f), clock %4.0f MHz | whole run: %6.1f TFLOP/s (%.2f ms; events %.2f ms)\n",
+                   c.what, sc / nw / 4000.0, cmin / 4000.0, cmax / 4000.0, sc / (st * 10e-9) * 1e-6, total_mfma * 2048 / span_s * 1e-12, span_s * 1e3, ms);
+        }
+        unsigned* cyc2; hipMalloc(&cyc2, sizeof(unsigned) * 4 * cus);
+        static unsigned hc2[4 * 1024];
+        auto report = [&](const char* what, int nacc) {
+            hipDeviceSynchronize();
+            hipMemcpy(hc2, cyc2, sizeof(unsigned) * 4 * cus, hipMemcpyDeviceToHost);
+            double m = 0; for (int i = 0; i < 4 * cus; ++i) m += hc2[i];
+            printf("dependent chains, %-44s %d accumulator(s) in rotation: %.1f cycles per MFMA\n", what, nacc, m / (4.0 * cus) / (4000.0 * nacc));
+        };
+        hipLaunchKernelGGL((mfma_chain<1, false>), dim3(cus), dim3(256), 0, 0, out, cyc2); report("AGPR acc, VGPR A/B:", 1);
+        hipLaunchKernelGGL((mfma_chain<2, false>), dim3(cus), dim3(256), 0, 0, out, cyc2); report("AGPR acc, VGPR A/B:", 2);
+        hipLaunchKernelGGL((mfma_chain<3, false>), dim3(cus), dim3(256), 0, 0, out, cyc2); report("AGPR acc, VGPR A/B:", 3);
+        hipLaunchKernelGGL((mfma_chain<4, false>), dim3(cus), dim3(256), 0, 0, out, cyc2); report("AGPR acc, VGPR A/B:", 4);
+        hipLaunchKernelGGL((mfma_chain<1, true>), dim3(cus), dim3(256), 0, 0, out, cyc2); report("AGPR acc, AGPR A/B:", 1);
+        hipLaunchKernelGGL((mfma_chain<2, true>), dim3(cus), dim3(256), 0, 0, out, cyc2); report("AGPR acc, AGPR A/B:", 2);
+        hipLaunchKernelGGL((mfma_chain<4, true>), dim3(cus), dim3(256), 0, 0, out, cyc2); report("AGPR acc, AGPR A/B:", 4);
     }
     {
         unsigned* cyc; hipMalloc(&cyc, sizeof(unsigned) * 8 * cus);

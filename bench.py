@@ -224,6 +224,42 @@ def cpu_baseline(freq, tau, z, seconds_budget=15.0, ref_structure_budget=8.0, pr
                                                 f"diag products restated one-for-one), 1 BLAS thread, {rdt:.1f} s"))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N child processes of this very command line, one per rank, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would set); rank 0's stdout
+    is passed through (the ONE JSON line), the other ranks' output goes to stderr.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    codes = [None] * n
+    try:
+        while any(c is None for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None and pr.poll() is not None:
+                    codes[r] = pr.returncode
+                    if codes[r] != 0:                # a dead rank leaves the others waiting in a collective
+                        for other in procs:
+                            if other.poll() is None:
+                                other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks exited non-zero: {bad}", file=sys.stderr)
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +282,10 @@ def main():
     ap.add_argument("--no-matrix-build", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the single-spectrum and config-5 timings")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched without torch.distributed.run: this process -- which has not touched the GPU and never will -- starts
+        # one fresh child per rank (no exec of a GPU-initialised process), relays rank 0's JSON line and fails if any did
+        raise SystemExit(self_launch(args.gpus))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     config = args.config if args.config != "auto" else ("c3" if world_env == 1 else "c4")
 
@@ -463,8 +503,9 @@ def main():
                                     f"gather on rank 0"),
                        "batch_per_gpu": B, "nf": 256, "ntau": 512, "n_unknowns": n,
                        "sharding": (f"{world} rank(s) x {B} independent spectra, no data-path collective" if config == "c3"
-                                    else f"{args.total} spectra over {world} rank(s), {counts} per rank, one all_gather "
-                                         f"of {len(tau) + 3} doubles per spectrum"),
+                                    else f"{args.total} spectra over {world} rank(s), {counts} per rank, one gather to rank 0 "
+                                         f"of {len(tau) + 9} doubles per spectrum per map (lookup tables broadcast once, "
+                                         f"before the timed region)"),
                        "batches_in_flight_per_gpu": nfl,
                        "converged_fraction": float((res["status"] == 0).mean()),
                        "mean_outer_iterations": float(res["outer_iters"].mean()),

@@ -115,7 +115,7 @@ static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
     const int NP = round_up(a.n, 32);
     if (!a.Ppk) { set_error("qp resident: packed copy of P missing"); return HIPDRT_E_INVALID; }
     const bool gu = a.n > RNP_MAX;                      // inverse diagonal blocks in global memory: any n <= 2048
-    const size_t lds = gu ? resident_gu_lds_bytes() : resident_lds_bytes(NP);
+    const size_t lds = gu ? resident_gu_lds_bytes(true) : resident_lds_bytes(NP, true);
     const void* fn = gu ? reinterpret_cast<const void*>(qp_kernel_resident<true>) : reinterpret_cast<const void*>(qp_kernel_resident<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(qp resident): ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
@@ -170,10 +170,10 @@ int qp_occupancy(int threads, int n) {
     hipError_t e;
     if (threads != 512) return -1;
     if (n > RNP_MAX) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<true, 512>, 512, resident_gu_lds_bytes());
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<true, 512>, 512, resident_gu_lds_bytes(true));
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_resident<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(NP));
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<false, 512>, 512, resident_lds_bytes(NP));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_resident<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(NP, true));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qp_kernel_resident<false, 512>, 512, resident_lds_bytes(NP, true));
     }
     return e == hipSuccess ? nb : -1;
 }

@@ -170,16 +170,19 @@ __device__ __forceinline__ double wmax(double v) {
     return fmax(fmax(bcast_lane(v, 0), bcast_lane(v, 16)), fmax(bcast_lane(v, 32), bcast_lane(v, 48)));
 }
 
-template <int NW>
+// SLOTS >= 2 result slots used in rotation: a wavefront can be at most one reduction (= one barrier) ahead of the slowest
+// reader of the previous one, so two suffice; the 64-column factorisation's LDS budget has room for exactly two
+template <int NW, int SLOTS = 4>
 struct Reducer {
-    double* buf;   // LDS [4][NW][4]
+    static_assert(SLOTS == 2 || SLOTS == 4, "");
+    double* buf;   // LDS [SLOTS][NW][4]
     int slot;
     __device__ Reducer(double* b) : buf(b), slot(0) {}
     // sums up to 4 values at once; every thread gets the totals
     template <int N>
     __device__ __forceinline__ void sum(double (&v)[N]) {
         static_assert(N <= 4, "");
-        double* s = buf + (slot & 3) * NW * 4;
+        double* s = buf + (slot & (SLOTS - 1)) * NW * 4;
         ++slot;
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = wsum(v[i]);
@@ -199,7 +202,7 @@ struct Reducer {
     template <int N>
     __device__ __forceinline__ void max(double (&v)[N]) {
         static_assert(N <= 4, "");
-        double* s = buf + (slot & 3) * NW * 4;
+        double* s = buf + (slot & (SLOTS - 1)) * NW * 4;
         ++slot;
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = wmax(v[i]);
@@ -223,7 +226,7 @@ struct Reducer {
 struct IpmSmem {
     double* vec;     // [n]  rhs / solution of the KKT solve; x for the mat-vec
     double* dvec;    // [n]  diagonal shift d^-2 for the factorisation; P x result
-    double* red;     // [4][NW][4]
+    double* red;     // [Ops::kRedSlots][NW][4]
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -244,7 +247,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                                            // 64-bit address registers kept alive across the whole kernel
     const double* qg = a.q + (size_t)b * n;
     const double* hg = a.h + (size_t)b * a.h_stride;
-    Reducer<NW> red(sm.red);
+    Reducer<NW, Ops::kRedSlots> red(sm.red);
     // P x is normally not formed by a pass over P: every step direction solves (P + D) dx = r to the backward error of
     // the Cholesky solve, so P dx = r - D dx and P x follows the iterate by an O(n) recurrence (start point:
     // (P + I) x0 = -q - h).  The recurrence carries rounding errors of size eps |P| |step dx| along, a direct product

@@ -93,6 +93,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
     // tiles, but every member needs the whole substituted vector for its (redundant) interior-point step; the predictor
     // solve is a full forward + backward sweep over the finished factor instead.
     static constexpr bool kFusedForward = false;
+    static constexpr int kRedSlots = 4;
     static constexpr int kSpinLimit = 1 << 24;
     int G = 1, g = 0;                      // members of the group, this member
     int* gs = nullptr;                     // global sync words of the problem (GRP_WORDS)
@@ -109,7 +110,12 @@ struct OpsGroup : OpsResidentT<true, 512> {
     // ---- group barrier: every member's stores complete, then one arrival per member on a monotonic counter -------------
     __device__ __forceinline__ void group_sync() {
         PROF_DECL
-        __syncthreads();                                   // (s_waitcnt vmcnt(0) in every wavefront: this member's stores are in L2)
+        // every wavefront drains its own vector stores first: on gfx950 (no threadgroup-split mode) __syncthreads() is
+        // `s_waitcnt lgkmcnt(0); s_barrier` -- a workgroup-scope release does not wait for vmcnt -- and the arrival below is a
+        // relaxed atomic, so without this wait nothing would keep a member's tile or state stores in front of the counter
+        // another member polls (tests/test_isa_hazards.py checks the assembly for it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (G > 1) {
             ++gepoch;
             if (threadIdx.x == 0) {

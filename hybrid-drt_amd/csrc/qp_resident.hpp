@@ -69,13 +69,19 @@ static constexpr int DLD = 17;           // row stride of the 16x16 LDS scratch 
 // LDS: the only structure of this kernel whose size grows with n^1 x 33, i.e. what limits the LDS-resident form to
 // n <= 528.  With U outside, the same kernel serves every n <= 2048 (LDS then holds the two n-vectors and the small
 // fixed buffers: 39 kB).
-template <bool GU, int RTT = 512>
+#ifndef HIPDRT_QP_PANEL64
+#define HIPDRT_QP_PANEL64 1      // the QP kernel's factorisation walks the finished part of L once per 64 columns (factor64)
+#endif
+// P64 = LDS layout of the 64-column factorisation (factor64, the QP kernel with 8 wavefronts): L21 of BOTH 32-blocks of a super
+// column in operand-fragment layout (t21: [2][4][64]), two reduction slots instead of four, dvec without the 32 padding
+// entries, a schedule table per super column -- at n = 514 the workgroup's 160 KB are used to the last 32 bytes.
+template <bool GU, int RTT = 512, bool P64 = false>
 struct ResSmemT {
     double* U;       // [NP][PLD]   inverse diagonal blocks (LDS, or global when GU)
     double* vec;     // [NP + 32]
-    double* dvec;    // [NP + 32]
-    double* red;     // [4][RNW][4]
-    double* t21;     // [16][DLD]   L21 of the current block
+    double* dvec;    // [NP + 32]   (P64: [NP])
+    double* red;     // [4][RNW][4] (P64: [2][RNW][4])
+    double* t21;     // [16][DLD]   L21 of the current block (P64: [2][4][64], register images of L21 of blocks a and b)
     double* dsc;     // [16][DLD]   diagonal block being factored
     double* img;     // [2][64][4]  register images of -D21', -D22' of the next diagonal block
     int* flag;       // [4]
@@ -83,21 +89,26 @@ struct ResSmemT {
 
     // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
     static constexpr int VEC = GU ? 2048 + 32 + 32 : 528 + 16 + 32;      // NP + 32 (NP <= 544, or <= 2080 with U outside)
+    static constexpr int DVEC = P64 ? VEC - 32 : VEC;
     static constexpr int SROW = GU ? 128 : 32;                           // table row: tile rows below a block column (<= 124 | 29)
-    static constexpr int SCHED = GU ? 64 * 128 / 8 : 17 * 32 / 8 + 4;    // doubles: nblk <= 64 | 17 rows of SROW bytes
-    static constexpr int FIXED = 4 * (RTT / 64) * 4 + 2 * 16 * 17 + 8 + 512 + SCHED + 2 * VEC;   // doubles before U
+    static constexpr int SCHED = GU ? 64 * 128 / 8 : (P64 ? 9 * 32 / 8 : 17 * 32 / 8 + 4);    // doubles: nblk <= 64 | 17 (9 super columns) rows of SROW bytes
+    static constexpr int RED = (P64 ? 2 : 4) * (RTT / 64) * 4;
+    static constexpr int T21 = P64 ? 2 * 256 : 16 * 17;
+    static constexpr int FIXED = RED + T21 + 16 * 17 + 8 + 512 + SCHED + VEC + DVEC;   // doubles before U
     __device__ __forceinline__ void carve(double* smem) {
         red = smem;
-        t21 = red + 4 * (RTT / 64) * 4;
-        dsc = t21 + 16 * 17;
+        t21 = red + RED;
+        dsc = t21 + T21;
         flag = reinterpret_cast<int*>(dsc + 16 * 17);
         img = dsc + 16 * 17 + 8;
         sched = reinterpret_cast<unsigned char*>(img + 512);
         vec = img + 512 + SCHED;
         dvec = vec + VEC;
-        U = dvec + VEC;
+        U = dvec + DVEC;
     }
 };
+static_assert((ResSmemT<false, 512, true>::FIXED + 544 * 33) * 8 <= 160 * 1024, "n = 514 must fit one CU's LDS");
+static_assert((ResSmemT<false, 512, true>::RED + ResSmemT<false, 512, true>::T21 + 16 * 17 + 8) % 4 == 0, "img must be 32-byte aligned");
 
 using ResSmem = ResSmemT<false>;
 
@@ -110,10 +121,13 @@ using ResSmem = ResSmemT<false>;
 // two) is parity-green as well -- the ~200 spilled registers stay outside the operand rings -- and measured 14.7 ms per
 // launch against 11.3 for one workgroup per CU in the same U-outside form (10.65 with U in LDS): halving every wavefront's
 // rows per pass, ring depth and sweep buffers costs more than the second workgroup's overlap returns.
-template <bool GU, int RTT = 512>
+template <bool GU, int RTT = 512, bool P64 = false>
 struct OpsResidentT {
     static constexpr int RT = RTT, RNW = RTT / 64;                     // (shadow the namespace-level defaults)
-    double* L; int nch; int n; ResSmemT<GU, RTT> sm;                   // nch = tiles per tile-row (NP/16)
+    static_assert(!P64 || RTT == 512, "factor64 is written for eight wavefronts");
+    using Smem = ResSmemT<GU, RTT, P64>;
+    static constexpr int kRedSlots = P64 ? 2 : 4;
+    double* L; int nch; int n; Smem sm;                                // nch = tiles per tile-row (NP/16)
     const double* Ppk; int nchp;                                       // P in L's tile layout (lower tiles)
     // Optional extra tile rows appended below the square matrix (tile rows nch .. nch+nex-1 of L, source tiles
     // Bex[nex][nchp][256]): the factorisation treats them as more panel rows, so they come out as Bex * L^-T --
@@ -132,10 +146,11 @@ struct OpsResidentT {
     // who computes a row.  Only for the plain factorisation (no appended rows) with 8 wavefronts.
     bool balanced = false;
     __device__ __forceinline__ void build_schedule() {
+        if constexpr (P64) { build_schedule64(); return; }
         balanced = (RNW == 8) && nex == 0;
         if (!balanced) return;
         const int ntr = (n + 15) >> 4, nblk = (n + NB - 1) / NB;
-        constexpr int SROW = ResSmemT<GU, RTT>::SROW;
+        constexpr int SROW = Smem::SROW;
         for (int jb = threadIdx.x; jb < nblk; jb += RT) {
             const int tb = 2 * jb, nk2 = 4 * jb;
             const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;
@@ -376,6 +391,7 @@ struct OpsResidentT {
     // substitution is fused, (B)): state carried from one block column to the next -- the source tiles requested a column
     // ahead -- is then live in its own role's loop only and costs the other roles no registers.
     __device__ __forceinline__ bool factor() {
+        if constexpr (P64) return factor64();
         const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int ntr = (n + 15) >> 4;           // tile rows that hold valid rows
         if (wv == 1) {
@@ -646,7 +662,7 @@ struct OpsResidentT {
         const int nsq = ntr - (tb + 4) > 0 ? ntr - (tb + 4) : 0;
         const int nothers = nsq + nex;
         if (balanced) {
-            constexpr int SROW = ResSmemT<GU, RTT>::SROW;
+            constexpr int SROW = Smem::SROW;
             const unsigned char* row = sm.sched + jb * SROW;
             unsigned long long m0 = __ballot(lane < nsq && row[lane] == wv), m1 = 0;
             if (SROW > 64) m1 = __ballot(lane + 64 < nsq && row[lane + 64] == wv);
@@ -689,7 +705,7 @@ struct OpsResidentT {
             // balanced schedule (build_schedule): bit r of (m0, m1) = tile row tb + 4 + r is this wavefront's
             unsigned long long m0 = 0, m1 = 0;
             if (balanced) {
-                constexpr int SROW = ResSmemT<GU, RTT>::SROW;
+                constexpr int SROW = Smem::SROW;
                 const unsigned char* row = sm.sched + jb * SROW;
                 m0 = __ballot(lane < nsq && row[lane] == wv);
                 if (SROW > 64) m1 = __ballot(lane + 64 < nsq && row[lane + 64] == wv);
@@ -856,6 +872,629 @@ struct OpsResidentT {
                 }
             }
             __syncthreads();                                        // (B) block column visible to everyone
+        }
+        return true;
+    }
+
+    // =====================================================================================================================
+    // factor64: the same factorisation with the finished part of L walked ONCE PER 64 COLUMNS (P64).
+    //
+    // The left-looking re-read of L is half of this kernel's HBM traffic (section 6 of DESIGN.md): a block column of 32 reads
+    // every tile row below it over all finished columns.  Here a row wavefront accumulates FOUR tile columns (two 32-blocks a
+    // and b = a "super column") per pass over the history, 3 tile rows x 4 tile columns of accumulators, so every A tile
+    // is fetched once per 64 columns.  What stays 32 wide is everything sequential: the diagonal chain, the inverse blocks
+    // in U, the triangular sweeps.  Per super column J (tile rows tA = 4J .. tA+3 hold its two diagonal blocks):
+    //   wavefront 0   chain a (diagonal block a was completed by wavefront 1 in super column J-1), y_a of the fused forward
+    //                 substitution, then itself the look-ahead of block b: tile rows tA+2, tA+3 -- four panel tiles in
+    //                 columns a and the three tiles of diagonal block b -- over the history, their panel solve with its own
+    //                 W_a, the rank-32 update of diagonal block b from registers, chain b, y_b.  All of it runs beside the
+    //                 other wavefronts' history pass; nothing is handed over inside it.
+    //   wavefront 1   tile rows tA+4, tA+5 (the diagonal rows of block a of super column J+1): eight panel tiles in columns
+    //                 a and b plus the three tiles of the next diagonal block a', over the history.
+    //   wavefronts 2..7  all tile rows from tA+6 on, dealt by build_schedule64.
+    //   barrier (A):  history accumulated everywhere, W / L21 of BOTH blocks, y_a, y_b and the solved tiles of rows tA+2,
+    //                 tA+3 published.  Then every wavefront solves its panel tiles against block a, applies block a's rank-32
+    //                 update to its column-b tiles FROM REGISTERS (the solved tile is its own operand fragment; the other
+    //                 operand, rows tA+2 / tA+3 in columns a, is read back from L: 8 KB through L1 / L2), solves against
+    //                 block b, stores, and updates the right-hand side; wavefront 1 also completes diagonal block a' and
+    //                 stages it for the chain.
+    //   barrier (B):  the super column's tiles are visible to everyone.
+    // Two barriers per 64 columns instead of six.  Every tile receives exactly the MFMA sequence it receives in factor()
+    // (history chunks ascending, x then y half of every half-chunk, the same operand order), so the factor, U and the forward-
+    // substituted right-hand side are bit for bit those of the 32-column form (tools/dump_fit.py --cmp).
+    static constexpr int RM = 3;                 // tile rows per row wavefront and pass (x 4 tile columns = 12 accumulator tiles)
+#ifndef HIPDRT_QP_CHAINLOAD64
+#define HIPDRT_QP_CHAINLOAD64 500
+#endif
+    __device__ __forceinline__ void build_schedule64() {
+        const int ntr = (n + 15) >> 4, nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
+        constexpr int SROW = Smem::SROW;
+        for (int J = threadIdx.x; J < nsup; J += RT) {
+            const int tA = 4 * J, nk2 = 8 * J;
+            const int nsq = ntr - (tA + 6) > 0 ? ntr - (tA + 6) : 0;
+            const int c = 8 * nk2 + 40;                               // MFMAs of one row: history + two panel solves + block a's update
+            const int cap = RM * (nsq > 6 * RM ? (nsq + 6 * RM - 1) / (6 * RM) : 1);
+            // SIMD 0 carries wavefront 0 (two chains + 14 MFMAs per half-chunk), SIMD 1 wavefront 1 (22 per half-chunk)
+            int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 2 < ntr) ? 14 * nk2 + 48 : 0);
+            int l1 = (tA + 4 < ntr) ? 22 * nk2 + 96 : 0, l2 = 0, l3 = 0;
+            int c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+            for (int r = 0; r < nsq; ++r) {
+                const int w2 = c2 <= c6 ? 2 : 6, n2 = c2 <= c6 ? c2 : c6;
+                const int w3 = c3 <= c7 ? 3 : 7, n3 = c3 <= c7 ? c3 : c7;
+                int best = -1, bl = 0x7fffffff;
+                if (c4 < cap && l0 < bl) { best = 4; bl = l0; }
+                if (n2 < cap && l2 < bl) { best = w2; bl = l2; }
+                if (n3 < cap && l3 < bl) { best = w3; bl = l3; }
+                if (c5 < cap && l1 < bl) { best = 5; bl = l1; }
+                sm.sched[J * SROW + r] = (unsigned char)best;
+                if (best == 4) { ++c4; l0 += c; }
+                else if (best == 5) { ++c5; l1 += c; }
+                else if (best == 2) { ++c2; l2 += c; }
+                else if (best == 6) { ++c6; l2 += c; }
+                else if (best == 3) { ++c3; l3 += c; }
+                else { ++c7; l3 += c; }
+            }
+        }
+    }
+
+    // operand fragments (k-steps 0..3) of L21 of block which (0 = a, 1 = b): register image of the chain's x21, lane for lane
+    __device__ __forceinline__ void load_l21(double (&l21)[4], int which, int lane) const {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) l21[s_] = sm.t21[which * 256 + s_ * 64 + lane];
+    }
+    // -W1 and -W2 of the 32-block at row j0 as A operands
+    __device__ __forceinline__ void load_wn(double (&wn1)[4], double (&wn2)[4], int j0, int li, int kq) const {
+        const double* U = sm.U;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            wn1[s_] = -U[(size_t)(j0 + li) * PLD + 4 * s_ + kq];
+            wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
+        }
+    }
+    // the four solved tiles of tile rows tA+2, tA+3 in columns a as B operands: bf[row][chunk][half]
+    struct BFrag { v2d f[2][2][2]; };
+    __device__ __forceinline__ void load_bfrag(BFrag& b_, int tA, bool v3, int fo) const {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double2* p = tile2((r == 1 && !v3) ? tA + 2 : tA + 2 + r, tA + k) + fo;       // (stand-in when row tA+3 is padding)
+                const double2 d0 = p[0], d1 = p[64];
+                b_.f[r][k][0] = (v2d){d0.x, d0.y};
+                b_.f[r][k][1] = (v2d){d1.x, d1.y};
+            }
+    }
+    // acc += (tile row tA+2+r, columns a) * xs'   with xs = (xa | xb) the solved tiles of one tile row in columns a
+    static __device__ __forceinline__ void upd_b(v4d& acc, const BFrag& b_, int r, const v4d& xa, const v4d& xb) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][0][0].x, xa[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][0][0].y, xa[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][0][1].x, xa[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][0][1].y, xa[3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][1][0].x, xb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][1][0].y, xb[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][1][1].x, xb[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][1][1].y, xb[3], acc, 0, 0, 0);
+    }
+    __device__ __forceinline__ void store_pair(int T, int c, const v4d& x1, const v4d& x2, int fo) const {
+        double2* d0 = const_cast<double2*>(tile2(T, c)) + fo;
+        d0[0] = make_double2(x1[0], x1[1]);   d0[64] = make_double2(x1[2], x1[3]);
+        d0[128] = make_double2(x2[0], x2[1]); d0[192] = make_double2(x2[2], x2[3]);
+    }
+    // lower-left block of the inverse, W21 = -W2 (L21 W1), and y_j = M_j b_j of the fused forward substitution (wavefront 0;
+    // x21 = this lane's registers of L21)
+    __device__ __forceinline__ void finish_block(const v4d& x21, int j0, int lane, int li, int kq) {
+        double* U = sm.U;
+        v4d y = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+            y = __builtin_amdgcn_mfma_f64_16x16x4f64(x21[s_], U[(size_t)(j0 + 4 * s_ + kq) * PLD + li], y, 0, 0, 0);
+        v4d w21 = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+            w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq], y[s_], w21, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
+        __builtin_amdgcn_wave_barrier();
+        const int r = lane & 31;
+        const double* Mr = U + (size_t)(j0 + r) * PLD;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NB; c += 4) {
+            s0 += Mr[c] * sm.vec[j0 + c];
+            s1 += Mr[c + 1] * sm.vec[j0 + c + 1];
+            s2 += Mr[c + 2] * sm.vec[j0 + c + 2];
+            s3 += Mr[c + 3] * sm.vec[j0 + c + 3];
+        }
+        const double yv = (s0 + s1) + (s2 + s3);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < NB) sm.vec[j0 + lane] = yv;
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    __device__ __forceinline__ bool factor64() {
+        const int tid = opaque_u32(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int ntr = (n + 15) >> 4;
+        if (wv == 1) {
+            // prologue: diagonal block of column 0 straight from P
+            const int li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
+            v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
+            const v4d d11 = init_tile(0, 0, ntr, fo, li, kq);
+            const v4d d21 = init_tile(1, 0, ntr, fo, li, kq);
+            const v4d d22 = init_tile(1, 1, ntr, fo, li, kq);
+            stage_dsc(d11);
+            img21[lane] = d21;
+            img21[64 + lane] = d22;
+        }
+        __syncthreads();
+        if (wv == 0) return f64_chain();
+        if (wv == 1) return f64_look2();
+        return f64_rows(wv);
+    }
+
+    // ======== wavefront 0: both chains of a super column and, between them, the look-ahead of block b ====================
+    __device__ __forceinline__ bool f64_chain() {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;
+        const int nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
+        const int ntr = (n + 15) >> 4;
+        double* U = sm.U;
+        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
+        v4d* const img22 = img21 + 64;
+        for (int J = 0; J < nsup; ++J) {
+            const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J;
+            const bool hasb = (2 * J + 1) < nblk;
+            const int R2 = tA + 2, R3 = tA + 3;
+            const bool v3 = R3 < ntr;
+            PROF_DECL
+            // ---- chain a ------------------------------------------------------------------------------------------
+            bool ok = cholinv16_dsc(j0a, 0);
+            PROF(12);
+            {
+                const v4d d21 = img21[lane];
+                v4d d22 = img22[lane];
+                v4d x21 = (v4d){0, 0, 0, 0};
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    x21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0a + li) * PLD + 4 * s_ + kq], d21[s_], x21, 0, 0, 0);
+                // lane (li, kq) register rg = L21[li][kq + 4 rg]: as an A operand of k-step s it is its own fragment
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) sm.t21[rg * 64 + lane] = x21[rg];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    d22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21[s_], x21[s_], d22, 0, 0, 0);
+                PROF(14);
+                ok = cholinv16(d22, j0a + 16, 16) && ok;
+                PROF(15);
+                finish_block(x21, j0a, lane, li, kq);
+            }
+            if (hasb) {
+                // ---- look-ahead of block b: rows R2, R3 in columns a, diagonal block b ------------------------------
+                v4d p20 = init_tile(R2, tA, ntr, fo, li, kq),     p21 = init_tile(R2, tA + 1, ntr, fo, li, kq);
+                v4d p30 = init_tile(R3, tA, ntr, fo, li, kq),     p31 = init_tile(R3, tA + 1, ntr, fo, li, kq);
+                v4d e11 = init_tile(R2, R2, ntr, fo, li, kq),     e21 = init_tile(R3, R2, ntr, fo, li, kq);
+                v4d e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                if (J > 0) {
+                    const char* q0 = uniform_ptr(tile2(tA, 0));
+                    const char* q1 = uniform_ptr(tile2(tA + 1, 0));
+                    const char* q2 = uniform_ptr(tile2(R2, 0));
+                    const char* q3 = uniform_ptr(tile2(v3 ? R3 : R2, 0));
+                    const unsigned voff = (unsigned)fo * 16u;
+                    struct Frag { v2d b0, b1, a2, a3; };
+                    const int nk2 = 8 * J, klast = nk2 - 1;
+                    auto loadf = [&](Frag& f_, int k2) {
+                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+                        f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
+                        f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
+                    };
+#define HIPDRT_STEP7(B0, B1, A2, A3)                                                                    \
+                    p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);               \
+                    p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);               \
+                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);               \
+                    if (v3) {                                                                       \
+                        p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);           \
+                        p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);           \
+                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);           \
+                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);           \
+                    }
+                    auto multf = [&](const Frag& f_) {
+                        HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
+                        HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+#undef HIPDRT_STEP7
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+                    __builtin_amdgcn_sched_barrier(0);
+                    Frag f0, f1, f2, f3;
+                    loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
+                    for (int k2 = 0; k2 < nk2; k2 += 4) {           // nk2 = 8 J: a multiple of 4
+                        loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
+                        loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
+                        loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
+                        loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
+                    }
+                    vm_wait<0>();
+                    if (!v3) {
+                        p30 = (v4d){0, 0, 0, 0}; p31 = (v4d){0, 0, 0, 0}; e21 = (v4d){0, 0, 0, 0};
+                        e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                    }
+                }
+                PROF(40);
+                // panel solve against block a (own W1, L21, W2)
+                double wn1[4], l21[4], wn2[4];
+                load_wn(wn1, wn2, j0a, li, kq);
+                load_l21(l21, 0, lane);
+                v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    x20 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p20[s_], x20, 0, 0, 0);
+                    x30 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p30[s_], x30, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x20[s_], p21, 0, 0, 0);
+                    p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x30[s_], p31, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    x21_ = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p21[s_], x21_, 0, 0, 0);
+                    x31 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], p31[s_], x31, 0, 0, 0);
+                }
+                store_pair(R2, tA, x20, x21_, fo);
+                if (v3) store_pair(R3, tA, x30, x31, fo);
+                // the two chunks just produced complete diagonal block b
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x20[s_], e11, 0, 0, 0);
+                    e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20[s_], x30[s_], e21, 0, 0, 0);
+                    e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x30[s_], x30[s_], e22, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x21_[s_], e11, 0, 0, 0);
+                    e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x31[s_], e21, 0, 0, 0);
+                    e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x31[s_], x31[s_], e22, 0, 0, 0);
+                }
+                // right-hand side of block b receives block a's update (y_a is this wavefront's own, above)
+                fwd_update(x20, x21_, R2, j0a, li, kq);
+                if (v3) fwd_update(x30, x31, R3, j0a, li, kq);
+                __builtin_amdgcn_wave_barrier();
+                PROF(41);
+                // ---- chain b ---------------------------------------------------------------------------------------
+                ok = cholinv16(e11, j0b, 0) && ok;
+                v4d xb = (v4d){0, 0, 0, 0};
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    xb = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0b + li) * PLD + 4 * s_ + kq], e21[s_], xb, 0, 0, 0);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) sm.t21[256 + rg * 64 + lane] = xb[rg];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[s_], xb[s_], e22, 0, 0, 0);
+                ok = cholinv16(e22, j0b + 16, 16) && ok;
+                finish_block(xb, j0b, lane, li, kq);
+                PROF(42);
+            }
+            if (lane == 0) sm.flag[0] = ok ? 0 : 1;
+            __syncthreads();                                    // (A)
+            PROF2(1, 16 + (J < 23 ? J : 23));
+            if (sm.flag[0]) return false;
+            __syncthreads();                                    // (B)
+            PROF(4);
+        }
+        return true;
+    }
+
+    // ======== wavefront 1: tile rows Q2 = tA+4, Q3 = tA+5 over all four columns + the next diagonal block a' =============
+    __device__ __forceinline__ bool f64_look2() {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;
+        const int nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
+        const int ntr = (n + 15) >> 4;
+        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
+        v4d* const img22 = img21 + 64;
+        for (int J = 0; J < nsup; ++J) {
+            const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
+            const int Q2 = tA + 4, Q3 = tA + 5;
+            const bool v2 = Q2 < ntr, v3 = Q3 < ntr;
+            if (v2) {
+                v4d ca[2][2], cb[2][2], f11, f21, f22;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        ca[r][c] = init_tile(Q2 + r, tA + c, ntr, fo, li, kq);
+                        cb[r][c] = init_tile(Q2 + r, tB + c, ntr, fo, li, kq);
+                    }
+                f11 = init_tile(Q2, Q2, ntr, fo, li, kq);
+                f21 = init_tile(Q3, Q2, ntr, fo, li, kq);
+                f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
+                if (J > 0) {
+                    const char* qb[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) qb[c] = uniform_ptr(tile2(tA + c, 0));
+                    const char* q2 = uniform_ptr(tile2(Q2, 0));
+                    const char* q3 = uniform_ptr(tile2(v3 ? Q3 : Q2, 0));
+                    const unsigned voff = (unsigned)fo * 16u;
+                    struct Frag { v2d b[4], a2, a3; };
+                    const int nk2 = 8 * J, klast = nk2 - 1;
+                    auto loadf = [&](Frag& f_, int k2) {
+                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) f_.b[c] = gload16(qb[c] + o, voff);
+                        f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
+                    };
+#define HIPDRT_STEP11(H)                                                                                          \
+                    ca[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[0].H, f_.a2.H, ca[0][0], 0, 0, 0);     \
+                    ca[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[1].H, f_.a2.H, ca[0][1], 0, 0, 0);     \
+                    cb[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[2].H, f_.a2.H, cb[0][0], 0, 0, 0);     \
+                    cb[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[3].H, f_.a2.H, cb[0][1], 0, 0, 0);     \
+                    f11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a2.H, f_.a2.H, f11, 0, 0, 0);                 \
+                    if (v3) {                                                                                   \
+                        ca[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[0].H, f_.a3.H, ca[1][0], 0, 0, 0); \
+                        ca[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[1].H, f_.a3.H, ca[1][1], 0, 0, 0); \
+                        cb[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[2].H, f_.a3.H, cb[1][0], 0, 0, 0); \
+                        cb[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[3].H, f_.a3.H, cb[1][1], 0, 0, 0); \
+                        f21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a2.H, f_.a3.H, f21, 0, 0, 0);             \
+                        f22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a3.H, f_.a3.H, f22, 0, 0, 0);             \
+                    }
+                    auto multf = [&](const Frag& f_) {
+                        HIPDRT_STEP11(x)
+                        HIPDRT_STEP11(y)
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+#undef HIPDRT_STEP11
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    Frag f0, f1, f2, f3;
+                    loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
+                    for (int k2 = 0; k2 < nk2; k2 += 4) {
+                        loadf(f3, k2 + 3); vm_wait<18>(); multf(f0);
+                        loadf(f0, k2 + 4); vm_wait<18>(); multf(f1);
+                        loadf(f1, k2 + 5); vm_wait<18>(); multf(f2);
+                        loadf(f2, k2 + 6); vm_wait<18>(); multf(f3);
+                    }
+                    vm_wait<0>();
+                    if (!v3) {
+                        ca[1][0] = (v4d){0, 0, 0, 0}; ca[1][1] = ca[1][0]; cb[1][0] = ca[1][0]; cb[1][1] = ca[1][0]; f21 = ca[1][0];
+                        f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
+                    }
+                }
+                __syncthreads();                                // (A)
+                if (sm.flag[0]) return false;
+                BFrag bf;
+                load_bfrag(bf, tA, true, fo);                   // (rows tA+2, tA+3 are valid whenever Q2 is)
+                v4d xa[2][2], xb[2][2];
+                {
+                    double wn1[4], l21[4], wn2[4];
+                    load_wn(wn1, wn2, j0a, li, kq);
+                    load_l21(l21, 0, lane);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { xa[r][0] = (v4d){0, 0, 0, 0}; xa[r][1] = (v4d){0, 0, 0, 0}; }
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) xa[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], ca[r][0][s_], xa[r][0], 0, 0, 0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) ca[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], xa[r][0][s_], ca[r][1], 0, 0, 0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) xa[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], ca[r][1][s_], xa[r][1], 0, 0, 0);
+                }
+                store_pair(Q2, tA, xa[0][0], xa[0][1], fo);
+                if (v3) store_pair(Q3, tA, xa[1][0], xa[1][1], fo);
+                // block a's rank-32 update of the column-b tiles and of the next diagonal block, from registers
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) upd_b(cb[r][c], bf, c, xa[r][0], xa[r][1]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        f11 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0][k][s_], xa[0][k][s_], f11, 0, 0, 0);
+                        f21 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0][k][s_], xa[1][k][s_], f21, 0, 0, 0);
+                        f22 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1][k][s_], xa[1][k][s_], f22, 0, 0, 0);
+                    }
+                fwd_update(xa[0][0], xa[0][1], Q2, j0a, li, kq);
+                if (v3) fwd_update(xa[1][0], xa[1][1], Q3, j0a, li, kq);
+                {
+                    double wn1[4], l21[4], wn2[4];
+                    load_wn(wn1, wn2, j0b, li, kq);
+                    load_l21(l21, 1, lane);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { xb[r][0] = (v4d){0, 0, 0, 0}; xb[r][1] = (v4d){0, 0, 0, 0}; }
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) xb[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], cb[r][0][s_], xb[r][0], 0, 0, 0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) cb[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], xb[r][0][s_], cb[r][1], 0, 0, 0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) xb[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], cb[r][1][s_], xb[r][1], 0, 0, 0);
+                }
+                store_pair(Q2, tB, xb[0][0], xb[0][1], fo);
+                if (v3) store_pair(Q3, tB, xb[1][0], xb[1][1], fo);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        f11 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[0][k][s_], xb[0][k][s_], f11, 0, 0, 0);
+                        f21 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[0][k][s_], xb[1][k][s_], f21, 0, 0, 0);
+                        f22 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[1][k][s_], xb[1][k][s_], f22, 0, 0, 0);
+                    }
+                stage_dsc(f11);
+                img21[lane] = f21;
+                img22[lane] = f22;
+                fwd_update(xb[0][0], xb[0][1], Q2, j0b, li, kq);
+                if (v3) fwd_update(xb[1][0], xb[1][1], Q3, j0b, li, kq);
+            } else {
+                __syncthreads();                                // (A)
+                if (sm.flag[0]) return false;
+            }
+            __syncthreads();                                    // (B)
+        }
+        return true;
+    }
+
+    // ======== wavefronts 2..7: tile rows tA+6 .. over all four columns ===================================================
+    __device__ __forceinline__ bool f64_rows(int wv) {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;
+        const int nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
+        const int ntr = (n + 15) >> 4;
+        constexpr int SROW = Smem::SROW;
+        for (int J = 0; J < nsup; ++J) {
+            const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
+            const int nsq = ntr - (tA + 6) > 0 ? ntr - (tA + 6) : 0;
+            const unsigned char* row = sm.sched + J * SROW;
+            unsigned long long m0 = __ballot(lane < nsq && row[lane] == wv), m1 = 0;
+            if (SROW > 64) m1 = __ballot(lane + 64 < nsq && row[lane + 64] == wv);
+            const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);
+            const int npass = mine > RM ? (mine + RM - 1) / RM : 1;
+#pragma unroll 1
+            for (int ps = 0; ps < npass; ++ps) {
+                int T[RM];
+                bool act[RM];
+#pragma unroll
+                for (int u = 0; u < RM; ++u) {
+                    int r = -1;
+                    if (m0) { r = __builtin_ctzll(m0); m0 &= m0 - 1; }
+                    else if (m1) { r = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+                    T[u] = r >= 0 ? tA + 6 + r : nch;
+                    act[u] = r >= 0;
+                }
+                v4d acc[RM][4];
+#pragma unroll
+                for (int u = 0; u < RM; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[u][c] = act[u] ? init_tile(T[u], tA + c, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                if (J > 0 && act[0]) {
+                    // operand ring as in factor_rows(): A tiles (own rows, HBM) three half-chunks ahead, B tiles (tile rows
+                    // tA .. tA+3, shared by all wavefronts: L1 / L2) one ahead; per step 4 B + RM A loads, B first
+                    const char* rb[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rb[c] = uniform_ptr(tile2(tA + c, 0));
+                    const char* ra[RM];
+#pragma unroll
+                    for (int u = 0; u < RM; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tA, 0));
+                    const unsigned voff = (unsigned)fo * 16u;
+                    struct SlA { v2d a[RM]; };
+                    struct SlB { v2d b[4]; };
+                    const int nk2 = 8 * J, klast = nk2 - 1;
+                    auto loadA = [&](SlA& s_, int k2) {
+                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+#pragma unroll
+                        for (int u = 0; u < RM; ++u) s_.a[u] = gload16(ra[u] + o, voff);
+                    };
+                    auto loadB = [&](SlB& s_, int k2) {
+                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) s_.b[c] = gload16(rb[c] + o, voff);
+                    };
+                    auto mult = [&](const SlA& a_, const SlB& b_) {
+#pragma unroll
+                        for (int u = 0; u < RM; ++u)
+                            if (act[u]) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b[c].x, a_.a[u].x, acc[u][c], 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int u = 0; u < RM; ++u)
+                            if (act[u]) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b[c].y, a_.a[u].y, acc[u][c], 0, 0, 0);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    SlA a0, a1, a2, a3;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+                    __builtin_amdgcn_sched_barrier(0);
+                    SlB b0, b1;
+                    loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
+                    for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 8 J: a multiple of 4
+                        loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RM + 4>(); mult(a0, b0);
+                        loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * RM + 4>(); mult(a1, b1);
+                        loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RM + 4>(); mult(a2, b0);
+                        loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<2 * RM + 4>(); mult(a3, b1);
+                    }
+                    vm_wait<0>();
+                }
+                if (ps == 0) {
+                    __syncthreads();                            // (A)
+                    if (sm.flag[0]) return false;
+                }
+                if (act[0]) {
+                    BFrag bf;
+                    load_bfrag(bf, tA, true, fo);               // (rows tA+2, tA+3 are valid whenever there are rows here)
+                    v4d x1[RM], x2[RM];
+                    {
+                        double wn1[4], l21[4], wn2[4];
+                        load_wn(wn1, wn2, j0a, li, kq);
+                        load_l21(l21, 0, lane);
+#pragma unroll
+                        for (int u = 0; u < RM; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RM; ++u) x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RM; ++u) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RM; ++u) x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RM; ++u)
+                        if (act[u]) store_pair(T[u], tA, x1[u], x2[u], fo);
+#pragma unroll
+                    for (int u = 0; u < RM; ++u) {
+                        upd_b(acc[u][2], bf, 0, x1[u], x2[u]);
+                        upd_b(acc[u][3], bf, 1, x1[u], x2[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RM; ++u)
+                        if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0a, li, kq);
+                    {
+                        double wn1[4], l21[4], wn2[4];
+                        load_wn(wn1, wn2, j0b, li, kq);
+                        load_l21(l21, 1, lane);
+#pragma unroll
+                        for (int u = 0; u < RM; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RM; ++u) x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][2][s_], x1[u], 0, 0, 0);
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RM; ++u) acc[u][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][3], 0, 0, 0);
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                            for (int u = 0; u < RM; ++u) x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][3][s_], x2[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RM; ++u)
+                        if (act[u]) store_pair(T[u], tB, x1[u], x2[u], fo);
+#pragma unroll
+                    for (int u = 0; u < RM; ++u)
+                        if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0b, li, kq);
+                }
+            }
+            __syncthreads();                                        // (B)
         }
         return true;
     }
@@ -1358,6 +1997,9 @@ __global__ __launch_bounds__(RTT) void cov_kernel_resident(CovArgs a, int NP) {
     }
 }
 
+// the QP kernel's factorisation: 64-column passes over the history (factor64) with eight wavefronts
+template <int RTT> static constexpr bool kQpPanel64 = (HIPDRT_QP_PANEL64 != 0) && RTT == 512;
+
 // (the second launch-bound argument is waves per SIMD: 2 in both forms, i.e. one 512-thread or two 256-thread workgroups per
 // CU and at most 256 registers per lane; without it hipcc gives the 256-thread form 393 registers and one workgroup per CU)
 template <bool GU, int RTT = 512>
@@ -1366,7 +2008,7 @@ __global__ __launch_bounds__(RTT, HIPDRT_QP_MINWAVES) void qp_kernel_resident(Qp
     const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
     if (a.active && !a.active[b]) return;
     extern __shared__ double smem[];
-    OpsResidentT<GU, RTT> ops;
+    OpsResidentT<GU, RTT, kQpPanel64<RTT>> ops;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk ? a.Ppk + (size_t)b * a.ppk_stride : nullptr; ops.nchp = a.nchp;
     ops.sm.carve(smem);
@@ -1382,11 +2024,14 @@ __global__ __launch_bounds__(RTT, HIPDRT_QP_MINWAVES) void qp_kernel_resident(Qp
 }
 
 // LDS bytes: everything for n <= 528, only the fixed part when U lives in global memory
-static size_t resident_lds_bytes(int NP) {
-    return ((size_t)NP * PLD + ResSmem::FIXED) * sizeof(double);
+// (qp = the QP kernel's layout, which differs from the posterior-variance kernel's when it runs factor64)
+static size_t resident_lds_bytes(int NP, bool qp = false) {
+    return ((size_t)NP * PLD + (qp ? ResSmemT<false, 512, kQpPanel64<512>>::FIXED : ResSmem::FIXED)) * sizeof(double);
 }
 template <int RTT = 512>
-static size_t resident_gu_lds_bytes() { return (size_t)ResSmemT<true, RTT>::FIXED * sizeof(double); }
+static size_t resident_gu_lds_bytes(bool qp = false) {
+    return (size_t)(qp ? ResSmemT<true, RTT, kQpPanel64<RTT>>::FIXED : ResSmemT<true, RTT>::FIXED) * sizeof(double);
+}
 // per-problem scratch doubles of the U-outside form: the tile-packed factor (NP^2) followed by U (NP x 33)
 static size_t resident_gu_doubles(int n) {
     const size_t NP = (size_t)round_up(n, 32);

@@ -276,14 +276,26 @@ def fit_observations(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_
 
 
 _GATHER_KEYS = ('obs_llh', 'obs_rss', 'outer_iters', 'qp_iters_total', 'status')
+# every special parameter a fit can report (x layout of drt1d.py:377-408); the gathered rows name them by position here
+_SPECIAL_REGISTRY = ('v_baseline', 'vz_offset', 'R_inf', 'inductance', 'C_inv', 'x_dop')
 
 
-def share_lookup_tables(drt, rank, world, src=0):
+def share_lookup_tables(drt, rank, world, src=0, force=False):
     """SURVEY 8e / north_star: the lookup tables of the shared tau basis (impedance Z', Z'' and the chrono response, 3 x
     2000 doubles) are built once, on rank `src`, and broadcast to the other ranks (RCCL over xGMI on a GPU node) -- ONE
-    collective; every rank's plans then take their tables from the broadcast instead of rebuilding them."""
+    collective per (DRT instance, epsilon, world, src), not per map: the first call of a DRT instance broadcasts and marks
+    the instance (and, through copy, its sibling clones); later calls return False without communicating.  Whether a
+    rank takes part is decided from state every rank shares by construction -- tau_epsilon is fixed in DRT.__init__ from the
+    constructor arguments, the mark is set by this very function -- so ranks that call the sharded driver with DRT
+    instances of the same history agree (an SPMD program does; a rank that swaps in a fresh DRT for a later map must do so on
+    every rank, or pass force=True everywhere).  Non-`src` ranks install the received tables BEFORE their plans exist where
+    they can (DRT._get_plan hands them to the new plan), so nothing is built twice on them; a plan that already exists is
+    re-pointed at the received tables (one matrix rebuild)."""
     from . import dist as hd
     if world <= 1 or drt.tau_epsilon is None or drt.integrate_method != 'interp':
+        return False
+    key = (float(drt.tau_epsilon), int(world), int(src))
+    if not force and getattr(drt, '_lut_shared_key', None) == key:
         return False
     shapes = [(len(drt._wt_re),), (len(drt._wt_im),), (2000,)]
     if rank == src:
@@ -293,24 +305,90 @@ def share_lookup_tables(drt, rank, world, src=0):
     z_re, z_im, resp = hd.broadcast_arrays([z_re, z_im, resp], src=src)
     if rank != src:
         drt.install_lookup_tables(z_re, z_im, resp)
+    drt._lut_shared_key = key
+    for clone in getattr(drt, '_sibling_clones', None) or []:
+        if rank != src:
+            clone.install_lookup_tables(z_re, z_im, resp)
+        clone._lut_shared_key = key
     return True
+
+
+def _pack_rows(obs_x, obs_special, res, drt_var):
+    """One rank's results as rows of doubles behind ONE header row that describes them, so that `dst` can unpack blocks from
+    ranks whose fits reported other special parameters (or none at all) without a second collective:
+        header = [nsup, drt_var, n_specials, (registry index, width, ndim) x n_specials, 0 ...]
+        row    = [obs_x (nsup) | specials at their real widths | _GATHER_KEYS | left, right | obs_drt_var (nsup), ok]"""
+    num, nsup = obs_x.shape
+    unknown = [k for k in obs_special if k not in _SPECIAL_REGISTRY]
+    if unknown:
+        raise NotImplementedError(f'special parameters {unknown} are not known to the sharded driver')
+    cols, head = [obs_x], [float(nsup), float(bool(drt_var)), 0.0]
+    for ki, key in enumerate(_SPECIAL_REGISTRY):
+        if obs_special.get(key) is None:
+            continue
+        raw = np.asarray(obs_special[key], dtype=float)
+        val = raw.reshape(num, -1)
+        cols.append(val)
+        head += [float(ki), float(val.shape[1]), float(raw.ndim)]
+        head[2] += 1
+    cols += [np.asarray(res[k], dtype=float)[:, None] for k in _GATHER_KEYS]
+    ti = res.get('obs_tau_indices', (0, nsup))
+    ti = np.array(ti, dtype=float) if isinstance(ti, list) else np.tile(np.array(ti, dtype=float), (num, 1))
+    cols.append(ti)
+    if drt_var:
+        cols += [res['obs_drt_var'], np.asarray(res['obs_drt_var_ok'], dtype=float)[:, None]]
+    body = np.concatenate(cols, axis=1)
+    width = max(body.shape[1], len(head))
+    packed = np.zeros((num + 1, width))
+    packed[0, :len(head)] = head
+    packed[1:, :body.shape[1]] = body
+    return packed
+
+
+def _unpack_block(block):
+    """inverse of _pack_rows for one rank's block (header row first): (obs_x, {special: (2-d array, ndim of the original)}, {key: column}, ti, var, vok)"""
+    head, body = block[0], block[1:]
+    nsup, drt_var, nsp = int(head[0]), bool(head[1]), int(head[2])
+    obs_x = body[:, :nsup]
+    pos = nsup
+    special = {}
+    for j in range(nsp):
+        key, w, nd = _SPECIAL_REGISTRY[int(head[3 + 3 * j])], int(head[4 + 3 * j]), int(head[5 + 3 * j])
+        special[key] = (body[:, pos:pos + w], nd)
+        pos += w
+    cols = {}
+    for k in _GATHER_KEYS:
+        cols[k] = body[:, pos]
+        pos += 1
+    ti = body[:, pos:pos + 2]
+    pos += 2
+    var = vok = None
+    if drt_var:
+        var, vok = body[:, pos:pos + nsup], body[:, pos + nsup] > 0.5
+    return obs_x, special, cols, ti, var, vok
 
 
 def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world=None, tau_supergrid=None, scheme='interleave',
                              drt_var=False, dst=0, fit=fit_observations, inflight=1, observations=None, ignore_errors=False,
                              **fit_kw):
     """BASELINE configs[3]: the observations of one map sharded over the ranks of a node (one process per GPU), every
-    rank fitting its share as device batches, the results gathered on rank `dst` with ONE collective; before that, ONE
-    broadcast of rank `dst`'s lookup tables (share_lookup_tables).
+    rank fitting its share as device batches, the results gathered on rank `dst` with ONE collective per map (a gather).
+    The lookup tables of rank `dst` are broadcast ONCE per DRT instance (share_lookup_tables: the first map of an instance
+    pays one more collective, later maps none); only when some rank owns no observation at all does the row width have to
+    be agreed by one more (scalar) all-reduce.
 
     Every rank calls this with the same (frequencies, z_obs) -- or at least with its own rows valid -- or the same
     ``observations`` list (any mix of data types and grids, see fit_observations), and its own `drt`.  Returns on `dst` the
     same triple as fit_observations for ALL observations in their original order (result dict reduced to the
     per-observation arrays obs_llh, obs_rss, outer_iters, qp_iters_total, status [, obs_tau_indices, obs_drt_var]); None
-    elsewhere.  `scheme`: see shard_indices ('lpt' uses difficulty_proxy(z_obs); shared-grid form only).  `fit` is the
-    per-rank fit function (the CPU tests inject a stand-in); `inflight` > 1 is handed to it (batches side by side on every
-    rank).  Every rank fits with ignore_errors=True, so that all of them reach the collective; a failed observation then
-    raises on `dst`, after the gather, unless ``ignore_errors``."""
+    elsewhere.  Special parameters travel at their real widths (x_dop: one column per basis_nu point, v_baseline: one per
+    coefficient): a key missing on some rank is zero-filled there, as DRTMD's initialize_obs_special does for observations
+    that do not report it.  `scheme`: see shard_indices ('lpt' uses difficulty_proxy(z_obs); shared-grid form only).  `fit`
+    is the per-rank fit function (the CPU tests inject a stand-in); `inflight` > 1 is handed to it (batches side by side on
+    every rank).  Every rank fits with ignore_errors=True, so that all of them reach the collective; a failed observation then
+    raises on `dst`, after the gather, unless ``ignore_errors``.
+    A fit's bits depend (at the 1e-14 level) on whether its device batch held more or fewer than #CUs / 16 spectra (two QP
+    kernels): a map re-sharded over another number of ranks reproduces to that level, not bit for bit."""
     from . import dist as hd
     if rank is None or world is None:
         import torch.distributed as tdist
@@ -330,13 +408,6 @@ def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world
     mine = owned[rank]
     if fit is fit_observations:
         share_lookup_tables(drt, rank, world, src=dst)
-    # special-parameter columns: the union over the whole map, in a fixed order, so that every rank packs the same row
-    special_keys = ['R_inf', 'inductance']
-    if general:
-        kinds = {kind for kind, _ in observation_groups(observations)}
-        if kinds - {'eis'}:
-            special_keys = ['v_baseline', 'vz_offset', 'R_inf', 'inductance']
-    nsup = None
     if len(mine):
         kw = dict(fit_kw, ignore_errors=True)
         if inflight != 1:
@@ -346,49 +417,56 @@ def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world
                                           observations=[observations[k] for k in mine], **kw)
         else:
             obs_x, obs_special, res = fit(drt, frequencies, z_obs[mine], tau_supergrid=tau_supergrid, drt_var=drt_var, **kw)
-        nsup = obs_x.shape[1]
-        cols = [obs_x]
-        for key in special_keys:
-            val = obs_special.get(key)
-            cols.append(np.zeros((len(mine), 1)) if val is None else np.asarray(val, dtype=float).reshape(len(mine), -1)[:, :1])
-        cols += [np.asarray(res[k], dtype=float)[:, None] for k in _GATHER_KEYS]
-        ti = res.get('obs_tau_indices', (0, nsup))
-        ti = np.array(ti, dtype=float) if isinstance(ti, list) else np.tile(np.array(ti, dtype=float), (len(mine), 1))
-        cols.append(ti)
-        if drt_var:
-            cols += [res['obs_drt_var'], np.asarray(res['obs_drt_var_ok'], dtype=float)[:, None]]
-        packed = np.concatenate(cols, axis=1)
+        packed = _pack_rows(obs_x, obs_special, res, drt_var)
     else:
         packed = None
-    # ranks without observations still take part in the collective: the row width comes from a rank that has some
-    width = hd.max_over_ranks(0 if packed is None else packed.shape[1])
-    if packed is None:
-        packed = np.zeros((0, int(width)))
-    counts = [len(o) for o in owned]
+    # blocks: one header row + the rank's observations; a rank without observations sends nothing
+    counts = [len(o) + 1 if len(o) else 0 for o in owned]
+    if min(counts) == 0 and world > 1:
+        # the row width is a function of the fit's configuration; a rank that fitted nothing learns it from the others
+        width = int(hd.max_over_ranks(0 if packed is None else packed.shape[1]))
+        if packed is None:
+            packed = np.zeros((0, width))
+        elif packed.shape[1] < width:            # (ranks whose fits report different specials: pad to the widest row)
+            packed = np.pad(packed, ((0, 0), (0, width - packed.shape[1])))
+    elif packed is None:
+        packed = np.zeros((0, 1))
+    elif world > 1 and general:
+        # heterogeneous lists: ranks may report different sets of special parameters, i.e. rows of different widths
+        width = int(hd.max_over_ranks(packed.shape[1]))
+        if packed.shape[1] < width:
+            packed = np.pad(packed, ((0, 0), (0, width - packed.shape[1])))
     full = hd.gather_rows(packed, counts, dst=dst)
     if rank != dst:
         return None
-    order = np.concatenate(owned) if world > 1 else mine
-    out = np.empty_like(full)
-    out[order] = full                                    # back to the original observation order
-    # row = [obs_x (nsup) | specials | _GATHER_KEYS | left, right | obs_drt_var (nsup) | ok]  (the last two with drt_var)
-    fixed = len(special_keys) + len(_GATHER_KEYS) + 2 + (1 if drt_var else 0)
-    nsup = (out.shape[1] - fixed) // (2 if drt_var else 1)
-    obs_x = out[:, :nsup]
-    pos = nsup
-    obs_special = {}
-    for key in special_keys:
-        obs_special[key] = out[:, pos]
-        pos += 1
-    res = {}
+    if num == 0:
+        raise ValueError('no observations')
+    blocks, pos = [], 0
+    for r in range(world):
+        if counts[r]:
+            blocks.append((owned[r], _unpack_block(full[pos:pos + counts[r]])))
+            pos += counts[r]
+    nsup = blocks[0][1][0].shape[1]
+    obs_x = np.zeros((num, nsup))
+    obs_special, res = {}, {}
     for k in _GATHER_KEYS:
-        res[k] = out[:, pos] if k in ('obs_llh', 'obs_rss') else out[:, pos].astype(np.int64)
-        pos += 1
-    res['obs_tau_indices'] = [(int(a_), int(b_)) for a_, b_ in out[:, pos:pos + 2]]
-    pos += 2
+        res[k] = np.zeros(num) if k in ('obs_llh', 'obs_rss') else np.zeros(num, dtype=np.int64)
+    tis = np.zeros((num, 2), dtype=np.int64)
     if drt_var:
-        res['obs_drt_var'] = out[:, pos:pos + nsup]
-        res['obs_drt_var_ok'] = out[:, pos + nsup] > 0.5
+        res['obs_drt_var'], res['obs_drt_var_ok'] = np.zeros((num, nsup)), np.zeros(num, dtype=bool)
+    for idx, (bx, bspecial, bcols, bti, bvar, bvok) in blocks:
+        obs_x[idx] = bx
+        for key, (val, nd) in bspecial.items():
+            if key not in obs_special:
+                obs_special[key] = np.zeros((num, val.shape[1]) if nd > 1 else (num,))
+            obs_special[key][idx] = val if nd > 1 else val[:, 0]
+        for k in _GATHER_KEYS:
+            res[k][idx] = bcols[k] if k in ('obs_llh', 'obs_rss') else bcols[k].astype(np.int64)
+        tis[idx] = bti.astype(np.int64)
+        if drt_var:
+            res['obs_drt_var'][idx], res['obs_drt_var_ok'][idx] = bvar, bvok
+    # (shapes as fit_observations returns them: (num,) for scalar specials, (num, width) for vector-valued ones)
+    res['obs_tau_indices'] = [(int(a_), int(b_)) for a_, b_ in tis]
     res['obs_fit_status'] = res['status'] >= 0
     res['obs_fit_errors'] = [None if good else ValueError("Rank(A) < p or Rank([P; A; G]) < n") for good in res['obs_fit_status']]
     _raise_first_error(res, ignore_errors)

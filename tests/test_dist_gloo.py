@@ -69,7 +69,10 @@ def _fake_fit(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_var=Fal
         res = {"obs_llh": -np.abs(zs), "obs_rss": np.abs(zs) ** 2,
                "outer_iters": np.array([len(f) + int(chrono is not None) for chrono, (f, z) in observations]) % 5 + 2,
                "qp_iters_total": np.arange(num) * 0 + 7, "status": np.zeros(num, dtype=np.int64), "obs_tau_indices": ti}
-        return obs_x, {"v_baseline": vb, "vz_offset": vb * 0.5, "R_inf": rinf, "inductance": rinf * 2}, res
+        # x_dop is vector valued (one column per basis_nu point), v_baseline here a two-coefficient polynomial
+        xdop = np.outer(rinf, np.arange(1.0, 6.0))
+        return obs_x, {"v_baseline": np.stack([vb, -vb], axis=1), "vz_offset": vb * 0.5, "R_inf": rinf, "inductance": rinf * 2,
+                       "x_dop": xdop}, res
     num, nsup = z_obs.shape[0], 12
     obs_x = np.outer(z_obs.real.sum(1), np.arange(1.0, nsup + 1))
     special = {"R_inf": z_obs.real[:, 0].copy(), "inductance": z_obs.imag[:, -1].copy()}
@@ -131,6 +134,7 @@ def _sharded_general_worker(rank, world, port, total):
         np.testing.assert_array_equal(obs_x, ex)
         assert set(special) == set(es)
         for k in es:
+            assert special[k].shape == es[k].shape, (k, special[k].shape, es[k].shape)      # x_dop (num, 5), v_baseline (num, 2)
             np.testing.assert_array_equal(special[k], es[k])
         for k in ("obs_llh", "obs_rss", "outer_iters", "qp_iters_total", "status"):
             np.testing.assert_array_equal(res[k], er[k], err_msg=k)
@@ -153,6 +157,68 @@ def test_fit_observations_sharded_world2_every_scheme():
     variance rows"""
     for scheme, drt_var, total in (("block", False, 7), ("interleave", True, 9), ("lpt", False, 10)):
         mp.spawn(_sharded_worker, args=(2, _free_port(), total, scheme, drt_var), nprocs=2, join=True)
+
+
+class _TableDRT:
+    """just enough of a DRT for share_lookup_tables: an epsilon, table abscissae, build / install hooks that count"""
+    def __init__(self, rank):
+        self.tau_epsilon, self.integrate_method = 22.19, 'interp'
+        self._wt_re, self._wt_im = np.ones(2000), np.ones(2000)
+        self.rank, self.built, self.installed = rank, 0, 0
+        self.tables = None
+
+    def lookup_tables(self):
+        self.built += 1
+        return np.arange(2000.0), np.arange(2000.0) * 2, np.arange(2000.0) * 3
+
+    def install_lookup_tables(self, z_re, z_im, resp):
+        self.installed += 1
+        self.tables = (z_re, z_im, resp)
+
+
+def _share_once_worker(rank, world, port):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from hipdrt.mapping import dist as hd
+    from hipdrt.mapping import drtmd
+    hd.init_from_env(backend="gloo")
+    calls = {"broadcast": 0, "all_reduce": 0, "gather": 0}
+    for name in calls:
+        orig = getattr(dist, name)
+        def counted(*a, _o=orig, _n=name, **k):
+            calls[_n] += 1
+            return _o(*a, **k)
+        setattr(dist, name, counted)
+    drt = _TableDRT(rank)
+    freq = np.logspace(3, 0, 16)
+    from hipdrt import synth
+    z = synth.zarc2_batch(freq, 9)
+    # `fit` is the real entry point's identity as far as the driver is concerned: wrap the stand-in so that the table
+    # broadcast is not skipped
+    orig_fit = drtmd.fit_observations
+    drtmd.fit_observations = _fake_fit
+    try:
+        for call in range(3):
+            out = drtmd.fit_observations_sharded(drt, freq, z, rank=rank, world=world, fit=drtmd.fit_observations)
+            assert (out is None) == (rank != 0)
+            # first map: one broadcast + one gather; every later map: the gather only (no all_reduce: every rank owns rows)
+            assert calls == {"broadcast": 1, "all_reduce": 0, "gather": call + 1}, (call, calls)
+    finally:
+        drtmd.fit_observations = orig_fit
+    assert drt.built == (1 if rank == 0 else 0) and drt.installed == (0 if rank == 0 else 1)
+    if rank != 0:
+        np.testing.assert_array_equal(drt.tables[2], np.arange(2000.0) * 3)
+    hd.barrier()
+    dist.destroy_process_group()
+
+
+def test_second_sharded_map_issues_no_broadcast():
+    """the lookup tables travel once per DRT instance, not once per map; a map whose ranks all own observations costs exactly
+    one collective (the gather)"""
+    mp.spawn(_share_once_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
 def test_shard_indices_partition_and_balance():

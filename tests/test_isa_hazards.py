@@ -36,13 +36,40 @@ def test_scanner_sees_a_planted_hazard():
     assert len(found) == 2 and all(f[1].startswith("global_load_dwordx4 v[4:7]") for f in found)
 
 
+def test_scanner_follows_fall_through_and_back_edges():
+    mod = _scanner()
+    planted = """_ZN6hipdrt5test2Ev:
+	v_readlane_b32 s2, v248, 59
+	v_readlane_b32 s3, v248, 60
+.LBB0_1:
+	global_load_dwordx4 v[4:7], v88, s[2:3]
+	s_nop 7
+	v_readlane_b32 s6, v248, 61
+	v_readlane_b32 s7, v248, 62
+	s_cbranch_scc1 .LBB0_3
+	s_branch .LBB0_4
+.LBB0_3:
+	global_load_dwordx4 v[8:11], v88, s[6:7]
+.LBB0_4:
+	s_nop 7
+	global_load_dwordx4 v[12:15], v88, s[6:7]
+.Lfunc_end0:
+"""
+    found = mod.scan(planted)
+    hit = sorted({f[1].split(',')[0] for f in found})
+    # the loop header load sees the reloads of the block in front of it; the branch target sees the reloads at the branch;
+    # the load behind eight wait states is clean
+    assert hit == ["global_load_dwordx4 v[4:7]", "global_load_dwordx4 v[8:11]"], found
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_hand_issued_loads_are_outside_the_sgpr_hazard_shadow(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["-DHIPDRT_QP_PROFILE"]], ids=["release", "profile"])
+def test_hand_issued_loads_are_outside_the_sgpr_hazard_shadow(tmp_path, extra):
     mod = _scanner()
     src = os.path.join(ROOT, "hybrid-drt_amd", "csrc", "qp.hip")
     out = tmp_path / "qp.s"
     subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
-                    "-S", "--cuda-device-only", src, "-o", str(out)], check=True, cwd=os.path.dirname(src),
+                    "-S", "--cuda-device-only"] + extra + [src, "-o", str(out)], check=True, cwd=os.path.dirname(src),
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     txt = out.read_text()
     assert "global_load_dwordx4" in txt and "qp_kernel_resident" in txt

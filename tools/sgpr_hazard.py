@@ -11,34 +11,65 @@ This lists every hand-issued load whose scalar base was written by a VALU instru
 import re
 import sys
 
+def _merge(a, b):
+    """union of two 'recently written' states, the younger write of an SGPR wins"""
+    d = dict(a)
+    for s_, age in b:
+        if s_ not in d or age < d[s_]:
+            d[s_] = age
+    return sorted(d.items())
+
+
 def scan(txt):
-    """-> list of (kernel, instruction, sgpr, wait states) for every hand-issued load that reads a VALU-written SGPR too early"""
-    found = []
+    """-> list of (kernel, instruction, sgpr, wait states) for every hand-issued load that reads a VALU-written SGPR too early.
+    Control flow is followed: the state at a label is the union of the fall-through state and of the states at every branch
+    to it (backward branches included: the scan of a function is repeated until the label states stop changing), so a spill
+    reload at the bottom of a loop body, or at the end of the block in front of a loop header, is seen by a load at the top."""
+    found = set()
     for m in re.finditer(r'^(_ZN6hipdrt\w+):', txt, re.M):
         name = m.group(1)
         end = txt.find('.Lfunc_end', m.start())
         lines = [l.split(';')[0].strip() for l in txt[m.start():end].split('\n')]
-        lines = [l for l in lines if l and not l.startswith('.') and not l.startswith('#')]
-        recent = []          # (sgpr number, wait states since the write)
-        for l in lines:
-            if l.endswith(':'):
-                recent = []  # block boundary (spill reloads sit in the block that uses them)
-                continue
-            op = l.split()[0]
-            w = re.match(r'v_read(?:first)?lane_b32\s+s(\d+)', l)
-            if op.startswith('global_load') or op.startswith('global_store'):
-                sb = re.search(r's\[(\d+):(\d+)\]', l)
-                if sb:
-                    lo, hi = int(sb.group(1)), int(sb.group(2))
-                    for s_, age in recent:
-                        if lo <= s_ <= hi and age < 5:
-                            found.append((name, l, s_, age))
-            nops = re.match(r's_nop\s+(\d+)', l)
-            step = int(nops.group(1)) + 1 if nops else 1
-            recent = [(s_, age + step) for s_, age in recent if age + step < 8]
-            if w:
-                recent.append((int(w.group(1)), 0))
-    return found
+        lines = [l for l in lines if l and not l.startswith('.set') and not l.startswith('#') and
+                 (not l.startswith('.') or l.endswith(':'))]
+        label_in = {}        # label -> state carried in by branches
+        for _ in range(4):
+            changed = False
+            recent, live = [], True          # (sgpr number, wait states since the write); live = reachable by fall-through
+            for l in lines:
+                if l.endswith(':'):
+                    lab = l[:-1]
+                    recent = _merge(recent if live else [], label_in.get(lab, []))
+                    live = True
+                    continue
+                op = l.split()[0]
+                w = re.match(r'v_read(?:first)?lane_b32\s+s(\d+)', l)
+                if op.startswith('global_load') or op.startswith('global_store'):
+                    sb = re.search(r's\[(\d+):(\d+)\]', l)
+                    if sb:
+                        lo, hi = int(sb.group(1)), int(sb.group(2))
+                        for s_, age in recent:
+                            if lo <= s_ <= hi and age < 5:
+                                found.add((name, l, s_, age))
+                nops = re.match(r's_nop\s+(\d+)', l)
+                step = int(nops.group(1)) + 1 if nops else 1
+                recent = [(s_, age + step) for s_, age in recent if age + step < 8]
+                if w:
+                    recent.append((int(w.group(1)), 0))
+                br = re.match(r's_c?branch\w*\s+(\S+)', l)
+                if br:
+                    lab = br.group(1)
+                    merged = _merge(label_in.get(lab, []), recent)
+                    if merged != label_in.get(lab, []):
+                        label_in[lab] = merged
+                        changed = True
+                    if op == 's_branch':
+                        live = False
+                elif op in ('s_endpgm', 's_setpc_b64'):
+                    live = False
+            if not changed:
+                break
+    return sorted(found)
 
 
 if __name__ == '__main__':

@@ -481,6 +481,8 @@ def main():
                     traffic_note = "profiles/qp_traffic.json was measured on other sources or another kernel: not reported"
             except Exception:
                 traffic_note = "profiles/qp_traffic.json unreadable"
+        alg_bytes_fact = (n * n + n * (n + 1) / 2.0) * 8.0
+        fact_per_launch = float((res["qp_iters_total"].astype(np.int64) + n_qp).sum()) / launches_batch
         value = job_fits * args.steps / elapsed
         nb = len(res["outer_iters"])
         outer_sum = float(res["outer_iters"].sum())
@@ -525,6 +527,20 @@ def main():
                          "note": None if config == "c3" else
                          "c4: launch times are HIP-event intervals on streams that share the GPU with the other plans in "
                          "flight, i.e. inflated by the overlap; the kernel's roofline figure is the c3 line's"},
+            # the same kernel against the other roof: SURVEY 8d's algorithmic bytes of a factorisation are the
+            # P read (n^2 doubles) and the factor write (n (n + 1) / 2 doubles); `traffic` is what the PMC counters saw
+            "roofline_hbm": {"bound": "hbm", "kernel": QP_KERNEL,
+                             "algorithmic_bytes_per_factorisation": alg_bytes_fact,
+                             "factorisations_per_launch": fact_per_launch,
+                             "algorithmic_bytes_per_launch": alg_bytes_fact * fact_per_launch,
+                             "achieved": alg_bytes_fact * fact_per_launch / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg_bytes_fact * fact_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+                             "traffic": traffic, "traffic_note": traffic_note,
+                             "traffic_over_algorithmic": None if traffic is None else traffic / (alg_bytes_fact * fact_per_launch),
+                             "traffic_bytes_per_factorisation": None if traffic is None else traffic / fact_per_launch,
+                             "traffic_GBps": None if traffic is None else traffic / avg_launch_s / 1e9,
+                             "traffic_frac_of_hbm_peak": None if traffic is None else traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+                             "avg_launch_ms": avg_launch_s * 1e3},
             "roofline_gram": {"bound": "mfma", "kernel": "gram_kernel", "ms_per_step": gram_s * 1e3,
                               "achieved": gram_flop / max(gram_s, 1e-12) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": gram_flop / max(gram_s, 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,

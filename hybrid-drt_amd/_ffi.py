@@ -92,7 +92,7 @@ SIGNATURES = {
     "hipdrt_qp_batch": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.POINTER(QpOpts), _dp, _ip, _dp, _ip],
     "hipdrt_qp_profile": [_vp, C.POINTER(C.c_ulonglong), C.c_int, C.c_int],
     "hipdrt_debug_qp_occupancy": [_vp, C.c_int, C.c_int],
-    "hipdrt_debug_qp_group": [C.c_int],
+    "hipdrt_debug_qp_group": [_vp, C.c_int],
     "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -363,8 +363,9 @@ class Context:
         return out
 
     def debug_qp_group(self, members):
-        """tests / diagnostics: force the workgroups per problem of the coneqp launches sized from now on (hipdrt_debug_qp_group)"""
-        _check(self._lib.hipdrt_debug_qp_group(int(members)))
+        """tests / diagnostics: force the workgroups per problem of this context's coneqp launches sized from now on
+        (hipdrt_debug_qp_group, include/hipdrt_debug.h)"""
+        _check(self._lib.hipdrt_debug_qp_group(self._h, int(members)))
 
     def qp_profile(self, reset=True):
         buf = (C.c_ulonglong * 64)()        # 0..47 the QP kernel's phases, 48..63 hyper_kernel's (PROFILE=1 builds)

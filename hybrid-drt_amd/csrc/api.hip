@@ -47,7 +47,7 @@ struct hipdrt_plan {
     // The kernel is chosen per fit from the number of spectra actually staged: a plan sized for a thousand spectra that is
     // handed one or a handful runs them on several workgroups each, inside the scratch it already has.
     void qp_layout(int B, QpArgs& qa) const {
-        int G = qp_group_size(B, n);
+        int G = qp_group_size(B, n, ctx ? ctx->qp_force_group : -1);
         const size_t have_l = L.bytes / sizeof(double), have_s = qpstate.bytes / sizeof(double);
         if (G >= 1 && G != qp_G) {
             const bool fits = gsync.p && (size_t)B * qp_scratch_doubles(n, G) <= have_l &&
@@ -454,7 +454,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     hipStream_t st = ctx->stream;
     DevBuf dP, dq, dh, dL, dx, dit, dpc, dst, dstate, dPpk, dgs;
     const int ldl = (int)qp_scratch_ld(n);
-    const int G = qp_group_size(B, n);           // 0: one workgroup per problem; >= 1: that many workgroups per problem
+    const int G = qp_group_size(B, n, ctx->qp_force_group);           // 0: one workgroup per problem; >= 1: that many workgroups per problem
     // device copy of P with an even leading dimension (16-byte row-pair loads in the kernels), pad column zeroed
     const int ldp = round_up(n, 2);
     const size_t nmat = (size_t)(p_batched ? B : 1);
@@ -495,8 +495,9 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     return HIPDRT_OK;
 }
 
-int hipdrt_debug_qp_group(int members) {
-    qp_debug_force_group(members);
+int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members) {
+    HIPDRT_REQUIRE(ctx, "NULL pointer");
+    ctx->qp_force_group = members;
     return HIPDRT_OK;
 }
 
@@ -597,7 +598,7 @@ static int plan_alloc_batch(hipdrt_plan* p) {
     for (DevBuf* ib : {&p->active, &p->outer_iters, &p->fit_status, &p->qp_iters_total, &p->qp_status, &p->qp_iters})
         HIPDRT_CHECK(ib->alloc(cap * sizeof(int)));
     HIPDRT_CHECK(p->n_active.alloc(sizeof(int)));
-    p->qp_G = qp_group_size(p->capacity, n);
+    p->qp_G = qp_group_size(p->capacity, n, p->ctx->qp_force_group);
     HIPDRT_REQUIRE(p->qp_G >= 0, "n too large for the QP kernels");
     HIPDRT_CHECK(p->L.alloc(cap * qp_scratch_doubles(n, p->qp_G) * sizeof(double)));
     HIPDRT_CHECK(p->Ptmp.alloc((size_t)n * p->ldp * sizeof(double)));

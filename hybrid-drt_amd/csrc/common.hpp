@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/hipdrt.h"
+#include "../../include/hipdrt_debug.h"
 
 namespace hipdrt {
 
@@ -70,6 +71,9 @@ struct hipdrt_ctx {
     // context lives on until its last plan is destroyed
     int plans = 0;
     bool released = false;
+    // hipdrt_debug_qp_group (include/hipdrt_debug.h; tests): workgroups per problem of this context's coneqp launches,
+    // -1 = the library chooses
+    int qp_force_group = -1;
 };
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ---------------------------------
@@ -234,8 +238,8 @@ struct QpArgs {
 int launch_qp(hipStream_t st, const QpArgs& a);
 // workgroups per problem for a launch of B problems of n unknowns: 0 = batch kernel (one workgroup per problem, n <= 2048),
 // >= 1 = group kernel with that many members (few problems, or n > 2048); -1 = n not supported
-int qp_group_size(int B, int n);
-void qp_debug_force_group(int members);
+// (`force`: the context's hipdrt_debug_qp_group setting, -1 = automatic)
+int qp_group_size(int B, int n, int force = -1);
 size_t qp_gsync_ints();
 // posterior variance on an evaluation grid (qp_resident.hpp: cov_kernel_resident); Bex = evaluation rows as packed tiles
 int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long ppk_stride, const double* Bex, int nex,

@@ -7,6 +7,7 @@
 // cvxopt's stopping test.  Everything FP64.  The interior-point driver is qp_common.hpp: ipm_solve; the linear
 // algebra (tile-packed left-looking Cholesky, triangular sweeps) is qp_resident.hpp, one kernel for every
 // n <= 2048: inverse diagonal blocks in LDS up to n = 528, in global memory beyond.  This file holds the launchers.
+#include <atomic>
 #include <mutex>
 #include <cstdlib>
 #include <cstdio>
@@ -42,14 +43,11 @@ int device_cus() {
 // not reach: such launches go to the group kernel.  Members per problem: one per two block rows (a member's fixed cost is
 // its redundant chain wavefront; the look-ahead tiles are accumulated by one member per block column), all members of a
 // problem on one XCD (32 CUs) with up to eight problems side by side.
-static int g_force_group = -1;           // hipdrt_debug_qp_group (tests)
-void qp_debug_force_group(int members) { g_force_group = members; }
-
-int qp_group_size(int B, int n) {
+int qp_group_size(int B, int n, int force) {
     if (n > GRP_NMAX) return -1;
-    if (g_force_group == 0 && n <= 2048) return 0;
-    if (g_force_group >= 1) {
-        int G = g_force_group;
+    if (force == 0 && n <= 2048) return 0;
+    if (force >= 1) {
+        int G = force;
         const int ntr = (n + 15) / 16, rounds = (B + 7) / 8;
         if (G > 32 / rounds) G = 32 / rounds;
         if (G > ntr / 2) G = ntr / 2;        // (at least one block row per member)
@@ -215,9 +213,11 @@ static int launch_qp_group(hipStream_t st, const QpArgs& a, int G) {
     return HIPDRT_OK;
 }
 
-// process-wide: set once a group launch has found its members spread over several XCDs (the placement the fence-free
-// hand-offs rely on does not hold on this device / driver): from then on every group runs with one member
-static bool g_group_spread = false;
+// per device: set once a group launch has found its members spread over several XCDs (the placement the fence-free
+// hand-offs rely on does not hold on this device / driver / partition mode): from then on every group on that device runs
+// with one member.  A launch whose members did not all become resident in time (another process's long kernel, a CU mask)
+// is repeated with one member as well, but that is not remembered: it says nothing about the next launch.
+static std::atomic<bool> g_group_spread[64];
 
 int launch_qp(hipStream_t st, const QpArgs& a) {
     if (a.n > GRP_NMAX) { set_error("qp: n > 4096 not supported"); return HIPDRT_E_INVALID; }
@@ -225,21 +225,40 @@ int launch_qp(hipStream_t st, const QpArgs& a) {
         if (a.n > 2048) { set_error("qp: n > 2048 needs the group kernel's buffers (QpArgs.G >= 1)"); return HIPDRT_E_INVALID; }
         return launch_qp_resident(st, a);
     }
-    const int G = g_group_spread ? 1 : a.G;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<bool>& spread_here = g_group_spread[dev & 63];
+    int G = spread_here.load(std::memory_order_relaxed) ? 1 : a.G;
+    if (G > 1) {
+        // co-residency is a precondition of the members' waits: never launch more workgroups than the device can hold at once
+        // by its own account (occupancy query x CUs); a launch that does not fit runs with fewer members per problem
+        const int NP = round_up(a.n, 32);
+        int per_cu = 0;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qp_kernel_group), hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds_bytes(NP));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_kernel_group, 512, group_lds_bytes(NP)) != hipSuccess || per_cu < 1) per_cu = 1;
+        const int rounds = (a.B + 7) / 8;
+        while (G > 1 && 8 * G * rounds > per_cu * device_cus()) --G;
+    }
     int rc = launch_qp_group(st, a, G);
     if (rc != HIPDRT_OK || G == 1) return rc;
-    // did every group find its members on one XCD?  (one short synchronisation per group launch: these are the launches of
-    // single fits, tens of microseconds against milliseconds of kernel)
+    // did every group find its members resident and on one XCD?  (one short synchronisation per group launch: these are the
+    // launches of single fits, tens of microseconds against milliseconds of kernel)
     std::vector<int> stt((size_t)a.B);
     hipError_t e = hipMemcpyAsync(stt.data(), a.status, (size_t)a.B * sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error(std::string("qp group status: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
-    bool spread = false;
-    for (int b = 0; b < a.B; ++b) spread = spread || stt[(size_t)b] == HIPDRT_QP_ABORTED;
-    if (!spread) return HIPDRT_OK;
-    g_group_spread = true;
+    bool aborted = false;
+    for (int b = 0; b < a.B; ++b) aborted = aborted || stt[(size_t)b] == HIPDRT_QP_ABORTED;
+    if (!aborted) return HIPDRT_OK;
+    // why: gsync word [4] of an aborted problem is 1 (spread over XCDs) or 2 (a member did not arrive in time)
+    std::vector<int> gs((size_t)a.B * GRP_WORDS);
+    e = hipMemcpyAsync(gs.data(), a.gsync, gs.size() * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error(std::string("qp group sync words: ") + hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    for (int b = 0; b < a.B; ++b)
+        if (stt[(size_t)b] == HIPDRT_QP_ABORTED && gs[(size_t)b * GRP_WORDS + 4] == 1) spread_here.store(true, std::memory_order_relaxed);
     QpArgs again = a;
-    again.redo_aborted = 1;                  // the spread groups once more, one member each (they had changed nothing)
+    again.redo_aborted = 1;                  // the aborted groups once more, one member each (they had changed nothing)
     return launch_qp_group(st, again, 1);
 }
 

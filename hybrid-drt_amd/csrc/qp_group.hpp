@@ -73,7 +73,8 @@ static constexpr int GRP_ROW_RING = HIPDRT_GRP_ROW_RING;  // slots of the rows' 
 static constexpr int GRP_RMAXT = 2;                    // tile rows per row wavefront and pass: a member has few rows, and a short
                                                        // pass leaves registers for an eight-slot operand ring (below)
 static constexpr int GRP_WORDS = 16 + GRP_OWN;         // ints of global sync state per problem
-// words: [0] members arrived at the start, [1] OR of (1 << XCC id), [2] barrier counter, [3] laprog: factorisation count * 256
+static constexpr int kNotResident = 1 << 30;           // poison bit in word [1]: a member gave up waiting for its partners
+// words: [0] members arrived at the start, [1] OR of (1 << XCC id) | kNotResident, [4] why a launch was aborted, [2] barrier counter, [3] laprog: factorisation count * 256
 // + block columns whose look-ahead accumulators are in labuf (written by the owner of the column's look-ahead rows),
 // [16 + T] rowprog: factorisation count * 256 + block columns of tile row T complete in memory (written by T's owner when T
 // becomes a look-ahead row: the member that accumulates the next look-ahead block reads T as an operand)
@@ -95,6 +96,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
     static constexpr bool kFusedForward = false;
     static constexpr int kRedSlots = 4;
     static constexpr int kSpinLimit = 1 << 24;
+    static constexpr int kRendezvousLimit = 1 << 22;       // polls of the start rendezvous (~0.5 s) before the launch gives up cleanly
     int G = 1, g = 0;                      // members of the group, this member
     int* gs = nullptr;                     // global sync words of the problem (GRP_WORDS)
     int fidx = 0, gepoch = 0;              // factorisations started, group barriers passed (identical in every member)
@@ -938,18 +940,28 @@ __global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int 
             const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;      // HW_REG_XCC_ID[3:0]
             __hip_atomic_fetch_or(&ops.gs[1], 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&ops.gs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // A member that does not see its partners in time poisons the mask instead of trapping: the members that did
+            // arrive -- and the late ones, whenever they get a CU: the counter still reaches G once every block has run --
+            // all read the poisoned mask and leave before they have touched anything but their own scratch.
             int spins = 0;
-            while (__hip_atomic_load(&ops.gs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+            while (__hip_atomic_load(&ops.gs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G &&
+                   !(__hip_atomic_load(&ops.gs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kNotResident)) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > OpsGroup::kSpinLimit) __builtin_trap();
+                if (++spins > OpsGroup::kRendezvousLimit) {
+                    __hip_atomic_fetch_or(&ops.gs[1], kNotResident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
             xcc_mask = __hip_atomic_load(&ops.gs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (__builtin_popcount(xcc_mask) != 1) {
-            // spread over several XCDs: the L2-coherence assumption does not hold -- every member leaves, the host repeats
-            // this problem on one workgroup
-            if (g == 0 && threadIdx.x == 0) a.status[b] = HIPDRT_QP_ABORTED;
+            // spread over several XCDs (the L2-coherence assumption does not hold) or not all resident: every member leaves,
+            // the host repeats this problem on one workgroup; word [4] says which (1 spread, 2 not resident)
+            if (g == 0 && threadIdx.x == 0) {
+                a.status[b] = HIPDRT_QP_ABORTED;
+                ops.gs[4] = (xcc_mask & kNotResident) ? 2 : 1;
+            }
             return;
         }
     }

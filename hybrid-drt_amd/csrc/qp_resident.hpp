@@ -60,6 +60,18 @@ static constexpr int RNW = RT / 64;      // 8 wavefronts
 #ifndef HIPDRT_QP_PREFETCH
 #define HIPDRT_QP_PREFETCH 1     // source tiles of block column jb + 1 requested before barrier (B) of column jb
 #endif
+#ifndef HIPDRT_QP_PREFETCH_CHAIN
+#define HIPDRT_QP_PREFETCH_CHAIN HIPDRT_QP_PREFETCH     // factor64: the same per role
+#endif
+#ifndef HIPDRT_QP_PREFETCH_LA
+#define HIPDRT_QP_PREFETCH_LA HIPDRT_QP_PREFETCH
+#endif
+#ifndef HIPDRT_QP_PREFETCH_ROWS
+#define HIPDRT_QP_PREFETCH_ROWS 0      // measured: 2326 -> 2193 fits/s with the row wavefronts' 12 source tiles each requested before
+#endif                                 // barrier (B), 8.63 -> 9.28 ms per launch (profiles/r04c_ab_prefetch_matrix.txt)
+#ifndef HIPDRT_QP_P_NT
+#define HIPDRT_QP_P_NT 0               // source tiles of P with non-temporal loads (read once per factorisation)
+#endif
 static constexpr int RMAXT = HIPDRT_QP_RMAXT;   // tile rows per wavefront and pass
 static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
@@ -339,8 +351,14 @@ struct OpsResidentT {
             const double2* tile = reinterpret_cast<const double2*>(Bex + ((size_t)(T - nch) * nchp + Cc) * 256);
             r_.d0 = tile[fo]; r_.d1 = tile[64 + fo];
         } else if (T < ntr) {
+#if HIPDRT_QP_P_NT
+            const v2d* tile = reinterpret_cast<const v2d*>(Ppk + ((size_t)T * nchp + Cc) * 256);
+            const v2d a_ = __builtin_nontemporal_load(tile + fo), b_ = __builtin_nontemporal_load(tile + 64 + fo);
+            r_.d0 = make_double2(a_.x, a_.y); r_.d1 = make_double2(b_.x, b_.y);
+#else
             const double2* tile = reinterpret_cast<const double2*>(Ppk + ((size_t)T * nchp + Cc) * 256);
             r_.d0 = tile[fo]; r_.d1 = tile[64 + fo];
+#endif
         }
         return r_;
     }
@@ -902,7 +920,10 @@ struct OpsResidentT {
     // Two barriers per 64 columns instead of six.  Every tile receives exactly the MFMA sequence it receives in factor()
     // (history chunks ascending, x then y half of every half-chunk, the same operand order), so the factor, U and the forward-
     // substituted right-hand side are bit for bit those of the 32-column form (tools/dump_fit.py --cmp).
-    static constexpr int RM = 3;                 // tile rows per row wavefront and pass (x 4 tile columns = 12 accumulator tiles)
+#ifndef HIPDRT_QP_RM
+#define HIPDRT_QP_RM 3
+#endif
+    static constexpr int RM = HIPDRT_QP_RM;      // tile rows per row wavefront and pass (x 4 tile columns = 12 accumulator tiles)
 #ifndef HIPDRT_QP_CHAINLOAD64
 #define HIPDRT_QP_CHAINLOAD64 500
 #endif
@@ -1040,6 +1061,8 @@ struct OpsResidentT {
         double* U = sm.U;
         v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
         v4d* const img22 = img21 + 64;
+        TileSrc pre[7];                          // source tiles of the next look-ahead rows, requested before barrier (B)
+        bool have_pre = false;
         for (int J = 0; J < nsup; ++J) {
             const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J;
             const bool hasb = (2 * J + 1) < nblk;
@@ -1069,10 +1092,18 @@ struct OpsResidentT {
             }
             if (hasb) {
                 // ---- look-ahead of block b: rows R2, R3 in columns a, diagonal block b ------------------------------
-                v4d p20 = init_tile(R2, tA, ntr, fo, li, kq),     p21 = init_tile(R2, tA + 1, ntr, fo, li, kq);
-                v4d p30 = init_tile(R3, tA, ntr, fo, li, kq),     p31 = init_tile(R3, tA + 1, ntr, fo, li, kq);
-                v4d e11 = init_tile(R2, R2, ntr, fo, li, kq),     e21 = init_tile(R3, R2, ntr, fo, li, kq);
-                v4d e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                v4d p20, p21, p30, p31, e11, e21, e22;
+                if (have_pre) {
+                    p20 = tile_image(pre[0], R2, tA, li, kq);      p21 = tile_image(pre[1], R2, tA + 1, li, kq);
+                    p30 = tile_image(pre[2], R3, tA, li, kq);      p31 = tile_image(pre[3], R3, tA + 1, li, kq);
+                    e11 = tile_image(pre[4], R2, R2, li, kq);      e21 = tile_image(pre[5], R3, R2, li, kq);
+                    e22 = tile_image(pre[6], R3, R3, li, kq);
+                } else {
+                    p20 = init_tile(R2, tA, ntr, fo, li, kq);      p21 = init_tile(R2, tA + 1, ntr, fo, li, kq);
+                    p30 = init_tile(R3, tA, ntr, fo, li, kq);      p31 = init_tile(R3, tA + 1, ntr, fo, li, kq);
+                    e11 = init_tile(R2, R2, ntr, fo, li, kq);      e21 = init_tile(R3, R2, ntr, fo, li, kq);
+                    e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                }
                 if (J > 0) {
                     const char* q0 = uniform_ptr(tile2(tA, 0));
                     const char* q1 = uniform_ptr(tile2(tA + 1, 0));
@@ -1178,6 +1209,21 @@ struct OpsResidentT {
             __syncthreads();                                    // (A)
             PROF2(1, 16 + (J < 23 ? J : 23));
             if (sm.flag[0]) return false;
+            have_pre = false;
+#if HIPDRT_QP_PREFETCH_CHAIN
+            // source tiles of the next super column's look-ahead rows: in flight through the others' panel solves and chain a'
+            {
+                // (requested unconditionally, from a stand-in tile when there is no next block b: a conditional definition would
+                // keep the previous super column's tiles alive -- through the operand ring -- on the path that skips it)
+                have_pre = 2 * J + 3 < nblk;
+                const int N2 = have_pre ? tA + 6 : 0, N3 = have_pre ? tA + 7 : 0, cA = have_pre ? tA + 4 : 0;
+                const int D2 = have_pre ? N2 : 0;
+                pre[0] = tile_src(N2, cA, ntr, fo); pre[1] = tile_src(N2, have_pre ? cA + 1 : 0, ntr, fo);
+                pre[2] = tile_src(N3, cA, ntr, fo); pre[3] = tile_src(N3, have_pre ? cA + 1 : 0, ntr, fo);
+                pre[4] = tile_src(N2, D2, ntr, fo); pre[5] = tile_src(N3, D2, ntr, fo);
+                pre[6] = tile_src(N3, have_pre ? N3 : 0, ntr, fo);
+            }
+#endif
             __syncthreads();                                    // (B)
             PROF(4);
         }
@@ -1192,22 +1238,37 @@ struct OpsResidentT {
         const int ntr = (n + 15) >> 4;
         v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
         v4d* const img22 = img21 + 64;
+        TileSrc pre[11];                         // source tiles of the next super column, requested before barrier (B)
+        bool have_pre = false;
         for (int J = 0; J < nsup; ++J) {
             const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
             const int Q2 = tA + 4, Q3 = tA + 5;
             const bool v2 = Q2 < ntr, v3 = Q3 < ntr;
             if (v2) {
                 v4d ca[2][2], cb[2][2], f11, f21, f22;
+                if (have_pre) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                    for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        ca[r][c] = init_tile(Q2 + r, tA + c, ntr, fo, li, kq);
-                        cb[r][c] = init_tile(Q2 + r, tB + c, ntr, fo, li, kq);
-                    }
-                f11 = init_tile(Q2, Q2, ntr, fo, li, kq);
-                f21 = init_tile(Q3, Q2, ntr, fo, li, kq);
-                f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
+                        for (int c = 0; c < 2; ++c) {
+                            ca[r][c] = tile_image(pre[4 * r + c], Q2 + r, tA + c, li, kq);
+                            cb[r][c] = tile_image(pre[4 * r + 2 + c], Q2 + r, tB + c, li, kq);
+                        }
+                    f11 = tile_image(pre[8], Q2, Q2, li, kq);
+                    f21 = tile_image(pre[9], Q3, Q2, li, kq);
+                    f22 = tile_image(pre[10], Q3, Q3, li, kq);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            ca[r][c] = init_tile(Q2 + r, tA + c, ntr, fo, li, kq);
+                            cb[r][c] = init_tile(Q2 + r, tB + c, ntr, fo, li, kq);
+                        }
+                    f11 = init_tile(Q2, Q2, ntr, fo, li, kq);
+                    f21 = init_tile(Q3, Q2, ntr, fo, li, kq);
+                    f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
+                }
                 if (J > 0) {
                     const char* qb[4];
 #pragma unroll
@@ -1261,6 +1322,7 @@ struct OpsResidentT {
                 }
                 __syncthreads();                                // (A)
                 if (sm.flag[0]) return false;
+                have_pre = false;
                 BFrag bf;
                 load_bfrag(bf, tA, true, fo);                   // (rows tA+2, tA+3 are valid whenever Q2 is)
                 v4d xa[2][2], xb[2][2];
@@ -1334,6 +1396,17 @@ struct OpsResidentT {
                 img22[lane] = f22;
                 fwd_update(xb[0][0], xb[0][1], Q2, j0b, li, kq);
                 if (v3) fwd_update(xb[1][0], xb[1][1], Q3, j0b, li, kq);
+#if HIPDRT_QP_PREFETCH_LA
+                {
+                    // (unconditional, stand-in tile (0, 0) when there are no such rows: see wavefront 0)
+                    have_pre = Q2 + 4 < ntr;
+                    const int N2 = have_pre ? Q2 + 4 : 0, N3 = have_pre ? Q2 + 5 : 0, cA = have_pre ? tA + 4 : 0, st = have_pre ? 1 : 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { pre[c] = tile_src(N2, cA + st * c, ntr, fo); pre[4 + c] = tile_src(N3, cA + st * c, ntr, fo); }
+                    pre[8] = tile_src(N2, N2, ntr, fo); pre[9] = tile_src(N3, N2, ntr, fo);
+                    pre[10] = tile_src(N3, N3, ntr, fo);
+                }
+#endif
             } else {
                 __syncthreads();                                // (A)
                 if (sm.flag[0]) return false;
@@ -1350,18 +1423,28 @@ struct OpsResidentT {
         const int nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
         const int ntr = (n + 15) >> 4;
         constexpr int SROW = Smem::SROW;
+        TileSrc pre[RM][4];                      // source tiles of pass 0 of the next super column, requested before barrier (B)
+        bool have_pre = false;
+        // this wavefront's rows of super column J_: bit r of (m0, m1) = tile row 4 J_ + 6 + r
+        auto my_rows = [&](int J_, unsigned long long& m0, unsigned long long& m1) {
+            const int nsq_ = ntr - (4 * J_ + 6) > 0 ? ntr - (4 * J_ + 6) : 0;
+            const unsigned char* row = sm.sched + J_ * SROW;
+            m0 = __ballot(lane < nsq_ && row[lane] == wv);
+            m1 = 0;
+            if (SROW > 64) m1 = __ballot(lane + 64 < nsq_ && row[lane + 64] == wv);
+        };
         for (int J = 0; J < nsup; ++J) {
             const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
-            const int nsq = ntr - (tA + 6) > 0 ? ntr - (tA + 6) : 0;
-            const unsigned char* row = sm.sched + J * SROW;
-            unsigned long long m0 = __ballot(lane < nsq && row[lane] == wv), m1 = 0;
-            if (SROW > 64) m1 = __ballot(lane + 64 < nsq && row[lane + 64] == wv);
+            unsigned long long m0, m1;
+            my_rows(J, m0, m1);
             const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);
             const int npass = mine > RM ? (mine + RM - 1) / RM : 1;
-#pragma unroll 1
-            for (int ps = 0; ps < npass; ++ps) {
-                int T[RM];
-                bool act[RM];
+            // rows and accumulators of pass 0 in front of the pass loop: the prefetched source tiles die here, not somewhere
+            // inside the loop (left in the loop they count as live through the operand ring: 96 registers)
+            int T[RM];
+            bool act[RM];
+            v4d acc[RM][4];
+            auto next_rows = [&]() {
 #pragma unroll
                 for (int u = 0; u < RM; ++u) {
                     int r = -1;
@@ -1370,12 +1453,32 @@ struct OpsResidentT {
                     T[u] = r >= 0 ? tA + 6 + r : nch;
                     act[u] = r >= 0;
                 }
-                v4d acc[RM][4];
+            };
+            next_rows();
+            if (have_pre) {
+#pragma unroll
+                for (int u = 0; u < RM; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[u][c] = act[u] ? tile_image(pre[u][c], T[u], tA + c, li, kq) : (v4d){0, 0, 0, 0};
+            } else {
 #pragma unroll
                 for (int u = 0; u < RM; ++u)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         acc[u][c] = act[u] ? init_tile(T[u], tA + c, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+            }
+            have_pre = false;
+#pragma unroll 1
+            for (int ps = 0; ps < npass; ++ps) {
+                if (ps > 0) {
+                    next_rows();
+#pragma unroll
+                    for (int u = 0; u < RM; ++u)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[u][c] = act[u] ? init_tile(T[u], tA + c, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                }
                 if (J > 0 && act[0]) {
                     // operand ring as in factor_rows(): A tiles (own rows, HBM) three half-chunks ahead, B tiles (tile rows
                     // tA .. tA+3, shared by all wavefronts: L1 / L2) one ahead; per step 4 B + RM A loads, B first
@@ -1494,6 +1597,24 @@ struct OpsResidentT {
                         if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0b, li, kq);
                 }
             }
+#if HIPDRT_QP_PREFETCH_ROWS
+            {
+                // the source tiles of the next super column's first pass: in flight while the stores above drain
+                unsigned long long n0 = 0, n1 = 0;
+                if (J + 1 < nsup) my_rows(J + 1, n0, n1);
+                have_pre = (n0 | n1) != 0;
+#pragma unroll
+                for (int u = 0; u < RM; ++u) {
+                    int r = -1;
+                    if (n0) { r = __builtin_ctzll(n0); n0 &= n0 - 1; }
+                    else if (n1) { r = 64 + __builtin_ctzll(n1); n1 &= n1 - 1; }
+                    // (unconditional, stand-in tile (0, 0) for a row that does not exist: see wavefront 0)
+                    const int Tn = r >= 0 ? tA + 10 + r : 0, cn = r >= 0 ? tA + 4 : 0, st = r >= 0 ? 1 : 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pre[u][c] = tile_src(Tn, cn + st * c, ntr, fo);
+                }
+            }
+#endif
             __syncthreads();                                        // (B)
         }
         return true;

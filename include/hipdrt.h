@@ -150,17 +150,8 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
                     int h_batched, const double* h, const hipdrt_qp_opts* opts,
                     double* x, int* iters, double* pcost, int* status);
 
-/* diagnostic: in-kernel phase cycle counters of qp_kernel (workgroup 0 only), non-zero only in a build with
- * -DHIPDRT_QP_PROFILE (make PROFILE=1); slots documented in csrc/qp.hip.  Never used in timed runs.        */
-int hipdrt_qp_profile(hipdrt_ctx* ctx, unsigned long long* cycles, int n, int reset);
-/* diagnostic: workgroups per CU the runtime reports for the coneqp kernel of n unknowns (threads = 512)          */
-int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n);
-/* diagnostic (tests): workgroups per problem of the coneqp launches sized from now on -- members >= 1 forces the group kernel
- * with (at most) that many members for every problem size, 0 forces the one-workgroup batch kernel (n <= 2048), -1 gives the
- * choice back to the library (few problems of n > 528, or n > 2048 -> group kernel).  The group kernel's results do not
- * depend on the group size (bit for bit); batch and group kernel differ by rounding (the batch kernel fuses the forward
- * substitution into the factorisation: another summation order), same iteration counts.                                */
-int hipdrt_debug_qp_group(int members);
+/* (diagnostic entry points -- kernel phase counters, occupancy, forcing a kernel choice -- are declared in hipdrt_debug.h:
+ * they are not part of the drop-in boundary and nothing in the host layer's product path calls them)                          */
 
 /* P = (W A)'(W A) + L2, q = -(W A)'(W b) + l1 of qphb.solve_convex_opt (qphb.py:465-466) for B weight
  * vectors over one shared A[m][n]:  w[B][m], b[B][m], l2[B or 1][n][n], l1[n] -> P[B][n][n], q[B][n]   */

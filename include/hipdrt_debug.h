@@ -1,0 +1,34 @@
+/* hipdrt_debug.h -- diagnostic and test hooks of libhipdrt.so.
+ *
+ * NOT part of the drop-in boundary (include/hipdrt.h): nothing here replaces a reference interface, and the Python host
+ * layer's product path never calls these.  They exist for tests/ (kernel-choice independence of the results) and tools/
+ * (in-kernel phase counters of a PROFILE build, occupancy queries).  Every hook takes a context: there is no process-wide
+ * switch.
+ */
+#ifndef HIPDRT_DEBUG_H
+#define HIPDRT_DEBUG_H
+
+#include "hipdrt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* diagnostic: in-kernel phase cycle counters of qp_kernel (workgroup 0 only), non-zero only in a build with
+ * -DHIPDRT_QP_PROFILE (make PROFILE=1); slots documented in csrc/qp.hip.  Never used in timed runs.        */
+int hipdrt_qp_profile(hipdrt_ctx* ctx, unsigned long long* cycles, int n, int reset);
+/* diagnostic: workgroups per CU the runtime reports for the coneqp kernel of n unknowns (threads = 512)          */
+int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n);
+/* diagnostic (tests): workgroups per problem of THIS CONTEXT's coneqp launches sized from now on (plans created on it,
+ * hipdrt_qp_batch calls through it; other contexts are not affected) -- members >= 1 forces the group kernel
+ * with (at most) that many members for every problem size, 0 forces the one-workgroup batch kernel (n <= 2048), -1 gives the
+ * choice back to the library (few problems of n > 528, or n > 2048 -> group kernel).  The group kernel's results do not
+ * depend on the group size (bit for bit); batch and group kernel differ by rounding (the batch kernel fuses the forward
+ * substitution into the factorisation: another summation order), same iteration counts.                                */
+int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HIPDRT_DEBUG_H */

@@ -8,8 +8,8 @@ import pytest
 from conftest import ROOT
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "hipdrt.h")).read()
+def header_functions(name="hipdrt.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return set(re.findall(r"\b(hipdrt_[a-z0-9_]+)\s*\(", txt))
 
@@ -25,10 +25,22 @@ def lib():
 
 def test_header_and_binding_agree(lib):
     from hipdrt import _ffi
-    declared = header_functions()
+    declared = header_functions() | header_functions("hipdrt_debug.h")
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_release_header_has_no_diagnostic_hooks():
+    """the drop-in boundary (include/hipdrt.h) declares operators only; test / profiling hooks live in hipdrt_debug.h and all
+    of them take a context (no process-wide switch)"""
+    release = header_functions()
+    assert not [f for f in release if "debug" in f or "profile" in f], release
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hipdrt_debug.h")).read(), flags=re.S)
+    hooks = re.findall(r"\bint\s+(hipdrt_[a-z0-9_]+)\s*\(([^)]*)\)", txt)
+    assert len(hooks) >= 3
+    for name, argl in hooks:
+        assert argl.strip().startswith("hipdrt_ctx* ctx"), (name, argl)
 
 
 def test_struct_layout_matches_defaults(lib):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, parity_close
 
 pytestmark = pytest.mark.gpu
 
@@ -29,19 +29,18 @@ def mixed_map_observations(n_obs=16):
 
 def _check_against_reference(g, obs_x, obs_special, res, drt_var):
     peak = np.abs(g["obs_x"]).max(axis=1, keepdims=True)
-    np.testing.assert_allclose(obs_x / peak, g["obs_x"] / peak, rtol=0, atol=2e-6)
+    parity_close("mixed_map.obs_x", obs_x / peak, g["obs_x"] / peak, 2e-6, scale=1.0)
     assert [tuple(t) for t in res["obs_tau_indices"]] == [tuple(t) for t in g["obs_tau_indices"].tolist()]
     assert set(obs_special) == set(str(k) for k in g["special_names"])
     for key in obs_special:
         ref = g["special_" + key].reshape(len(obs_x), -1)[:, 0]
-        np.testing.assert_allclose(np.asarray(obs_special[key]).reshape(len(obs_x), -1)[:, 0], ref, rtol=2e-5,
-                                   atol=2e-6 * max(np.abs(ref).max(), 1e-300), err_msg=key)
+        parity_close("mixed_map.special_" + key, np.asarray(obs_special[key]).reshape(len(obs_x), -1)[:, 0], ref, 2e-5)
     # DRTMD's default metrics: weights='uniform', normalize=True (drtmd.py:121-134)
-    np.testing.assert_allclose(res["obs_llh"], g["obs_llh"], rtol=1e-5)
-    np.testing.assert_allclose(res["obs_rss"], g["obs_rss"], rtol=1e-4)
+    parity_close("mixed_map.obs_llh", res["obs_llh"] / g["obs_llh"], np.ones(len(obs_x)), 1e-5, scale=1.0)
+    parity_close("mixed_map.obs_rss", res["obs_rss"] / g["obs_rss"], np.ones(len(obs_x)), 1e-4, scale=1.0)
     if drt_var:
         vmax = g["obs_drt_var"].max(axis=1, keepdims=True)
-        np.testing.assert_allclose(res["obs_drt_var"] / vmax, g["obs_drt_var"] / vmax, rtol=0, atol=1e-4)
+        parity_close("mixed_map.obs_drt_var", res["obs_drt_var"] / vmax, g["obs_drt_var"] / vmax, 1e-4, scale=1.0)
 
 
 def test_mixed_map_matches_the_reference_drtmd():

@@ -27,3 +27,9 @@ if prof[13]:
 chain = prof[12] + prof[14] + prof[15]
 print("diagonal chain", round(chain / tot, 3), "(cholinv1", prof[12], "l21+d2", prof[14], "cholinv2", prof[15], ")",
       "=> rank-k phase", round((chain + prof[1]) / tot, 3))
+# factor64 (round 4): wavefront 0's timeline per super column
+f = lambda i: round(prof[i] / tot, 3)
+print("factor64, wavefront 0: chain a", f(12) + f(14) + f(15), "| look-ahead history (rows tA+2, tA+3)", f(40), "| its solve + diagonal update", f(41),
+      "| chain b", f(42), "| wait at (A)", f(1), "| (A) -> (B): everybody's panel solves", f(4))
+nf = max(prof[11], 1)
+print("wait at (A) by super column, ticks per factorisation:", [int(v / nf) for v in prof[16:40] if v])

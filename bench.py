@@ -353,6 +353,8 @@ def main():
     if config == "c3":
         drts = [DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local)) for _ in range(nfl)]
         plans = [d.stage_batch(freq, z[c]) for d, c in zip(drts, chunks)]     # lookups + matrices built, spectra resident
+        for p_ in plans:
+            p_.set_subbatches(1)          # the legs below choose: several plans of ONE launch sequence each, or one plan that cuts its batch itself
     else:
         # c4 goes through the product's own driver (mapping.fit_observations_sharded: shard -> `nfl` batches side by side
         # on sibling plans -> one gather); this first call builds the sibling plans
@@ -437,7 +439,7 @@ def main():
         return hd.max_over_ranks(time.perf_counter() - t0), gathered
 
     reset = lambda: [s_.update(qp_ms=0.0, qp_launch=0, phase={"gram": 0.0, "qp": 0.0, "hyper": 0.0}) for s_ in stats]  # noqa: E731
-    single_elapsed = transfer_elapsed = None
+    single_elapsed = transfer_elapsed = one_caller_elapsed = None
     if config == "c3":
         elapsed = timed_c3(nfl, worker_resident)
         reset()
@@ -446,6 +448,9 @@ def main():
         single_elapsed = timed_c3(1, worker_resident)               # one batch in flight: un-overlapped launches
         qp_ms, qp_launch = stats[0]["qp_ms"], stats[0]["qp_launch"]
         phase = dict(stats[0]["phase"])
+        plans[0].set_subbatches(0)                                  # one caller, one plan, the library cuts the batch into ranges
+        one_caller_elapsed = timed_c3(1, worker_resident)
+        plans[0].set_subbatches(1)
         steps_in_stats = args.steps
         res = drt.collect_staged()
     else:
@@ -556,6 +561,10 @@ def main():
             "single_stream": None if single_elapsed is None else {
                 "value": world * B * args.steps / single_elapsed, "ms_per_step": single_elapsed / args.steps * 1e3,
                 "note": "same K steps with one batch in flight; roofline / phase timings are taken from this run"},
+            "single_caller": None if one_caller_elapsed is None else {
+                "value": world * B * args.steps / one_caller_elapsed, "ms_per_step": one_caller_elapsed / args.steps * 1e3,
+                "note": "same K steps from ONE caller thread on ONE plan (one plan's memory): hipdrt_plan_fit cuts the staged batch "
+                        "into ranges that run side by side on the plan's own streams (hipdrt_plan_set_subbatches, automatic)"},
             "with_transfers": None if transfer_elapsed is None else {
                 "value": world * B * args.steps / transfer_elapsed, "ms_per_step": transfer_elapsed / args.steps * 1e3,
                 "note": "same K steps with the upload of the spectra and the download of all results inside every step"},

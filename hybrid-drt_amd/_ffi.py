@@ -108,6 +108,7 @@ SIGNATURES = {
     "hipdrt_plan_set_lookup": [_vp, _dp, _dp],
     "hipdrt_plan_upload": [_vp, C.c_int, _dp, _dp],
     "hipdrt_plan_fit": [_vp],
+    "hipdrt_plan_set_subbatches": [_vp, C.c_int],
     "hipdrt_plan_download": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip],
     "hipdrt_plan_get_p_matrix": [_vp, C.c_int, _dp],
     "hipdrt_plan_distribution_var": [_vp, _dp, C.c_int, _dp, _ip],
@@ -411,6 +412,8 @@ class Plan:
                                             _p(wt_im), _p(lre), _p(lim), C.byref(self.opts), int(capacity),
                                             C.byref(h)))
         self._h = h
+        if os.environ.get("HIPDRT_SUBBATCHES"):           # tools / A-B runs
+            self.set_subbatches(int(os.environ["HIPDRT_SUBBATCHES"]))
         n, m, ns = C.c_int(), C.c_int(), C.c_int()
         _check(self._lib.hipdrt_plan_dims(self._h, C.byref(n), C.byref(m), C.byref(ns)))
         self.n, self.m, self.ns = n.value, m.value, ns.value
@@ -456,6 +459,11 @@ class Plan:
 
     def fit(self):
         _check(self._lib.hipdrt_plan_fit(self._h))
+
+    def set_subbatches(self, k):
+        """ranges the staged batch is fitted in, side by side inside one fit() call (hipdrt_plan_set_subbatches): 0 = the
+        library chooses from the batch size (default; env HIPDRT_SUBBATCHES overrides at plan creation), 1 = one launch sequence"""
+        _check(self._lib.hipdrt_plan_set_subbatches(self._h, int(k)))
 
     def llh_terms(self, stored=False, weights=None):
         """(rss, sum(log w)) per spectrum; stored=False: weights re-estimated from the current x (PFRT steps),

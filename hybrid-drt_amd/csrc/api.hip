@@ -1,11 +1,14 @@
 // C-ABI of libhipdrt.so (include/hipdrt.h): context, stand-alone operators, and the plan that runs
 // DRT._qphb_fit_core (hybdrt/models/drt1d.py:102-1104, EIS branch) for a batch of spectra on the device.
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
 #include <mutex>
 
 #include "common.hpp"
+#include <thread>
 #include <vector>
 
 namespace hipdrt {
@@ -64,6 +67,13 @@ struct hipdrt_plan {
     // timings of the last fit
     float t_ms[5] = {0, 0, 0, 0, 0};
     int launches[5] = {0, 0, 0, 0, 0};
+    // sub-batches of one fit (hipdrt_plan_set_subbatches): the staged spectra split into `k` contiguous ranges, every range
+    // fitted by the same device loop on its own stream, all inside ONE hipdrt_plan_fit call and the plan's own buffers
+    int subbatches = 0;                                   // 0 = automatic (subbatch_count), >= 1 fixed
+    std::vector<std::unique_ptr<struct hipdrt_subfit>> subs;
+    DevBuf n_active_sub;                                  // one "still active" counter per sub-batch
+    hipdrt_plan() = default;
+    ~hipdrt_plan();
 
     FitState state() const {
         FitState st{};
@@ -89,6 +99,16 @@ struct hipdrt_plan {
         return st;
     }
 };
+
+// one sub-batch of a plan: a plan object whose buffers are windows into the parent's, with a stream of its own
+struct hipdrt_subfit {
+    hipdrt_ctx ctx;
+    hipdrt_plan view;
+    int rc = 0;
+    std::string err;
+    ~hipdrt_subfit() { if (ctx.stream) (void)hipStreamDestroy(ctx.stream); }
+};
+hipdrt_plan::~hipdrt_plan() = default;
 
 static int upload(DevBuf& buf, const void* src, size_t bytes, hipStream_t st) {
     HIPDRT_CHECK(buf.alloc(bytes));
@@ -916,7 +936,8 @@ struct PhaseTimer {
 };
 }  // namespace
 
-int hipdrt_plan_fit(hipdrt_plan* p) {
+// the whole fit of the plan's staged spectra on the plan's stream (hipdrt_plan_fit; also run per sub-batch view)
+static int plan_fit_one(hipdrt_plan* p) {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no spectra staged (call hipdrt_plan_upload)");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
@@ -1070,6 +1091,105 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     tm.mark(-1);
     HIPDRT_CHECK(hipStreamSynchronize(st));
     tm.collect(p->t_ms, p->launches);
+    return HIPDRT_OK;
+}
+
+// ---- sub-batches ---------------------------------------------------------------------------------------------------------
+// Spectra finish after 4 ... 50 outer iterations, so the tail of ONE batch's launch sequence leaves most CUs idle, and between
+// two kernels of a sequence the device waits for the host's "anyone still active?" read-back.  Several sequences side by side
+// fill both gaps.  bench.py / mapping.fit_observations(inflight=k) do that with k plans (k x the memory, k host threads of the
+// caller); here the SAME effect comes from inside one plan: its staged batch is cut into contiguous ranges, every range is
+// fitted by plan_fit_one on a view whose buffers are windows into the plan's own (nothing is allocated per range but a
+// stream and a 4-byte counter), each on its own stream and worker thread, and the call returns when all are done.  Every
+// kernel of the loop works per spectrum (reductions included), so a spectrum's result does not depend on which range it is in:
+// bit-identical to the un-split fit as long as both use the same coneqp kernel (ranges of more than #CUs / 16 spectra).
+static int subbatch_count(const hipdrt_plan* p) {
+    if (p->prepared || p->hist_b >= 0 || p->has_weight_factors() || p->opts.outlier_p > 0.0 || p->qp_G != 0 || p->premv.p) return 1;
+    if (p->subbatches >= 1) return std::min(p->subbatches, std::max(1, p->B / 64));
+    // measured on one MI355X (profiles/r04_subbatch_sweep.txt): ranges below ~300 spectra lose to launch-wave quantisation
+    // (fits/s with k = 1 / 2 / 3 / 4 ranges: 1024 spectra 1699 / 1885 / 1891 / 1485, 1250: 1781 / 1974 / 1979 / 1608, 2500: 1987 / 2121 / 2149 / 1876)
+    return p->B >= 1200 ? 3 : (p->B >= 600 ? 2 : 1);
+}
+
+static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb) {
+    hipdrt_plan& v = sf.view;
+    if (!sf.ctx.stream) {
+        sf.ctx.device = p->ctx->device; sf.ctx.num_cu = p->ctx->num_cu; sf.ctx.hbm_bytes = p->ctx->hbm_bytes; sf.ctx.arch = p->ctx->arch;
+        HIPDRT_CHECK(hipStreamCreateWithFlags(&sf.ctx.stream, hipStreamNonBlocking));
+    }
+    sf.ctx.qp_force_group = p->ctx->qp_force_group;
+    v.ctx = &sf.ctx;
+    v.nf = p->nf; v.ntau = p->ntau; v.n = p->n; v.m = p->m; v.ns = p->ns; v.ngrid = p->ngrid; v.ny = p->ny; v.mode = p->mode;
+    v.toeplitz_a = p->toeplitz_a; v.toeplitz_m = p->toeplitz_m; v.idx_rinf = p->idx_rinf; v.idx_induc = p->idx_induc;
+    v.ldrm = p->ldrm; v.ldm = p->ldm; v.ldp = p->ldp; v.ldl = p->ldl; v.eps = p->eps; v.opts = p->opts;
+    v.capacity = nb; v.B = nb; v.qp_G = p->qp_G; v.subbatches = 1;
+    // shared, read-only in the loop
+    auto whole = [](DevBuf& d, const DevBuf& s_) { d.alias(s_, 0, s_.bytes); };
+    whole(v.freq, p->freq); whole(v.tau, p->tau); whole(v.ln_tau, p->ln_tau); whole(v.wt_re, p->wt_re); whole(v.wt_im, p->wt_im);
+    whole(v.lut6, p->lut6); whole(v.a_re, p->a_re); whole(v.a_im, p->a_im); whole(v.cr, p->cr); whole(v.rm, p->rm);
+    for (int k = 0; k < 3; ++k) whole(v.mk[k], p->mk[k]);
+    whole(v.vmm, p->vmm); whole(v.h, p->h); whole(v.l1, p->l1); whole(v.h_init, p->h_init); whole(v.vmm_base, p->vmm_base);
+    whole(v.Ptmp, p->Ptmp);
+    // per spectrum: `per` bytes each
+    auto rows = [&](DevBuf& d, const DevBuf& s_, size_t per) { d.alias(s_, (size_t)b0 * per, (size_t)nb * per); };
+    const size_t D = sizeof(double), I = sizeof(int), nn = (size_t)p->n, mm = (size_t)p->m;
+    rows(v.z_re, p->z_re, p->nf * D); rows(v.z_im, p->z_im, p->nf * D);
+    rows(v.rv, p->rv, mm * D); rows(v.w, p->w, mm * D); rows(v.est_w, p->est_w, mm * D);
+    rows(v.x, p->x, nn * D); rows(v.x_in, p->x_in, nn * D); rows(v.q, p->q, nn * D); rows(v.s, p->s, 3 * nn * D);
+    rows(v.rho, p->rho, 3 * D); rows(v.xmx, p->xmx, 3 * D); rows(v.coef_scale, p->coef_scale, D); rows(v.var_floor, p->var_floor, D);
+    rows(v.pcost, p->pcost, D);
+    rows(v.active, p->active, I); rows(v.outer_iters, p->outer_iters, I); rows(v.fit_status, p->fit_status, I);
+    rows(v.qp_iters_total, p->qp_iters_total, I); rows(v.qp_status, p->qp_status, I); rows(v.qp_iters, p->qp_iters, I);
+    rows(v.order, p->order, I);
+    rows(v.L, p->L, qp_scratch_doubles(p->n, p->qp_G) * D);
+    rows(v.qpstate, p->qpstate, (size_t)(p->qp_G > 1 ? p->qp_G : 1) * qp_state_doubles(p->n) * D);
+    rows(v.gsync, p->gsync, qp_gsync_ints() * I);
+    rows(v.Ppk, p->Ppk, qp_ppk_doubles(p->n) * D);
+    v.n_active.alias(p->n_active_sub, (size_t)idx * I, I);
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_set_subbatches(hipdrt_plan* p, int k) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_REQUIRE(k >= 0 && k <= 16, "0 (automatic) <= k <= 16");
+    p->subbatches = k;
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_fit(hipdrt_plan* p) {
+    HIPDRT_REQUIRE(p, "plan is NULL");
+    HIPDRT_REQUIRE(p->B >= 1, "no spectra staged (call hipdrt_plan_upload)");
+    const int k = subbatch_count(p);
+    if (k <= 1) return plan_fit_one(p);
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
+    HIPDRT_CHECK(hipStreamSynchronize(p->ctx->stream));       // whatever staged the batch is done
+    if (p->n_active_sub.bytes < (size_t)k * sizeof(int)) HIPDRT_CHECK(p->n_active_sub.alloc(16 * sizeof(int)));
+    while ((int)p->subs.size() < k) p->subs.emplace_back(new hipdrt_subfit());
+    const int B = p->B;
+    for (int i = 0; i < k; ++i) {
+        const int b0 = (int)((long long)B * i / k), b1 = (int)((long long)B * (i + 1) / k);
+        TRY(make_view(p, *p->subs[i], i, b0, b1 - b0));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (int i = 0; i < k; ++i) {
+        hipdrt_subfit* sf = p->subs[i].get();
+        workers.emplace_back([sf] {
+            sf->rc = plan_fit_one(&sf->view);
+            if (sf->rc) sf->err = hipdrt_last_error();
+        });
+    }
+    for (auto& w : workers) w.join();
+    const float wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int i = 0; i < 5; ++i) { p->t_ms[i] = 0; p->launches[i] = 0; }
+    for (int i = 0; i < k; ++i) {
+        hipdrt_subfit* sf = p->subs[i].get();
+        if (sf->rc) { set_error("sub-batch " + std::to_string(i) + ": " + sf->err); return sf->rc; }
+        // phase times are HIP-event intervals on streams that share the GPU: summed over the ranges they exceed the wall time
+        for (int c = 1; c < 5; ++c) { p->t_ms[c] += sf->view.t_ms[c]; p->launches[c] += sf->view.launches[c]; }
+    }
+    p->t_ms[0] = wall_ms; p->launches[0] = 1;
+    p->prepped = 1;
     return HIPDRT_OK;
 }
 
@@ -1315,7 +1435,7 @@ static int plan_quadratic_forms(hipdrt_plan* p, const double* basis_eval, int ne
                                 int* status) {
     HIPDRT_REQUIRE(p->B > 0, "no fitted batch in the plan");
     HIPDRT_REQUIRE(neval >= 1, "neval >= 1");
-    HIPDRT_REQUIRE(p->n <= 2048, "posterior variance: n <= 2048");
+    HIPDRT_REQUIRE(p->n <= 4096, "posterior variance: n <= 4096");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const int n = p->n, m = p->m, B = p->B;

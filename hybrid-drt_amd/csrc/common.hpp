@@ -35,14 +35,16 @@ void set_error(const std::string& msg);
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool own = true;          // false: a window into another buffer (sub-batch views of a plan), never freed here
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && own) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        own = true;
     }
     hipError_t alloc(size_t n) {
         release();
@@ -50,6 +52,14 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, n);
         if (e == hipSuccess) bytes = n;
         return e;
+    }
+    // window [offset, offset + n) of `src` (nothing when src is empty)
+    void alias(const DevBuf& src, size_t offset, size_t n) {
+        release();
+        if (!src.p) return;
+        p = static_cast<char*>(src.p) + offset;
+        bytes = n;
+        own = false;
     }
     template <class T>
     T* as() const { return static_cast<T*>(p); }

@@ -126,7 +126,7 @@ static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
 
 int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long ppk_stride, const double* Bex, int nex,
                     double* L, long long l_stride, double* out, long long out_stride, int* status) {
-    if (n > 2048) { set_error("posterior variance: n > 2048 not supported"); return HIPDRT_E_INVALID; }
+    if (n > GRP_NMAX) { set_error("posterior variance: n > 4096 not supported"); return HIPDRT_E_INVALID; }
     if (n > RNP_MAX) {
         const int NP = round_up(n, 32);
         const size_t lds = resident_gu_lds_bytes();

@@ -49,7 +49,9 @@ _NOT_PER_OBS = ('basis_tau', 'timings_ms', 'launches', 'obs_tau_indices', 'obs_f
 
 
 def auto_inflight(num_obs):
-    """Batches in flight that served `num_obs` C2-size observations best on one MI355X (tools/probe_inflight.py, fits/s with
+    """(Round 4: one plan cuts its batch into ranges itself -- hipdrt_plan_set_subbatches, same effect with one plan's
+    memory and one caller thread -- so inflight=1 is no longer the slow choice; this rule is kept for callers that ask for
+    'auto'.)  Batches in flight that served `num_obs` C2-size observations best on one MI355X (tools/probe_inflight.py, fits/s with
     1 / 2 / 3 / 4 batches: 1250 obs. 1631 / 1814 / 1718 / 1473; 2500: 1792 / 1954 / 1971 / 1738; 10 000: 1994 / 2035 / 2053 /
     1986): a batch should keep more than ~500 spectra, and more than three host threads get in each other's way."""
     return 1 if num_obs < 512 else (2 if num_obs < 2000 else 3)
@@ -79,6 +81,12 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
     num = z_obs.shape[0]
     chunks = [c for c in np.array_split(np.arange(num), inflight) if len(c)]
     sibs = drt_siblings(drt, len(chunks))
+    for sib in sibs:
+        # several plans side by side already fill the tails of each other's launches: every plan fits its chunk as ONE range
+        # (cutting each of them again inside the library loses: profiles/r04_subbatch_sweep.txt)
+        sib.plan_subbatches = 1
+        if getattr(sib, '_plan', None) is not None:
+            sib._plan.set_subbatches(1)
     outs, errs = [None] * len(chunks), [None] * len(chunks)
 
     def work(i):

@@ -117,6 +117,9 @@ class DRT(PreparedFitMixin):
                                opts=opts, capacity=capacity)
         self._plan_key = key
         self.basis_tau = basis_tau
+        sub = getattr(self, 'plan_subbatches', None)      # None: the library's choice (hipdrt_plan_set_subbatches(0))
+        if sub is not None:
+            self._plan.set_subbatches(sub)
         if getattr(self, '_luts_installed', False) and getattr(self, '_lut_key', None) == float(self.tau_epsilon):
             (_, z_re), (_, z_im) = self._luts['z']          # tables received from another rank (install_lookup_tables)
             self._plan.set_lookup(z_re, z_im)

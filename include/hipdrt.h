@@ -223,6 +223,13 @@ int hipdrt_plan_upload(hipdrt_plan* plan, int B, const double* z_re, const doubl
  * convergence masks, calculate_pq's q (qphb.py:1154-1183).  Asynchronous on the ctx stream except for one
  * 4-byte "all converged" read-back per outer iteration.                                                */
 int hipdrt_plan_fit(hipdrt_plan* plan);
+/* How many contiguous ranges ("sub-batches") hipdrt_plan_fit cuts the staged spectra into: every range runs the same device
+ * loop on a stream of its own, side by side, inside the one call and the plan's own buffers -- what DRTMD's serial loop over
+ * observations (hybdrt/mapping/drtmd.py:303-319) becomes when the tail of one range's launches is filled by the others'.
+ * k = 0 (default): chosen from the batch size (1 below 600 spectra, up to 4 from 2400 on); k >= 1: that many (capped so that a
+ * range keeps >= 64 spectra).  Plans with prepared matrices, a recorded history, weight factors or outlier_p fit in one range.
+ * Per-spectrum results do not depend on k (every kernel of the loop works per spectrum).                                    */
+int hipdrt_plan_set_subbatches(hipdrt_plan* plan, int k);
 /* results for the B staged spectra (any pointer may be NULL):
  * x[B][n] QP solution in scaled units, fit_x[B][ntau] / r_inf[B] / induc[B] rescaled like
  * extract_qphb_parameters (drt1d.py:6228-6289), weights[B][m] (1/sigma, scaled units),
@@ -238,10 +245,10 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* plan, int b, double* p);
  * normalisation), i.e. what DRTMD.fit_observation stores as obs_drt_var (hybdrt/mapping/drtmd.py:278-279) before its
  * extend_var post-processing.  basis_eval[neval][ntau] = basis.construct_func_eval_matrix(ln basis_tau, ln tau_eval).
  * For every fitted spectrum: final P (calculate_pq state), P = L L' on the device, out[b][i] = |L^-1 b_i|^2 * cs_b^2.
- * status[b] (may be NULL): 0 ok, -1 P not positive definite (the reference's LinAlgError -> None).  n <= 2048. */
+ * status[b] (may be NULL): 0 ok, -1 P not positive definite (the reference's LinAlgError -> None).  n <= 4096. */
 int hipdrt_plan_distribution_var(hipdrt_plan* plan, const double* basis_eval, int neval, double* out, int* status);
 /* same machinery with the identity as evaluation rows: out[b][i] = diag(inv(P_b))_i * cs_b^2, the parameter variances
- * np.diag(DRT.estimate_param_cov()) (hybdrt/models/drt1d.py:4116-4138) of every fitted spectrum.  n <= 2048.          */
+ * np.diag(DRT.estimate_param_cov()) (hybdrt/models/drt1d.py:4116-4138) of every fitted spectrum.  n <= 4096.          */
 int hipdrt_plan_param_var(hipdrt_plan* plan, double* out, int* status);
 
 /* per-outer-iteration history of spectrum b recorded when record_history was enabled before the fit:

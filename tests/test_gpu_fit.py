@@ -339,6 +339,26 @@ def test_distribution_variance_batch_256x512():
     np.testing.assert_array_equal(v1[0], var[0])
 
 
+@pytest.mark.timeout(600)
+def test_distribution_variance_beyond_2048_unknowns():
+    """the posterior-variance kernel serves every size the QP serves (n <= 4096; it refused n > 2048 until round 4): one
+    spectrum on a 2498-point tau grid (n = 2500, the QP on the several-workgroups kernel), 40 evaluation points, against the
+    CPU checker's dense inverse of the very P the device built"""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    from oracle import drt_oracle as orc
+    c2 = synth.config_c2()
+    tau = np.logspace(-8, 2, 2498)
+    drt = DRT(fixed_basis_tau=tau)
+    res = drt.fit_eis_batch(c2["freq"], synth.zarc2_batch(c2["freq"], 1, first_seed=3), max_iter=2)
+    assert res["status"][0] >= 0 and drt._plan.n == 2500
+    sup = np.logspace(-7.5, 1.5, 40)
+    var, ok = drt.estimate_distribution_var_batch(tau=sup)
+    assert ok.all() and var.shape == (1, 40) and np.all(var >= 0)
+    ref = orc.estimate_distribution_var(drt._plan.p_matrix(0), tau, sup, drt.tau_epsilon, 2, res["coefficient_scale"][0])
+    parity_close("dist_var_n2500", var[0], ref, 1e-7)
+
+
 def test_warm_restarts_and_candidates_vs_reference_fixture():
     """survey 8f rank 3: drt1d._continue_from_init as the reference's candidate generators drive it (2 s_0 steps x4,
     3 weight steps x0.5 after the known-answer fit): identical iteration counts per step and every intermediate x of
@@ -539,6 +559,32 @@ def test_full_size_equivariance_properties():
     np.testing.assert_array_equal(res2["coefficient_scale"], (res["coefficient_scale"] * factor)[perm])
 
 
+
+
+def test_sub_batched_fit_is_bit_identical_to_the_one_range_fit():
+    """hipdrt_plan_set_subbatches: the staged batch fitted as k ranges side by side inside one fit call (own streams, the
+    plan's own buffers) gives every spectrum exactly the bits of the un-split fit -- every kernel of the loop works per
+    spectrum -- for an explicit k, for an uneven split, and for the automatic choice."""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    c2 = synth.config_c2()
+    B = 700
+    z = synth.zarc2_batch(c2["freq"], B, first_seed=5000)
+    drt = DRT(fixed_basis_tau=c2["tau"])
+    plan = drt.stage_batch(c2["freq"], z)
+    plan.set_subbatches(1)
+    drt.fit_staged()
+    ref = drt.collect_staged()
+    assert ref["launches"]["qp"] == ref["outer_iters"].max() + 1
+    for k in (3, 0):
+        plan.set_subbatches(k)
+        drt.fit_staged()
+        res = drt.collect_staged()
+        for key in ("x", "weights", "rho", "s_vectors", "outer_iters", "qp_iters_total", "status", "q_vector"):
+            np.testing.assert_array_equal(res[key], ref[key], err_msg=f"k={k} {key}")
+        if k == 3:
+            assert res["launches"]["qp"] > ref["launches"]["qp"]          # three launch sequences
+    plan.set_subbatches(0)
 
 
 @pytest.mark.timeout(1200)

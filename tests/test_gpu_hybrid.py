@@ -249,16 +249,17 @@ def test_config5_full_size_joint_fit_with_dop():
     scale = np.abs(g["hist_x"]).max(axis=1)
     dev_err = np.abs(dx - g["hist_x"]).max(axis=1) / scale
     print("device vs reference per outer iteration:", np.array2string(dev_err, precision=2))
-    parity_close("config5_full.hist_x", dev_err, np.zeros_like(dev_err), 1e-6, scale=1.0)
+    parity_close("config5_full.hist_x", dev_err, np.zeros_like(dev_err), 1e-8, scale=1.0)       # measured 4.8e-10
     np.testing.assert_allclose(np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], rtol=1e-6)
     np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in drt.qphb_history]), g["hist_dop_rho"], rtol=1e-6)
     np.testing.assert_allclose(qp["rv"], g["rv"], rtol=1e-12, atol=1e-13 * np.abs(g["rv"]).max())
     np.testing.assert_allclose(drt.coefficient_scale, float(g["coefficient_scale"]), rtol=1e-13)
-    parity_close("config5_full.x", fp["x"], g["x"], 1e-6)
-    parity_close("config5_full.x_dop", fp["x_dop"], g["x_dop"], 1e-6)
-    for key in ("R_inf", "inductance", "vz_offset"):
-        parity_close("config5_full." + key, np.atleast_1d(fp[key]), np.atleast_1d(float(g[key])), 1e-5)
-    parity_close("config5_full.est_weights", qp["est_weights"] / g["est_weights"], np.ones_like(g["est_weights"]), 1e-5, scale=1.0)
+    # (bounds = ten to twenty times the deviations measured in round 4: 5.5e-11, 1.4e-9, 8.8e-11 / 8.2e-9 / 2.4e-11, 8.3e-12)
+    parity_close("config5_full.x", fp["x"], g["x"], 1e-9)
+    parity_close("config5_full.x_dop", fp["x_dop"], g["x_dop"], 2e-8)
+    for key, bound in (("R_inf", 1e-9), ("inductance", 1e-7), ("vz_offset", 1e-9)):
+        parity_close("config5_full." + key, np.atleast_1d(fp[key]), np.atleast_1d(float(g[key])), bound)
+    parity_close("config5_full.est_weights", qp["est_weights"] / g["est_weights"], np.ones_like(g["est_weights"]), 1e-10, scale=1.0)
 
     # the full run (defaults, 50 outer iterations at most): properties of the result
     t0 = time.time()
@@ -449,9 +450,9 @@ def test_outlier_p_in_a_joint_fit_matches_reference_run():
     # history of the plan starts at the last initial QP
     assert qp["qp_iterations"].tolist() == g["qp_iterations"].tolist()[1:]
     assert qp["outer_iterations"] == int(g["outer_iterations"])
-    np.testing.assert_allclose(drt.cvx_result["x"], g["x_scaled"], rtol=1e-5, atol=1e-6)
+    parity_close("hybrid_outlier.x_scaled", drt.cvx_result["x"], g["x_scaled"], 1e-6)
     np.testing.assert_allclose(qp["true_weights"], g["weights"], rtol=1e-5)
-    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-4, atol=1e-7)
+    parity_close("hybrid_outlier.x", fp["x"], g["x"], 1e-6)
 
 
 @pytest.mark.parametrize("name", ["eis_rmout", "hybrid_rmout"])
@@ -635,7 +636,7 @@ def test_randomised_joint_fits_follow_the_oracle(seed):
     assert hx.shape == dx.shape
     scale = np.abs(hx).max(axis=1, keepdims=True)
     # (start-point QPs are direct solves: cond * eps, test_randomized_fits_vs_oracle's docstring)
-    parity_close("random_joint_fits.hist_x", dx, hx, 2e-6, scale=scale.max())
+    parity_close("random_joint_fits.hist_x", dx, hx, 1e-7, scale=scale.max())         # measured 3.3e-9 over the 24 draws
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
 
 
@@ -688,8 +689,7 @@ def test_randomised_option_combinations_follow_the_oracle(seed):
     hx = np.array([h["x"] for h in ref["history"]])
     dx = np.array([h["x"] for h in drt.qphb_history])
     assert hx.shape == dx.shape
-    drift = np.abs(dx - hx).max(axis=1) / np.abs(hx).max()        # per outer iteration: shows amplification if any
-    assert drift.max() < 5e-6, (seed, kw, dop, [f"{d:.1e}" for d in drift])
+    parity_close("random_option_eis_fits.hist_x", dx, hx, 5e-6, scale=np.abs(hx).max())
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
     np.testing.assert_allclose(drt.coefficient_scale, cs0 / (ref["scale_factor"] * ref["data_scale"]), rtol=1e-7)
 
@@ -747,10 +747,9 @@ def test_randomised_joint_fits_with_option_combinations(seed):
     hx = np.array([h["x"] for h in ref["history"]])
     dx = np.array([h["x"] for h in drt.qphb_history])
     assert hx.shape == dx.shape
-    drift = np.abs(dx - hx).max(axis=1) / np.abs(hx).max()
-    assert drift.max() < 5e-6, (seed, kw, dop, cap, [f"{d:.1e}" for d in drift])
+    parity_close("random_option_fits.hist_x", dx, hx, 5e-6, scale=np.abs(hx).max())
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
-    np.testing.assert_allclose(qp["rm"], ref["rzm"], rtol=0, atol=1e-6 * np.abs(ref["rzm"]).max())
+    parity_close("random_option_fits.rzm", qp["rm"], ref["rzm"], 1e-6)
 
 
 def test_uniform_chrono_variance_shortcut_is_bit_identical():
@@ -810,8 +809,8 @@ def test_config5_bench_workload_first_outer_iterations():
     assert dx.shape == g["hist_x"].shape == (K, 1078)
     dev_err = np.abs(dx - g["hist_x"]).max(axis=1) / np.abs(g["hist_x"]).max(axis=1)
     print("device vs reference per outer iteration (2 uV):", np.array2string(dev_err, precision=2))
-    parity_close("config5_2uV.hist_x", dev_err, np.zeros_like(dev_err), 1e-6, scale=1.0)
+    parity_close("config5_2uV.hist_x", dev_err, np.zeros_like(dev_err), 1e-7, scale=1.0)        # measured 7.4e-9
     np.testing.assert_allclose(np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], rtol=1e-5)
     np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in drt.qphb_history]), g["hist_dop_rho"], rtol=1e-5)
-    parity_close("config5_2uV.x", fp["x"], g["x"], 1e-6)
-    parity_close("config5_2uV.x_dop", fp["x_dop"], g["x_dop"], 1e-6)
+    parity_close("config5_2uV.x", fp["x"], g["x"], 1e-7)                    # measured 5.1e-9
+    parity_close("config5_2uV.x_dop", fp["x_dop"], g["x_dop"], 5e-7)        # measured 5.0e-8 (this loop is not contractive)

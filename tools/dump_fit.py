@@ -9,6 +9,13 @@ if sys.argv[1] == "--cmp":
     a, b = np.load(sys.argv[2]), np.load(sys.argv[3])
     bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
     print("identical" if not bad else f"DIFFERENT: {bad}")
+    for k in bad:       # how far apart: iteration counts as a mismatch count, everything else relative to the largest entry
+        x, y = np.asarray(a[k], dtype=float), np.asarray(b[k], dtype=float)
+        if "iters" in k:
+            print(f"  {k}: {int((x != y).sum())} of {x.size} differ")
+        else:
+            sc = np.abs(x).max(axis=-1, keepdims=True) if x.ndim > 1 else np.abs(x).max()
+            print(f"  {k}: max |a - b| / peak = {np.max(np.abs(x - y) / np.maximum(sc, 1e-300)):.2e}")
     sys.exit(1 if bad else 0)
 from hipdrt import synth
 from hipdrt.models import DRT

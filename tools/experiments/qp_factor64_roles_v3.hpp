@@ -60,11 +60,11 @@ static constexpr int RNW = RT / 64;      // 8 wavefronts
 #ifndef HIPDRT_QP_PREFETCH
 #define HIPDRT_QP_PREFETCH 1     // source tiles of block column jb + 1 requested before barrier (B) of column jb
 #endif
-#ifndef HIPDRT_QP_PREFETCH_CHAIN
-#define HIPDRT_QP_PREFETCH_CHAIN HIPDRT_QP_PREFETCH     // factor64: the same per role
+#ifndef HIPDRT_QP_PREFETCH_W1
+#define HIPDRT_QP_PREFETCH_W1 HIPDRT_QP_PREFETCH        // factor64, the same per role: wavefront 1 (look-ahead of block b, 7 tiles)
 #endif
-#ifndef HIPDRT_QP_PREFETCH_LA
-#define HIPDRT_QP_PREFETCH_LA HIPDRT_QP_PREFETCH
+#ifndef HIPDRT_QP_PREFETCH_W0
+#define HIPDRT_QP_PREFETCH_W0 0        // wavefront 0 (11 tiles): they would be live across chain a, whose code then spills
 #endif
 #ifndef HIPDRT_QP_PREFETCH_ROWS
 #define HIPDRT_QP_PREFETCH_ROWS 0      // measured: 2326 -> 2193 fits/s with the row wavefronts' 12 source tiles each requested before
@@ -100,8 +100,7 @@ struct ResSmemT {
     unsigned char* sched;   // [nblk][SROW] owner wavefront of every tile row below a block column (build_schedule)
 
     // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
-    static constexpr int VEC = GU ? 4096 + 32 + 32 : 528 + 16 + 32;      // NP + 32 (NP <= 544, or <= 4128 with U outside: the
-                                                                         // posterior-variance kernel serves n <= 4096 like the QP)
+    static constexpr int VEC = GU ? 2048 + 32 + 32 : 528 + 16 + 32;      // NP + 32 (NP <= 544, or <= 2080 with U outside)
     static constexpr int DVEC = P64 ? VEC - 32 : VEC;
     static constexpr int SROW = GU ? 128 : 32;                           // table row: tile rows below a block column (<= 124 | 29)
     static constexpr int SCHED = GU ? 64 * 128 / 8 : (P64 ? 9 * 32 / 8 : 17 * 32 / 8 + 4);    // doubles: nblk <= 64 | 17 (9 super columns) rows of SROW bytes
@@ -918,15 +917,6 @@ struct OpsResidentT {
     //                 block b, stores, and updates the right-hand side; wavefront 1 also completes diagonal block a' and
     //                 stages it for the chain.
     //   barrier (B):  the super column's tiles are visible to everyone.
-    //   What of the two chains nobody needs before (A) -- the lower-left blocks W21 of the inverse diagonal blocks (used by the
-    //   triangular sweeps only) and y_a, y_b of the fused forward substitution (used by the right-hand-side updates at the end
-    //   of the panel solves) -- wavefront 0 computes behind (A), where it has nothing else to do (finish_later); the others'
-    //   updates of the right-hand side wait for an LDS word that is set long before they get there.
-    // Other divisions of the sequential work were built and measured (all bit-identical, tools/experiments/
-    // qp_factor64_roles_v3.hpp, profiles/r04e_*, r04g_*): chain b on wavefront 1 behind a second barrier with wavefront 0 taking the
-    // heavier look-ahead rows (9.30 ms per launch), and wavefront 0 with the chains + the next diagonal block only, rows tA+4,
-    // tA+5 as ordinary rows (9.07 ms) -- against 8.63 ms for this form: a third barrier per super column costs more than the
-    // shorter chain path returns, and the two-row look-ahead wavefronts are what the busiest SIMD carries either way.
     // Two barriers per 64 columns instead of six.  Every tile receives exactly the MFMA sequence it receives in factor()
     // (history chunks ascending, x then y half of every half-chunk, the same operand order), so the factor, U and the forward-
     // substituted right-hand side are bit for bit those of the 32-column form (tools/dump_fit.py --cmp).
@@ -935,19 +925,19 @@ struct OpsResidentT {
 #endif
     static constexpr int RM = HIPDRT_QP_RM;      // tile rows per row wavefront and pass (x 4 tile columns = 12 accumulator tiles)
 #ifndef HIPDRT_QP_CHAINLOAD64
-#define HIPDRT_QP_CHAINLOAD64 0
+#define HIPDRT_QP_CHAINLOAD64 200
 #endif
     __device__ __forceinline__ void build_schedule64() {
         const int ntr = (n + 15) >> 4, nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
         constexpr int SROW = Smem::SROW;
         for (int J = threadIdx.x; J < nsup; J += RT) {
             const int tA = 4 * J, nk2 = 8 * J;
-            const int nsq = ntr - (tA + 6) > 0 ? ntr - (tA + 6) : 0;
+            const int nsq = ntr - (tA + 4) > 0 ? ntr - (tA + 4) : 0;      // every tile row below the super column's diagonal blocks
             const int c = 8 * nk2 + 40;                               // MFMAs of one row: history + two panel solves + block a's update
             const int cap = RM * (nsq > 6 * RM ? (nsq + 6 * RM - 1) / (6 * RM) : 1);
-            // SIMD 0 carries wavefront 0 (two chains + 14 MFMAs per half-chunk), SIMD 1 wavefront 1 (22 per half-chunk)
-            int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 2 < ntr) ? 14 * nk2 + 48 : 0);
-            int l1 = (tA + 4 < ntr) ? 22 * nk2 + 96 : 0, l2 = 0, l3 = 0;
+            // SIMD 0 carries wavefront 0 (chain a + 6 MFMAs per half-chunk), SIMD 1 wavefront 1 (14 per half-chunk)
+            int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 4 < ntr) ? 10 * nk2 : 0);      // (three dependent accumulators: ~100 cycles per MFMA)
+            int l1 = (tA + 2 < ntr) ? 14 * nk2 + 48 : 0, l2 = 0, l3 = 0;
             int c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
             for (int r = 0; r < nsq; ++r) {
                 const int w2 = c2 <= c6 ? 2 : 6, n2 = c2 <= c6 ? c2 : c6;
@@ -982,10 +972,10 @@ struct OpsResidentT {
             wn2[s_] = -U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq];
         }
     }
-    // y of the fused forward substitution is in vec: flag[2] >= 2 J + 1 for block a, 2 J + 2 for block b (wavefront 0, behind (A))
-    __device__ __forceinline__ void wait_y(int word) const {
+    // wavefront 1 has stored tile rows tA+2, tA+3 of super column J in columns a (LDS word flag[1] = J + 1 behind its vmcnt(0))
+    __device__ __forceinline__ void wait_x2(int J) const {
         int spins = 0;
-        while (lds_peek32(&sm.flag[2]) < word) {
+        while (lds_peek32(&sm.flag[1]) < J + 1) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 22)) __builtin_trap();           // (a protocol error must not hang the device)
         }
@@ -1063,7 +1053,7 @@ struct OpsResidentT {
             stage_dsc(d11);
             img21[lane] = d21;
             img21[64 + lane] = d22;
-            if (lane == 0) sm.flag[2] = 0;
+            if (lane == 0) sm.flag[1] = 0;
         }
         __syncthreads();
         if (wv == 0) return f64_chain();
@@ -1071,22 +1061,25 @@ struct OpsResidentT {
         return f64_rows(wv);
     }
 
-    // ======== wavefront 0: both chains of a super column and, between them, the look-ahead of block b ====================
+    // ======== wavefront 0: chain a and the next diagonal block a' ==========================================================
+    // Tile rows Q2 = tA+4, Q3 = tA+5 hold the diagonal block of the next super column.  Their eight panel tiles are ordinary
+    // rows (a row wavefront's); what is special about them is the 32 x 32 product X X' that completes the next diagonal block:
+    // its history part (three tiles, 6 MFMAs per half-chunk) is accumulated here behind chain a, and the contribution of this
+    // super column's own 64 columns is added after barrier (B) from the solved tiles as they lie in L (8 KB through L2) --
+    // then chain a' starts, beside everybody else's history pass.
     __device__ __forceinline__ bool f64_chain() {
-        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
-        const int fo = li * 4 + kq;
         const int nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
         const int ntr = (n + 15) >> 4;
         double* U = sm.U;
         v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
         v4d* const img22 = img21 + 64;
-        TileSrc pre[7];                          // source tiles of the next look-ahead rows, requested before barrier (B)
-        bool have_pre = false;
         for (int J = 0; J < nsup; ++J) {
-            const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J;
-            const bool hasb = (2 * J + 1) < nblk;
-            const int R2 = tA + 2, R3 = tA + 3;
-            const bool v3 = R3 < ntr;
+            const int j0a = J * 64, tA = 4 * J;
+            const int Q2 = tA + 4, Q3 = tA + 5;
+            const bool v2 = Q2 < ntr, v3 = Q3 < ntr;
+            // (lane-derived values are recomputed per phase -- two VALU instructions -- instead of being hoisted out of the loop
+            // and kept alive, with everything derived from them, across the chain: its code spilled 30 registers otherwise)
+            int lane = fresh_lane(), li = lane & 15, kq = lane >> 4, fo = li * 4 + kq;
             PROF_DECL
             // ---- chain a ------------------------------------------------------------------------------------------
             bool ok = cholinv16_dsc(j0a, 0);
@@ -1107,13 +1100,126 @@ struct OpsResidentT {
                 PROF(14);
                 ok = cholinv16(d22, j0a + 16, 16) && ok;
                 PROF(15);
-                // (W21 of the inverse block and y_a of the fused forward substitution are not needed before the panel solves:
-                // they are computed behind barrier (A), while this wavefront has nothing else to do -- finish_later below)
+                finish_block(x21, j0a, lane, li, kq);
             }
-            v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
+            if (lane == 0) sm.flag[0] = ok ? 0 : 1;
+            // (nothing of what follows may be hoisted into the chain)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            lane = fresh_lane(); li = lane & 15; kq = lane >> 4; fo = li * 4 + kq;
+            v4d f11, f21, f22;
+            if (v2) {
+                f11 = init_tile(Q2, Q2, ntr, fo, li, kq);
+                f21 = init_tile(Q3, Q2, ntr, fo, li, kq);
+                f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
+                if (J > 0) {
+                    const char* q2 = uniform_ptr(tile2(Q2, 0));
+                    const char* q3 = uniform_ptr(tile2(v3 ? Q3 : Q2, 0));
+                    const unsigned voff = (unsigned)fo * 16u;
+                    struct Frag { v2d a2, a3; };
+                    const int nk2 = 8 * J, klast = nk2 - 1;
+                    auto loadf = [&](Frag& f_, int k2) {
+                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+                        f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
+                    };
+#define HIPDRT_STEP3(H)                                                                                  \
+                    f11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a2.H, f_.a2.H, f11, 0, 0, 0);         \
+                    if (v3) {                                                                           \
+                        f21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a2.H, f_.a3.H, f21, 0, 0, 0);     \
+                        f22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a3.H, f_.a3.H, f22, 0, 0, 0);     \
+                    }
+                    auto multf = [&](const Frag& f_) {
+                        HIPDRT_STEP3(x)
+                        HIPDRT_STEP3(y)
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+#undef HIPDRT_STEP3
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    // (three accumulators only: every MFMA waits for the one three back; eight half-chunks in flight)
+                    Frag f0, f1, f2, f3, f4, f5, f6, f7;
+                    loadf(f0, 0); loadf(f1, 1); loadf(f2, 2); loadf(f3, 3); loadf(f4, 4); loadf(f5, 5); loadf(f6, 6);
+                    for (int k2 = 0; k2 < nk2; k2 += 8) {           // nk2 = 8 J: a multiple of 8
+                        loadf(f7, k2 + 7); vm_wait<14>(); multf(f0);
+                        loadf(f0, k2 + 8); vm_wait<14>(); multf(f1);
+                        loadf(f1, k2 + 9); vm_wait<14>(); multf(f2);
+                        loadf(f2, k2 + 10); vm_wait<14>(); multf(f3);
+                        loadf(f3, k2 + 11); vm_wait<14>(); multf(f4);
+                        loadf(f4, k2 + 12); vm_wait<14>(); multf(f5);
+                        loadf(f5, k2 + 13); vm_wait<14>(); multf(f6);
+                        loadf(f6, k2 + 14); vm_wait<14>(); multf(f7);
+                    }
+                    vm_wait<0>();
+                    if (!v3) {
+                        f21 = (v4d){0, 0, 0, 0};
+                        f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
+                    }
+                }
+            }
+            PROF(40);
+            __syncthreads();                                    // (A1) history everywhere; W / L21 / y of block a
+            PROF2(1, 16 + (J < 23 ? J : 23));
+            if (sm.flag[0]) return false;
+            __syncthreads();                                    // (A2) W / L21 / y of block b
+            PROF(42);
+            if (sm.flag[0]) return false;
+            __syncthreads();                                    // (B) the super column's tiles are in L
+            PROF(4);
+            if (v2) {
+                // ---- this super column's own 64 columns of X X' from the solved tiles of rows Q2, Q3 --------------------
+                lane = fresh_lane(); li = lane & 15; kq = lane >> 4; fo = li * 4 + kq;
+                v2d g2[4][2], g3[4][2];                         // [chunk tA .. tA+3][half]
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double2* p2 = tile2(Q2, tA + c) + fo;
+                    const double2* p3 = tile2(v3 ? Q3 : Q2, tA + c) + fo;
+                    const double2 a0 = p2[0], a1 = p2[64], b0 = p3[0], b1 = p3[64];
+                    g2[c][0] = (v2d){a0.x, a0.y}; g2[c][1] = (v2d){a1.x, a1.y};
+                    g3[c][0] = (v2d){b0.x, b0.y}; g3[c][1] = (v2d){b1.x, b1.y};
+                }
+#define HIPDRT_FIN3(A2, A3)                                                                      \
+                f11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, f11, 0, 0, 0);               \
+                if (v3) {                                                                       \
+                    f21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, f21, 0, 0, 0);           \
+                    f22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, f22, 0, 0, 0);           \
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    HIPDRT_FIN3(g2[c][0].x, g3[c][0].x)
+                    HIPDRT_FIN3(g2[c][0].y, g3[c][0].y)
+                    HIPDRT_FIN3(g2[c][1].x, g3[c][1].x)
+                    HIPDRT_FIN3(g2[c][1].y, g3[c][1].y)
+                }
+#undef HIPDRT_FIN3
+                stage_dsc(f11);
+                img21[lane] = f21;
+                img22[lane] = f22;
+                __builtin_amdgcn_wave_barrier();
+            }
+            PROF(41);
+        }
+        return true;
+    }
+
+    // ======== wavefront 1: the look-ahead of block b -- tile rows R2 = tA+2, R3 = tA+3 in columns a and diagonal block b over
+    // the history, their panel solve against block a behind barrier (A1), and then chain b itself: the sequential work of a
+    // super column is split over two wavefronts, each running its chain on tiles it accumulated itself =====================
+    __device__ __forceinline__ bool f64_look2() {
+        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
+        const int fo = li * 4 + kq;
+        const int nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
+        const int ntr = (n + 15) >> 4;
+        double* U = sm.U;
+        TileSrc pre[7];                          // source tiles of the next look-ahead rows, requested before barrier (B)
+        bool have_pre = false;
+        for (int J = 0; J < nsup; ++J) {
+            const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J;
+            const bool hasb = (2 * J + 1) < nblk;
+            const int R2 = tA + 2, R3 = tA + 3;
+            const bool v3 = R3 < ntr;
+            PROF_DECL
+            v4d p20, p21, p30, p31, e11, e21, e22;
             if (hasb) {
-                // ---- look-ahead of block b: rows R2, R3 in columns a, diagonal block b ------------------------------
-                v4d p20, p21, p30, p31, e11, e21, e22;
                 if (have_pre) {
                     p20 = tile_image(pre[0], R2, tA, li, kq);      p21 = tile_image(pre[1], R2, tA + 1, li, kq);
                     p30 = tile_image(pre[2], R3, tA, li, kq);      p31 = tile_image(pre[3], R3, tA + 1, li, kq);
@@ -1170,11 +1276,18 @@ struct OpsResidentT {
                         e22 = init_tile(R3, R3, ntr, fo, li, kq);
                     }
                 }
-                PROF(40);
-                // panel solve against block a (own W1, L21, W2)
+            }
+            PROFW(32);
+            __syncthreads();                                    // (A1)
+            PROFW(33);
+            if (sm.flag[0]) return false;
+            have_pre = false;
+            if (hasb) {
+                // panel solve against block a
                 double wn1[4], l21[4], wn2[4];
                 load_wn(wn1, wn2, j0a, li, kq);
                 load_l21(l21, 0, lane);
+                v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) {
                     x20 = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], p20[s_], x20, 0, 0, 0);
@@ -1192,6 +1305,10 @@ struct OpsResidentT {
                 }
                 store_pair(R2, tA, x20, x21_, fo);
                 if (v3) store_pair(R3, tA, x30, x31, fo);
+                // the other wavefronts take these two tile rows as operands of block a's update of their column-b tiles: once the
+                // stores have left this wavefront the LDS word tells them so (same CU: its loads are ordered behind these stores)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) sm.flag[1] = J + 1;
                 // the two chunks just produced complete diagonal block b
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) {
@@ -1205,9 +1322,13 @@ struct OpsResidentT {
                     e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21_[s_], x31[s_], e21, 0, 0, 0);
                     e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x31[s_], x31[s_], e22, 0, 0, 0);
                 }
-                PROF(41);
-                // ---- chain b ---------------------------------------------------------------------------------------
-                ok = cholinv16(e11, j0b, 0) && ok;
+                // right-hand side of block b receives block a's update (y_a: published at (A1))
+                fwd_update(x20, x21_, R2, j0a, li, kq);
+                if (v3) fwd_update(x30, x31, R3, j0a, li, kq);
+                __builtin_amdgcn_wave_barrier();
+                PROFW(34);
+                // ---- chain b (the scratch block dsc is this wavefront's between (A1) and (A2): wavefront 0 stages a' behind (A2)) ----
+                bool ok = cholinv16(e11, j0b, 0);
                 v4d xb = (v4d){0, 0, 0, 0};
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_)
@@ -1218,36 +1339,16 @@ struct OpsResidentT {
                 for (int s_ = 0; s_ < 4; ++s_)
                     e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[s_], xb[s_], e22, 0, 0, 0);
                 ok = cholinv16(e22, j0b + 16, 16) && ok;
-                PROF(42);
+                finish_block(xb, j0b, lane, li, kq);
+                if (!ok && lane == 0) sm.flag[0] = 1;
+                PROFW(35);
             }
-            if (lane == 0) sm.flag[0] = ok ? 0 : 1;
-            __syncthreads();                                    // (A)
-            PROF2(1, 16 + (J < 23 ? J : 23));
+            __syncthreads();                                    // (A2)
+            PROFW(36);
             if (sm.flag[0]) return false;
-            have_pre = false;
-            // ---- finish_later: what of the two chains nobody needed before (A).  The others' updates of the right-hand side
-            // wait for the word flag[2] (2 J + 1: y_a is in vec, 2 J + 2: y_b), which they reach long after it is set.
+#if HIPDRT_QP_PREFETCH_W1
             {
-                double l21[4];
-                load_l21(l21, 0, lane);
-                finish_block((v4d){l21[0], l21[1], l21[2], l21[3]}, j0a, lane, li, kq);
-                if (lane == 0) sm.flag[2] = 2 * J + 1;
-                if (hasb) {
-                    // right-hand side of block b receives block a's update, then y_b
-                    fwd_update(x20, x21_, R2, j0a, li, kq);
-                    if (v3) fwd_update(x30, x31, R3, j0a, li, kq);
-                    __builtin_amdgcn_wave_barrier();
-                    load_l21(l21, 1, lane);
-                    finish_block((v4d){l21[0], l21[1], l21[2], l21[3]}, j0b, lane, li, kq);
-                    if (lane == 0) sm.flag[2] = 2 * J + 2;
-                }
-            }
-            PROF(43);
-#if HIPDRT_QP_PREFETCH_CHAIN
-            // source tiles of the next super column's look-ahead rows: in flight through the others' panel solves and chain a'
-            {
-                // (requested unconditionally, from a stand-in tile when there is no next block b: a conditional definition would
-                // keep the previous super column's tiles alive -- through the operand ring -- on the path that skips it)
+                // source tiles of the next super column's look-ahead rows (unconditional definition: see wavefront 0)
                 have_pre = 2 * J + 3 < nblk;
                 const int N2 = have_pre ? tA + 6 : 0, N3 = have_pre ? tA + 7 : 0, cA = have_pre ? tA + 4 : 0;
                 const int D2 = have_pre ? N2 : 0;
@@ -1258,200 +1359,12 @@ struct OpsResidentT {
             }
 #endif
             __syncthreads();                                    // (B)
-            PROF(4);
+            PROFW(37);
         }
         return true;
     }
 
-    // ======== wavefront 1: tile rows Q2 = tA+4, Q3 = tA+5 over all four columns + the next diagonal block a' =============
-    __device__ __forceinline__ bool f64_look2() {
-        const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
-        const int fo = li * 4 + kq;
-        const int nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
-        const int ntr = (n + 15) >> 4;
-        v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
-        v4d* const img22 = img21 + 64;
-        TileSrc pre[11];                         // source tiles of the next super column, requested before barrier (B)
-        bool have_pre = false;
-        for (int J = 0; J < nsup; ++J) {
-            const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
-            const int Q2 = tA + 4, Q3 = tA + 5;
-            const bool v2 = Q2 < ntr, v3 = Q3 < ntr;
-            if (v2) {
-                v4d ca[2][2], cb[2][2], f11, f21, f22;
-                if (have_pre) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            ca[r][c] = tile_image(pre[4 * r + c], Q2 + r, tA + c, li, kq);
-                            cb[r][c] = tile_image(pre[4 * r + 2 + c], Q2 + r, tB + c, li, kq);
-                        }
-                    f11 = tile_image(pre[8], Q2, Q2, li, kq);
-                    f21 = tile_image(pre[9], Q3, Q2, li, kq);
-                    f22 = tile_image(pre[10], Q3, Q3, li, kq);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            ca[r][c] = init_tile(Q2 + r, tA + c, ntr, fo, li, kq);
-                            cb[r][c] = init_tile(Q2 + r, tB + c, ntr, fo, li, kq);
-                        }
-                    f11 = init_tile(Q2, Q2, ntr, fo, li, kq);
-                    f21 = init_tile(Q3, Q2, ntr, fo, li, kq);
-                    f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
-                }
-                if (J > 0) {
-                    const char* qb[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) qb[c] = uniform_ptr(tile2(tA + c, 0));
-                    const char* q2 = uniform_ptr(tile2(Q2, 0));
-                    const char* q3 = uniform_ptr(tile2(v3 ? Q3 : Q2, 0));
-                    const unsigned voff = (unsigned)fo * 16u;
-                    struct Frag { v2d b[4], a2, a3; };
-                    const int nk2 = 8 * J, klast = nk2 - 1;
-                    auto loadf = [&](Frag& f_, int k2) {
-                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) f_.b[c] = gload16(qb[c] + o, voff);
-                        f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
-                    };
-#define HIPDRT_STEP11(H)                                                                                          \
-                    ca[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[0].H, f_.a2.H, ca[0][0], 0, 0, 0);     \
-                    ca[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[1].H, f_.a2.H, ca[0][1], 0, 0, 0);     \
-                    cb[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[2].H, f_.a2.H, cb[0][0], 0, 0, 0);     \
-                    cb[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[3].H, f_.a2.H, cb[0][1], 0, 0, 0);     \
-                    f11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a2.H, f_.a2.H, f11, 0, 0, 0);                 \
-                    if (v3) {                                                                                   \
-                        ca[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[0].H, f_.a3.H, ca[1][0], 0, 0, 0); \
-                        ca[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[1].H, f_.a3.H, ca[1][1], 0, 0, 0); \
-                        cb[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[2].H, f_.a3.H, cb[1][0], 0, 0, 0); \
-                        cb[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.b[3].H, f_.a3.H, cb[1][1], 0, 0, 0); \
-                        f21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a2.H, f_.a3.H, f21, 0, 0, 0);             \
-                        f22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f_.a3.H, f_.a3.H, f22, 0, 0, 0);             \
-                    }
-                    auto multf = [&](const Frag& f_) {
-                        HIPDRT_STEP11(x)
-                        HIPDRT_STEP11(y)
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-#undef HIPDRT_STEP11
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    Frag f0, f1, f2, f3;
-                    loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
-                    for (int k2 = 0; k2 < nk2; k2 += 4) {
-                        loadf(f3, k2 + 3); vm_wait<18>(); multf(f0);
-                        loadf(f0, k2 + 4); vm_wait<18>(); multf(f1);
-                        loadf(f1, k2 + 5); vm_wait<18>(); multf(f2);
-                        loadf(f2, k2 + 6); vm_wait<18>(); multf(f3);
-                    }
-                    vm_wait<0>();
-                    if (!v3) {
-                        ca[1][0] = (v4d){0, 0, 0, 0}; ca[1][1] = ca[1][0]; cb[1][0] = ca[1][0]; cb[1][1] = ca[1][0]; f21 = ca[1][0];
-                        f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
-                    }
-                }
-                __syncthreads();                                // (A)
-                if (sm.flag[0]) return false;
-                have_pre = false;
-                BFrag bf;
-                load_bfrag(bf, tA, true, fo);                   // (rows tA+2, tA+3 are valid whenever Q2 is)
-                v4d xa[2][2], xb[2][2];
-                {
-                    double wn1[4], l21[4], wn2[4];
-                    load_wn(wn1, wn2, j0a, li, kq);
-                    load_l21(l21, 0, lane);
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) { xa[r][0] = (v4d){0, 0, 0, 0}; xa[r][1] = (v4d){0, 0, 0, 0}; }
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) xa[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], ca[r][0][s_], xa[r][0], 0, 0, 0);
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) ca[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], xa[r][0][s_], ca[r][1], 0, 0, 0);
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) xa[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], ca[r][1][s_], xa[r][1], 0, 0, 0);
-                }
-                store_pair(Q2, tA, xa[0][0], xa[0][1], fo);
-                if (v3) store_pair(Q3, tA, xa[1][0], xa[1][1], fo);
-                // block a's rank-32 update of the column-b tiles and of the next diagonal block, from registers
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) upd_b(cb[r][c], bf, c, xa[r][0], xa[r][1]);
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        f11 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0][k][s_], xa[0][k][s_], f11, 0, 0, 0);
-                        f21 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0][k][s_], xa[1][k][s_], f21, 0, 0, 0);
-                        f22 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1][k][s_], xa[1][k][s_], f22, 0, 0, 0);
-                    }
-                wait_y(2 * J + 1);
-                fwd_update(xa[0][0], xa[0][1], Q2, j0a, li, kq);
-                if (v3) fwd_update(xa[1][0], xa[1][1], Q3, j0a, li, kq);
-                {
-                    double wn1[4], l21[4], wn2[4];
-                    load_wn(wn1, wn2, j0b, li, kq);
-                    load_l21(l21, 1, lane);
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) { xb[r][0] = (v4d){0, 0, 0, 0}; xb[r][1] = (v4d){0, 0, 0, 0}; }
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) xb[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], cb[r][0][s_], xb[r][0], 0, 0, 0);
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) cb[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], xb[r][0][s_], cb[r][1], 0, 0, 0);
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) xb[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], cb[r][1][s_], xb[r][1], 0, 0, 0);
-                }
-                store_pair(Q2, tB, xb[0][0], xb[0][1], fo);
-                if (v3) store_pair(Q3, tB, xb[1][0], xb[1][1], fo);
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        f11 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[0][k][s_], xb[0][k][s_], f11, 0, 0, 0);
-                        f21 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[0][k][s_], xb[1][k][s_], f21, 0, 0, 0);
-                        f22 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[1][k][s_], xb[1][k][s_], f22, 0, 0, 0);
-                    }
-                stage_dsc(f11);
-                img21[lane] = f21;
-                img22[lane] = f22;
-                wait_y(2 * J + 2);
-                fwd_update(xb[0][0], xb[0][1], Q2, j0b, li, kq);
-                if (v3) fwd_update(xb[1][0], xb[1][1], Q3, j0b, li, kq);
-#if HIPDRT_QP_PREFETCH_LA
-                {
-                    // (unconditional, stand-in tile (0, 0) when there are no such rows: see wavefront 0)
-                    have_pre = Q2 + 4 < ntr;
-                    const int N2 = have_pre ? Q2 + 4 : 0, N3 = have_pre ? Q2 + 5 : 0, cA = have_pre ? tA + 4 : 0, st = have_pre ? 1 : 0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { pre[c] = tile_src(N2, cA + st * c, ntr, fo); pre[4 + c] = tile_src(N3, cA + st * c, ntr, fo); }
-                    pre[8] = tile_src(N2, N2, ntr, fo); pre[9] = tile_src(N3, N2, ntr, fo);
-                    pre[10] = tile_src(N3, N3, ntr, fo);
-                }
-#endif
-            } else {
-                __syncthreads();                                // (A)
-                if (sm.flag[0]) return false;
-            }
-            __syncthreads();                                    // (B)
-        }
-        return true;
-    }
-
-    // ======== wavefronts 2..7: tile rows tA+6 .. over all four columns ===================================================
+    // ======== wavefronts 2..7: tile rows tA+4 .. over all four columns ===================================================
     __device__ __forceinline__ bool f64_rows(int wv) {
         const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
         const int fo = li * 4 + kq;
@@ -1460,9 +1373,9 @@ struct OpsResidentT {
         constexpr int SROW = Smem::SROW;
         TileSrc pre[RM][4];                      // source tiles of pass 0 of the next super column, requested before barrier (B)
         bool have_pre = false;
-        // this wavefront's rows of super column J_: bit r of (m0, m1) = tile row 4 J_ + 6 + r
+        // this wavefront's rows of super column J_: bit r of (m0, m1) = tile row 4 J_ + 4 + r
         auto my_rows = [&](int J_, unsigned long long& m0, unsigned long long& m1) {
-            const int nsq_ = ntr - (4 * J_ + 6) > 0 ? ntr - (4 * J_ + 6) : 0;
+            const int nsq_ = ntr - (4 * J_ + 4) > 0 ? ntr - (4 * J_ + 4) : 0;
             const unsigned char* row = sm.sched + J_ * SROW;
             m0 = __ballot(lane < nsq_ && row[lane] == wv);
             m1 = 0;
@@ -1472,6 +1385,7 @@ struct OpsResidentT {
             const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
             unsigned long long m0, m1;
             my_rows(J, m0, m1);
+            PROF_DECL
             const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);
             const int npass = mine > RM ? (mine + RM - 1) / RM : 1;
             // rows and accumulators of pass 0 in front of the pass loop: the prefetched source tiles die here, not somewhere
@@ -1485,7 +1399,7 @@ struct OpsResidentT {
                     int r = -1;
                     if (m0) { r = __builtin_ctzll(m0); m0 &= m0 - 1; }
                     else if (m1) { r = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
-                    T[u] = r >= 0 ? tA + 6 + r : nch;
+                    T[u] = r >= 0 ? tA + 4 + r : nch;
                     act[u] = r >= 0;
                 }
             };
@@ -1568,12 +1482,12 @@ struct OpsResidentT {
                     vm_wait<0>();
                 }
                 if (ps == 0) {
-                    __syncthreads();                            // (A)
+                    if (wv == 2) PROFW(26);
+                    __syncthreads();                            // (A1)
+                    if (wv == 2) PROFW(27);
                     if (sm.flag[0]) return false;
                 }
                 if (act[0]) {
-                    BFrag bf;
-                    load_bfrag(bf, tA, true, fo);               // (rows tA+2, tA+3 are valid whenever there are rows here)
                     v4d x1[RM], x2[RM];
                     {
                         double wn1[4], l21[4], wn2[4];
@@ -1598,14 +1512,26 @@ struct OpsResidentT {
                     for (int u = 0; u < RM; ++u)
                         if (act[u]) store_pair(T[u], tA, x1[u], x2[u], fo);
 #pragma unroll
+                    for (int u = 0; u < RM; ++u)
+                        if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0a, li, kq);
+                    // block a's rank-32 update of the column-b tiles from registers, once wavefront 1 has put rows tA+2, tA+3 into L
+                    wait_x2(J);
+                    BFrag bf;
+                    load_bfrag(bf, tA, true, fo);               // (rows tA+2, tA+3 are valid whenever there are rows here)
+#pragma unroll
                     for (int u = 0; u < RM; ++u) {
                         upd_b(acc[u][2], bf, 0, x1[u], x2[u]);
                         upd_b(acc[u][3], bf, 1, x1[u], x2[u]);
                     }
-                    wait_y(2 * J + 1);
-#pragma unroll
-                    for (int u = 0; u < RM; ++u)
-                        if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0a, li, kq);
+                }
+                if (ps == 0) {
+                    if (wv == 2) PROFW(28);
+                    __syncthreads();                            // (A2)
+                    if (wv == 2) PROFW(29);
+                    if (sm.flag[0]) return false;
+                }
+                if (act[0]) {
+                    v4d x1[RM], x2[RM];
                     {
                         double wn1[4], l21[4], wn2[4];
                         load_wn(wn1, wn2, j0b, li, kq);
@@ -1628,7 +1554,6 @@ struct OpsResidentT {
 #pragma unroll
                     for (int u = 0; u < RM; ++u)
                         if (act[u]) store_pair(T[u], tB, x1[u], x2[u], fo);
-                    wait_y(2 * J + 2);
 #pragma unroll
                     for (int u = 0; u < RM; ++u)
                         if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0b, li, kq);
@@ -1646,13 +1571,15 @@ struct OpsResidentT {
                     if (n0) { r = __builtin_ctzll(n0); n0 &= n0 - 1; }
                     else if (n1) { r = 64 + __builtin_ctzll(n1); n1 &= n1 - 1; }
                     // (unconditional, stand-in tile (0, 0) for a row that does not exist: see wavefront 0)
-                    const int Tn = r >= 0 ? tA + 10 + r : 0, cn = r >= 0 ? tA + 4 : 0, st = r >= 0 ? 1 : 0;
+                    const int Tn = r >= 0 ? tA + 8 + r : 0, cn = r >= 0 ? tA + 4 : 0, st = r >= 0 ? 1 : 0;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) pre[u][c] = tile_src(Tn, cn + st * c, ntr, fo);
                 }
             }
 #endif
+            if (wv == 2) PROFW(30);
             __syncthreads();                                        // (B)
+            if (wv == 2) PROFW(31);
         }
         return true;
     }

@@ -8,7 +8,7 @@ one() {
   python3 - $O/prof_$T/*/*kernel_stats.csv >> $O/${T}_kernels.txt <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if any(k in r["Name"] for k in ("gram_kernel", "qvec_kernel", "qp_kernel", "hyper_kernel", "lpt_order")):
+    if any(k in r["Name"] for k in ("gram_kernel", "gram_kr", "qvec_kernel", "qp_kernel", "hyper_kernel", "lpt_order")):
         print("%-44s calls %4s  total %9.3f ms  avg %8.1f us  min %8.1f  max %8.1f" % (r["Name"].split("(")[0][-44:], r["Calls"],
               float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY

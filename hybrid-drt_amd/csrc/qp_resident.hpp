@@ -69,9 +69,8 @@ static constexpr int RNW = RT / 64;      // 8 wavefronts
 #ifndef HIPDRT_QP_PREFETCH_ROWS
 #define HIPDRT_QP_PREFETCH_ROWS 0      // measured: 2326 -> 2193 fits/s with the row wavefronts' 12 source tiles each requested before
 #endif                                 // barrier (B), 8.63 -> 9.28 ms per launch (profiles/r04c_ab_prefetch_matrix.txt)
-#ifndef HIPDRT_QP_P_NT
-#define HIPDRT_QP_P_NT 0               // source tiles of P with non-temporal loads (read once per factorisation)
-#endif
+// (non-temporal loads for the source tiles of P -- read once per factorisation -- were tried: __builtin_nontemporal_load in
+// tile_src makes hipcc 7.2's simplifycfg pass crash on this translation unit, in either coneqp kernel)
 static constexpr int RMAXT = HIPDRT_QP_RMAXT;   // tile rows per wavefront and pass
 static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
@@ -352,14 +351,8 @@ struct OpsResidentT {
             const double2* tile = reinterpret_cast<const double2*>(Bex + ((size_t)(T - nch) * nchp + Cc) * 256);
             r_.d0 = tile[fo]; r_.d1 = tile[64 + fo];
         } else if (T < ntr) {
-#if HIPDRT_QP_P_NT
-            const v2d* tile = reinterpret_cast<const v2d*>(Ppk + ((size_t)T * nchp + Cc) * 256);
-            const v2d a_ = __builtin_nontemporal_load(tile + fo), b_ = __builtin_nontemporal_load(tile + 64 + fo);
-            r_.d0 = make_double2(a_.x, a_.y); r_.d1 = make_double2(b_.x, b_.y);
-#else
             const double2* tile = reinterpret_cast<const double2*>(Ppk + ((size_t)T * nchp + Cc) * 256);
             r_.d0 = tile[fo]; r_.d1 = tile[64 + fo];
-#endif
         }
         return r_;
     }
@@ -946,8 +939,14 @@ struct OpsResidentT {
             const int c = 8 * nk2 + 40;                               // MFMAs of one row: history + two panel solves + block a's update
             const int cap = RM * (nsq > 6 * RM ? (nsq + 6 * RM - 1) / (6 * RM) : 1);
             // SIMD 0 carries wavefront 0 (two chains + 14 MFMAs per half-chunk), SIMD 1 wavefront 1 (22 per half-chunk)
-            int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 2 < ntr) ? 14 * nk2 + 48 : 0);
-            int l1 = (tA + 4 < ntr) ? 22 * nk2 + 96 : 0, l2 = 0, l3 = 0;
+#ifndef HIPDRT_QP_LA1LOAD
+#define HIPDRT_QP_LA1LOAD 14         // MFMAs per half-chunk charged to SIMD 0 for wavefront 0's look-ahead (part of it now runs behind (A))
+#endif
+            int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 2 < ntr) ? HIPDRT_QP_LA1LOAD * nk2 + 48 : 0);
+#ifndef HIPDRT_QP_LA2LOAD
+#define HIPDRT_QP_LA2LOAD 22
+#endif
+            int l1 = (tA + 4 < ntr) ? HIPDRT_QP_LA2LOAD * nk2 + 96 : 0, l2 = 0, l3 = 0;
             int c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
             for (int r = 0; r < nsq; ++r) {
                 const int w2 = c2 <= c6 ? 2 : 6, n2 = c2 <= c6 ? c2 : c6;
@@ -1003,16 +1002,15 @@ struct OpsResidentT {
                 b_.f[r][k][1] = (v2d){d1.x, d1.y};
             }
     }
-    // acc += (tile row tA+2+r, columns a) * xs'   with xs = (xa | xb) the solved tiles of one tile row in columns a
-    static __device__ __forceinline__ void upd_b(v4d& acc, const BFrag& b_, int r, const v4d& xa, const v4d& xb) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][0][0].x, xa[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][0][0].y, xa[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][0][1].x, xa[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][0][1].y, xa[3], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][1][0].x, xb[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][1][0].y, xb[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][1][1].x, xb[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.f[r][1][1].y, xb[3], acc, 0, 0, 0);
+    // acc += (tile row tA+2+r, columns a) * xs'   with xs = (xa | xb) the solved tiles of one tile row in columns a: the eight
+    // k-steps of that product one at a time (st = 0 .. 7: chunk tA steps 0..3, chunk tA+1 steps 0..3), so that a caller with
+    // several accumulators rotates over them -- eight MFMAs in a row on ONE accumulator wait for each other (~100+ cycles each
+    // instead of 64); per accumulator the order of the steps, hence the sum, is unchanged
+    static __device__ __forceinline__ void upd_b_step(v4d& acc, const BFrag& b_, int r, const v4d& xa, const v4d& xb, int st) {
+        const int k = st >> 2, h = (st >> 1) & 1;
+        const double bo = (st & 1) ? b_.f[r][k][h].y : b_.f[r][k][h].x;
+        const double xo = k ? xb[st & 3] : xa[st & 3];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bo, xo, acc, 0, 0, 0);
     }
     __device__ __forceinline__ void store_pair(int T, int c, const v4d& x1, const v4d& x2, int fo) const {
         double2* d0 = const_cast<double2*>(tile2(T, c)) + fo;
@@ -1063,7 +1061,7 @@ struct OpsResidentT {
             stage_dsc(d11);
             img21[lane] = d21;
             img21[64 + lane] = d22;
-            if (lane == 0) sm.flag[2] = 0;
+            if (lane == 0) { sm.flag[2] = 0; sm.flag[3] = 0; }
         }
         __syncthreads();
         if (wv == 0) return f64_chain();
@@ -1080,14 +1078,71 @@ struct OpsResidentT {
         double* U = sm.U;
         v4d* const img21 = reinterpret_cast<v4d*>(sm.img);
         v4d* const img22 = img21 + 64;
-        TileSrc pre[7];                          // source tiles of the next look-ahead rows, requested before barrier (B)
-        bool have_pre = false;
+        // The look-ahead accumulators live across super columns: behind barrier (A) this wavefront has nothing to do but W21 / y,
+        // so it starts the NEXT super column's look-ahead there -- its tiles from P and their history over everything that is
+        // final already (columns < 4 J: the "old range") -- and only the 64 columns being solved right now are left for after
+        // chain a'.  (This wavefront's chain a -> look-ahead history -> solve -> chain b is what the others wait for at (A).)
+        v4d p20 = (v4d){0, 0, 0, 0}, p21 = p20, p30 = p20, p31 = p20, e11 = p20, e21 = p20, e22 = p20;
+        bool la_ready = false;                   // the accumulators hold super column J's tiles already (+ la_done half-chunks of history)
+        int la_done = 0;
+        const unsigned voff = (unsigned)fo * 16u;
+        struct Frag { v2d b0, b1, a2, a3; };
+        // rank-k update of the seven tiles of super column Jc over half-chunks [k_lo, k_hi) (multiples of 4).  With `poll`, stops
+        // in front of the first group of four whose start finds the others waiting at barrier (B) (flag[3] >= arrived);
+        // returns the first half-chunk not accumulated.
+        auto la1_ring = [&](int Jc, int k_lo, int k_hi, bool poll, int arrived) -> int {
+            const int tAc = 4 * Jc;
+            const bool v3c = tAc + 3 < ntr;
+            const char* q0 = uniform_ptr(tile2(tAc, 0));
+            const char* q1 = uniform_ptr(tile2(tAc + 1, 0));
+            const char* q2 = uniform_ptr(tile2(tAc + 2, 0));
+            const char* q3 = uniform_ptr(tile2(v3c ? tAc + 3 : tAc + 2, 0));
+            const int klast = k_hi - 1;
+            auto loadf = [&](Frag& f_, int k2) {
+                const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+                f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
+                f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
+            };
+#define HIPDRT_STEP7(B0, B1, A2, A3)                                                                    \
+            p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);                       \
+            p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);                       \
+            e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);                       \
+            if (v3c) {                                                                              \
+                p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);                   \
+                p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);                   \
+                e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);                   \
+                e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);                   \
+            }
+            auto multf = [&](const Frag& f_) {
+                HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
+                HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#undef HIPDRT_STEP7
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // whatever was in flight: from here on the count is ours
+            __builtin_amdgcn_sched_barrier(0);
+            Frag f0, f1, f2, f3;
+            loadf(f0, k_lo); loadf(f1, k_lo + 1); loadf(f2, k_lo + 2);
+            int k2 = k_lo;
+            for (; k2 < k_hi; k2 += 4) {
+                if (poll && lds_peek32(&sm.flag[3]) >= arrived) break;
+                loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
+                loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
+                loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
+                loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
+            }
+            vm_wait<0>();
+            return k2;
+        };
         for (int J = 0; J < nsup; ++J) {
             const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J;
             const bool hasb = (2 * J + 1) < nblk;
             const int R2 = tA + 2, R3 = tA + 3;
             const bool v3 = R3 < ntr;
             PROF_DECL
+#ifdef HIPDRT_QP_PROFILE
+            const unsigned long long _jt0 = __builtin_amdgcn_s_memtime();      // slots 26 + J: the whole super column, by J
+#endif
             // ---- chain a ------------------------------------------------------------------------------------------
             bool ok = cholinv16_dsc(j0a, 0);
             PROF(12);
@@ -1113,58 +1168,15 @@ struct OpsResidentT {
             v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
             if (hasb) {
                 // ---- look-ahead of block b: rows R2, R3 in columns a, diagonal block b ------------------------------
-                v4d p20, p21, p30, p31, e11, e21, e22;
-                if (have_pre) {
-                    p20 = tile_image(pre[0], R2, tA, li, kq);      p21 = tile_image(pre[1], R2, tA + 1, li, kq);
-                    p30 = tile_image(pre[2], R3, tA, li, kq);      p31 = tile_image(pre[3], R3, tA + 1, li, kq);
-                    e11 = tile_image(pre[4], R2, R2, li, kq);      e21 = tile_image(pre[5], R3, R2, li, kq);
-                    e22 = tile_image(pre[6], R3, R3, li, kq);
-                } else {
+                if (!la_ready) {                 // (super column 0, or no early start: tiles straight from P)
                     p20 = init_tile(R2, tA, ntr, fo, li, kq);      p21 = init_tile(R2, tA + 1, ntr, fo, li, kq);
                     p30 = init_tile(R3, tA, ntr, fo, li, kq);      p31 = init_tile(R3, tA + 1, ntr, fo, li, kq);
                     e11 = init_tile(R2, R2, ntr, fo, li, kq);      e21 = init_tile(R3, R2, ntr, fo, li, kq);
                     e22 = init_tile(R3, R3, ntr, fo, li, kq);
+                    la_done = 0;
                 }
                 if (J > 0) {
-                    const char* q0 = uniform_ptr(tile2(tA, 0));
-                    const char* q1 = uniform_ptr(tile2(tA + 1, 0));
-                    const char* q2 = uniform_ptr(tile2(R2, 0));
-                    const char* q3 = uniform_ptr(tile2(v3 ? R3 : R2, 0));
-                    const unsigned voff = (unsigned)fo * 16u;
-                    struct Frag { v2d b0, b1, a2, a3; };
-                    const int nk2 = 8 * J, klast = nk2 - 1;
-                    auto loadf = [&](Frag& f_, int k2) {
-                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-                        f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
-                        f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
-                    };
-#define HIPDRT_STEP7(B0, B1, A2, A3)                                                                    \
-                    p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);               \
-                    p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);               \
-                    e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);               \
-                    if (v3) {                                                                       \
-                        p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);           \
-                        p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);           \
-                        e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);           \
-                        e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);           \
-                    }
-                    auto multf = [&](const Frag& f_) {
-                        HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
-                        HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-#undef HIPDRT_STEP7
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
-                    __builtin_amdgcn_sched_barrier(0);
-                    Frag f0, f1, f2, f3;
-                    loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
-                    for (int k2 = 0; k2 < nk2; k2 += 4) {           // nk2 = 8 J: a multiple of 4
-                        loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
-                        loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
-                        loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
-                        loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
-                    }
-                    vm_wait<0>();
+                    if (la_done < 8 * J) la1_ring(J, la_done, 8 * J, false, 0);      // what is left: normally the last 64 columns
                     if (!v3) {
                         p30 = (v4d){0, 0, 0, 0}; p31 = (v4d){0, 0, 0, 0}; e21 = (v4d){0, 0, 0, 0};
                         e22 = init_tile(R3, R3, ntr, fo, li, kq);
@@ -1224,7 +1236,6 @@ struct OpsResidentT {
             __syncthreads();                                    // (A)
             PROF2(1, 16 + (J < 23 ? J : 23));
             if (sm.flag[0]) return false;
-            have_pre = false;
             // ---- finish_later: what of the two chains nobody needed before (A).  The others' updates of the right-hand side
             // wait for the word flag[2] (2 J + 1: y_a is in vec, 2 J + 2: y_b), which they reach long after it is set.
             {
@@ -1243,22 +1254,34 @@ struct OpsResidentT {
                 }
             }
             PROF(43);
+            // ---- early start of the next super column's look-ahead (tile rows tA+6, tA+7): source tiles, then the old range of
+            // their history, until it is done or the other wavefronts stand at barrier (B) -- then (B) first, the rest after
+            bool at_b = false;
+            la_ready = false;
 #if HIPDRT_QP_PREFETCH_CHAIN
-            // source tiles of the next super column's look-ahead rows: in flight through the others' panel solves and chain a'
-            {
-                // (requested unconditionally, from a stand-in tile when there is no next block b: a conditional definition would
-                // keep the previous super column's tiles alive -- through the operand ring -- on the path that skips it)
-                have_pre = 2 * J + 3 < nblk;
-                const int N2 = have_pre ? tA + 6 : 0, N3 = have_pre ? tA + 7 : 0, cA = have_pre ? tA + 4 : 0;
-                const int D2 = have_pre ? N2 : 0;
-                pre[0] = tile_src(N2, cA, ntr, fo); pre[1] = tile_src(N2, have_pre ? cA + 1 : 0, ntr, fo);
-                pre[2] = tile_src(N3, cA, ntr, fo); pre[3] = tile_src(N3, have_pre ? cA + 1 : 0, ntr, fo);
-                pre[4] = tile_src(N2, D2, ntr, fo); pre[5] = tile_src(N3, D2, ntr, fo);
-                pre[6] = tile_src(N3, have_pre ? N3 : 0, ntr, fo);
+            if (2 * J + 3 < nblk) {
+                const int N2 = tA + 6, N3 = tA + 7, cA = tA + 4;
+                p20 = init_tile(N2, cA, ntr, fo, li, kq);      p21 = init_tile(N2, cA + 1, ntr, fo, li, kq);
+                p30 = init_tile(N3, cA, ntr, fo, li, kq);      p31 = init_tile(N3, cA + 1, ntr, fo, li, kq);
+                e11 = init_tile(N2, N2, ntr, fo, li, kq);      e21 = init_tile(N3, N2, ntr, fo, li, kq);
+                e22 = init_tile(N3, N3, ntr, fo, li, kq);
+                la_ready = true;
+                la_done = 0;
+                const int kend = 8 * J;          // columns < 4 J are final; this super column's own 64 columns are being solved now
+                while (la_done < kend) {
+                    la_done = la1_ring(J + 1, la_done, kend, !at_b, 7 * (J + 1));
+                    if (la_done < kend && !at_b) {
+                        __syncthreads();                        // (B): everybody else is there
+                        at_b = true;
+                    }
+                }
             }
 #endif
-            __syncthreads();                                    // (B)
+            if (!at_b) __syncthreads();                         // (B)
             PROF(4);
+#ifdef HIPDRT_QP_PROFILE
+            if (threadIdx.x == 0 && blockIdx.x == 0 && J < 14) atomicAdd(&g_qp_prof[26 + J], __builtin_amdgcn_s_memtime() - _jt0);
+#endif
         }
         return true;
     }
@@ -1382,9 +1405,11 @@ struct OpsResidentT {
                 if (v3) store_pair(Q3, tA, xa[1][0], xa[1][1], fo);
                 // block a's rank-32 update of the column-b tiles and of the next diagonal block, from registers
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int st = 0; st < 8; ++st)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) upd_b(cb[r][c], bf, c, xa[r][0], xa[r][1]);
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) upd_b_step(cb[r][c], bf, c, xa[r][0], xa[r][1], st);
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -1446,6 +1471,7 @@ struct OpsResidentT {
                 __syncthreads();                                // (A)
                 if (sm.flag[0]) return false;
             }
+            if (lane == 0) __hip_atomic_fetch_add(&sm.flag[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (wavefront 0 polls it)
             __syncthreads();                                    // (B)
         }
         return true;
@@ -1598,10 +1624,12 @@ struct OpsResidentT {
                     for (int u = 0; u < RM; ++u)
                         if (act[u]) store_pair(T[u], tA, x1[u], x2[u], fo);
 #pragma unroll
-                    for (int u = 0; u < RM; ++u) {
-                        upd_b(acc[u][2], bf, 0, x1[u], x2[u]);
-                        upd_b(acc[u][3], bf, 1, x1[u], x2[u]);
-                    }
+                    for (int st = 0; st < 8; ++st)
+#pragma unroll
+                        for (int u = 0; u < RM; ++u) {
+                            upd_b_step(acc[u][2], bf, 0, x1[u], x2[u], st);
+                            upd_b_step(acc[u][3], bf, 1, x1[u], x2[u], st);
+                        }
                     wait_y(2 * J + 1);
 #pragma unroll
                     for (int u = 0; u < RM; ++u)
@@ -1652,6 +1680,7 @@ struct OpsResidentT {
                 }
             }
 #endif
+            if (lane == 0) __hip_atomic_fetch_add(&sm.flag[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (wavefront 0 polls it)
             __syncthreads();                                        // (B)
         }
         return true;

@@ -356,7 +356,7 @@ def test_distribution_variance_beyond_2048_unknowns():
     var, ok = drt.estimate_distribution_var_batch(tau=sup)
     assert ok.all() and var.shape == (1, 40) and np.all(var >= 0)
     ref = orc.estimate_distribution_var(drt._plan.p_matrix(0), tau, sup, drt.tau_epsilon, 2, res["coefficient_scale"][0])
-    parity_close("dist_var_n2500", var[0], ref, 1e-7)
+    parity_close("dist_var_n2500", var[0], ref, 1e-8)        # measured 6.6e-10
 
 
 def test_warm_restarts_and_candidates_vs_reference_fixture():

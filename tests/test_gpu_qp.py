@@ -1,6 +1,7 @@
 """GPU parity of the weighted normal equations and the batched coneqp kernel against the oracle and the QPs
 captured from the reference run (P, q, h -> x, iterations)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -270,3 +271,53 @@ def test_group_kernel_reports_breakdown():
     P[700, 700] = -5.0
     res = ctx.qp_batch(P[None], np.ones((1, n)), np.zeros(n))
     assert res["status"][0] < 0
+
+
+@pytest.mark.timeout(600)
+def test_group_launches_beside_a_batch_launch_that_fills_the_chip():
+    """Co-residency is a precondition of the several-workgroups-per-problem kernel, and the device is shared: while another
+    context's stream keeps every CU busy with 1024-problem batch launches (one workgroup per problem, whole LDS and register
+    file of its CU), group launches from this context must neither hang nor trap -- their members either become resident
+    together or the launch gives up cleanly and is repeated with one member per problem (qp_group.hpp, start rendezvous) --
+    and must return the bits of the uncontended launch (results do not depend on the group size)."""
+    import threading
+    from hipdrt import _ffi, synth
+    from hipdrt.models import DRT
+    rng = np.random.default_rng(5)
+    n = 600
+    Ps, qs = zip(*[_random_qp(n, rng) for _ in range(2)])
+    Ps, qs = np.array(Ps), np.array(qs)
+    h = np.zeros(n)
+    ctx = _ffi.get_context()
+    quiet = ctx.qp_batch(Ps, qs, h)                    # nothing else running: the library's own choice (group kernel, 2 problems)
+    c2 = synth.config_c2()
+    z = synth.zarc2_batch(c2["freq"], 1024, first_seed=100)
+    hog = DRT(fixed_basis_tau=c2["tau"], context=_ffi.Context(0))
+    hog_plan = hog.stage_batch(c2["freq"], z)
+    hog_plan.set_subbatches(1)
+    stop, errors, steps = threading.Event(), [], [0]
+
+    def keep_busy():
+        try:
+            while not stop.is_set():
+                hog.fit_staged()                       # ~0.5 s of back-to-back full-chip launches per call
+                steps[0] += 1
+        except BaseException as exc:                   # noqa: BLE001 -- reported in the main thread
+            errors.append(exc)
+
+    t = threading.Thread(target=keep_busy)
+    t.start()
+    try:
+        outs = []
+        while steps[0] < 1 and t.is_alive():           # the first batch fit is under way
+            time.sleep(0.01)
+        for _ in range(6):
+            outs.append(ctx.qp_batch(Ps, qs, h))
+    finally:
+        stop.set()
+        t.join()
+    assert not errors, errors
+    assert steps[0] >= 1
+    for o in outs:
+        assert o["status"].tolist() == quiet["status"].tolist() and o["iterations"].tolist() == quiet["iterations"].tolist()
+        np.testing.assert_array_equal(o["x"], quiet["x"])

@@ -27,13 +27,11 @@ if prof[13]:
 chain = prof[12] + prof[14] + prof[15]
 print("diagonal chain", round(chain / tot, 3), "(cholinv1", prof[12], "l21+d2", prof[14], "cholinv2", prof[15], ")",
       "=> rank-k phase", round((chain + prof[1]) / tot, 3))
-# factor64 (round 4): wavefront 0's timeline per super column -- chain a, history of the next diagonal block, barrier (A1),
-# barrier (A2) (wavefront 1 runs chain b meanwhile), barrier (B), then the next diagonal block's last 64 columns + staging
+# factor64 (round 4): wavefront 0's timeline per super column -- chain a, look-ahead history of block b, its solve, chain b, barrier (A),
+# W21 / y behind (A), barrier (B)
 f = lambda i: round(prof[i] / tot, 3)
-print("factor64, wavefront 0: chain a", round(f(12) + f(14) + f(15), 3), "| history of the next diagonal block", f(40), "| wait at (A1)", f(1),
-      "| (A1) -> (A2): panel solves a + chain b on wavefront 1", f(42), "| (A2) -> (B): panel solves b", f(4),
-      "| next diagonal block from L + staging", f(41))
+print("factor64, wavefront 0: chain a", round(f(12) + f(14) + f(15), 3), "| look-ahead history (rows tA+2, tA+3)", f(40), "| its solve + diagonal update", f(41),
+      "| chain b", f(42), "| wait at (A)", f(1), "| W21, y_a, y_b behind (A)", f(43), "| rest of (A) -> (B): everybody's panel solves", f(4))
 nf = max(prof[11], 1)
-print("wait at (A1) by super column, ticks per factorisation:", [int(v / nf) for v in prof[16:40] if v])
-print("wavefront 2 (rows): history ring", f(26), "| wait (A1)", f(27), "| solve a + update b", f(28), "| wait (A2)", f(29), "| solve b (+ later passes)", f(30), "| wait (B)", f(31))
-print("wavefront 1: history ring", f(32), "| wait (A1)", f(33), "| solve + diagonal update", f(34), "| chain b", f(35), "| wait (A2)", f(36), "| prefetch + wait (B)", f(37))
+print("wait at (A) by super column, ticks per factorisation:", [int(v / nf) for v in prof[16:25]])
+print("whole super column by J, ticks per factorisation:", [int(v / nf) for v in prof[26:40] if v])

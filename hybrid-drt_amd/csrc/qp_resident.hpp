@@ -915,6 +915,12 @@ struct OpsResidentT {
     //   triangular sweeps only) and y_a, y_b of the fused forward substitution (used by the right-hand-side updates at the end
     //   of the panel solves) -- wavefront 0 computes behind (A), where it has nothing else to do (finish_later); the others'
     //   updates of the right-hand side wait for an LDS word that is set long before they get there.
+    //   Behind that, still before (B), wavefront 0 already STARTS super column J+1's look-ahead (tile rows tA+6, tA+7): source
+    //   tiles from P, then the part of their history that is final (columns < 4 J; this super column's own 64 columns are
+    //   being solved by the others right now).  The other seven wavefronts count themselves into the LDS word flag[3] before
+    //   they enter (B); wavefront 0 polls it between ring steps and takes (B) as soon as all seven stand there, finishing the
+    //   old range afterwards -- so nobody ever waits at (B) for the early work, and the next super column's look-ahead has only
+    //   the 64 new columns left (8.375 -> 8.34 ms per launch; profiles/r04o_*).
     // Other divisions of the sequential work were built and measured (all bit-identical, tools/experiments/
     // qp_factor64_roles_v3.hpp, profiles/r04e_*, r04g_*): chain b on wavefront 1 behind a second barrier with wavefront 0 taking the
     // heavier look-ahead rows (9.30 ms per launch), and wavefront 0 with the chains + the next diagonal block only, rows tA+4,
@@ -985,6 +991,25 @@ struct OpsResidentT {
     __device__ __forceinline__ void wait_y(int word) const {
         int spins = 0;
         while (lds_peek32(&sm.flag[2]) < word) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) __builtin_trap();           // (a protocol error must not hang the device)
+        }
+    }
+    // Barrier (B) in two halves (HIPDRT_QP_SPLITB): a wavefront that has stored its tiles of super column J counts itself into
+    // flag[3] (release) and goes straight on to super column J + 1 -- source tiles, then the part of the history that is final
+    // already -- and waits for the other six (seven for wavefront 0, which stores nothing behind (A)) only in front of its
+    // first load from the 64 columns just solved.  No s_barrier: who finishes its panel solves early is not held up by who
+    // finishes late, and the phases of the wavefronts on one SIMD drift apart (one in its MFMA-bound history pass, the other
+    // in its latency-bound panel solves) instead of coinciding.
+#ifndef HIPDRT_QP_SPLITB
+#define HIPDRT_QP_SPLITB 1
+#endif
+    __device__ __forceinline__ void arrive_b(int lane) {
+        if (lane == 0) __hip_atomic_fetch_add(&sm.flag[3], 1, HIPDRT_QP_SPLITB ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void wait_b(int J_) const {        // everybody's tiles of super column J_ are stored
+        int spins = 0;
+        while (lds_peek32(&sm.flag[3]) < 7 * (J_ + 1)) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 22)) __builtin_trap();           // (a protocol error must not hang the device)
         }
@@ -1064,9 +1089,16 @@ struct OpsResidentT {
             if (lane == 0) { sm.flag[2] = 0; sm.flag[3] = 0; }
         }
         __syncthreads();
+#if HIPDRT_QP_SPLITB
+        // (no barrier (B) behind the last super column either: everybody's tiles are stored before anybody starts a sweep)
+        const bool ok = wv == 0 ? f64_chain() : (wv == 1 ? f64_look2() : f64_rows(wv));
+        __syncthreads();
+        return ok;
+#else
         if (wv == 0) return f64_chain();
         if (wv == 1) return f64_look2();
         return f64_rows(wv);
+#endif
     }
 
     // ======== wavefront 0: both chains of a super column and, between them, the look-ahead of block b ====================
@@ -1271,13 +1303,19 @@ struct OpsResidentT {
                 while (la_done < kend) {
                     la_done = la1_ring(J + 1, la_done, kend, !at_b, 7 * (J + 1));
                     if (la_done < kend && !at_b) {
+#if !HIPDRT_QP_SPLITB
                         __syncthreads();                        // (B): everybody else is there
+#endif
                         at_b = true;
                     }
                 }
             }
 #endif
+#if HIPDRT_QP_SPLITB
+            if (!at_b) wait_b(J);                               // (B), this wavefront's half: the next chain overwrites t21 / img
+#else
             if (!at_b) __syncthreads();                         // (B)
+#endif
             PROF(4);
 #ifdef HIPDRT_QP_PROFILE
             if (threadIdx.x == 0 && blockIdx.x == 0 && J < 14) atomicAdd(&g_qp_prof[26 + J], __builtin_amdgcn_s_memtime() - _jt0);
@@ -1363,8 +1401,16 @@ struct OpsResidentT {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     Frag f0, f1, f2, f3;
+#if HIPDRT_QP_SPLITB
+                    const int knew = nk2 - 8;                   // first half-chunk of the 64 columns solved in super column J - 1
+                    bool arrived = false;
+                    if (knew <= 2) { wait_b(J - 1); arrived = true; }
+#endif
                     loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
                     for (int k2 = 0; k2 < nk2; k2 += 4) {
+#if HIPDRT_QP_SPLITB
+                        if (!arrived && k2 + 6 >= knew) { wait_b(J - 1); arrived = true; }
+#endif
                         loadf(f3, k2 + 3); vm_wait<18>(); multf(f0);
                         loadf(f0, k2 + 4); vm_wait<18>(); multf(f1);
                         loadf(f1, k2 + 5); vm_wait<18>(); multf(f2);
@@ -1471,8 +1517,10 @@ struct OpsResidentT {
                 __syncthreads();                                // (A)
                 if (sm.flag[0]) return false;
             }
-            if (lane == 0) __hip_atomic_fetch_add(&sm.flag[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (wavefront 0 polls it)
+            arrive_b(lane);
+#if !HIPDRT_QP_SPLITB
             __syncthreads();                                    // (B)
+#endif
         }
         return true;
     }
@@ -1584,8 +1632,16 @@ struct OpsResidentT {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
                     __builtin_amdgcn_sched_barrier(0);
                     SlB b0, b1;
+#if HIPDRT_QP_SPLITB
+                    const int knew = nk2 - 8;                   // first half-chunk of the 64 columns solved in super column J - 1
+                    bool arrived = ps > 0;                      // (a later pass starts behind (A))
+                    if (!arrived && knew <= 2) { wait_b(J - 1); arrived = true; }
+#endif
                     loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
                     for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 8 J: a multiple of 4
+#if HIPDRT_QP_SPLITB
+                        if (!arrived && k2 + 6 >= knew) { wait_b(J - 1); arrived = true; }
+#endif
                         loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RM + 4>(); mult(a0, b0);
                         loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * RM + 4>(); mult(a1, b1);
                         loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RM + 4>(); mult(a2, b0);
@@ -1598,6 +1654,11 @@ struct OpsResidentT {
                     if (sm.flag[0]) return false;
                 }
                 if (act[0]) {
+                    // (rows are dealt in order: a wavefront with fewer than RM rows in this pass skips the absent rows' MFMAs --
+                    // in the last super columns most wavefronts hold one row)
+                    int na = 1;
+#pragma unroll
+                    for (int u = 1; u < RM; ++u) if (act[u]) na = u + 1;
                     BFrag bf;
                     load_bfrag(bf, tA, true, fo);               // (rows tA+2, tA+3 are valid whenever there are rows here)
                     v4d x1[RM], x2[RM];
@@ -1610,15 +1671,15 @@ struct OpsResidentT {
 #pragma unroll
                         for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                            for (int u = 0; u < RM; ++u) x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
+                            for (int u = 0; u < RM; ++u) if (u < na) x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
 #pragma unroll
                         for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                            for (int u = 0; u < RM; ++u) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
+                            for (int u = 0; u < RM; ++u) if (u < na) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
 #pragma unroll
                         for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                            for (int u = 0; u < RM; ++u) x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
+                            for (int u = 0; u < RM; ++u) if (u < na) x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
                     }
 #pragma unroll
                     for (int u = 0; u < RM; ++u)
@@ -1626,10 +1687,11 @@ struct OpsResidentT {
 #pragma unroll
                     for (int st = 0; st < 8; ++st)
 #pragma unroll
-                        for (int u = 0; u < RM; ++u) {
-                            upd_b_step(acc[u][2], bf, 0, x1[u], x2[u], st);
-                            upd_b_step(acc[u][3], bf, 1, x1[u], x2[u], st);
-                        }
+                        for (int u = 0; u < RM; ++u)
+                            if (u < na) {
+                                upd_b_step(acc[u][2], bf, 0, x1[u], x2[u], st);
+                                upd_b_step(acc[u][3], bf, 1, x1[u], x2[u], st);
+                            }
                     wait_y(2 * J + 1);
 #pragma unroll
                     for (int u = 0; u < RM; ++u)
@@ -1643,15 +1705,15 @@ struct OpsResidentT {
 #pragma unroll
                         for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                            for (int u = 0; u < RM; ++u) x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][2][s_], x1[u], 0, 0, 0);
+                            for (int u = 0; u < RM; ++u) if (u < na) x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][2][s_], x1[u], 0, 0, 0);
 #pragma unroll
                         for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                            for (int u = 0; u < RM; ++u) acc[u][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][3], 0, 0, 0);
+                            for (int u = 0; u < RM; ++u) if (u < na) acc[u][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][3], 0, 0, 0);
 #pragma unroll
                         for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                            for (int u = 0; u < RM; ++u) x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][3][s_], x2[u], 0, 0, 0);
+                            for (int u = 0; u < RM; ++u) if (u < na) x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][3][s_], x2[u], 0, 0, 0);
                     }
 #pragma unroll
                     for (int u = 0; u < RM; ++u)
@@ -1680,8 +1742,10 @@ struct OpsResidentT {
                 }
             }
 #endif
-            if (lane == 0) __hip_atomic_fetch_add(&sm.flag[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (wavefront 0 polls it)
+            arrive_b(lane);
+#if !HIPDRT_QP_SPLITB
             __syncthreads();                                        // (B)
+#endif
         }
         return true;
     }

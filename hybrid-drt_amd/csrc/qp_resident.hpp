@@ -932,6 +932,12 @@ struct OpsResidentT {
 #ifndef HIPDRT_QP_RM
 #define HIPDRT_QP_RM 3
 #endif
+#ifndef HIPDRT_QP_LA1HELPER
+#define HIPDRT_QP_LA1HELPER 0          // the old range of wavefront 0's look-ahead history on a row wavefront (la1_helper): measured slower
+#endif
+#ifndef HIPDRT_QP_LA1HELPER_WAVE
+#define HIPDRT_QP_LA1HELPER_WAVE 5
+#endif
     static constexpr int RM = HIPDRT_QP_RM;      // tile rows per row wavefront and pass (x 4 tile columns = 12 accumulator tiles)
 #ifndef HIPDRT_QP_CHAINLOAD64
 #define HIPDRT_QP_CHAINLOAD64 0
@@ -948,11 +954,24 @@ struct OpsResidentT {
 #ifndef HIPDRT_QP_LA1LOAD
 #define HIPDRT_QP_LA1LOAD 14         // MFMAs per half-chunk charged to SIMD 0 for wavefront 0's look-ahead (part of it now runs behind (A))
 #endif
+#if HIPDRT_QP_LA1HELPER
+            // (wavefront 0 keeps the last 64 columns of its look-ahead history; the rest of super column J + 1's is accumulated
+            // during this one by wavefront HIPDRT_QP_LA1HELPER_WAVE -- la1_helper)
+            int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 2 < ntr) ? HIPDRT_QP_LA1LOAD * (nk2 < 8 ? nk2 : 8) + 48 : 0);
+            const int lh = (J >= 1 && 2 * J + 3 < nblk) ? HIPDRT_QP_LA1LOAD * nk2 : 0;
+#else
             int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 2 < ntr) ? HIPDRT_QP_LA1LOAD * nk2 + 48 : 0);
+#endif
 #ifndef HIPDRT_QP_LA2LOAD
 #define HIPDRT_QP_LA2LOAD 22
 #endif
             int l1 = (tA + 4 < ntr) ? HIPDRT_QP_LA2LOAD * nk2 + 96 : 0, l2 = 0, l3 = 0;
+#if HIPDRT_QP_LA1HELPER
+            if ((HIPDRT_QP_LA1HELPER_WAVE & 3) == 0) l0 += lh;
+            else if ((HIPDRT_QP_LA1HELPER_WAVE & 3) == 1) l1 += lh;
+            else if ((HIPDRT_QP_LA1HELPER_WAVE & 3) == 2) l2 += lh;
+            else l3 += lh;
+#endif
             int c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
             for (int r = 0; r < nsq; ++r) {
                 const int w2 = c2 <= c6 ? 2 : 6, n2 = c2 <= c6 ? c2 : c6;
@@ -1086,7 +1105,7 @@ struct OpsResidentT {
             stage_dsc(d11);
             img21[lane] = d21;
             img21[64 + lane] = d22;
-            if (lane == 0) { sm.flag[2] = 0; sm.flag[3] = 0; }
+            if (lane == 0) { sm.flag[1] = 0; sm.flag[2] = 0; sm.flag[3] = 0; }
         }
         __syncthreads();
 #if HIPDRT_QP_SPLITB
@@ -1099,6 +1118,80 @@ struct OpsResidentT {
         if (wv == 1) return f64_look2();
         return f64_rows(wv);
 #endif
+    }
+
+    // ======== look-ahead helper (HIPDRT_QP_LA1HELPER) =====================================================================
+    // Wavefront 0's look-ahead tiles (rows R2 = 4 Jn + 2, R3 = 4 Jn + 3 of super column Jn: four panel tiles in columns a, the three
+    // tiles of diagonal block b) need their whole history before chain b can start, and wavefront 0 is the one everybody waits for at
+    // (A): with the history on wavefront 0 itself -- even started early, behind (A) of the super column before -- its MFMA-bound
+    // operand ring (shared SIMD) sat in series with the two latency-bound chains, ~40 % of a middle super column.  So the part of
+    // that history that is final a whole super column earlier, columns < 4 (Jn - 1), is accumulated by wavefront 4 (the row
+    // wavefront on wavefront 0's SIMD, which the schedule charges for it anyway) at the START of super column Jn - 1, and
+    // handed over through memory: the seven accumulators' register images go to seven unused tiles of L's upper triangle
+    // (tile row Jn & 1), the LDS word flag[1] = Jn says they are there.  Wavefront 0 picks them up behind chain a of Jn and adds
+    // the last 64 columns itself.  Each accumulator still receives its source tile and then the history chunks in ascending
+    // order, the same MFMA sequence: bit for bit the same tiles (tools/dump_fit.py --cmp).
+    // MEASURED, NOT THE DEFAULT (profiles/r04y_*, r04z_*): 8.10 ms per launch without it; with the helper on wavefront 4 8.56 ms
+    // (its seven-MFMA ring steps saturate SIMD 0's matrix pipe and the first inversion of chain a takes 15.4 k cycles instead
+    // of 5.9 k), on wavefront 5 8.61 ms, on wavefront 6 8.43 ms (the chain is back to its pace and super column 3 drops from
+    // 112 k to 96 k cycles, but the helper's SIMD now finishes its panel solves 15 - 20 k cycles later in super columns 4 and 5
+    // and everybody waits for that at (B)).  The matrix pipes are the bound either way: moving the ring only moves the queue.
+    __device__ __forceinline__ v4d* la1_slot(int Jn, int k) const {          // k = 0 .. 6
+        const int par = Jn & 1;
+        return reinterpret_cast<v4d*>(const_cast<double2*>(tile2(par, par + 2 + k)));
+    }
+    __device__ __forceinline__ void la1_helper(int Jn, int lane, int li, int kq, int fo, int ntr) {
+        const int tAc = 4 * Jn, R2 = tAc + 2, R3 = tAc + 3;
+        const bool v3c = R3 < ntr;
+        v4d p20 = init_tile(R2, tAc, ntr, fo, li, kq), p21 = init_tile(R2, tAc + 1, ntr, fo, li, kq);
+        v4d p30 = init_tile(R3, tAc, ntr, fo, li, kq), p31 = init_tile(R3, tAc + 1, ntr, fo, li, kq);
+        v4d e11 = init_tile(R2, R2, ntr, fo, li, kq), e21 = init_tile(R3, R2, ntr, fo, li, kq);
+        v4d e22 = init_tile(R3, R3, ntr, fo, li, kq);
+        const char* q0 = uniform_ptr(tile2(tAc, 0));
+        const char* q1 = uniform_ptr(tile2(tAc + 1, 0));
+        const char* q2 = uniform_ptr(tile2(R2, 0));
+        const char* q3 = uniform_ptr(tile2(v3c ? R3 : R2, 0));
+        const unsigned voff = (unsigned)fo * 16u;
+        const int kend = 8 * (Jn - 1), klast = kend - 1, knew = kend - 8;      // [knew, kend): the columns of super column Jn - 2
+        struct Frag { v2d b0, b1, a2, a3; };
+        auto loadf = [&](Frag& f_, int k2) {
+            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+            f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
+            f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
+        };
+#define HIPDRT_STEP7(B0, B1, A2, A3)                                                                \
+        p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);                       \
+        p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);                       \
+        e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);                       \
+        if (v3c) {                                                                              \
+            p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);                   \
+            p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);                   \
+            e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);                   \
+            e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);                   \
+        }
+        auto multf = [&](const Frag& f_) {
+            HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
+            HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#undef HIPDRT_STEP7
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the source tiles: from here on the count is ours
+        __builtin_amdgcn_sched_barrier(0);
+        bool arrived = false;
+        if (knew <= 2) { wait_b(Jn - 2); arrived = true; }
+        Frag f0, f1, f2, f3;
+        loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
+        for (int k2 = 0; k2 < kend; k2 += 4) {
+            if (!arrived && k2 + 6 >= knew) { wait_b(Jn - 2); arrived = true; }
+            loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
+            loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
+            loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
+            loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
+        }
+        vm_wait<0>();
+        la1_slot(Jn, 0)[lane] = p20; la1_slot(Jn, 1)[lane] = p21; la1_slot(Jn, 2)[lane] = p30; la1_slot(Jn, 3)[lane] = p31;
+        la1_slot(Jn, 4)[lane] = e11; la1_slot(Jn, 5)[lane] = e21; la1_slot(Jn, 6)[lane] = e22;
+        if (lane == 0) __hip_atomic_store(&sm.flag[1], Jn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
     // ======== wavefront 0: both chains of a super column and, between them, the look-ahead of block b ====================
@@ -1200,6 +1293,19 @@ struct OpsResidentT {
             v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
             if (hasb) {
                 // ---- look-ahead of block b: rows R2, R3 in columns a, diagonal block b ------------------------------
+#if HIPDRT_QP_LA1HELPER
+                if (J >= 2) {                    // wavefront 4 accumulated everything up to the last 64 columns (la1_helper)
+                    int spins = 0;
+                    while (lds_peek32(&sm.flag[1]) < J) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1 << 22)) __builtin_trap();
+                    }
+                    p20 = la1_slot(J, 0)[lane]; p21 = la1_slot(J, 1)[lane]; p30 = la1_slot(J, 2)[lane]; p31 = la1_slot(J, 3)[lane];
+                    e11 = la1_slot(J, 4)[lane]; e21 = la1_slot(J, 5)[lane]; e22 = la1_slot(J, 6)[lane];
+                    la_done = 8 * (J - 1);
+                    la_ready = true;
+                }
+#endif
                 if (!la_ready) {                 // (super column 0, or no early start: tiles straight from P)
                     p20 = init_tile(R2, tA, ntr, fo, li, kq);      p21 = init_tile(R2, tA + 1, ntr, fo, li, kq);
                     p30 = init_tile(R3, tA, ntr, fo, li, kq);      p31 = init_tile(R3, tA + 1, ntr, fo, li, kq);
@@ -1266,7 +1372,14 @@ struct OpsResidentT {
             }
             if (lane == 0) sm.flag[0] = ok ? 0 : 1;
             __syncthreads();                                    // (A)
-            PROF2(1, 16 + (J < 23 ? J : 23));
+            PROF(1);
+#ifdef HIPDRT_QP_PROFILE
+            const unsigned long long _ta = __builtin_amdgcn_s_memtime();       // slots 16 + J: (A) -> everybody's arrival at (B), by J
+            unsigned long long _tarr = _ta;
+#define HIPDRT_PROF_ARRIVED() do { _tarr = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HIPDRT_PROF_ARRIVED()
+#endif
             if (sm.flag[0]) return false;
             // ---- finish_later: what of the two chains nobody needed before (A).  The others' updates of the right-hand side
             // wait for the word flag[2] (2 J + 1: y_a is in vec, 2 J + 2: y_b), which they reach long after it is set.
@@ -1290,7 +1403,7 @@ struct OpsResidentT {
             // their history, until it is done or the other wavefronts stand at barrier (B) -- then (B) first, the rest after
             bool at_b = false;
             la_ready = false;
-#if HIPDRT_QP_PREFETCH_CHAIN
+#if HIPDRT_QP_PREFETCH_CHAIN && !HIPDRT_QP_LA1HELPER
             if (2 * J + 3 < nblk) {
                 const int N2 = tA + 6, N3 = tA + 7, cA = tA + 4;
                 p20 = init_tile(N2, cA, ntr, fo, li, kq);      p21 = init_tile(N2, cA + 1, ntr, fo, li, kq);
@@ -1307,19 +1420,22 @@ struct OpsResidentT {
                         __syncthreads();                        // (B): everybody else is there
 #endif
                         at_b = true;
+                        HIPDRT_PROF_ARRIVED();
                     }
                 }
             }
 #endif
 #if HIPDRT_QP_SPLITB
-            if (!at_b) wait_b(J);                               // (B), this wavefront's half: the next chain overwrites t21 / img
+            if (!at_b) { wait_b(J); HIPDRT_PROF_ARRIVED(); }    // (B), this wavefront's half: the next chain overwrites t21 / img
 #else
             if (!at_b) __syncthreads();                         // (B)
 #endif
             PROF(4);
 #ifdef HIPDRT_QP_PROFILE
             if (threadIdx.x == 0 && blockIdx.x == 0 && J < 14) atomicAdd(&g_qp_prof[26 + J], __builtin_amdgcn_s_memtime() - _jt0);
+            if (threadIdx.x == 0 && blockIdx.x == 0 && J < 10) atomicAdd(&g_qp_prof[16 + J], _tarr - _ta);
 #endif
+#undef HIPDRT_PROF_ARRIVED
         }
         return true;
     }
@@ -1544,6 +1660,9 @@ struct OpsResidentT {
         };
         for (int J = 0; J < nsup; ++J) {
             const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
+#if HIPDRT_QP_LA1HELPER
+            if (wv == HIPDRT_QP_LA1HELPER_WAVE && J >= 1 && 2 * J + 3 < nblk) la1_helper(J + 1, lane, li, kq, fo, ntr);
+#endif
             unsigned long long m0, m1;
             my_rows(J, m0, m1);
             const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);

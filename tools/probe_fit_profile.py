@@ -33,5 +33,5 @@ f = lambda i: round(prof[i] / tot, 3)
 print("factor64, wavefront 0: chain a", round(f(12) + f(14) + f(15), 3), "| look-ahead history (rows tA+2, tA+3)", f(40), "| its solve + diagonal update", f(41),
       "| chain b", f(42), "| wait at (A)", f(1), "| W21, y_a, y_b behind (A)", f(43), "| rest of (A) -> (B): everybody's panel solves", f(4))
 nf = max(prof[11], 1)
-print("wait at (A) by super column, ticks per factorisation:", [int(v / nf) for v in prof[16:25]])
+print("(A) -> everybody has arrived at (B), as wavefront 0 sees it, by super column, ticks per factorisation:", [int(v / nf) for v in prof[16:25]])
 print("whole super column by J, ticks per factorisation:", [int(v / nf) for v in prof[26:40] if v])

@@ -1107,7 +1107,7 @@ static int subbatch_count(const hipdrt_plan* p) {
     if (p->prepared || p->hist_b >= 0 || p->has_weight_factors() || p->opts.outlier_p > 0.0 || p->qp_G != 0 || p->premv.p) return 1;
     if (p->subbatches >= 1) return std::min(p->subbatches, std::max(1, p->B / 64));
     // measured on one MI355X (profiles/r04_subbatch_sweep.txt): ranges below ~300 spectra lose to launch-wave quantisation
-    // (fits/s with k = 1 / 2 / 3 / 4 ranges: 1024 spectra 1699 / 1885 / 1891 / 1485, 1250: 1781 / 1974 / 1979 / 1608, 2500: 1987 / 2121 / 2149 / 1876)
+    // (fits/s with k = 1 / 2 / 3 / 4 ranges: 1024 spectra 1902 / 2110 / 2106 / 1660, 1250: 2001 / 2205 / 2219 / 1796, 2500: 2229 / 2375 / 2408 / 2104)
     return p->B >= 1200 ? 3 : (p->B >= 600 ? 2 : 1);
 }
 

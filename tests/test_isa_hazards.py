@@ -76,3 +76,36 @@ def test_hand_issued_loads_are_outside_the_sgpr_hazard_shadow(tmp_path, extra):
     found = mod.scan(txt)
     assert not found, "hand-issued loads behind a VALU-written scalar base:\n" + "\n".join(
         "%s | %s | s%d %d wait states" % (n[:50], l, s_, age) for n, l, s_, age in found[:10])
+
+
+def _instructions(body):
+    return [ln.strip() for ln in body.split("\n")
+            if ln.strip() and not ln.strip().startswith((";", ".", "//")) and not ln.strip().endswith(":")]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_group_barrier_drains_vector_stores_before_the_arrival(tmp_path):
+    """qp_group.hpp group_sync(): the members of a group sit on different CUs, so every wavefront has to wait for its own vector
+    stores (`s_waitcnt vmcnt(0)`) in front of the workgroup barrier that precedes the member's arrival on the group counter --
+    a workgroup-scope `__syncthreads()` alone is `s_waitcnt lgkmcnt(0); s_barrier` on gfx950.  Checked on the assembly: every
+    arrival (the agent-scope add on gsync word 2) has a barrier in front of it, and between that barrier and the `vmcnt(0)` wait before
+    it there is neither a vector memory instruction nor a branch."""
+    src = os.path.join(ROOT, "hybrid-drt_amd", "csrc", "qp.hip")
+    out = tmp_path / "qp.s"
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
+                    "-S", "--cuda-device-only", src, "-o", str(out)], check=True, cwd=os.path.dirname(src),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    start = txt.index("_ZN6hipdrt15qp_kernel_groupENS_6QpArgsEii:")
+    ins = _instructions(txt[start:txt.index(".Lfunc_end", start)])
+    arrivals = [i for i, s_ in enumerate(ins) if s_.startswith("global_atomic_add") and s_.endswith("offset:8")]
+    assert len(arrivals) >= 2, "the group arrival was not found in the assembly (gsync word 2 = byte offset 8)"
+    for i in arrivals:
+        b = max(j for j in range(i) if ins[j].startswith("s_barrier"))
+        # back from the barrier to the wait: nothing in between may touch vector memory (hipcc moves scalar bookkeeping there)
+        j = b - 1
+        while j >= 0 and not (ins[j].startswith("s_waitcnt") and "vmcnt(0)" in ins[j]):
+            assert not ins[j].startswith(("global_", "buffer_", "flat_", "scratch_")), (ins[j], "between the wait and the barrier")
+            assert not ins[j].startswith(("s_barrier", "s_cbranch", "s_branch")), ("no vmcnt(0) in front of the group barrier", ins[j - 3:b + 1])
+            j -= 1
+        assert j >= 0

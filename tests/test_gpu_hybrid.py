@@ -749,7 +749,7 @@ def test_randomised_joint_fits_with_option_combinations(seed):
     assert hx.shape == dx.shape
     parity_close("random_option_fits.hist_x", dx, hx, 5e-7, scale=np.abs(hx).max())           # measured 2.4e-8 over the 24 draws
     np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
-    parity_close("random_option_fits.rzm", qp["rm"], ref["rzm"], 1e-8)                        # measured 3.9e-10
+    parity_close("random_option_fits.rzm", qp["rm"], ref["rzm"], 1e-7)       # measured 3.9e-10 here, 1.6e-8 over 60 further seeds (tools/fuzz_parity.py)
 
 
 def test_uniform_chrono_variance_shortcut_is_bit_identical():

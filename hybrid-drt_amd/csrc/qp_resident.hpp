@@ -2018,8 +2018,11 @@ struct OpsResidentT {
             };
             auto fstep = [&](SweepBuf& B_, int jb) {
                 const int j0 = jb * NB, tb = 2 * jb, tbelow = ntr - (tb + 4);
+                PROFW(44);                                          // (PROFILE build, wavefronts 1..: arithmetic + requests | barrier | loads)
                 lds_barrier();
+                PROFW(45);
                 vm_wait_tiles(fcount(jb + 1));                      // this block's tiles are in; the next block's may be in flight
+                PROFW(46);
                 if (tbelow > 0) {
                     // q = 2*chunk + half: lane holds columns 8q + l4 and 8q + l4 + 4 of tile row g4
                     double ya[4], yb[4];

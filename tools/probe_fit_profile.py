@@ -35,3 +35,7 @@ print("factor64, wavefront 0: chain a", round(f(12) + f(14) + f(15), 3), "| look
 nf = max(prof[11], 1)
 print("(A) -> everybody has arrived at (B), as wavefront 0 sees it, by super column, ticks per factorisation:", [int(v / nf) for v in prof[16:25]])
 print("whole super column by J, ticks per factorisation:", [int(v / nf) for v in prof[26:40] if v])
+if prof[44] or prof[45] or prof[46]:
+    t = prof[44] + prof[45] + prof[46]
+    print("forward sweep, wavefronts 1..7 (sum over the seven, ticks per factorisation %d): arithmetic + requests %.2f | barrier %.2f | waiting for the block's tiles %.2f"
+          % (t / nf, prof[44] / t, prof[45] / t, prof[46] / t))

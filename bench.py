@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix-build", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the single-spectrum and config-5 timings")
+    ap.add_argument("--no-single-caller", action="store_true",
+                    help="skip the sub-batched one-caller leg (its launches are half-size: a rocprofv3 --stats average over a run "
+                         "with it is not the one-range launch's)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched without torch.distributed.run: this process -- which has not touched the GPU and never will -- starts
@@ -448,9 +451,10 @@ def main():
         single_elapsed = timed_c3(1, worker_resident)               # one batch in flight: un-overlapped launches
         qp_ms, qp_launch = stats[0]["qp_ms"], stats[0]["qp_launch"]
         phase = dict(stats[0]["phase"])
-        plans[0].set_subbatches(0)                                  # one caller, one plan, the library cuts the batch into ranges
-        one_caller_elapsed = timed_c3(1, worker_resident)
-        plans[0].set_subbatches(1)
+        if not args.no_single_caller:
+            plans[0].set_subbatches(0)                              # one caller, one plan, the library cuts the batch into ranges
+            one_caller_elapsed = timed_c3(1, worker_resident)
+            plans[0].set_subbatches(1)
         steps_in_stats = args.steps
         res = drt.collect_staged()
     else:

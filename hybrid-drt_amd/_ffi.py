@@ -373,6 +373,14 @@ class Context:
         _check(self._lib.hipdrt_qp_profile(self._h, buf, 64, int(reset)))
         return [int(v) for v in buf]
 
+    def qp_timeline(self):
+        """PROFILE builds: s_memtime stamps [wavefront 8][super column 16][stamp 8] of workgroup 0's last factorisation
+        (csrc/qp_common.hpp, g_qp_tl); zeros otherwise"""
+        n = 64 + 8 * 16 * 8
+        buf = (C.c_ulonglong * n)()
+        _check(self._lib.hipdrt_qp_profile(self._h, buf, n, 0))
+        return np.array(buf[64:], dtype=np.uint64).reshape(8, 16, 8)
+
     def weighted_gram(self, A, w, b, l2=None, l1=None):
         A, w, b = _f64(A), _f64(w), _f64(b)
         if w.ndim == 1:

@@ -76,7 +76,12 @@ int qp_profile_read(unsigned long long* out, int n, int reset) {
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_qp_prof), sizeof(h)) != hipSuccess) return -1;
     for (int i = 0; i < n; ++i) out[i] = i < QP_PROF_SLOTS ? h[i] : 0;
     if (reset) { unsigned long long z[QP_PROF_SLOTS] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qp_prof), z, sizeof(z)); }
-    if (n > QP_PROF_SLOTS && hyper_profile_read(out + QP_PROF_SLOTS, n - QP_PROF_SLOTS, reset) < 0) return -1;
+    if (n > QP_PROF_SLOTS && hyper_profile_read(out + QP_PROF_SLOTS, (n < 64 ? n : 64) - QP_PROF_SLOTS, reset) < 0) return -1;
+    if (n > 64) {            // behind the two kernels' phase counters: the factorisation time line (qp_common.hpp, g_qp_tl)
+        static unsigned long long tl[8 * QP_TL_J * QP_TL_K];
+        if (hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_qp_tl), sizeof(tl)) != hipSuccess) return -1;
+        for (int i = 64; i < n; ++i) out[i] = i - 64 < 8 * QP_TL_J * QP_TL_K ? tl[i - 64] : 0;
+    }
     return 1;
 #else
     for (int i = 0; i < n; ++i) out[i] = 0;

@@ -12,6 +12,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #ifdef HIPDRT_QP_PROFILE
 static constexpr int QP_PROF_SLOTS = 48;
 __device__ unsigned long long g_qp_prof[QP_PROF_SLOTS];
+// time line of workgroup 0's LAST factorisation (factor64): s_memtime of wavefront w in super column J at stamp k --
+// 0 start of the super column, 1 at barrier (A), 2 behind (A), 3 tiles stored (arrival at (B); wavefront 0: everybody's arrival seen),
+// wavefront 0 also 4 chain a done, 5 look-ahead history done, 6 look-ahead solve done, 7 W21 / y done
+static constexpr int QP_TL_J = 16, QP_TL_K = 8;
+__device__ unsigned long long g_qp_tl[8 * QP_TL_J * QP_TL_K];
+#define TL(w, J, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && (J) < QP_TL_J) \
+    g_qp_tl[((w) * QP_TL_J + (J)) * QP_TL_K + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime();
 #define PROF(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
     atomicAdd(&g_qp_prof[slot], _n - _pt); _pt = _n; } else { _pt = 0; } } while (0)
@@ -27,6 +34,7 @@ static constexpr int QP_PROF_SLOTS = 48;
 #define PROF(slot)
 #define PROF2(slot, slot2)
 #define PROFW(slot)
+#define TL(w, J, k)
 #endif
 
 static constexpr int NB = 32;     // Cholesky block

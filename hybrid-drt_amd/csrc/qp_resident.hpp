@@ -1268,6 +1268,7 @@ struct OpsResidentT {
 #ifdef HIPDRT_QP_PROFILE
             const unsigned long long _jt0 = __builtin_amdgcn_s_memtime();      // slots 26 + J: the whole super column, by J
 #endif
+            TL(0, J, 0);
             // ---- chain a ------------------------------------------------------------------------------------------
             bool ok = cholinv16_dsc(j0a, 0);
             PROF(12);
@@ -1287,6 +1288,7 @@ struct OpsResidentT {
                 PROF(14);
                 ok = cholinv16(d22, j0a + 16, 16) && ok;
                 PROF(15);
+                TL(0, J, 4);
                 // (W21 of the inverse block and y_a of the fused forward substitution are not needed before the panel solves:
                 // they are computed behind barrier (A), while this wavefront has nothing else to do -- finish_later below)
             }
@@ -1321,6 +1323,7 @@ struct OpsResidentT {
                     }
                 }
                 PROF(40);
+                TL(0, J, 5);
                 // panel solve against block a (own W1, L21, W2)
                 double wn1[4], l21[4], wn2[4];
                 load_wn(wn1, wn2, j0a, li, kq);
@@ -1356,6 +1359,7 @@ struct OpsResidentT {
                     e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(x31[s_], x31[s_], e22, 0, 0, 0);
                 }
                 PROF(41);
+                TL(0, J, 6);
                 // ---- chain b ---------------------------------------------------------------------------------------
                 ok = cholinv16(e11, j0b, 0) && ok;
                 v4d xb = (v4d){0, 0, 0, 0};
@@ -1371,7 +1375,9 @@ struct OpsResidentT {
                 PROF(42);
             }
             if (lane == 0) sm.flag[0] = ok ? 0 : 1;
+            TL(0, J, 1);
             __syncthreads();                                    // (A)
+            TL(0, J, 2);
             PROF(1);
 #ifdef HIPDRT_QP_PROFILE
             const unsigned long long _ta = __builtin_amdgcn_s_memtime();       // slots 16 + J: (A) -> everybody's arrival at (B), by J
@@ -1399,6 +1405,7 @@ struct OpsResidentT {
                 }
             }
             PROF(43);
+            TL(0, J, 7);
             // ---- early start of the next super column's look-ahead (tile rows tA+6, tA+7): source tiles, then the old range of
             // their history, until it is done or the other wavefronts stand at barrier (B) -- then (B) first, the rest after
             bool at_b = false;
@@ -1431,6 +1438,7 @@ struct OpsResidentT {
             if (!at_b) __syncthreads();                         // (B)
 #endif
             PROF(4);
+            TL(0, J, 3);
 #ifdef HIPDRT_QP_PROFILE
             if (threadIdx.x == 0 && blockIdx.x == 0 && J < 14) atomicAdd(&g_qp_prof[26 + J], __builtin_amdgcn_s_memtime() - _jt0);
             if (threadIdx.x == 0 && blockIdx.x == 0 && J < 10) atomicAdd(&g_qp_prof[16 + J], _tarr - _ta);
@@ -1454,6 +1462,7 @@ struct OpsResidentT {
             const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
             const int Q2 = tA + 4, Q3 = tA + 5;
             const bool v2 = Q2 < ntr, v3 = Q3 < ntr;
+            TL(1, J, 0);
             if (v2) {
                 v4d ca[2][2], cb[2][2], f11, f21, f22;
                 if (have_pre) {
@@ -1538,7 +1547,9 @@ struct OpsResidentT {
                         f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
                     }
                 }
+                TL(1, J, 1);
                 __syncthreads();                                // (A)
+                TL(1, J, 2);
                 if (sm.flag[0]) return false;
                 have_pre = false;
                 BFrag bf;
@@ -1633,6 +1644,7 @@ struct OpsResidentT {
                 __syncthreads();                                // (A)
                 if (sm.flag[0]) return false;
             }
+            TL(1, J, 3);
             arrive_b(lane);
 #if !HIPDRT_QP_SPLITB
             __syncthreads();                                    // (B)
@@ -1663,6 +1675,7 @@ struct OpsResidentT {
 #if HIPDRT_QP_LA1HELPER
             if (wv == HIPDRT_QP_LA1HELPER_WAVE && J >= 1 && 2 * J + 3 < nblk) la1_helper(J + 1, lane, li, kq, fo, ntr);
 #endif
+            TL(wv, J, 0);
             unsigned long long m0, m1;
             my_rows(J, m0, m1);
             const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);
@@ -1769,7 +1782,9 @@ struct OpsResidentT {
                     vm_wait<0>();
                 }
                 if (ps == 0) {
+                    TL(wv, J, 1);
                     __syncthreads();                            // (A)
+                    TL(wv, J, 2);
                     if (sm.flag[0]) return false;
                 }
                 if (act[0]) {
@@ -1861,6 +1876,7 @@ struct OpsResidentT {
                 }
             }
 #endif
+            TL(wv, J, 3);
             arrive_b(lane);
 #if !HIPDRT_QP_SPLITB
             __syncthreads();                                        // (B)

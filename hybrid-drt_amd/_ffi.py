@@ -381,6 +381,16 @@ class Context:
         _check(self._lib.hipdrt_qp_profile(self._h, buf, n, 0))
         return np.array(buf[64:], dtype=np.uint64).reshape(8, 16, 8)
 
+    def qp_timeline_mean(self, reset=True):
+        """PROFILE builds: the same stamps as mean cycles since the start of the factorisation, over all factorisations of
+        workgroup 0 since the last reset -> (array [8][16][8], number of factorisations)"""
+        nt = 8 * 16 * 8
+        n = 64 + 2 * nt + 1
+        buf = (C.c_ulonglong * n)()
+        _check(self._lib.hipdrt_qp_profile(self._h, buf, n, int(reset)))
+        cnt = int(buf[64 + 2 * nt])
+        return np.array(buf[64 + nt:64 + 2 * nt], dtype=np.float64).reshape(8, 16, 8) / max(cnt, 1), cnt
+
     def weighted_gram(self, A, w, b, l2=None, l1=None):
         A, w, b = _f64(A), _f64(w), _f64(b)
         if w.ndim == 1:

@@ -77,10 +77,13 @@ int qp_profile_read(unsigned long long* out, int n, int reset) {
     for (int i = 0; i < n; ++i) out[i] = i < QP_PROF_SLOTS ? h[i] : 0;
     if (reset) { unsigned long long z[QP_PROF_SLOTS] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qp_prof), z, sizeof(z)); }
     if (n > QP_PROF_SLOTS && hyper_profile_read(out + QP_PROF_SLOTS, (n < 64 ? n : 64) - QP_PROF_SLOTS, reset) < 0) return -1;
-    if (n > 64) {            // behind the two kernels' phase counters: the factorisation time line (qp_common.hpp, g_qp_tl)
-        static unsigned long long tl[8 * QP_TL_J * QP_TL_K];
+    if (n > 64) {            // behind the two kernels' phase counters: the factorisation time line (qp_common.hpp, g_qp_tl), then its sums
+        constexpr int NT = 8 * QP_TL_J * QP_TL_K;
+        static unsigned long long tl[NT], ts[NT + 1];
         if (hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_qp_tl), sizeof(tl)) != hipSuccess) return -1;
-        for (int i = 64; i < n; ++i) out[i] = i - 64 < 8 * QP_TL_J * QP_TL_K ? tl[i - 64] : 0;
+        if (hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_qp_tl_sum), sizeof(ts)) != hipSuccess) return -1;
+        for (int i = 64; i < n; ++i) out[i] = i - 64 < NT ? tl[i - 64] : (i - 64 - NT <= NT ? ts[i - 64 - NT] : 0);
+        if (reset) { static unsigned long long z[NT + 1]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qp_tl_sum), z, sizeof(z)); }
     }
     return 1;
 #else

@@ -15,10 +15,17 @@ __device__ unsigned long long g_qp_prof[QP_PROF_SLOTS];
 // time line of workgroup 0's LAST factorisation (factor64): s_memtime of wavefront w in super column J at stamp k --
 // 0 start of the super column, 1 at barrier (A), 2 behind (A), 3 tiles stored (arrival at (B); wavefront 0: everybody's arrival seen),
 // wavefront 0 also 4 chain a done, 5 look-ahead history done, 6 look-ahead solve done, 7 W21 / y done
+// g_qp_tl_sum: the same stamps as cycles since the start of the factorisation (TL_START, wavefront 1 in front of the first
+// barrier), summed over all factorisations of workgroup 0 since the last reset; entry [8 * J * K] counts the factorisations
 static constexpr int QP_TL_J = 16, QP_TL_K = 8;
 __device__ unsigned long long g_qp_tl[8 * QP_TL_J * QP_TL_K];
-#define TL(w, J, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && (J) < QP_TL_J) \
-    g_qp_tl[((w) * QP_TL_J + (J)) * QP_TL_K + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_qp_tl_sum[8 * QP_TL_J * QP_TL_K + 1];
+__device__ unsigned long long g_qp_tl_ref;
+#define TL_START() do { if (blockIdx.x == 0) { g_qp_tl_ref = __builtin_amdgcn_s_memtime(); atomicAdd(&g_qp_tl_sum[8 * QP_TL_J * QP_TL_K], 1ull); } } while (0)
+#define TL(w, J, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && (J) < QP_TL_J) { \
+    const unsigned long long _tn = __builtin_amdgcn_s_memtime(); \
+    g_qp_tl[((w) * QP_TL_J + (J)) * QP_TL_K + (k)] = _tn; \
+    atomicAdd(&g_qp_tl_sum[((w) * QP_TL_J + (J)) * QP_TL_K + (k)], _tn - g_qp_tl_ref); } } while (0)
 #define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime();
 #define PROF(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long _n = __builtin_amdgcn_s_memtime(); \
     atomicAdd(&g_qp_prof[slot], _n - _pt); _pt = _n; } else { _pt = 0; } } while (0)
@@ -35,6 +42,7 @@ static constexpr int QP_PROF_SLOTS = 48;
 #define PROF2(slot, slot2)
 #define PROFW(slot)
 #define TL(w, J, k)
+#define TL_START()
 #endif
 
 static constexpr int NB = 32;     // Cholesky block

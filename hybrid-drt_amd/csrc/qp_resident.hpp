@@ -1105,7 +1105,7 @@ struct OpsResidentT {
             stage_dsc(d11);
             img21[lane] = d21;
             img21[64 + lane] = d22;
-            if (lane == 0) { sm.flag[1] = 0; sm.flag[2] = 0; sm.flag[3] = 0; }
+            if (lane == 0) { sm.flag[1] = 0; sm.flag[2] = 0; sm.flag[3] = 0; TL_START(); }
         }
         __syncthreads();
 #if HIPDRT_QP_SPLITB

@@ -17,9 +17,15 @@ plan = drt.stage_batch(cfg["freq"], z)
 plan.set_subbatches(1)
 drt.fit_staged()
 drt.fit_staged()
+ctx.qp_timeline_mean(reset=True)
+drt.fit_staged()
+mean, cnt = ctx.qp_timeline_mean(reset=True)
 tl = ctx.qp_timeline().astype(np.int64)
 if not tl.any():
     raise SystemExit("no time line: not a PROFILE build")
+if "--last" not in sys.argv:
+    print("MEAN over the", cnt, "factorisations of workgroup 0 in one 1024-spectrum fit (--last: the last one only)")
+    tl = np.rint(mean).astype(np.int64)
 nsup = int(np.count_nonzero(tl[0, :, 0]))
 print("super columns", nsup, "| cycles, relative to wavefront 0's start of the super column (k = 1000 cycles)")
 k = lambda v: "%6.1f" % (v / 1e3)

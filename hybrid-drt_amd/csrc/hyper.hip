@@ -266,6 +266,10 @@ __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, in
     }
 }
 
+// a per-lane value the compiler may not hoist address arithmetic out of a loop for (hyper_kernel at 128 VGPRs: offsets formed where
+// they are used instead of being carried in scratch from the kernel's start)
+__device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // estimate_weights for spectrum b: xs = LDS x[n]; tmp = LDS [m]; result written to w_out[m] (global)
 // estimate_weights (qphb.py:1545-1594) for spectrum b with variance matrix V: xs = LDS x[n]; tmp, tmp2 = LDS [m]; with
 // outlier_p > 0 also tmp3, tmp4 = LDS [m] (solve_outlier_t / outlier_tvt, qphb.py:1497-1539:
@@ -273,7 +277,7 @@ __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, in
 __device__ void estimate_weights_dev(const FitState& st, int b, const double* V, const double* xs, double* tmp, double* tmp2,
                                      double* tmp3, double* tmp4, const double* est_w, double* w_out, int r0 = 0, int r1 = -1,
                                      double vf_range = -1.0, const double* pre = nullptr) {
-    const int m = st.m, n = st.n, tid = threadIdx.x;
+    const int m = st.m, n = st.n, tid = opaque_lane(threadIdx.x);
     const double* rv = st.rv + (size_t)b * m;
     const double op = st.opts.outlier_p;
     HPROF_START();
@@ -507,9 +511,13 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
 
     // solve_s + solve_rho (qphb.py:320-356, 385-405) of one derivative order on one block of x: the DRT coefficients
     // (with the G matrix for k = 0) or the x_dop block (qphb.py:822-933, no G matrix)
+    const int tid0 = tid;
     auto update_block = [&](const int k, const double* xd, const int nd, const int off, const bool tpl, const bool use_g,
                             const double alpha, const double s0, const double sigma, const double ra, const double r0,
-                            double* rho_out, const double* xmx_in, const double reff) {
+                            double* rho_out, const double* xmx_in, const double reff, const bool fresh_rows = false) {
+        // (fresh_rows, the second use of this block: thread and row offsets are formed again instead of being carried -- in
+        // scratch, at 128 VGPRs -- from the kernel's start)
+        const int tid = fresh_rows ? opaque_lane(tid0) : tid0;
         double* sk = st.s + ((size_t)b * 3 + k) * n + off;
         const double* Mk = st.mk[k] + (size_t)off * st.ldm + off;
         const double* M1 = st.mk[1] + (size_t)off * st.ldm + off;
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                 if (use_g) {
                     const double xhsa = xh[ia] / sig2, xhsb = hb ? xh[ib] / sig2 : 0.0;
                     const double* c1a = c1 + ia;
-                    double sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0, ma0 = 0.0, ma1 = 0.0, mb0 = 0.0, mb1 = 0.0;
+                    double sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0, ma0 = 0.0, mb0 = 0.0;
                     double pk = hb ? cka[1] : cka[0], p1 = hb ? c1a[1] : c1a[0];
                     int j = 0;
                     for (; j + 1 < nd; j += 2) {
@@ -560,8 +568,8 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                         const double gb1 = xrb * (k0 * v1) + xhsb * (q0 * h1);
                         pk = k1; p1 = q1;
                         sa0 += ga0; sa1 += ga1; sb0 += gb0; sb1 += gb1;
-                        ma0 = fmax(ma0, fabs(ga0)); ma1 = fmax(ma1, fabs(ga1));
-                        mb0 = fmax(mb0, fabs(gb0)); mb1 = fmax(mb1, fabs(gb1));
+                        ma0 = fmax(ma0, fmax(fabs(ga0), fabs(ga1)));
+                        mb0 = fmax(mb0, fmax(fabs(gb0), fabs(gb1)));
                     }
                     if (j < nd) {
                         const double ga0 = xra * (cka[-j] * vs[j]) + xhsa * (c1a[-j] * vh[j]);
@@ -569,17 +577,17 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                         sa0 += ga0; ma0 = fmax(ma0, fabs(ga0));
                         sb0 += gb0; mb0 = fmax(mb0, fabs(gb0));
                     }
-                    lmax = fmax(lmax, fmax(ma0, ma1));
+                    lmax = fmax(lmax, ma0);
                     bsum[ia] = sa0 + sa1;
                     gdia[ia] = ((xra * ck00) * xia + ((xh[ia] * c100) * xh[ia]) / sig2) + beta;
                     if (hb) {
-                        lmax = fmax(lmax, fmax(mb0, mb1));
+                        lmax = fmax(lmax, mb0);
                         bsum[ib] = sb0 + sb1;
                         gdia[ib] = ((xrb * ck00) * xib + ((xh[ib] * c100) * xh[ib]) / sig2) + beta;
                     }
                 } else {
                     double sa0 = 0.0, sa1 = 0.0, sa2 = 0.0, sa3 = 0.0, sb0 = 0.0, sb1 = 0.0, sb2 = 0.0, sb3 = 0.0;
-                    double ma0 = 0.0, ma1 = 0.0, mb0 = 0.0, mb1 = 0.0;
+                    double ma0 = 0.0, mb0 = 0.0;          // (one running maximum per row: a maximum does not care about the grouping)
                     double pk = hb ? cka[1] : cka[0];
                     int j = 0;
                     for (; j + 3 < nd; j += 4) {
@@ -590,10 +598,8 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                         pk = k3;
                         sa0 += ta0; sa1 += ta1; sa2 += ta2; sa3 += ta3;
                         sb0 += tb0; sb1 += tb1; sb2 += tb2; sb3 += tb3;
-                        ma0 = fmax(ma0, fmax(fabs(ta0), fabs(ta1)));
-                        ma1 = fmax(ma1, fmax(fabs(ta2), fabs(ta3)));
-                        mb0 = fmax(mb0, fmax(fabs(tb0), fabs(tb1)));
-                        mb1 = fmax(mb1, fmax(fabs(tb2), fabs(tb3)));
+                        ma0 = fmax(ma0, fmax(fmax(fabs(ta0), fabs(ta1)), fmax(fabs(ta2), fabs(ta3))));
+                        mb0 = fmax(mb0, fmax(fmax(fabs(tb0), fabs(tb1)), fmax(fabs(tb2), fabs(tb3))));
                     }
                     for (; j < nd; ++j) {
                         const double k0 = cka[-j];
@@ -602,11 +608,11 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                         sa0 += ta0; ma0 = fmax(ma0, fabs(ta0));
                         sb0 += tb0; mb0 = fmax(mb0, fabs(tb0));
                     }
-                    lmax = fmax(lmax, fabs(xra) * fmax(ma0, ma1));
+                    lmax = fmax(lmax, fabs(xra) * ma0);
                     bsum[ia] = xra * ((sa0 + sa1) + (sa2 + sa3));
                     gdia[ia] = (xra * ck00) * xia + beta;
                     if (hb) {
-                        lmax = fmax(lmax, fabs(xrb) * fmax(mb0, mb1));
+                        lmax = fmax(lmax, fabs(xrb) * mb0);
                         bsum[ib] = xrb * ((sb0 + sb1) + (sb2 + sb3));
                         gdia[ib] = (xrb * ck00) * xib + beta;
                     }
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
             __syncthreads();
             if (tid == 0) { ctp[k * cw + (nd - 1)] = ck00; if (use_g) ctp[cw + (nd - 1)] = c100; }
         } else
-        for (int i = wv; i < nd; i += HNW) {
+        for (int i = fresh_rows ? opaque_lane(wv) : wv; i < nd; i += HNW) {     // (fresh_rows: the row addresses are formed here, not carried in scratch)
             const double* row = Mk + (size_t)i * st.ldm;
             const double* row1 = M1 + (size_t)i * st.ldm;
             const double xi = xd[i], xhi = xh[i], xr = reff * xi;
@@ -675,13 +681,14 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                      st.xmx + (size_t)b * 3, st.opts.eff_hp ? 1.0 : st.rho[(size_t)b * 3 + k]);
         HPROF(1 + k);
     }
+    const int tidw = opaque_lane(tid);      // (a fresh copy: the per-lane offsets of everything below are formed here, not carried in scratch)
     if (st.prepared && st.desc.dop_size > 0) {
         for (int k = 0; k < 3; ++k) {
             if (!(st.desc.dop_derivative_weights[k] > 0.0)) continue;
             update_block(k, xs + st.desc.dop_start, st.desc.dop_size, st.desc.dop_start, false, false,
                          st.desc.dop_s_alpha[k], st.desc.dop_s_0[k], 1.0, st.desc.dop_rho_alpha[k],
                          st.desc.dop_rho_0[k], st.dop_rho + (size_t)b * 3, st.dop_xmx + (size_t)b * 3,
-                         st.opts.eff_hp ? 1.0 : st.dop_rho[(size_t)b * 3 + k]);
+                         st.opts.eff_hp ? 1.0 : st.dop_rho[(size_t)b * 3 + k], true);
         }
     }
 
@@ -692,9 +699,9 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
             else rows_matvec(Mk, st.ldm, nd, nd, xd, tmp2);
             __syncthreads();
             double part = 0.0;
-            for (int i = tid; i < nd; i += HT) part += xd[i] * tmp2[i];
+            for (int i = tidw; i < nd; i += HT) part += xd[i] * tmp2[i];
             const double v = blk_sum(part, red);
-            if (tid == 0) st.xmx[(size_t)b * 3 + k] = v;
+            if (tidw == 0) st.xmx[(size_t)b * 3 + k] = v;
             __syncthreads();
         }
         if (st.prepared && st.desc.dop_size > 0) {      // dop_xmx_norms (drt1d.py:953-960)
@@ -703,9 +710,9 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                 rows_matvec(st.mk[k] + (size_t)d0 * st.ldm + d0, st.ldm, dn, dn, xs + d0, tmp2);
                 __syncthreads();
                 double part = 0.0;
-                for (int i = tid; i < dn; i += HT) part += xs[d0 + i] * tmp2[i];
+                for (int i = tidw; i < dn; i += HT) part += xs[d0 + i] * tmp2[i];
                 const double v = blk_sum(part, red);
-                if (tid == 0) st.dop_xmx[(size_t)b * 3 + k] = v;
+                if (tidw == 0) st.dop_xmx[(size_t)b * 3 + k] = v;
                 __syncthreads();
             }
         }
@@ -721,7 +728,7 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
     // convergence (qphb.py:597-603, 969-970)
     double* xin = st.x_in + (size_t)b * n;
     double mrel = 0.0, mabs = 0.0, sx = 0.0;
-    for (int i = tid; i < n; i += HT) {
+    for (int i = tidw; i < n; i += HT) {
         const double xi0 = xin[i];
         const double dlt = xs[i] - xi0;
         mrel = fmax(mrel, fabs(dlt / (xi0 + 1e-15)));
@@ -733,14 +740,14 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
     sx = blk_sum(sx, red);
     const double atol = sx / (double)n * 1e-3;
     const bool conv = (mrel <= st.opts.xtol) || (mabs <= atol);
-    for (int i = tid; i < n; i += HT) xin[i] = xs[i];
+    for (int i = tidw; i < n; i += HT) xin[i] = xs[i];
     if (st.hist_b == b && it < st.hist_cap) {
-        for (int i = tid; i < n; i += HT) st.hist_x[(size_t)it * n + i] = xs[i];
-        for (int i = tid; i < m; i += HT) st.hist_w[(size_t)it * m + i] = wg[i];
-        if (tid < 3) st.hist_rho[(size_t)it * 3 + tid] = st.rho[(size_t)b * 3 + tid];
-        if (tid < 3 && st.prepared && st.desc.dop_size > 0)
-            st.hist_dop_rho[(size_t)it * 3 + tid] = st.dop_rho[(size_t)b * 3 + tid];
-        if (tid == 0) { st.hist_qp[it + 1] = st.qp_iters[b]; st.hist_rows[0] = it + 1; }
+        for (int i = tidw; i < n; i += HT) st.hist_x[(size_t)it * n + i] = xs[i];
+        for (int i = tidw; i < m; i += HT) st.hist_w[(size_t)it * m + i] = wg[i];
+        if (tidw < 3) st.hist_rho[(size_t)it * 3 + tidw] = st.rho[(size_t)b * 3 + tidw];
+        if (tidw < 3 && st.prepared && st.desc.dop_size > 0)
+            st.hist_dop_rho[(size_t)it * 3 + tidw] = st.dop_rho[(size_t)b * 3 + tidw];
+        if (tidw == 0) { st.hist_qp[it + 1] = st.qp_iters[b]; st.hist_rows[0] = it + 1; }
     }
     if (st.prepared && st.desc.vz_index >= 0 && st.continue_mode != 2) {
         // drt1d.py:973-979: the vz_offset column becomes the current prediction of the matrix without the baseline and
@@ -748,14 +755,14 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
         // strength vector.  The weights above were estimated with the previous column, as in iterate_qphb.
         __syncthreads();
         const int vz = st.desc.vz_index;
-        for (int i = tid; i < n; i += HT)
+        for (int i = tidw; i < n; i += HT)
             if (i == vz || (i >= st.desc.vb_start && i < st.desc.vb_start + st.desc.vb_size)) xs[i] = 0.0;
         __syncthreads();
         double* rmb = st.rm_rw + (size_t)b * st.rm_stride;
-        if (st.premv) { for (int i = tid; i < m; i += HT) tmp[i] = st.premv[(2 * (size_t)gridDim.x + b) * m + i]; }
+        if (st.premv) { for (int i = tidw; i < m; i += HT) tmp[i] = st.premv[(2 * (size_t)gridDim.x + b) * m + i]; }
         else rows_matvec(rmb, st.ldrm, m, n, xs, tmp);
         __syncthreads();
-        for (int i = tid; i < m; i += HT)
+        for (int i = tidw; i < m; i += HT)
             rmb[(size_t)i * st.ldrm + vz] = (i < st.desc.num_chrono ? tmp[i] : -tmp[i]) * st.vz_strength[i];
     }
     const bool stop = conv && it + 1 >= st.min_iter;          // `converged and it >= min_iter - 1` (drt1d.py:1356)
@@ -764,22 +771,22 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
         // polarisation resistance at rp_scale by rescaling the data and everything that carries its units
         __syncthreads();
         double part = 0.0;
-        for (int i = ns + tid; i < n; i += HT) part += fabs(xs[i]);
+        for (int i = ns + tidw; i < n; i += HT) part += fabs(xs[i]);
         const double rp = blk_sum(part, red) * st.basis_area;                 // predict_r_p(absolute=True, raw=True)
         const double sf = sqrt(st.opts.rp_scale / rp);                        // damped scale factor
-        for (int i = tid; i < n; i += HT) xin[i] *= sf;
+        for (int i = tidw; i < n; i += HT) xin[i] *= sf;
         double* rvb = st.rv + (size_t)b * m;
         double* ewb = st.est_w + (size_t)b * m;
-        for (int i = tid; i < m; i += HT) { rvb[i] *= sf; ewb[i] /= sf; wg[i] /= sf; }
-        if (tid < 3) {
-            st.xmx[(size_t)b * 3 + tid] *= sqrt(sf);                          // as coded upstream (drt1d.py:918)
-            if (st.prepared && st.desc.dop_size > 0) st.dop_xmx[(size_t)b * 3 + tid] *= sqrt(sf);
+        for (int i = tidw; i < m; i += HT) { rvb[i] *= sf; ewb[i] /= sf; wg[i] /= sf; }
+        if (tidw < 3) {
+            st.xmx[(size_t)b * 3 + tidw] *= sqrt(sf);                          // as coded upstream (drt1d.py:918)
+            if (st.prepared && st.desc.dop_size > 0) st.dop_xmx[(size_t)b * 3 + tidw] *= sqrt(sf);
         }
-        if (tid == 0) { st.coef_scale[b] /= sf; st.var_floor[b] *= sf * sf; }
+        if (tidw == 0) { st.coef_scale[b] /= sf; st.var_floor[b] *= sf * sf; }
     }
     HPROF(6);
     HPROF_COUNT(15);
-    if (tid == 0) {
+    if (tidw == 0) {
         st.outer_iters[b] = it + 1;
         if (stop) { st.active[b] = 0; st.fit_status[b] = 0; }
         else if (it + 1 >= st.opts.max_iter) { st.active[b] = 0; st.fit_status[b] = 1; }

@@ -5,7 +5,8 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-Workloads (`--config`, default `auto` = c3 on one GPU, c4 on several):
+Workloads (`--config`, default `auto` = c3 for EVERY N, so that a 1 / 2 / 4 / 8 curve compares one workload with itself; the c4
+map is timed as well on every N and reported as `scale_reference` in the same line):
   c3  BASELINE configs[2]: `--batch` (1024) synthetic 2-ZARC spectra per GPU, shared 256-point frequency grid, 512-point
       tau grid.  A step = one full QPHB fit (DRT._qphb_fit_core: scaling, initial-weights QP, hyper-parameter loop to
       convergence, final q) of the batch, inputs resident in HBM when the timed region starts.  Weak scaling over ranks.
@@ -267,7 +268,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=("auto", "c3", "c4"), default="auto",
                     help="c3 = configs[2] (1024 spectra per GPU, weak), c4 = configs[3] (one 10 000-spectrum map sharded "
-                         "over the ranks, strong); auto = c3 on one GPU, c4 on several")
+                         "over the ranks, strong); auto = c3 for every N, with the c4 map timed beside it (`scale_reference`)")
+    ap.add_argument("--no-scale-reference", action="store_true", help="c3: skip the configs[3] map leg")
+    ap.add_argument("--scale-steps", type=int, default=2, help="maps timed by the `scale_reference` leg (one warm-up map before)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group and run every collective through the backend even with ONE rank (a world-1 "
+                         "nccl group exercises RCCL, the device binding and the staging on a one-GPU box)")
     ap.add_argument("--batch", type=int, default=1024, help="c3: spectra per GPU per step")
     ap.add_argument("--total", type=int, default=10000, help="c4: spectra of the whole map")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' lets several "
@@ -290,7 +296,7 @@ def main():
         # one fresh child per rank (no exec of a GPU-initialised process), relays rank 0's JSON line and fails if any did
         raise SystemExit(self_launch(args.gpus))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    config = args.config if args.config != "auto" else ("c3" if world_env == 1 else "c4")
+    config = args.config if args.config != "auto" else "c3"
 
     lib = os.path.join(ROOT, "hybrid-drt_amd", "libhipdrt.so")
     if not os.path.exists(lib) and "HIPDRT_LIB" not in os.environ:      # fresh checkout: build the (git-ignored) library once
@@ -328,7 +334,12 @@ def main():
     if args.backend == "gloo":
         local %= torch.cuda.device_count()               # functional check: ranks may share a GPU
     torch.cuda.set_device(local)
-    rank, world, _ = hd.init_from_env(backend=args.backend, device=local)
+    try:
+        # before any fit has touched the GPU: a backend that does not come up ends the run here, non-zero, nothing is restarted
+        rank, world, _ = hd.init_from_env(backend=args.backend, device=local, force=args.force_dist)
+    except Exception as e:          # noqa: BLE001
+        print(f"bench.py: process group initialisation failed: {e!r}", file=sys.stderr)
+        raise SystemExit(3)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -372,7 +383,7 @@ def main():
     drt, plan = drts[0], plans[0]
     if plan is None:
         raise SystemExit(f"bench.py: rank {rank} has no observations to fit ({job_fits} spectra over {world} ranks)")
-    if world > 1 and config == "c3":
+    if hd.active(world) and config == "c3":
         # rank 0's lookup tables -> everyone, one RCCL broadcast (c4: mapping.fit_observations_sharded does this itself)
         from hipdrt.mapping.drtmd import share_lookup_tables
         for d in drts:
@@ -469,6 +480,38 @@ def main():
             assert obs_x.shape == (args.total, len(tau)) and np.isfinite(obs_x).all() and res_all["obs_fit_status"].all()
             res = {k: res_all[k][mine] for k in ("outer_iters", "qp_iters_total", "status")}     # this rank's share
 
+    # ---- BASELINE configs[3] beside the headline, on every N (one workload per curve, and the other one visible) ----
+    scale_ref = None
+    if config == "c3" and not args.no_scale_reference:
+        from hipdrt.mapping.drtmd import auto_inflight, fit_observations_sharded
+        mine4 = shard_indices(args.total, world, rank, args.shard)
+        z4 = np.zeros((args.total, len(freq)), dtype=complex)          # every rank holds its own rows only
+        if len(mine4):
+            z4[mine4] = np.concatenate([synth.zarc2_batch(freq, 1, first_seed=int(i)) for i in mine4])
+        nfl4 = auto_inflight(len(mine4)) if args.inflight in (None, "auto") else args.inflight
+        d4 = DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local))
+        run4 = lambda: fit_observations_sharded(d4, freq, z4, rank=rank, world=world, scheme=args.shard, inflight=nfl4)  # noqa: E731
+        run4()                                                          # builds the sibling plans; warm-up map
+        hd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.scale_steps):
+            got4 = run4()            # upload, fit, llh / rss, download on every rank + ONE gather: returns when rank 0 holds the map
+        torch.cuda.synchronize()
+        hd.barrier()
+        el4 = hd.max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            assert got4[0].shape == (args.total, len(tau)) and np.isfinite(got4[0]).all() and got4[2]["obs_fit_status"].all()
+            scale_ref = {"value": args.total * args.scale_steps / el4, "unit": "fits/s", "scaling": "strong",
+                         "seconds_per_map": el4 / args.scale_steps, "maps_timed": args.scale_steps, "n_gpus": world,
+                         "spectra_per_rank": [len(shard_indices(args.total, world, r, args.shard)) for r in range(world)],
+                         "batches_in_flight_per_gpu": nfl4,
+                         "workload": (f"BASELINE configs[3]: one map of {args.total} synthetic 2-ZARC spectra (256 x 512) sharded "
+                                      f"over {world} rank(s) ({args.shard} shards) by mapping.fit_observations_sharded: per map "
+                                      f"upload + full QPHB loop + llh / rss + download on every rank and one gather on rank 0, all "
+                                      f"timed (inputs start in HOST memory)")}
+        del d4, z4
+
     n, m = plan.n, plan.m
     out = None
     if rank == 0:
@@ -501,13 +544,20 @@ def main():
         gram_flop = (outer_sum + nb) * m * n * n            # lower triangle of A'WA: m n^2 per spectrum and QP
         out = {
             "metric": "DRT fits/sec (256 freq x 512 tau, batched)", "value": value, "unit": "fits/s",
+            # the two forms of the headline side by side (bench contract: `value` = inputs resident in HBM when the timed region
+            # starts; SURVEY 8d's "B / wall including H2D / D2H" is `value_streamed`: the same K steps with the upload of the
+            # spectra and the download of every result inside each step)
+            "value_resident": value,
+            "value_streamed": None if transfer_elapsed is None else world * B * args.steps / transfer_elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if config == "c3" else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[2]: {B} synthetic 2-ZARC spectra per GPU, shared 256-point frequency "
                                     f"grid x 512-point tau grid, full QPHB loop (DRT.fit_eis defaults, interp lookups), "
-                                    f"inputs resident in HBM") if config == "c3" else
+                                    f"inputs resident in HBM (`value`, `value_resident`); `value_streamed` = the same steps with "
+                                    f"upload + download inside; weak scaling: every rank fits its own {B} spectra, no data-path "
+                                    f"collective; the configs[3] map on the same N is `scale_reference`") if config == "c3" else
                                    (f"BASELINE configs[3]: one map of {args.total} synthetic 2-ZARC spectra (256 x 512) "
                                     f"sharded over {world} rank(s) ({args.shard} shards) by mapping.fit_observations_sharded: "
                                     f"per step upload + full QPHB loop + llh / rss + download on every rank and one "
@@ -569,6 +619,7 @@ def main():
                 "value": world * B * args.steps / one_caller_elapsed, "ms_per_step": one_caller_elapsed / args.steps * 1e3,
                 "note": "same K steps from ONE caller thread on ONE plan (one plan's memory): hipdrt_plan_fit cuts the staged batch "
                         "into ranges that run side by side on the plan's own streams (hipdrt_plan_set_subbatches, automatic)"},
+            "scale_reference": scale_ref,
             "with_transfers": None if transfer_elapsed is None else {
                 "value": world * B * args.steps / transfer_elapsed, "ms_per_step": transfer_elapsed / args.steps * 1e3,
                 "note": "same K steps with the upload of the spectra and the download of all results inside every step"},
@@ -661,8 +712,8 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     hd.barrier()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1105,10 +1105,16 @@ static int plan_fit_one(hipdrt_plan* p) {
 // bit-identical to the un-split fit as long as both use the same coneqp kernel (ranges of more than #CUs / 16 spectra).
 static int subbatch_count(const hipdrt_plan* p) {
     if (p->prepared || p->hist_b >= 0 || p->has_weight_factors() || p->opts.outlier_p > 0.0 || p->qp_G != 0 || p->premv.p) return 1;
-    if (p->subbatches >= 1) return std::min(p->subbatches, std::max(1, p->B / 64));
     // measured on one MI355X (profiles/r04_subbatch_sweep.txt): ranges below ~300 spectra lose to launch-wave quantisation
     // (fits/s with k = 1 / 2 / 3 / 4 ranges: 1024 spectra 1902 / 2110 / 2106 / 1660, 1250: 2001 / 2205 / 2219 / 1796, 2500: 2229 / 2375 / 2408 / 2104)
-    return p->B >= 1200 ? 3 : (p->B >= 600 ? 2 : 1);
+    int k = p->subbatches >= 1 ? std::min(p->subbatches, std::max(1, p->B / 64)) : (p->B >= 1200 ? 3 : (p->B >= 600 ? 2 : 1));
+    // the promise is "the bits of the un-split fit": the whole batch AND the smallest range must choose the batch coneqp kernel as
+    // the views will see it (qp_layout runs qp_group_size on the view's own count with the context's current override, which may
+    // have been set after the plan was allocated) -- otherwise fewer ranges, down to one
+    const int force = p->ctx ? p->ctx->qp_force_group : -1;
+    if (qp_group_size(p->B, p->n, force) != 0) return 1;
+    while (k > 1 && qp_group_size(p->B / k, p->n, force) != 0) --k;
+    return k;
 }
 
 static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb) {
@@ -1171,15 +1177,30 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
         TRY(make_view(p, *p->subs[i], i, b0, b1 - b0));
     }
     const auto t0 = std::chrono::steady_clock::now();
+    // no exception may cross the C ABI, and a joinable std::thread must not be destroyed: ranges whose worker thread cannot
+    // be created (std::system_error) are fitted right here, on the caller's thread, after the started ones were joined
     std::vector<std::thread> workers;
+    workers.reserve(k);
+    int started = 0;
     for (int i = 0; i < k; ++i) {
         hipdrt_subfit* sf = p->subs[i].get();
-        workers.emplace_back([sf] {
-            sf->rc = plan_fit_one(&sf->view);
-            if (sf->rc) sf->err = hipdrt_last_error();
-        });
+        sf->rc = HIPDRT_OK;
+        try {
+            workers.emplace_back([sf] {
+                sf->rc = plan_fit_one(&sf->view);
+                if (sf->rc) sf->err = hipdrt_last_error();
+            });
+            ++started;
+        } catch (...) {
+            break;
+        }
     }
     for (auto& w : workers) w.join();
+    for (int i = started; i < k; ++i) {
+        hipdrt_subfit* sf = p->subs[i].get();
+        sf->rc = plan_fit_one(&sf->view);
+        if (sf->rc) sf->err = hipdrt_last_error();
+    }
     const float wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (int i = 0; i < 5; ++i) { p->t_ms[i] = 0; p->launches[i] = 0; }
     for (int i = 0; i < k; ++i) {

@@ -73,8 +73,9 @@ static constexpr int GRP_ROW_RING = HIPDRT_GRP_ROW_RING;  // slots of the rows' 
 static constexpr int GRP_RMAXT = 2;                    // tile rows per row wavefront and pass: a member has few rows, and a short
                                                        // pass leaves registers for an eight-slot operand ring (below)
 static constexpr int GRP_WORDS = 16 + GRP_OWN;         // ints of global sync state per problem
-static constexpr int kNotResident = 1 << 30;           // poison bit in word [1]: a member gave up waiting for its partners
-// words: [0] members arrived at the start, [1] OR of (1 << XCC id) | kNotResident, [4] why a launch was aborted, [2] barrier counter, [3] laprog: factorisation count * 256
+static constexpr int kNotResident = 1 << 30;           // poison bit in word [0]: a member gave up waiting for its partners
+// words: [0] members arrived at the start | kNotResident (ONE word decides go / abort for every member), [1] OR of (1 << XCC id),
+// [4] why a launch was aborted, [2] barrier counter, [3] laprog: factorisation count * 256
 // + block columns whose look-ahead accumulators are in labuf (written by the owner of the column's look-ahead rows),
 // [16 + T] rowprog: factorisation count * 256 + block columns of tile row T complete in memory (written by T's owner when T
 // becomes a look-ahead row: the member that accumulates the next look-ahead block reads T as an operand)
@@ -939,23 +940,34 @@ __global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int 
         if (threadIdx.x == 0) {
             const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;      // HW_REG_XCC_ID[3:0]
             __hip_atomic_fetch_or(&ops.gs[1], 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&ops.gs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // A member that does not see its partners in time poisons the mask instead of trapping: the members that did
-            // arrive -- and the late ones, whenever they get a CU: the counter still reaches G once every block has run --
-            // all read the poisoned mask and leave before they have touched anything but their own scratch.
+            // Go or abort is decided on ONE word, so that no two members can decide differently: word [0] = arrivals, plus the
+            // poison bit of a member that did not see its partners in time (set by compare-and-swap on the very value it
+            // saw: either the count was still short and EVERY later reader -- pollers, and arrivers through the value their
+            // fetch_add returns -- finds the bit, or somebody arrived meanwhile and the member looks again).  "All arrived,
+            // not poisoned" can therefore not be seen by one member and missed by another; the late ones, whenever they
+            // get a CU, find the bit and leave before they have touched anything but their own scratch.
+            int seen = __hip_atomic_fetch_add(&ops.gs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             int spins = 0;
-            while (__hip_atomic_load(&ops.gs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G &&
-                   !(__hip_atomic_load(&ops.gs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kNotResident)) {
+            while (!(seen & kNotResident) && seen < G) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > OpsGroup::kRendezvousLimit) {
-                    __hip_atomic_fetch_or(&ops.gs[1], kNotResident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                    int expected = seen;
+                    if (__hip_atomic_compare_exchange_strong(&ops.gs[0], &expected, seen | kNotResident, __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        seen |= kNotResident;
+                        break;
+                    }
+                    seen = expected;                         // the count moved: judge the new value
+                    continue;
                 }
+                seen = __hip_atomic_load(&ops.gs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            xcc_mask = __hip_atomic_load(&ops.gs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the XCC mask is complete once every member has arrived (a member ORs its bit in before it counts itself)
+            xcc_mask = (seen & kNotResident) ? kNotResident
+                                             : __hip_atomic_load(&ops.gs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (__builtin_popcount(xcc_mask) != 1) {
+        if (__builtin_popcount(xcc_mask) != 1 || (xcc_mask & kNotResident)) {
             // spread over several XCDs (the L2-coherence assumption does not hold) or not all resident: every member leaves,
             // the host repeats this problem on one workgroup; word [4] says which (1 spread, 2 not resident)
             if (g == 0 && threadIdx.x == 0) {

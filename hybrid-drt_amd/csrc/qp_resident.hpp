@@ -34,44 +34,20 @@
 #pragma once
 #include "qp_common.hpp"
 
-#ifndef HIPDRT_QP_CHOLINV_MFMA
-#define HIPDRT_QP_CHOLINV_MFMA 1      // 0: the register-only Gauss-Jordan by rows (sixteen pivot steps)
-#endif
 
 namespace hipdrt {
 
 static constexpr int RT = 512;           // threads
 static constexpr int RNW = RT / 64;      // 8 wavefronts
-#ifndef HIPDRT_QP_RMAXT
-#define HIPDRT_QP_RMAXT 4
-#endif
-#ifndef HIPDRT_QP_SWEEPCAP
-#define HIPDRT_QP_SWEEPCAP 5     // (vm_wait_tiles covers counts up to 5)
-#endif
-#ifndef HIPDRT_QP_LADEPTH
-#define HIPDRT_QP_LADEPTH 4
-#endif
-#ifndef HIPDRT_QP_MINWAVES
-#define HIPDRT_QP_MINWAVES 2
-#endif
-#ifndef HIPDRT_QP_OVR
-#define HIPDRT_QP_OVR 0
-#endif
-#ifndef HIPDRT_QP_PREFETCH
-#define HIPDRT_QP_PREFETCH 1     // source tiles of block column jb + 1 requested before barrier (B) of column jb
-#endif
-#ifndef HIPDRT_QP_PREFETCH_CHAIN
-#define HIPDRT_QP_PREFETCH_CHAIN HIPDRT_QP_PREFETCH     // factor64: the same per role
-#endif
-#ifndef HIPDRT_QP_PREFETCH_LA
-#define HIPDRT_QP_PREFETCH_LA HIPDRT_QP_PREFETCH
-#endif
-#ifndef HIPDRT_QP_PREFETCH_ROWS
-#define HIPDRT_QP_PREFETCH_ROWS 0      // measured: 2326 -> 2193 fits/s with the row wavefronts' 12 source tiles each requested before
-#endif                                 // barrier (B), 8.63 -> 9.28 ms per launch (profiles/r04c_ab_prefetch_matrix.txt)
 // (non-temporal loads for the source tiles of P -- read once per factorisation -- were tried: __builtin_nontemporal_load in
 // tile_src makes hipcc 7.2's simplifycfg pass crash on this translation unit, in either coneqp kernel)
-static constexpr int RMAXT = HIPDRT_QP_RMAXT;   // tile rows per wavefront and pass
+// Tunables that were swept on the device and are settled (the sweeps: DESIGN.md section 6; the variants that lost -- register-only
+// Gauss-Jordan chain, two workgroups per CU, row prefetch before barrier (B), look-ahead helper, un-split barrier (B), 4 rows per
+// pass -- are kept as patches under tools/experiments/, not as dead branches here):
+static constexpr int RMAXT = 4;          // factor(): tile rows per wavefront and pass
+static constexpr int kSweepCap = 5;      // register-buffered tiles per trailing-update wavefront in the sweeps (vm_wait_tiles covers <= 5)
+static constexpr int kLa1Load = 14;      // factor64 row schedule: MFMAs per half-chunk booked on SIMD 0 for wavefront 0's look-ahead
+static constexpr int kLa2Load = 22;      //                        ... on SIMD 1 for wavefront 1's (0 / 7 / 14 / 21 / 28 and 16 / 22 / 30 measured)
 static constexpr int RNP_MAX = 528;
 static constexpr int TSZ = 256;          // doubles per 16x16 tile
 static constexpr int DLD = 17;           // row stride of the 16x16 LDS scratch blocks
@@ -99,8 +75,10 @@ struct ResSmemT {
     unsigned char* sched;   // [nblk][SROW] owner wavefront of every tile row below a block column (build_schedule)
 
     // fixed offsets for everything but U, so that the small buffers have compile-time LDS addresses
-    static constexpr int VEC = GU ? 4096 + 32 + 32 : 528 + 16 + 32;      // NP + 32 (NP <= 544, or <= 4128 with U outside: the
-                                                                         // posterior-variance kernel serves n <= 4096 like the QP)
+    // NP + 32: NP <= 544 with U in LDS; with U outside the QP kernel (P64: n <= 2048) needs 2112, the posterior-variance kernel
+    // (n <= 4096, as far as the QP entry point reaches with the group kernel) 4160 -- per instantiation, so that the QP kernel's
+    // workgroup does not hold 33 kB of LDS it never touches away from the Gram / hyper kernels of other streams on its CU
+    static constexpr int VEC = GU ? (P64 ? 2048 + 32 + 32 : 4096 + 32 + 32) : 528 + 16 + 32;
     static constexpr int DVEC = P64 ? VEC - 32 : VEC;
     static constexpr int SROW = GU ? 128 : 32;                           // table row: tile rows below a block column (<= 124 | 29)
     static constexpr int SCHED = GU ? 64 * 128 / 8 : (P64 ? 9 * 32 / 8 : 17 * 32 / 8 + 4);    // doubles: nblk <= 64 | 17 (9 super columns) rows of SROW bytes
@@ -128,11 +106,11 @@ using ResSmem = ResSmemT<false>;
 // is built.  256 (chain, look-ahead, two row wavefronts, U in global memory, two workgroups per CU so that one's sequential
 // phases overlap the other's matrix work) compiles to 256 VGPRs and is parity-green, but measured 12.5 ms per launch against
 // 10.6: both workgroups put their row wavefronts on the same two SIMDs and every block column needs three to four passes.
-// Two 512-THREAD workgroups per CU (128 VGPRs each: `make VARIANT=two EXTRA="-DHIPDRT_QP_RMAXT=2 -DHIPDRT_QP_MINWAVES=4
-// -DHIPDRT_QP_SWEEPCAP=2 -DHIPDRT_QP_LADEPTH=2"`, run with HIPDRT_QP_GU=1 so that U lives in global memory and LDS admits
-// two) is parity-green as well -- the ~200 spilled registers stay outside the operand rings -- and measured 14.7 ms per
-// launch against 11.3 for one workgroup per CU in the same U-outside form (10.65 with U in LDS): halving every wavefront's
-// rows per pass, ring depth and sweep buffers costs more than the second workgroup's overlap returns.
+// Two 512-THREAD workgroups per CU (128 VGPRs each: two rows per pass, ring depth 2, two buffered sweep tiles, U in global memory
+// so that LDS admits two; round 2, the knobs went with tools/experiments/qp_resident_retired_knobs.patch) was parity-green as
+// well -- the ~200 spilled registers stayed outside the operand rings -- and measured 14.7 ms per launch against 11.3 for one
+// workgroup per CU in the same U-outside form (10.65 with U in LDS): halving every wavefront's rows per pass, ring depth and
+// sweep buffers costs more than the second workgroup's overlap returns.
 template <bool GU, int RTT = 512, bool P64 = false>
 struct OpsResidentT {
     static constexpr int RT = RTT, RNW = RTT / 64;                     // (shadow the namespace-level defaults)
@@ -170,15 +148,9 @@ struct OpsResidentT {
             // no more passes than the round-robin needs: a wavefront's rows beyond its first RMAXT are streamed after
             // barrier (A), i.e. in series with the diagonal chain
             const int cap = RMAXT * (nsq > 6 * RMAXT ? (nsq + 6 * RMAXT - 1) / (6 * RMAXT) : 1);
-#ifndef HIPDRT_QP_CHAINLOAD
-#define HIPDRT_QP_CHAINLOAD 150
-#endif
-#ifndef HIPDRT_QP_LALOAD
-#define HIPDRT_QP_LALOAD 14
-#endif
             // SIMD 0 also runs the diagonal chain (~21k cycles per block column = ~300 MFMA slots of FP64 vector work that a
             // partner's FP64 MFMAs slow down by 40 %, profiles/r02d_chain_partner.txt): wavefront 4 is charged with it
-            int l0 = HIPDRT_QP_CHAINLOAD, l1 = (tb + 2 < ntr) ? HIPDRT_QP_LALOAD * nk2 + 24 : 0, l2 = 0, l3 = 0;      // MFMAs per SIMD
+            int l0 = 150, l1 = (tb + 2 < ntr) ? 14 * nk2 + 24 : 0, l2 = 0, l3 = 0;      // MFMAs per SIMD
             int c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;                          // rows per wavefront
             for (int r = 0; r < nsq; ++r) {
                 // candidate of each SIMD: its row wavefront with fewer rows (SIMD 0: 4, SIMD 1: 5, SIMD 2: 2|6, SIMD 3: 3|7)
@@ -227,13 +199,7 @@ struct OpsResidentT {
         __builtin_amdgcn_wave_barrier();
         return cholinv16_dsc(r0, c0);
     }
-    __device__ __forceinline__ bool cholinv16_dsc(int r0, int c0) const {
-#if HIPDRT_QP_CHOLINV_MFMA
-        return cholinv16_blocked(r0, c0);
-#else
-        return cholinv16_rows(r0, c0);
-#endif
-    }
+    __device__ __forceinline__ bool cholinv16_dsc(int r0, int c0) const { return cholinv16_blocked(r0, c0); }
     // The same in four block steps of four pivots on the matrix pipe: forward elimination of [D | I] to [L' | W], the two
     // halves kept as two MFMA accumulators (lane (li, kq) register rg <-> row kq + 4 rg, column li).  Step k reads its 4 x 4
     // diagonal block (ten v_readlane pairs), factors and inverts it in uniform arithmetic (every lane the same values: four
@@ -292,48 +258,6 @@ struct OpsResidentT {
                 aA = __builtin_amdgcn_mfma_f64_16x16x4f64(pan, X[0], aA, 0, 0, 0);
                 aW = __builtin_amdgcn_mfma_f64_16x16x4f64(pan, Y[0], aW, 0, 0, 0);
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        return ok;
-    }
-    __device__ __forceinline__ bool cholinv16_rows(int r0, int c0) const {
-        const int lane = fresh_lane(), li = lane & 15;
-        const double* D = sm.dsc;
-        const int r = li;
-        double a[16], w[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) { a[c] = D[r * DLD + c]; w[c] = (c == r) ? 1.0 : 0.0; }
-        bool ok = true;
-        double myrinv = 1.0;                             // 1 / L_rr of this lane's row: its scaling is applied once, at the end
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const double piv = bcast_lane(a[c], c);
-            if (!(piv > 0.0)) ok = false;
-            const double rinv = rsqrt(piv);              // 1 / L_cc
-            const double lrc = a[c] * rinv;              // L_rc for r >= c
-            // row operation  row_r -= L_rc * (row_c / L_cc)  below the pivot only.  The pivot row is read here for the last time,
-            // so it stays unscaled in its registers (the factor 1 / L_cc goes into the multiplier) and every row is scaled by
-            // its own 1 / L_rr after the last step: one FMA per element and step instead of two multiplies and an FMA
-            const double lmr = (r > c) ? lrc * rinv : 0.0;
-            myrinv = (r == c) ? rinv : myrinv;
-#pragma unroll
-            for (int j = 0; j <= c; ++j) {
-                w[j] -= lmr * bcast_lane(w[j], c);
-                asm volatile("" : "+v"(w[j]));           // pinned: see below
-            }
-            // the updates are pinned here (opaque use): left to itself the optimiser sinks them to their first use and
-            // keeps every broadcast value alive, which spills -- and a scratch reload queues behind the other
-            // wavefronts' operand traffic
-#pragma unroll
-            for (int k = c + 1; k < 16; ++k) {
-                const double lkc = bcast_lane(lrc, k);
-                a[k] -= lrc * lkc;
-                asm volatile("" : "+v"(a[k]));
-            }
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sm.U[(size_t)(r0 + r) * PLD + c0 + j] = (j <= r) ? w[j] * myrinv : 0.0;
         }
         __builtin_amdgcn_wave_barrier();
         return ok;
@@ -563,14 +487,6 @@ struct OpsResidentT {
 #undef HIPDRT_STEP7
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
                     __builtin_amdgcn_sched_barrier(0);
-#if HIPDRT_QP_LADEPTH == 2
-                    Frag f0, f1;                                     // (two-per-CU experiment: half the registers)
-                    loadf(f0, 0);
-                    for (int k2 = 0; k2 < nk2; k2 += 2) {
-                        loadf(f1, k2 + 1); vm_wait<4>(); multf(f0);
-                        loadf(f0, k2 + 2); vm_wait<4>(); multf(f1);
-                    }
-#else
                     Frag f0, f1, f2, f3;
                     loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
                     for (int k2 = 0; k2 < nk2; k2 += 4) {           // nk2 = 4 jb: a multiple of 4
@@ -579,7 +495,6 @@ struct OpsResidentT {
                         loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
                         loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
                     }
-#endif
                     vm_wait<0>();
                     if (!v3) {
                         // R3 is pure padding (its operand was a stand-in): no panel tiles, identity diagonal
@@ -625,7 +540,6 @@ struct OpsResidentT {
                     d0[0] = make_double2(x30[0], x30[1]);   d0[64] = make_double2(x30[2], x30[3]);
                     d0[128] = make_double2(x31[0], x31[1]); d0[192] = make_double2(x31[2], x31[3]);
                 }
-#if HIPDRT_QP_PREFETCH
                 // next column's source tiles (rows tb+4, tb+5): in flight while the stores above drain
                 if (R2 + 2 < ntr) {
                     const int N2 = R2 + 2, N3 = R3 + 2;
@@ -635,7 +549,6 @@ struct OpsResidentT {
                     pre[6] = tile_src(N3, N3, ntr, fo);
                     have_pre = true;
                 }
-#endif
                 // the two chunks just produced complete the next diagonal block: a tile's register image is its own
                 // operand fragment (register s <-> k-step s)
 #pragma unroll
@@ -857,7 +770,6 @@ struct OpsResidentT {
                             d0[192] = make_double2(x2[u][2], x2[u][3]);
                         }
                     }
-#if HIPDRT_QP_PREFETCH
                     if (ps == npass - 1 && jb + 1 < nblk) {
                         // the source tiles of the next block column's first pass: in flight while the stores above drain
                         int Tn[RMAXT];
@@ -872,7 +784,6 @@ struct OpsResidentT {
                             have_pre = true;
                         }
                     }
-#endif
                     if (fwd) {
                         if (ps == 0) lds_barrier();             // (A2) y_j published by wavefront 0
 #pragma unroll
@@ -929,19 +840,7 @@ struct OpsResidentT {
     // Two barriers per 64 columns instead of six.  Every tile receives exactly the MFMA sequence it receives in factor()
     // (history chunks ascending, x then y half of every half-chunk, the same operand order), so the factor, U and the forward-
     // substituted right-hand side are bit for bit those of the 32-column form (tools/dump_fit.py --cmp).
-#ifndef HIPDRT_QP_RM
-#define HIPDRT_QP_RM 3
-#endif
-#ifndef HIPDRT_QP_LA1HELPER
-#define HIPDRT_QP_LA1HELPER 0          // the old range of wavefront 0's look-ahead history on a row wavefront (la1_helper): measured slower
-#endif
-#ifndef HIPDRT_QP_LA1HELPER_WAVE
-#define HIPDRT_QP_LA1HELPER_WAVE 5
-#endif
-    static constexpr int RM = HIPDRT_QP_RM;      // tile rows per row wavefront and pass (x 4 tile columns = 12 accumulator tiles)
-#ifndef HIPDRT_QP_CHAINLOAD64
-#define HIPDRT_QP_CHAINLOAD64 0
-#endif
+    static constexpr int RM = 3;      // tile rows per row wavefront and pass (x 4 tile columns = 12 accumulator tiles)
     __device__ __forceinline__ void build_schedule64() {
         const int ntr = (n + 15) >> 4, nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
         constexpr int SROW = Smem::SROW;
@@ -951,27 +850,8 @@ struct OpsResidentT {
             const int c = 8 * nk2 + 40;                               // MFMAs of one row: history + two panel solves + block a's update
             const int cap = RM * (nsq > 6 * RM ? (nsq + 6 * RM - 1) / (6 * RM) : 1);
             // SIMD 0 carries wavefront 0 (two chains + 14 MFMAs per half-chunk), SIMD 1 wavefront 1 (22 per half-chunk)
-#ifndef HIPDRT_QP_LA1LOAD
-#define HIPDRT_QP_LA1LOAD 14         // MFMAs per half-chunk charged to SIMD 0 for wavefront 0's look-ahead (part of it now runs behind (A))
-#endif
-#if HIPDRT_QP_LA1HELPER
-            // (wavefront 0 keeps the last 64 columns of its look-ahead history; the rest of super column J + 1's is accumulated
-            // during this one by wavefront HIPDRT_QP_LA1HELPER_WAVE -- la1_helper)
-            int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 2 < ntr) ? HIPDRT_QP_LA1LOAD * (nk2 < 8 ? nk2 : 8) + 48 : 0);
-            const int lh = (J >= 1 && 2 * J + 3 < nblk) ? HIPDRT_QP_LA1LOAD * nk2 : 0;
-#else
-            int l0 = HIPDRT_QP_CHAINLOAD64 + ((tA + 2 < ntr) ? HIPDRT_QP_LA1LOAD * nk2 + 48 : 0);
-#endif
-#ifndef HIPDRT_QP_LA2LOAD
-#define HIPDRT_QP_LA2LOAD 22
-#endif
-            int l1 = (tA + 4 < ntr) ? HIPDRT_QP_LA2LOAD * nk2 + 96 : 0, l2 = 0, l3 = 0;
-#if HIPDRT_QP_LA1HELPER
-            if ((HIPDRT_QP_LA1HELPER_WAVE & 3) == 0) l0 += lh;
-            else if ((HIPDRT_QP_LA1HELPER_WAVE & 3) == 1) l1 += lh;
-            else if ((HIPDRT_QP_LA1HELPER_WAVE & 3) == 2) l2 += lh;
-            else l3 += lh;
-#endif
+            int l0 = (tA + 2 < ntr) ? kLa1Load * nk2 + 48 : 0;
+            int l1 = (tA + 4 < ntr) ? kLa2Load * nk2 + 96 : 0, l2 = 0, l3 = 0;
             int c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
             for (int r = 0; r < nsq; ++r) {
                 const int w2 = c2 <= c6 ? 2 : 6, n2 = c2 <= c6 ? c2 : c6;
@@ -1020,11 +900,8 @@ struct OpsResidentT {
     // first load from the 64 columns just solved.  No s_barrier: who finishes its panel solves early is not held up by who
     // finishes late, and the phases of the wavefronts on one SIMD drift apart (one in its MFMA-bound history pass, the other
     // in its latency-bound panel solves) instead of coinciding.
-#ifndef HIPDRT_QP_SPLITB
-#define HIPDRT_QP_SPLITB 1
-#endif
     __device__ __forceinline__ void arrive_b(int lane) {
-        if (lane == 0) __hip_atomic_fetch_add(&sm.flag[3], 1, HIPDRT_QP_SPLITB ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_add(&sm.flag[3], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ __forceinline__ void wait_b(int J_) const {        // everybody's tiles of super column J_ are stored
         int spins = 0;
@@ -1108,90 +985,10 @@ struct OpsResidentT {
             if (lane == 0) { sm.flag[1] = 0; sm.flag[2] = 0; sm.flag[3] = 0; TL_START(); }
         }
         __syncthreads();
-#if HIPDRT_QP_SPLITB
         // (no barrier (B) behind the last super column either: everybody's tiles are stored before anybody starts a sweep)
         const bool ok = wv == 0 ? f64_chain() : (wv == 1 ? f64_look2() : f64_rows(wv));
         __syncthreads();
         return ok;
-#else
-        if (wv == 0) return f64_chain();
-        if (wv == 1) return f64_look2();
-        return f64_rows(wv);
-#endif
-    }
-
-    // ======== look-ahead helper (HIPDRT_QP_LA1HELPER) =====================================================================
-    // Wavefront 0's look-ahead tiles (rows R2 = 4 Jn + 2, R3 = 4 Jn + 3 of super column Jn: four panel tiles in columns a, the three
-    // tiles of diagonal block b) need their whole history before chain b can start, and wavefront 0 is the one everybody waits for at
-    // (A): with the history on wavefront 0 itself -- even started early, behind (A) of the super column before -- its MFMA-bound
-    // operand ring (shared SIMD) sat in series with the two latency-bound chains, ~40 % of a middle super column.  So the part of
-    // that history that is final a whole super column earlier, columns < 4 (Jn - 1), is accumulated by wavefront 4 (the row
-    // wavefront on wavefront 0's SIMD, which the schedule charges for it anyway) at the START of super column Jn - 1, and
-    // handed over through memory: the seven accumulators' register images go to seven unused tiles of L's upper triangle
-    // (tile row Jn & 1), the LDS word flag[1] = Jn says they are there.  Wavefront 0 picks them up behind chain a of Jn and adds
-    // the last 64 columns itself.  Each accumulator still receives its source tile and then the history chunks in ascending
-    // order, the same MFMA sequence: bit for bit the same tiles (tools/dump_fit.py --cmp).
-    // MEASURED, NOT THE DEFAULT (profiles/r04y_*, r04z_*): 8.10 ms per launch without it; with the helper on wavefront 4 8.56 ms
-    // (its seven-MFMA ring steps saturate SIMD 0's matrix pipe and the first inversion of chain a takes 15.4 k cycles instead
-    // of 5.9 k), on wavefront 5 8.61 ms, on wavefront 6 8.43 ms (the chain is back to its pace and super column 3 drops from
-    // 112 k to 96 k cycles, but the helper's SIMD now finishes its panel solves 15 - 20 k cycles later in super columns 4 and 5
-    // and everybody waits for that at (B)).  The matrix pipes are the bound either way: moving the ring only moves the queue.
-    __device__ __forceinline__ v4d* la1_slot(int Jn, int k) const {          // k = 0 .. 6
-        const int par = Jn & 1;
-        return reinterpret_cast<v4d*>(const_cast<double2*>(tile2(par, par + 2 + k)));
-    }
-    __device__ __forceinline__ void la1_helper(int Jn, int lane, int li, int kq, int fo, int ntr) {
-        const int tAc = 4 * Jn, R2 = tAc + 2, R3 = tAc + 3;
-        const bool v3c = R3 < ntr;
-        v4d p20 = init_tile(R2, tAc, ntr, fo, li, kq), p21 = init_tile(R2, tAc + 1, ntr, fo, li, kq);
-        v4d p30 = init_tile(R3, tAc, ntr, fo, li, kq), p31 = init_tile(R3, tAc + 1, ntr, fo, li, kq);
-        v4d e11 = init_tile(R2, R2, ntr, fo, li, kq), e21 = init_tile(R3, R2, ntr, fo, li, kq);
-        v4d e22 = init_tile(R3, R3, ntr, fo, li, kq);
-        const char* q0 = uniform_ptr(tile2(tAc, 0));
-        const char* q1 = uniform_ptr(tile2(tAc + 1, 0));
-        const char* q2 = uniform_ptr(tile2(R2, 0));
-        const char* q3 = uniform_ptr(tile2(v3c ? R3 : R2, 0));
-        const unsigned voff = (unsigned)fo * 16u;
-        const int kend = 8 * (Jn - 1), klast = kend - 1, knew = kend - 8;      // [knew, kend): the columns of super column Jn - 2
-        struct Frag { v2d b0, b1, a2, a3; };
-        auto loadf = [&](Frag& f_, int k2) {
-            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-            f_.b0 = gload16(q0 + o, voff); f_.b1 = gload16(q1 + o, voff);
-            f_.a2 = gload16(q2 + o, voff); f_.a3 = gload16(q3 + o, voff);
-        };
-#define HIPDRT_STEP7(B0, B1, A2, A3)                                                                \
-        p20 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A2, p20, 0, 0, 0);                       \
-        p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A2, p21, 0, 0, 0);                       \
-        e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A2, e11, 0, 0, 0);                       \
-        if (v3c) {                                                                              \
-            p30 = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, A3, p30, 0, 0, 0);                   \
-            p31 = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, A3, p31, 0, 0, 0);                   \
-            e21 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, A3, e21, 0, 0, 0);                   \
-            e22 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, A3, e22, 0, 0, 0);                   \
-        }
-        auto multf = [&](const Frag& f_) {
-            HIPDRT_STEP7(f_.b0.x, f_.b1.x, f_.a2.x, f_.a3.x)
-            HIPDRT_STEP7(f_.b0.y, f_.b1.y, f_.a2.y, f_.a3.y)
-            __builtin_amdgcn_sched_barrier(0);
-        };
-#undef HIPDRT_STEP7
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the source tiles: from here on the count is ours
-        __builtin_amdgcn_sched_barrier(0);
-        bool arrived = false;
-        if (knew <= 2) { wait_b(Jn - 2); arrived = true; }
-        Frag f0, f1, f2, f3;
-        loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
-        for (int k2 = 0; k2 < kend; k2 += 4) {
-            if (!arrived && k2 + 6 >= knew) { wait_b(Jn - 2); arrived = true; }
-            loadf(f3, k2 + 3); vm_wait<12>(); multf(f0);
-            loadf(f0, k2 + 4); vm_wait<12>(); multf(f1);
-            loadf(f1, k2 + 5); vm_wait<12>(); multf(f2);
-            loadf(f2, k2 + 6); vm_wait<12>(); multf(f3);
-        }
-        vm_wait<0>();
-        la1_slot(Jn, 0)[lane] = p20; la1_slot(Jn, 1)[lane] = p21; la1_slot(Jn, 2)[lane] = p30; la1_slot(Jn, 3)[lane] = p31;
-        la1_slot(Jn, 4)[lane] = e11; la1_slot(Jn, 5)[lane] = e21; la1_slot(Jn, 6)[lane] = e22;
-        if (lane == 0) __hip_atomic_store(&sm.flag[1], Jn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
     // ======== wavefront 0: both chains of a super column and, between them, the look-ahead of block b ====================
@@ -1295,19 +1092,6 @@ struct OpsResidentT {
             v4d x20 = (v4d){0, 0, 0, 0}, x30 = x20, x21_ = x20, x31 = x20;
             if (hasb) {
                 // ---- look-ahead of block b: rows R2, R3 in columns a, diagonal block b ------------------------------
-#if HIPDRT_QP_LA1HELPER
-                if (J >= 2) {                    // wavefront 4 accumulated everything up to the last 64 columns (la1_helper)
-                    int spins = 0;
-                    while (lds_peek32(&sm.flag[1]) < J) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 22)) __builtin_trap();
-                    }
-                    p20 = la1_slot(J, 0)[lane]; p21 = la1_slot(J, 1)[lane]; p30 = la1_slot(J, 2)[lane]; p31 = la1_slot(J, 3)[lane];
-                    e11 = la1_slot(J, 4)[lane]; e21 = la1_slot(J, 5)[lane]; e22 = la1_slot(J, 6)[lane];
-                    la_done = 8 * (J - 1);
-                    la_ready = true;
-                }
-#endif
                 if (!la_ready) {                 // (super column 0, or no early start: tiles straight from P)
                     p20 = init_tile(R2, tA, ntr, fo, li, kq);      p21 = init_tile(R2, tA + 1, ntr, fo, li, kq);
                     p30 = init_tile(R3, tA, ntr, fo, li, kq);      p31 = init_tile(R3, tA + 1, ntr, fo, li, kq);
@@ -1410,7 +1194,6 @@ struct OpsResidentT {
             // their history, until it is done or the other wavefronts stand at barrier (B) -- then (B) first, the rest after
             bool at_b = false;
             la_ready = false;
-#if HIPDRT_QP_PREFETCH_CHAIN && !HIPDRT_QP_LA1HELPER
             if (2 * J + 3 < nblk) {
                 const int N2 = tA + 6, N3 = tA + 7, cA = tA + 4;
                 p20 = init_tile(N2, cA, ntr, fo, li, kq);      p21 = init_tile(N2, cA + 1, ntr, fo, li, kq);
@@ -1423,20 +1206,12 @@ struct OpsResidentT {
                 while (la_done < kend) {
                     la_done = la1_ring(J + 1, la_done, kend, !at_b, 7 * (J + 1));
                     if (la_done < kend && !at_b) {
-#if !HIPDRT_QP_SPLITB
-                        __syncthreads();                        // (B): everybody else is there
-#endif
                         at_b = true;
                         HIPDRT_PROF_ARRIVED();
                     }
                 }
             }
-#endif
-#if HIPDRT_QP_SPLITB
             if (!at_b) { wait_b(J); HIPDRT_PROF_ARRIVED(); }    // (B), this wavefront's half: the next chain overwrites t21 / img
-#else
-            if (!at_b) __syncthreads();                         // (B)
-#endif
             PROF(4);
             TL(0, J, 3);
 #ifdef HIPDRT_QP_PROFILE
@@ -1526,16 +1301,12 @@ struct OpsResidentT {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     Frag f0, f1, f2, f3;
-#if HIPDRT_QP_SPLITB
                     const int knew = nk2 - 8;                   // first half-chunk of the 64 columns solved in super column J - 1
                     bool arrived = false;
                     if (knew <= 2) { wait_b(J - 1); arrived = true; }
-#endif
                     loadf(f0, 0); loadf(f1, 1); loadf(f2, 2);
                     for (int k2 = 0; k2 < nk2; k2 += 4) {
-#if HIPDRT_QP_SPLITB
                         if (!arrived && k2 + 6 >= knew) { wait_b(J - 1); arrived = true; }
-#endif
                         loadf(f3, k2 + 3); vm_wait<18>(); multf(f0);
                         loadf(f0, k2 + 4); vm_wait<18>(); multf(f1);
                         loadf(f1, k2 + 5); vm_wait<18>(); multf(f2);
@@ -1629,7 +1400,6 @@ struct OpsResidentT {
                 wait_y(2 * J + 2);
                 fwd_update(xb[0][0], xb[0][1], Q2, j0b, li, kq);
                 if (v3) fwd_update(xb[1][0], xb[1][1], Q3, j0b, li, kq);
-#if HIPDRT_QP_PREFETCH_LA
                 {
                     // (unconditional, stand-in tile (0, 0) when there are no such rows: see wavefront 0)
                     have_pre = Q2 + 4 < ntr;
@@ -1639,16 +1409,12 @@ struct OpsResidentT {
                     pre[8] = tile_src(N2, N2, ntr, fo); pre[9] = tile_src(N3, N2, ntr, fo);
                     pre[10] = tile_src(N3, N3, ntr, fo);
                 }
-#endif
             } else {
                 __syncthreads();                                // (A)
                 if (sm.flag[0]) return false;
             }
             TL(1, J, 3);
             arrive_b(lane);
-#if !HIPDRT_QP_SPLITB
-            __syncthreads();                                    // (B)
-#endif
         }
         return true;
     }
@@ -1672,9 +1438,6 @@ struct OpsResidentT {
         };
         for (int J = 0; J < nsup; ++J) {
             const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
-#if HIPDRT_QP_LA1HELPER
-            if (wv == HIPDRT_QP_LA1HELPER_WAVE && J >= 1 && 2 * J + 3 < nblk) la1_helper(J + 1, lane, li, kq, fo, ntr);
-#endif
             TL(wv, J, 0);
             unsigned long long m0, m1;
             my_rows(J, m0, m1);
@@ -1764,16 +1527,12 @@ struct OpsResidentT {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
                     __builtin_amdgcn_sched_barrier(0);
                     SlB b0, b1;
-#if HIPDRT_QP_SPLITB
                     const int knew = nk2 - 8;                   // first half-chunk of the 64 columns solved in super column J - 1
                     bool arrived = ps > 0;                      // (a later pass starts behind (A))
                     if (!arrived && knew <= 2) { wait_b(J - 1); arrived = true; }
-#endif
                     loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
                     for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 8 J: a multiple of 4
-#if HIPDRT_QP_SPLITB
                         if (!arrived && k2 + 6 >= knew) { wait_b(J - 1); arrived = true; }
-#endif
                         loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RM + 4>(); mult(a0, b0);
                         loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * RM + 4>(); mult(a1, b1);
                         loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RM + 4>(); mult(a2, b0);
@@ -1858,29 +1617,8 @@ struct OpsResidentT {
                         if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0b, li, kq);
                 }
             }
-#if HIPDRT_QP_PREFETCH_ROWS
-            {
-                // the source tiles of the next super column's first pass: in flight while the stores above drain
-                unsigned long long n0 = 0, n1 = 0;
-                if (J + 1 < nsup) my_rows(J + 1, n0, n1);
-                have_pre = (n0 | n1) != 0;
-#pragma unroll
-                for (int u = 0; u < RM; ++u) {
-                    int r = -1;
-                    if (n0) { r = __builtin_ctzll(n0); n0 &= n0 - 1; }
-                    else if (n1) { r = 64 + __builtin_ctzll(n1); n1 &= n1 - 1; }
-                    // (unconditional, stand-in tile (0, 0) for a row that does not exist: see wavefront 0)
-                    const int Tn = r >= 0 ? tA + 10 + r : 0, cn = r >= 0 ? tA + 4 : 0, st = r >= 0 ? 1 : 0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) pre[u][c] = tile_src(Tn, cn + st * c, ntr, fo);
-                }
-            }
-#endif
             TL(wv, J, 3);
             arrive_b(lane);
-#if !HIPDRT_QP_SPLITB
-            __syncthreads();                                        // (B)
-#endif
         }
         return true;
     }
@@ -1903,8 +1641,8 @@ struct OpsResidentT {
     //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane  ->  row i = lane/4,
     //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
     static constexpr int SW_TW = RNW - 1;                // trailing-update wavefronts
-    static constexpr int SW_FT = (29 + SW_TW - 1) / SW_TW < HIPDRT_QP_SWEEPCAP ? (29 + SW_TW - 1) / SW_TW : HIPDRT_QP_SWEEPCAP;   // forward: buffered tiles each
-    static constexpr int SW_BC = (30 + SW_TW - 1) / SW_TW < HIPDRT_QP_SWEEPCAP ? (30 + SW_TW - 1) / SW_TW : HIPDRT_QP_SWEEPCAP;   // backward: buffered chunks each
+    static constexpr int SW_FT = (29 + SW_TW - 1) / SW_TW < kSweepCap ? (29 + SW_TW - 1) / SW_TW : kSweepCap;   // forward: buffered tiles each
+    static constexpr int SW_BC = (30 + SW_TW - 1) / SW_TW < kSweepCap ? (30 + SW_TW - 1) / SW_TW : kSweepCap;   // backward: buffered chunks each
     static constexpr int SW_NBUF = SW_FT > SW_BC ? SW_FT : SW_BC;
     struct SweepBuf { v2d t[SW_NBUF][4]; };
     struct UrgentBuf { v2d t[2][4]; };
@@ -2053,7 +1791,7 @@ struct OpsResidentT {
                         // more tile rows below than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
                         // from memory, four tile rows per round -- their sixteen loads are requested together, so a round costs
                         // one memory round trip instead of four
-                        constexpr int OVR = (GU && HIPDRT_QP_OVR > 1) ? HIPDRT_QP_OVR : 1;       // (n <= 528 never gets here: no registers spent on it)
+                        constexpr int OVR = 1;       // (n <= 528 never gets here: no registers spent on it)
                         for (int tt0 = tw_ + SW_FT * SW_TW; tt0 < tbelow; tt0 += OVR * SW_TW) {
                             v2d t_[OVR][4];
 #pragma unroll
@@ -2205,7 +1943,7 @@ struct OpsResidentT {
                     {
                         // more finished chunks than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
                         // from memory, four chunks per round (sixteen loads requested together: one round trip per round)
-                        constexpr int OVR = (GU && HIPDRT_QP_OVR > 1) ? HIPDRT_QP_OVR : 1;
+                        constexpr int OVR = 1;
                         for (int c0 = tw_ + SW_BC * SW_TW; c0 < nc; c0 += OVR * SW_TW) {
                             v2d t_[OVR][4];
 #pragma unroll
@@ -2392,7 +2130,7 @@ template <int RTT> static constexpr bool kQpPanel64 = (HIPDRT_QP_PANEL64 != 0) &
 // (the second launch-bound argument is waves per SIMD: 2 in both forms, i.e. one 512-thread or two 256-thread workgroups per
 // CU and at most 256 registers per lane; without it hipcc gives the 256-thread form 393 registers and one workgroup per CU)
 template <bool GU, int RTT = 512>
-__global__ __launch_bounds__(RTT, HIPDRT_QP_MINWAVES) void qp_kernel_resident(QpArgs a, int NP) {
+__global__ __launch_bounds__(RTT, 2) void qp_kernel_resident(QpArgs a, int NP) {
     constexpr int RT = RTT;
     const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
     if (a.active && !a.active[b]) return;

@@ -9,13 +9,35 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, device=None):
+# A world of ONE rank normally skips every collective.  `force` (init_from_env(force=True), or HIPDRT_FORCE_DIST=1 in the
+# environment) keeps them: a one-rank process group is created and broadcast / gather / all-reduce really go through the
+# backend -- on a one-GPU box that is the only way to run RCCL load, the device binding and the host <-> device staging below
+# before a multi-GPU node exists (tests/test_gpu_mapping.py::test_world_one_nccl_group_runs_every_collective, bench.py --force-dist).
+_FORCED = os.environ.get("HIPDRT_FORCE_DIST", "") not in ("", "0")
+
+
+def forced():
+    return _FORCED
+
+
+def active(world=None):
+    """do the collectives of a `world`-rank job go through torch.distributed? (several ranks, or one with `force`)"""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    return dist.is_initialized() and (world > 1 or _FORCED)
+
+
+def init_from_env(backend=None, device=None, force=False):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets
-    them).  Returns (rank, world_size, local_rank).  Single-process runs skip initialisation."""
+    them).  Returns (rank, world_size, local_rank).  Single-process runs skip initialisation unless `force`.
+    A backend that cannot be initialised raises here, before any fit has touched the GPU: the caller exits non-zero
+    (bench.py does), nothing is retried or restarted."""
+    global _FORCED
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    _FORCED = _FORCED or bool(force)
+    if (world > 1 or _FORCED) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -36,7 +58,7 @@ def _dev():
 def broadcast_arrays(arrays, src=0):
     """Broadcast a list of float64 numpy arrays of rank-identical shapes from `src` in ONE collective
     (they are packed into one buffer: the lookup tables are 2 x 16 kB, latency bound)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return [np.asarray(a, dtype=np.float64) for a in arrays]
     shapes = [np.shape(a) for a in arrays]
     flat = np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in arrays])
@@ -56,7 +78,7 @@ def gather_rows(local, counts, dst=0):
     (a gather: only `dst` receives; blocks padded to the largest count); counts[r] = rows owned by rank r.  Returns the
     concatenated array on dst, None elsewhere."""
     local = np.ascontiguousarray(local, dtype=np.float64)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     tail = local.shape[1:]
@@ -73,7 +95,7 @@ def gather_rows(local, counts, dst=0):
 
 
 def max_over_ranks(value):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_dev())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -81,5 +103,5 @@ def max_over_ranks(value):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.barrier()

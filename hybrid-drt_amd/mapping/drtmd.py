@@ -81,12 +81,18 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
     num = z_obs.shape[0]
     chunks = [c for c in np.array_split(np.arange(num), inflight) if len(c)]
     sibs = drt_siblings(drt, len(chunks))
-    for sib in sibs:
-        # several plans side by side already fill the tails of each other's launches: every plan fits its chunk as ONE range
-        # (cutting each of them again inside the library loses: profiles/r04_subbatch_sweep.txt)
-        sib.plan_subbatches = 1
+    # several plans side by side already fill the tails of each other's launches: every plan fits its chunk as ONE range
+    # (cutting each of them again inside the library loses: profiles/r04_subbatch_sweep.txt) -- for the duration of this
+    # call only: the DRT objects get their own setting back below, so that a later one-plan fit on `drt` sub-batches again
+    before = [getattr(sib, 'plan_subbatches', 0) for sib in sibs]
+
+    def pin(sib, k):
+        sib.plan_subbatches = k
         if getattr(sib, '_plan', None) is not None:
-            sib._plan.set_subbatches(1)
+            sib._plan.set_subbatches(k)
+
+    for sib in sibs:
+        pin(sib, 1)
     outs, errs = [None] * len(chunks), [None] * len(chunks)
 
     def work(i):
@@ -97,10 +103,14 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
             errs[i] = exc
 
     threads = [threading.Thread(target=work, args=(i,)) for i in range(len(chunks))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        for sib, k in zip(sibs, before):
+            pin(sib, k)
     for exc in errs:
         if exc is not None:
             raise exc
@@ -300,7 +310,7 @@ def share_lookup_tables(drt, rank, world, src=0, force=False):
     they can (DRT._get_plan hands them to the new plan), so nothing is built twice on them; a plan that already exists is
     re-pointed at the received tables (one matrix rebuild)."""
     from . import dist as hd
-    if world <= 1 or drt.tau_epsilon is None or drt.integrate_method != 'interp':
+    if not (world > 1 or hd.forced()) or drt.tau_epsilon is None or drt.integrate_method != 'interp':
         return False
     key = (float(drt.tau_epsilon), int(world), int(src))
     if not force and getattr(drt, '_lut_shared_key', None) == key:
@@ -439,7 +449,7 @@ def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world
             packed = np.pad(packed, ((0, 0), (0, width - packed.shape[1])))
     elif packed is None:
         packed = np.zeros((0, 1))
-    elif world > 1 and general:
+    elif (world > 1 or hd.forced()) and general:
         # heterogeneous lists: ranks may report different sets of special parameters, i.e. rows of different widths
         width = int(hd.max_over_ranks(packed.shape[1]))
         if packed.shape[1] < width:

@@ -50,6 +50,55 @@ def parity_close(label, actual, desired, bound, scale=None):
     return err
 
 
+# parity(): the same record-and-assert, for the many per-quantity checks of the fixture tests.  The label is "<test id>:<quantity>";
+# its bound comes from tests/parity_bounds.json, a committed table "label -> [measured on the GPU, bound]" that
+# tools/update_parity_bounds.py rewrites from a GPU run's record (bound = 20 x measured, rounded up to 1 / 2 / 5 x 10^k, never
+# below the noise floor of the metric).  A label the table does not know yet is asserted at `default` (the documented tolerance
+# of that quantity) and shows up as "default" in the record, so that the next table update picks it up.
+#   rel=False: max |a - d| / max |d|                  (coefficients: fraction of the largest one)
+#   rel=True : max |a - d| / max(|d|, floor * max|d|) (weights, s vectors, sigma: element by element, entries below `floor`
+#              of the largest measured against that floor)
+_BOUNDS = None
+
+
+def _bounds_table():
+    global _BOUNDS
+    if _BOUNDS is None:
+        import json
+        try:
+            with open(os.path.join(ROOT, "tests", "parity_bounds.json")) as f:
+                _BOUNDS = json.load(f)
+        except OSError:
+            _BOUNDS = {}
+    return _BOUNDS
+
+
+def current_test_id():
+    t = os.environ.get("PYTEST_CURRENT_TEST", "unknown").split(" ")[0]
+    return t.split("::")[-1]
+
+
+def parity(quantity, actual, desired, default=1e-7, rel=False, floor=1e-3, scale=None, bound=None, label=None):
+    import numpy as np
+    label = label or f"{current_test_id()}:{quantity}"
+    actual, desired = np.asarray(actual, dtype=float), np.asarray(desired, dtype=float)
+    assert actual.shape == desired.shape, (label, actual.shape, desired.shape)
+    peak = float(np.abs(desired).max()) if scale is None else float(scale)
+    if rel:
+        den = np.maximum(np.abs(desired), floor * peak)
+        err = float((np.abs(actual - desired) / np.maximum(den, 1e-300)).max()) if actual.size else 0.0
+    else:
+        err = float(np.abs(actual - desired).max()) / max(peak, 1e-300) if actual.size else 0.0
+    src = "call"
+    if bound is None:
+        entry = _bounds_table().get(label)
+        bound, src = (float(entry[1]), "table") if entry is not None else (default, "default")
+    _PARITY_LOG.append((label, err, bound))
+    print(f"parity {label}: measured {err:.2e} bound {bound:.1e} ({src})")
+    assert np.isfinite(err) and err <= bound, f"{label}: deviation {err:.3e} exceeds the bound {bound:.1e} ({src})"
+    return err
+
+
 def pytest_sessionfinish(session, exitstatus):
     if not _PARITY_LOG:
         return

@@ -235,3 +235,34 @@ def test_shard_indices_partition_and_balance():
             lpt = [cost[shard_indices(num, world, r, "lpt", cost)].sum() for r in range(world)]
             blk = [cost[shard_indices(num, world, r, "block", cost)].sum() for r in range(world)]
             assert max(lpt) / min(lpt) < 1.02 <= max(1.02, max(blk) / min(blk))
+
+
+def _forced_world1_worker(rank, world, port):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from hipdrt.mapping import dist as hd
+    assert hd.init_from_env(backend="gloo")[:2] == (0, 1) and not dist.is_initialized() and not hd.active(1)   # default: no group
+    assert hd.init_from_env(backend="gloo", force=True)[:2] == (0, 1) and dist.is_initialized() and hd.active(1)
+    calls = {"broadcast": 0, "gather": 0, "all_reduce": 0}
+    for name in calls:
+        def counted(*a, _f=getattr(dist, name), _n=name, **k):
+            calls[_n] += 1
+            return _f(*a, **k)
+        setattr(dist, name, counted)
+    a = np.arange(5.0)
+    np.testing.assert_array_equal(hd.broadcast_arrays([a])[0], a)
+    rows = np.arange(8.0).reshape(4, 2)
+    np.testing.assert_array_equal(hd.gather_rows(rows, [4]), rows)
+    assert hd.max_over_ranks(3.0) == 3.0
+    assert calls == {"broadcast": 1, "gather": 1, "all_reduce": 1}
+    hd.barrier()
+    dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_runs_the_collectives():
+    """`force` (bench.py --force-dist, HIPDRT_FORCE_DIST=1): a world of one rank creates its process group and sends
+    broadcast / gather / all-reduce through the backend instead of short-cutting them -- the form the GPU suite uses to
+    exercise RCCL on a one-GPU box."""
+    mp.spawn(_forced_world1_worker, args=(1, _free_port()), nprocs=1, join=True)

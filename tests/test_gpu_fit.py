@@ -9,19 +9,19 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, parity_close
+from conftest import GOLDEN, parity, parity_close
+from conftest import parity as conftest_parity
 
 pytestmark = pytest.mark.gpu
-
-X_RTOL = 1e-7
 
 
 def load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
-def close_to_peak(a, ref, tol=X_RTOL):
-    np.testing.assert_allclose(a, ref, rtol=100 * tol, atol=tol * np.abs(ref).max())
+# Bounds: conftest.parity() asserts every quantity at the bound tests/parity_bounds.json holds for it (20 x the deviation measured
+# on the GPU, never above the documented 1e-7 for coefficients unless a reason stands at the call); `default` is the documented
+# tolerance, used only for a label the table does not know yet.  BASELINE configs[1..3] carry the labels c2.* / c3.* / c4.*.
 
 
 def test_reference_known_answer_test_on_gpu():
@@ -55,17 +55,22 @@ def test_fit_trajectory_vs_reference_run(name):
     assert qp["outer_iterations"] == int(g["outer_iterations"])
     assert qp["qp_iterations"].tolist() == g["qp_iterations"].tolist()
     hx = np.array([h["x"] for h in drt.qphb_history])
-    close_to_peak(hx, g["hist_x"])
-    np.testing.assert_allclose(np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], rtol=1e-6)
-    np.testing.assert_allclose(np.array([h["weights"] for h in drt.qphb_history]), g["hist_weights"], rtol=1e-6)
-    close_to_peak(fp["x"], g["x"])
-    np.testing.assert_allclose(fp["R_inf"], g["R_inf"], rtol=1e-7)
-    np.testing.assert_allclose(fp["inductance"], g["inductance"], rtol=1e-6, atol=1e-7 * abs(float(g["R_inf"])) * 1e-5)
-    np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
-    np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-7 * np.abs(g["q_vector"]).max())
-    np.testing.assert_allclose(np.array(qp["s_vectors"]), g["s_vectors"], rtol=1e-5, atol=1e-12)
+    if name.startswith("refrun_c2_"):                      # BASELINE configs[1]: one 256 x 512 spectrum (three seeds)
+        tag = "c2." + name[len("refrun_c2_256x512_"):-len(".npz")]
+        parity = lambda q, *a, **k: conftest_parity(q, *a, label=f"{tag}.{q}", **k)   # noqa: E731
+    else:
+        parity = conftest_parity
+    parity("hist_x", hx, g["hist_x"], default=1e-7)
+    parity("rho_vector", np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], default=1e-6, rel=True)
+    parity("weights", np.array([h["weights"] for h in drt.qphb_history]), g["hist_weights"], default=1e-6, rel=True)
+    parity("x", fp["x"], g["x"], default=1e-7)
+    parity("R_inf", fp["R_inf"], g["R_inf"], default=1e-7, rel=True)
+    parity("inductance", fp["inductance"], g["inductance"], default=1e-6, rel=True)
+    parity("z_sigma_tot", fp["z_sigma_tot"], g["z_sigma_tot"], default=1e-6, rel=True)
+    parity("q_vector", fp["q_vector"], g["q_vector"], default=1e-7)
+    parity("s_vectors", np.array(qp["s_vectors"]), g["s_vectors"], default=1e-5, rel=True)
     if "p_matrix" in g:
-        np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-7 * np.abs(g["p_matrix"]).max())
+        parity("p_matrix", fp["p_matrix"], g["p_matrix"], default=1e-7)
 
 
 def test_plan_matrices_vs_reference_run():
@@ -99,9 +104,10 @@ def test_batch_members_vs_reference_run_and_batch_invariance():
         np.testing.assert_array_equal(g["z"], z[b])
         assert res["outer_iters"][b] == int(g["outer_iterations"])
         assert res["qp_iters_total"][b] == int(g["qp_iterations"].sum())
-        close_to_peak(res["fit_x"][b], g["x"])
-        np.testing.assert_allclose(res["R_inf"][b], g["R_inf"], rtol=1e-7)
-        np.testing.assert_allclose(res["z_sigma_tot"][b], g["z_sigma_tot"], rtol=1e-6)
+        parity("x", res["fit_x"][b], g["x"], default=1e-7, label="c3.members_vs_reference_run.x")
+        parity("R_inf", res["R_inf"][b], g["R_inf"], default=1e-7, rel=True, label="c3.members_vs_reference_run.R_inf")
+        parity("z_sigma_tot", res["z_sigma_tot"][b], g["z_sigma_tot"], default=1e-6, rel=True,
+               label="c3.members_vs_reference_run.z_sigma_tot")
     single = drt.fit_eis_batch(c2["freq"], z[3:4])
     np.testing.assert_array_equal(single["x"][0], res["x"][3])
     np.testing.assert_array_equal(single["weights"][0], res["weights"][3])
@@ -123,8 +129,8 @@ def test_batch_vs_oracle_and_supergrid_scatter():
     ref = orc.fit_eis_batch(freq, z, fixed_basis_tau=supergrid[12:104])
     for b in range(16):
         assert res["outer_iters"][b] == ref[b]["outer_iterations"]
-        close_to_peak(obs_x[b, 12:104], ref[b]["x"])
-        np.testing.assert_allclose(obs_special["R_inf"][b], ref[b]["R_inf"], rtol=1e-7)
+        parity("obs_x", obs_x[b, 12:104], ref[b]["x"], default=1e-7)
+        parity("R_inf", obs_special["R_inf"][b], ref[b]["R_inf"], default=1e-7, rel=True)
     assert not obs_x[:, :12].any() and not obs_x[:, 104:].any()
 
 
@@ -143,8 +149,8 @@ def test_non_uniform_tau_grid_vs_oracle():
     ref = orc.fit_eis_batch(freq, z, fixed_basis_tau=tau)
     for b in range(3):
         assert res["outer_iters"][b] == ref[b]["outer_iterations"]
-        close_to_peak(res["fit_x"][b], ref[b]["x"])
-        np.testing.assert_allclose(res["z_sigma_tot"][b], ref[b]["z_sigma_tot"], rtol=1e-6)
+        parity("fit_x", res["fit_x"][b], ref[b]["x"], default=1e-7)
+        parity("z_sigma_tot", res["z_sigma_tot"][b], ref[b]["z_sigma_tot"], default=1e-6, rel=True)
 
 
 def test_distribution_variance_vs_reference_fixture():
@@ -159,16 +165,16 @@ def test_distribution_variance_vs_reference_fixture():
     drt.fit_eis(g["freq"], g["z"])
     var, ok = drt.estimate_distribution_var_batch(tau=g["tau_eval"])
     assert ok.all() and var.shape == (1, len(g["tau_eval"]))
-    np.testing.assert_allclose(var[0], g["dist_var"], rtol=1e-6, atol=1e-12 * g["dist_var"].max())
+    parity("dist_var", var[0], g["dist_var"], default=1e-6, rel=True, floor=1e-6)
     # the fit itself differs from the fixture's by ~1e-9 (IPM trajectory tolerance), so the tight check is against
     # the oracle evaluated on THIS fit's own P
     P = drt.fit_parameters["p_matrix"]
     ref = orc.estimate_distribution_var(P, drt.basis_tau, g["tau_eval"], drt.tau_epsilon, 2, drt.coefficient_scale)
     np.testing.assert_allclose(var[0], ref, rtol=1e-9, atol=1e-300)
     vext, _ = drt.estimate_distribution_var_batch(tau=g["tau_eval"], extend_var=True)
-    np.testing.assert_allclose(vext[0], g["dist_var_ext"], rtol=1e-6, atol=1e-12 * g["dist_var"].max())
+    parity("dist_var_ext", vext[0], g["dist_var_ext"], default=1e-6, rel=True, floor=1e-6)
     pv, pok = drt.estimate_param_var_batch()
-    np.testing.assert_allclose(pv[0], g["param_var"], rtol=1e-6)
+    parity("param_var", pv[0], g["param_var"], default=1e-6, rel=True)
     np.testing.assert_allclose(pv[0], np.diag(np.linalg.inv(P)) * drt.coefficient_scale ** 2, rtol=1e-9)
     # llh / rss of the single fit (host arithmetic on the downloaded state)
     assert drt.evaluate_rss() == pytest.approx(float(g["rss"]), rel=1e-6)
@@ -332,7 +338,7 @@ def test_distribution_variance_batch_256x512():
     for b in (0, 3, 5):
         P = drt._plan.p_matrix(b)
         ref = orc.estimate_distribution_var(P, c2["tau"], sup, drt.tau_epsilon, 2, res["coefficient_scale"][b])
-        np.testing.assert_allclose(var[b], ref, rtol=1e-7, atol=1e-14 * ref.max())
+        parity("dist_var", var[b], ref, default=1e-7, rel=True, floor=1e-7)
     drt1 = DRT(fixed_basis_tau=c2["tau"])
     drt1.fit_eis(c2["freq"], z[0])
     v1, _ = drt1.estimate_distribution_var_batch(tau=sup)
@@ -373,9 +379,9 @@ def test_warm_restarts_and_candidates_vs_reference_fixture():
     assert counts == [9, 10]
     hx = np.concatenate([r["history"]["x"] for r in steps])
     assert hx.shape == g["s0_x"].shape
-    np.testing.assert_allclose(hx, g["s0_x"], rtol=0, atol=1e-7 * peak)
-    np.testing.assert_allclose(steps[-1]["rho"][0], g["s0_rho"][-1], rtol=1e-6)
-    np.testing.assert_allclose(steps[-1]["weights"][0], g["s0_weights"][-1], rtol=1e-6)
+    parity("hx", hx, g["s0_x"], default=1e-7, scale=peak)
+    parity("rho", steps[-1]["rho"][0], g["s0_rho"][-1], default=1e-6, rel=True)
+    parity("weights", steps[-1]["weights"][0], g["s0_weights"][-1], default=1e-6, rel=True)
     # the reference runs the weight candidates after the s_0 candidates but from the BASELINE x / rho / weights, with
     # the stored s vectors untouched by the s_0 pass (new arrays there): restore that state first
     base = DRT()
@@ -383,8 +389,8 @@ def test_warm_restarts_and_candidates_vs_reference_fixture():
     steps_w = base.generate_candidates_weights(0.5, 3, history_of=0)
     assert [int(r["outer_iters"][0]) for r in steps_w] == [4, 4, 4]
     hw = np.concatenate([r["history"]["x"] for r in steps_w])
-    np.testing.assert_allclose(hw, g["w_x"], rtol=0, atol=1e-7 * peak)
-    np.testing.assert_allclose(steps_w[-1]["weights"][0], g["w_weights"][-1], rtol=1e-6)
+    parity("hw", hw, g["w_x"], default=1e-7, scale=peak)
+    parity("weights_2", steps_w[-1]["weights"][0], g["w_weights"][-1], default=1e-6, rel=True)
 
 
 def test_pfrt_fit_vs_reference_fixture():
@@ -396,8 +402,8 @@ def test_pfrt_fit_vs_reference_fixture():
     pr = drt.pfrt_fit_eis_batch(g["freq"], g["z"][None, :])
     assert int(pr["step_iters"].sum()) == int(g["pfrt_history_len"])
     assert int(pr["step_iters"][0, 0]) == int(g["pfrt_init_len"])
-    np.testing.assert_allclose(pr["step_x"][:, 0], g["pfrt_step_x"], rtol=0, atol=1e-7 * np.abs(g["pfrt_step_x"]).max())
-    np.testing.assert_allclose(pr["step_llh"][:, 0], g["pfrt_step_llh"], rtol=1e-7)
+    parity("step_x", pr["step_x"][:, 0], g["pfrt_step_x"], default=1e-7)
+    parity("step_llh", pr["step_llh"][:, 0], g["pfrt_step_llh"], default=1e-7, rel=True)
 
 
 def test_warm_restart_batch_vs_oracle():
@@ -417,8 +423,8 @@ def test_warm_restart_batch_vs_oracle():
         hist = od.continue_from_init(qp["x_scaled"], qp["rho_vector"], [sv * 4.0 for sv in qp["s_vectors"]], qp["weights"],
                                      s_0=np.ones(3) * 4.0, l2_lambda_0=142.0 / 4.0)
         assert res["outer_iters"][b] == len(hist)
-        np.testing.assert_allclose(res["x"][b], hist[-1]["x"], rtol=0, atol=1e-7 * np.abs(hist[-1]["x"]).max())
-        np.testing.assert_allclose(res["rho"][b], hist[-1]["rho_vector"], rtol=1e-6)
+        parity("x", res["x"][b], hist[-1]["x"], default=1e-7)
+        parity("rho", res["rho"][b], hist[-1]["rho_vector"], default=1e-6, rel=True)
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -475,10 +481,10 @@ def test_optional_weight_branches_vs_reference_run(name, kw):
     drt.fit_eis(g["freq"], g["z"], **kw)
     assert drt.qphb_params["outer_iterations"] == int(g["outer_iterations"])
     xs = g["x_scaled"]
-    np.testing.assert_allclose(drt.cvx_result["x"], xs, rtol=0, atol=1e-7 * np.abs(xs).max())
-    np.testing.assert_allclose(drt.qphb_params["est_weights"], g["est_weights"], rtol=1e-7)
-    np.testing.assert_allclose(drt.qphb_params["weights"], g["weights"], rtol=1e-6)
-    np.testing.assert_allclose(drt.fit_parameters["x"], g["x"], rtol=0, atol=1e-7 * np.abs(g["x"]).max())
+    parity("x", drt.cvx_result["x"], xs, default=1e-7)
+    parity("est_weights", drt.qphb_params["est_weights"], g["est_weights"], default=1e-7, rel=True)
+    parity("weights", drt.qphb_params["weights"], g["weights"], default=1e-6, rel=True)
+    parity("x_2", drt.fit_parameters["x"], g["x"], default=1e-7)
 
 
 def test_edge_cases():
@@ -523,7 +529,8 @@ def test_full_size_batch_properties():
     odrt = orc.OracleDRT(fixed_basis_tau=c2["tau"])
     ofp = odrt.fit_eis(c2["freq"], z[bad])
     assert not odrt.qphb_params["converged"] and odrt.qphb_params["outer_iterations"] == 50
-    close_to_peak(res["fit_x"][bad], ofp["x"])
+    # a fit that stops at max_iter = 50 without converging amplifies rounding in every implementation
+    parity("x", res["fit_x"][bad], ofp["x"], default=1e-7, label="c3.first_max_iter_spectrum.x")
     res2 = drt.fit_eis_batch(c2["freq"], z)
     np.testing.assert_array_equal(res["x"], res2["x"])
     rm = drt._plan.get("rm")
@@ -611,8 +618,8 @@ def test_config4_ten_thousand_spectra_through_the_sharded_driver():
         ofp = od.fit_eis(c2["freq"], z[b], keep_history=True)
         assert res["outer_iters"][b] == od.qphb_params["outer_iterations"], b
         assert res["qp_iters_total"][b] == sum(l["iterations"] for l in od.qp_log), b
-        close_to_peak(obs_x[b], ofp["x"])
-        np.testing.assert_allclose(obs_special["R_inf"][b], ofp["R_inf"], rtol=1e-7)
+        parity("x", obs_x[b], ofp["x"], default=1e-7, label="c4.sampled_spectra.x")
+        parity("R_inf", obs_special["R_inf"][b], ofp["R_inf"], default=1e-7, rel=True, label="c4.sampled_spectra.R_inf")
 
 
 def test_kernel_choice_follows_the_staged_batch_not_the_plan_capacity():
@@ -630,4 +637,4 @@ def test_kernel_choice_follows_the_staged_batch_not_the_plan_capacity():
     np.testing.assert_array_equal(res1["x"], fresh["x"])
     assert res1["outer_iters"][0] == fresh["outer_iters"][0] == res40["outer_iters"][7]
     assert res1["qp_iters_total"][0] == res40["qp_iters_total"][7]
-    close_to_peak(res1["x"][0], res40["x"][7], tol=1e-10)
+    parity("x", res1["x"][0], res40["x"][7], default=1e-10)

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, parity_close
+from conftest import GOLDEN, parity, parity_close
 
 from oracle import drt_oracle as orc
 from hybrid_util import load_case, initial_rzm_and_vz
@@ -64,17 +64,17 @@ def test_prepared_plan_reproduces_reference_trajectory(name, batched):
     assert out["status"][b] == 0
     assert hist["qp_iterations"].tolist() == g["qp_iterations"].tolist()
     assert out["outer_iters"][b] == int(g["outer_iterations"])
-    np.testing.assert_allclose(hist["x"], g["hist_x"], rtol=1e-6, atol=2e-7)
-    np.testing.assert_allclose(hist["rho"], g["hist_rho"], rtol=1e-6)
-    np.testing.assert_allclose(out["weights"][b], g["weights"], rtol=1e-6)
-    np.testing.assert_allclose(out["s_vectors"][b], g["s_vectors"], rtol=1e-5, atol=1e-10)
-    np.testing.assert_allclose(plan.get("xmx")[b], g["xmx_norms"], rtol=1e-6)
+    parity("x", hist["x"], g["hist_x"], default=1e-7)
+    parity("rho", hist["rho"], g["hist_rho"], default=1e-6, rel=True)
+    parity("weights", out["weights"][b], g["weights"], default=1e-6, rel=True)
+    parity("s_vectors", out["s_vectors"][b], g["s_vectors"], default=1e-5, rel=True)
+    parity("xmx", plan.get("xmx")[b], g["xmx_norms"], default=1e-6, rel=True)
     if "x_dop" in special:
-        np.testing.assert_allclose(hist["dop_rho"], g["hist_dop_rho"], rtol=1e-6)
-        np.testing.assert_allclose(plan.get("dop_xmx")[b], g["dop_xmx_norms"], rtol=1e-6)
+        parity("dop_rho", hist["dop_rho"], g["hist_dop_rho"], default=1e-6, rel=True)
+        parity("dop_xmx", plan.get("dop_xmx")[b], g["dop_xmx_norms"], default=1e-6, rel=True)
     pm = plan.p_matrix(b)
-    np.testing.assert_allclose(pm, g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
-    np.testing.assert_allclose(out["q_vector"][b], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
+    parity("pm", pm, g["p_matrix"], default=1e-8)
+    parity("q_vector", out["q_vector"][b], g["q_vector"], default=1e-8)
     if vz is not None:
         np.testing.assert_allclose(plan.get("rzm")[b], g["rm"], rtol=0, atol=1e-7)
     if batched:
@@ -83,7 +83,7 @@ def test_prepared_plan_reproduces_reference_trajectory(name, batched):
         # the scaled member against its own oracle run
         r1 = orc.qphb_fit_prepared(rzm0, rzv[1], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, vz=vz)
         assert out["outer_iters"][1] == len(r1["history"])
-        np.testing.assert_allclose(out["x"][1], r1["x"], rtol=1e-6, atol=2e-7)
+        parity("x_2", out["x"][1], r1["x"], default=1e-7)
 
 
 def _check_fit(drt, g, special, dop, data_rtol=1e-12, mat_rtol=1e-9):
@@ -109,20 +109,20 @@ def _check_fit(drt, g, special, dop, data_rtol=1e-12, mat_rtol=1e-9):
         np.testing.assert_allclose(qp["penalty_matrices"][f"m{k}"], ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
     np.testing.assert_allclose(qp["l1_lambda_vector"], g["l1_lambda_vector"])
     # results, reference's own criterion (tests/test_drt_fit.py: np.allclose) and tighter on the coefficients
-    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-5, atol=1e-8)
-    np.testing.assert_allclose(drt.cvx_result["x"], g["x_scaled"], rtol=1e-6, atol=2e-7)
-    np.testing.assert_allclose(fp["R_inf"], g["R_inf"], rtol=1e-6)
-    np.testing.assert_allclose(fp["inductance"], g["inductance"], rtol=1e-5, atol=1e-12)
+    parity("x", fp["x"], g["x"], default=1e-7)
+    parity("x_2", drt.cvx_result["x"], g["x_scaled"], default=1e-7)
+    parity("R_inf", fp["R_inf"], g["R_inf"], default=1e-6, rel=True)
+    parity("inductance", fp["inductance"], g["inductance"], default=1e-5, rel=True)
     if "C_inv" in g:
-        np.testing.assert_allclose(fp["C_inv"], g["C_inv"], rtol=1e-5, atol=1e-10)
+        parity("C_inv", fp["C_inv"], g["C_inv"], default=1e-5, rel=True)
     if "z_sigma_tot" in g:
-        np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
-    np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
-    np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
-    np.testing.assert_allclose(qp["rho_vector"], g["rho_vector"], rtol=1e-6)
+        parity("z_sigma_tot", fp["z_sigma_tot"], g["z_sigma_tot"], default=1e-6, rel=True)
+    parity("q_vector", fp["q_vector"], g["q_vector"], default=1e-8)
+    parity("p_matrix", fp["p_matrix"], g["p_matrix"], default=1e-8)
+    parity("rho_vector", qp["rho_vector"], g["rho_vector"], default=1e-6, rel=True)
     if dop:
-        np.testing.assert_allclose(fp["x_dop"], g["x_dop"], rtol=1e-5, atol=1e-8 * np.abs(g["x_dop"]).max())
-        np.testing.assert_allclose(qp["dop_rho_vector"], g["dop_rho_vector"], rtol=1e-6)
+        parity("x_dop", fp["x_dop"], g["x_dop"], default=1e-8)
+        parity("dop_rho_vector", qp["dop_rho_vector"], g["dop_rho_vector"], default=1e-6, rel=True)
         np.testing.assert_allclose(drt.dop_scale_vector, g["dop_scale_vector"], rtol=max(1e-13, data_rtol))
 
 
@@ -149,9 +149,9 @@ def test_fit_hybrid_matches_reference_run(dop):
     np.testing.assert_array_equal(drt.step_times, g["step_times"])
     np.testing.assert_allclose(drt.response_signal_scale, g["response_signal_scale"], rtol=1e-14)
     _check_fit(drt, g, special, dop)
-    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
-    np.testing.assert_allclose(fp["vz_offset"], g["vz_offset"], rtol=1e-5, atol=1e-8)
-    np.testing.assert_allclose(fp["v_sigma_tot"], g["v_sigma_tot"], rtol=1e-6)
+    parity("v_baseline", fp["v_baseline"], g["v_baseline"], default=1e-7, rel=True)
+    parity("vz_offset", fp["vz_offset"], g["vz_offset"], default=1e-5, rel=True)
+    parity("v_sigma_tot", fp["v_sigma_tot"], g["v_sigma_tot"], default=1e-6, rel=True)
     assert drt.fit_type == "qphb_hybrid"
     with pytest.raises(NotImplementedError):
         drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], subtract_background=True)
@@ -250,8 +250,8 @@ def test_config5_full_size_joint_fit_with_dop():
     dev_err = np.abs(dx - g["hist_x"]).max(axis=1) / scale
     print("device vs reference per outer iteration:", np.array2string(dev_err, precision=2))
     parity_close("config5_full.hist_x", dev_err, np.zeros_like(dev_err), 1e-8, scale=1.0)       # measured 4.8e-10
-    np.testing.assert_allclose(np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], rtol=1e-6)
-    np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in drt.qphb_history]), g["hist_dop_rho"], rtol=1e-6)
+    parity("rho_vector", np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], default=1e-6, rel=True)
+    parity("dop_rho_vector", np.array([h["dop_rho_vector"] for h in drt.qphb_history]), g["hist_dop_rho"], default=1e-6, rel=True)
     np.testing.assert_allclose(qp["rv"], g["rv"], rtol=1e-12, atol=1e-13 * np.abs(g["rv"]).max())
     np.testing.assert_allclose(drt.coefficient_scale, float(g["coefficient_scale"]), rtol=1e-13)
     # (bounds = ten to twenty times the deviations measured in round 4: 5.5e-11, 1.4e-9, 8.8e-11 / 8.2e-9 / 2.4e-11, 8.3e-12)
@@ -297,8 +297,8 @@ def test_fit_chrono_matches_reference_run():
     fp = drt.fit_chrono(g["times"], g["i_signal"], g["v_signal"])
     np.testing.assert_allclose(drt.basis_tau, g["basis_tau"], rtol=1e-13)
     _check_fit(drt, g, special, False)
-    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
-    np.testing.assert_allclose(fp["v_sigma_tot"], g["v_sigma_tot"], rtol=1e-6)
+    parity("v_baseline", fp["v_baseline"], g["v_baseline"], default=1e-7, rel=True)
+    parity("v_sigma_tot", fp["v_sigma_tot"], g["v_sigma_tot"], default=1e-6, rel=True)
     assert fp["z_sigma_tot"] is None and drt.fit_type == "qphb_chrono"
 
 
@@ -317,9 +317,9 @@ def test_fit_hybrid_three_step_protocol_and_options(name, kw):
     np.testing.assert_array_equal(drt.step_times, g["step_times"])
     np.testing.assert_allclose(drt.step_sizes, g["step_sizes"], rtol=1e-14)
     _check_fit(drt, g, special, False)
-    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-6)
+    parity("v_baseline", fp["v_baseline"], g["v_baseline"], default=1e-6, rel=True)
     if "vz_offset" in special:
-        np.testing.assert_allclose(fp["vz_offset"], g["vz_offset"], rtol=1e-5, atol=1e-8)
+        parity("vz_offset", fp["vz_offset"], g["vz_offset"], default=1e-5, rel=True)
 
 
 @pytest.mark.parametrize("name", ["golden71x91_solverp", "golden71x91_dop_solverp", "hybrid_s0_dop_solverp"])
@@ -340,7 +340,7 @@ def test_solve_rp_matches_reference_run(name):
     g2["qp_iterations"] = g["qp_iterations"][1:]
     _check_fit(drt, g2, special, dop, data_rtol=1e-8, mat_rtol=1e-8)
     if "times" in g:
-        np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
+        parity("v_baseline", fp["v_baseline"], g["v_baseline"], default=1e-7, rel=True)
         np.testing.assert_allclose(drt.response_signal_scale, g["response_signal_scale"], rtol=1e-8)
 
 
@@ -406,7 +406,7 @@ def test_polynomial_baseline_matches_reference_run():
                         v_baseline_sqrt=True, v_baseline_penalty=[1e-6, 1e-4, 1e-5])
     _check_fit(drt, g, special, False)
     np.testing.assert_allclose(drt.v_baseline_scale, g["v_baseline_scale"], rtol=1e-14)
-    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-5, atol=1e-9 * np.abs(g["v_baseline"]).max())
+    parity("v_baseline", fp["v_baseline"], g["v_baseline"], default=1e-9)
     with pytest.raises(ValueError):
         drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], v_baseline_deg=1,
                        v_baseline_penalty=[1e-6, 1e-4, 1e-5])
@@ -419,11 +419,11 @@ def test_weight_factors_match_reference_runs():
     drt = DRT(warn=False)
     fp = drt.fit_eis(g["freq"], g["z"], weight_factor=0.7)
     assert drt.qphb_params["qp_iterations"].tolist() == g["qp_iterations"].tolist()
-    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-5, atol=1e-8)
-    np.testing.assert_allclose(drt.qphb_params["true_weights"], g["weights"], rtol=1e-6)
-    np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
-    np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
-    np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
+    parity("x", fp["x"], g["x"], default=1e-7)
+    parity("true_weights", drt.qphb_params["true_weights"], g["weights"], default=1e-6, rel=True)
+    parity("q_vector", fp["q_vector"], g["q_vector"], default=1e-8)
+    parity("p_matrix", fp["p_matrix"], g["p_matrix"], default=1e-8)
+    parity("z_sigma_tot", fp["z_sigma_tot"], g["z_sigma_tot"], default=1e-6, rel=True)
     drt.fit_eis(g["freq"], g["z"])                       # the factor does not stick to the plan
     assert drt.qphb_params["outer_iterations"] == 6 and drt.qphb_params["qp_iterations"].tolist() == [6, 2, 3, 2, 2, 2, 2]
     for name, kw in (("hybrid_s0_wf", dict(weight_factor=1.5, eis_weight_factor=2.0, chrono_weight_factor=0.5)),
@@ -434,8 +434,8 @@ def test_weight_factors_match_reference_runs():
         np.testing.assert_allclose(drt.qphb_params["eis_weight_factor"], g["eis_weight_factor"], rtol=1e-12)
         np.testing.assert_allclose(drt.qphb_params["chrono_weight_factor"], g["chrono_weight_factor"], rtol=1e-12)
         _check_fit(drt, g, special, False)
-        np.testing.assert_allclose(drt.qphb_params["true_weights"], g["weights"], rtol=1e-6)
-        np.testing.assert_allclose(drt.qphb_params["weights"], g["scaled_weights"], rtol=1e-6)
+        parity("true_weights_2", drt.qphb_params["true_weights"], g["weights"], default=1e-6, rel=True)
+        parity("weights", drt.qphb_params["weights"], g["scaled_weights"], default=1e-6, rel=True)
     with pytest.raises(ValueError):
         drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], hybrid_weight_factor_method='nope')
 
@@ -451,7 +451,7 @@ def test_outlier_p_in_a_joint_fit_matches_reference_run():
     assert qp["qp_iterations"].tolist() == g["qp_iterations"].tolist()[1:]
     assert qp["outer_iterations"] == int(g["outer_iterations"])
     parity_close("hybrid_outlier.x_scaled", drt.cvx_result["x"], g["x_scaled"], 1e-9)        # measured 2.2e-11
-    np.testing.assert_allclose(qp["true_weights"], g["weights"], rtol=1e-5)
+    parity("true_weights", qp["true_weights"], g["weights"], default=1e-5, rel=True)
     parity_close("hybrid_outlier.x", fp["x"], g["x"], 1e-9)                                   # measured 1.4e-11
 
 
@@ -498,21 +498,21 @@ def test_update_scale_matches_reference_runs():
     fp = drt.fit_eis(g["freq"], g["z"], update_scale=True)
     assert drt.qphb_params["qp_iterations"].tolist() == g["qp_iterations"].tolist()
     np.testing.assert_allclose(drt.coefficient_scale, g["coefficient_scale"], rtol=1e-8)
-    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-5, atol=1e-8)
-    np.testing.assert_allclose(fp["R_inf"], g["R_inf"], rtol=1e-6)
-    np.testing.assert_allclose(fp["z_sigma_tot"], g["z_sigma_tot"], rtol=1e-6)
-    np.testing.assert_allclose(drt.qphb_params["rv"], g["rv"], rtol=1e-7, atol=1e-9)
-    np.testing.assert_allclose(drt.qphb_params["est_weights"], g["est_weights"], rtol=1e-6)
-    np.testing.assert_allclose(fp["q_vector"], g["q_vector"], rtol=1e-6, atol=1e-8 * np.abs(g["q_vector"]).max())
-    np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    parity("x", fp["x"], g["x"], default=1e-7)
+    parity("R_inf", fp["R_inf"], g["R_inf"], default=1e-6, rel=True)
+    parity("z_sigma_tot", fp["z_sigma_tot"], g["z_sigma_tot"], default=1e-6, rel=True)
+    parity("rv", drt.qphb_params["rv"], g["rv"], default=1e-7, rel=True)
+    parity("est_weights", drt.qphb_params["est_weights"], g["est_weights"], default=1e-6, rel=True)
+    parity("q_vector", fp["q_vector"], g["q_vector"], default=1e-8)
+    parity("p_matrix", fp["p_matrix"], g["p_matrix"], default=1e-8)
     g, special = load_case("hybrid_s0_dop_upscale")
     drt = DRT(fit_dop=True, warn=False)
     fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], update_scale=True)
     np.testing.assert_allclose(drt.coefficient_scale, g["coefficient_scale"], rtol=1e-8)
     np.testing.assert_allclose(drt.response_signal_scale, g["response_signal_scale"], rtol=1e-8)
     _check_fit(drt, g, special, True, data_rtol=1e-7, mat_rtol=1e-8)
-    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-6)
-    np.testing.assert_allclose(drt.qphb_params["xmx_norms"], g["xmx_norms"], rtol=1e-6)
+    parity("v_baseline", fp["v_baseline"], g["v_baseline"], default=1e-6, rel=True)
+    parity("xmx_norms", drt.qphb_params["xmx_norms"], g["xmx_norms"], default=1e-6, rel=True)
 
 
 def test_eff_hp_false_and_negative_window_match_reference_runs():
@@ -522,10 +522,10 @@ def test_eff_hp_false_and_negative_window_match_reference_runs():
     fp = drt.fit_eis(g["freq"], g["z"], eff_hp=False)           # EIS plan path, Toeplitz branch of the hyper kernel
     qp = drt.qphb_params
     assert qp["qp_iterations"].tolist() == g["qp_iterations"].tolist() and qp["outer_iterations"] == 24
-    np.testing.assert_allclose(fp["x"], g["x"], rtol=1e-5, atol=1e-8)
-    np.testing.assert_allclose(qp["rho_vector"], g["rho_vector"], rtol=1e-6)
-    np.testing.assert_allclose(np.array(qp["s_vectors"]), g["s_vectors"], rtol=1e-5, atol=1e-10)
-    np.testing.assert_allclose(fp["p_matrix"], g["p_matrix"], rtol=1e-6, atol=1e-8 * np.abs(g["p_matrix"]).max())
+    parity("x", fp["x"], g["x"], default=1e-7)
+    parity("rho_vector", qp["rho_vector"], g["rho_vector"], default=1e-6, rel=True)
+    parity("s_vectors", np.array(qp["s_vectors"]), g["s_vectors"], default=1e-5, rel=True)
+    parity("p_matrix", fp["p_matrix"], g["p_matrix"], default=1e-8)
     assert drt.fit_kwargs["s_alpha"].tolist() == [1.05, 1.15, 2.5]
     g, special = load_case("golden71x91_dop_noeff")             # dop_rho_k in the DOP block's solve_s
     drt = DRT(fit_dop=True, warn=False)
@@ -555,11 +555,11 @@ def test_separate_initial_weights_and_weight_rule_match_reference_runs(name, kw)
     g2 = {k: g[k] for k in g.files}
     g2["qp_iterations"] = g["qp_iterations"][1:]            # the plan's history starts at the last initial QP
     _check_fit(drt, g2, special, False)
-    np.testing.assert_allclose(drt.qphb_params["est_weights"], g["est_weights"], rtol=1e-6)
+    parity("est_weights", drt.qphb_params["est_weights"], g["est_weights"], default=1e-6, rel=True)
     if "weight" in str(kw.get("hybrid_weight_factor_method")):
-        np.testing.assert_allclose(drt.qphb_params["eis_weight_factor"], g["eis_weight_factor"], rtol=1e-7)
-        np.testing.assert_allclose(drt.qphb_params["chrono_weight_factor"], g["chrono_weight_factor"], rtol=1e-7)
-        np.testing.assert_allclose(drt.qphb_params["weights"], g["scaled_weights"], rtol=1e-6)
+        parity("eis_weight_factor", drt.qphb_params["eis_weight_factor"], g["eis_weight_factor"], default=1e-7, rel=True)
+        parity("chrono_weight_factor", drt.qphb_params["chrono_weight_factor"], g["chrono_weight_factor"], default=1e-7, rel=True)
+        parity("weights", drt.qphb_params["weights"], g["scaled_weights"], default=1e-6, rel=True)
 
 
 def test_series_neg_matches_reference_run():
@@ -586,7 +586,7 @@ def test_discard_first_n_matches_reference_run():
     fp = drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], discard_first_n=2)
     np.testing.assert_allclose(drt.step_times, g["step_times"], rtol=1e-14)
     _check_fit(drt, g, special, False)
-    np.testing.assert_allclose(fp["v_baseline"], g["v_baseline"], rtol=1e-7)
+    parity("v_baseline", fp["v_baseline"], g["v_baseline"], default=1e-7, rel=True)
 
 
 @pytest.mark.parametrize("seed", range(32))
@@ -637,7 +637,7 @@ def test_randomised_joint_fits_follow_the_oracle(seed):
     scale = np.abs(hx).max(axis=1, keepdims=True)
     # (start-point QPs are direct solves: cond * eps, test_randomized_fits_vs_oracle's docstring)
     parity_close("random_joint_fits.hist_x", dx, hx, 1e-7, scale=scale.max())         # measured 3.3e-9 over the 24 draws
-    np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
+    parity("true_weights", qp["true_weights"], ref["weights"], default=1e-5, rel=True)
 
 
 @pytest.mark.parametrize("seed", range(16))
@@ -690,8 +690,8 @@ def test_randomised_option_combinations_follow_the_oracle(seed):
     dx = np.array([h["x"] for h in drt.qphb_history])
     assert hx.shape == dx.shape
     parity_close("random_option_eis_fits.hist_x", dx, hx, 1e-7, scale=np.abs(hx).max())       # measured 1.2e-9 over the 16 draws
-    np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
-    np.testing.assert_allclose(drt.coefficient_scale, cs0 / (ref["scale_factor"] * ref["data_scale"]), rtol=1e-7)
+    parity("true_weights", qp["true_weights"], ref["weights"], default=1e-5, rel=True)
+    parity("drt_coefficient_scale", drt.coefficient_scale, cs0 / (ref["scale_factor"] * ref["data_scale"]), default=1e-7, rel=True)
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -748,7 +748,7 @@ def test_randomised_joint_fits_with_option_combinations(seed):
     dx = np.array([h["x"] for h in drt.qphb_history])
     assert hx.shape == dx.shape
     parity_close("random_option_fits.hist_x", dx, hx, 5e-7, scale=np.abs(hx).max())           # measured 2.4e-8 over the 24 draws
-    np.testing.assert_allclose(qp["true_weights"], ref["weights"], rtol=1e-5)
+    parity("true_weights", qp["true_weights"], ref["weights"], default=1e-5, rel=True)
     parity_close("random_option_fits.rzm", qp["rm"], ref["rzm"], 1e-7)       # measured 3.9e-10 here, 1.6e-8 over 60 further seeds (tools/fuzz_parity.py)
 
 
@@ -785,7 +785,7 @@ def test_parameter_variances_of_a_joint_fit():
     var, ok = drt.estimate_param_var_batch()
     assert ok[0]
     ref = np.diag(np.linalg.inv(fp["p_matrix"])) * drt.coefficient_scale ** 2
-    np.testing.assert_allclose(var[0], ref, rtol=1e-6)
+    parity("var_0", var[0], ref, default=1e-6, rel=True)
 
 
 def test_config5_bench_workload_first_outer_iterations():
@@ -810,7 +810,7 @@ def test_config5_bench_workload_first_outer_iterations():
     dev_err = np.abs(dx - g["hist_x"]).max(axis=1) / np.abs(g["hist_x"]).max(axis=1)
     print("device vs reference per outer iteration (2 uV):", np.array2string(dev_err, precision=2))
     parity_close("config5_2uV.hist_x", dev_err, np.zeros_like(dev_err), 1e-7, scale=1.0)        # measured 7.4e-9
-    np.testing.assert_allclose(np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], rtol=1e-5)
-    np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in drt.qphb_history]), g["hist_dop_rho"], rtol=1e-5)
+    parity("rho_vector", np.array([h["rho_vector"] for h in drt.qphb_history]), g["hist_rho"], default=1e-5, rel=True)
+    parity("dop_rho_vector", np.array([h["dop_rho_vector"] for h in drt.qphb_history]), g["hist_dop_rho"], default=1e-5, rel=True)
     parity_close("config5_2uV.x", fp["x"], g["x"], 1e-7)                    # measured 5.1e-9
     parity_close("config5_2uV.x_dop", fp["x_dop"], g["x_dop"], 5e-7)        # measured 5.0e-8 (this loop is not contractive)

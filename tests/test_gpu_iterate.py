@@ -3,6 +3,8 @@ signature -- against the reference-run fixtures (first pass of a recorded fit) a
 import numpy as np
 import pytest
 
+from conftest import parity
+
 from oracle import drt_oracle as orc
 from hybrid_util import load_case
 
@@ -47,11 +49,11 @@ def test_first_pass_reproduces_the_recorded_reference_iteration(name):
     st = _start_state(g, hyp, n, dop)
     history = []
     x, s, rho, dop_rho, w, outlier_t, out_tvt, cvx, conv = _ours(qphb, st, g, special, hyp, pen, history)
-    np.testing.assert_allclose(x, g["hist_x"][0], rtol=1e-6, atol=2e-7)
-    np.testing.assert_allclose(rho, g["hist_rho"][0], rtol=1e-6)
-    np.testing.assert_allclose(w, g["hist_weights"][0], rtol=1e-6)
+    parity("x", x, g["hist_x"][0], default=1e-7)
+    parity("rho", rho, g["hist_rho"][0], default=1e-6, rel=True)
+    parity("w", w, g["hist_weights"][0], default=1e-6, rel=True)
     if dop is not None:
-        np.testing.assert_allclose(dop_rho, g["hist_dop_rho"][0], rtol=1e-6)
+        parity("dop_rho", dop_rho, g["hist_dop_rho"][0], default=1e-6, rel=True)
     else:
         assert dop_rho is None
     assert cvx["iterations"] == int(g["qp_iterations"][1]) and cvx["status"] == "optimal"
@@ -75,12 +77,12 @@ def test_chained_passes_follow_the_oracle(name):
         x, s, rho, dop_rho, w, cvx, conv = orc.iterate_qphb_general(
             st["x"], s_in, st["rho"], st["dop_rho"], g["rv"], st["weights"], g["est_weights"], g["rm"], g["vmm"], plist,
             g["l1_lambda_vector"], hyp, st["xmx"], st["dop_xmx"], True, special, ns, dop, 1e-2)
-        np.testing.assert_allclose(ours[0], x, rtol=1e-6, atol=2e-7)
-        np.testing.assert_allclose(ours[1], np.array(s), rtol=1e-5, atol=1e-10)
-        np.testing.assert_allclose(ours[2], rho, rtol=1e-6)
-        np.testing.assert_allclose(ours[4], w, rtol=1e-6)
+        parity("x", ours[0], x, default=1e-7)
+        parity("s_vectors", ours[1], np.array(s), default=1e-5, rel=True)
+        parity("rho", ours[2], rho, default=1e-6, rel=True)
+        parity("weights", ours[4], w, default=1e-6, rel=True)
         if dop is not None:
-            np.testing.assert_allclose(ours[3], dop_rho, rtol=1e-6)
+            parity("dop_rho", ours[3], dop_rho, default=1e-6, rel=True)
         assert ours[7]["iterations"] == cvx["iterations"]
         np.testing.assert_allclose(ours[7]["primal objective"], cvx["primal objective"], rtol=1e-8)
         assert ours[8] == conv

@@ -100,3 +100,62 @@ def test_lookup_tables_travel_between_instances():
     c.install_lookup_tables(*a.lookup_tables())
     fc = c.fit_hybrid(*m)
     np.testing.assert_array_equal(fa["x"], fc["x"])
+
+
+_WORLD_ONE_NCCL = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["HIPDRT_ROOT"])
+import torch
+import torch.distributed as tdist
+from hipdrt.mapping import dist as hd
+torch.cuda.set_device(0)
+rank, world, local = hd.init_from_env(backend="nccl", device=0, force=True)      # a ONE-rank RCCL process group
+assert (rank, world) == (0, 1) and tdist.is_initialized() and tdist.get_backend() == "nccl" and hd.active(world)
+calls = {"broadcast": 0, "gather": 0, "all_reduce": 0}
+for name in calls:
+    def counted(*a, _f=getattr(tdist, name), _n=name, **k):
+        calls[_n] += 1
+        return _f(*a, **k)
+    setattr(tdist, name, counted)
+a, b = np.arange(7.0), np.linspace(0, 1, 12).reshape(3, 4)
+ra, rb = hd.broadcast_arrays([a, b], src=0)
+assert np.array_equal(ra, a) and np.array_equal(rb, b)
+rows = np.arange(15.0).reshape(5, 3)
+assert np.array_equal(hd.gather_rows(rows, [5], dst=0), rows)
+assert hd.max_over_ranks(2.5) == 2.5
+hd.barrier()
+assert calls == {"broadcast": 1, "gather": 1, "all_reduce": 1}, calls
+# the sharded driver itself on the one-rank group: lookup tables broadcast once, the map gathered with one collective
+from hipdrt import synth
+from hipdrt.mapping import fit_observations, fit_observations_sharded
+from hipdrt.models import DRT
+freq = np.logspace(5, 0, 41)
+z = synth.zarc2_batch(freq, 6, first_seed=60)
+drt = DRT()
+obs_x, obs_special, res = fit_observations_sharded(drt, freq, z)                  # rank / world from the process group
+assert calls["broadcast"] == 2 and calls["gather"] == 2, calls
+ref_x, ref_special, ref = fit_observations(DRT(), freq, z)
+assert np.array_equal(obs_x, ref_x) and np.array_equal(obs_special["R_inf"], ref_special["R_inf"])
+assert np.array_equal(res["outer_iters"], ref["outer_iters"])
+fit_observations_sharded(drt, freq, z)                                            # second map: no broadcast, one gather
+assert calls["broadcast"] == 2 and calls["gather"] == 3, calls
+hd.barrier()
+tdist.destroy_process_group()
+print("WORLD1_NCCL_OK " + json.dumps(calls))
+'''
+
+
+def test_world_one_nccl_group_runs_every_collective():
+    """The multi-GPU path's collectives through the REAL backend on the one GPU of the box: a fresh child process creates a
+    world-1 `nccl` (= RCCL) process group bound to cuda:0 and runs broadcast_arrays / gather_rows / max_over_ranks / barrier
+    and two maps of fit_observations_sharded through it (`force`: no world == 1 early-out), with the collectives counted
+    and the gathered map bit-equal to the un-sharded driver's.  What this pins before an 8-GPU node exists: RCCL loads and
+    initialises, `device_id` binding, the numpy -> device tensor -> collective -> host staging of mapping/dist.py."""
+    import subprocess
+    import sys
+    from conftest import ROOT as root
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517",
+               HIPDRT_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    pr = subprocess.run([sys.executable, "-c", _WORLD_ONE_NCCL], env=env, capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0 and "WORLD1_NCCL_OK" in pr.stdout, (pr.returncode, pr.stdout[-2000:], pr.stderr[-4000:])

@@ -6,7 +6,7 @@ import time
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, parity
 
 pytestmark = pytest.mark.gpu
 
@@ -62,7 +62,7 @@ def test_qp_vs_reference_run(ctx, name):
     assert res["iterations"].tolist() == g["qp_iterations"].tolist()
     for i in range(nqp):
         ref = g[f"qp{i}_x"]
-        np.testing.assert_allclose(res["x"][i], ref, rtol=1e-6, atol=1e-7 * np.abs(ref).max())
+        parity("x", res["x"][i], ref, default=1e-7)
         assert abs(res["pcost"][i] - float(g[f"qp{i}_pcost"])) <= 1e-9 * abs(float(g[f"qp{i}_pcost"]))
 
 
@@ -127,7 +127,7 @@ def test_solve_convex_opt_mirror(ctx):
     out = qphb.solve_convex_opt(w * rv, w[:, None] * rm, l2, l1, True, special)
     ref = g["qp1_x"]
     assert out['iterations'] == int(g["qp_iterations"][1]) and out['status'] == 'optimal'
-    np.testing.assert_allclose(np.array(list(out['x'])), ref, rtol=1e-6, atol=1e-7 * np.abs(ref).max())
+    parity("x", np.array(list(out['x'])), ref, default=1e-7)
 
 
 @pytest.mark.parametrize("n", [529, 564, 641, 700, 1078, 1500, 2048])
@@ -154,7 +154,7 @@ def test_large_problems_on_the_tile_packed_kernel(n):
         for b in (0, B - 1):
             r = coneqp_boxlow(Ps[b], qs[b], h)
             assert r["iterations"] == res["iterations"][b]
-            np.testing.assert_allclose(res["x"][b], r["x"], rtol=0, atol=1e-9 * np.abs(r["x"]).max())
+            parity("x", res["x"][b], r["x"], default=1e-9)
     res6 = ctx.qp_batch(np.concatenate([Ps, Ps[:2]]), np.concatenate([qs, qs[:2]]), h)
     np.testing.assert_array_equal(res6["x"][:4], res["x"])
     np.testing.assert_array_equal(res6["x"][4:], res["x"][:2])
@@ -222,7 +222,7 @@ def test_group_kernel_few_large_problems(n, B):
     if n <= 2500:
         r = coneqp_boxlow(Ps[0], qs[0], h)
         assert r["iterations"] == res["iterations"][0]
-        np.testing.assert_allclose(res["x"][0], r["x"], rtol=0, atol=1e-9 * np.abs(r["x"]).max())
+        parity("x", res["x"][0], r["x"], default=1e-9)
     else:
         # KKT residual of the returned point instead of a (slow) CPU solve: P x + q - z = 0, z >= 0, z (x + h) ~ 0
         for b in range(B):

@@ -6,7 +6,7 @@ import types
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, parity_close
+from conftest import GOLDEN, parity, parity_close
 
 KEYS = ["p_matrix", "q_vector", "v_baseline", "vz_offset", "R_inf", "coefficient_scale", "response_signal_scale",
         "scaled_response_offset", "v_baseline_scale"]
@@ -42,10 +42,10 @@ def test_oracle_resolve_matches_reference_run(name):
     np.testing.assert_allclose(np.diag(P), g["qp0_P_diag"], rtol=1e-12)
     np.testing.assert_allclose(q, g["qp0_q"], rtol=1e-12, atol=1e-12 * np.abs(g["qp0_q"]).max())
     np.testing.assert_array_equal(h, g["qp0_h"])
-    np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=1e-9 * np.abs(g["x_opt"]).max())   # host BLAS may differ
+    parity("x", x, g["x_opt"], default=1e-9)   # host BLAS may differ
     x2, res2, _ = ro.resolve_observations(obs, special, sigma=2, lambda_psi=10)
     assert res2["iterations"] == int(g["qp_iterations"][1])
-    np.testing.assert_allclose(x2, g["x_opt_sigma2_lambda10"], rtol=0, atol=1e-9 * np.abs(g["x_opt"]).max())
+    parity("x2", x2, g["x_opt_sigma2_lambda10"], default=1e-9, scale=np.abs(g["x_opt"]).max())
 
 
 def test_resize_pq_and_special_shift():
@@ -94,14 +94,13 @@ def test_device_resolve_matches_reference_run(name):
     assert match == (0, nt)
     assert resolve.resolve_observations.last_qp["iterations"] == int(g["qp_iterations"][0])
     scale = np.abs(g["x_opt"]).max()
-    np.testing.assert_allclose(x, g["x_opt"], rtol=0, atol=1e-7 * scale)
+    parity("x", x, g["x_opt"], default=1e-7, scale=scale)
     x2, _ = resolve.resolve_observations(drts, [(0, nt)] * len(drts), True, sigma=2, lambda_psi=10)
     assert resolve.resolve_observations.last_qp["iterations"] == int(g["qp_iterations"][1])
-    np.testing.assert_allclose(x2, g["x_opt_sigma2_lambda10"], rtol=0, atol=1e-7 * scale)
+    parity("x2", x2, g["x_opt_sigma2_lambda10"], default=1e-7, scale=scale)
     x_drt, x_special, _ = resolve.resolve_observations(drts, [(0, nt)] * len(drts), True, unpack=True)
     so = len(g["x_opt"][0]) - nt
-    np.testing.assert_allclose(x_drt, g["x_opt"][:, so:] * g["coefficient_scale"][:, None], rtol=0,
-                               atol=1e-7 * scale * g["coefficient_scale"].max())
+    parity("x_drt", x_drt, g["x_opt"][:, so:] * g["coefficient_scale"][:, None], default=1e-7, scale=scale * g["coefficient_scale"].max())
     assert set(x_special) == {k for k in special if k not in ("v_baseline", "vz_offset")}
 
 
@@ -140,9 +139,9 @@ def test_resolve_group_matches_reference_drtmd():
                                           overlap=int(g["overlap"]))
     assert resolve.resolve_group.last_qp["iterations"] == g["qp_iterations"].tolist()
     scale = np.abs(g["obs_x_resolved"]).max()
-    np.testing.assert_allclose(x_res, g["obs_x_resolved"], rtol=0, atol=1e-7 * scale)
-    np.testing.assert_allclose(sp_res["R_inf"], g["R_inf_resolved"], rtol=1e-6)
-    np.testing.assert_allclose(sp_res["inductance"], g["inductance_resolved"], rtol=1e-5, atol=1e-12)
+    parity("x_res", x_res, g["obs_x_resolved"], default=1e-7, scale=scale)
+    parity("R_inf", sp_res["R_inf"], g["R_inf_resolved"], default=1e-6, rel=True)
+    parity("inductance", sp_res["inductance"], g["inductance_resolved"], default=1e-5, rel=True)
     assert np.abs(x_res - g["obs_x"]).max() > 1e-4 * scale           # the coupling moved the coefficients
 
 
@@ -160,8 +159,7 @@ def test_batch_fits_feed_resolve_like_single_fits():
     nt = int(g["ntau"])
     x, _ = resolve.resolve_observations(fits, [(0, nt)] * len(fits), True)
     parity_close("resolve.batch_fits.x_opt", x, g["x_opt"], 1e-9)            # measured 1.8e-11
-    np.testing.assert_allclose(fits[3].fit_parameters["p_matrix"], g["p_matrix"][3], rtol=1e-5,
-                               atol=1e-7 * np.abs(g["p_matrix"][3]).max())
+    parity("p_matrix", fits[3].fit_parameters["p_matrix"], g["p_matrix"][3], default=1e-7)
 
 
 @pytest.mark.gpu

@@ -116,6 +116,7 @@ SIGNATURES = {
     "hipdrt_plan_obs_llh_terms": [_vp, _dp, _dp],
     "hipdrt_plan_obs_llh_terms_w": [_vp, C.c_int, C.c_double, _dp, _dp],
     "hipdrt_plan_set_state": [_vp, _dp, _dp, _dp, _dp],
+    "hipdrt_plan_set_state_dop": [_vp, _dp],
     "hipdrt_plan_continue": [_vp, C.POINTER(FitOpts), C.c_double, C.c_int],
     "hipdrt_plan_iterate": [_vp, C.POINTER(IterateState), _ip, _ip, _ip, _dp],
     "hipdrt_plan_param_var": [_vp, _dp, _ip],
@@ -500,9 +501,11 @@ class Plan:
             _check(self._lib.hipdrt_plan_obs_llh_terms_w(self._h, 3, float(weights), _p(rss), _p(slw)))
         return rss, slw
 
-    def set_state(self, x=None, rho=None, s=None, weights=None):
+    def set_state(self, x=None, rho=None, s=None, weights=None, dop_rho=None):
         arrs = [None if a is None else _f64(a) for a in (x, rho, s, weights)]
         _check(self._lib.hipdrt_plan_set_state(self._h, *[None if a is None else _p(a) for a in arrs]))
+        if dop_rho is not None:
+            _check(self._lib.hipdrt_plan_set_state_dop(self._h, _p(_f64(dop_rho))))
 
     def continue_fit(self, opts, weight_factor=1.0, min_iter=2):
         _check(self._lib.hipdrt_plan_continue(self._h, C.byref(opts), float(weight_factor), int(min_iter)))

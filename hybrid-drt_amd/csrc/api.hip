@@ -32,7 +32,7 @@ struct hipdrt_plan {
     int prepped = 0;           // launch_prep has run on the staged batch (hipdrt_plan_iterate runs it once)
     hipdrt_prepared_desc desc{};
     long long rm_stride = 0;
-    DevBuf vz_strength, dop_rho, dop_xmx, hist_dop_rho, outlier_t;
+    DevBuf vz_strength, dop_rho, dop_xmx, hist_dop_rho, outlier_t, vz_entry;
     // weight factors (hipdrt_plan_set_weight_factors): w_eff = w * row factor * weight_factor is what the QP sees
     double weight_factor = 1.0;
     int wrow_batched = 0;
@@ -81,7 +81,7 @@ struct hipdrt_plan {
         st.opts = opts; st.continue_mode = 0; st.min_iter = 1;
         st.basis_area = prepared ? desc.basis_area : (eps > 0 ? 1.7724538509055159 / eps : 0.0);   // sqrt(pi) / epsilon
         st.prepared = prepared; st.desc = desc; st.rm_stride = rm_stride; st.rm_rw = rm.d();
-        st.vz_strength = vz_strength.d(); st.dop_rho = dop_rho.d(); st.dop_xmx = dop_xmx.d();
+        st.vz_strength = vz_strength.d(); st.vz_entry = nullptr; st.dop_rho = dop_rho.d(); st.dop_xmx = dop_xmx.d();
         st.hist_dop_rho = hist_dop_rho.d(); st.outlier_t = outlier_t.d();
         st.rm = rm.d(); st.vmm = vmm.d(); st.vmm_iw = vmm_base.p ? vmm_base.d() : vmm.d();
         for (int k = 0; k < 3; ++k) st.mk[k] = mk[k].d();
@@ -1260,6 +1260,16 @@ int hipdrt_plan_set_state(hipdrt_plan* p, const double* x, const double* rho, co
     return HIPDRT_OK;
 }
 
+int hipdrt_plan_set_state_dop(hipdrt_plan* p, const double* dop_rho) {
+    HIPDRT_REQUIRE(p && dop_rho, "NULL pointer");
+    HIPDRT_REQUIRE(p->prepared && p->desc.dop_size > 0, "the plan has no distribution of phasances");
+    HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
+    HIPDRT_CHECK(hipMemcpyAsync(p->dop_rho.p, dop_rho, (size_t)p->B * 3 * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPDRT_CHECK(hipStreamSynchronize(p->ctx->stream));
+    return HIPDRT_OK;
+}
+
 // QP arguments of the outer loop: one P per spectrum in the packed tile layout, the loop's constraint vector
 static QpArgs loop_qp_args(hipdrt_plan* p, const hipdrt_qp_opts& qpo) {
     const int n = p->n;
@@ -1276,20 +1286,34 @@ static QpArgs loop_qp_args(hipdrt_plan* p, const hipdrt_qp_opts& qpo) {
 }
 
 // drt1d._continue_from_init (hybdrt/models/drt1d.py:1270-1365) for the fitted batch: the same outer loop re-entered from
-// the state on the device (x, s, rho, weights; est_weights, xmx norms and data scale stay) with updated hyper-parameters.
+// the state on the device (x, s, rho [, dop_rho], weights; est_weights, xmx / dop_xmx norms and data scale stay) with updated
+// hyper-parameters.  Any data type: on prepared plans (chrono / joint fits, DOP) the plan's row factors -- chrono / eis weight
+// factors, hipdrt_plan_set_weight_factors -- multiply the weights at the top of every iteration together with `weight_factor`
+// (1314-1318), the DOP pass runs as in the fit, and the vz_offset column is rewritten after every iteration from a matrix
+// whose offset column is FROZEN as this call found it (1295-1298, 1353-1357: the reference copies rm at entry, zeroing the
+// baseline columns only; the fit itself copied while the column was still zero).  The plan's scalar weight_factor is not used.
 int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double weight_factor, int min_iter) {
     HIPDRT_REQUIRE(p && opts, "NULL pointer");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
     HIPDRT_REQUIRE(opts->max_iter >= 1 && min_iter >= 1, "max_iter, min_iter >= 1");
     // rejected calls must leave the finished fit as it is: every check comes before the first write
-    HIPDRT_REQUIRE(!p->prepared, "warm restarts are not available on prepared plans");
-    HIPDRT_REQUIRE(!p->has_weight_factors(), "warm restarts take their weight_factor argument; clear the plan's weight factors");
+    HIPDRT_REQUIRE(!(p->prepared && opts->outlier_p > 0.0), "warm restarts of prepared plans with outlier_p are not built");
+    HIPDRT_REQUIRE(p->prepared || !p->has_weight_factors(),
+                   "warm restarts take their weight_factor argument; clear the plan's weight factors");
+    HIPDRT_REQUIRE(!(p->wrow.p && p->wrow_late), "a vector-valued weight_factor belongs to the fit, not to its warm restarts");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
     const int B = p->B, n = p->n, m = p->m;
     TRY(plan_hist_reserve(p, opts->max_iter));
     FitState fs = p->state();
     fs.opts = *opts; fs.continue_mode = 1; fs.min_iter = min_iter;
+    const long long astr = p->rm_stride;
+    if (p->prepared && p->desc.vz_index >= 0) {
+        if (!p->vz_entry.p) HIPDRT_CHECK(p->vz_entry.alloc((size_t)p->capacity * m * sizeof(double)));
+        launch_copy_column(st, B, m, p->rm.d(), astr, p->ldrm, p->desc.vz_index, p->vz_entry.d());
+        LAUNCH_OK();
+        fs.vz_entry = p->vz_entry.d();
+    }
     PhaseTimer tm(st);
     tm.mark(4);
     if (p->hist_b >= 0) HIPDRT_CHECK(hipMemsetAsync(p->hist_rows.p, 0, sizeof(int), st));
@@ -1299,16 +1323,20 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
         HIPDRT_CHECK(hipMemsetAsync(p->qp_iters_total.p, 0, (size_t)B * sizeof(int), st));
         HIPDRT_CHECK(hipStreamSynchronize(st));
     }
-    GramL2 g = plan_l2(p, opts->l2_lambda_0, opts->derivative_weights, 0.0);
+    GramL2 g = plan_l2(p, opts->l2_lambda_0, opts->derivative_weights, p->prepared ? p->desc.dop_l2_lambda_0 : 0.0);
     QpArgs qa = loop_qp_args(p, opts->qp);
     double* const Prow = nullptr;
     for (int it = 0; it < opts->max_iter; ++it) {
         tm.mark(1);
         HIPDRT_CHECK(hipMemsetAsync(p->n_active.p, 0, sizeof(int), st));
-        if (weight_factor != 1.0) launch_scale_weights(st, fs, B, weight_factor);
+        // in place, like the reference's `weights[:num_chrono] *= ...; weights = weights * weight_factor`: the hyper step
+        // replaces the weights with a fresh estimate afterwards
+        if (p->prepared && p->wrow.p)
+            launch_scale_rows(st, B, m, p->w.d(), p->wrow.d(), p->wrow_batched, weight_factor, p->active.i(), p->w.d());
+        else if (weight_factor != 1.0) launch_scale_weights(st, fs, B, weight_factor);
         launch_gram_l2(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), g, Prow, p->ldp, (long long)n * p->ldp, p->active.i(),
-                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n));
-        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i());
+                       p->Ppk.d(), (long long)qp_ppk_doubles(n), qp_nchp(n), astr);
+        launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), p->active.i(), astr);
         LAUNCH_OK();
         tm.mark(2);
         if (B * sizeof(int) <= 48 * 1024) {
@@ -1325,7 +1353,7 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
         if (n_active == 0) break;
     }
     tm.mark(4);
-    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr);
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr, astr);
     LAUNCH_OK();
     tm.mark(-1);
     HIPDRT_CHECK(hipStreamSynchronize(st));

@@ -167,6 +167,8 @@ struct FitState {
     long long rm_stride;   // doubles between the response matrices of consecutive spectra (0 = shared)
     double* rm_rw;         // == rm when the matrices are per spectrum (the vz_offset column is rewritten every iteration)
     const double* vz_strength;   // [m]
+    const double* vz_entry;      // [B][m] or null: warm restarts (continue_mode 1) predict the vz_offset column from a matrix whose
+                                 // offset column is frozen as it stood when the restart began (drt1d.py:1295-1298), not zero
     double *dop_rho, *dop_xmx;   // [B][3]
     double* outlier_t;           // [B][m] or null: 1 - posterior outlier probability of the last estimate_weights (outlier_p set)
     double* hist_dop_rho;
@@ -206,6 +208,7 @@ int device_cus();      // compute units of the current device (qp.hip)
 void launch_scale_weights(hipStream_t s, const FitState& st, int B, double factor);
 void launch_scale_rows(hipStream_t s, int B, int m, const double* w, const double* rows, int batched, double factor,
                        const int* active, double* out);
+void launch_copy_column(hipStream_t s, int B, int m, const double* rm, long long rm_stride, int ldrm, int col, double* out);
 int launch_llh(hipStream_t s, const FitState& st, int B, double* rss, double* slw, int stored = 0, double scalar_w = 1.0);
 void launch_assemble_rm(hipStream_t s, const FitState& st, const double* a_re, const double* a_im, const double* freq,
                         double* rm, int idx_rinf, int idx_induc);

@@ -762,8 +762,15 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
         if (st.premv) { for (int i = tidw; i < m; i += HT) tmp[i] = st.premv[(2 * (size_t)gridDim.x + b) * m + i]; }
         else rows_matvec(rmb, st.ldrm, m, n, xs, tmp);
         __syncthreads();
-        for (int i = tidw; i < m; i += HT)
-            rmb[(size_t)i * st.ldrm + vz] = (i < st.desc.num_chrono ? tmp[i] : -tmp[i]) * st.vz_strength[i];
+        // warm restart (drt1d.py:1295-1298, 1353): rzm_vz is a copy made when _continue_from_init was entered, with the baseline
+        // columns zeroed but the offset column as the previous loop left it -- its contribution comes on top
+        const bool frozen = st.continue_mode == 1 && st.vz_entry != nullptr;
+        const double xvz = frozen ? xg[vz] : 0.0;
+        const double* vze = frozen ? st.vz_entry + (size_t)b * m : nullptr;
+        for (int i = tidw; i < m; i += HT) {
+            const double pred = frozen ? tmp[i] + vze[i] * xvz : tmp[i];
+            rmb[(size_t)i * st.ldrm + vz] = (i < st.desc.num_chrono ? pred : -pred) * st.vz_strength[i];
+        }
     }
     const bool stop = conv && it + 1 >= st.min_iter;          // `converged and it >= min_iter - 1` (drt1d.py:1356)
     if (st.opts.update_scale && st.opts.scale_data && it >= 1 && !stop && it + 1 < st.opts.max_iter && !st.continue_mode) {
@@ -982,6 +989,17 @@ __global__ void scale_rows_kernel(int m, const double* __restrict__ w, const dou
     double v = w[(size_t)b * m + i] * factor;
     if (rows) v *= rows[(size_t)(batched ? b : 0) * m + i];
     out[(size_t)b * m + i] = v;
+}
+
+// out[b][i] = rm_b[i][col]: the vz_offset column as a warm restart finds it; grid (ceil(m/256), B)
+__global__ void copy_column_kernel(int m, const double* __restrict__ rm, long long rm_stride, int ldrm, int col,
+                                   double* __restrict__ out) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[(size_t)b * m + i] = rm[(size_t)b * rm_stride + (size_t)i * ldrm + col];
+}
+
+void launch_copy_column(hipStream_t s, int B, int m, const double* rm, long long rm_stride, int ldrm, int col, double* out) {
+    hipLaunchKernelGGL(copy_column_kernel, dim3((m + 255) / 256, B), dim3(256), 0, s, m, rm, rm_stride, ldrm, col, out);
 }
 
 void launch_scale_rows(hipStream_t s, int B, int m, const double* w, const double* rows, int batched, double factor,

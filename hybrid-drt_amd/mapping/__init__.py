@@ -1,1 +1,2 @@
-from .drtmd import auto_inflight, fit_observations, fit_observations_sharded, shard_indices  # noqa: F401
+from .drtmd import (auto_inflight, fit_observations, fit_observations_pfrt, fit_observations_sharded,  # noqa: F401
+                    shard_indices)

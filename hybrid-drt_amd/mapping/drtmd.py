@@ -238,8 +238,103 @@ def fit_observation_list(drt, observations, tau_supergrid, drt_var=False, ignore
     return obs_x, obs_special, res
 
 
+def fit_observations_pfrt(drt, observations, tau_supergrid, pfrt_factors=None, drt_var=False, ignore_errors=False,
+                          llh_kw=None, rss_kw=None, **fit_kw):
+    """DRTMD with fit_type='pfrt' (drtmd.py:98-100, 1136-1158, 1338-1342): every observation through _pfrt_fit_core
+    (drt1d.py:2558-2700) -- one full fit at the first regularisation factor, one warm restart per further factor -- with one
+    solution PER FACTOR recorded.  Factors: ``pfrt_factors`` (or ``factors=`` among the fit keywords, which is where upstream
+    reads them); None = logspace(-1, 1, 11), _pfrt_fit_core's own default, which is what an upstream DRTMD actually fits with:
+    its ``pfrt_factors`` attribute says logspace(-0.7, 0.7, 11) (drtmd.py:98-100) but its fit_kw never receives them
+    (fit_kw is a plain attribute, the setter at drtmd.py:1490-1500 is not bound), checked against its own run
+    (tests/golden/refrun_drtmd_pfrt6.npz).  Recorded: obs_x (num, S, len(supergrid)), every special
+    parameter (num, S[, size]).  Grouped and batched like fit_observation_list (one device plan per sampling grid).  What the
+    reference takes from the drt1d object after the PFRT run refers to its FIRST step: obs_llh / obs_rss are evaluate_llh /
+    evaluate_rss of the first step's last iterate (qphb_history[-1], drt1d.py:4433-4496) and obs_drt_var the variance of the
+    first step's P matrix (fit_parameters['p_matrix']); the same here.  The reference's own DRTMD stops at a joint observation
+    (v_baseline arrives as (S, 1) where (S,) was allocated, drtmd.py:287); here such specials are stored (num, S, size).
+    Also returned per observation: step_llh (num, S), step_iters (num, S)."""
+    tau_supergrid = np.asarray(tau_supergrid, dtype=float)
+    if 'factors' in fit_kw:
+        pfrt_factors = fit_kw.pop('factors')
+    factors = np.logspace(-1, 1, 11) if pfrt_factors is None else np.asarray(pfrt_factors, dtype=float)
+    num, S, nsup = len(observations), len(factors), len(tau_supergrid)
+    llh_kw, rss_kw = _metric_kw(llh_kw, rss_kw)
+    obs_x = np.zeros((num, S, nsup))
+    obs_special = {}
+    res = dict(obs_llh=np.zeros(num), obs_rss=np.zeros(num), obs_tau_indices=[None] * num, obs_group=np.zeros(num, dtype=int),
+               obs_fit_status=np.zeros(num, dtype=bool), obs_fit_errors=[None] * num, status=np.zeros(num, dtype=np.int64),
+               step_llh=np.zeros((num, S)), step_iters=np.zeros((num, S), dtype=np.int64), pfrt_factors=factors, groups=[])
+    if drt_var:
+        res['obs_drt_var'] = np.zeros((num, S, nsup))
+        res['obs_drt_var_ok'] = np.zeros(num, dtype=bool)
+    pf_kw = {k: fit_kw.pop(k) for k in ('max_iter_per_step', 'max_init_iter', 'xtol', 'nonneg') if k in fit_kw}
+    for g, (kind, idx) in enumerate(observation_groups(observations)):
+        idx = np.asarray(idx)
+        first = {}
+
+        def after_init(out, first=first):
+            # the drt1d object the reference reads from still describes the first step's fit at this point
+            first['llh'], first['rss'] = drt.evaluate_obs_llh_rss_batch(llh_kw=llh_kw, rss_kw=rss_kw)
+            if drt_var:
+                first['var'], first['vok'] = drt.estimate_distribution_var_batch(tau=tau_supergrid, extend_var=True)
+
+        if kind == 'eis':
+            freq = np.asarray(observations[idx[0]][1][0], dtype=float)
+            pr = drt.pfrt_fit_eis_batch(freq, np.array([observations[k][1][1] for k in idx]), factors=factors,
+                                        after_init=after_init, **pf_kw, **fit_kw)
+            basis_tau, cs = pr['basis_tau'], pr['coefficient_scale']
+            ns = drt._plan.ns
+            sp = drt.special_qp_params
+            fx = pr['step_x'][:, :, ns:] * cs[None, :, None]                               # (S, B, ntau)
+            specials = {}
+            if 'R_inf' in sp:
+                specials['R_inf'] = pr['step_x'][:, :, sp['R_inf']['index']] * cs[None, :]
+            if 'inductance' in sp:
+                specials['inductance'] = pr['step_x'][:, :, sp['inductance']['index']] * cs[None, :] * drt.inductance_scale
+        else:
+            meas = []
+            for k in idx:
+                chrono, eis = observations[k]
+                eis = eis if (eis is not None and eis[0] is not None) else (None, None)
+                meas.append((chrono[0], chrono[1], chrono[2], eis[0], eis[1]))
+            preps, out, hypers, kw2, ckw = drt._pfrt_prepared(meas, factors, pf_kw.get('max_iter_per_step', 10),
+                                                              pf_kw.get('max_init_iter', 20), pf_kw.get('xtol', 1e-2),
+                                                              pf_kw.get('nonneg', True), dict(fit_kw), after_init=after_init)
+            pr = drt.pfrt_result
+            basis_tau = preps[0]['basis_tau']
+            fps = [[drt._extract(prep, pr['step_x'][s_, b], out['weights'][b], kw2, ckw) for b, prep in enumerate(preps)]
+                   for s_ in range(S)]
+            fx = np.array([[fp['x'] for fp in row] for row in fps])
+            specials = {key: np.array([[np.asarray(fp[key], dtype=float) for fp in row] for row in fps])
+                        for key in drt.special_qp_params if key in fps[0][0]}
+        left, right = _supergrid_slots(tau_supergrid, basis_tau)
+        ok = np.asarray(pr['status']) >= 0
+        obs_x[idx, :, left:right] = np.where(ok[:, None, None], np.swapaxes(fx, 0, 1), 0.0)
+        for key, val in specials.items():
+            val = np.swapaxes(val, 0, 1)                                                  # (B, S[, size])
+            if key not in obs_special:
+                obs_special[key] = np.zeros((num,) + val.shape[1:])
+            obs_special[key][idx] = np.where(ok.reshape((-1,) + (1,) * (val.ndim - 1)), val, 0.0)
+        res['obs_llh'][idx], res['obs_rss'][idx] = np.where(ok, first['llh'], 0.0), np.where(ok, first['rss'], 0.0)
+        res['step_llh'][idx], res['step_iters'][idx] = pr['step_llh'].T, pr['step_iters'].T
+        res['obs_fit_status'][idx] = ok
+        res['status'][idx] = pr['status']
+        res['obs_group'][idx] = g
+        for j, k in enumerate(idx):
+            res['obs_tau_indices'][k] = (left, right)
+            if not ok[j]:
+                res['obs_fit_errors'][k] = ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+        if drt_var:
+            vok = np.asarray(first['vok'], dtype=bool) & ok
+            res['obs_drt_var'][idx] = np.where(vok[:, None, None], first['var'][:, None, :], 0.0)   # one variance, every factor
+            res['obs_drt_var_ok'][idx] = vok
+        res['groups'].append(dict(kind=kind, indices=idx, basis_tau=basis_tau, tau_indices=(left, right)))
+    _raise_first_error(res, ignore_errors)
+    return obs_x, obs_special, res
+
+
 def fit_observations(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_var=False, ignore_errors=False, llh_kw=None,
-                     rss_kw=None, inflight=1, observations=None, **fit_kw):
+                     rss_kw=None, inflight=1, observations=None, fit_type='drt', pfrt_factors=None, **fit_kw):
     """Fit every observation and scatter the coefficients into supergrid slots like DRTMD.fit_observation does
     (drtmd.py:245-301): returns obs_x (B, len(supergrid)), obs_special dict, and the raw result dict, which also
     carries what the reference keeps per observation:
@@ -257,6 +352,19 @@ def fit_observations(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_
     `tau_supergrid`).  ``inflight`` > 1 (shared-grid form) fits the observations as that many batches side by side
     (sibling plans of `drt`, one host thread each): same results, in the same order, at the throughput of several batches
     in flight; 'auto' = auto_inflight(number of observations).  (Afterwards `drt` itself holds the first batch only.)"""
+    if fit_type not in ('drt', 'pfrt'):
+        raise ValueError(f"Invalid fit_type {fit_type}. Options: ['drt', 'pfrt']")          # drtmd.py:1479-1482
+    if fit_type == 'pfrt':
+        # DRTMD(fit_type='pfrt') (drtmd.py:98-100, 1338-1342): one solution per regularisation factor and observation
+        if observations is None:
+            frequencies, z_obs = np.asarray(frequencies, dtype=float), np.asarray(z_obs)
+            observations = [(None, (frequencies, zb)) for zb in z_obs]
+            if tau_supergrid is None:
+                tau_supergrid = drt.fixed_basis_tau if drt.fixed_basis_tau is not None else drt.tau_supergrid
+        if tau_supergrid is None:
+            raise ValueError("fit_type='pfrt' needs tau_supergrid")
+        return fit_observations_pfrt(drt, observations, tau_supergrid, pfrt_factors=pfrt_factors, drt_var=drt_var,
+                                     ignore_errors=ignore_errors, llh_kw=llh_kw, rss_kw=rss_kw, **fit_kw)
     if observations is not None:
         if tau_supergrid is None:
             raise ValueError('a heterogeneous observation list needs tau_supergrid')

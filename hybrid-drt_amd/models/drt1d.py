@@ -296,11 +296,15 @@ class DRT(PreparedFitMixin):
 
     # ---- warm restarts of the device loop (drt1d.py:1270-1365) and the candidate generators on top (1497-1632) ---
     def continue_from_init(self, x_init=None, rho_vector=None, s_vectors=None, weights=None, weight_factor=1,
-                           xtol=1e-2, max_iter=10, min_iter=2, history_of=-1, **kw):
+                           xtol=1e-2, max_iter=10, min_iter=2, history_of=-1, dop_rho_vector=None, **kw):
         """DRT._continue_from_init for the last fitted batch: the outer loop re-entered on the device from the given
         state (arrays with a leading batch axis; None = the state left by the previous call) with ``kw`` updating the
         hyper-parameters (e.g. s_0, l2_lambda_0).  est_weights, xmx norms and the data scale stay as fitted.
         Returns the same dict of arrays as fit_eis_batch (outer_iters = iterations of this call)."""
+        if isinstance(self._plan, _ffi.PreparedPlan):         # chrono / joint fits, DOP: the same loop on the prepared plan
+            return self._continue_prepared(x_init=x_init, rho_vector=rho_vector, s_vectors=s_vectors, weights=weights,
+                                           dop_rho_vector=dop_rho_vector, weight_factor=weight_factor, xtol=xtol, max_iter=max_iter, min_iter=min_iter,
+                                           history_of=history_of, **kw)
         if self._plan is None or self._last_batch is None:
             raise Exception('continue_from_init needs a finished qphb fit')
         fit_kw = dict(self.fit_kwargs)
@@ -316,20 +320,37 @@ class DRT(PreparedFitMixin):
             res['history'] = plan.history()
         return res
 
+    def _candidate_baseline(self):
+        """What the reference's candidate generators re-read from the finished fit before their first warm restart
+        (drt1d.py:1517-1525, 1587-1594): x of the last recorded iterate, rho / dop_rho and the (scaled) weights of
+        qphb_params -- NOT the s vectors, which its shallow list copies let earlier warm restarts update in place.  Single
+        fits only (a batch fit keeps no per-spectrum qphb_params: its restarts go on from the state on the device)."""
+        qp, hist = getattr(self, 'qphb_params', None), getattr(self, 'qphb_history', None)
+        if not qp or not hist or self._plan.B != 1 or len(qp['weights']) != self._plan.m:
+            return {}
+        base = dict(x_init=np.asarray(hist[-1]['x'])[None, :], rho_vector=np.asarray(qp['rho_vector'])[None, :],
+                    weights=np.asarray(qp['weights'])[None, :])
+        if qp.get('dop_rho_vector') is not None:
+            base['dop_rho_vector'] = np.asarray(qp['dop_rho_vector'])[None, :]
+        return base
+
     def generate_candidates_s0(self, multiplier, steps, xtol=1e-2, max_iter=10, history_of=-1):
-        """DRT._generate_candidates_s0 (drt1d.py:1497-1565) for every spectrum of the last fitted batch: step i
+        """DRT._generate_candidates_s0 (drt1d.py:1497-1565) for the last fit (EIS, chrono or joint; single or batch): step i
         restarts with s_0 * multiplier^i, l2_lambda_0 / multiplier^i and (multiplier > 1) the baseline s vectors
-        scaled by multiplier^i.  Returns the list of per-step result dicts."""
-        base = self.collect_staged()
+        scaled by multiplier^i; the first step from the fit's x / rho / weights, later ones from their predecessor's.
+        Returns the list of per-step result dicts."""
+        base = self._collect_prepared() if isinstance(self._plan, _ffi.PreparedPlan) else self.collect_staged()
         s_base = base['s_vectors'].copy()
         s_in = s_base.copy()
         s_0 = np.broadcast_to(np.asarray(self.fit_kwargs['s_0'], dtype=float), (3,)).copy()
         out = []
+        start = self._candidate_baseline()
         for i in range(1, steps + 1):
             f = multiplier ** i
             s_in = s_base * f if multiplier > 1 else s_in * multiplier
             res = self.continue_from_init(s_vectors=s_in, xtol=xtol, max_iter=max_iter, history_of=history_of,
-                                          s_0=s_0 * f, l2_lambda_0=self.fit_kwargs['l2_lambda_0'] / f)
+                                          s_0=s_0 * f, l2_lambda_0=self.fit_kwargs['l2_lambda_0'] / f, **start)
+            start = {}
             s_in = res['s_vectors'].copy()
             out.append(res)
         return out
@@ -339,9 +360,11 @@ class DRT(PreparedFitMixin):
         As in the reference (whose shallow list copy lets iterate_qphb update the stored s vectors in place) every
         step starts from the s vectors the previous step ended with."""
         out = []
+        start = self._candidate_baseline()
         for i in range(1, steps + 1):
             out.append(self.continue_from_init(weight_factor=multiplier ** i, xtol=xtol, max_iter=max_iter,
-                                               history_of=history_of))
+                                               history_of=history_of, **start))
+            start = {}
         return out
 
     def evaluate_obs_llh_rss_batch(self, llh_kw=None, rss_kw=None):
@@ -390,7 +413,7 @@ class DRT(PreparedFitMixin):
         return alpha_0 * np.log(beta_0) - alpha_n * np.log(beta_n) + loggamma(alpha_n) - loggamma(alpha_0) + slw
 
     def pfrt_fit_eis_batch(self, frequencies, z_batch, factors=None, max_iter_per_step=10, max_init_iter=20,
-                           xtol=1e-2, nonneg=True, **kw):
+                           xtol=1e-2, nonneg=True, after_init=None, **kw):
         """DRT.pfrt_fit_eis (drt1d.py:2558-2690) for B spectra at once: a full fit at the first regularisation factor
         (s_0 * f, l2_lambda_0 / f), then one warm restart per further factor on the device.  Returns
         {'factors', 'step_x' (S, B, n) scaled-space solutions, 'step_llh' (S, B), 'step_iters' (S, B)}."""
@@ -407,13 +430,16 @@ class DRT(PreparedFitMixin):
         init_kw.update(step_hypers(factors[0]))
         res = self.fit_eis_batch(frequencies, z_batch, nonneg=nonneg, max_iter=max_init_iter, xtol=xtol, **init_kw)
         step_x, step_llh, step_iters = [res['x'].copy()], [self.evaluate_step_llh_batch()], [res['outer_iters'].copy()]
+        if after_init is not None:          # (what DRTMD reads from the FIRST step's fit: its P matrix, llh / rss -- mapping)
+            after_init(res)
         for f in factors[1:]:
             res = self.continue_from_init(xtol=xtol, max_iter=max_iter_per_step, **step_hypers(f))
             step_x.append(res['x'].copy())
             step_llh.append(self.evaluate_step_llh_batch())
             step_iters.append(res['outer_iters'].copy())
         self.pfrt_result = {'factors': np.asarray(factors), 'step_x': np.array(step_x), 'step_llh': np.array(step_llh),
-                            'step_iters': np.array(step_iters)}
+                            'step_iters': np.array(step_iters), 'status': res['status'],
+                            'coefficient_scale': res['coefficient_scale'], 'basis_tau': res['basis_tau']}
         return self.pfrt_result
 
     # ---- what DRTMD takes from a finished fit (mapping/drtmd.py:258-279) ----------------------------------------

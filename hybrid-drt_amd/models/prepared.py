@@ -653,6 +653,135 @@ class PreparedFitMixin:
         self._last_prepared = None
         return fp
 
+    # ---- warm restarts on prepared plans (drt1d.py:1270-1365): candidates (1497-1632) and PFRT (2558-2715) ------------
+    def _last_preps(self):
+        lp = getattr(self, '_last_prepared', None)
+        if lp:
+            return lp[0]
+        if getattr(self, '_prep', None) is None:
+            raise Exception('continue_from_init needs a finished qphb fit')
+        return [self._prep]
+
+    def _collect_prepared(self):
+        """the state a warm restart leaves on the device, as arrays with a leading measurement axis"""
+        plan = self._plan
+        out = plan.download(s_vectors=True)
+        res = {k: out[k] for k in ('x', 'rho', 'weights', 's_vectors', 'q_vector', 'outer_iters', 'qp_iters_total', 'status')}
+        if plan.desc.dop_size > 0:
+            res['dop_rho'] = plan.get('dop_rho')
+        res['timings_ms'], res['launches'] = plan.timings()
+        return res
+
+    def _continue_prepared(self, x_init=None, rho_vector=None, s_vectors=None, weights=None, dop_rho_vector=None,
+                           weight_factor=1, eis_weight_factor=None, chrono_weight_factor=None, xtol=1e-2, max_iter=10,
+                           min_iter=2, history_of=-1, **kw):
+        """DRT._continue_from_init (drt1d.py:1270-1365) for the last chrono / joint / DOP fit (single or batch): arrays
+        carry a leading measurement axis, None keeps what the device holds.  As upstream: the chrono / eis weight
+        factors multiply the weights at the top of every iteration together with ``weight_factor`` -- a factor that is
+        not given falls back to the FIT's chrono factor, for both blocks (1284-1287) --, the vz_offset column is rewritten
+        after every iteration from a copy of the matrix frozen at entry (1295-1298), est_weights, xmx / dop_xmx norms
+        and the data scale stay."""
+        plan, preps = self._plan, self._last_preps()
+        fit_kw = dict(self.fit_kwargs)
+        fit_kw.update(kw)
+        fit_kw.update(xtol=xtol, max_iter=max_iter)
+        _, rest = self._split_kwargs(fit_kw)
+        opts, _, _ = self._make_opts(rest)
+        rows = []
+        for pr in preps:
+            nc, m = pr['num_chrono'], pr['m']
+            if nc > 0 and pr['num_eis'] > 0:
+                cf = pr['chrono_weight_factor'] if chrono_weight_factor is None else chrono_weight_factor
+                ef = pr['chrono_weight_factor'] if eis_weight_factor is None else eis_weight_factor
+            else:
+                cf = ef = 1.0
+            rows.append(np.concatenate([np.full(nc, float(cf)), np.full(m - nc, float(ef))]))
+        rows = np.array(rows)
+        plan.set_weight_factors(1.0, None if np.all(rows == 1.0) else rows)
+        plan.set_state(x=x_init, rho=rho_vector, s=s_vectors, weights=weights, dop_rho=dop_rho_vector)
+        plan.record_history(history_of)
+        plan.continue_fit(opts, weight_factor=weight_factor, min_iter=min_iter)
+        res = self._collect_prepared()
+        if history_of >= 0:
+            res['history'] = plan.history()
+        return res
+
+    def _pfrt_prepared(self, measurements, factors, max_iter_per_step, max_init_iter, xtol, nonneg, kw, after_init=None):
+        """DRT._pfrt_fit_core (drt1d.py:2558-2700) on a prepared plan: the full fit at factors[0], one warm restart per
+        further factor with the fit's own chrono / eis weight factors (2660-2668); step log-likelihoods from weights
+        re-estimated on the current iterate alone (2618-2622), all on the device."""
+        from . import qphb
+        base = qphb.get_default_hypers(True, self.fit_dop, self.nu_basis_type)
+        base.update({k: v for k, v in kw.items() if k in base})
+        if factors is None:
+            factors = np.logspace(-1, 1, 11)
+        factors = np.asarray(factors, dtype=float)
+        s_0 = np.broadcast_to(np.asarray(base['s_0'], dtype=float), (3,))
+
+        def step_hypers(f):
+            return dict(s_0=s_0 * f, l2_lambda_0=base['l2_lambda_0'] / f)
+
+        single = len(measurements) == 1
+        init_kw = dict(kw, nonneg=nonneg, max_iter=max_init_iter, xtol=xtol, **step_hypers(factors[0]))
+        fitted = self._fit_prepared(measurements, init_kw, history_of=0 if single else -1)
+        preps, out = fitted[0], fitted[1]
+        if single:          # fit_parameters / qphb_params / qphb_history of the first step, as fit_hybrid leaves them upstream
+            self._store_single(*fitted, 'qphb_hybrid' if preps[0]['num_eis'] and preps[0]['num_chrono'] else
+                               ('qphb_chrono' if preps[0]['num_chrono'] else 'qphb_eis'))
+        else:
+            self._last_prepared = (preps, None)
+        step_x, step_llh, step_iters = [out['x'].copy()], [self.evaluate_step_llh_batch()], [out['outer_iters'].copy()]
+        history = [self._plan.history()] if single else None
+        if after_init is not None:
+            after_init(out)
+        for f in factors[1:]:
+            cf = np.array([pr['chrono_weight_factor'] for pr in preps])
+            ef = np.array([pr['eis_weight_factor'] for pr in preps])
+            same = np.all(cf == cf[0]) and np.all(ef == ef[0])
+            if not same:
+                raise NotImplementedError('per-measurement chrono / eis weight factors in a PFRT batch')
+            res = self._continue_prepared(xtol=xtol, max_iter=max_iter_per_step, history_of=0 if single else -1,
+                                          chrono_weight_factor=float(cf[0]), eis_weight_factor=float(ef[0]),
+                                          **step_hypers(f))
+            step_x.append(res['x'].copy())
+            step_llh.append(self.evaluate_step_llh_batch())
+            step_iters.append(res['outer_iters'].copy())
+            if single:
+                history.append(res['history'])
+        self.pfrt_result = {'factors': factors, 'step_x': np.array(step_x), 'step_llh': np.array(step_llh),
+                            'step_iters': np.array(step_iters), 'status': out['status']}
+        if single:
+            self.pfrt_history = [dict(x=h['x'][i], rho_vector=h['rho'][i], weights=h['weights'][i],
+                                      dop_rho_vector=h['dop_rho'][i] if 'dop_rho' in h else None)
+                                 for h in history for i in range(len(h['x']))]
+        return fitted
+
+    def pfrt_fit_hybrid(self, times, i_signal, v_signal, frequencies, z, factors=None, max_iter_per_step=10,
+                        max_init_iter=20, xtol=1e-2, nonneg=True, **kw):
+        """DRT.pfrt_fit_hybrid (drt1d.py:2705-2715): leaves fit_parameters / qphb_params of the LAST step's state as a fit
+        does, pfrt_result {'factors', 'step_x' (S, 1, n), 'step_llh' (S, 1), 'step_iters' (S, 1)} and pfrt_history."""
+        fitted = self._pfrt_prepared([(times, i_signal, v_signal, frequencies, z)], factors, max_iter_per_step,
+                                     max_init_iter, xtol, nonneg, kw)
+        self.fit_type = 'qphb_hybrid'
+        return self.pfrt_result
+
+    def pfrt_fit_chrono(self, times, i_signal, v_signal, factors=None, max_iter_per_step=10, max_init_iter=20,
+                        xtol=1e-2, nonneg=True, error_structure='uniform', vmm_epsilon=4, **kw):
+        """DRT.pfrt_fit_chrono (drt1d.py:2699-2703)"""
+        self._pfrt_prepared([(times, i_signal, v_signal, None, None)], factors, max_iter_per_step, max_init_iter, xtol,
+                            nonneg, dict(kw, chrono_error_structure=error_structure, chrono_vmm_epsilon=vmm_epsilon))
+        self.fit_type = 'qphb_chrono'
+        return self.pfrt_result
+
+    def pfrt_fit_hybrid_batch(self, times, i_batch, v_batch, frequencies, z_batch, factors=None, max_iter_per_step=10,
+                              max_init_iter=20, xtol=1e-2, nonneg=True, **kw):
+        """pfrt_fit_hybrid for B joint measurements of one protocol at once (what DRTMD with fit_type='pfrt' loops over,
+        drtmd.py:98-100, 1338): step_x (S, B, n), step_llh (S, B), step_iters (S, B)."""
+        meas = [(times, i_batch[b], v_batch[b], frequencies, z_batch[b]) for b in range(len(z_batch))]
+        fitted = self._pfrt_prepared(meas, factors, max_iter_per_step, max_init_iter, xtol, nonneg, kw)
+        self._last_prepared = (fitted[0], None)
+        return self.pfrt_result
+
     # ---- public fits --------------------------------------------------------------------------------------------------
     def fit_hybrid(self, times, i_signal, v_signal, frequencies, z, **kw):
         """DRT.fit_hybrid (drt1d.py:1244-1268): joint fit of one chrono measurement and one impedance spectrum."""

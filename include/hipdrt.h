@@ -280,12 +280,19 @@ int hipdrt_plan_obs_llh_terms_w(hipdrt_plan* plan, int weights_mode, double scal
 /* Overwrite parts of the fitted batch's state on the device (NULL = keep): x[B][n] (also becomes the previous iterate),
  * rho[B][3], s[B][3][n], weights[B][m].  The inputs of drt1d._continue_from_init (x_init, rho_vector, s_vectors, weights). */
 int hipdrt_plan_set_state(hipdrt_plan* plan, const double* x, const double* rho, const double* s, const double* weights);
+/* ... and dop_rho[B][3] of a prepared plan with a distribution of phasances (dop_rho_vector of _continue_from_init) */
+int hipdrt_plan_set_state_dop(hipdrt_plan* plan, const double* dop_rho);
 
-/* drt1d._continue_from_init (hybdrt/models/drt1d.py:1270-1365), EIS fits: re-enter the outer loop from the state on the
+/* drt1d._continue_from_init (hybdrt/models/drt1d.py:1270-1365), any data type: re-enter the outer loop from the state on the
  * device with updated hyper-parameters (opts: s_0, l2_lambda_0, ..., xtol, max_iter), at least min_iter iterations;
- * every iteration first multiplies the weights by weight_factor.  est_weights, xmx norms and the data scale are kept.
+ * every iteration first multiplies the weights by weight_factor -- and, on prepared plans, by the plan's row factors (the
+ * chrono / eis weight factors, 1314-1316: hipdrt_plan_set_weight_factors(plan, 1, rows, batched) beforehand).  est_weights,
+ * xmx / dop_xmx norms and the data scale are kept.  Joint fits: the vz_offset column of every measurement's matrix is
+ * rewritten after each iteration as in the fit, but from a copy whose offset column is frozen as this call found it
+ * (1295-1298, 1353-1357) -- the reference's behaviour, so a chain of warm restarts reproduces pfrt_fit_hybrid (2558-2715).
  * Results through hipdrt_plan_download / _get_history as after hipdrt_plan_fit (outer_iters = iterations of this call).
- * Used by the candidate generators (drt1d.py:1497-1632) and PFRT (2558-2700).                                       */
+ * Used by the candidate generators (drt1d.py:1497-1632) and PFRT (2558-2715, DRTMD fit_type='pfrt': drtmd.py:98-100, 1338).
+ * Not built: outlier_p on prepared plans.                                                                             */
 int hipdrt_plan_continue(hipdrt_plan* plan, const hipdrt_fit_opts* opts, double weight_factor, int min_iter);
 
 /* ---- prepared-matrix plans: the same device loop for any data type (config-5 family) -----------------------------

@@ -225,6 +225,65 @@ def run_candidates(DRT, name, freq, z, ctor_kw):
     print(f"candidates_{name}: s0 history {len(hist_s)}, weights history {len(hist_w)}")
 
 
+def run_warm_restarts_prepared(DRT, name, data, ctor_kw, factors=None):
+    """survey 8f rank 3 on chrono / joint / DOP fits: _continue_from_init re-enters the loop with the vz_offset column rewrite
+    and the chrono / eis weight factors (drt1d.py:1270-1365), driven by pfrt_fit_hybrid / pfrt_fit_chrono (2558-2715; DRTMD's
+    factors logspace(-0.7, 0.7, 11), drtmd.py:98-100) and by the candidate generators (1497-1632).  Every warm restart's
+    iterates are recorded through a wrapper around the reference's own _continue_from_init."""
+    times, i_sig, v_sig, freq, z = data
+    factors = np.logspace(-0.7, 0.7, 11) if factors is None else factors
+    calls = []
+
+    def wrap(drt):
+        inner = drt._continue_from_init
+
+        def recording(*a, **k):
+            hist = inner(*a, **k)
+            calls.append(hist)
+            return hist
+        drt._continue_from_init = recording
+
+    with _quiet():
+        drt = DRT(**ctor_kw)
+        wrap(drt)
+        if freq is None:
+            drt.pfrt_fit_chrono(times, i_sig, v_sig, factors=factors)
+        else:
+            drt.pfrt_fit_hybrid(times, i_sig, v_sig, freq, z, factors=factors)
+    pr = drt.pfrt_result
+    dop = bool(ctor_kw.get("fit_dop"))
+    out = dict(pfrt_factors=np.asarray(pr["factors"]), pfrt_step_x=np.array(pr["step_x"]),
+               pfrt_step_llh=np.array(pr["step_llh"]), pfrt_init_len=len(drt.qphb_history),
+               pfrt_step_iters=np.array([len(drt.qphb_history)] + [len(h) for h in calls]),
+               pfrt_hist_x=np.array([h["x"] for h in drt.pfrt_history]),
+               pfrt_hist_rho=np.array([h["rho_vector"] for h in drt.pfrt_history]),
+               pfrt_hist_weights=np.array([h["weights"] for h in drt.pfrt_history]),
+               pfrt_final_rm=drt.qphb_params["rm"],
+               pfrt_step_p_diag=np.array([np.diag(pm) for pm in pr["step_p_mat"]]))
+    if dop:
+        out["pfrt_hist_dop_rho"] = np.array([h["dop_rho_vector"] for h in drt.pfrt_history])
+    # candidates on a fresh fit (the weight candidates first, as generate_candidates runs them)
+    calls.clear()
+    with _quiet():
+        drt2 = DRT(**ctor_kw)
+        wrap(drt2)
+        if freq is None:
+            drt2.fit_chrono(times, i_sig, v_sig)
+        else:
+            drt2.fit_hybrid(times, i_sig, v_sig, freq, z)
+        base_len = len(drt2.qphb_history)
+        cx_w, hist_w, _ = drt2._generate_candidates_weights(0.5, 3, 1e-2, 10)
+        cx_s, hist_s, _ = drt2._generate_candidates_s0(4, 2, 1e-2, 10)
+    out.update(cand_base_len=base_len, cand_call_iters=np.array([len(h) for h in calls]),
+               cand_w_x=np.array([h["x"] for h in hist_w]), cand_w_weights=np.array([h["weights"] for h in hist_w]),
+               cand_w_rho=np.array([h["rho_vector"] for h in hist_w]),
+               cand_s0_x=np.array([h["x"] for h in hist_s]), cand_s0_weights=np.array([h["weights"] for h in hist_s]),
+               cand_s0_rho=np.array([h["rho_vector"] for h in hist_s]),
+               cand_s0_s=np.array([np.array(h["s_vectors"]) for h in hist_s]))
+    np.savez_compressed(os.path.join(OUT, f"refrun_warm_{name}.npz"), **out)
+    print(f"warm_{name}: pfrt step iterations {out['pfrt_step_iters'].tolist()}, candidate calls {out['cand_call_iters'].tolist()}")
+
+
 def run_hybrid_case(DRT, cvxopt, name, data, ctor_kw, fit_kw):
     """config-5 family (drt1d.py:1244-1268 -> 102-1104): joint chrono + EIS fit, optionally with the distribution of
     phasances; every prepared quantity the build's host layer must reproduce, the QP matrices, the per-iteration
@@ -502,6 +561,30 @@ def run_drtmd_mixed(n_obs=16):
     print(f"drtmd_mixed16: {n_obs} obs, specials {list(dmd.obs_special)}, tau slices {sorted(set(map(tuple, dmd.obs_tau_indices)))}")
 
 
+def run_drtmd_pfrt(n_obs=6):
+    """the reference's own DRTMD with fit_type='pfrt' (mapping/drtmd.py:98-100, 1136-1158, 1338-1342: every observation through
+    _pfrt_fit_core with the factors logspace(-0.7, 0.7, 11)) on the first observations of the mixed map: obs_x
+    (n_obs, 11, supergrid), every special parameter per factor, obs_llh / obs_rss, obs_tau_indices, obs_drt_var."""
+    from hybdrt.mapping.drtmd import DRTMD
+    sup = np.logspace(-8, 4, 121)
+    # (impedance observations only: with a joint observation the reference's DRTMD stops in its own bookkeeping --
+    # v_baseline comes back as (11, 1) per observation and obs_special['v_baseline'] was initialised (num, 11), drtmd.py:287)
+    obs = [o for o in mixed_map_observations(3 * n_obs) if o[0] is None][:n_obs]
+    with _quiet():
+        dmd = DRTMD(tau_supergrid=sup, psi_dim_names=['T'], print_progress=False, warn=False, fit_type='pfrt')
+        for k, (chrono, eis) in enumerate(obs):
+            dmd.add_observation(np.array([float(k)]), chrono, eis, group_id='g')
+        dmd.fit_all()
+    assert dmd.obs_fit_status.all()
+    out = dict(n_obs=n_obs, tau_supergrid=sup, pfrt_factors=np.asarray(dmd.pfrt_factors), obs_x=dmd.obs_x, obs_llh=dmd.obs_llh,
+               obs_rss=dmd.obs_rss, obs_tau_indices=np.array(dmd.obs_tau_indices), obs_drt_var=dmd.obs_drt_var,
+               special_names=np.array(list(dmd.obs_special.keys())))
+    for key, val in dmd.obs_special.items():
+        out["special_" + key] = np.asarray(val)
+    np.savez_compressed(os.path.join(OUT, "refrun_drtmd_pfrt6.npz"), **out)
+    print(f"drtmd_pfrt6: obs_x {dmd.obs_x.shape}, specials { {k: np.shape(v) for k, v in dmd.obs_special.items()} }")
+
+
 DECIMATE_CASES = [     # (record, keywords of preprocessing.downsample_data)
     ("one_step", dict(method='decimate', prestep_samples=10)),
     ("one_step", dict(method='decimate', prestep_samples=7, decimation_interval=25, decimation_factor=1.5)),
@@ -617,6 +700,10 @@ def main():
         DRT, cvxopt = _boot_reference()
         run_resolve(DRT, cvxopt, "c2grid", False, basis_tau=synth.config_c2()["tau"], store_p=False)
         return
+    if "--only-drtmd-pfrt" in sys.argv:
+        _boot_reference()
+        run_drtmd_pfrt()
+        return
     if "--only-drtmd" in sys.argv:
         _boot_reference()
         run_drtmd_mixed()
@@ -634,6 +721,15 @@ def main():
                  save_qps=False)
         run_case(DRT, cvxopt, "golden71x91_iw", freq_g, z_g, default, dict(iw_alpha=1.5, iw_beta=0.5), save_mats=False,
                  save_qps=False)
+        return
+    if "--only-warm-prepared" in sys.argv:
+        from hipdrt import synth
+        DRT, cvxopt = _boot_reference()
+        base = dict(fit_inductance=True, fit_capacitance=False, fit_ohmic=True)
+        meas = synth.hybrid_measurement(seed=0)
+        run_warm_restarts_prepared(DRT, "hybrid_s0", meas, dict(base, fit_dop=False))
+        run_warm_restarts_prepared(DRT, "hybrid_s0_dop", meas, dict(base, fit_dop=True))
+        run_warm_restarts_prepared(DRT, "chrono_s1", meas[:3] + (None, None), dict(base, fit_dop=False))
         return
     if "--only-candidates" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()

@@ -81,6 +81,10 @@ def current_test_id():
 def parity(quantity, actual, desired, default=1e-7, rel=False, floor=1e-3, scale=None, bound=None, label=None):
     import numpy as np
     label = label or f"{current_test_id()}:{quantity}"
+    actual, desired = np.asarray(actual), np.asarray(desired)
+    if np.iscomplexobj(actual) or np.iscomplexobj(desired):     # sigma of an impedance: real and imaginary parts side by side
+        actual = np.stack([np.real(actual), np.imag(actual)], axis=-1)
+        desired = np.stack([np.real(desired), np.imag(desired)], axis=-1)
     actual, desired = np.asarray(actual, dtype=float), np.asarray(desired, dtype=float)
     assert actual.shape == desired.shape, (label, actual.shape, desired.shape)
     peak = float(np.abs(desired).max()) if scale is None else float(scale)

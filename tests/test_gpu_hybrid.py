@@ -814,3 +814,78 @@ def test_config5_bench_workload_first_outer_iterations():
     parity("dop_rho_vector", np.array([h["dop_rho_vector"] for h in drt.qphb_history]), g["hist_dop_rho"], default=1e-5, rel=True)
     parity_close("config5_2uV.x", fp["x"], g["x"], 1e-7)                    # measured 5.1e-9
     parity_close("config5_2uV.x_dop", fp["x_dop"], g["x_dop"], 5e-7)        # measured 5.0e-8 (this loop is not contractive)
+
+
+# ---- survey 8f rank 3 beyond EIS: warm restarts on prepared plans (drt1d.py:1270-1365), PFRT (2558-2715), candidates (1497-1632) --
+def _warm(name):
+    return np.load(os.path.join(GOLDEN, f"refrun_warm_{name}.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", ["hybrid_s0", "hybrid_s0_dop", "chrono_s1"])
+def test_pfrt_on_chrono_and_joint_fits_vs_reference_run(name):
+    """DRT.pfrt_fit_hybrid / pfrt_fit_chrono with DRTMD's eleven factors against the reference's own run: per-step iteration
+    counts, every iterate of every step (the device loop re-entered ten times on the prepared plan: weight factors on every
+    iteration's weights, the vz_offset column rewritten from the copy frozen at entry), the step log-likelihoods and the
+    matrix after the last rewrite."""
+    from hipdrt.models import DRT
+    g, special = load_case(name)
+    w = _warm(name)
+    drt = DRT(fit_dop="x_dop" in special, warn=False)
+    if name == "chrono_s1":
+        pr = drt.pfrt_fit_chrono(g["times"], g["i_signal"], g["v_signal"], factors=w["pfrt_factors"])
+    else:
+        pr = drt.pfrt_fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], factors=w["pfrt_factors"])
+    assert pr["step_iters"][:, 0].tolist() == w["pfrt_step_iters"].tolist()
+    peak = np.abs(w["pfrt_hist_x"]).max()
+    hx = np.array([h["x"] for h in drt.pfrt_history])
+    # several steps stop at max_iter_per_step = 10 without converging: rounding is amplified from step to step in both
+    parity("hist_x", hx, w["pfrt_hist_x"], default=1e-6, scale=peak)
+    parity("step_x", pr["step_x"][:, 0], w["pfrt_step_x"], default=1e-6, scale=peak)
+    parity("step_llh", pr["step_llh"][:, 0], w["pfrt_step_llh"], default=1e-7, rel=True)
+    parity("hist_weights", np.array([h["weights"] for h in drt.pfrt_history]), w["pfrt_hist_weights"], default=1e-5, rel=True)
+    rm = drt._plan.get("rzm")
+    parity("final_rm", rm[0] if rm.ndim == 3 else rm, w["pfrt_final_rm"], default=1e-6)
+    assert len(drt.qphb_history) == int(w["pfrt_init_len"])          # fit_parameters / qphb_history describe the first step
+
+
+@pytest.mark.parametrize("name", ["hybrid_s0", "hybrid_s0_dop", "chrono_s1"])
+def test_candidates_on_chrono_and_joint_fits_vs_reference_run(name):
+    """generate_candidates' two passes on one fitted object, weights first (drt1d.py:1660-1664): three weight steps x 0.5 from the
+    fit's x / rho / (scaled) weights, then two s_0 steps x 4 from the same baseline but with the s vectors and the rewritten
+    matrix the weight steps left behind -- the reference's shallow copies, reproduced."""
+    from hipdrt.models import DRT
+    g, special = load_case(name)
+    w = _warm(name)
+    drt = DRT(fit_dop="x_dop" in special, warn=False)
+    if name == "chrono_s1":
+        drt.fit_chrono(g["times"], g["i_signal"], g["v_signal"])
+    else:
+        drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"])
+    assert len(drt.qphb_history) == int(w["cand_base_len"])
+    steps_w = drt.generate_candidates_weights(0.5, 3, history_of=0)
+    steps_s = drt.generate_candidates_s0(4, 2, history_of=0)
+    assert [int(r["outer_iters"][0]) for r in steps_w + steps_s] == w["cand_call_iters"].tolist()
+    peak = np.abs(w["cand_w_x"]).max()
+    parity("w_x", np.concatenate([r["history"]["x"] for r in steps_w]), w["cand_w_x"], default=1e-6, scale=peak)
+    parity("w_weights", np.concatenate([r["history"]["weights"] for r in steps_w]), w["cand_w_weights"], default=1e-5, rel=True)
+    parity("s0_x", np.concatenate([r["history"]["x"] for r in steps_s]), w["cand_s0_x"], default=1e-6, scale=peak)
+    parity("s0_rho", np.concatenate([r["history"]["rho"] for r in steps_s]), w["cand_s0_rho"], default=1e-5, rel=True)
+    parity("s0_s", steps_s[-1]["s_vectors"][0], w["cand_s0_s"][-1], default=1e-4, rel=True)
+
+
+def test_pfrt_batch_of_joint_fits_matches_single_runs():
+    """pfrt_fit_hybrid_batch: three joint measurements of one protocol through the eleven steps at once; every member's steps
+    are those of its own single run (iteration counts equal, iterates to rounding: the batch and the single plan run the same
+    kernels per measurement), and the restart refuses what is not built (outlier_p)."""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    meas = [synth.hybrid_measurement(seed=s_, jitter=True) for s_ in (0, 1, 2)]
+    drt = DRT(warn=False)
+    pr = drt.pfrt_fit_hybrid_batch(meas[0][0], [m_[1] for m_ in meas], [m_[2] for m_ in meas], meas[0][3], [m_[4] for m_ in meas])
+    assert pr["step_x"].shape[:2] == (11, 3) and np.isfinite(pr["step_llh"]).all()
+    one = DRT(warn=False)
+    p1 = one.pfrt_fit_hybrid(*meas[1])
+    assert pr["step_iters"][:, 1].tolist() == p1["step_iters"][:, 0].tolist()
+    parity("step_x", pr["step_x"][:, 1], p1["step_x"][:, 0], default=1e-9)
+    with pytest.raises(Exception):
+        one.continue_from_init(outlier_p=0.05)

@@ -159,3 +159,31 @@ def test_world_one_nccl_group_runs_every_collective():
                HIPDRT_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
     pr = subprocess.run([sys.executable, "-c", _WORLD_ONE_NCCL], env=env, capture_output=True, text=True, timeout=600)
     assert pr.returncode == 0 and "WORLD1_NCCL_OK" in pr.stdout, (pr.returncode, pr.stdout[-2000:], pr.stderr[-4000:])
+
+
+def test_drtmd_fit_type_pfrt_matches_the_reference():
+    """mapping.fit_observations(fit_type='pfrt') against the reference's own DRTMD(fit_type='pfrt').fit_all (drtmd.py:98-100,
+    1136-1158, 1338-1342) on six impedance observations on two frequency grids (refrun_drtmd_pfrt6.npz): one solution per
+    factor and observation in the supergrid slots, specials per factor, obs_llh / obs_rss / obs_drt_var of the first step."""
+    from hipdrt.mapping import fit_observations
+    from hipdrt.models import DRT
+    g = np.load(os.path.join(GOLDEN, "refrun_drtmd_pfrt6.npz"), allow_pickle=False)
+    obs = [o for o in mixed_map_observations(18) if o[0] is None][:6]
+    sup = g["tau_supergrid"]
+    drt = DRT(tau_supergrid=sup, warn=False)
+    obs_x, obs_special, res = fit_observations(drt, observations=obs, tau_supergrid=sup, fit_type='pfrt', drt_var=True)
+    assert obs_x.shape == g["obs_x"].shape == (6, 11, len(sup)) and res["obs_fit_status"].all()
+    # (the reference's DRTMD fits with _pfrt_fit_core's default factors, not with its own pfrt_factors attribute: see the driver)
+    np.testing.assert_array_equal(res["pfrt_factors"], np.logspace(-1, 1, 11))
+    assert not np.array_equal(g["pfrt_factors"], res["pfrt_factors"])
+    assert [tuple(t) for t in res["obs_tau_indices"]] == [tuple(t) for t in g["obs_tau_indices"].tolist()]
+    peak = np.abs(g["obs_x"]).max(axis=(1, 2), keepdims=True)
+    parity_close("pfrt_map.obs_x", obs_x / peak, g["obs_x"] / peak, 5e-10, scale=1.0)            # measured 1.3e-11
+    for key in ("R_inf", "inductance"):
+        parity_close("pfrt_map.special_" + key, obs_special[key], g["special_" + key], 2e-10)             # 7.9e-12
+    parity_close("pfrt_map.obs_llh", res["obs_llh"] / g["obs_llh"], np.ones(6), 5e-11, scale=1.0)        # 1.9e-12
+    parity_close("pfrt_map.obs_rss", res["obs_rss"] / g["obs_rss"], np.ones(6), 2e-10, scale=1.0)        # 7.2e-12
+    vpeak = g["obs_drt_var"].max(axis=(1, 2), keepdims=True)
+    parity_close("pfrt_map.obs_drt_var", res["obs_drt_var"] / vpeak, g["obs_drt_var"] / vpeak, 5e-11, scale=1.0)   # 1.7e-12
+    with pytest.raises(ValueError):
+        fit_observations(drt, observations=obs, tau_supergrid=sup, fit_type='nope')

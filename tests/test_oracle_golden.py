@@ -362,3 +362,28 @@ def test_general_loop_dop_pass_without_eff_hp():
     assert [l["iterations"] for l in r["qp_log"]] == g["qp_iterations"].tolist()
     np.testing.assert_allclose(np.array([h["x"] for h in r["history"]]), g["hist_x"], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in r["history"]]), g["hist_dop_rho"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["hybrid_s0", "hybrid_s0_dop", "chrono_s1"])
+def test_warm_restarts_on_prepared_fits_reproduce_the_reference(name):
+    """survey 8f rank 3 beyond EIS: oracle.pfrt_fit_prepared / continue_prepared (drt1d.py:1270-1365, 2558-2715: the
+    vz_offset column rewritten from a copy frozen at entry, chrono / eis factors and weight_factor on every iteration's
+    weights, min_iter = 2) against the reference's own pfrt_fit_hybrid / pfrt_fit_chrono with DRTMD's factors
+    (refrun_warm_*.npz: every iterate of the eleven steps, per-step iteration counts, step log-likelihoods, the matrix after
+    the last rewrite)."""
+    from hybrid_util import load_case, initial_rzm_and_vz
+    g, special = load_case(name)
+    w = np.load(os.path.join(GOLDEN, f"refrun_warm_{name}.npz"), allow_pickle=False)
+    hyp = orc.get_default_hypers()
+    if "x_dop" in special:
+        hyp.update(orc.get_default_dop_hypers())
+    rzm0, vz = initial_rzm_and_vz(g, special)
+    r = orc.pfrt_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, w["pfrt_factors"], vz=vz)
+    assert r["step_iters"].tolist() == w["pfrt_step_iters"].tolist()
+    peak = np.abs(w["pfrt_hist_x"]).max()
+    hx = np.array([h["x"] for h in r["history"]])
+    np.testing.assert_allclose(hx, w["pfrt_hist_x"], rtol=0, atol=1e-8 * peak)
+    np.testing.assert_allclose(r["step_x"], w["pfrt_step_x"], rtol=0, atol=1e-8 * peak)
+    np.testing.assert_allclose(r["step_llh"], w["pfrt_step_llh"], rtol=1e-9)
+    np.testing.assert_allclose(np.array([h["weights"] for h in r["history"]]), w["pfrt_hist_weights"], rtol=1e-7)
+    np.testing.assert_allclose(r["rm"], w["pfrt_final_rm"], rtol=0, atol=1e-8 * np.abs(w["pfrt_final_rm"]).max())

@@ -41,10 +41,11 @@ def round_up_125(v):
     if v <= 0:
         return FLOOR
     k = math.floor(math.log10(v))
-    for m in (1.0, 2.0, 5.0, 10.0):
-        if m * 10.0 ** k >= v * (1 - 1e-12):
-            return m * 10.0 ** k
-    return 10.0 ** (k + 1)
+    for m in (1, 2, 5, 10):
+        cand = float(f"{m}e{k}")
+        if cand >= v * (1 - 1e-12):
+            return cand
+    return float(f"1e{k + 1}")
 
 
 def main():
@@ -64,14 +65,16 @@ def main():
             continue                                   # parity_close labels carry their bound at the call
         meas = float(meas)
         new = max(round_up_125(FACTOR * meas), FLOOR)
-        cap, why = 1e-7 if COEFF.search(label) else None, None
-        for pat, c, reason in EXCEPTIONS:
+        cap, reason, why = 1e-7 if COEFF.search(label) else None, None, None
+        for pat, c, r in EXCEPTIONS:
             if pat.search(label):
-                cap, why = c, reason
+                cap, reason = c, r
         if cap is not None and new > cap:
             if meas > cap:
                 print(f"!! {label}: measured {meas:.2e} exceeds the cap {cap:.0e}")
             new = cap
+        if reason is not None and new > 1e-7:
+            why = reason                               # the stated reason for a bound above the documented 1e-7
         old = table.get(label)
         if old is not None and keep_larger and old[1] > new:
             new = old[1]

@@ -120,6 +120,8 @@ SIGNATURES = {
     "hipdrt_plan_continue": [_vp, C.POINTER(FitOpts), C.c_double, C.c_int],
     "hipdrt_plan_iterate": [_vp, C.POINTER(IterateState), _ip, _ip, _ip, _dp],
     "hipdrt_plan_param_var": [_vp, _dp, _ip],
+    "hipdrt_plan_param_cov": [_vp, C.c_int, _dp, _ip],
+    "hipdrt_plan_distribution_cov": [_vp, C.c_int, _dp, C.c_int, _dp, _ip],
     "hipdrt_plan_record_history": [_vp, C.c_int],
     "hipdrt_plan_get_history": [_vp, _dp, _dp, _dp, _ip, C.c_int, _ip],
     "hipdrt_plan_timings": [_vp, C.POINTER(C.c_float), _ip],
@@ -553,6 +555,22 @@ class Plan:
         status = np.empty(int(batch), dtype=np.int32)
         _check(self._lib.hipdrt_plan_distribution_var(self._h, _p(basis_eval), basis_eval.shape[0], _p(out), _pi(status)))
         return out, status
+
+    def param_cov(self, b=0):
+        """inv(P_b) cs_b^2 (n, n) of fitted spectrum b, and whether P_b was positive definite"""
+        out = np.empty((self.n, self.n))
+        status = C.c_int()
+        _check(self._lib.hipdrt_plan_param_cov(self._h, int(b), _p(out), C.byref(status)))
+        return out, status.value == 0
+
+    def distribution_cov(self, basis_eval, b=0):
+        """basis_eval inv(P_b)[DRT block] basis_eval' cs_b^2 (neval, neval) of fitted spectrum b"""
+        basis_eval = _f64(basis_eval)
+        out = np.empty((basis_eval.shape[0], basis_eval.shape[0]))
+        status = C.c_int()
+        _check(self._lib.hipdrt_plan_distribution_cov(self._h, int(b), _p(basis_eval), basis_eval.shape[0], _p(out),
+                                                      C.byref(status)))
+        return out, status.value == 0
 
     def param_var(self, batch):
         out = np.empty((int(batch), self.n))

@@ -1526,6 +1526,67 @@ static int plan_quadratic_forms(hipdrt_plan* p, const double* basis_eval, int ne
     return HIPDRT_OK;
 }
 
+// out[neval][neval] = rows P_b^-1 rows' * cs_b^2 for ONE fitted spectrum: the variance kernel leaves Y = rows L^-T behind the
+// factor (one more panel of the same factorisation), rows_outer_kernel forms Y Y'
+static int plan_full_cov(hipdrt_plan* p, int b, const double* rows, int neval, int ncol, int col_offset, double* out, int* status) {
+    HIPDRT_REQUIRE(p->B > 0, "no fitted batch in the plan");
+    HIPDRT_REQUIRE(b >= 0 && b < p->B, "spectrum index out of range");
+    HIPDRT_REQUIRE(neval >= 1, "neval >= 1");
+    HIPDRT_REQUIRE(p->n <= 4096, "posterior covariance: n <= 4096");
+    HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
+    hipStream_t st = p->ctx->stream;
+    const int n = p->n, m = p->m;
+    const int nex = (neval + 15) / 16, nchp = qp_nchp(n), nch = round_up(n, 32) / 16;
+    // final P of this spectrum (calculate_pq with the final weights / s / rho), packed tiles, into its own slot of Ppk
+    GramL2 g = plan_l2(p, p->opts.l2_lambda_0, p->opts.derivative_weights, p->prepared ? p->desc.dop_l2_lambda_0 : 0.0);
+    g.s = p->s.d() + (size_t)b * 3 * n; g.rho = p->rho.d() + (size_t)b * 3;
+    if (g.dop_size > 0) g.dop_rho = p->dop_rho.d() + (size_t)b * 3;
+    const double* wfin = p->has_weight_factors() ? p->w_eff.d() : p->w.d();
+    double* ppk = p->Ppk.d() + (size_t)b * qp_ppk_doubles(n);
+    launch_gram_l2(st, 1, m, n, p->rm.d() + (size_t)b * p->rm_stride, p->ldrm, wfin + (size_t)b * m, g, nullptr, p->ldp, 0,
+                   nullptr, ppk, 0, nchp, 0);
+    LAUNCH_OK();
+    DevBuf dbe, bex, scratch, dvar, dstat, dcov;
+    TRY(upload(dbe, rows, (size_t)neval * ncol * sizeof(double), st));
+    HIPDRT_CHECK(bex.alloc((size_t)nex * nchp * 256 * sizeof(double)));
+    launch_pack_rows(st, neval, ncol, col_offset, dbe.d(), ncol, nex, bex.d(), nchp);
+    LAUNCH_OK();
+    HIPDRT_CHECK(scratch.alloc(dist_var_scratch_doubles(n, nex) * sizeof(double)));
+    HIPDRT_CHECK(dvar.alloc((size_t)nex * 16 * sizeof(double)));
+    HIPDRT_CHECK(dstat.alloc(sizeof(int)));
+    HIPDRT_CHECK(dcov.alloc((size_t)neval * neval * sizeof(double)));
+    TRY(launch_dist_var(st, 1, n, ppk, 0, bex.d(), nex, scratch.d(), 0, dvar.d(), 0, dstat.i()));
+    double cs = 1.0;
+    int hs = 0;
+    HIPDRT_CHECK(hipMemcpyAsync(&cs, p->coef_scale.d() + b, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipMemcpyAsync(&hs, dstat.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    if (status) *status = hs;
+    if (hs != 0) {                               // P not positive definite (np.linalg.inv would still return something; the
+        for (size_t i = 0; i < (size_t)neval * neval; ++i) out[i] = __builtin_nan("");      // reference warns and returns None)
+        return HIPDRT_OK;
+    }
+    // Y = rows L^-T sits in tile rows nch .. nch + nex - 1 of the scratch; only the first ceil(n / 16) tile columns are non-zero
+    launch_rows_outer(st, scratch.d() + (size_t)nch * nch * 256, nch, nch, nex, neval, cs * cs, dcov.d(), neval);
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(out, dcov.p, (size_t)neval * neval * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+}
+
+int hipdrt_plan_distribution_cov(hipdrt_plan* p, int b, const double* basis_eval, int neval, double* out, int* status) {
+    HIPDRT_REQUIRE(p && basis_eval && out, "NULL pointer");
+    return plan_full_cov(p, b, basis_eval, neval, p->ntau, p->ns, out, status);
+}
+
+int hipdrt_plan_param_cov(hipdrt_plan* p, int b, double* out, int* status) {
+    HIPDRT_REQUIRE(p && out, "NULL pointer");
+    const int n = p->n;
+    std::vector<double> eye((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) eye[(size_t)i * n + i] = 1.0;
+    return plan_full_cov(p, b, eye.data(), n, n, 0, out, status);
+}
+
 int hipdrt_plan_distribution_var(hipdrt_plan* p, const double* basis_eval, int neval, double* out, int* status) {
     HIPDRT_REQUIRE(p && basis_eval && out, "NULL pointer");
     return plan_quadratic_forms(p, basis_eval, neval, p->ntau, p->ns, out, status);

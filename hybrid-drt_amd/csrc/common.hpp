@@ -258,6 +258,7 @@ size_t qp_gsync_ints();
 int launch_dist_var(hipStream_t st, int B, int n, const double* Ppk, long long ppk_stride, const double* Bex, int nex,
                     double* L, long long l_stride, double* out, long long out_stride, int* status);
 size_t dist_var_scratch_doubles(int n, int nex);
+void launch_rows_outer(hipStream_t st, const double* Y, int nch, int ncol, int nex, int nrow, double scale, double* out, int ld);
 void launch_pack_rows(hipStream_t st, int nrow, int ncol, int col_offset, const double* M, int ldm, int ntile_rows,
                       double* tiles, int nchp);
 // order[] = problem indices sorted by descending iteration count of the previous solve (inactive ones last)

@@ -283,6 +283,36 @@ void launch_pack_rows(hipStream_t st, int nrow, int ncol, int col_offset, const 
                        nchp);
 }
 
+// out = scale * Y Y' for the rows Y of `nex` tile rows (tile-packed, `nch` tiles per tile row, the first `ncol` tile columns
+// count): the full posterior covariance from the rows B L^-T that the variance kernel leaves behind the factor.  One 16 x 16
+// tile of the (symmetric) result per workgroup, lower tiles computed and mirrored; chunks in ascending order (fixed sums).
+__global__ __launch_bounds__(256) void rows_outer_kernel(const double* __restrict__ Y, int nch, int ncol, int nrow, double scale,
+                                                         double* __restrict__ out, int ld) {
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    __shared__ double A[256], Bt[256];
+    const int t = threadIdx.x, i = t >> 4, j = t & 15;
+    auto at = [](int r, int k) { return 2 * ((k >> 3) * 64 + r * 4 + (k & 3)) + ((k >> 2) & 1); };   // (row, column) inside a tile
+    double acc = 0.0;
+    for (int c = 0; c < ncol; ++c) {
+        A[t] = Y[((size_t)ti * nch + c) * 256 + t];
+        Bt[t] = Y[((size_t)tj * nch + c) * 256 + t];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += A[at(i, k)] * Bt[at(j, k)];
+        __syncthreads();
+    }
+    const int r = ti * 16 + i, cc = tj * 16 + j;
+    if (r < nrow && cc < nrow) {
+        out[(size_t)r * ld + cc] = acc * scale;
+        out[(size_t)cc * ld + r] = acc * scale;
+    }
+}
+
+void launch_rows_outer(hipStream_t st, const double* Y, int nch, int ncol, int nex, int nrow, double scale, double* out, int ld) {
+    hipLaunchKernelGGL(rows_outer_kernel, dim3(nex, nex), dim3(256), 0, st, Y, nch, ncol, nrow, scale, out, ld);
+}
+
 void launch_pack_p(hipStream_t st, int B, int n, const double* P, int ldp, long long p_stride, double* Ppk,
                    long long ppk_stride, int nchp) {
     const int nt = (n + 15) / 16;

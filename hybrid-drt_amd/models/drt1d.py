@@ -493,6 +493,69 @@ class DRT(PreparedFitMixin):
         var, status = self._plan.param_var(self._last_batch)
         return var, status == 0
 
+    def _cov_scale(self, b):
+        """(coefficient_scale of fitted measurement b where the device loop ran at unit scale, else 1; its prep or None)"""
+        if isinstance(self._plan, _ffi.PreparedPlan):
+            preps = self._last_prepared[0] if getattr(self, '_last_prepared', None) and \
+                len(self._last_prepared[0]) == self._plan.batch else [self._prep]
+            return preps[b]['coefficient_scale'], preps[b]
+        return 1.0, None
+
+    def estimate_param_cov(self, b=0):
+        """DRT.estimate_param_cov (drt1d.py:4116-4138): inv(P) * coefficient_scale^2 with the DOP block rescaled by
+        dop_scale_vector, from the Cholesky factor of the final P on the device (hipdrt_plan_param_cov); ``b`` picks a
+        member of the last batch.  None (with upstream's warning) when P is not positive definite."""
+        if self._plan is None or (self._last_batch is None and not isinstance(self._plan, _ffi.PreparedPlan)):
+            raise Exception('Parameter covariance estimation is only available for qphb fits')
+        cov, ok = self._plan.param_cov(b)
+        if not ok:
+            warnings.warn('Singular P matrix - could not obtain covariance estimate')
+            return None
+        cs, prep = self._cov_scale(b)
+        cov = cov * cs ** 2
+        if prep is not None and prep['dop']:
+            a, e = prep['dop']
+            cov[:, a:e] *= prep['dop_scale_vector'][None, :]
+            cov[a:e, :] *= prep['dop_scale_vector'][:, None]
+        return cov
+
+    def estimate_distribution_cov(self, tau=None, ppd=20, extend_var=False, var_floor=0.0, b=0):
+        """DRT.estimate_distribution_cov (drt1d.py:3063-3151; order 0, sign 1, no normalisation): basis_matrix @ x_cov @
+        basis_matrix.T of the DRT block, formed on the device (hipdrt_plan_distribution_cov), then upstream's ``extend_var``
+        clamp of the diagonal outside the measured tau range (3126-3143) and ``var_floor``."""
+        from ..matrices import basis
+        if self._plan is None or (self._last_batch is None and not isinstance(self._plan, _ffi.PreparedPlan)):
+            raise Exception('Parameter covariance estimation is only available for qphb fits')
+        if self.series_neg:
+            raise NotImplementedError("distribution covariance of series_neg fits is not built")
+        if tau is None:
+            tau = self.get_tau_eval(ppd)
+        tau = np.asarray(tau, dtype=float)
+        bm = basis.construct_func_eval_matrix(np.log(self.basis_tau), np.log(tau), self.tau_basis_type,
+                                              epsilon=self.tau_epsilon, order=0)
+        cov, ok = self._plan.distribution_cov(bm, b)
+        if not ok:
+            warnings.warn('Singular P matrix - could not obtain covariance estimate')
+            return None
+        cs, prep = self._cov_scale(b)
+        cov = cov * cs ** 2
+        if extend_var:
+            if prep is not None:
+                t_left, t_right = pp.get_tau_lim(prep['frequencies'], prep.get('sample_times'), prep.get('nonconsec_step_times'))
+            else:
+                t_left, t_right = 1 / (2 * np.pi * np.max(self.f_fit)), 1 / (2 * np.pi * np.min(self.f_fit))
+            left_index = int(np.argmin(np.abs(tau - t_left))) + 1
+            right_index = int(np.argmin(np.abs(tau - t_right)))
+            var = np.diag(cov).copy()
+            var[:left_index] = np.maximum(var[:left_index], var[left_index])
+            var[right_index:] = np.maximum(var[right_index:], var[right_index])
+            cov[np.diag_indices(cov.shape[0])] = var
+        if var_floor > 0:
+            var = np.diag(cov).copy()
+            var[var < var_floor] = var_floor
+            np.fill_diagonal(cov, var)
+        return cov
+
     def get_tau_eval(self, ppd):
         """drtbase.get_tau_eval (drtbase.py:263-285): one decade beyond the basis grid on each side."""
         basis_tau = self.basis_tau

@@ -252,6 +252,14 @@ int hipdrt_plan_distribution_var(hipdrt_plan* plan, const double* basis_eval, in
 /* same machinery with the identity as evaluation rows: out[b][i] = diag(inv(P_b))_i * cs_b^2, the parameter variances
  * np.diag(DRT.estimate_param_cov()) (hybdrt/models/drt1d.py:4116-4138) of every fitted spectrum.  n <= 4096.          */
 int hipdrt_plan_param_var(hipdrt_plan* plan, double* out, int* status);
+/* The FULL matrices, for one fitted spectrum b: out[n][n] = inv(P_b) * cs_b^2 = DRT.estimate_param_cov() (drt1d.py:4116-4138;
+ * the DOP rescaling of 4126-4130 is the caller's: it needs dop_scale_vector) -- what DRTMD's PFRT post-processing takes per
+ * step (hybdrt/mapping/drtmd.py:934-941) -- and out[neval][neval] = basis_eval inv(P_b)[DRT block] basis_eval' * cs_b^2 =
+ * DRT.estimate_distribution_cov (drt1d.py:3063-3151; order 0, no normalisation, before extend_var).  Same factorisation as
+ * the variances: the evaluation rows ride along as extra panel rows and come out as rows L^-T, one more product gives
+ * rows L^-T L^-1 rows'.  *status (may be NULL): 0 ok, -1 P not positive definite (out is then NaN).  n <= 4096.            */
+int hipdrt_plan_param_cov(hipdrt_plan* plan, int b, double* out, int* status);
+int hipdrt_plan_distribution_cov(hipdrt_plan* plan, int b, const double* basis_eval, int neval, double* out, int* status);
 
 /* per-outer-iteration history of spectrum b recorded when record_history was enabled before the fit:
  * hist_x[iters][n], hist_rho[iters][3], hist_w[iters][m], qp_iters[iters+1]                            */

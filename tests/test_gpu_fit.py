@@ -638,3 +638,46 @@ def test_kernel_choice_follows_the_staged_batch_not_the_plan_capacity():
     assert res1["outer_iters"][0] == fresh["outer_iters"][0] == res40["outer_iters"][7]
     assert res1["qp_iters_total"][0] == res40["qp_iters_total"][7]
     parity("x", res1["x"][0], res40["x"][7], default=1e-10)
+
+
+def test_full_posterior_covariance_matrices():
+    """survey 8f rank 1, full matrices (hipdrt_plan_param_cov / hipdrt_plan_distribution_cov): DRT.estimate_param_cov =
+    inv(P) cs^2 and DRT.estimate_distribution_cov = B x_cov[DRT block] B' (drt1d.py:3063-3151, 4116-4138) (i) against what the
+    reference's formulas give on the reference run's own P (refrun_posterior_golden71x91), (ii) against numpy's inverse of the
+    device's own P at the C2 size (n = 514) for a member of a batch, (iii) symmetric, consistent with the variance entry points."""
+    from hipdrt import synth
+    from hipdrt.matrices import basis
+    from hipdrt.models import DRT
+    g = load("refrun_posterior_golden71x91.npz")
+    drt = DRT()
+    drt.fit_eis(g["freq"], g["z"])
+    ns = int(g["num_special"])
+    ref_cov = np.linalg.inv(g["p_matrix"]) * float(g["coefficient_scale"]) ** 2
+    cov = drt.estimate_param_cov()
+    parity("param_cov_vs_reference_P", cov, ref_cov, default=1e-6)          # the two fits differ by ~1e-9, cond(P) ~ 5e4
+    own = np.linalg.inv(drt.fit_parameters["p_matrix"]) * drt.coefficient_scale ** 2
+    parity("param_cov_vs_own_P", cov, own, default=1e-9)
+    np.testing.assert_array_equal(cov, cov.T)
+    bm = basis.construct_func_eval_matrix(np.log(drt.basis_tau), np.log(g["tau_eval"]), 'gaussian', epsilon=drt.tau_epsilon, order=0)
+    dcov = drt.estimate_distribution_cov(tau=g["tau_eval"])
+    parity("dist_cov_vs_reference_P", dcov, bm @ ref_cov[ns:, ns:] @ bm.T, default=1e-6)
+    parity("dist_cov_vs_own_P", dcov, bm @ own[ns:, ns:] @ bm.T, default=1e-9)
+    parity("dist_cov_diag_vs_fixture", np.diag(dcov), g["dist_var"], default=1e-6, rel=True, floor=1e-6)
+    var, _ = drt.estimate_distribution_var_batch(tau=g["tau_eval"])
+    parity("dist_cov_diag_vs_var_entry_point", np.diag(dcov), var[0], default=1e-10, rel=True, floor=1e-9)
+    dext = drt.estimate_distribution_cov(tau=g["tau_eval"], extend_var=True)
+    parity("dist_cov_ext_diag", np.diag(dext), g["dist_var_ext"], default=1e-6, rel=True, floor=1e-6)
+    off = ~np.eye(len(dext), dtype=bool)
+    np.testing.assert_array_equal(dext[off], dcov[off])                      # extend_var touches the diagonal only
+    # C2 size, member 2 of a batch of 3
+    c2 = synth.config_c2()
+    z = synth.zarc2_batch(c2["freq"], 3, first_seed=20)
+    big = DRT(fixed_basis_tau=c2["tau"])
+    res = big.fit_eis_batch(c2["freq"], z)
+    P = big._plan.p_matrix(2)
+    cov2 = big.estimate_param_cov(b=2)
+    parity("param_cov_n514", cov2, np.linalg.inv(P) * res["coefficient_scale"][2] ** 2, default=1e-8)
+    sup = np.logspace(-9, 3, 241)
+    bm2 = basis.construct_func_eval_matrix(np.log(c2["tau"]), np.log(sup), 'gaussian', epsilon=big.tau_epsilon, order=0)
+    parity("dist_cov_n514", big.estimate_distribution_cov(tau=sup, b=2),
+           bm2 @ (np.linalg.inv(P)[2:, 2:] * res["coefficient_scale"][2] ** 2) @ bm2.T, default=1e-8)

@@ -889,3 +889,28 @@ def test_pfrt_batch_of_joint_fits_matches_single_runs():
     parity("step_x", pr["step_x"][:, 1], p1["step_x"][:, 0], default=1e-9)
     with pytest.raises(Exception):
         one.continue_from_init(outlier_p=0.05)
+
+
+def test_full_covariance_of_a_joint_fit_with_dop():
+    """estimate_param_cov on a joint chrono + EIS fit with a distribution of phasances: the device loop of a prepared plan runs
+    at unit scale, so coefficient_scale^2 and the DOP rescaling (drt1d.py:4126-4131) are applied by the host layer -- against
+    the reference's formula on the reference run's own P (refrun_hybrid_s0_dop) and on the device's P."""
+    from hipdrt.models import DRT
+    g, special = load_case("hybrid_s0_dop")
+    drt = DRT(fit_dop=True)
+    drt.fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"])
+    a = special["x_dop"]["index"]
+    e = a + special["x_dop"]["size"]
+
+    def reference_formula(P):
+        inv = np.linalg.inv(P)
+        inv[:, a:e] *= g["dop_scale_vector"][None, :]
+        inv[a:e, :] *= g["dop_scale_vector"][:, None]
+        return inv * float(g["coefficient_scale"]) ** 2
+
+    cov = drt.estimate_param_cov()
+    parity("param_cov_vs_own_P", cov, reference_formula(drt.fit_parameters["p_matrix"]), default=1e-8)
+    parity("param_cov_vs_reference_P", cov, reference_formula(g["p_matrix"]), default=1e-5)
+    dcov = drt.estimate_distribution_cov(ppd=10)
+    var, _ = drt.estimate_distribution_var_batch(ppd=10)
+    parity("dist_cov_diag", np.diag(dcov), var[0], default=1e-9, rel=True, floor=1e-9)

@@ -46,6 +46,8 @@ struct hipdrt_plan {
     DevBuf active, outer_iters, fit_status, qp_iters_total, qp_status, qp_iters, n_active, pcost;
     DevBuf premv;          // [3][capacity][m]: hyper-parameter step of few, large fits (hyper.hip, premv_kernel)
     DevBuf L, Ptmp, qpstate, Ppk, order, vmm_base, gsync;
+    int toep_maxd = -1;     // reach of the Toeplitz penalty blocks in grid points (plan_toep_reach), -1 = not determined
+    int spec_zero = 0;      // the special-parameter rows / columns of the penalty matrices are zero outside the special block
     int qp_G = 0;           // workgroups per QP when the plan is full (qp_group_size at its capacity): 0 = the batch kernel
     // The kernel is chosen per fit from the number of spectra actually staged: a plan sized for a thousand spectra that is
     // handed one or a handful runs them on several workgroups each, inside the scratch it already has.
@@ -121,6 +123,7 @@ static int upload(DevBuf& buf, const void* src, size_t bytes, hipStream_t st) {
 extern "C" {
 
 static int plan_hist_reserve(hipdrt_plan* p, int rows);
+static int plan_toep_reach(hipdrt_plan* p);
 
 const char* hipdrt_last_error(void) { return g_err.c_str(); }
 
@@ -703,6 +706,7 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     launch_make_h(st, p->h.d(), n, ns, p->opts.nonneg);
     LAUNCH_OK();
     HIPDRT_CHECK(hipStreamSynchronize(st));
+    TRY(plan_toep_reach(p.get()));
     { std::lock_guard<std::mutex> lk(g_life); ++ctx->plans; }
     *out = p.release();
     return HIPDRT_OK;
@@ -747,6 +751,7 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, 
     HIPDRT_CHECK(p->dop_rho.alloc((size_t)capacity * 3 * sizeof(double)));
     HIPDRT_CHECK(p->dop_xmx.alloc((size_t)capacity * 3 * sizeof(double)));
     HIPDRT_CHECK(hipStreamSynchronize(st));
+    TRY(plan_toep_reach(p.get()));
     { std::lock_guard<std::mutex> lk(g_life); ++ctx->plans; }
     *out = p.release();
     return HIPDRT_OK;
@@ -889,6 +894,8 @@ static GramL2 plan_l2(const hipdrt_plan* p, double l2_lambda_0, const double* de
     g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1;
     g.sym = p->prepared ? 0 : p->toeplitz_m;      // caller-supplied matrices are not assumed bitwise symmetric
     g.toep = p->toeplitz_m;                       // log-uniform tau grid (the hyper kernel relies on the same structure)
+    g.toep_maxd = p->toeplitz_m ? p->toep_maxd : -1;
+    g.spec_zero = p->spec_zero;
     for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = l2_lambda_0 * derivative_weights[k]; }
     g.s = p->s.d(); g.rho = p->rho.d();
     if (p->prepared && p->desc.dop_size > 0) {
@@ -896,6 +903,37 @@ static GramL2 plan_l2(const hipdrt_plan* p, double l2_lambda_0, const double* de
         for (int k = 0; k < 3; ++k) g.dop_dfac[k] = dop_l2_lambda_0 * p->desc.dop_derivative_weights[k];
     }
     return g;
+}
+
+// Reach of the penalty matrices on a log-uniform grid: the largest distance from the diagonal at which the first row of the DRT
+// block of any order is not exactly zero (Gaussian basis: e^(-a^2 / 2) underflows ~39 grid points out at 10 points per decade,
+// whatever the matrix size).  The Gram kernel's L2 epilogue skips tiles that lie wholly beyond it.  Once per plan.
+static int plan_toep_reach(hipdrt_plan* p) {
+    p->toep_maxd = -1;
+    if (!p->toeplitz_m) return HIPDRT_OK;
+    const int nd = p->n - p->ns;
+    std::vector<double> row(nd);
+    int reach = 0;
+    for (int k = 0; k < 3; ++k) {
+        HIPDRT_CHECK(hipMemcpy(row.data(), p->mk[k].d() + (size_t)p->ns * p->ldm + p->ns, (size_t)nd * sizeof(double), hipMemcpyDeviceToHost));
+        for (int d = nd - 1; d > reach; --d)
+            if (row[d] != 0.0) { reach = d; break; }
+    }
+    p->toep_maxd = reach;
+    // the columns of the special parameters below the special block, and their rows to the right of it
+    p->spec_zero = 1;
+    if (p->ns > 0) {
+        std::vector<double> cols((size_t)nd * p->ns), rows((size_t)p->ns * nd);
+        for (int k = 0; k < 3 && p->spec_zero; ++k) {
+            HIPDRT_CHECK(hipMemcpy2D(cols.data(), (size_t)p->ns * sizeof(double), p->mk[k].d() + (size_t)p->ns * p->ldm,
+                                     (size_t)p->ldm * sizeof(double), (size_t)p->ns * sizeof(double), nd, hipMemcpyDeviceToHost));
+            HIPDRT_CHECK(hipMemcpy2D(rows.data(), (size_t)nd * sizeof(double), p->mk[k].d() + p->ns, (size_t)p->ldm * sizeof(double),
+                                     (size_t)nd * sizeof(double), p->ns, hipMemcpyDeviceToHost));
+            for (double v : cols) if (v != 0.0) { p->spec_zero = 0; break; }
+            for (double v : rows) if (v != 0.0) { p->spec_zero = 0; break; }
+        }
+    }
+    return HIPDRT_OK;
 }
 
 // hyper-parameter step of one outer iteration.  Few fits with large matrices: their matrix-vector products are spread over
@@ -1126,7 +1164,7 @@ static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb)
     sf.ctx.qp_force_group = p->ctx->qp_force_group;
     v.ctx = &sf.ctx;
     v.nf = p->nf; v.ntau = p->ntau; v.n = p->n; v.m = p->m; v.ns = p->ns; v.ngrid = p->ngrid; v.ny = p->ny; v.mode = p->mode;
-    v.toeplitz_a = p->toeplitz_a; v.toeplitz_m = p->toeplitz_m; v.idx_rinf = p->idx_rinf; v.idx_induc = p->idx_induc;
+    v.toeplitz_a = p->toeplitz_a; v.toeplitz_m = p->toeplitz_m; v.toep_maxd = p->toep_maxd; v.spec_zero = p->spec_zero; v.idx_rinf = p->idx_rinf; v.idx_induc = p->idx_induc;
     v.ldrm = p->ldrm; v.ldm = p->ldm; v.ldp = p->ldp; v.ldl = p->ldl; v.eps = p->eps; v.opts = p->opts;
     v.capacity = nb; v.B = nb; v.qp_G = p->qp_G; v.subbatches = 1;
     // shared, read-only in the loop

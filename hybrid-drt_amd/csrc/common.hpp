@@ -131,6 +131,9 @@ struct GramL2 {
     int use_rho;
     int sym;               // penalty matrices are bitwise symmetric (Toeplitz build): read them along rows
     int toep;              // the DRT block (indices >= ns) of every mk is symmetric Toeplitz: mk[i][j] = mk[ns][ns + |i - j|]
+    int toep_maxd;         // largest |i - j| at which any order's first row is non-zero (-1: not known): the Gaussian penalties
+                           // underflow to exactly 0 a few dozen grid points off the diagonal, so a tile further out adds exact zeros
+    int spec_zero;         // every penalty entry that couples a special parameter with a DRT coefficient is exactly zero
     // x_dop block (qphb.py:92-100): entries with both indices in [dop_start, dop_start + dop_size) are scaled by
     // dop_dfac[k] * dop_rho[b][k] instead
     int dop_start, dop_size;

@@ -19,7 +19,8 @@ static constexpr int GK = 16;        // K slab
 static constexpr int GLD = 80;       // LDS row stride in doubles (k-rows land 32 banks apart: conflict-free b64 reads)
 
 
-template <bool DOP>
+// ROWP: also write the row-major copy P (stand-alone entry points); the fit loop reads the packed tiles only
+template <bool DOP, bool ROWP>
 __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double* __restrict__ A, int lda,
                                                    const double* __restrict__ w, GramL2 g, double* __restrict__ P,
                                                    int ldp, long long p_stride, const int* __restrict__ active,
@@ -124,7 +125,16 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
     constexpr int TW = 2 * GT;                                      // window slots per order (127 used)
     double (*tw)[TW] = reinterpret_cast<double (*)[TW]>(sI + 3 * GT);
     const int dbase = i0 - j0 - (GT - 1);                           // difference of window slot 0
-    if (g.s) {
+    double fac[3] = {0, 0, 0};
+    // Tiles of the DRT block that lie wholly beyond the reach of the penalty matrices -- every |i - j| of the tile larger than the
+    // last non-zero entry of the Toeplitz first rows -- would add (sqrt(s_i) * 0) * sqrt(s_j) = 0 to every element: no tables,
+    // no epilogue arithmetic, the same bits (28 of the 45 tiles of a 514 x 514 matrix lie two or more tile diagonals out; the 7
+    // of them that touch the special-parameter columns qualify when those columns of the penalty matrices are zero outside the
+    // special block, which the plan checks once)
+    const bool l2on = g.s && !(!DOP && g.toep && g.toep_maxd >= 0 && (j0 >= g.ns || g.spec_zero) && i0 >= g.ns && dbase > g.toep_maxd);
+    if (l2on) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fac[k] = g.dfac[k] * (g.use_rho ? g.rho[(size_t)b * 3 + k] : 1.0);
         __syncthreads();   // last slab consumed
         const double* sb_ = g.s + (size_t)b * 3 * n;
         for (int e = tid; e < 3 * GT; e += 256) {
@@ -133,23 +143,22 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
             sqJ[k][c] = (j0 + c < n) ? sqrt(sb_[k * n + j0 + c]) : 0.0;
         }
         if (g.toep) {
+            // (the window holds M_k[|i - j|] * fac[k]: the product the epilogue used to form per element)
             const int nd = n - g.ns;                                // size of the DRT block
             for (int e = tid; e < 3 * TW; e += 256) {
                 const int k = e / TW, sl = e % TW;
                 int dd = dbase + sl;
                 dd = dd < 0 ? -dd : dd;
-                tw[k][sl] = (g.dfac[k] > 0.0 && dd < nd) ? g.mk[k][(size_t)g.ns * g.ldm + g.ns + dd] : 0.0;
+                tw[k][sl] = (g.dfac[k] > 0.0 && dd < nd) ? g.mk[k][(size_t)g.ns * g.ldm + g.ns + dd] * fac[k] : 0.0;
             }
         }
         __syncthreads();
     }
     // epilogue: + L2, store lower tile and its mirror.  With the swapped operands the accumulator of lane l, register
     // r is element (row = l&15, column = (l>>4) + 4r) of the sub-tile.
-    double* Pb = P ? P + (size_t)b * p_stride : nullptr;   // row-major copy is optional (the resident QP kernel reads Ppk)
-    double fac[3] = {0, 0, 0}, dfac2[3] = {0, 0, 0};
-    if (g.s) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) fac[k] = g.dfac[k] * (g.use_rho ? g.rho[(size_t)b * 3 + k] : 1.0);
+    double* Pb = (ROWP && P) ? P + (size_t)b * p_stride : nullptr;   // row-major copy is optional (the resident QP kernel reads Ppk)
+    double dfac2[3] = {0, 0, 0};
+    if (l2on) {
         if (DOP) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) dfac2[k] = g.dop_dfac[k] * (g.use_rho ? g.dop_rho[(size_t)b * 3 + k] : 1.0);
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
                 double v = 0.0;
                 if (i < n && j < n) {
                     v = acc[a][c][r];
-                    if (g.s) {
+                    if (l2on) {
                         double l2 = 0.0;
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
                                 // addresses contiguous when the matrices are bitwise symmetric
                                 double mv;
                                 if (g.toep && i >= g.ns && j >= g.ns) {
-                                    mv = tw[k][(i - j) - dbase] * fac[k];
+                                    mv = tw[k][(i - j) - dbase];
                                 } else {
                                     mv = g.sym ? g.mk[k][(size_t)j * g.ldm + i] : g.mk[k][(size_t)i * g.ldm + j];
                                     if (i >= g.ns && j >= g.ns) mv *= fac[k];
@@ -188,10 +197,10 @@ __global__ __launch_bounds__(256, 5) void gram_kernel(int m, int n, const double
                             }
                         }
                         v += l2;
-                    } else if (g.l2) {
+                    } else if (!g.s && g.l2) {
                         v += g.l2[(size_t)b * g.l2_stride + (size_t)i * g.ldl2 + j];
                     }
-                    if (Pb && !(diag && j > i)) {      // upper part of a diagonal tile comes from the mirror
+                    if (ROWP && Pb && !(diag && j > i)) {      // upper part of a diagonal tile comes from the mirror
                         Pb[(size_t)i * ldp + j] = v;
                         if (i != j) Pb[(size_t)j * ldp + i] = v;
                     }
@@ -325,12 +334,12 @@ void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int ld
                     int nchp, long long a_stride) {
     const int nt = (n + GT - 1) / GT;
     const int ntile = nt * (nt + 1) / 2;
-    if (g.s && g.dop_size > 0)
-        hipLaunchKernelGGL(gram_kernel<true>, dim3(ntile, B), dim3(256), 0, st, m, n, A, lda, w, g, P, ldp, p_stride,
-                           active, ntile, Ppk, ppk_stride, nchp, a_stride);
-    else
-        hipLaunchKernelGGL(gram_kernel<false>, dim3(ntile, B), dim3(256), 0, st, m, n, A, lda, w, g, P, ldp, p_stride,
-                           active, ntile, Ppk, ppk_stride, nchp, a_stride);
+    const bool dop = g.s && g.dop_size > 0;
+#define HIPDRT_GRAM(D, R) hipLaunchKernelGGL((gram_kernel<D, R>), dim3(ntile, B), dim3(256), 0, st, m, n, A, lda, w, g, P, ldp, \
+                                             p_stride, active, ntile, Ppk, ppk_stride, nchp, a_stride)
+    if (P) { if (dop) HIPDRT_GRAM(true, true); else HIPDRT_GRAM(false, true); }
+    else { if (dop) HIPDRT_GRAM(true, false); else HIPDRT_GRAM(false, false); }
+#undef HIPDRT_GRAM
 }
 
 void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,

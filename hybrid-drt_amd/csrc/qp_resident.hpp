@@ -200,6 +200,16 @@ struct OpsResidentT {
         return cholinv16_dsc(r0, c0);
     }
     __device__ __forceinline__ bool cholinv16_dsc(int r0, int c0) const { return cholinv16_blocked(r0, c0); }
+    // 1 / sqrt(x) as the library's rsqrt() computes it for a finite x > 0 -- v_rsq_f64 and one refinement, the same five
+    // operations -- without its select that keeps the raw result for 0 / inf / nan (three more dependent vector instructions per
+    // pivot: the pivots are checked for > 0 below anyway).  Every vector instruction of this chain counts twice: it is latency
+    // on the path everybody waits for, and beside a SIMD partner that streams v_mfma_f64 it gets one issue slot per MFMA
+    // (tools/cholinv16_bench.hip: 4592 -> 3836 cycles per call alone, 102.6 k -> 69.2 k beside a saturating partner; same bits).
+    static __device__ __forceinline__ double rsq_pivot(double x) {
+        const double y0 = __builtin_amdgcn_rsq(x);
+        const double e = __builtin_fma(y0 * -x, y0, 1.0);
+        return __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
+    }
     // The same in four block steps of four pivots on the matrix pipe: forward elimination of [D | I] to [L' | W], the two
     // halves kept as two MFMA accumulators (lane (li, kq) register rg <-> row kq + 4 rg, column li).  Step k reads its 4 x 4
     // diagonal block (ten v_readlane pairs), factors and inverts it in uniform arithmetic (every lane the same values: four
@@ -219,7 +229,7 @@ struct OpsResidentT {
             aA[rg] = D[(i > li ? i : li) * DLD + (i > li ? li : i)];      // lower triangle mirrored
             aW[rg] = (i == li) ? 1.0 : 0.0;
         }
-        bool ok = true;
+        double pmin = 1.0, plast = 0.0;          // smallest pivot so far (one v_min per pivot instead of a compare + scalar and)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const double tA = aA[k], tW = aW[k];
@@ -227,27 +237,31 @@ struct OpsResidentT {
             auto dg = [&](int a_, int b_) { return bcast_lane(tA, 4 * k + b_ + 16 * a_); };
             const double d00 = dg(0, 0), d10 = dg(1, 0), d20 = dg(2, 0), d30 = dg(3, 0);
             const double d11 = dg(1, 1), d21 = dg(2, 1), d31 = dg(3, 1), d22 = dg(2, 2), d32 = dg(3, 2), d33 = dg(3, 3);
-            const double i0 = rsqrt(d00);
+            const double i0 = rsq_pivot(d00);
             const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
             const double p1 = d11 - l10 * l10;
-            const double i1 = rsqrt(p1);
+            const double i1 = rsq_pivot(p1);
             const double l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
             const double p2 = d22 - l20 * l20 - l21 * l21;
-            const double i2 = rsqrt(p2);
+            const double i2 = rsq_pivot(p2);
             const double l32 = (d32 - l30 * l20 - l31 * l21) * i2;
             const double p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
-            const double i3 = rsqrt(p3);
-            if (!(d00 > 0.0) || !(p1 > 0.0) || !(p2 > 0.0) || !(p3 > 0.0)) ok = false;
+            const double i3 = rsq_pivot(p3);
+            // (fmin drops NaNs, so they are caught at the end: a NaN anywhere in the block -- in the input, or bred by a pivot
+            // <= 0 -- travels through the multipliers and the panel into every later pivot, the very last one included)
+            pmin = fmin(fmin(pmin, fmin(d00, p1)), fmin(p2, p3));
+            plast = p3;
             // Wkk = inverse of the 4 x 4 factor
             const double w10 = -(l10 * i0) * i1;
             const double w21 = -(l21 * i1) * i2, w20 = -(l20 * i0 + l21 * w10) * i2;
             const double w32 = -(l32 * i2) * i3, w31 = -(l31 * i1 + l32 * w21) * i3, w30 = -(l30 * i0 + l31 * w10 + l32 * w20) * i3;
-            // A operand: row li (< 4) of Wkk, inner index kq
-            const double r0_ = kq == 0 ? i0 : 0.0;
-            const double r1_ = kq == 0 ? w10 : kq == 1 ? i1 : 0.0;
-            const double r2_ = kq == 0 ? w20 : kq == 1 ? w21 : kq == 2 ? i2 : 0.0;
-            const double r3_ = kq == 0 ? w30 : kq == 1 ? w31 : kq == 2 ? w32 : i3;
-            const double wsel = li == 0 ? r0_ : li == 1 ? r1_ : li == 2 ? r2_ : li == 3 ? r3_ : 0.0;
+            // A operand: lane (li < 4, kq <= li) holds Wkk[li][kq], every other lane zero -- selected column by column (ten
+            // selects; the row-by-row form compiled to fourteen and a nest of exec-mask branches)
+            const double c0_ = li == 0 ? i0 : li == 1 ? w10 : li == 2 ? w20 : w30;
+            const double c1_ = li == 1 ? i1 : li == 2 ? w21 : w31;
+            const double c2_ = li == 2 ? i2 : w32;
+            double wsel = kq == 0 ? c0_ : kq == 1 ? c1_ : kq == 2 ? c2_ : i3;
+            wsel = (li < 4 && kq <= li) ? wsel : 0.0;
             const v4d z4 = (v4d){0, 0, 0, 0};
             const v4d X = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, tA, z4, 0, 0, 0);
             const v4d Y = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, tW, z4, 0, 0, 0);
@@ -260,7 +274,7 @@ struct OpsResidentT {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        return ok;
+        return pmin > 0.0 && plast == plast;
     }
 
     // accumulator image of -(S tile (T, Cc))': lane (li, kq) register rg <-> row li, column kq + 4 rg.  In two steps so that

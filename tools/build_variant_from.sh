@@ -4,7 +4,7 @@
 
 c="$1"; name="$2"; d=/tmp/variant_$name
 rm -rf $d; mkdir -p $d/hybrid-drt_amd $d/include
-cp -r hybrid-drt_amd/csrc $d/hybrid-drt_amd/; cp include/hipdrt.h $d/include/
+cp -r hybrid-drt_amd/csrc $d/hybrid-drt_amd/; cp include/hipdrt.h include/hipdrt_debug.h $d/include/
 rm -f $d/hybrid-drt_amd/csrc/*.o
 for f in qp_resident.hpp qp_common.hpp qp.hip qp_super.hpp; do
   git show $c:hybrid-drt_amd/csrc/$f > $d/hybrid-drt_amd/csrc/$f 2>/dev/null || rm -f $d/hybrid-drt_amd/csrc/$f

@@ -258,7 +258,8 @@ int launch_qp(hipStream_t st, const QpArgs& a) {
     bool aborted = false;
     for (int b = 0; b < a.B; ++b) aborted = aborted || stt[(size_t)b] == HIPDRT_QP_ABORTED;
     if (!aborted) return HIPDRT_OK;
-    // why: gsync word [4] of an aborted problem is 1 (spread over XCDs) or 2 (a member did not arrive in time)
+    // why: gsync word [4] of an aborted problem is 1 (spread over XCDs), 2 (a member did not arrive in time) or 3 (a bounded wait
+    // inside the factorisation expired: qp_group.hpp, trap_if)
     std::vector<int> gs((size_t)a.B * GRP_WORDS);
     e = hipMemcpyAsync(gs.data(), a.gsync, gs.size() * sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

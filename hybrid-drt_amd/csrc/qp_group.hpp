@@ -108,7 +108,20 @@ struct OpsGroup : OpsResidentT<true, 512> {
     int* lacnt = nullptr;                  // LDS: look-ahead tiles delivered in this factorisation (6 per block column this member owns)
     double* labuf = nullptr;               // global [block columns][7][256]: look-ahead accumulators published by their owner
 
-    __device__ __forceinline__ void trap_if(bool c) const { if (c) __builtin_trap(); }
+    int* abort_status = nullptr;           // &status[problem]: a wait that expires reports HIPDRT_QP_ABORTED there
+    // A bounded wait that expires INSIDE a running factorisation (it can only do so through a protocol error, not through the
+    // environment -- residency is settled at the start rendezvous) used to trap, which kills the HIP context and the host process
+    // with it.  Now the wavefront reports the problem as aborted (status + reason 3 in sync word [4]) and ends: a terminated
+    // wavefront leaves its workgroup's barriers, the partner members run into their own time-outs at their next hand-over and end
+    // the same way, the kernel returns, and the launcher repeats the problem on one workgroup from its untouched inputs (the
+    // group kernel writes x, the iteration counts and the status only at the very end).
+    __device__ __forceinline__ void trap_if(bool c) const {
+        if (c) {
+            __hip_atomic_store(abort_status, HIPDRT_QP_ABORTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&gs[4], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_endpgm();
+        }
+    }
 
     // ---- group barrier: every member's stores complete, then one arrival per member on a monotonic counter -------------
     __device__ __forceinline__ void group_sync() {
@@ -915,6 +928,7 @@ __global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int 
     OpsGroup ops;
     ops.G = G; ops.g = g;
     ops.gs = a.gsync + (size_t)b * GRP_WORDS;
+    ops.abort_status = a.status + b;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk + (size_t)b * a.ppk_stride; ops.nchp = a.nchp;
     // LDS carve (the pointers of the base class's layout struct are set by hand: n-vectors sized by this launch)

@@ -494,9 +494,21 @@ def _unpack_block(block):
     return obs_x, special, cols, ti, var, vok
 
 
+def _one_kernel(drt, members):
+    """pin (members = 0: one workgroup per problem, the batch kernel) or release (-1) the coneqp kernel choice of `drt` and its
+    sibling clones; plans made under the other choice are dropped (their scratch layout follows the kernel)"""
+    from .. import _ffi
+    for d in [drt] + list(getattr(drt, '_sibling_clones', None) or []):
+        ctx = d._context if d._context is not None else _ffi.get_context(d.device)
+        ctx.debug_qp_group(members)
+        if getattr(d, '_plan', None) is not None:
+            d._plan.close()
+            d._plan = d._plan_key = None
+
+
 def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world=None, tau_supergrid=None, scheme='interleave',
                              drt_var=False, dst=0, fit=fit_observations, inflight=1, observations=None, ignore_errors=False,
-                             **fit_kw):
+                             reproducible=False, **fit_kw):
     """BASELINE configs[3]: the observations of one map sharded over the ranks of a node (one process per GPU), every
     rank fitting its share as device batches, the results gathered on rank `dst` with ONE collective per map (a gather).
     The lookup tables of rank `dst` are broadcast ONCE per DRT instance (share_lookup_tables: the first map of an instance
@@ -514,8 +526,19 @@ def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world
     every rank).  Every rank fits with ignore_errors=True, so that all of them reach the collective; a failed observation then
     raises on `dst`, after the gather, unless ``ignore_errors``.
     A fit's bits depend (at the 1e-14 level) on whether its device batch held more or fewer than #CUs / 16 spectra (two QP
-    kernels): a map re-sharded over another number of ranks reproduces to that level, not bit for bit."""
+    kernels): a map re-sharded over another number of ranks reproduces to that level, not bit for bit --
+    unless ``reproducible=True``, which keeps every device batch of this call on the one-workgroup-per-problem kernel whatever
+    its size (n <= 2048; small shares then fit slower, ~1.2 x for a single spectrum): the gathered map is then bit-identical
+    for every world size, shard scheme and `inflight`."""
     from . import dist as hd
+    if reproducible and fit is fit_observations:
+        _one_kernel(drt, 0)
+        try:
+            return fit_observations_sharded(drt, frequencies, z_obs, rank=rank, world=world, tau_supergrid=tau_supergrid,
+                                            scheme=scheme, drt_var=drt_var, dst=dst, fit=fit, inflight=inflight,
+                                            observations=observations, ignore_errors=ignore_errors, **fit_kw)
+        finally:
+            _one_kernel(drt, -1)
     if rank is None or world is None:
         import torch.distributed as tdist
         rank = tdist.get_rank() if tdist.is_initialized() else 0

@@ -187,3 +187,24 @@ def test_drtmd_fit_type_pfrt_matches_the_reference():
     parity_close("pfrt_map.obs_drt_var", res["obs_drt_var"] / vpeak, g["obs_drt_var"] / vpeak, 5e-11, scale=1.0)   # 1.7e-12
     with pytest.raises(ValueError):
         fit_observations(drt, observations=obs, tau_supergrid=sup, fit_type='nope')
+
+
+def test_reproducible_map_is_bit_identical_however_it_is_sharded():
+    """fit_observations_sharded(reproducible=True): 24 spectra at the configs[2] grids as one device batch (one workgroup per
+    problem) and as three shares of eight (which would each take the several-workgroups kernel: 1e-14 apart) give the same bits;
+    without the flag the two maps agree to rounding only."""
+    from hipdrt import synth
+    from hipdrt.mapping import fit_observations_sharded
+    from hipdrt.models import DRT
+    c2 = synth.config_c2()
+    z = synth.zarc2_batch(c2["freq"], 24, first_seed=700)
+    drt = DRT(fixed_basis_tau=c2["tau"])
+    whole = fit_observations_sharded(drt, c2["freq"], z, rank=0, world=1, reproducible=True)
+    parts = [fit_observations_sharded(drt, c2["freq"], z[8 * r:8 * r + 8], rank=0, world=1, reproducible=True) for r in range(3)]
+    np.testing.assert_array_equal(np.concatenate([p_[0] for p_ in parts]), whole[0])
+    np.testing.assert_array_equal(np.concatenate([p_[1]["R_inf"] for p_ in parts]), whole[1]["R_inf"])
+    np.testing.assert_array_equal(np.concatenate([p_[2]["outer_iters"] for p_ in parts]), whole[2]["outer_iters"])
+    loose = [fit_observations_sharded(drt, c2["freq"], z[8 * r:8 * r + 8], rank=0, world=1) for r in range(3)]
+    lx = np.concatenate([p_[0] for p_ in loose])
+    assert not np.array_equal(lx, whole[0])                     # (the small shares ran on the group kernel)
+    parity_close("reproducible_map.group_vs_batch_kernel", lx, whole[0], 2e-9)      # measured 1.1e-10 (a fit of 27 outer iterations, two kernels)

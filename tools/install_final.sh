@@ -3,12 +3,13 @@
 #   bash tools/install_final.sh r04          (in the repository root; nothing is removed, no document is edited)
 T="$1"
 for f in kernel_stats.csv kernel_stats_inflight1.csv pmc_fetch_size.csv pmc_write_size.csv pmc_sq_summary.txt fuzz_c2.txt pytest_gpu.txt \
-         parity_measured.txt subbatch_sweep.txt mfma_f64_chip_bench.txt; do cp gpurun_out/${T}_$f profiles/; done
+         parity_measured.txt subbatch_sweep.txt cholinv16_bench.txt; do cp gpurun_out/${T}_$f profiles/; done
 cp gpurun_out/${T}_single.txt profiles/${T}_single_fits.txt
 cp gpurun_out/qp_traffic.json profiles/qp_traffic.json
 tail -1 gpurun_out/bench_${T}.json > profiles/${T}_bench.json
 tail -1 gpurun_out/bench_${T}_c4.json > profiles/${T}_bench_c4_1gpu.json
 tail -1 gpurun_out/bench_${T}_gloo2.json > profiles/${T}_bench_gloo2.json
+tail -1 gpurun_out/bench_${T}_force_dist.json > profiles/${T}_bench_force_dist.json
 mkdir -p /tmp/st_res
 ( cd hybrid-drt_amd/csrc && for f in api gram hyper matrices qp; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -I../../include -c $f.hip -o /tmp/st_res/$f.o --save-temps=obj 2>/dev/null; done )
 python tools/kernel_resources.py /tmp/st_res > profiles/${T}_kernel_resources.txt

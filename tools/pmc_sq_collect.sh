@@ -9,7 +9,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_
          "SQ_WAVE_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" \
          "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $O/sq_${T}_$i -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-matrix-build --no-other-configs > $O/sq_${T}_$i.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $O/sq_${T}_$i -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-matrix-build --no-other-configs --no-scale-reference > $O/sq_${T}_$i.log 2>&1
 done
 python3 - "$O" "$T" <<'PY' > $O/${T}_pmc_sq_summary.txt
 import csv, glob, sys, collections

@@ -97,7 +97,7 @@ struct hipdrt_plan {
         st.hist_b = hist_b; st.hist_cap = hist_cap;
         st.hist_x = hist_x.d(); st.hist_w = hist_w.d(); st.hist_rho = hist_rho.d();
         st.hist_qp = hist_qp.i(); st.hist_rows = hist_rows.i();
-        st.premv = nullptr;
+        st.premv = nullptr; st.premv_batched = 0;
         return st;
     }
 };
@@ -940,9 +940,17 @@ static int plan_toep_reach(hipdrt_plan* p) {
 // many workgroups first (premv_kernel), else the one workgroup per fit of hyper_kernel would stream them through one CU each.
 static int plan_hyper(hipdrt_plan* p, hipStream_t st, const FitState& fs_in, int B, int it) {
     FitState fs = fs_in;
+    const size_t premv_need = 3 * (size_t)(p->capacity > B ? p->capacity : B) * p->m * sizeof(double);
     if (B * 8 <= device_cus() && (size_t)p->m * p->n >= ((size_t)1 << 20) && !(p->opts.outlier_p > 0.0)) {
-        if (!p->premv.p) HIPDRT_CHECK(p->premv.alloc(3 * (size_t)p->capacity * p->m * sizeof(double)));
+        if (p->premv.bytes < premv_need) HIPDRT_CHECK(p->premv.alloc(premv_need));
         fs.premv = p->premv.d();
+    } else if (p->rm_stride == 0 && !(p->opts.outlier_p > 0.0) && !(p->prepared && p->desc.vz_index >= 0)) {
+        // one response matrix and one variance matrix for the whole batch (every EIS plan, prepared plans without a vz_offset
+        // column): rm @ x and vmm @ resid^2 of all spectra as two batched products (hyper.hip: batch_products_kernel) -- for any
+        // batch size, so that a spectrum's bits do not depend on whether it is fitted alone or among a thousand
+        if (p->premv.bytes < premv_need) HIPDRT_CHECK(p->premv.alloc(premv_need));     // (a sub-batch view: a window of the parent's)
+        fs.premv = p->premv.d();
+        fs.premv_batched = 1;
     }
     return launch_hyper(st, fs, B, it);
 }
@@ -1142,7 +1150,7 @@ static int plan_fit_one(hipdrt_plan* p) {
 // kernel of the loop works per spectrum (reductions included), so a spectrum's result does not depend on which range it is in:
 // bit-identical to the un-split fit as long as both use the same coneqp kernel (ranges of more than #CUs / 16 spectra).
 static int subbatch_count(const hipdrt_plan* p) {
-    if (p->prepared || p->hist_b >= 0 || p->has_weight_factors() || p->opts.outlier_p > 0.0 || p->qp_G != 0 || p->premv.p) return 1;
+    if (p->prepared || p->hist_b >= 0 || p->has_weight_factors() || p->opts.outlier_p > 0.0 || p->qp_G != 0) return 1;
     // measured on one MI355X (profiles/r04_subbatch_sweep.txt): ranges below ~300 spectra lose to launch-wave quantisation
     // (fits/s with k = 1 / 2 / 3 / 4 ranges: 1024 spectra 1902 / 2110 / 2106 / 1660, 1250: 2001 / 2205 / 2219 / 1796, 2500: 2229 / 2375 / 2408 / 2104).
     // Round 5: TWO ranges from 600 spectra on, never three.  Which of k = 3 and k = 4 is the slow one depends on how the ranges'
@@ -1193,6 +1201,7 @@ static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb)
     rows(v.qpstate, p->qpstate, (size_t)(p->qp_G > 1 ? p->qp_G : 1) * qp_state_doubles(p->n) * D);
     rows(v.gsync, p->gsync, qp_gsync_ints() * I);
     rows(v.Ppk, p->Ppk, qp_ppk_doubles(p->n) * D);
+    rows(v.premv, p->premv, 3 * mm * D);                   // [3][nb][m] of this range (plan_hyper: batched products)
     v.n_active.alias(p->n_active_sub, (size_t)idx * I, I);
     return HIPDRT_OK;
 }
@@ -1212,6 +1221,8 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     HIPDRT_CHECK(hipStreamSynchronize(p->ctx->stream));       // whatever staged the batch is done
     if (p->n_active_sub.bytes < (size_t)k * sizeof(int)) HIPDRT_CHECK(p->n_active_sub.alloc(16 * sizeof(int)));
+    if (p->premv.bytes < 3 * (size_t)p->capacity * p->m * sizeof(double))      // the ranges' products buffers are windows of this one
+        HIPDRT_CHECK(p->premv.alloc(3 * (size_t)p->capacity * p->m * sizeof(double)));
     while ((int)p->subs.size() < k) p->subs.emplace_back(new hipdrt_subfit());
     const int B = p->B;
     for (int i = 0; i < k; ++i) {

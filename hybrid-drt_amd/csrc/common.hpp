@@ -149,6 +149,8 @@ void launch_pack_p(hipStream_t st, int B, int n, const double* P, int ldp, long 
                    long long ppk_stride, int nchp);
 inline int qp_nchp(int n) { return round_up(n, 32) / 16; }
 inline size_t qp_ppk_doubles(int n) { return (size_t)qp_nchp(n) * qp_nchp(n) * 256; }
+void launch_qvec_batched(hipStream_t s, int B, int m, int n, const double* rm, int ldrm, const double* w, const double* y,
+                         const double* l1, double l1_scalar, double* q, const int* active);
 void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,
                  const double* l1, double l1_scalar, double* q, const int* active, long long a_stride = 0);
 void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w,
@@ -192,6 +194,7 @@ struct FitState {
     // few, large fits: the three matrix-vector products of an outer iteration (rm @ x, vmm @ resid^2, rm @ x for the
     // vz_offset column) computed by a many-workgroup kernel before hyper_kernel, which then only reads them ([3][B][m], or null)
     double* premv;
+    int premv_batched;     // premv is filled by batch_products_kernel (many fits sharing rm and vmm: two products on the matrix pipe)
     // optional history of one spectrum
     int hist_b, hist_cap;
     double *hist_x, *hist_w, *hist_rho;

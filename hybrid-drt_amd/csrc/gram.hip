@@ -344,6 +344,13 @@ void launch_gram_l2(hipStream_t st, int B, int m, int n, const double* A, int ld
 
 void launch_qvec(hipStream_t st, int B, int m, int n, const double* A, int lda, const double* w, const double* y,
                  const double* l1, double l1_scalar, double* q, const int* active, long long a_stride) {
+    // one matrix for the whole batch: a matrix product with a shared operand (hyper.hip: batch_products_kernel), whatever the
+    // batch size -- a fit's bits do not depend on how many are fitted beside it; few fits with very large matrices keep the
+    // vector kernel (a handful of workgroups would stream all of A)
+    if (a_stride == 0 && (size_t)m * n < ((size_t)1 << 20)) {
+        launch_qvec_batched(st, B, m, n, A, lda, w, y, l1, l1_scalar, q, active);
+        return;
+    }
     hipLaunchKernelGGL(qvec_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, m, n, A, lda, w, y, l1, l1_scalar, q,
                        active, a_stride);
 }

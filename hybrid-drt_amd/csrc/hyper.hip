@@ -461,6 +461,133 @@ __global__ __launch_bounds__(HT) void premv_kernel(FitState st, int phase, int B
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Many fits that SHARE their matrices (an EIS plan: one response matrix rm and one variance matrix vmm for the whole batch):
+// the two products of estimate_weights, rm @ x_b and vmm @ (rm x_b - rv_b)^2 for every spectrum b, and the linear term of the
+// QP, rm' (w_b^2 rv_b), are matrix-matrix products with a shared operand -- [B][n] x [m][n]', [B][m] x [m][m]' and [B][m] x [m][n]
+// -- and belong on the matrix pipe, where they read the shared matrix once per 32 spectra instead of once per spectrum
+// (hyper_kernel streamed 4.2 MB from L2 per spectrum and outer iteration: 126 GB per 1024-spectrum step, more than half of its
+// 22 ms; qvec_kernel 2.1 MB).  C[b][i] = sum_k f(A[b][k]) M[i][k] with
+//   MODE 0: f = identity                      (A = x: the model impedance rm x)
+//   MODE 1: f(v) = (v - rv[b][k])^2           (A = the MODE-0 result: vmm @ resid^2)
+//   MODE 2: f(v) = v * (v * rv[b][k])         (A = w, rv = the data: C = -sum + l1, the QP's q; M is given TRANSposed, [K][ni])
+// on v_mfma_f64_16x16x4 from slabs of 16 k staged through LDS, the next slab requested while this one is multiplied.  A row's
+// sum runs over k in ascending order whatever the batch holds, so a spectrum's bits do not depend on its neighbours or on B.
+// grid = (ceil(ni / 64), ceil(B / 32)), 256 threads (4 wavefronts as 2 x 2 of 16 spectra x 32 rows).
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int BG_TB = 32, BG_TI = 64, BG_K = 16, BG_LD = BG_K + 1;     // 32 spectra x 64 rows per workgroup, K slabs of 16
+template <int MODE, bool TRANS>
+__global__ __launch_bounds__(256) void batch_products_kernel(int B, int ni, int K, const double* __restrict__ A, int lda,
+                                                             const double* __restrict__ rv, const double* __restrict__ M, int ldm,
+                                                             const int* __restrict__ active, double* __restrict__ C,
+                                                             const double* __restrict__ l1, double l1_scalar) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    __shared__ double sA[BG_TB * BG_LD];
+    __shared__ double sM[BG_TI * BG_LD];
+    const int b0 = blockIdx.y * BG_TB, i0 = blockIdx.x * BG_TI;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // nothing to do for a slab of spectra that have all converged
+    if (active && !__any(lane < BG_TB && b0 + lane < B && active[b0 + lane] != 0)) return;
+    const int wb = (wv >> 1) * 16, wi = (wv & 1) * 32;       // wavefront: 16 spectra x 32 rows
+    const int li = lane & 15, kq = lane >> 4;
+    v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+    // staging.  A (and M when it is stored [ni][K]): row sr, four consecutive k.  M stored [K][ni]: slab row tk, four consecutive i
+    const int sr = tid >> 2, sk = (tid & 3) * 4;
+    const int tk = tid >> 4, ti = (tid & 15) * 4;
+    const bool evenA = ((lda | K) & 1) == 0, evenM = TRANS ? (ldm & 1) == 0 : ((ldm | K) & 1) == 0;
+    const bool ldA = sr < BG_TB && b0 + sr < B, ldM = i0 + sr < ni;
+    const double* arow = A + (size_t)(ldA ? b0 + sr : 0) * lda;
+    const double* rrow = MODE ? rv + (size_t)(ldA ? b0 + sr : 0) * lda : nullptr;
+    const double* mrow = TRANS ? M + i0 + ti : M + (size_t)(ldM ? i0 + sr : 0) * ldm;
+    double va[4], vr[4], vm[4];
+    auto fetch = [&](int k0) {
+        const int kk = k0 + sk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { va[e] = 0.0; vr[e] = 0.0; vm[e] = 0.0; }
+        if (ldA) {
+            if (evenA && kk + 3 < K) {
+                const double2 t0 = *reinterpret_cast<const double2*>(arow + kk), t1 = *reinterpret_cast<const double2*>(arow + kk + 2);
+                va[0] = t0.x; va[1] = t0.y; va[2] = t1.x; va[3] = t1.y;
+                if (MODE) {
+                    const double2 r0 = *reinterpret_cast<const double2*>(rrow + kk), r1 = *reinterpret_cast<const double2*>(rrow + kk + 2);
+                    vr[0] = r0.x; vr[1] = r0.y; vr[2] = r1.x; vr[3] = r1.y;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk + e < K) { va[e] = arow[kk + e]; if (MODE) vr[e] = rrow[kk + e]; }
+            }
+        }
+        if (TRANS) {
+            if (k0 + tk < K) {
+                const double* mp = mrow + (size_t)(k0 + tk) * ldm;
+                if (evenM && i0 + ti + 3 < ni) {
+                    const double2 t0 = *reinterpret_cast<const double2*>(mp), t1 = *reinterpret_cast<const double2*>(mp + 2);
+                    vm[0] = t0.x; vm[1] = t0.y; vm[2] = t1.x; vm[3] = t1.y;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (i0 + ti + e < ni) vm[e] = mp[e];
+                }
+            }
+        } else if (ldM) {
+            if (evenM && kk + 3 < K) {
+                const double2 t0 = *reinterpret_cast<const double2*>(mrow + kk), t1 = *reinterpret_cast<const double2*>(mrow + kk + 2);
+                vm[0] = t0.x; vm[1] = t0.y; vm[2] = t1.x; vm[3] = t1.y;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (kk + e < K) vm[e] = mrow[kk + e];
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += BG_K) {
+        __syncthreads();       // previous slab consumed
+        if (sr < BG_TB) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double v = va[e];
+                if (MODE == 1) { const double r = va[e] - vr[e]; v = r * r; }      // (entries past K: 0 - 0)
+                if (MODE == 2) v = va[e] * (va[e] * vr[e]);
+                sA[sr * BG_LD + sk + e] = v;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (TRANS) sM[(ti + e) * BG_LD + tk] = vm[e];
+            else sM[sr * BG_LD + sk + e] = vm[e];
+        }
+        __syncthreads();
+        if (k0 + BG_K < K) fetch(k0 + BG_K);
+#pragma unroll
+        for (int s_ = 0; s_ < BG_K; s_ += 4) {
+            // operands of v_mfma_f64_16x16x4: lane (li, kq) supplies element [row li][k = kq] of either factor; with the shared
+            // matrix as the first operand the accumulator of lane (li, kq), register r is C[spectrum li][row kq + 4 r]
+            const double a0 = sA[(wb + li) * BG_LD + s_ + kq];
+            const double m0 = sM[(wi + li) * BG_LD + s_ + kq], m1 = sM[(wi + 16 + li) * BG_LD + s_ + kq];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, a0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, a0, acc[1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bb = b0 + wb + li, ii = i0 + wi + c * 16 + kq + 4 * r;
+            if (bb < B && ii < ni && (!active || MODE != 2 || active[bb])) {
+                double v = acc[c][r];
+                if (MODE == 2) v = -v + (l1 ? l1[ii] : l1_scalar);
+                C[(size_t)bb * ni + ii] = v;
+            }
+        }
+}
+
+// q_b = -rm' (w_b (w_b y_b)) + l1 for a batch that shares rm (row-major [m][n])
+void launch_qvec_batched(hipStream_t s, int B, int m, int n, const double* rm, int ldrm, const double* w, const double* y,
+                         const double* l1, double l1_scalar, double* q, const int* active) {
+    const dim3 grid((n + BG_TI - 1) / BG_TI, (B + BG_TB - 1) / BG_TB);
+    hipLaunchKernelGGL((batch_products_kernel<2, true>), grid, dim3(256), 0, s, B, n, m, w, m, y, rm, ldrm, active, q, l1, l1_scalar);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // hyper-parameter update + weights + convergence for one outer iteration.  grid = B
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {     // <= 128 VGPRs: two workgroups per CU
@@ -1027,7 +1154,14 @@ int launch_hyper(hipStream_t s, const FitState& st_in, int B, int it) {
     }
     if (lds > kLdsLimit) { set_error("hyper-parameter kernel: problem too large for LDS (m, n)"); return HIPDRT_E_INVALID; }
     if (int rc = set_lds(reinterpret_cast<const void*>(hyper_kernel), lds)) return rc;
-    if (st.premv && st.opts.outlier_p <= 0.0) {
+    if (st.premv && st.premv_batched && st.opts.outlier_p <= 0.0) {
+        // many fits sharing rm and vmm: both products of estimate_weights for the whole batch on the matrix pipe
+        const dim3 grid((st.m + BG_TI - 1) / BG_TI, (B + BG_TB - 1) / BG_TB);
+        hipLaunchKernelGGL((batch_products_kernel<0, false>), grid, dim3(256), 0, s, B, st.m, st.n, st.x, st.n, nullptr, st.rm,
+                           st.ldrm, st.active, st.premv, nullptr, 0.0);
+        hipLaunchKernelGGL((batch_products_kernel<1, false>), grid, dim3(256), 0, s, B, st.m, st.m, st.premv, st.m, st.rv, st.vmm,
+                           st.m, st.active, st.premv + (size_t)B * st.m, nullptr, 0.0);
+    } else if (st.premv && st.opts.outlier_p <= 0.0) {
         const size_t l0 = (size_t)st.n * sizeof(double), l1 = (size_t)st.m * sizeof(double);
         const dim3 grid((st.m + PREMV_ROWS - 1) / PREMV_ROWS, B);
         hipLaunchKernelGGL(premv_kernel, grid, dim3(HT), l0, s, st, 0, B);

@@ -1773,16 +1773,17 @@ struct OpsResidentT {
                 const int k = tbelow - tw_ > 0 ? (tbelow - tw_ + SW_TW - 1) / SW_TW : 0;
                 return k < SW_FT ? k : SW_FT;
             };
-            auto fpre = [&](SweepBuf& B_, int jb) {     // tiles (tb+4+tt, 2jb..2jb+1): [tile][chunk*2 + half]
-                const int tb = 2 * jb, nv = fcount(jb);
+            auto fpre1 = [&](SweepBuf& B_, int jb, int nv, int u) {     // tile (tb+4+tt, 2jb..2jb+1) into slot u: [chunk*2 + half]
+                if (u < nv) {
+                    const char* p = uniform_ptr(tile2(2 * jb + 4 + tw_ + u * SW_TW, 2 * jb));   // chunks 2jb, 2jb+1 are adjacent
 #pragma unroll
-                for (int u = 0; u < SW_FT; ++u) {
-                    if (u < nv) {
-                        const char* p = uniform_ptr(tile2(tb + 4 + tw_ + u * SW_TW, 2 * jb));   // chunks 2jb, 2jb+1 are adjacent
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) B_.t[u][q] = gload16(p + q * 1024, voff);
-                    }
+                    for (int q = 0; q < 4; ++q) B_.t[u][q] = gload16(p + q * 1024, voff);
                 }
+            };
+            auto fpre = [&](SweepBuf& B_, int jb) {
+                const int nv = fcount(jb);
+#pragma unroll
+                for (int u = 0; u < SW_FT; ++u) fpre1(B_, jb, nv, u);
             };
             auto fstep = [&](SweepBuf& B_, int jb) {
                 const int j0 = jb * NB, tb = 2 * jb, tbelow = ntr - (tb + 4);
@@ -1796,10 +1797,16 @@ struct OpsResidentT {
                     double ya[4], yb[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { ya[q] = vec[j0 + 8 * q + l4]; yb[q] = vec[j0 + 8 * q + l4 + 4]; }
+                    // (a slot's next tile -- block jb + 2 -- is requested right behind its arithmetic: the seven updaters' requests
+                    // reach the CU's one address path spread over the step instead of as one burst behind it)
+                    const int nv2 = fcount(jb + 2);
 #pragma unroll
                     for (int u = 0; u < SW_FT; ++u) {
                         const int tt = tw_ + u * SW_TW;
                         if (tt < tbelow) fwd_tile(B_.t[u], ya, yb, tb + 4 + tt, l4, g4);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fpre1(B_, jb + 2, nv2, u);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     {
                         // more tile rows below than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
@@ -1825,7 +1832,6 @@ struct OpsResidentT {
                         }
                     }
                 }
-                fpre(B_, jb + 2);
             };
             {
                 SweepBuf fa, fb;
@@ -1926,19 +1932,20 @@ struct OpsResidentT {
                 const int k = nc - tw_ > 0 ? (nc - tw_ + SW_TW - 1) / SW_TW : 0;
                 return k < SW_BC ? k : SW_BC;
             };
-            auto bpre = [&](SweepBuf& B_, int jb) {     // tiles (tb..tb+1, c): [chunk][tile*2 + half]
-                const int tb = 2 * jb, nv = bcount(jb);
-                const bool two = (tb + 1) < ntr;
-#pragma unroll
-                for (int u = 0; u < SW_BC; ++u) {
-                    if (u < nv) {
-                        const int c = tw_ + u * SW_TW;
-                        const char* p0 = uniform_ptr(tile2(tb, c));
-                        const char* p1 = uniform_ptr(tile2(two ? tb + 1 : tb, c));
-                        B_.t[u][0] = gload16(p0, voff); B_.t[u][1] = gload16(p0 + 1024, voff);
-                        B_.t[u][2] = gload16(p1, voff); B_.t[u][3] = gload16(p1 + 1024, voff);
-                    }
+            auto bpre1 = [&](SweepBuf& B_, int jb, int nv, int u) {     // tiles (tb..tb+1, c) into slot u: [tile*2 + half]
+                if (u < nv) {
+                    const int tb = 2 * jb, c = tw_ + u * SW_TW;
+                    const bool two = (tb + 1) < ntr;
+                    const char* p0 = uniform_ptr(tile2(tb, c));
+                    const char* p1 = uniform_ptr(tile2(two ? tb + 1 : tb, c));
+                    B_.t[u][0] = gload16(p0, voff); B_.t[u][1] = gload16(p0 + 1024, voff);
+                    B_.t[u][2] = gload16(p1, voff); B_.t[u][3] = gload16(p1 + 1024, voff);
                 }
+            };
+            auto bpre = [&](SweepBuf& B_, int jb) {
+                const int nv = bcount(jb);
+#pragma unroll
+                for (int u = 0; u < SW_BC; ++u) bpre1(B_, jb, nv, u);
             };
             auto bstep = [&](SweepBuf& B_, int jb) {
                 const int j0 = jb * NB, tb = 2 * jb, nc = 2 * jb - 2;
@@ -1949,10 +1956,14 @@ struct OpsResidentT {
                     // x of the block: row g4 of tile tb and of tile tb+1 (zero padding beyond n)
                     const double x0 = vec[j0 + g4];
                     const double x1 = two ? vec[j0 + 16 + g4] : 0.0;
+                    const int nv2 = bcount(jb - 2);
 #pragma unroll
                     for (int u = 0; u < SW_BC; ++u) {
                         const int c = tw_ + u * SW_TW;
                         if (c < nc) bwd_chunk(B_.t[u], x0, x1, c, lane, l4);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bpre1(B_, jb - 2, nv2, u);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     {
                         // more finished chunks than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
@@ -1979,7 +1990,6 @@ struct OpsResidentT {
                         }
                     }
                 }
-                bpre(B_, jb - 2);
             };
             {
                 SweepBuf ba, bb;

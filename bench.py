@@ -261,6 +261,14 @@ def self_launch(n):
     return 1 if bad else 0
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +350,7 @@ def main():
         raise SystemExit(3)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    _flush_c_stdio()                                         # (RCCL's start-up banner leaves every rank's buffer now)
 
     if config == "c3":
         B = args.batch
@@ -710,11 +719,15 @@ def main():
             cpu["gpu_over_reference_structure"] = value / cpu["reference_structure"]["value"]
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+    # the JSON line is the LAST thing this job writes to stdout: RCCL prints its banner through C stdio, which is block-buffered
+    # on a pipe and would otherwise be flushed at exit, behind the line
     hd.barrier()
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

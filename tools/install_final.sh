@@ -9,7 +9,7 @@ cp gpurun_out/qp_traffic.json profiles/qp_traffic.json
 tail -1 gpurun_out/bench_${T}.json > profiles/${T}_bench.json
 tail -1 gpurun_out/bench_${T}_c4.json > profiles/${T}_bench_c4_1gpu.json
 tail -1 gpurun_out/bench_${T}_gloo2.json > profiles/${T}_bench_gloo2.json
-tail -1 gpurun_out/bench_${T}_force_dist.json > profiles/${T}_bench_force_dist.json
+grep '"metric"' gpurun_out/bench_${T}_force_dist.json | tail -1 > profiles/${T}_bench_force_dist.json
 mkdir -p /tmp/st_res
 ( cd hybrid-drt_amd/csrc && for f in api gram hyper matrices qp; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -I../../include -c $f.hip -o /tmp/st_res/$f.o --save-temps=obj 2>/dev/null; done )
 python tools/kernel_resources.py /tmp/st_res > profiles/${T}_kernel_resources.txt

@@ -73,6 +73,7 @@ static constexpr int GRP_ROW_RING = HIPDRT_GRP_ROW_RING;  // slots of the rows' 
 static constexpr int GRP_RMAXT = 2;                    // tile rows per row wavefront and pass: a member has few rows, and a short
                                                        // pass leaves registers for an eight-slot operand ring (below)
 static constexpr int GRP_WORDS = 16 + GRP_OWN;         // ints of global sync state per problem
+static constexpr int GRP_LA_SLOT = 7 * 256 + 32;       // doubles per block column in labuf: seven accumulator tiles + 32 right-hand-side entries
 static constexpr int kNotResident = 1 << 30;           // poison bit in word [0]: a member gave up waiting for its partners
 // words: [0] members arrived at the start | kNotResident (ONE word decides go / abort for every member), [1] OR of (1 << XCC id),
 // [4] why a launch was aborted, [2] barrier counter, [3] laprog: factorisation count * 256
@@ -91,10 +92,16 @@ static __device__ __forceinline__ v2d gload16_sc1(const char* sbase, unsigned vo
 struct OpsGroup : OpsResidentT<true, 512> {
     using Base = OpsResidentT<true, 512>;
     static constexpr int RT = 512, RNW = 8;
-    // The predictor's forward substitution is NOT fused into the factorisation here: a member only touches its own rows'
-    // tiles, but every member needs the whole substituted vector for its (redundant) interior-point step; the predictor
-    // solve is a full forward + backward sweep over the finished factor instead.
-    static constexpr bool kFusedForward = false;
+    // The predictor's forward substitution is fused into the factorisation as in the batch kernel (round 5; before, every member
+    // ran a full forward sweep over the finished factor: one of four sweeps per interior-point iteration).  A member only solves
+    // its own rows' tiles, so only ITS copy of those rows' right-hand-side entries receives the block columns' updates -- but
+    // what every member needs is y_j = M_j b_j of every diagonal block, and b_j are the two look-ahead rows of block column
+    // j - 1: their owner publishes the 32 entries (updated through block column j - 2 by its row wavefronts) behind the seven
+    // look-ahead accumulators it publishes anyway, every member's wavefront 1 takes them over and applies block column j - 1's
+    // update itself, as it does for the tiles.  Every member's chain then computes every y_j from identical bits, and at the end
+    // of the factorisation every member's vector holds the whole substituted right-hand side.  Per row the block columns'
+    // contributions arrive in ascending order whoever owns the row: the result does not depend on G.
+    static constexpr bool kFusedForward = true;
     static constexpr int kRedSlots = 4;
     static constexpr int kSpinLimit = 1 << 24;
     static constexpr int kRendezvousLimit = 1 << 22;       // polls of the start rendezvous (~0.5 s) before the launch gives up cleanly
@@ -106,7 +113,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
                                                  // and the look-ahead rows this member computes itself)
     double* latile = nullptr;              // LDS [6][256]: the look-ahead tiles computed by wavefronts 2..7 (register images)
     int* lacnt = nullptr;                  // LDS: look-ahead tiles delivered in this factorisation (6 per block column this member owns)
-    double* labuf = nullptr;               // global [block columns][7][256]: look-ahead accumulators published by their owner
+    double* labuf = nullptr;               // global [block columns][GRP_LA_SLOT]: look-ahead accumulators (+ the rows' right-hand side) published by their owner
 
     int* abort_status = nullptr;           // &status[problem]: a wait that expires reports HIPDRT_QP_ABORTED there
     // A bounded wait that expires INSIDE a running factorisation (it can only do so through a protocol error, not through the
@@ -159,7 +166,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
     __device__ __forceinline__ void build_owner() {
         if (threadIdx.x != 0) return;
         const int ntr = (n + 15) >> 4;
-        const unsigned char order[6] = {4, 5, 2, 3, 6, 7};
+        const unsigned char order[6] = {2, 3, 5, 6, 7, 4};
         int k = 0;
         for (int T = ntr - 1; T >= 0; --T) {
             if (!mine(T)) { owner[T] = 0; continue; }
@@ -578,8 +585,24 @@ struct OpsGroup : OpsResidentT<true, 512> {
                 w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(size_t)(j0 + 16 + li) * PLD + 16 + 4 * s_ + kq], y[s_], w21, 0, 0, 0);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) U[(size_t)(j0 + 16 + kq + 4 * rg) * PLD + li] = w21[rg];
-            // (A2): separates this block column's readers of the L21 scratch block from its next writer (in the batch kernel
-            // it also publishes the forward-substituted right-hand-side block)
+            if (fwd) {
+                // fused forward substitution: y_j = M_j b_j (b_j: published by the rows' owner, last update by wavefront 1)
+                __builtin_amdgcn_wave_barrier();
+                const int r = lane & 31;
+                const double* Mr = U + (size_t)(j0 + r) * PLD;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; c += 4) {
+                    s0 += Mr[c] * sm.vec[j0 + c];
+                    s1 += Mr[c + 1] * sm.vec[j0 + c + 1];
+                    s2 += Mr[c + 2] * sm.vec[j0 + c + 2];
+                    s3 += Mr[c + 3] * sm.vec[j0 + c + 3];
+                }
+                const double yv = (s0 + s1) + (s2 + s3);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < NB) sm.vec[j0 + lane] = yv;
+            }
+            // (A2): separates this block column's readers of the L21 scratch block from its next writer, and publishes y_j
             TS(8);
             lds_barrier();                                      // (A2)
             PROF(3);
@@ -664,8 +687,11 @@ struct OpsGroup : OpsResidentT<true, 512> {
                         p20 = T_.p20; p21 = T_.p21; p30 = T_.p30; p31 = T_.p31; e11 = T_.e11; e21 = T_.e21; e22 = T_.e22;
                         if (G > 1) {
                             // publish the seven raw accumulators (register images) for the other members
-                            v4d* dst = reinterpret_cast<v4d*>(labuf + (size_t)jb * 7 * 256) + lane;
+                            v4d* dst = reinterpret_cast<v4d*>(labuf + (size_t)jb * GRP_LA_SLOT) + lane;
                             dst[0] = p20; dst[64] = p21; dst[128] = p30; dst[192] = p31; dst[256] = e11; dst[320] = e21; dst[384] = e22;
+                            // ... and the rows' right-hand-side entries as this member's row wavefronts left them (block columns
+                            // 0 .. jb - 1 applied: la_new_range waited for those rows)
+                            if (fwd && lane < 32) labuf[(size_t)jb * GRP_LA_SLOT + 7 * 256 + lane] = sm.vec[R2 * 16 + lane];
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             if (lane == 0) __hip_atomic_store(&gs[3], prog_value(jb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -682,7 +708,7 @@ struct OpsGroup : OpsResidentT<true, 512> {
                         asm volatile("" ::: "memory");
                         PROFW(22);
                         TS(3);
-                        const char* src = uniform_ptr(labuf + (size_t)jb * 7 * 256);
+                        const char* src = uniform_ptr(labuf + (size_t)jb * GRP_LA_SLOT);
                         const unsigned vo = (unsigned)lane * 32u;
                         v2d t_[14];
 #pragma unroll
@@ -695,6 +721,13 @@ struct OpsGroup : OpsResidentT<true, 512> {
                         for (int q = 0; q < 14; ++q) asm volatile("" : "+v"(t_[q]));
                         auto cat = [&](int q) { return (v4d){t_[2 * q].x, t_[2 * q].y, t_[2 * q + 1].x, t_[2 * q + 1].y}; };
                         p20 = cat(0); p21 = cat(1); p30 = cat(2); p31 = cat(3); e11 = cat(4); e21 = cat(5); e22 = cat(6);
+                        if (fwd && lane < 32) {
+                            // the owner's right-hand-side entries of rows R2, R3 replace this member's stale ones (agent-scope load:
+                            // past the L1, like the accumulators)
+                            unsigned long long* rp_ = reinterpret_cast<unsigned long long*>(labuf + (size_t)jb * GRP_LA_SLOT + 7 * 256 + lane);
+                            const unsigned long long bits = __hip_atomic_load(rp_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            sm.vec[R2 * 16 + lane] = __longlong_as_double((long long)bits);
+                        }
                         TS(4);
                     }
                     if (!v3) {
@@ -763,6 +796,11 @@ struct OpsGroup : OpsResidentT<true, 512> {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) *(volatile int*)&sm.flag[1] = jb + 1;      // diagonal block jb + 1 staged: the chain may start
                 lds_barrier();                                  // (A2)
+                if (fwd) {
+                    // block column jb's update of the right-hand side of rows R2, R3 (every member, identical bits)
+                    fwd_update(x20, x21_, R2, j0, li, kq);
+                    if (v3) fwd_update(x30, x31, R3, j0, li, kq);
+                }
             } else {
                 lds_barrier();                                  // (A2)
             }
@@ -890,7 +928,12 @@ struct OpsGroup : OpsResidentT<true, 512> {
                             d0[192] = make_double2(x2[u][2], x2[u][3]);
                         }
                     }
-                    if (ps == 0) lds_barrier();                 // (A2)
+                    if (ps == 0) lds_barrier();                 // (A2): y_j is in vec
+                    if (fwd) {
+#pragma unroll
+                        for (int u = 0; u < GRP_RMAXT; ++u)
+                            if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0, li, kq);
+                    }
                 } else if (ps == 0) {
                     lds_barrier();                              // (A2)
                 }
@@ -912,7 +955,7 @@ static size_t group_lds_bytes(int NP) { return (size_t)(GRP_FIXED + 2 * (NP + 64
 // has not fetched yet)
 static size_t group_scratch_doubles(int n, int G) {
     const size_t NP = (size_t)round_up(n, 32);
-    return NP * NP + (size_t)G * NP * PLD + (NP / NB) * 7 * 256;
+    return NP * NP + (size_t)G * NP * PLD + (NP / NB) * (size_t)GRP_LA_SLOT;
 }
 
 // grid: block 8 (r G + g) + s = member g of problem 8 r + s -- the members of a problem are 8 blocks apart, i.e. on one XCD

@@ -56,6 +56,14 @@ def scan(txt):
                 recent = [(s_, age + step) for s_, age in recent if age + step < 8]
                 if w:
                     recent.append((int(w.group(1)), 0))
+                elif op.startswith('s_') and not op.startswith(('s_cmp', 's_cbranch', 's_branch', 's_nop', 's_waitcnt', 's_barrier',
+                                                                  's_sleep', 's_setreg', 's_bitcmp', 's_endpgm', 's_setprio')):
+                    # a scalar instruction that overwrites the register ends the hazard: the value a later load reads is SALU-written
+                    dm = re.match(r'\S+\s+(?:s(\d+)|s\[(\d+):(\d+)\])\s*,', l)
+                    if dm:
+                        lo_ = int(dm.group(1) if dm.group(1) is not None else dm.group(2))
+                        hi_ = int(dm.group(1) if dm.group(1) is not None else dm.group(3))
+                        recent = [(s_, age) for s_, age in recent if not (lo_ <= s_ <= hi_)]
                 br = re.match(r's_c?branch\w*\s+(\S+)', l)
                 if br:
                     lab = br.group(1)

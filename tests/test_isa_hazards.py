@@ -36,6 +36,29 @@ def test_scanner_sees_a_planted_hazard():
     assert len(found) == 2 and all(f[1].startswith("global_load_dwordx4 v[4:7]") for f in found)
 
 
+def test_scalar_overwrite_ends_the_hazard_and_a_scalar_copy_does_not_start_one():
+    """The hazard is on the REGISTER a VALU instruction wrote: once a scalar instruction has overwritten it the load reads a
+    scalar result (no wait states needed); a base computed by scalar arithmetic FROM a v_readlane result is clean as well,
+    the VALU-written register itself stays dirty."""
+    mod = _scanner()
+    txt = """_ZN6hipdrt4testEv:
+	v_readlane_b32 s22, v248, 0
+	v_readlane_b32 s1, v248, 1
+	s_add_u32 s22, s22, s5
+	s_addc_u32 s23, s1, s0
+	s_add_u32 s0, s22, 16
+	global_load_dwordx4 v[122:125], v191, s[22:23] sc1
+	s_addc_u32 s1, s23, 0
+	global_load_dwordx4 v[126:129], v191, s[0:1] sc1
+	v_readlane_b32 s7, v248, 2
+	s_mov_b32 s6, s22
+	global_load_dwordx4 v[130:133], v191, s[6:7]
+.Lfunc_end0:
+"""
+    found = mod.scan(txt)
+    assert [(f[1].split()[1], f[2]) for f in found] == [("v[130:133],", 7)]
+
+
 def test_scanner_follows_fall_through_and_back_edges():
     mod = _scanner()
     planted = """_ZN6hipdrt5test2Ev:

@@ -1153,10 +1153,13 @@ static int subbatch_count(const hipdrt_plan* p) {
     if (p->prepared || p->hist_b >= 0 || p->has_weight_factors() || p->opts.outlier_p > 0.0 || p->qp_G != 0) return 1;
     // measured on one MI355X (profiles/r04_subbatch_sweep.txt): ranges below ~300 spectra lose to launch-wave quantisation
     // (fits/s with k = 1 / 2 / 3 / 4 ranges: 1024 spectra 1902 / 2110 / 2106 / 1660, 1250: 2001 / 2205 / 2219 / 1796, 2500: 2229 / 2375 / 2408 / 2104).
-    // Round 5: TWO ranges from 600 spectra on, never three.  Which of k = 3 and k = 4 is the slow one depends on how the ranges'
-    // launch sequences happen to interleave: with this round's shorter Gram launches the same box measured 1250 spectra at
-    // 2024 / 2240 / 1789 / 1922 (k = 3 now where k = 4 was, profiles/r05h_subbatch_sweep.txt) -- k = 2 is within 1 % of the best in
-    // both and the only choice that does not flip.
+    // Round 5: TWO ranges from 600 spectra on, never three.  The kernel trace says why k = 3 and k = 4 lose (tools/trace_ranges.sh,
+    // profiles/r05w_trace_ranges_1250.txt): the runtime maps streams onto 4 hardware queues by default, the ranges' streams landed
+    // on TWO of them -- with k = 3 one queue carries two ranges' launch sequences one behind the other (102 coneqp launches
+    // against 51 on the other queue), with k = 4 two each, and never more than two coneqp launches run at a time.  With
+    // GPU_MAX_HW_QUEUES=8 in the process environment every range has its own queue and k = 2 / 3 / 4 measure 2285 / 2281 / 2330
+    // at 1250 spectra (profiles/r05x_ab_hw_queues.txt) -- the library cannot set that for its host (it is read when the HIP
+    // runtime starts), so it keeps the choice that is right with either setting.
     int k = p->subbatches >= 1 ? std::min(p->subbatches, std::max(1, p->B / 64)) : (p->B >= 600 ? 2 : 1);
     // the promise is "the bits of the un-split fit": the whole batch AND the smallest range must choose the batch coneqp kernel as
     // the views will see it (qp_layout runs qp_group_size on the view's own count with the context's current override, which may

@@ -80,6 +80,7 @@ struct hipdrt_plan {
     FitState state() const {
         FitState st{};
         st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm; st.toeplitz_m = toeplitz_m;
+        st.toep_reach = toeplitz_m ? toep_maxd : -1;
         st.opts = opts; st.continue_mode = 0; st.min_iter = 1;
         st.basis_area = prepared ? desc.basis_area : (eps > 0 ? 1.7724538509055159 / eps : 0.0);   // sqrt(pi) / epsilon
         st.prepared = prepared; st.desc = desc; st.rm_stride = rm_stride; st.rm_rw = rm.d();

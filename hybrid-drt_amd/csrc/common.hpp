@@ -161,6 +161,7 @@ void launch_weighted_gram(hipStream_t st, int B, int m, int n, const double* A, 
 struct FitState {
     int nf, m, n, ns, ldrm, ldm;
     int toeplitz_m;        // penalty blocks are symmetric Toeplitz (uniform ln-tau grid): first column suffices
+    int toep_reach;        // ... and exactly zero beyond this distance from the diagonal in every order (-1: not known)
     int continue_mode;     // 1: warm restart (_continue_from_init): xmx norms stay frozen, no rescaling;
                            // 2: a bare iterate_qphb (hipdrt_plan_iterate): as 1 and no vz_offset column rewrite
     int min_iter;          // a spectrum may only stop once it has done this many outer iterations (fit: 1)

@@ -244,23 +244,31 @@ __device__ __forceinline__ void rows_matvec(const double* __restrict__ M, int ld
 // y[i] = sum_j c[i - j] v[j].  Two adjacent rows per thread: v[j] is a broadcast read, c[i - j] runs over consecutive
 // addresses across the lanes, nothing is reduced across lanes, and row i+1's operand at column j+1 is row i's at column j
 // (kept in a register) -- one LDS read per product instead of two.  Four partial sums per row (j mod 4), as before.
+// reach >= 0: c[d] is exactly zero for |d| > reach (the Gaussian penalties underflow a few dozen grid points off the diagonal):
+// the columns outside [ia - reach, ia + 1 + reach], widened to multiples of four so that every product keeps its partial sum,
+// would add exact zeros and are left out -- the same bits from a fifth of the products at nd = 512.
 __device__ __forceinline__ void toeplitz_matvec(const double* __restrict__ c, int nd, const double* __restrict__ v,
-                                                double* __restrict__ out) {
+                                                double* __restrict__ out, int reach = -1) {
     for (int p = threadIdx.x; 2 * p < nd; p += HT) {
         const int ia = 2 * p;
         const bool hb = ia + 1 < nd;
         const double* ca = c + ia;                 // ca[-j] = c[ia - j]
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-        double prev = hb ? ca[1] : ca[0];          // c[ib - 0]
-        int j = 0;
-        for (; j + 3 < nd; j += 4) {
+        int j = 0, jhi = nd;
+        if (reach >= 0) {
+            j = ia - reach > 0 ? (ia - reach) & ~3 : 0;
+            const int e_ = (ia + 2 + reach + 3) & ~3;
+            jhi = e_ < nd ? e_ : nd;
+        }
+        double prev = hb ? ca[1 - j] : ca[-j];     // c[ib - j]
+        for (; j + 3 < jhi; j += 4) {
             const double c0 = ca[-j], c1 = ca[-j - 1], c2 = ca[-j - 2], c3 = ca[-j - 3];
             const double v0 = v[j], v1 = v[j + 1], v2 = v[j + 2], v3 = v[j + 3];
             a0 += c0 * v0; a1 += c1 * v1; a2 += c2 * v2; a3 += c3 * v3;
             b0 += prev * v0; b1 += c0 * v1; b2 += c1 * v2; b3 += c2 * v3;
             prev = c3;
         }
-        for (; j < nd; ++j) { const double c0 = ca[-j]; a0 += c0 * v[j]; b0 += prev * v[j]; prev = c0; }
+        for (; j < jhi; ++j) { const double c0 = ca[-j]; a0 += c0 * v[j]; b0 += prev * v[j]; prev = c0; }
         out[ia] = (a0 + a1) + (a2 + a3);
         if (hb) out[ia + 1] = (b0 + b1) + (b2 + b3);
     }
@@ -680,13 +688,20 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                 const double xia = xd[ia], xra = reff * xia;                 // rho_k_eff * x_i (1 under eff_hp, qphb.py:747-750)
                 const double xib = hb ? xd[ib] : 0.0, xrb = reff * xib;
                 const double* cka = ck + ia;
+                // (columns beyond the reach of the penalty matrices hold exact zeros in ck and c1: see toeplitz_matvec)
+                int jlo = 0, jhi = nd;
+                if (st.toep_reach >= 0) {
+                    jlo = ia - st.toep_reach > 0 ? (ia - st.toep_reach) & ~3 : 0;
+                    const int e_ = (ia + 2 + st.toep_reach + 3) & ~3;
+                    jhi = e_ < nd ? e_ : nd;
+                }
                 if (use_g) {
                     const double xhsa = xh[ia] / sig2, xhsb = hb ? xh[ib] / sig2 : 0.0;
                     const double* c1a = c1 + ia;
                     double sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0, ma0 = 0.0, mb0 = 0.0;
-                    double pk = hb ? cka[1] : cka[0], p1 = hb ? c1a[1] : c1a[0];
-                    int j = 0;
-                    for (; j + 1 < nd; j += 2) {
+                    double pk = hb ? cka[1 - jlo] : cka[-jlo], p1 = hb ? c1a[1 - jlo] : c1a[-jlo];
+                    int j = jlo;
+                    for (; j + 1 < jhi; j += 2) {
                         const double k0 = cka[-j], k1 = cka[-j - 1], q0 = c1a[-j], q1 = c1a[-j - 1];
                         const double v0 = vs[j], v1 = vs[j + 1], h0 = vh[j], h1 = vh[j + 1];
                         const double ga0 = xra * (k0 * v0) + xhsa * (q0 * h0);
@@ -698,7 +713,7 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                         ma0 = fmax(ma0, fmax(fabs(ga0), fabs(ga1)));
                         mb0 = fmax(mb0, fmax(fabs(gb0), fabs(gb1)));
                     }
-                    if (j < nd) {
+                    if (j < jhi) {
                         const double ga0 = xra * (cka[-j] * vs[j]) + xhsa * (c1a[-j] * vh[j]);
                         const double gb0 = xrb * (pk * vs[j]) + xhsb * (p1 * vh[j]);
                         sa0 += ga0; ma0 = fmax(ma0, fabs(ga0));
@@ -715,9 +730,9 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                 } else {
                     double sa0 = 0.0, sa1 = 0.0, sa2 = 0.0, sa3 = 0.0, sb0 = 0.0, sb1 = 0.0, sb2 = 0.0, sb3 = 0.0;
                     double ma0 = 0.0, mb0 = 0.0;          // (one running maximum per row: a maximum does not care about the grouping)
-                    double pk = hb ? cka[1] : cka[0];
-                    int j = 0;
-                    for (; j + 3 < nd; j += 4) {
+                    double pk = hb ? cka[1 - jlo] : cka[-jlo];
+                    int j = jlo;
+                    for (; j + 3 < jhi; j += 4) {
                         const double k0 = cka[-j], k1 = cka[-j - 1], k2 = cka[-j - 2], k3 = cka[-j - 3];
                         const double v0 = vs[j], v1 = vs[j + 1], v2 = vs[j + 2], v3 = vs[j + 3];
                         const double ta0 = k0 * v0, ta1 = k1 * v1, ta2 = k2 * v2, ta3 = k3 * v3;
@@ -728,7 +743,7 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
                         ma0 = fmax(ma0, fmax(fmax(fabs(ta0), fabs(ta1)), fmax(fabs(ta2), fabs(ta3))));
                         mb0 = fmax(mb0, fmax(fmax(fabs(tb0), fabs(tb1)), fmax(fabs(tb2), fabs(tb3))));
                     }
-                    for (; j < nd; ++j) {
+                    for (; j < jhi; ++j) {
                         const double k0 = cka[-j];
                         const double ta0 = k0 * vs[j], tb0 = pk * vs[j];
                         pk = k0;
@@ -789,7 +804,7 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
             tmp[i] = sqrt(sh) * xd[i];       // v = S^1/2 x for solve_rho
         }
         __syncthreads();
-        if (tpl) toeplitz_matvec(ctp + k * cw + (nd - 1), nd, tmp, tmp2);
+        if (tpl) toeplitz_matvec(ctp + k * cw + (nd - 1), nd, tmp, tmp2, st.toep_reach);
         else rows_matvec(Mk, st.ldm, nd, nd, tmp, tmp2);
         __syncthreads();
         double part = 0.0;
@@ -822,7 +837,7 @@ __global__ __launch_bounds__(HT, 4) void hyper_kernel(FitState st, int it) {    
     if (it == 0 && !st.continue_mode) {   // xmx_norms frozen after the first iteration (drt1d.py:946-951)
         for (int k = 0; k < 3; ++k) {
             const double* Mk = st.mk[k] + (size_t)ns * st.ldm + ns;
-            if (tpl) toeplitz_matvec(ctp + k * cw + (nd - 1), nd, xd, tmp2);
+            if (tpl) toeplitz_matvec(ctp + k * cw + (nd - 1), nd, xd, tmp2, st.toep_reach);
             else rows_matvec(Mk, st.ldm, nd, nd, xd, tmp2);
             __syncthreads();
             double part = 0.0;

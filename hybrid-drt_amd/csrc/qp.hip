@@ -98,22 +98,27 @@ int qp_profile_read(unsigned long long* out, int n, int reset) {
 // force (B^2 comparisons, B ~ 1e3); ties keep index order, so the permutation is deterministic.
 __global__ __launch_bounds__(256) void lpt_order_kernel(int B, const int* __restrict__ iters,
                                                         const int* __restrict__ active, int* __restrict__ order) {
+    // sixteen threads per problem, each ranking it against a sixteenth of the keys (one thread against all of them took
+    // 30 us per outer iteration on the critical path in front of every coneqp launch)
     extern __shared__ int keys[];
     for (int i = threadIdx.x; i < B; i += blockDim.x) keys[i] = (active && !active[i]) ? -1 : iters[i];
     __syncthreads();
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> 4, part = t & 15;
+    int rank = 0;
+    if (b < B) {
         const int kb = keys[b];
-        int rank = 0;
-        for (int j = 0; j < B; ++j) {
+        for (int j = part; j < B; j += 16) {
             const int kj = keys[j];
             rank += (kj > kb) || (kj == kb && j < b);
         }
-        order[rank] = b;
     }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) rank += __shfl_xor(rank, o, 16);
+    if (b < B && part == 0) order[rank] = b;
 }
 
 void launch_lpt_order(hipStream_t st, int B, const int* iters, const int* active, int* order) {
-    const int blocks = (B + 255) / 256;
+    const int blocks = (B * 16 + 255) / 256;
     hipLaunchKernelGGL(lpt_order_kernel, dim3(blocks), dim3(256), (size_t)B * sizeof(int), st, B, iters, active, order);
 }
 

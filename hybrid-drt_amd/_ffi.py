@@ -93,6 +93,7 @@ SIGNATURES = {
     "hipdrt_qp_profile": [_vp, C.POINTER(C.c_ulonglong), C.c_int, C.c_int],
     "hipdrt_debug_qp_occupancy": [_vp, C.c_int, C.c_int],
     "hipdrt_debug_qp_group": [_vp, C.c_int],
+    "hipdrt_debug_exact_zero_shortcuts": [_vp, C.c_int],
     "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -370,6 +371,11 @@ class Context:
         """tests / diagnostics: force the workgroups per problem of this context's coneqp launches sized from now on
         (hipdrt_debug_qp_group, include/hipdrt_debug.h)"""
         _check(self._lib.hipdrt_debug_qp_group(self._h, int(members)))
+
+    def debug_exact_zero_shortcuts(self, on):
+        """tests: with on = False this context's fits visit the penalty matrices' exact zeros as well (same bits, slower)
+        (hipdrt_debug_exact_zero_shortcuts, include/hipdrt_debug.h)"""
+        _check(self._lib.hipdrt_debug_exact_zero_shortcuts(self._h, int(bool(on))))
 
     def qp_profile(self, reset=True):
         buf = (C.c_ulonglong * 64)()        # 0..47 the QP kernel's phases, 48..63 hyper_kernel's (PROFILE=1 builds)

@@ -80,7 +80,7 @@ struct hipdrt_plan {
     FitState state() const {
         FitState st{};
         st.nf = nf; st.m = m; st.n = n; st.ns = ns; st.ldrm = ldrm; st.ldm = ldm; st.toeplitz_m = toeplitz_m;
-        st.toep_reach = toeplitz_m ? toep_maxd : -1;
+        st.toep_reach = (toeplitz_m && !(ctx && !ctx->zero_shortcuts)) ? toep_maxd : -1;
         st.opts = opts; st.continue_mode = 0; st.min_iter = 1;
         st.basis_area = prepared ? desc.basis_area : (eps > 0 ? 1.7724538509055159 / eps : 0.0);   // sqrt(pi) / epsilon
         st.prepared = prepared; st.desc = desc; st.rm_stride = rm_stride; st.rm_rw = rm.d();
@@ -525,6 +525,12 @@ int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members) {
     return HIPDRT_OK;
 }
 
+int hipdrt_debug_exact_zero_shortcuts(hipdrt_ctx* ctx, int on) {
+    HIPDRT_REQUIRE(ctx, "NULL pointer");
+    ctx->zero_shortcuts = on ? 1 : 0;
+    return HIPDRT_OK;
+}
+
 int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n) {
     if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return -1;
     return qp_occupancy(threads, n);
@@ -895,7 +901,7 @@ static GramL2 plan_l2(const hipdrt_plan* p, double l2_lambda_0, const double* de
     g.l2 = nullptr; g.ldm = p->ldm; g.ns = p->ns; g.use_rho = 1;
     g.sym = p->prepared ? 0 : p->toeplitz_m;      // caller-supplied matrices are not assumed bitwise symmetric
     g.toep = p->toeplitz_m;                       // log-uniform tau grid (the hyper kernel relies on the same structure)
-    g.toep_maxd = p->toeplitz_m ? p->toep_maxd : -1;
+    g.toep_maxd = (p->toeplitz_m && !(p->ctx && !p->ctx->zero_shortcuts)) ? p->toep_maxd : -1;
     g.spec_zero = p->spec_zero;
     for (int k = 0; k < 3; ++k) { g.mk[k] = p->mk[k].d(); g.dfac[k] = l2_lambda_0 * derivative_weights[k]; }
     g.s = p->s.d(); g.rho = p->rho.d();
@@ -1178,6 +1184,7 @@ static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb)
         HIPDRT_CHECK(hipStreamCreateWithFlags(&sf.ctx.stream, hipStreamNonBlocking));
     }
     sf.ctx.qp_force_group = p->ctx->qp_force_group;
+    sf.ctx.zero_shortcuts = p->ctx->zero_shortcuts;
     v.ctx = &sf.ctx;
     v.nf = p->nf; v.ntau = p->ntau; v.n = p->n; v.m = p->m; v.ns = p->ns; v.ngrid = p->ngrid; v.ny = p->ny; v.mode = p->mode;
     v.toeplitz_a = p->toeplitz_a; v.toeplitz_m = p->toeplitz_m; v.toep_maxd = p->toep_maxd; v.spec_zero = p->spec_zero; v.idx_rinf = p->idx_rinf; v.idx_induc = p->idx_induc;

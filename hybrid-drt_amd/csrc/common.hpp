@@ -84,6 +84,9 @@ struct hipdrt_ctx {
     // hipdrt_debug_qp_group (include/hipdrt_debug.h; tests): workgroups per problem of this context's coneqp launches,
     // -1 = the library chooses
     int qp_force_group = -1;
+    // hipdrt_debug_exact_zero_shortcuts (tests): 0 = the Gram epilogue and the hyper kernel visit the penalty matrices' exact
+    // zeros as well (no reach restriction, no tile skip)
+    int zero_shortcuts = 1;
 };
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ---------------------------------

@@ -26,6 +26,10 @@ int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n);
  * depend on the group size (bit for bit); batch and group kernel differ by rounding (the batch kernel fuses the forward
  * substitution into the factorisation: another summation order), same iteration counts.                                */
 int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members);
+/* diagnostic (tests): on = 0 makes THIS CONTEXT's fits visit the exact zeros of the penalty matrices as well -- the Gram
+ * epilogue adds the L2 part to every tile and the hyper kernel's Toeplitz convolutions run over all columns instead of the
+ * penalties' reach (csrc/gram.hip, csrc/hyper.hip).  The results are the same bits either way; tests/test_gpu_fit.py checks it. */
+int hipdrt_debug_exact_zero_shortcuts(hipdrt_ctx* ctx, int on);
 
 #ifdef __cplusplus
 }

@@ -681,3 +681,26 @@ def test_full_posterior_covariance_matrices():
     bm2 = basis.construct_func_eval_matrix(np.log(c2["tau"]), np.log(sup), 'gaussian', epsilon=big.tau_epsilon, order=0)
     parity("dist_cov_n514", big.estimate_distribution_cov(tau=sup, b=2),
            bm2 @ (np.linalg.inv(P)[2:, 2:] * res["coefficient_scale"][2] ** 2) @ bm2.T, default=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntau,ppd", [(512, 10), (121, 10), (81, 8), (62, 6), (39, 4)])
+def test_exact_zero_shortcuts_do_not_change_a_bit(ntau, ppd):
+    """The Gram epilogue skips tiles beyond the reach of the penalty matrices and the hyper kernel's Toeplitz convolutions run
+    over the reach only (exact zeros add nothing): with the shortcuts switched off for a context (hipdrt_debug_exact_zero_shortcuts)
+    the same spectra give the same bits -- sizes with every remainder of the tau grid modulo four, and grids shorter than the
+    reach."""
+    from hipdrt import synth, _ffi
+    from hipdrt.models import DRT
+    freq = np.logspace(5, -1, 61)
+    tau = np.logspace(-6.5, -6.5 + (ntau - 1) / ppd, ntau)
+    z = synth.zarc2_batch(freq, 6, first_seed=40)
+    res = {}
+    for on in (True, False):
+        ctx = _ffi.Context(0)
+        ctx.debug_exact_zero_shortcuts(on)
+        drt = DRT(fixed_basis_tau=tau, context=ctx)
+        r = drt.fit_eis_batch(freq, z)
+        res[on] = {k: np.array(r[k]) for k in ("x", "weights", "rho", "s_vectors", "outer_iters", "qp_iters_total")}
+    for k in res[True]:
+        np.testing.assert_array_equal(res[True][k], res[False][k], err_msg=k)

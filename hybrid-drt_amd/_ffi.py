@@ -94,6 +94,7 @@ SIGNATURES = {
     "hipdrt_debug_qp_occupancy": [_vp, C.c_int, C.c_int],
     "hipdrt_debug_qp_group": [_vp, C.c_int],
     "hipdrt_debug_exact_zero_shortcuts": [_vp, C.c_int],
+    "hipdrt_debug_qp_waves": [_vp, C.c_int],
     "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -371,6 +372,11 @@ class Context:
         """tests / diagnostics: force the workgroups per problem of this context's coneqp launches sized from now on
         (hipdrt_debug_qp_group, include/hipdrt_debug.h)"""
         _check(self._lib.hipdrt_debug_qp_group(self._h, int(members)))
+
+    def debug_qp_waves(self, waves):
+        """tests / tools: 4 = this context's batch coneqp launches (n <= 528) use the fat four-wavefront kernel, 8 = the
+        eight-wavefront one, -1 = the library's choice (hipdrt_debug_qp_waves, include/hipdrt_debug.h)"""
+        _check(self._lib.hipdrt_debug_qp_waves(self._h, int(waves)))
 
     def debug_exact_zero_shortcuts(self, on):
         """tests: with on = False this context's fits visit the penalty matrices' exact zeros as well (same bits, slower)

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -62,6 +63,7 @@ struct hipdrt_plan {
             G = qp_G;            // (a plan created for few spectra keeps its group layout when it is full)
         }
         qa.G = G; qa.gsync = gsync.i(); qa.l_stride = (long long)qp_scratch_doubles(n, G);
+        qa.waves = ctx ? ctx->qp_waves : -1;
     }
     // history
     int hist_b = -1, hist_cap = 0;
@@ -150,6 +152,10 @@ int hipdrt_create(int device, hipdrt_ctx** out) {
     c->num_cu = prop.multiProcessorCount;
     c->hbm_bytes = prop.totalGlobalMem;
     c->arch = arch.substr(0, arch.find(':'));
+    if (const char* wv = std::getenv("HIPDRT_QP_WAVES")) {        // (tools/: A/B of the two batch coneqp kernels without a code change)
+        const int w = std::atoi(wv);
+        if (w == 4 || w == 8) c->qp_waves = w;
+    }
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; set_error(hipGetErrorString(e)); return HIPDRT_E_HIP; }
     *out = c;
@@ -500,6 +506,7 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     a.x = dx.d(); a.iters = dit.i(); a.pcost = dpc.d(); a.status = dst.i();
     a.active = nullptr; a.iters_accum = nullptr;
     a.G = G;
+    a.waves = ctx->qp_waves;
     if (G >= 1) {
         HIPDRT_CHECK(dgs.alloc((size_t)B * qp_gsync_ints() * sizeof(int)));
         a.gsync = dgs.i();
@@ -522,6 +529,13 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
 int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members) {
     HIPDRT_REQUIRE(ctx, "NULL pointer");
     ctx->qp_force_group = members;
+    return HIPDRT_OK;
+}
+
+int hipdrt_debug_qp_waves(hipdrt_ctx* ctx, int waves) {
+    HIPDRT_REQUIRE(ctx, "NULL pointer");
+    HIPDRT_REQUIRE(waves == -1 || waves == 4 || waves == 8, "waves: 4, 8 or -1");
+    ctx->qp_waves = waves;
     return HIPDRT_OK;
 }
 
@@ -1185,6 +1199,7 @@ static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb)
     }
     sf.ctx.qp_force_group = p->ctx->qp_force_group;
     sf.ctx.zero_shortcuts = p->ctx->zero_shortcuts;
+    sf.ctx.qp_waves = p->ctx->qp_waves;
     v.ctx = &sf.ctx;
     v.nf = p->nf; v.ntau = p->ntau; v.n = p->n; v.m = p->m; v.ns = p->ns; v.ngrid = p->ngrid; v.ny = p->ny; v.mode = p->mode;
     v.toeplitz_a = p->toeplitz_a; v.toeplitz_m = p->toeplitz_m; v.toep_maxd = p->toep_maxd; v.spec_zero = p->spec_zero; v.idx_rinf = p->idx_rinf; v.idx_induc = p->idx_induc;

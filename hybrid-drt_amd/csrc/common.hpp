@@ -87,6 +87,9 @@ struct hipdrt_ctx {
     // hipdrt_debug_exact_zero_shortcuts (tests): 0 = the Gram epilogue and the hyper kernel visit the penalty matrices' exact
     // zeros as well (no reach restriction, no tile skip)
     int zero_shortcuts = 1;
+    // hipdrt_debug_qp_waves (tests, tools): wavefronts per workgroup of this context's batch coneqp launches at n <= 528 --
+    // 4 = the fat form, 8 = eight wavefronts, -1 = the library chooses.  Initialised from HIPDRT_QP_WAVES when the context is made.
+    int qp_waves = -1;
 };
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ---------------------------------
@@ -257,6 +260,7 @@ struct QpArgs {
     int G = 0;
     int* gsync = nullptr; // [B][qp_gsync_ints()] global sync words of the groups (zeroed by the launcher)
     int redo_aborted = 0; // group kernel: only the problems whose status is HIPDRT_QP_ABORTED (second pass of launch_qp)
+    int waves = 0;        // batch kernel, n <= 528: 4 = the fat form (four wavefronts x 512 registers), anything else = eight wavefronts
 };
 int launch_qp(hipStream_t st, const QpArgs& a);
 // workgroups per problem for a launch of B problems of n unknowns: 0 = batch kernel (one workgroup per problem, n <= 2048),

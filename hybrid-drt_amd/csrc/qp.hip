@@ -126,6 +126,17 @@ static int launch_qp_resident(hipStream_t st, const QpArgs& a) {
     const int NP = round_up(a.n, 32);
     if (!a.Ppk) { set_error("qp resident: packed copy of P missing"); return HIPDRT_E_INVALID; }
     const bool gu = a.n > RNP_MAX;                      // inverse diagonal blocks in global memory: any n <= 2048
+    if (!gu && a.waves == 4) {
+        // the fat form: four wavefronts with 512 registers each (qp_resident.hpp), n <= 528
+        const size_t ldsf = resident_fat_lds_bytes(NP);
+        const void* ff = reinterpret_cast<const void*>(qp_kernel_resident<false, 256, 1, kFatPanel64, 2>);
+        hipError_t ef = hipFuncSetAttribute(ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+        if (ef != hipSuccess) { set_error(std::string("hipFuncSetAttribute(qp fat): ") + hipGetErrorString(ef)); return HIPDRT_E_HIP; }
+        hipLaunchKernelGGL((qp_kernel_resident<false, 256, 1, kFatPanel64, 2>), dim3(a.B), dim3(256), ldsf, st, a, NP);
+        ef = hipGetLastError();
+        if (ef != hipSuccess) { set_error(std::string("qp fat launch: ") + hipGetErrorString(ef)); return HIPDRT_E_HIP; }
+        return HIPDRT_OK;
+    }
     const size_t lds = gu ? resident_gu_lds_bytes(true) : resident_lds_bytes(NP, true);
     const void* fn = gu ? reinterpret_cast<const void*>(qp_kernel_resident<true>) : reinterpret_cast<const void*>(qp_kernel_resident<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -187,52 +187,65 @@ __device__ __forceinline__ double wmax(double v) {
 }
 
 // SLOTS >= 2 result slots used in rotation: a wavefront can be at most one reduction (= one barrier) ahead of the slowest
-// reader of the previous one, so two suffice; the 64-column factorisation's LDS budget has room for exactly two
-template <int NW, int SLOTS = 4>
+// reader of the previous one, so two suffice; the 64-column factorisation's LDS budget has room for exactly two.
+// VT > 1: every physical thread stands for VT virtual ones (thread t, t + 64 NW, ...: the fat four-wavefront kernel runs
+// the interior-point vectors as the eight-wavefront kernel does, two virtual threads each), a physical wavefront w for the
+// virtual wavefronts w, w + NW, ...; partial sums are formed per VIRTUAL thread and combined per virtual wavefront in
+// ascending order, so a reduction returns the same bits whatever the number of physical wavefronts.
+template <int NW, int SLOTS = 4, int VT = 1>
 struct Reducer {
     static_assert(SLOTS == 2 || SLOTS == 4, "");
-    double* buf;   // LDS [SLOTS][NW][4]
+    static constexpr int NWV = NW * VT;
+    double* buf;   // LDS [SLOTS][NWV][4]
     int slot;
     __device__ Reducer(double* b) : buf(b), slot(0) {}
-    // sums up to 4 values at once; every thread gets the totals
+    // sums up to 4 values at once; every thread gets the totals (in v[0])
     template <int N>
-    __device__ __forceinline__ void sum(double (&v)[N]) {
+    __device__ __forceinline__ void sum(double (&v)[VT][N]) {
         static_assert(N <= 4, "");
-        double* s = buf + (slot & (SLOTS - 1)) * NW * 4;
+        double* s = buf + (slot & (SLOTS - 1)) * NWV * 4;
         ++slot;
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = wsum(v[i]);
+        for (int t = 0; t < VT; ++t)
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[t][i] = wsum(v[t][i]);
         if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) s[(threadIdx.x >> 6) * 4 + i] = v[i];
+            for (int t = 0; t < VT; ++t)
+#pragma unroll
+                for (int i = 0; i < N; ++i) s[((threadIdx.x >> 6) + NW * t) * 4 + i] = v[t][i];
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             double t = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) t += s[w * 4 + i];
-            v[i] = t;
+            for (int w = 0; w < NWV; ++w) t += s[w * 4 + i];
+            v[0][i] = t;
         }
     }
     template <int N>
-    __device__ __forceinline__ void max(double (&v)[N]) {
+    __device__ __forceinline__ void max(double (&v)[VT][N]) {
         static_assert(N <= 4, "");
-        double* s = buf + (slot & (SLOTS - 1)) * NW * 4;
+        double* s = buf + (slot & (SLOTS - 1)) * NWV * 4;
         ++slot;
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = wmax(v[i]);
+        for (int t = 0; t < VT; ++t)
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[t][i] = wmax(v[t][i]);
         if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) s[(threadIdx.x >> 6) * 4 + i] = v[i];
+            for (int t = 0; t < VT; ++t)
+#pragma unroll
+                for (int i = 0; i < N; ++i) s[((threadIdx.x >> 6) + NW * t) * 4 + i] = v[t][i];
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             double t = s[i];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) t = fmax(t, s[w * 4 + i]);
-            v[i] = t;
+            for (int w = 1; w < NWV; ++w) t = fmax(t, s[w * 4 + i]);
+            v[0][i] = t;
         }
     }
 };
@@ -248,7 +261,10 @@ struct IpmSmem {
 // ---------------------------------------------------------------------------------------------------------
 // The interior-point iteration.  O(n) vectors live in registers, element i owned by thread i % THREADS.
 // ---------------------------------------------------------------------------------------------------------
-template <int THREADS, int EPT, class Ops>
+// VT = virtual threads per physical thread (Reducer above): EPT is then the element count of a VIRTUAL thread, element i is
+// owned by virtual thread i % (THREADS VT) = physical thread i % THREADS, and per-thread partial sums run over a virtual
+// thread's elements -- the reductions, hence the whole trajectory, are bit for bit those of a THREADS VT-thread workgroup.
+template <int THREADS, int EPT, class Ops, int VT = 1>
 __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, const IpmSmem& sm, int slot = -1,
                                           bool leader = true) {
     // slot / leader: several workgroups may run the same problem redundantly (qp.hip, workgroup groups); each then keeps
@@ -263,7 +279,7 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                                            // 64-bit address registers kept alive across the whole kernel
     const double* qg = a.q + (size_t)b * n;
     const double* hg = a.h + (size_t)b * a.h_stride;
-    Reducer<NW, Ops::kRedSlots> red(sm.red);
+    Reducer<NW, Ops::kRedSlots, VT> red(sm.red);
     // P x is normally not formed by a pass over P: every step direction solves (P + D) dx = r to the backward error of
     // the Cholesky solve, so P dx = r - D dx and P x follows the iterate by an O(n) recurrence (start point:
     // (P + I) x0 = -q - h).  The recurrence carries rounding errors of size eps |P| |step dx| along, a direct product
@@ -292,17 +308,16 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     double* const rx = SV(8); double* const rz = SV(9); double* const dx = SV(10); double* const ds = SV(11);
     double* const dz = SV(12); double* const ws3 = SV(13); double* const zz = SV(14); double* const sv = SV(15);
     double* const px = SV(16);      // P x, carried along by the recurrence below
-#define FOR_E for (unsigned e_ = 0, i = opaque_u32(tid); e_ < (unsigned)EPT; ++e_, i += THREADS)
+#define FOR_E _Pragma("unroll") for (unsigned v_ = 0; v_ < (unsigned)VT; ++v_) \
+        _Pragma("unroll EUNR") for (unsigned e_ = 0, i = opaque_u32(tid) + v_ * THREADS; e_ < (unsigned)EPT; ++e_, i += THREADS * VT)
 #define VALID (i < (unsigned)n)
-#pragma unroll EUNR
     FOR_E if (VALID) { qv[i] = qg[i]; hv[i] = hg[i]; x[i] = z[i] = 0.0; s[i] = lm[i] = 1.0; d[i] = di[i] = 1.0; }
 
-    double nq[2] = {0.0, 0.0};
-#pragma unroll EUNR
-    FOR_E if (VALID) { nq[0] += qv[i] * qv[i]; nq[1] += hv[i] * hv[i]; }
+    double nq[VT][2] = {};
+    FOR_E if (VALID) { nq[v_][0] += qv[i] * qv[i]; nq[v_][1] += hv[i] * hv[i]; }
     red.sum(nq);
-    const double resx0 = uni(fmax(1.0, sqrt(nq[0])));
-    const double resz0 = uni(fmax(1.0, sqrt(nq[1])));
+    const double resx0 = uni(fmax(1.0, sqrt(nq[0][0])));
+    const double resz0 = uni(fmax(1.0, sqrt(nq[0][1])));
 
     PROF_DECL
 #ifdef HIPDRT_QP_PROFILE
@@ -320,7 +335,6 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             const bool direct = !kRecurPx || refresh;       // this pass's P x is a direct product
             if (direct) {
                 __syncthreads();
-#pragma unroll EUNR
                 FOR_E if (VALID) sm.vec[i] = x[i];
                 __syncthreads();
                 { PROF_DECL
@@ -328,7 +342,6 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 __syncthreads();
                 PROF(9); }
                 if (kRecurPx) {
-#pragma unroll EUNR
                     FOR_E if (VALID) px[i] = sm.dvec[i];
                     refresh = false;
                     canc = 0.0;
@@ -336,29 +349,28 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             }
             // (the element loops read everything they need first and store last: the state vectors are slices of one
             // buffer, so a store in between would order every later load behind it -- one L2 round trip per statement)
-            double t4[4] = {0.0, 0.0, 0.0, 0.0}, zr[1] = {0.0};
-#pragma unroll EUNR
+            double t4[VT][4] = {}, zr[VT][1] = {};
             FOR_E {
                 if (VALID) {
                     const double px_ = kRecurPx ? px[i] : sm.dvec[i], q_ = qv[i], x_ = x[i], z_ = z[i], s_ = s[i], h_ = hv[i];
                     double r = px_ + q_;                    // P x + q
-                    t4[0] += x_ * r;                        // x'(Px+q)
-                    t4[1] += x_ * q_;                       // x'q
+                    t4[v_][0] += x_ * r;                      // x'(Px+q)
+                    t4[v_][1] += x_ * q_;                      // x'q
                     r -= z_;                                // + G'z
-                    t4[2] += r * r;
+                    t4[v_][2] += r * r;
                     const double rzz = s_ - h_ - x_;        // s + Gx - h
-                    t4[3] += rzz * rzz;
-                    zr[0] += z_ * rzz;
+                    t4[v_][3] += rzz * rzz;
+                    zr[v_][0] += z_ * rzz;
                     rx[i] = r;
                     rz[i] = rzz;
                 }
             }
             red.sum(t4);
             red.sum(zr);
-            const double f0 = 0.5 * (t4[0] + t4[1]);
-            const double resx = sqrt(t4[2]), resz = sqrt(t4[3]);
+            const double f0 = 0.5 * (t4[0][0] + t4[0][1]);
+            const double resx = sqrt(t4[0][2]), resz = sqrt(t4[0][3]);
             pcost = uni(f0);
-            const double dcost = f0 + zr[0] - gap;
+            const double dcost = f0 + zr[0][0] - gap;
             bool has_rel = false;
             double relgap = 0.0;
             if (pcost < 0.0) { relgap = gap / -pcost; has_rel = true; }
@@ -381,7 +393,6 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             if (conv) { status = HIPDRT_QP_OPTIMAL; break; }
             if (iters == a.opts.maxiters) { status = HIPDRT_QP_MAXITER; break; }
             if (iters == 0) {
-#pragma unroll EUNR
                 FOR_E if (VALID) { const double s_ = s[i], z_ = z[i], d_ = sqrt(s_ / z_); d[i] = d_; di[i] = 1.0 / d_; lm[i] = sqrt(s_ * z_); }
             }
         }
@@ -391,7 +402,6 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
         const int nsolve = start ? 1 : 2;
         // right-hand side of KKT solve pc (sigma = 0 for the predictor, so its rhs is known before the factorisation)
         auto set_rhs = [&](int pc) {
-#pragma unroll EUNR
             FOR_E {
                 if (VALID) {
                     if (start) {
@@ -411,7 +421,6 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             }
         };
         __syncthreads();
-#pragma unroll EUNR
         FOR_E if (VALID) sm.dvec[i] = di[i] * di[i];
         if (Ops::kFusedForward) set_rhs(0);     // the factorisation also forward-substitutes the first rhs
         __syncthreads();
@@ -430,14 +439,14 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 ops.solve();
             }
             if (start) {
-                double st[2] = {0.0, 0.0}, mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll EUNR
+                double st[VT][2] = {}, mx[VT][2];
+                for (int t_ = 0; t_ < VT; ++t_) mx[t_][0] = mx[t_][1] = -INFINITY;
                 FOR_E {
                     if (VALID) {
                         const double x_ = sm.vec[i], q_ = qv[i], h_ = hv[i];
                         const double z_ = -x_ - h_, s_ = -z_;
-                        st[0] += s_ * s_; st[1] += z_ * z_;
-                        mx[0] = fmax(mx[0], -s_); mx[1] = fmax(mx[1], -z_);
+                        st[v_][0] += s_ * s_; st[v_][1] += z_ * z_;
+                        mx[v_][0] = fmax(mx[v_][0], -s_); mx[v_][1] = fmax(mx[v_][1], -z_);
                         x[i] = x_;
                         if (kRecurPx) px[i] = (-q_ - h_) - x_;           // (P + I) x = -q - h
                         z[i] = z_;
@@ -447,41 +456,37 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 red.sum(st);
                 red.max(mx);
                 if (kRecurPx) {
-                    double mm[2] = {0.0, 0.0};
-#pragma unroll EUNR
-                    FOR_E if (VALID) { const double ax = fabs(x[i]); mm[0] = fmax(mm[0], ax); mm[1] = fmax(mm[1], fabs(qv[i] + hv[i]) + ax); }
+                    double mm[VT][2] = {};
+                    FOR_E if (VALID) { const double ax = fabs(x[i]); mm[v_][0] = fmax(mm[v_][0], ax); mm[v_][1] = fmax(mm[v_][1], fabs(qv[i] + hv[i]) + ax); }
                     red.max(mm);
-                    drift = uni(mm[0]);
-                    canc = uni(mm[1]);
+                    drift = uni(mm[0][0]);
+                    canc = uni(mm[0][1]);
                 }
-                const double nrms = sqrt(st[0]), nrmz = sqrt(st[1]);
-                if (mx[0] >= -1e-8 * fmax(nrms, 1.0)) {
-#pragma unroll EUNR
-                    FOR_E if (VALID) s[i] += 1.0 + mx[0];
+                const double nrms = sqrt(st[0][0]), nrmz = sqrt(st[0][1]);
+                if (mx[0][0] >= -1e-8 * fmax(nrms, 1.0)) {
+                    FOR_E if (VALID) s[i] += 1.0 + mx[0][0];
                 }
-                if (mx[1] >= -1e-8 * fmax(nrmz, 1.0)) {
-#pragma unroll EUNR
-                    FOR_E if (VALID) z[i] += 1.0 + mx[1];
+                if (mx[0][1] >= -1e-8 * fmax(nrmz, 1.0)) {
+                    FOR_E if (VALID) z[i] += 1.0 + mx[0][1];
                 }
-                double gp[1] = {0.0};
-#pragma unroll EUNR
-                FOR_E if (VALID) gp[0] += s[i] * z[i];
+                double gp[VT][1] = {};
+                FOR_E if (VALID) gp[v_][0] += s[i] * z[i];
                 red.sum(gp);
-                gap = uni(gp[0]);
+                gap = uni(gp[0][0]);
             } else {
-                double dd[1] = {0.0}, mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll EUNR
+                double dd[VT][1] = {}, mx[VT][2];
+                for (int t_ = 0; t_ < VT; ++t_) mx[t_][0] = mx[t_][1] = -INFINITY;
                 FOR_E {
                     if (VALID) {
                         const double dx_ = sm.vec[i], di_ = di[i], zz_ = zz[i], sv_ = sv[i], lm_ = lm[i];
                         double dz_ = -di_ * dx_ - zz_;
                         double ds_ = sv_ - dz_;
                         const double w3 = ds_ * dz_;
-                        dd[0] += w3;
+                        dd[v_][0] += w3;
                         ds_ /= lm_;
                         dz_ /= lm_;
-                        mx[0] = fmax(mx[0], -ds_);
-                        mx[1] = fmax(mx[1], -dz_);
+                        mx[v_][0] = fmax(mx[v_][0], -ds_);
+                        mx[v_][1] = fmax(mx[v_][1], -dz_);
                         dx[i] = dx_;
                         if (pc == 0) ws3[i] = w3;
                         ds[i] = ds_;
@@ -490,20 +495,19 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                 }
                 red.sum(dd);
                 red.max(mx);
-                const double t = fmax(0.0, fmax(mx[0], mx[1]));
+                const double t = fmax(0.0, fmax(mx[0][0], mx[0][1]));
                 if (t == 0.0) step = 1.0;
                 else if (pc == 0) step = uni(fmin(1.0, 1.0 / t));
                 else step = uni(fmin(1.0, 0.99 / t));
                 if (pc == 0) {
-                    const double sg = fmin(1.0, fmax(0.0, 1.0 - step + dd[0] / gap * (step * step)));
+                    const double sg = fmin(1.0, fmax(0.0, 1.0 - step + dd[0][0] / gap * (step * step)));
                     sigma = uni(sg * sg * sg);
                 }
             }
         }
         if (start) { start = false; continue; }
         // ---- update ---------------------------------------------------------------------------------------
-        double g2[1] = {0.0}, mm[3] = {0.0, 0.0, 0.0};
-#pragma unroll EUNR
+        double g2[VT][1] = {}, mm[VT][3] = {};
         FOR_E {
             if (VALID) {
                 const double dx_ = dx[i], ds_ = ds[i], dz_ = dz[i], lm_ = lm[i], d_ = d[i], x_ = x[i];
@@ -512,18 +516,18 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
                     const double rx_ = rx[i], di_ = di[i], zz_ = zz[i];
                     const double r_ = -rx_ - di_ * zz_, t_ = (di_ * di_) * dx_;
                     px_ = px[i] + step * (r_ - t_);
-                    mm[0] = fmax(mm[0], fabs(step * dx_));
-                    mm[2] = fmax(mm[2], step * (fabs(r_) + fabs(t_)));
+                    mm[v_][0] = fmax(mm[v_][0], fabs(step * dx_));
+                    mm[v_][2] = fmax(mm[v_][2], step * (fabs(r_) + fabs(t_)));
                 }
                 const double xn = x_ + step * dx_;
-                mm[1] = fmax(mm[1], fabs(xn));
+                mm[v_][1] = fmax(mm[v_][1], fabs(xn));
                 const double dss = (1.0 + step * ds_) * lm_;
                 const double dzz = (1.0 + step * dz_) * lm_;
                 const double sqs = sqrt(dss), sqz = sqrt(dzz);
                 const double dn = d_ * sqs / sqz;
                 const double din = 1.0 / dn;
                 const double lmn = sqs * sqz;
-                g2[0] += lmn * lmn;
+                g2[v_][0] += lmn * lmn;
                 if (kRecurPx) px[i] = px_;
                 x[i] = xn;
                 d[i] = dn;
@@ -534,12 +538,12 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
             }
         }
         red.sum(g2);
-        gap = uni(g2[0]);
+        gap = uni(g2[0][0]);
         if (kRecurPx) {
             red.max(mm);
-            drift = uni(drift + mm[0]);
-            canc = uni(canc + mm[2]);
-            if (drift > kDriftTol * mm[1]) { refresh = true; drift = uni(mm[1]); }
+            drift = uni(drift + mm[0][0]);
+            canc = uni(canc + mm[0][2]);
+            if (drift > kDriftTol * mm[0][1]) { refresh = true; drift = uni(mm[0][1]); }
         }
         ++iters;
     }
@@ -549,7 +553,6 @@ __device__ __forceinline__ void ipm_solve(const QpArgs& a, int b, Ops& ops, cons
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_qp_prof[13], __builtin_amdgcn_s_memrealtime() - _rt0);
 #endif
     if (leader) {
-#pragma unroll EUNR
         FOR_E if (VALID) a.x[(size_t)b * n + i] = x[i];
     }
     if (tid == 0 && leader) {

@@ -62,7 +62,8 @@ static constexpr int DLD = 17;           // row stride of the 16x16 LDS scratch 
 // P64 = LDS layout of the 64-column factorisation (factor64, the QP kernel with 8 wavefronts): L21 of BOTH 32-blocks of a super
 // column in operand-fragment layout (t21: [2][4][64]), two reduction slots instead of four, dvec without the 32 padding
 // entries, a schedule table per super column -- at n = 514 the workgroup's 160 KB are used to the last 32 bytes.
-template <bool GU, int RTT = 512, bool P64 = false>
+// VT = virtual threads per thread of the interior-point driver (qp_common.hpp: Reducer): the reduction slots are per VIRTUAL wavefront
+template <bool GU, int RTT = 512, bool P64 = false, int VT = 1>
 struct ResSmemT {
     double* U;       // [NP][PLD]   inverse diagonal blocks (LDS, or global when GU)
     double* vec;     // [NP + 32]
@@ -82,7 +83,7 @@ struct ResSmemT {
     static constexpr int DVEC = P64 ? VEC - 32 : VEC;
     static constexpr int SROW = GU ? 128 : 32;                           // table row: tile rows below a block column (<= 124 | 29)
     static constexpr int SCHED = GU ? 64 * 128 / 8 : (P64 ? 9 * 32 / 8 : 17 * 32 / 8 + 4);    // doubles: nblk <= 64 | 17 (9 super columns) rows of SROW bytes
-    static constexpr int RED = (P64 ? 2 : 4) * (RTT / 64) * 4;
+    static constexpr int RED = (P64 ? 2 : 4) * (RTT / 64) * VT * 4;
     static constexpr int T21 = P64 ? 2 * 256 : 16 * 17;
     static constexpr int FIXED = RED + T21 + 16 * 17 + 8 + 512 + SCHED + VEC + DVEC;   // doubles before U
     __device__ __forceinline__ void carve(double* smem) {
@@ -111,11 +112,12 @@ using ResSmem = ResSmemT<false>;
 // well -- the ~200 spilled registers stayed outside the operand rings -- and measured 14.7 ms per launch against 11.3 for one
 // workgroup per CU in the same U-outside form (10.65 with U in LDS): halving every wavefront's rows per pass, ring depth and
 // sweep buffers costs more than the second workgroup's overlap returns.
-template <bool GU, int RTT = 512, bool P64 = false>
+template <bool GU, int RTT = 512, bool P64 = false, int VT = 1>
 struct OpsResidentT {
     static constexpr int RT = RTT, RNW = RTT / 64;                     // (shadow the namespace-level defaults)
-    static_assert(!P64 || RTT == 512, "factor64 is written for eight wavefronts");
-    using Smem = ResSmemT<GU, RTT, P64>;
+    static_assert(!P64 || RTT == 512 || RTT == 256, "factor64 is written for eight wavefronts, or four fat ones");
+    using Smem = ResSmemT<GU, RTT, P64, VT>;
+    static constexpr int kVT = VT;
     static constexpr int kRedSlots = P64 ? 2 : 4;
     double* L; int nch; int n; Smem sm;                                // nch = tiles per tile-row (NP/16)
     const double* Ppk; int nchp;                                       // P in L's tile layout (lower tiles)
@@ -323,7 +325,7 @@ struct OpsResidentT {
         if (kq == 0) sm.vec[T * 16 + li] -= p_;
     }
 
-    // s_waitcnt vmcnt(4 k) for a wave-uniform k <= 5: the sweeps leave the k tiles (4 loads each) of the next block in flight
+    // s_waitcnt vmcnt(4 k) for a wave-uniform k <= 7: the sweeps leave the k tiles (4 loads each) of the next block in flight
     static __device__ __forceinline__ void vm_wait_tiles(int k) {
         switch (k) {
             case 0: vm_wait<0>(); break;
@@ -331,7 +333,9 @@ struct OpsResidentT {
             case 2: vm_wait<8>(); break;
             case 3: vm_wait<12>(); break;
             case 4: vm_wait<16>(); break;
-            default: vm_wait<20>(); break;
+            case 5: vm_wait<20>(); break;
+            case 6: vm_wait<24>(); break;
+            default: vm_wait<28>(); break;
         }
     }
 
@@ -854,7 +858,20 @@ struct OpsResidentT {
     // Two barriers per 64 columns instead of six.  Every tile receives exactly the MFMA sequence it receives in factor()
     // (history chunks ascending, x then y half of every half-chunk, the same operand order), so the factor, U and the forward-
     // substituted right-hand side are bit for bit those of the 32-column form (tools/dump_fit.py --cmp).
-    static constexpr int RM = 3;      // tile rows per row wavefront and pass (x 4 tile columns = 12 accumulator tiles)
+    // kFat: the four-wavefront form (one wavefront per SIMD, 512 registers each: 32 accumulator tiles in AccVGPRs).  Wavefront 0
+    // is the chain + look-ahead of block b exactly as with eight wavefronts -- alone on its SIMD, so no row wavefront's MFMA
+    // stream stretches the chains --, wavefront 1 carries tile rows tA+4, tA+5 (11 tiles) plus up to RM1 ordinary rows,
+    // wavefronts 2 and 3 up to RM = 6 rows x 4 columns per pass: from super column 3 on every row is accumulated in ONE pass
+    // (27 / 23 / 19 / 15 tile rows below the look-ahead rows in super columns 0 / 1 / 2 / 3 at n = 514).
+    static constexpr bool kFat = P64 && RNW == 4;
+    // (fat form: 6 rows x 4 columns = 24 of a wavefront's 32 accumulator tiles; the panel solves need two more tiles per row of
+    // a group -- the solved tiles x1, x2 are MFMA results too -- and with 7 rows + groups of 4 = 32 tiles exactly hipcc kept ONE
+    // tile for all of them and moved every intermediate result through VGPRs around every MFMA, 19 wait states each time:
+    // panel solves 2.5 x slower than the matrix pipe, profiles/r06_fat_*)
+    static constexpr int RM = kFat ? 6 : 3;      // tile rows per row wavefront and pass (x 4 tile columns of accumulator tiles)
+    static constexpr int RM1 = 3;                // fat form: ordinary rows of wavefront 1, next to its 11 look-ahead tiles (one pass)
+    static constexpr int PG = 3;                 // panel solves in groups of at most PG rows
+    static constexpr int NARR = RNW - 1;         // wavefronts that count themselves into flag[3] per super column (all but wavefront 0)
     __device__ __forceinline__ void build_schedule64() {
         const int ntr = (n + 15) >> 4, nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
         constexpr int SROW = Smem::SROW;
@@ -862,6 +879,31 @@ struct OpsResidentT {
             const int tA = 4 * J, nk2 = 8 * J;
             const int nsq = ntr - (tA + 6) > 0 ? ntr - (tA + 6) : 0;
             const int c = 8 * nk2 + 40;                               // MFMAs of one row: history + two panel solves + block a's update
+            if constexpr (kFat) {
+                // one wavefront per SIMD: wavefront 1 starts with its look-ahead tiles' MFMAs and takes at most RM1 rows,
+                // wavefronts 2 and 3 share the rest (as many passes of RM rows as that takes)
+                const int rest = nsq > RM1 ? nsq - RM1 : 0;
+                const int cap = RM * (rest > 2 * RM ? (rest + 2 * RM - 1) / (2 * RM) : 1);
+                int l1 = (tA + 4 < ntr) ? kLa2Load * nk2 + 96 : 0, l2 = 0, l3 = 0;
+                int c1 = 0, c2 = 0, c3 = 0;
+                for (int r = 0; r < nsq; ++r) {
+                    int best = -1, bl = 0x7fffffff;
+                    if (J & 1) {                                      // (ties: the odd row of a super column goes to 2 and 3 in turn)
+                        if (c3 < cap && l3 < bl) { best = 3; bl = l3; }
+                        if (c2 < cap && l2 < bl) { best = 2; bl = l2; }
+                    } else {
+                        if (c2 < cap && l2 < bl) { best = 2; bl = l2; }
+                        if (c3 < cap && l3 < bl) { best = 3; bl = l3; }
+                    }
+                    if (c1 < RM1 && l1 < bl) { best = 1; bl = l1; }
+                    if (best < 0) best = c2 <= c3 ? 2 : 3;            // (cannot happen: the caps cover nsq)
+                    sm.sched[J * SROW + r] = (unsigned char)best;
+                    if (best == 1) { ++c1; l1 += c; }
+                    else if (best == 2) { ++c2; l2 += c; }
+                    else { ++c3; l3 += c; }
+                }
+                continue;
+            }
             const int cap = RM * (nsq > 6 * RM ? (nsq + 6 * RM - 1) / (6 * RM) : 1);
             // SIMD 0 carries wavefront 0 (two chains + 14 MFMAs per half-chunk), SIMD 1 wavefront 1 (22 per half-chunk)
             int l0 = (tA + 2 < ntr) ? kLa1Load * nk2 + 48 : 0;
@@ -914,12 +956,25 @@ struct OpsResidentT {
     // first load from the 64 columns just solved.  No s_barrier: who finishes its panel solves early is not held up by who
     // finishes late, and the phases of the wavefronts on one SIMD drift apart (one in its MFMA-bound history pass, the other
     // in its latency-bound panel solves) instead of coinciding.
+    // (A) of the fat form is not a barrier either: the row wavefronts need wavefront 0's W / L21 (LDS) and solved look-ahead tiles
+    // (global memory), nothing from each other, and wavefront 0 needs nothing from anybody -- it publishes super column J in
+    // flag[1] (release, as arrive_b) and goes on to W21 / y and the next look-ahead while the rows are still in their history
+    __device__ __forceinline__ void publish_a(int J_, int lane) {
+        if (lane == 0) __hip_atomic_store(&sm.flag[1], J_ + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void wait_a(int J_) const {
+        int spins = 0;
+        while (lds_peek32(&sm.flag[1]) < J_ + 1) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) __builtin_trap();
+        }
+    }
     __device__ __forceinline__ void arrive_b(int lane) {
         if (lane == 0) __hip_atomic_fetch_add(&sm.flag[3], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ __forceinline__ void wait_b(int J_) const {        // everybody's tiles of super column J_ are stored
         int spins = 0;
-        while (lds_peek32(&sm.flag[3]) < 7 * (J_ + 1)) {
+        while (lds_peek32(&sm.flag[3]) < NARR * (J_ + 1)) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 22)) __builtin_trap();           // (a protocol error must not hang the device)
         }
@@ -1174,7 +1229,12 @@ struct OpsResidentT {
             }
             if (lane == 0) sm.flag[0] = ok ? 0 : 1;
             TL(0, J, 1);
-            __syncthreads();                                    // (A)
+            if constexpr (kFat) {
+                publish_a(J, lane);
+                if (!ok) return false;
+            } else {
+                __syncthreads();                                // (A)
+            }
             TL(0, J, 2);
             PROF(1);
 #ifdef HIPDRT_QP_PROFILE
@@ -1218,7 +1278,7 @@ struct OpsResidentT {
                 la_done = 0;
                 const int kend = 8 * J;          // columns < 4 J are final; this super column's own 64 columns are being solved now
                 while (la_done < kend) {
-                    la_done = la1_ring(J + 1, la_done, kend, !at_b, 7 * (J + 1));
+                    la_done = la1_ring(J + 1, la_done, kend, !at_b, NARR * (J + 1));
                     if (la_done < kend && !at_b) {
                         at_b = true;
                         HIPDRT_PROF_ARRIVED();
@@ -1277,6 +1337,15 @@ struct OpsResidentT {
                     f21 = init_tile(Q3, Q2, ntr, fo, li, kq);
                     f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
                 }
+                // fat form: this wavefront's ordinary rows (at most RM1, one pass), accumulated behind the look-ahead tiles
+                RowSet<RM1> xr;
+                v4d xacc[RM1][4];
+                if constexpr (kFat) {
+                    unsigned long long m0, m1;
+                    my_rows(J, 1, lane, ntr, m0, m1);
+                    rows_next(xr, m0, m1, tA);
+                    rows_init(xacc, xr, tA, ntr, fo, li, kq);
+                }
                 if (J > 0) {
                     const char* qb[4];
 #pragma unroll
@@ -1331,9 +1400,12 @@ struct OpsResidentT {
                         ca[1][0] = (v4d){0, 0, 0, 0}; ca[1][1] = ca[1][0]; cb[1][0] = ca[1][0]; cb[1][1] = ca[1][0]; f21 = ca[1][0];
                         f22 = init_tile(Q3, Q3, ntr, fo, li, kq);
                     }
+                    if constexpr (kFat) {
+                        if (xr.act[0]) rows_ring(xacc, xr, J, tA, fo, true);     // (the ring above has waited for super column J - 1)
+                    }
                 }
                 TL(1, J, 1);
-                __syncthreads();                                // (A)
+                if constexpr (kFat) wait_a(J); else __syncthreads();      // (A)
                 TL(1, J, 2);
                 if (sm.flag[0]) return false;
                 have_pre = false;
@@ -1414,6 +1486,7 @@ struct OpsResidentT {
                 wait_y(2 * J + 2);
                 fwd_update(xb[0][0], xb[0][1], Q2, j0b, li, kq);
                 if (v3) fwd_update(xb[1][0], xb[1][1], Q3, j0b, li, kq);
+                if constexpr (kFat) rows_panel(xacc, xr, J, lane, li, kq, fo);
                 {
                     // (unconditional, stand-in tile (0, 0) when there are no such rows: see wavefront 0)
                     have_pre = Q2 + 4 < ntr;
@@ -1424,7 +1497,7 @@ struct OpsResidentT {
                     pre[10] = tile_src(N3, N3, ntr, fo);
                 }
             } else {
-                __syncthreads();                                // (A)
+                if constexpr (kFat) wait_a(J); else __syncthreads();      // (A)
                 if (sm.flag[0]) return false;
             }
             TL(1, J, 3);
@@ -1433,203 +1506,231 @@ struct OpsResidentT {
         return true;
     }
 
-    // ======== wavefronts 2..7: tile rows tA+6 .. over all four columns ===================================================
+    // ======== ordinary rows: tile rows tA+6 .. over all four columns =====================================================
+    // The pieces of a row wavefront's super column, over R rows x 4 columns of accumulator tiles (R = RM; fat form: also RM1,
+    // wavefront 1's rows): who owns what, source tiles, the history ring, the panel solves in groups of at most PG rows.
+    template <int R> struct RowSet { int T[R]; bool act[R]; };
+    // the rows of super column J_ owned by wavefront wv: bit r of (m0, m1) = tile row 4 J_ + 6 + r
+    __device__ __forceinline__ void my_rows(int J_, int wv, int lane, int ntr, unsigned long long& m0, unsigned long long& m1) const {
+        constexpr int SROW = Smem::SROW;
+        const int nsq_ = ntr - (4 * J_ + 6) > 0 ? ntr - (4 * J_ + 6) : 0;
+        const unsigned char* row = sm.sched + J_ * SROW;
+        m0 = __ballot(lane < nsq_ && row[lane] == wv);
+        m1 = 0;
+        if (SROW > 64) m1 = __ballot(lane + 64 < nsq_ && row[lane + 64] == wv);
+    }
+    template <int R>
+    __device__ __forceinline__ void rows_next(RowSet<R>& rs, unsigned long long& m0, unsigned long long& m1, int tA) const {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            int r = -1;
+            if (m0) { r = __builtin_ctzll(m0); m0 &= m0 - 1; }
+            else if (m1) { r = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+            rs.T[u] = r >= 0 ? tA + 6 + r : nch;
+            rs.act[u] = r >= 0;
+        }
+    }
+    template <int R>
+    __device__ __forceinline__ void rows_init(v4d (&acc)[R][4], const RowSet<R>& rs, int tA, int ntr, int fo, int li, int kq) const {
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[u][c] = rs.act[u] ? init_tile(rs.T[u], tA + c, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+    }
+    // operand ring as in factor_rows(): A tiles (own rows, HBM) three half-chunks ahead, B tiles (tile rows tA .. tA+3, shared by
+    // all wavefronts: L1 / L2) one ahead; per step 4 B + R A loads, B first.  `arrived`: everybody's tiles of super column J - 1
+    // are known to be stored (a later pass, or a caller that has waited already); otherwise wait_b in front of the first load
+    // from those 64 columns.
+    template <int R>
+    __device__ __forceinline__ void rows_ring(v4d (&acc)[R][4], const RowSet<R>& rs, int J, int tA, int fo, bool arrived) const {
+        const char* rb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rb[c] = uniform_ptr(tile2(tA + c, 0));
+        const char* ra[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) ra[u] = uniform_ptr(tile2(rs.act[u] ? rs.T[u] : tA, 0));
+        const unsigned voff = (unsigned)fo * 16u;
+        struct SlA { v2d a[R]; };
+        struct SlB { v2d b[4]; };
+        const int nk2 = 8 * J, klast = nk2 - 1;
+        auto loadA = [&](SlA& s_, int k2) {
+            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+#pragma unroll
+            for (int u = 0; u < R; ++u) s_.a[u] = gload16(ra[u] + o, voff);
+        };
+        auto loadB = [&](SlB& s_, int k2) {
+            const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_.b[c] = gload16(rb[c] + o, voff);
+        };
+        auto mult = [&](const SlA& a_, const SlB& b_) {
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (rs.act[u]) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b[c].x, a_.a[u].x, acc[u][c], 0, 0, 0);
+                }
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (rs.act[u]) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b[c].y, a_.a[u].y, acc[u][c], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
+        __builtin_amdgcn_sched_barrier(0);
+        const int knew = nk2 - 8;                   // first half-chunk of the 64 columns solved in super column J - 1
+        if (!arrived && knew <= 2) { wait_b(J - 1); arrived = true; }
+        if constexpr (kFat) {
+            // one wavefront per SIMD: nobody covers for a late operand, and the shared B rows come from as far away as the A
+            // rows (32 problems' factors per XCD do not fit its L2) -- A and B both two half-chunks ahead (a half-chunk is
+            // 8 R MFMAs = 3.6 k cycles at R = 7), three buffers each, three half-chunks per trip
+            SlA a0, a1, a2;
+            SlB b0, b1, b2;
+            loadB(b0, 0); loadA(a0, 0); loadB(b1, 1); loadA(a1, 1);
+            for (int k2 = 0; k2 < nk2; k2 += 3) {
+                if (!arrived && k2 + 4 >= knew) { wait_b(J - 1); arrived = true; }
+                loadB(b2, k2 + 2); loadA(a2, k2 + 2); vm_wait<2 * (R + 4)>(); mult(a0, b0);
+                loadB(b0, k2 + 3); loadA(a0, k2 + 3); vm_wait<2 * (R + 4)>(); if (k2 + 1 < nk2) mult(a1, b1);
+                loadB(b1, k2 + 4); loadA(a1, k2 + 4); vm_wait<2 * (R + 4)>(); if (k2 + 2 < nk2) mult(a2, b2);
+            }
+            vm_wait<0>();
+            return;
+        }
+        SlA a0, a1, a2, a3;
+        SlB b0, b1;
+        loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
+        for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 8 J: a multiple of 4
+            if (!arrived && k2 + 6 >= knew) { wait_b(J - 1); arrived = true; }
+            loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * R + 4>(); mult(a0, b0);
+            loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * R + 4>(); mult(a1, b1);
+            loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * R + 4>(); mult(a2, b0);
+            loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<2 * R + 4>(); mult(a3, b1);
+        }
+        vm_wait<0>();
+    }
+    // behind (A): rows U0 .. U0 + G - 1 (those of them below na) solved against block a, block a's update of their column-b tiles
+    // from registers, solved against block b, stored, right-hand side updated
+    template <int R, int U0, int G>
+    __device__ __forceinline__ void rows_panel_group(v4d (&acc)[R][4], const RowSet<R>& rs, int na, const BFrag& bf, int J,
+                                                     int lane, int li, int kq, int fo) {
+        const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
+        v4d x1[G], x2[G];
+        {
+            double wn1[4], l21[4], wn2[4];
+            load_wn(wn1, wn2, j0a, li, kq);
+            load_l21(l21, 0, lane);
+#pragma unroll
+            for (int g = 0; g < G; ++g) { x1[g] = (v4d){0, 0, 0, 0}; x2[g] = (v4d){0, 0, 0, 0}; }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int g = 0; g < G; ++g) if (U0 + g < na) x1[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[U0 + g][0][s_], x1[g], 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int g = 0; g < G; ++g) if (U0 + g < na) acc[U0 + g][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[g][s_], acc[U0 + g][1], 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int g = 0; g < G; ++g) if (U0 + g < na) x2[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[U0 + g][1][s_], x2[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (rs.act[U0 + g]) store_pair(rs.T[U0 + g], tA, x1[g], x2[g], fo);
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (U0 + g < na) {
+                    upd_b_step(acc[U0 + g][2], bf, 0, x1[g], x2[g], st);
+                    upd_b_step(acc[U0 + g][3], bf, 1, x1[g], x2[g], st);
+                }
+        wait_y(2 * J + 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (rs.act[U0 + g] && rs.T[U0 + g] < nch) fwd_update(x1[g], x2[g], rs.T[U0 + g], j0a, li, kq);
+        {
+            double wn1[4], l21[4], wn2[4];
+            load_wn(wn1, wn2, j0b, li, kq);
+            load_l21(l21, 1, lane);
+#pragma unroll
+            for (int g = 0; g < G; ++g) { x1[g] = (v4d){0, 0, 0, 0}; x2[g] = (v4d){0, 0, 0, 0}; }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int g = 0; g < G; ++g) if (U0 + g < na) x1[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[U0 + g][2][s_], x1[g], 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int g = 0; g < G; ++g) if (U0 + g < na) acc[U0 + g][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[g][s_], acc[U0 + g][3], 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int g = 0; g < G; ++g) if (U0 + g < na) x2[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[U0 + g][3][s_], x2[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (rs.act[U0 + g]) store_pair(rs.T[U0 + g], tB, x1[g], x2[g], fo);
+        wait_y(2 * J + 2);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (rs.act[U0 + g] && rs.T[U0 + g] < nch) fwd_update(x1[g], x2[g], rs.T[U0 + g], j0b, li, kq);
+    }
+    template <int R>
+    __device__ __forceinline__ void rows_panel(v4d (&acc)[R][4], const RowSet<R>& rs, int J, int lane, int li, int kq, int fo) {
+        if (!rs.act[0]) return;
+        // (rows are dealt in order: a wavefront with fewer than R rows in this pass skips the absent rows' MFMAs -- in the
+        // last super columns most wavefronts hold one row)
+        int na = 1;
+#pragma unroll
+        for (int u = 1; u < R; ++u) if (rs.act[u]) na = u + 1;
+        BFrag bf;
+        load_bfrag(bf, 4 * J, true, fo);               // (rows tA+2, tA+3 are valid whenever there are rows here)
+        if constexpr (R <= PG) {
+            rows_panel_group<R, 0, R>(acc, rs, na, bf, J, lane, li, kq, fo);
+        } else {
+            static_assert(R <= 2 * PG, "two groups");
+            rows_panel_group<R, 0, PG>(acc, rs, na, bf, J, lane, li, kq, fo);
+            if (na > PG) rows_panel_group<R, PG, R - PG>(acc, rs, na, bf, J, lane, li, kq, fo);
+        }
+    }
+
+    // ======== the row wavefronts (2..7; fat form: 2, 3) ===================================================================
     __device__ __forceinline__ bool f64_rows(int wv) {
         const int lane = fresh_lane(), li = lane & 15, kq = lane >> 4;
         const int fo = li * 4 + kq;
         const int nblk = (n + NB - 1) / NB, nsup = (nblk + 1) >> 1;
         const int ntr = (n + 15) >> 4;
-        constexpr int SROW = Smem::SROW;
-        TileSrc pre[RM][4];                      // source tiles of pass 0 of the next super column, requested before barrier (B)
-        bool have_pre = false;
-        // this wavefront's rows of super column J_: bit r of (m0, m1) = tile row 4 J_ + 6 + r
-        auto my_rows = [&](int J_, unsigned long long& m0, unsigned long long& m1) {
-            const int nsq_ = ntr - (4 * J_ + 6) > 0 ? ntr - (4 * J_ + 6) : 0;
-            const unsigned char* row = sm.sched + J_ * SROW;
-            m0 = __ballot(lane < nsq_ && row[lane] == wv);
-            m1 = 0;
-            if (SROW > 64) m1 = __ballot(lane + 64 < nsq_ && row[lane + 64] == wv);
-        };
         for (int J = 0; J < nsup; ++J) {
-            const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
+            const int tA = 4 * J;
             TL(wv, J, 0);
             unsigned long long m0, m1;
-            my_rows(J, m0, m1);
+            my_rows(J, wv, lane, ntr, m0, m1);
             const int mine = __builtin_popcountll(m0) + __builtin_popcountll(m1);
             const int npass = mine > RM ? (mine + RM - 1) / RM : 1;
-            // rows and accumulators of pass 0 in front of the pass loop: the prefetched source tiles die here, not somewhere
-            // inside the loop (left in the loop they count as live through the operand ring: 96 registers)
-            int T[RM];
-            bool act[RM];
+            RowSet<RM> rs;
             v4d acc[RM][4];
-            auto next_rows = [&]() {
-#pragma unroll
-                for (int u = 0; u < RM; ++u) {
-                    int r = -1;
-                    if (m0) { r = __builtin_ctzll(m0); m0 &= m0 - 1; }
-                    else if (m1) { r = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
-                    T[u] = r >= 0 ? tA + 6 + r : nch;
-                    act[u] = r >= 0;
-                }
-            };
-            next_rows();
-            if (have_pre) {
-#pragma unroll
-                for (int u = 0; u < RM; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[u][c] = act[u] ? tile_image(pre[u][c], T[u], tA + c, li, kq) : (v4d){0, 0, 0, 0};
-            } else {
-#pragma unroll
-                for (int u = 0; u < RM; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[u][c] = act[u] ? init_tile(T[u], tA + c, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
-            }
-            have_pre = false;
+            rows_next(rs, m0, m1, tA);
+            rows_init(acc, rs, tA, ntr, fo, li, kq);
 #pragma unroll 1
             for (int ps = 0; ps < npass; ++ps) {
                 if (ps > 0) {
-                    next_rows();
-#pragma unroll
-                    for (int u = 0; u < RM; ++u)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[u][c] = act[u] ? init_tile(T[u], tA + c, ntr, fo, li, kq) : (v4d){0, 0, 0, 0};
+                    rows_next(rs, m0, m1, tA);
+                    rows_init(acc, rs, tA, ntr, fo, li, kq);
                 }
-                if (J > 0 && act[0]) {
-                    // operand ring as in factor_rows(): A tiles (own rows, HBM) three half-chunks ahead, B tiles (tile rows
-                    // tA .. tA+3, shared by all wavefronts: L1 / L2) one ahead; per step 4 B + RM A loads, B first
-                    const char* rb[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) rb[c] = uniform_ptr(tile2(tA + c, 0));
-                    const char* ra[RM];
-#pragma unroll
-                    for (int u = 0; u < RM; ++u) ra[u] = uniform_ptr(tile2(act[u] ? T[u] : tA, 0));
-                    const unsigned voff = (unsigned)fo * 16u;
-                    struct SlA { v2d a[RM]; };
-                    struct SlB { v2d b[4]; };
-                    const int nk2 = 8 * J, klast = nk2 - 1;
-                    auto loadA = [&](SlA& s_, int k2) {
-                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-#pragma unroll
-                        for (int u = 0; u < RM; ++u) s_.a[u] = gload16(ra[u] + o, voff);
-                    };
-                    auto loadB = [&](SlB& s_, int k2) {
-                        const size_t o = (size_t)(k2 < klast ? k2 : klast) * 1024;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) s_.b[c] = gload16(rb[c] + o, voff);
-                    };
-                    auto mult = [&](const SlA& a_, const SlB& b_) {
-#pragma unroll
-                        for (int u = 0; u < RM; ++u)
-                            if (act[u]) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c)
-                                    acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b[c].x, a_.a[u].x, acc[u][c], 0, 0, 0);
-                            }
-#pragma unroll
-                        for (int u = 0; u < RM; ++u)
-                            if (act[u]) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c)
-                                    acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(b_.b[c].y, a_.a[u].y, acc[u][c], 0, 0, 0);
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-                    SlA a0, a1, a2, a3;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile loads above: from here on the count is ours
-                    __builtin_amdgcn_sched_barrier(0);
-                    SlB b0, b1;
-                    const int knew = nk2 - 8;                   // first half-chunk of the 64 columns solved in super column J - 1
-                    bool arrived = ps > 0;                      // (a later pass starts behind (A))
-                    if (!arrived && knew <= 2) { wait_b(J - 1); arrived = true; }
-                    loadB(b0, 0); loadA(a0, 0); loadA(a1, 1); loadA(a2, 2);
-                    for (int k2 = 0; k2 < nk2; k2 += 4) {       // nk2 = 8 J: a multiple of 4
-                        if (!arrived && k2 + 6 >= knew) { wait_b(J - 1); arrived = true; }
-                        loadB(b1, k2 + 1); loadA(a3, k2 + 3); vm_wait<2 * RM + 4>(); mult(a0, b0);
-                        loadB(b0, k2 + 2); loadA(a0, k2 + 4); vm_wait<2 * RM + 4>(); mult(a1, b1);
-                        loadB(b1, k2 + 3); loadA(a1, k2 + 5); vm_wait<2 * RM + 4>(); mult(a2, b0);
-                        loadB(b0, k2 + 4); loadA(a2, k2 + 6); vm_wait<2 * RM + 4>(); mult(a3, b1);
-                    }
-                    vm_wait<0>();
-                }
+                if (J > 0 && rs.act[0]) rows_ring(acc, rs, J, tA, fo, ps > 0);      // (a later pass starts behind (A))
                 if (ps == 0) {
                     TL(wv, J, 1);
-                    __syncthreads();                            // (A)
+                    if constexpr (kFat) wait_a(J); else __syncthreads();      // (A)
                     TL(wv, J, 2);
                     if (sm.flag[0]) return false;
                 }
-                if (act[0]) {
-                    // (rows are dealt in order: a wavefront with fewer than RM rows in this pass skips the absent rows' MFMAs --
-                    // in the last super columns most wavefronts hold one row)
-                    int na = 1;
-#pragma unroll
-                    for (int u = 1; u < RM; ++u) if (act[u]) na = u + 1;
-                    BFrag bf;
-                    load_bfrag(bf, tA, true, fo);               // (rows tA+2, tA+3 are valid whenever there are rows here)
-                    v4d x1[RM], x2[RM];
-                    {
-                        double wn1[4], l21[4], wn2[4];
-                        load_wn(wn1, wn2, j0a, li, kq);
-                        load_l21(l21, 0, lane);
-#pragma unroll
-                        for (int u = 0; u < RM; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RM; ++u) if (u < na) x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][0][s_], x1[u], 0, 0, 0);
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RM; ++u) if (u < na) acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][1], 0, 0, 0);
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RM; ++u) if (u < na) x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][1][s_], x2[u], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < RM; ++u)
-                        if (act[u]) store_pair(T[u], tA, x1[u], x2[u], fo);
-#pragma unroll
-                    for (int st = 0; st < 8; ++st)
-#pragma unroll
-                        for (int u = 0; u < RM; ++u)
-                            if (u < na) {
-                                upd_b_step(acc[u][2], bf, 0, x1[u], x2[u], st);
-                                upd_b_step(acc[u][3], bf, 1, x1[u], x2[u], st);
-                            }
-                    wait_y(2 * J + 1);
-#pragma unroll
-                    for (int u = 0; u < RM; ++u)
-                        if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0a, li, kq);
-                    {
-                        double wn1[4], l21[4], wn2[4];
-                        load_wn(wn1, wn2, j0b, li, kq);
-                        load_l21(l21, 1, lane);
-#pragma unroll
-                        for (int u = 0; u < RM; ++u) { x1[u] = (v4d){0, 0, 0, 0}; x2[u] = (v4d){0, 0, 0, 0}; }
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RM; ++u) if (u < na) x1[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn1[s_], acc[u][2][s_], x1[u], 0, 0, 0);
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RM; ++u) if (u < na) acc[u][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[s_], x1[u][s_], acc[u][3], 0, 0, 0);
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                            for (int u = 0; u < RM; ++u) if (u < na) x2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[u][3][s_], x2[u], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < RM; ++u)
-                        if (act[u]) store_pair(T[u], tB, x1[u], x2[u], fo);
-                    wait_y(2 * J + 2);
-#pragma unroll
-                    for (int u = 0; u < RM; ++u)
-                        if (act[u] && T[u] < nch) fwd_update(x1[u], x2[u], T[u], j0b, li, kq);
-                }
+                rows_panel(acc, rs, J, lane, li, kq, fo);
             }
             TL(wv, J, 3);
             arrive_b(lane);
@@ -1655,8 +1756,13 @@ struct OpsResidentT {
     //   tile load map: instruction h (k-half) of a 2 KB tile covers double2 index h*64 + lane  ->  row i = lane/4,
     //   columns 8h + (lane%4) and 8h + (lane%4) + 4.
     static constexpr int SW_TW = RNW - 1;                // trailing-update wavefronts
-    static constexpr int SW_FT = (29 + SW_TW - 1) / SW_TW < kSweepCap ? (29 + SW_TW - 1) / SW_TW : kSweepCap;   // forward: buffered tiles each
-    static constexpr int SW_BC = (30 + SW_TW - 1) / SW_TW < kSweepCap ? (30 + SW_TW - 1) / SW_TW : kSweepCap;   // backward: buffered chunks each
+    // (fat form: three updaters with up to ten tiles each per block -- seven in the two register buffers (2 x 7 x 16 registers:
+    // they must stay in real VGPRs, a copy made before the hand-counted wait would copy stale registers), the rest of an
+    // early block's tiles requested together behind the buffered ones: one more memory round trip in 4-5 of the 17 blocks)
+    static constexpr int kCap = kFat ? 5 : kSweepCap;
+    static constexpr int kOvr = kFat ? 1 : 1;
+    static constexpr int SW_FT = (29 + SW_TW - 1) / SW_TW < kCap ? (29 + SW_TW - 1) / SW_TW : kCap;   // forward: buffered tiles each
+    static constexpr int SW_BC = (30 + SW_TW - 1) / SW_TW < kCap ? (30 + SW_TW - 1) / SW_TW : kCap;   // backward: buffered chunks each
     static constexpr int SW_NBUF = SW_FT > SW_BC ? SW_FT : SW_BC;
     struct SweepBuf { v2d t[SW_NBUF][4]; };
     struct UrgentBuf { v2d t[2][4]; };
@@ -1812,7 +1918,7 @@ struct OpsResidentT {
                         // more tile rows below than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
                         // from memory, four tile rows per round -- their sixteen loads are requested together, so a round costs
                         // one memory round trip instead of four
-                        constexpr int OVR = 1;       // (n <= 528 never gets here: no registers spent on it)
+                        constexpr int OVR = kOvr;    // (eight wavefronts, n <= 528 never get here: no registers spent on it)
                         for (int tt0 = tw_ + SW_FT * SW_TW; tt0 < tbelow; tt0 += OVR * SW_TW) {
                             v2d t_[OVR][4];
 #pragma unroll
@@ -1968,7 +2074,7 @@ struct OpsResidentT {
                     {
                         // more finished chunks than the register buffers hold (n > 528, or fewer wavefronts): the rest straight
                         // from memory, four chunks per round (sixteen loads requested together: one round trip per round)
-                        constexpr int OVR = 1;
+                        constexpr int OVR = kOvr;
                         for (int c0 = tw_ + SW_BC * SW_TW; c0 < nc; c0 += OVR * SW_TW) {
                             v2d t_[OVR][4];
 #pragma unroll
@@ -2024,11 +2130,17 @@ struct OpsResidentT {
         const int ntr = (n + 15) >> 4;
         const int NPd = nch * 16;
         const double* xin = sm.vec;
-        double* yw = sm.U + (size_t)wv * NPd;               // this wavefront's partial result
-        for (int i = lane; i < NPd; i += 64) yw[i] = 0.0;
+        // VT > 1: this wavefront also runs the tile runs of the virtual wavefronts wv + RNW, ... into their own partial vectors:
+        // the sum over (virtual) wavefronts below is the one a workgroup of RNW VT wavefronts forms
+        constexpr int RNWV = RNW * VT;
         const int ntile = ntr * (ntr + 1) / 2;
-        const int per = (ntile + RNW - 1) / RNW;
-        const int t0 = wv * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
+        const int per = (ntile + RNWV - 1) / RNWV;
+#pragma unroll 1
+        for (int vt = 0; vt < VT; ++vt) {
+        const int vw = wv + RNW * vt;
+        double* yw = sm.U + (size_t)vw * NPd;               // this (virtual) wavefront's partial result
+        for (int i = lane; i < NPd; i += 64) yw[i] = 0.0;
+        const int t0 = vw * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
         // locate (C, T) of tile t0: column C holds ntr - C tiles (T = C .. ntr-1)
         int C = 0, rem = t0;
         while (C < ntr && rem >= ntr - C) { rem -= ntr - C; ++C; }
@@ -2079,16 +2191,17 @@ struct OpsResidentT {
             }
         }
         flush();
+        }
         __syncthreads();
         for (int i = tid; i < n; i += RT) {
             double s_ = 0.0;
 #pragma unroll
-            for (int w = 0; w < RNW; ++w) s_ += sm.U[(size_t)w * NPd + i];
+            for (int w = 0; w < RNWV; ++w) s_ += sm.U[(size_t)w * NPd + i];
             sm.dvec[i] = s_;
         }
         __syncthreads();
         // the scratch goes back to the factorisation with its upper-right quarters zero
-        for (int i = tid; i < RNW * NPd; i += RT) sm.U[i] = 0.0;
+        for (int i = tid; i < RNWV * NPd; i += RT) sm.U[i] = 0.0;
     }
 };
 
@@ -2153,13 +2266,17 @@ template <int RTT> static constexpr bool kQpPanel64 = (HIPDRT_QP_PANEL64 != 0) &
 
 // (the second launch-bound argument is waves per SIMD: 2 in both forms, i.e. one 512-thread or two 256-thread workgroups per
 // CU and at most 256 registers per lane; without it hipcc gives the 256-thread form 393 registers and one workgroup per CU)
-template <bool GU, int RTT = 512>
-__global__ __launch_bounds__(RTT, 2) void qp_kernel_resident(QpArgs a, int NP) {
+// The FAT form (RTT = 256, WPS = 1, VT = 2): four wavefronts, one per SIMD, with the whole register file of their SIMD -- 256
+// architectural registers for operand rings and 256 accumulation registers (AccVGPRs: hipcc puts every MFMA result there once
+// a kernel may use more than 256 registers) = 32 accumulator tiles per wavefront.  The interior-point vectors run as two
+// virtual threads per thread (qp_common.hpp), so its results are bit for bit the eight-wavefront kernel's.
+template <bool GU, int RTT = 512, int WPS = 2, bool P64 = kQpPanel64<RTT>, int VT = 1>
+__global__ __launch_bounds__(RTT, WPS) void qp_kernel_resident(QpArgs a, int NP) {
     constexpr int RT = RTT;
     const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
     if (a.active && !a.active[b]) return;
     extern __shared__ double smem[];
-    OpsResidentT<GU, RTT, kQpPanel64<RTT>> ops;
+    OpsResidentT<GU, RTT, P64, VT> ops;
     ops.L = a.L + (size_t)b * a.l_stride; ops.nch = NP / 16; ops.n = a.n;
     ops.Ppk = a.Ppk ? a.Ppk + (size_t)b * a.ppk_stride : nullptr; ops.nchp = a.nchp;
     ops.sm.carve(smem);
@@ -2171,7 +2288,8 @@ __global__ __launch_bounds__(RTT, 2) void qp_kernel_resident(QpArgs a, int NP) {
     for (int i = threadIdx.x; i < NP + 32; i += RT) ops.sm.vec[i] = 0.0;
     __syncthreads();
     IpmSmem is{ops.sm.vec, ops.sm.dvec, ops.sm.red};
-    ipm_solve<RT, GU ? (2048 + RT - 1) / RT : (RNP_MAX + RT - 1) / RT>(a, b, ops, is);
+    constexpr int VTH = RT * VT;             // virtual threads
+    ipm_solve<RT, GU ? (2048 + VTH - 1) / VTH : (RNP_MAX + VTH - 1) / VTH, decltype(ops), VT>(a, b, ops, is);
 }
 
 // LDS bytes: everything for n <= 528, only the fixed part when U lives in global memory
@@ -2179,6 +2297,11 @@ __global__ __launch_bounds__(RTT, 2) void qp_kernel_resident(QpArgs a, int NP) {
 static size_t resident_lds_bytes(int NP, bool qp = false) {
     return ((size_t)NP * PLD + (qp ? ResSmemT<false, 512, kQpPanel64<512>>::FIXED : ResSmem::FIXED)) * sizeof(double);
 }
+// the fat four-wavefront form of the QP kernel
+static constexpr bool kFatPanel64 = true;
+using FatSmem = ResSmemT<false, 256, kFatPanel64, 2>;
+static size_t resident_fat_lds_bytes(int NP) { return ((size_t)NP * PLD + FatSmem::FIXED) * sizeof(double); }
+static_assert((FatSmem::FIXED + 544 * 33) * 8 <= 160 * 1024, "n = 514 must fit one CU's LDS (fat form)");
 template <int RTT = 512>
 static size_t resident_gu_lds_bytes(bool qp = false) {
     return (size_t)(qp ? ResSmemT<true, RTT, kQpPanel64<RTT>>::FIXED : ResSmemT<true, RTT>::FIXED) * sizeof(double);

@@ -26,6 +26,11 @@ int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n);
  * depend on the group size (bit for bit); batch and group kernel differ by rounding (the batch kernel fuses the forward
  * substitution into the factorisation: another summation order), same iteration counts.                                */
 int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members);
+/* diagnostic (tests, tools): wavefronts per workgroup of THIS CONTEXT's batch coneqp launches at n <= 528 -- 4 = the fat form
+ * (four wavefronts, one per SIMD, 512 registers each), 8 = eight wavefronts with 256 registers, -1 = the library's choice.
+ * A context starts from the environment variable HIPDRT_QP_WAVES (4 | 8) when it is set.  Both kernels run the same arithmetic
+ * in the same order: the results are the same bits (tests/test_gpu_qp.py).                                             */
+int hipdrt_debug_qp_waves(hipdrt_ctx* ctx, int waves);
 /* diagnostic (tests): on = 0 makes THIS CONTEXT's fits visit the exact zeros of the penalty matrices as well -- the Gram
  * epilogue adds the L2 part to every tile and the hyper kernel's Toeplitz convolutions run over all columns instead of the
  * penalties' reach (csrc/gram.hip, csrc/hyper.hip).  The results are the same bits either way; tests/test_gpu_fit.py checks it. */

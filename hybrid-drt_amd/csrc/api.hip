@@ -1384,6 +1384,10 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     hipStream_t st = p->ctx->stream;
     const int B = p->B, n = p->n, m = p->m;
     TRY(plan_hist_reserve(p, opts->max_iter));
+    // the row factors may be new with this call (hipdrt_plan_set_weight_factors after the fit): the buffer of the scaled final
+    // weights is filled behind the loop, below
+    const bool rowfac = p->prepared && p->wrow.p;
+    if (rowfac && !p->w_eff.p) HIPDRT_CHECK(p->w_eff.alloc((size_t)p->capacity * m * sizeof(double)));
     FitState fs = p->state();
     fs.opts = *opts; fs.continue_mode = 1; fs.min_iter = min_iter;
     const long long astr = p->rm_stride;
@@ -1432,7 +1436,17 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
         if (n_active == 0) break;
     }
     tm.mark(4);
-    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, p->w.d(), p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr, astr);
+    // What the posterior entry points call "the final P" (hipdrt_plan_p_matrix, _param_cov, _distribution_cov, _param_var read
+    // w_eff whenever the plan has weight factors): the weights this restart ended with -- the last iteration's fresh estimate --
+    // times the factors its QPs saw, i.e. the matrix the NEXT iteration would have solved with, and q to match.  (The fit
+    // leaves true_weights x row factors there, drt1d.py:990-1006; left alone, w_eff would still hold the FIRST fit's scaled
+    // weights, or nothing at all when the factors came with this call.)
+    const double* wfin = p->w.d();
+    if (rowfac) {
+        launch_scale_rows(st, B, m, p->w.d(), p->wrow.d(), p->wrow_batched, weight_factor, nullptr, p->w_eff.d());
+        wfin = p->w_eff.d();
+    }
+    launch_qvec(st, B, m, n, p->rm.d(), p->ldrm, wfin, p->rv.d(), p->l1.d(), 0.0, p->q.d(), nullptr, astr);
     LAUNCH_OK();
     tm.mark(-1);
     HIPDRT_CHECK(hipStreamSynchronize(st));

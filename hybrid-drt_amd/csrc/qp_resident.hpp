@@ -1615,10 +1615,20 @@ struct OpsResidentT {
     }
     // behind (A): rows U0 .. U0 + G - 1 (those of them below na) solved against block a, block a's update of their column-b tiles
     // from registers, solved against block b, stored, right-hand side updated
+#ifdef HIPDRT_QP_PROFILE
+    // PROFILE builds: time line of wavefront 2's panel solves in the rows of the unused wavefronts 4..7 of g_qp_tl
+    // (4 + 2 pass + group; stamps: 0 entry, 1 solved against block a, 2 stored + block a's update, 3 y_a there, 4 right-hand side
+    // updated, 5 solved against block b, 6 stored + y_b there, 7 right-hand side updated)
+    int dbg_tl = -1;
+#define TLP(k) do { if (dbg_tl >= 0) TL(dbg_tl + (U0 ? 1 : 0), J, k); } while (0)
+#else
+#define TLP(k)
+#endif
     template <int R, int U0, int G>
     __device__ __forceinline__ void rows_panel_group(v4d (&acc)[R][4], const RowSet<R>& rs, int na, const BFrag& bf, int J,
                                                      int lane, int li, int kq, int fo) {
         const int j0a = J * 64, j0b = j0a + NB, tA = 4 * J, tB = tA + 2;
+        TLP(0);
         v4d x1[G], x2[G];
         {
             double wn1[4], l21[4], wn2[4];
@@ -1639,6 +1649,7 @@ struct OpsResidentT {
 #pragma unroll
                 for (int g = 0; g < G; ++g) if (U0 + g < na) x2[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[U0 + g][1][s_], x2[g], 0, 0, 0);
         }
+        TLP(1);
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (rs.act[U0 + g]) store_pair(rs.T[U0 + g], tA, x1[g], x2[g], fo);
@@ -1650,10 +1661,13 @@ struct OpsResidentT {
                     upd_b_step(acc[U0 + g][2], bf, 0, x1[g], x2[g], st);
                     upd_b_step(acc[U0 + g][3], bf, 1, x1[g], x2[g], st);
                 }
+        TLP(2);
         wait_y(2 * J + 1);
+        TLP(3);
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (rs.act[U0 + g] && rs.T[U0 + g] < nch) fwd_update(x1[g], x2[g], rs.T[U0 + g], j0a, li, kq);
+        TLP(4);
         {
             double wn1[4], l21[4], wn2[4];
             load_wn(wn1, wn2, j0b, li, kq);
@@ -1673,13 +1687,16 @@ struct OpsResidentT {
 #pragma unroll
                 for (int g = 0; g < G; ++g) if (U0 + g < na) x2[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wn2[s_], acc[U0 + g][3][s_], x2[g], 0, 0, 0);
         }
+        TLP(5);
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (rs.act[U0 + g]) store_pair(rs.T[U0 + g], tB, x1[g], x2[g], fo);
         wait_y(2 * J + 2);
+        TLP(6);
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (rs.act[U0 + g] && rs.T[U0 + g] < nch) fwd_update(x1[g], x2[g], rs.T[U0 + g], j0b, li, kq);
+        TLP(7);
     }
     template <int R>
     __device__ __forceinline__ void rows_panel(v4d (&acc)[R][4], const RowSet<R>& rs, int J, int lane, int li, int kq, int fo) {
@@ -1730,6 +1747,9 @@ struct OpsResidentT {
                     TL(wv, J, 2);
                     if (sm.flag[0]) return false;
                 }
+#ifdef HIPDRT_QP_PROFILE
+                dbg_tl = (wv == 2 && ps < 2) ? 4 + 2 * ps : -1;
+#endif
                 rows_panel(acc, rs, J, lane, li, kq, fo);
             }
             TL(wv, J, 3);
@@ -2179,7 +2199,10 @@ struct OpsResidentT {
                         ca0 = ca1 = ca2 = ca3 = 0.0;
                     }
                     // lane: row g4 of the tile, columns l4, l4+4 (d0) and l4+8, l4+12 (d1)
-                    double pr = cur.d0.x * xc0 + cur.d0.y * xc1 + cur.d1.x * xc2 + cur.d1.y * xc3;
+                    // (explicit fused multiply-adds: left to itself hipcc contracts `a b + c d` with EITHER product as the fused
+                    // one, and which one changed with an unrelated edit of this function -- 7.5e-12 of the peak in x after a fit;
+                    // this is the association every build up to round 5 happened to get)
+                    double pr = __builtin_fma(cur.d1.y, xc3, __builtin_fma(cur.d1.x, xc2, __builtin_fma(cur.d0.y, xc1, cur.d0.x * xc0)));
                     pr = quad_sum(pr);
                     if (l4 == 0) yw[T * 16 + g4] += pr;
                     if (T != C) {                              // the diagonal tile is stored in full

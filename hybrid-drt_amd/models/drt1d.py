@@ -13,7 +13,7 @@ from .. import _ffi, preprocessing as pp
 from ..matrices import mat1d
 from ..utils.array import is_uniform
 from . import qphb
-from .prepared import PreparedFitMixin
+from .prepared import PreparedFitMixin, combine_status
 
 _FIT_KW_DEFAULTS = dict(  # DRT._qphb_fit_core keyword defaults (drt1d.py:102-137) that the device loop honours
     nonneg=True, scale_data=True, ohmic_penalty=1e-6, inductance_penalty=1e-6, inductance_scale=1e-5,
@@ -430,6 +430,7 @@ class DRT(PreparedFitMixin):
         init_kw.update(step_hypers(factors[0]))
         res = self.fit_eis_batch(frequencies, z_batch, nonneg=nonneg, max_iter=max_init_iter, xtol=xtol, **init_kw)
         step_x, step_llh, step_iters = [res['x'].copy()], [self.evaluate_step_llh_batch()], [res['outer_iters'].copy()]
+        status = np.array(res['status']).copy()
         if after_init is not None:          # (what DRTMD reads from the FIRST step's fit: its P matrix, llh / rss -- mapping)
             after_init(res)
         for f in factors[1:]:
@@ -437,8 +438,9 @@ class DRT(PreparedFitMixin):
             step_x.append(res['x'].copy())
             step_llh.append(self.evaluate_step_llh_batch())
             step_iters.append(res['outer_iters'].copy())
+            status = combine_status(status, res['status'])
         self.pfrt_result = {'factors': np.asarray(factors), 'step_x': np.array(step_x), 'step_llh': np.array(step_llh),
-                            'step_iters': np.array(step_iters), 'status': res['status'],
+                            'step_iters': np.array(step_iters), 'status': status,
                             'coefficient_scale': res['coefficient_scale'], 'basis_tau': res['basis_tau']}
         return self.pfrt_result
 

@@ -28,6 +28,14 @@ _UNSUPPORTED = dict(subtract_background=False,
                     peak_locations=None)
 
 
+def combine_status(so_far, step):
+    """per-spectrum status of a chain of fits (a full fit and its warm restarts): a failure (< 0: QP breakdown, singular KKT
+    system) in ANY step stays -- its iterate went into every later step --, otherwise the last step's verdict (0 converged,
+    1 stopped at max_iter)"""
+    so_far, step = np.asarray(so_far), np.asarray(step)
+    return np.where(step < 0, step, np.where(so_far < 0, so_far, step))
+
+
 class PreparedFitMixin:
     """Methods of DRT for chrono + EIS (+ DOP) fits."""
 
@@ -731,6 +739,7 @@ class PreparedFitMixin:
         else:
             self._last_prepared = (preps, None)
         step_x, step_llh, step_iters = [out['x'].copy()], [self.evaluate_step_llh_batch()], [out['outer_iters'].copy()]
+        status = np.array(out['status']).copy()
         history = [self._plan.history()] if single else None
         if after_init is not None:
             after_init(out)
@@ -746,10 +755,11 @@ class PreparedFitMixin:
             step_x.append(res['x'].copy())
             step_llh.append(self.evaluate_step_llh_batch())
             step_iters.append(res['outer_iters'].copy())
+            status = combine_status(status, res['status'])
             if single:
                 history.append(res['history'])
         self.pfrt_result = {'factors': factors, 'step_x': np.array(step_x), 'step_llh': np.array(step_llh),
-                            'step_iters': np.array(step_iters), 'status': out['status']}
+                            'step_iters': np.array(step_iters), 'status': status}
         if single:
             self.pfrt_history = [dict(x=h['x'][i], rho_vector=h['rho'][i], weights=h['weights'][i],
                                       dop_rho_vector=h['dop_rho'][i] if 'dop_rho' in h else None)

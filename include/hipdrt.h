@@ -240,7 +240,11 @@ int hipdrt_plan_set_subbatches(hipdrt_plan* plan, int k);
 int hipdrt_plan_download(hipdrt_plan* plan, double* x, double* fit_x, double* r_inf, double* induc,
                          double* weights, double* coef_scale, double* rho, double* s_vectors,
                          double* q_vector, int* outer_iters, int* qp_iters_total, int* status);
-/* final P (calculate_pq) of spectrum b: p[n][n] */
+/* final P (calculate_pq) of spectrum b: p[n][n].  After hipdrt_plan_fit: the matrix calculate_pq builds from the fit's final
+ * state (true_weights x chrono / eis row factors, drt1d.py:990-1006).  After hipdrt_plan_continue (upstream's
+ * _continue_from_init returns its history only and leaves fit_parameters alone): the same construction on the state the
+ * restart ended with -- its last s / rho and the last re-estimated weights times the factors the restart's QPs saw (row
+ * factors x weight_factor), q_vector of hipdrt_plan_download to match.  The posterior entry points below use this P.     */
 int hipdrt_plan_get_p_matrix(hipdrt_plan* plan, int b, double* p);
 /* Posterior variance of the fitted distribution on an evaluation grid: the diagonal of
  * DRT.estimate_distribution_cov (hybdrt/models/drt1d.py:3063-3151 with estimate_param_cov, 4116-4138; order 0, no

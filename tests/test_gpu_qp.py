@@ -321,3 +321,54 @@ def test_group_launches_beside_a_batch_launch_that_fills_the_chip():
     for o in outs:
         assert o["status"].tolist() == quiet["status"].tolist() and o["iterations"].tolist() == quiet["iterations"].tolist()
         np.testing.assert_array_equal(o["x"], quiet["x"])
+
+
+@pytest.mark.parametrize("n", [1, 17, 33, 64, 65, 93, 123, 129, 257, 400, 497, 513, 514, 528])
+def test_fat_four_wavefront_kernel_same_bits(n):
+    """The fat form of the batch coneqp kernel (four wavefronts, one per SIMD, 512 registers each: accumulators in AccVGPRs,
+    qp_kernel_resident<false, 256, 1, true, 2>; debug switch hipdrt_debug_qp_waves) against the eight-wavefront kernel: every
+    tile receives the same MFMA sequence whoever owns it, the sweeps apply the blocks' contributions in the same order, and the
+    interior-point reductions run over two VIRTUAL threads per thread -- the results are the same bits, the failure statuses too."""
+    from hipdrt import _ffi
+    rng = np.random.default_rng(1000 + n)
+    ctx = _ffi.Context(0)
+    B = 5
+    Ps, qs, hs = [], [], []
+    for b in range(B):
+        M = rng.standard_normal((n + 3, n))
+        Ps.append(M.T @ M + 0.1 * np.eye(n))
+        qs.append(rng.standard_normal(n) * 3)
+        hs.append(np.where(rng.random(n) < 0.8, 0.0, 1000.0))
+    Ps[B - 1] = -np.eye(n)                           # not positive definite: status -1 from both
+    Ps, qs, hs = np.stack(Ps), np.stack(qs), np.stack(hs)
+    ctx.debug_qp_group(0)
+    ctx.debug_qp_waves(8)
+    ref = ctx.qp_batch(Ps, qs, hs)
+    ctx.debug_qp_waves(4)
+    fat = ctx.qp_batch(Ps, qs, hs)
+    assert ref["status"].tolist() == [0] * (B - 1) + [-1]
+    for key in ("status", "iterations"):
+        assert fat[key].tolist() == ref[key].tolist()
+    np.testing.assert_array_equal(fat["x"][:B - 1], ref["x"][:B - 1])
+    np.testing.assert_array_equal(fat["pcost"][:B - 1], ref["pcost"][:B - 1])
+
+
+def test_fat_kernel_whole_fits_same_bits():
+    """64 config-2 spectra (n = 514) and 8 spectra on the reference's default 91-point grid through the whole QPHB loop with
+    either kernel: identical x, weights, rho, iteration counts, posterior variances"""
+    from hipdrt import _ffi, synth
+    from hipdrt.models import DRT
+    out = {}
+    for waves in (8, 4):
+        ctx = _ffi.Context(0)
+        ctx.debug_qp_waves(waves)
+        c2 = synth.config_c2()
+        d = DRT(fixed_basis_tau=c2["tau"], context=ctx)
+        r = d.fit_eis_batch(c2["freq"], synth.zarc2_batch(c2["freq"], 64))
+        v = d.estimate_distribution_var_batch(c2["tau"][::8])
+        f = np.logspace(6, -1, 71)
+        r1 = DRT(context=ctx).fit_eis_batch(f, synth.zarc2_batch(f, 8, first_seed=3))
+        out[waves] = [r["x"], r["weights"], r["rho"], r["outer_iters"], r["qp_iters_total"],
+                      np.asarray(v[0] if isinstance(v, tuple) else v), r1["x"], r1["qp_iters_total"]]
+    for a, b in zip(out[8], out[4]):
+        np.testing.assert_array_equal(a, b)

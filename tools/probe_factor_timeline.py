@@ -35,9 +35,14 @@ for J in range(nsup):
     print("J = %d  wavefront 0: chain a done %s | look-ahead history %s | its solve %s | at (A) %s | W21, y %s | all arrived %s | total %s" % (
         J, k(w0[4] - t0), k(w0[5] - t0) if w0[5] else "     -", k(w0[6] - t0) if w0[6] else "     -", k(w0[1] - t0), k(w0[7] - t0), k(w0[3] - t0),
         k((tl[0, J + 1, 0] if J + 1 < nsup else w0[3]) - t0)))
+    fat = os.environ.get("HIPDRT_QP_WAVES") == "4"
     for w in range(1, 8):
         r = tl[w, J]
         if not r[0]:
+            continue
+        if fat and w >= 4:       # fat form, PROFILE build: wavefront 2's panel solves (pass, group) in the rows of the absent wavefronts
+            print("       wavefront 2, pass %d group %d: entry %s | solved a +%s | stored, a's update +%s | y_a +%s | rhs +%s | solved b +%s | stored, y_b +%s | rhs +%s" % (
+                (w - 4) // 2, (w - 4) % 2, k(r[0] - t0), *[k(r[i] - r[i - 1]) for i in range(1, 8)]))
             continue
         print("       wavefront %d: starts %s | at (A) %s (waits %s) | tiles stored %s (%s behind (A))" % (
             w, k(r[0] - t0), k(r[1] - t0), k(r[2] - r[1]), k(r[3] - t0), k(r[3] - r[2])))

@@ -962,10 +962,12 @@ static int plan_toep_reach(hipdrt_plan* p) {
 static int plan_hyper(hipdrt_plan* p, hipStream_t st, const FitState& fs_in, int B, int it) {
     FitState fs = fs_in;
     const size_t premv_need = 3 * (size_t)(p->capacity > B ? p->capacity : B) * p->m * sizeof(double);
-    if (B * 8 <= device_cus() && (size_t)p->m * p->n >= ((size_t)1 << 20) && !(p->opts.outlier_p > 0.0)) {
+    // (the options of THIS loop decide -- a warm restart may switch outlier_p on or off against the plan's fit)
+    const bool outl = fs_in.opts.outlier_p > 0.0;
+    if (B * 8 <= device_cus() && (size_t)p->m * p->n >= ((size_t)1 << 20) && !outl) {
         if (p->premv.bytes < premv_need) HIPDRT_CHECK(p->premv.alloc(premv_need));
         fs.premv = p->premv.d();
-    } else if (p->rm_stride == 0 && !(p->opts.outlier_p > 0.0) && !(p->prepared && p->desc.vz_index >= 0)) {
+    } else if (p->rm_stride == 0 && !outl && !(p->prepared && p->desc.vz_index >= 0)) {
         // one response matrix and one variance matrix for the whole batch (every EIS plan, prepared plans without a vz_offset
         // column): rm @ x and vmm @ resid^2 of all spectra as two batched products (hyper.hip: batch_products_kernel) -- for any
         // batch size, so that a spectrum's bits do not depend on whether it is fitted alone or among a thousand
@@ -1376,7 +1378,6 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
     HIPDRT_REQUIRE(opts->max_iter >= 1 && min_iter >= 1, "max_iter, min_iter >= 1");
     // rejected calls must leave the finished fit as it is: every check comes before the first write
-    HIPDRT_REQUIRE(!(p->prepared && opts->outlier_p > 0.0), "warm restarts of prepared plans with outlier_p are not built");
     HIPDRT_REQUIRE(p->prepared || !p->has_weight_factors(),
                    "warm restarts take their weight_factor argument; clear the plan's weight factors");
     HIPDRT_REQUIRE(!(p->wrow.p && p->wrow_late), "a vector-valued weight_factor belongs to the fit, not to its warm restarts");
@@ -1388,6 +1389,9 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     // weights is filled behind the loop, below
     const bool rowfac = p->prepared && p->wrow.p;
     if (rowfac && !p->w_eff.p) HIPDRT_CHECK(p->w_eff.alloc((size_t)p->capacity * m * sizeof(double)));
+    // outlier_p (qphb.py:1545-1594: estimate_weights forms outlier_t and the T V T matrix anew from every iterate, what
+    // _continue_from_init is handed is never read, drt1d.py:1300-1304): only the record of 1 - outlier probability needs room
+    if (opts->outlier_p > 0.0 && !p->outlier_t.p) HIPDRT_CHECK(p->outlier_t.alloc((size_t)p->capacity * m * sizeof(double)));
     FitState fs = p->state();
     fs.opts = *opts; fs.continue_mode = 1; fs.min_iter = min_iter;
     const long long astr = p->rm_stride;

@@ -445,7 +445,22 @@ class DRT(PreparedFitMixin):
         return self.pfrt_result
 
     # ---- what DRTMD takes from a finished fit (mapping/drtmd.py:258-279) ----------------------------------------
-    def estimate_distribution_var_batch(self, tau=None, ppd=20, extend_var=False):
+    def _signed_basis(self, bm, sign):
+        """series_neg fits carry 2 ntau coefficients [positive copy | negative copy]: the evaluation rows of
+        estimate_distribution_cov's three cases (drt1d.py:3090-3103) as ONE matrix over both copies -- sign=1 the positive
+        block, -1 the negative one, 0 their difference (B, -B): B S++ B' + B S-- B' - B (S+- + S-+) B'"""
+        if not self.series_neg:
+            return bm
+        zero = np.zeros_like(bm)
+        if sign == 1:
+            return np.hstack([bm, zero])
+        if sign == -1:
+            return np.hstack([zero, bm])
+        if sign == 0:
+            return np.hstack([bm, -bm])
+        raise ValueError('sign must be 1, -1 or 0')
+
+    def estimate_distribution_var_batch(self, tau=None, ppd=20, extend_var=False, sign=1):
         """Diagonal of DRT.estimate_distribution_cov (drt1d.py:3063-3151; order 0, no normalisation) for every
         spectrum of the last fitted batch: diag(B P^-1 B') coefficient_scale^2, computed on the device from the
         Cholesky factor of each final P.  Returns (var (B, len(tau)), ok (B,) bool); ``extend_var`` applies the
@@ -459,9 +474,8 @@ class DRT(PreparedFitMixin):
         tau = np.asarray(tau, dtype=float)
         bm = basis.construct_func_eval_matrix(np.log(self.basis_tau), np.log(tau), self.tau_basis_type,
                                               epsilon=self.tau_epsilon, order=0)
+        bm = self._signed_basis(bm, sign)
         if prepared:
-            if self.series_neg:
-                raise NotImplementedError("distribution variance of series_neg fits is not built")
             # the device loop of a prepared plan runs at unit scale: estimate_param_cov's coefficient_scale^2 is applied here
             var, status = self._plan.distribution_var(bm, self._plan.batch)
             preps = self._last_prepared[0] if getattr(self, '_last_prepared', None) and \
@@ -521,21 +535,19 @@ class DRT(PreparedFitMixin):
             cov[a:e, :] *= prep['dop_scale_vector'][:, None]
         return cov
 
-    def estimate_distribution_cov(self, tau=None, ppd=20, extend_var=False, var_floor=0.0, b=0):
+    def estimate_distribution_cov(self, tau=None, ppd=20, extend_var=False, var_floor=0.0, b=0, sign=1):
         """DRT.estimate_distribution_cov (drt1d.py:3063-3151; order 0, sign 1, no normalisation): basis_matrix @ x_cov @
         basis_matrix.T of the DRT block, formed on the device (hipdrt_plan_distribution_cov), then upstream's ``extend_var``
         clamp of the diagonal outside the measured tau range (3126-3143) and ``var_floor``."""
         from ..matrices import basis
         if self._plan is None or (self._last_batch is None and not isinstance(self._plan, _ffi.PreparedPlan)):
             raise Exception('Parameter covariance estimation is only available for qphb fits')
-        if self.series_neg:
-            raise NotImplementedError("distribution covariance of series_neg fits is not built")
         if tau is None:
             tau = self.get_tau_eval(ppd)
         tau = np.asarray(tau, dtype=float)
         bm = basis.construct_func_eval_matrix(np.log(self.basis_tau), np.log(tau), self.tau_basis_type,
                                               epsilon=self.tau_epsilon, order=0)
-        cov, ok = self._plan.distribution_cov(bm, b)
+        cov, ok = self._plan.distribution_cov(self._signed_basis(bm, sign), b)
         if not ok:
             warnings.warn('Singular P matrix - could not obtain covariance estimate')
             return None

@@ -304,7 +304,8 @@ int hipdrt_plan_set_state_dop(hipdrt_plan* plan, const double* dop_rho);
  * (1295-1298, 1353-1357) -- the reference's behaviour, so a chain of warm restarts reproduces pfrt_fit_hybrid (2558-2715).
  * Results through hipdrt_plan_download / _get_history as after hipdrt_plan_fit (outer_iters = iterations of this call).
  * Used by the candidate generators (drt1d.py:1497-1632) and PFRT (2558-2715, DRTMD fit_type='pfrt': drtmd.py:98-100, 1338).
- * Not built: outlier_p on prepared plans.                                                                             */
+ * opts->outlier_p > 0 (any plan; it may differ from the fit's): estimate_weights forms outlier_t and T V T anew from every
+ * iterate (qphb.py:1545-1594) -- the outlier_t / outlier_tvt a caller hands _continue_from_init are never read (1300-1304).  */
 int hipdrt_plan_continue(hipdrt_plan* plan, const hipdrt_fit_opts* opts, double weight_factor, int min_iter);
 
 /* ---- prepared-matrix plans: the same device loop for any data type (config-5 family) -----------------------------

@@ -199,6 +199,24 @@ def run_posterior(DRT, name, freq, z, ctor_kw, tau_eval):
     print(f"posterior_{name}: llh={llh:.6f} rss={rss:.6f} var range {out['dist_var'].min():.3e}..{out['dist_var'].max():.3e}")
 
 
+def run_posterior_sneg(DRT, freq, z, ctor_kw, tau_eval):
+    """series_neg=True (drt1d.py:3090-3103): the posterior of the positive copy (sign=1, what DRTMD stores), of the negative
+    copy (sign=-1) and of their difference (sign=0: pos + neg - cross terms), plus the parameter variances of all 2 ntau + ns"""
+    with _quiet():
+        drt = DRT(**ctor_kw)
+        drt.fit_eis(freq, z, series_neg=True)
+        out = dict(freq=freq, z=z, tau_eval=tau_eval, basis_tau=drt.basis_tau, coefficient_scale=drt.coefficient_scale,
+                   x=drt.fit_parameters["x"], param_var=np.diag(drt.estimate_param_cov()),
+                   p_matrix=drt.fit_parameters["p_matrix"])
+        for sign, tag in ((1, "pos"), (-1, "neg"), (0, "both")):
+            cov = drt.estimate_distribution_cov(tau=tau_eval, sign=sign)
+            out[f"dist_var_{tag}"] = np.diag(cov)
+            out[f"dist_cov_{tag}_row40"] = cov[40]
+        out["dist_var_pos_ext"] = np.diag(drt.estimate_distribution_cov(tau=tau_eval, extend_var=True))
+    np.savez_compressed(os.path.join(OUT, "refrun_posterior_golden71x91_sneg.npz"), **out)
+    print("posterior_sneg: var ranges", {t: (float(out[f'dist_var_{t}'].min()), float(out[f'dist_var_{t}'].max())) for t in ("pos", "neg", "both")})
+
+
 def run_candidates(DRT, name, freq, z, ctor_kw):
     """survey 8f rank 3: warm restarts of the outer loop (_continue_from_init) as the candidate generators drive them
     (drt1d.py:1497-1632): 2 s_0 steps x4 and 3 weight steps x0.5, every per-iteration state."""
@@ -225,13 +243,14 @@ def run_candidates(DRT, name, freq, z, ctor_kw):
     print(f"candidates_{name}: s0 history {len(hist_s)}, weights history {len(hist_w)}")
 
 
-def run_warm_restarts_prepared(DRT, name, data, ctor_kw, factors=None):
+def run_warm_restarts_prepared(DRT, name, data, ctor_kw, factors=None, fit_kw=None, candidates=True):
     """survey 8f rank 3 on chrono / joint / DOP fits: _continue_from_init re-enters the loop with the vz_offset column rewrite
     and the chrono / eis weight factors (drt1d.py:1270-1365), driven by pfrt_fit_hybrid / pfrt_fit_chrono (2558-2715; DRTMD's
     factors logspace(-0.7, 0.7, 11), drtmd.py:98-100) and by the candidate generators (1497-1632).  Every warm restart's
     iterates are recorded through a wrapper around the reference's own _continue_from_init."""
     times, i_sig, v_sig, freq, z = data
     factors = np.logspace(-0.7, 0.7, 11) if factors is None else factors
+    fit_kw = dict(fit_kw or {})        # e.g. outlier_p: the first fit AND every warm restart run with it (drt1d.py:2564-2566, 2673)
     calls = []
 
     def wrap(drt):
@@ -247,9 +266,9 @@ def run_warm_restarts_prepared(DRT, name, data, ctor_kw, factors=None):
         drt = DRT(**ctor_kw)
         wrap(drt)
         if freq is None:
-            drt.pfrt_fit_chrono(times, i_sig, v_sig, factors=factors)
+            drt.pfrt_fit_chrono(times, i_sig, v_sig, factors=factors, **fit_kw)
         else:
-            drt.pfrt_fit_hybrid(times, i_sig, v_sig, freq, z, factors=factors)
+            drt.pfrt_fit_hybrid(times, i_sig, v_sig, freq, z, factors=factors, **fit_kw)
     pr = drt.pfrt_result
     dop = bool(ctor_kw.get("fit_dop"))
     out = dict(pfrt_factors=np.asarray(pr["factors"]), pfrt_step_x=np.array(pr["step_x"]),
@@ -262,6 +281,10 @@ def run_warm_restarts_prepared(DRT, name, data, ctor_kw, factors=None):
                pfrt_step_p_diag=np.array([np.diag(pm) for pm in pr["step_p_mat"]]))
     if dop:
         out["pfrt_hist_dop_rho"] = np.array([h["dop_rho_vector"] for h in drt.pfrt_history])
+    if not candidates:
+        np.savez_compressed(os.path.join(OUT, f"refrun_warm_{name}.npz"), **out)
+        print(f"warm_{name}: pfrt step iterations {out['pfrt_step_iters'].tolist()}")
+        return
     # candidates on a fresh fit (the weight candidates first, as generate_candidates runs them)
     calls.clear()
     with _quiet():
@@ -730,6 +753,22 @@ def main():
         run_warm_restarts_prepared(DRT, "hybrid_s0", meas, dict(base, fit_dop=False))
         run_warm_restarts_prepared(DRT, "hybrid_s0_dop", meas, dict(base, fit_dop=True))
         run_warm_restarts_prepared(DRT, "chrono_s1", meas[:3] + (None, None), dict(base, fit_dop=False))
+        return
+    if "--only-posterior-sneg" in sys.argv:
+        from oracle.drt_oracle import get_basis_tau
+        freq_g, z_g = extract_reference_test_vectors()
+        DRT, cvxopt = _boot_reference()
+        bt = get_basis_tau(freq_g)
+        run_posterior_sneg(DRT, freq_g, z_g, dict(fit_inductance=True, fit_capacitance=False, fit_dop=False, fit_ohmic=True),
+                           np.logspace(np.log10(bt[0]) - 0.5, np.log10(bt[-1]) + 0.5, 10 * 13 + 1))
+        return
+    if "--only-warm-outlier" in sys.argv:
+        # outlier_p in the warm restarts of a joint fit: five factors, the first fit and every restart with it
+        from hipdrt import synth
+        DRT, cvxopt = _boot_reference()
+        base = dict(fit_inductance=True, fit_capacitance=False, fit_ohmic=True)
+        run_warm_restarts_prepared(DRT, "hybrid_s0_outlier", synth.hybrid_measurement(seed=0), dict(base, fit_dop=False),
+                                   factors=np.logspace(-0.5, 0.5, 5), fit_kw=dict(outlier_p=0.05), candidates=False)
         return
     if "--only-candidates" in sys.argv:
         freq_g, z_g = extract_reference_test_vectors()

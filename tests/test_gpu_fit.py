@@ -704,3 +704,38 @@ def test_exact_zero_shortcuts_do_not_change_a_bit(ntau, ppd):
         res[on] = {k: np.array(r[k]) for k in ("x", "weights", "rho", "s_vectors", "outer_iters", "qp_iters_total")}
     for k in res[True]:
         np.testing.assert_array_equal(res[True][k], res[False][k], err_msg=k)
+
+
+def test_posterior_of_a_series_neg_fit_vs_reference_run():
+    """series_neg=True carries a positive and a negative copy of the basis (2 ntau coefficients, drt1d.py:5497-5530);
+    estimate_distribution_cov picks the positive block (sign=1, the default DRTMD uses), the negative one (sign=-1) or the
+    difference of the two with its cross terms (sign=0) (drt1d.py:3090-3103).  Here all three are ONE product with an
+    evaluation matrix over both copies -- (B, 0), (0, B), (B, -B) -- on the device; against the reference's own run
+    (refrun_posterior_golden71x91_sneg.npz, oracle/make_golden.py: run_posterior_sneg) and, tightly, against numpy on this
+    fit's own P."""
+    from hipdrt.models import DRT
+    from hipdrt.matrices import basis
+    g = load("refrun_posterior_golden71x91_sneg.npz")
+    drt = DRT()
+    drt.fit_eis(g["freq"], g["z"], series_neg=True)
+    nt = len(g["basis_tau"])
+    assert drt.series_neg and len(drt.fit_parameters["x"]) == 2 * nt
+    P = drt.fit_parameters["p_matrix"]
+    cov_x = np.linalg.inv(P)[2:, 2:] * drt.coefficient_scale ** 2
+    bm = basis.construct_func_eval_matrix(np.log(drt.basis_tau), np.log(g["tau_eval"]), 'gaussian', epsilon=drt.tau_epsilon, order=0)
+    blocks = {1: cov_x[:nt, :nt], -1: cov_x[nt:, nt:],
+              0: cov_x[:nt, :nt] + cov_x[nt:, nt:] - cov_x[:nt, nt:] - cov_x[nt:, :nt]}
+    for sign, tag in ((1, "pos"), (-1, "neg"), (0, "both")):
+        var, ok = drt.estimate_distribution_var_batch(tau=g["tau_eval"], sign=sign)
+        assert ok.all()
+        parity("dist_var_" + tag, var[0], g["dist_var_" + tag], default=1e-6, rel=True, floor=1e-6)
+        ref = bm @ blocks[sign] @ bm.T
+        np.testing.assert_allclose(var[0], np.diag(ref), rtol=1e-8, atol=1e-12 * np.diag(ref).max())
+        cov = drt.estimate_distribution_cov(tau=g["tau_eval"], sign=sign)
+        np.testing.assert_allclose(cov, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+        parity("dist_cov_row40_" + tag, cov[40], g[f"dist_cov_{tag}_row40"], default=1e-6, scale=np.abs(g[f"dist_cov_{tag}_row40"]).max())
+    vext, _ = drt.estimate_distribution_var_batch(tau=g["tau_eval"], extend_var=True)
+    parity("dist_var_pos_ext", vext[0], g["dist_var_pos_ext"], default=1e-6, rel=True, floor=1e-6)
+    pv, pok = drt.estimate_param_var_batch()
+    assert pok.all()
+    parity("param_var", pv[0], g["param_var"], default=1e-6, rel=True)

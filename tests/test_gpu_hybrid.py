@@ -821,7 +821,7 @@ def _warm(name):
     return np.load(os.path.join(GOLDEN, f"refrun_warm_{name}.npz"), allow_pickle=False)
 
 
-@pytest.mark.parametrize("name", ["hybrid_s0", "hybrid_s0_dop", "chrono_s1"])
+@pytest.mark.parametrize("name", ["hybrid_s0", "hybrid_s0_dop", "chrono_s1", "hybrid_s0_outlier"])
 def test_pfrt_on_chrono_and_joint_fits_vs_reference_run(name):
     """DRT.pfrt_fit_hybrid / pfrt_fit_chrono with DRTMD's eleven factors against the reference's own run: per-step iteration
     counts, every iterate of every step (the device loop re-entered ten times on the prepared plan: weight factors on every
@@ -833,6 +833,9 @@ def test_pfrt_on_chrono_and_joint_fits_vs_reference_run(name):
     drt = DRT(fit_dop="x_dop" in special, warn=False)
     if name == "chrono_s1":
         pr = drt.pfrt_fit_chrono(g["times"], g["i_signal"], g["v_signal"], factors=w["pfrt_factors"])
+    elif name.endswith("_outlier"):        # outlier_p in the first fit and in every warm restart of a prepared plan
+        pr = drt.pfrt_fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], factors=w["pfrt_factors"],
+                                 outlier_p=0.05)
     else:
         pr = drt.pfrt_fit_hybrid(g["times"], g["i_signal"], g["v_signal"], g["freq"], g["z"], factors=w["pfrt_factors"])
     assert pr["step_iters"][:, 0].tolist() == w["pfrt_step_iters"].tolist()
@@ -876,7 +879,7 @@ def test_candidates_on_chrono_and_joint_fits_vs_reference_run(name):
 def test_pfrt_batch_of_joint_fits_matches_single_runs():
     """pfrt_fit_hybrid_batch: three joint measurements of one protocol through the eleven steps at once; every member's steps
     are those of its own single run (iteration counts equal, iterates to rounding: the batch and the single plan run the same
-    kernels per measurement), and the restart refuses what is not built (outlier_p)."""
+    kernels per measurement); a restart with outlier_p switched on runs."""
     from hipdrt import synth
     from hipdrt.models import DRT
     meas = [synth.hybrid_measurement(seed=s_, jitter=True) for s_ in (0, 1, 2)]
@@ -887,8 +890,8 @@ def test_pfrt_batch_of_joint_fits_matches_single_runs():
     p1 = one.pfrt_fit_hybrid(*meas[1])
     assert pr["step_iters"][:, 1].tolist() == p1["step_iters"][:, 0].tolist()
     parity("step_x", pr["step_x"][:, 1], p1["step_x"][:, 0], default=1e-9)
-    with pytest.raises(Exception):
-        one.continue_from_init(outlier_p=0.05)
+    res = one.continue_from_init(outlier_p=0.05, max_iter=3)          # (built in round 6: any plan, any outlier_p)
+    assert np.isfinite(res["x"]).all() and (res["status"] >= 0).all()
 
 
 def test_full_covariance_of_a_joint_fit_with_dop():

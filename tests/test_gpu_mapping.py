@@ -208,3 +208,25 @@ def test_reproducible_map_is_bit_identical_however_it_is_sharded():
     lx = np.concatenate([p_[0] for p_ in loose])
     assert not np.array_equal(lx, whole[0])                     # (the small shares ran on the group kernel)
     parity_close("reproducible_map.group_vs_batch_kernel", lx, whole[0], 2e-9)      # measured 1.1e-10 (a fit of 27 outer iterations, two kernels)
+
+
+def test_store_fit_all_resumes_where_it_stopped_and_matches_the_reference_map():
+    """mapping.DRTMD (observation store, drtmd.py:186-329): ten observations of the reference's 16-observation map are added and
+    fitted, six more are added, fit_all(refit=False) sends exactly those six to the device (drtmd.py:321-329) -- and the store
+    then holds the reference's own DRTMD result for all sixteen (a fit does not depend on what shares its device batch)."""
+    from hipdrt.mapping import DRTMD
+    g = np.load(os.path.join(GOLDEN, "refrun_drtmd_mixed16.npz"))
+    obs = mixed_map_observations(int(g["n_obs"]))
+    md = DRTMD(g["tau_supergrid"], warn=False)
+    for k in range(10):
+        md.add_observation([k], *obs[k])
+    assert md.fit_all().tolist() == list(range(10)) and md.obs_fit_status.all()
+    first_x = md.obs_x.copy()
+    for k in range(10, 16):
+        md.add_observation([k], *obs[k])
+    assert md.fit_all(refit=False).tolist() == list(range(10, 16))
+    assert md.last_fit_index.tolist() == list(range(10, 16)) and md.obs_fit_status.all() and not md.obs_ignore_flag.any()
+    np.testing.assert_array_equal(md.obs_x[:10], first_x)                     # untouched by the second call
+    assert md.fit_all(refit=False).tolist() == []
+    res = dict(obs_tau_indices=md.obs_tau_indices, obs_llh=md.obs_llh, obs_rss=md.obs_rss, obs_drt_var=md.obs_drt_var)
+    _check_against_reference(g, md.obs_x, md.obs_special, res, drt_var=True)

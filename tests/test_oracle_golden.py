@@ -364,7 +364,7 @@ def test_general_loop_dop_pass_without_eff_hp():
     np.testing.assert_allclose(np.array([h["dop_rho_vector"] for h in r["history"]]), g["hist_dop_rho"], rtol=1e-8)
 
 
-@pytest.mark.parametrize("name", ["hybrid_s0", "hybrid_s0_dop", "chrono_s1"])
+@pytest.mark.parametrize("name", ["hybrid_s0", "hybrid_s0_dop", "chrono_s1", "hybrid_s0_outlier"])
 def test_warm_restarts_on_prepared_fits_reproduce_the_reference(name):
     """survey 8f rank 3 beyond EIS: oracle.pfrt_fit_prepared / continue_prepared (drt1d.py:1270-1365, 2558-2715: the
     vz_offset column rewritten from a copy frozen at entry, chrono / eis factors and weight_factor on every iteration's
@@ -377,6 +377,8 @@ def test_warm_restarts_on_prepared_fits_reproduce_the_reference(name):
     hyp = orc.get_default_hypers()
     if "x_dop" in special:
         hyp.update(orc.get_default_dop_hypers())
+    if name.endswith("_outlier"):          # outlier_p in the first fit and in every warm restart (five factors)
+        hyp["outlier_p"] = 0.05
     rzm0, vz = initial_rzm_and_vz(g, special)
     r = orc.pfrt_fit_prepared(rzm0, g["rv"], [g["m0"], g["m1"], g["m2"]], g["vmm"], special, hyp, w["pfrt_factors"], vz=vz)
     assert r["step_iters"].tolist() == w["pfrt_step_iters"].tolist()

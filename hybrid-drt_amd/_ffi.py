@@ -378,6 +378,7 @@ class Context:
         """tests / diagnostics: force the workgroups per problem of this context's coneqp launches sized from now on
         (hipdrt_debug_qp_group, include/hipdrt_debug.h)"""
         _check(self._lib.hipdrt_debug_qp_group(self._h, int(members)))
+        self._qp_group_override = int(members)          # (remembered for callers that switch it temporarily: mapping._one_kernel)
 
     def debug_qp_waves(self, waves):
         """tests / tools: 4 = this context's batch coneqp launches (n <= 528) use the fat four-wavefront kernel, 8 = the

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 
 #include "common.hpp"
 #include <thread>
@@ -123,6 +125,13 @@ static int upload(DevBuf& buf, const void* src, size_t bytes, hipStream_t st) {
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 #define LAUNCH_OK() HIPDRT_CHECK(hipGetLastError())
 
+// No exception may cross the C ABI: every entry point below is a function-try-block.  (Host-side std::vector buffers -- an
+// n x n identity of 134 MB at n = 4096, download staging, the Toeplitz reach scan of plan creation -- can throw std::bad_alloc.)
+#define HIPDRT_CATCH                                                                                              \
+    catch (const std::bad_alloc&) { hipdrt::set_error("out of host memory"); return HIPDRT_E_HIP; }                \
+    catch (const std::exception& e) { hipdrt::set_error(std::string("internal error: ") + e.what()); return HIPDRT_E_HIP; } \
+    catch (...) { hipdrt::set_error("internal error"); return HIPDRT_E_HIP; }
+
 extern "C" {
 
 static int plan_hist_reserve(hipdrt_plan* p, int rows);
@@ -130,7 +139,7 @@ static int plan_toep_reach(hipdrt_plan* p);
 
 const char* hipdrt_last_error(void) { return g_err.c_str(); }
 
-int hipdrt_create(int device, hipdrt_ctx** out) {
+int hipdrt_create(int device, hipdrt_ctx** out) try {
     HIPDRT_REQUIRE(out != nullptr, "out is NULL");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -160,7 +169,7 @@ int hipdrt_create(int device, hipdrt_ctx** out) {
     if (e != hipSuccess) { delete c; set_error(hipGetErrorString(e)); return HIPDRT_E_HIP; }
     *out = c;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 static std::mutex g_life;          // context / plan creation and destruction (any thread, e.g. a garbage collector's)
 
@@ -170,34 +179,34 @@ static void free_ctx(hipdrt_ctx* ctx) {
     delete ctx;
 }
 
-int hipdrt_destroy(hipdrt_ctx* ctx) {
+int hipdrt_destroy(hipdrt_ctx* ctx) try {
     if (!ctx) return HIPDRT_OK;
     std::lock_guard<std::mutex> lk(g_life);
     if (ctx->plans > 0) { ctx->released = true; return HIPDRT_OK; }     // the last plan's destruction frees it
     free_ctx(ctx);
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 void* hipdrt_stream(hipdrt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-int hipdrt_synchronize(hipdrt_ctx* ctx) {
+int hipdrt_synchronize(hipdrt_ctx* ctx) try {
     HIPDRT_REQUIRE(ctx, "ctx is NULL");
     HIPDRT_CHECK(hipStreamSynchronize(ctx->stream));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_device_info(hipdrt_ctx* ctx, char* arch, int arch_len, int* num_cu, long long* hbm_bytes) {
+int hipdrt_device_info(hipdrt_ctx* ctx, char* arch, int arch_len, int* num_cu, long long* hbm_bytes) try {
     HIPDRT_REQUIRE(ctx, "ctx is NULL");
     if (arch && arch_len > 0) { std::strncpy(arch, ctx->arch.c_str(), arch_len - 1); arch[arch_len - 1] = 0; }
     if (num_cu) *num_cu = ctx->num_cu;
     if (hbm_bytes) *hbm_bytes = (long long)ctx->hbm_bytes;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 // ---- stand-alone operators --------------------------------------------------------------------------------
 
 int hipdrt_impedance_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, const double* wt_re,
-                            const double* wt_im, double* z_re, double* z_im) {
+                            const double* wt_im, double* z_re, double* z_im) try {
     HIPDRT_REQUIRE(ctx && wt_re && wt_im && z_re && z_im, "NULL pointer");
     HIPDRT_REQUIRE(ngrid >= 2 && ny >= 2 && ny <= 6000, "ngrid >= 2, 2 <= ny <= 6000");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -212,10 +221,10 @@ int hipdrt_impedance_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, 
     HIPDRT_CHECK(hipMemcpyAsync(z_im, dzi.p, gb, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_phasor_z_matrix(hipdrt_ctx* ctx, const double* freq, int nf, const double* basis_nu, int n_nu, double nu_epsilon,
-                           double* zm_re, double* zm_im) {
+                           double* zm_re, double* zm_im) try {
     HIPDRT_REQUIRE(ctx && freq && basis_nu && zm_re && zm_im, "NULL pointer");
     HIPDRT_REQUIRE(nf >= 1 && n_nu >= 1 && nu_epsilon > 0.0, "nf, n_nu >= 1, nu_epsilon > 0");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -231,10 +240,10 @@ int hipdrt_phasor_z_matrix(hipdrt_ctx* ctx, const double* freq, int nf, const do
     HIPDRT_CHECK(hipMemcpyAsync(zm_im, di.p, ob, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_phasor_v_matrix(hipdrt_ctx* ctx, const double* times, int nt, const double* basis_nu, int n_nu, double nu_epsilon,
-                           const double* step_times, const double* step_sizes, int nsteps, double* rm, double* layered) {
+                           const double* step_times, const double* step_sizes, int nsteps, double* rm, double* layered) try {
     HIPDRT_REQUIRE(ctx && times && basis_nu && step_times && step_sizes && rm, "NULL pointer");
     HIPDRT_REQUIRE(nt >= 1 && n_nu >= 1 && nsteps >= 1 && nu_epsilon > 0.0, "nt, n_nu, nsteps >= 1, nu_epsilon > 0");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -253,10 +262,10 @@ int hipdrt_phasor_v_matrix(hipdrt_ctx* ctx, const double* times, int nt, const d
     if (layered) HIPDRT_CHECK(hipMemcpyAsync(layered, dl.p, ob * nsteps, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_chrono_var_matrix(hipdrt_ctx* ctx, const double* tt, int nt, const int* seg, int nseg, double vmm_epsilon,
-                             int uniform, double* vmm) {
+                             int uniform, double* vmm) try {
     HIPDRT_REQUIRE(ctx && tt && seg && vmm, "NULL pointer");
     HIPDRT_REQUIRE(nt >= 1 && nseg >= 1, "nt >= 1, nseg >= 1");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -270,9 +279,9 @@ int hipdrt_chrono_var_matrix(hipdrt_ctx* ctx, const double* tt, int nt, const in
     HIPDRT_CHECK(hipMemcpyAsync(vmm, dv.p, (size_t)nt * nt * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_response_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, const double* td, double* v) {
+int hipdrt_response_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, const double* td, double* v) try {
     HIPDRT_REQUIRE(ctx && td && v, "NULL pointer");
     HIPDRT_REQUIRE(ngrid >= 2 && ny >= 2 && ny <= 6000, "ngrid >= 2, 2 <= ny <= 6000");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -286,11 +295,11 @@ int hipdrt_response_lookup(hipdrt_ctx* ctx, double epsilon, int ngrid, int ny, c
     HIPDRT_CHECK(hipMemcpyAsync(v, dv.p, gb, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_response_matrix(hipdrt_ctx* ctx, const double* times, int nt, const double* tau, int ntau,
                            const double* step_times, const double* step_sizes, int nsteps, int mode, double epsilon,
-                           int ngrid, const double* log_td, const double* v, int ny, double* a, double* layered) {
+                           int ngrid, const double* log_td, const double* v, int ny, double* a, double* layered) try {
     HIPDRT_REQUIRE(ctx && times && tau && step_times && step_sizes && a, "NULL pointer");
     HIPDRT_REQUIRE(nt >= 1 && ntau >= 1 && nsteps >= 1, "nt, ntau, nsteps >= 1");
     HIPDRT_REQUIRE(mode == HIPDRT_MODE_INTERP || mode == HIPDRT_MODE_TRAPZ, "mode must be INTERP or TRAPZ");
@@ -324,7 +333,7 @@ int hipdrt_response_matrix(hipdrt_ctx* ctx, const double* times, int nt, const d
     if (layered) HIPDRT_CHECK(hipMemcpyAsync(layered, dl.p, ab * nsteps, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 // lut6 = {log_wt_re, z_re, slope_re, log_wt_im, z_im, slope_im}
 static int build_lut6(hipStream_t st, DevBuf& lut6, int ngrid, const double* log_wt_re, const double* z_re,
@@ -382,16 +391,16 @@ int hipdrt_impedance_matrix_dev(hipdrt_ctx* ctx, int B, int freq_batched, const 
                                 const double* tau, int ntau, int mode, int toeplitz, double epsilon, int ngrid,
                                 const double* log_wt_re, const double* z_re, const double* log_wt_im,
                                 const double* z_im, int ny, void* a_re_dev, void* a_im_dev, int repeat,
-                                float* elapsed_ms) {
+                                float* elapsed_ms) try {
     return impedance_matrix_common(ctx, B, freq_batched, freq, nf, tau, ntau, mode, toeplitz, epsilon, ngrid,
                                    log_wt_re, z_re, log_wt_im, z_im, ny, (double*)a_re_dev, (double*)a_im_dev, repeat,
                                    elapsed_ms);
-}
+} HIPDRT_CATCH
 
 int hipdrt_impedance_matrix(hipdrt_ctx* ctx, int B, int freq_batched, const double* freq, int nf, const double* tau,
                             int ntau, int mode, int toeplitz, double epsilon, int ngrid, const double* log_wt_re,
                             const double* z_re, const double* log_wt_im, const double* z_im, int ny, double* a_re,
-                            double* a_im) {
+                            double* a_im) try {
     HIPDRT_REQUIRE(ctx && a_re && a_im, "NULL pointer");
     HIPDRT_REQUIRE(B >= 1 && nf >= 1 && ntau >= 1, "B, nf, ntau >= 1");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -403,12 +412,12 @@ int hipdrt_impedance_matrix(hipdrt_ctx* ctx, int B, int freq_batched, const doub
     HIPDRT_CHECK(hipMemcpy(a_re, dre.p, bytes, hipMemcpyDeviceToHost));
     HIPDRT_CHECK(hipMemcpy(a_im, dim.p, bytes, hipMemcpyDeviceToHost));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_nonuniform_gaussian_filter1d(hipdrt_ctx* ctx, const double* y, int n, const double* sigma, const int* seg, int nseg,
                                         const int* filtered, const double* nodes, int K, const double* node_delta,
                                         const double* weights, long long nweights, const int* woff, const int* radius,
-                                        double* out) {
+                                        double* out) try {
     HIPDRT_REQUIRE(ctx && y && sigma && seg && filtered && nodes && node_delta && weights && woff && radius && out, "NULL pointer");
     HIPDRT_REQUIRE(n >= 1 && nseg >= 1 && K >= 1 && nweights >= 1, "n, nseg, K, nweights >= 1");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -436,10 +445,10 @@ int hipdrt_nonuniform_gaussian_filter1d(hipdrt_ctx* ctx, const double* y, int n,
     HIPDRT_CHECK(hipMemcpyAsync(out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_penalty_matrices(hipdrt_ctx* ctx, const double* ln_tau, int n, double epsilon, int toeplitz, double* m0,
-                            double* m1, double* m2) {
+                            double* m1, double* m2) try {
     HIPDRT_REQUIRE(ctx && ln_tau && m0 && m1 && m2, "NULL pointer");
     HIPDRT_REQUIRE(n >= 1, "n >= 1");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -455,10 +464,10 @@ int hipdrt_penalty_matrices(hipdrt_ctx* ctx, const double* ln_tau, int n, double
     HIPDRT_CHECK(hipMemcpyAsync(m2, d2.p, bytes, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_eis_var_matrix(hipdrt_ctx* ctx, const double* freq, int nf, double vmm_epsilon, double reim_cor,
-                          int uniform, double* vmm) {
+                          int uniform, double* vmm) try {
     HIPDRT_REQUIRE(ctx && freq && vmm, "NULL pointer");
     HIPDRT_REQUIRE(nf >= 1, "nf >= 1");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -472,12 +481,12 @@ int hipdrt_eis_var_matrix(hipdrt_ctx* ctx, const double* freq, int nf, double vm
     HIPDRT_CHECK(hipMemcpyAsync(vmm, dv.p, bytes, hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 static hipdrt_qp_opts default_qp_opts() { return hipdrt_qp_opts{1e-7, 1e-6, 1e-7, 100}; }
 
 int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* P, const double* q, int h_batched,
-                    const double* h, const hipdrt_qp_opts* opts, double* x, int* iters, double* pcost, int* status) {
+                    const double* h, const hipdrt_qp_opts* opts, double* x, int* iters, double* pcost, int* status) try {
     HIPDRT_REQUIRE(ctx && P && q && h && x && status, "NULL pointer");
     HIPDRT_REQUIRE(B >= 1 && n >= 1 && n <= 4096, "B >= 1, 1 <= n <= 4096");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -524,41 +533,41 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
     HIPDRT_CHECK(hipMemcpyAsync(status, dst.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members) {
+int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members) try {
     HIPDRT_REQUIRE(ctx, "NULL pointer");
     ctx->qp_force_group = members;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_debug_qp_waves(hipdrt_ctx* ctx, int waves) {
+int hipdrt_debug_qp_waves(hipdrt_ctx* ctx, int waves) try {
     HIPDRT_REQUIRE(ctx, "NULL pointer");
     HIPDRT_REQUIRE(waves == -1 || waves == 4 || waves == 8, "waves: 4, 8 or -1");
     ctx->qp_waves = waves;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_debug_exact_zero_shortcuts(hipdrt_ctx* ctx, int on) {
+int hipdrt_debug_exact_zero_shortcuts(hipdrt_ctx* ctx, int on) try {
     HIPDRT_REQUIRE(ctx, "NULL pointer");
     ctx->zero_shortcuts = on ? 1 : 0;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n) {
+int hipdrt_debug_qp_occupancy(hipdrt_ctx* ctx, int threads, int n) try {
     if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return -1;
     return qp_occupancy(threads, n);
-}
+} HIPDRT_CATCH
 
-int hipdrt_qp_profile(hipdrt_ctx* ctx, unsigned long long* cycles, int n, int reset) {
+int hipdrt_qp_profile(hipdrt_ctx* ctx, unsigned long long* cycles, int n, int reset) try {
     HIPDRT_REQUIRE(ctx && cycles, "NULL pointer");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
     HIPDRT_CHECK(hipStreamSynchronize(ctx->stream));
     return qp_profile_read(cycles, n, reset) < 0 ? HIPDRT_E_HIP : HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_weighted_gram(hipdrt_ctx* ctx, int B, int m, int n, const double* A, const double* w, const double* b,
-                         int l2_batched, const double* l2, const double* l1, double* P, double* q) {
+                         int l2_batched, const double* l2, const double* l1, double* P, double* q) try {
     HIPDRT_REQUIRE(ctx && A && w && b && P && q, "NULL pointer");
     HIPDRT_REQUIRE(B >= 1 && m >= 1 && n >= 1, "B, m, n >= 1");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
@@ -579,7 +588,7 @@ int hipdrt_weighted_gram(hipdrt_ctx* ctx, int B, int m, int n, const double* A, 
     HIPDRT_CHECK(hipMemcpyAsync(q, dq.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 // ---- plan ---------------------------------------------------------------------------------------------------
 
@@ -661,7 +670,7 @@ static int plan_alloc_batch(hipdrt_plan* p) {
 int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double* tau, int ntau, double epsilon,
                        int mode, int toeplitz_a, int toeplitz_m, int ngrid, int ny, const double* wt_re,
                        const double* wt_im, const double* log_wt_re, const double* log_wt_im,
-                       const hipdrt_fit_opts* opts, int capacity, hipdrt_plan** out) {
+                       const hipdrt_fit_opts* opts, int capacity, hipdrt_plan** out) try {
     HIPDRT_REQUIRE(ctx && freq && tau && out, "NULL pointer");
     HIPDRT_REQUIRE(nf >= 2 && ntau >= 2 && capacity >= 1, "nf, ntau >= 2, capacity >= 1");
     HIPDRT_REQUIRE(mode == HIPDRT_MODE_INTERP || mode == HIPDRT_MODE_TRAPZ, "mode");
@@ -731,11 +740,11 @@ int hipdrt_plan_create(hipdrt_ctx* ctx, const double* freq, int nf, const double
     { std::lock_guard<std::mutex> lk(g_life); ++ctx->plans; }
     *out = p.release();
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, const double* m0, const double* m1,
                                 const double* m2, const double* vmm, const double* h, const double* l1,
-                                const double* vz_strength, const hipdrt_fit_opts* opts, int capacity, hipdrt_plan** out) {
+                                const double* vz_strength, const hipdrt_fit_opts* opts, int capacity, hipdrt_plan** out) try {
     HIPDRT_REQUIRE(ctx && d && m0 && m1 && m2 && vmm && h && l1 && out, "NULL pointer");
     HIPDRT_REQUIRE(d->m >= 2 && d->n >= 2 && d->ns >= 0 && d->ns < d->n && capacity >= 1, "m, n >= 2, 0 <= ns < n, capacity >= 1");
     HIPDRT_REQUIRE(d->n <= 4096, "n <= 4096");
@@ -776,9 +785,9 @@ int hipdrt_plan_create_prepared(hipdrt_ctx* ctx, const hipdrt_prepared_desc* d, 
     { std::lock_guard<std::mutex> lk(g_life); ++ctx->plans; }
     *out = p.release();
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_upload_prepared(hipdrt_plan* p, int B, int rm_batched, const double* rzm, const double* rzv) {
+int hipdrt_plan_upload_prepared(hipdrt_plan* p, int B, int rm_batched, const double* rzm, const double* rzv) try {
     HIPDRT_REQUIRE(p && rzm && rzv, "NULL pointer");
     HIPDRT_REQUIRE(p->prepared, "not a prepared plan");
     HIPDRT_REQUIRE(B >= 1 && B <= p->capacity, "1 <= B <= capacity");
@@ -798,9 +807,9 @@ int hipdrt_plan_upload_prepared(hipdrt_plan* p, int B, int rm_batched, const dou
     p->B = B;
     p->prepped = 0;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const double* row_factors, int batched) {
+int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const double* row_factors, int batched) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(weight_factor > 0.0, "weight_factor > 0");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
@@ -817,18 +826,18 @@ int hipdrt_plan_set_weight_factors(hipdrt_plan* p, double weight_factor, const d
     if (p->has_weight_factors() && !p->w_eff.p) HIPDRT_CHECK(p->w_eff.alloc((size_t)p->capacity * p->m * sizeof(double)));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_set_init_h(hipdrt_plan* p, const double* h_init) {
+int hipdrt_plan_set_init_h(hipdrt_plan* p, const double* h_init) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     if (!h_init) { p->h_init.release(); return HIPDRT_OK; }
     TRY(upload(p->h_init, h_init, (size_t)p->n * sizeof(double), p->ctx->stream));
     HIPDRT_CHECK(hipStreamSynchronize(p->ctx->stream));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_destroy(hipdrt_plan* plan) {
+int hipdrt_plan_destroy(hipdrt_plan* plan) try {
     if (!plan) return HIPDRT_OK;
     std::lock_guard<std::mutex> lk(g_life);
     hipdrt_ctx* ctx = plan->ctx;
@@ -836,15 +845,15 @@ int hipdrt_plan_destroy(hipdrt_plan* plan) {
     delete plan;
     if (--ctx->plans == 0 && ctx->released) free_ctx(ctx);
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_dims(hipdrt_plan* plan, int* n, int* m, int* ns) {
+int hipdrt_plan_dims(hipdrt_plan* plan, int* n, int* m, int* ns) try {
     HIPDRT_REQUIRE(plan, "plan is NULL");
     if (n) *n = plan->n;
     if (m) *m = plan->m;
     if (ns) *ns = plan->ns;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 static int copy_strided(double* out, const double* dev, int rows, int cols, int ld, hipStream_t st) {
     HIPDRT_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), dev, (size_t)ld * sizeof(double),
@@ -853,7 +862,7 @@ static int copy_strided(double* out, const double* dev, int rows, int cols, int 
     return 0;
 }
 
-int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long count) {
+int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long count) try {
     HIPDRT_REQUIRE(p && which && out, "NULL pointer");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     hipStream_t st = p->ctx->stream;
@@ -880,9 +889,9 @@ int hipdrt_plan_get(hipdrt_plan* p, const char* which, double* out, long long co
     HIPDRT_REQUIRE(src != nullptr, "matrix not available in this mode");
     HIPDRT_REQUIRE(count == (long long)rows * cols, "count does not match the matrix size");
     return copy_strided(out, src, rows, cols, ld, st);
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_set_lookup(hipdrt_plan* p, const double* z_re, const double* z_im) {
+int hipdrt_plan_set_lookup(hipdrt_plan* p, const double* z_re, const double* z_im) try {
     HIPDRT_REQUIRE(p && z_re && z_im, "NULL pointer");
     HIPDRT_REQUIRE(p->mode == HIPDRT_MODE_INTERP, "plan is not in interp mode");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
@@ -893,9 +902,9 @@ int hipdrt_plan_set_lookup(hipdrt_plan* p, const double* z_re, const double* z_i
     TRY(plan_build_matrices(p, false));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_upload(hipdrt_plan* p, int B, const double* z_re, const double* z_im) {
+int hipdrt_plan_upload(hipdrt_plan* p, int B, const double* z_re, const double* z_im) try {
     HIPDRT_REQUIRE(p && z_re && z_im, "NULL pointer");
     HIPDRT_REQUIRE(!p->prepared, "prepared plans take hipdrt_plan_upload_prepared");
     HIPDRT_REQUIRE(B >= 1 && B <= p->capacity, "1 <= B <= capacity");
@@ -907,7 +916,7 @@ int hipdrt_plan_upload(hipdrt_plan* p, int B, const double* z_re, const double* 
     HIPDRT_CHECK(hipStreamSynchronize(st));
     p->B = B;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 // L2 part of P in hyper-parameter form (calculate_qp_l2_matrix, qphb.py:53-120) for the plan's current state
 static GramL2 plan_l2(const hipdrt_plan* p, double l2_lambda_0, const double* derivative_weights, double dop_l2_lambda_0) {
@@ -1234,14 +1243,14 @@ static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb)
     return HIPDRT_OK;
 }
 
-int hipdrt_plan_set_subbatches(hipdrt_plan* p, int k) {
+int hipdrt_plan_set_subbatches(hipdrt_plan* p, int k) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(k >= 0 && k <= 16, "0 (automatic) <= k <= 16");
     p->subbatches = k;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_fit(hipdrt_plan* p) {
+int hipdrt_plan_fit(hipdrt_plan* p) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no spectra staged (call hipdrt_plan_upload)");
     const int k = subbatch_count(p);
@@ -1293,7 +1302,7 @@ int hipdrt_plan_fit(hipdrt_plan* p) {
     p->t_ms[0] = wall_ms; p->launches[0] = 1;
     p->prepped = 1;
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored, double scalar_w = 1.0);
 
@@ -1301,12 +1310,12 @@ int hipdrt_plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) { retu
 
 int hipdrt_plan_obs_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w) { return plan_llh_terms(p, rss, sum_log_w, 1); }
 
-int hipdrt_plan_obs_llh_terms_w(hipdrt_plan* p, int weights_mode, double scalar_weight, double* rss, double* sum_log_w) {
+int hipdrt_plan_obs_llh_terms_w(hipdrt_plan* p, int weights_mode, double scalar_weight, double* rss, double* sum_log_w) try {
     HIPDRT_REQUIRE(weights_mode == HIPDRT_LLH_W_EST || weights_mode == HIPDRT_LLH_W_UNIFORM || weights_mode == HIPDRT_LLH_W_SCALAR,
                    "weights_mode");
     HIPDRT_REQUIRE(weights_mode != HIPDRT_LLH_W_SCALAR || scalar_weight > 0.0, "scalar weight must be positive");
     return plan_llh_terms(p, rss, sum_log_w, weights_mode, scalar_weight);
-}
+} HIPDRT_CATCH
 
 static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int stored, double scalar_w) {
     HIPDRT_REQUIRE(p && rss && sum_log_w, "NULL pointer");
@@ -1324,7 +1333,7 @@ static int plan_llh_terms(hipdrt_plan* p, double* rss, double* sum_log_w, int st
     return HIPDRT_OK;
 }
 
-int hipdrt_plan_set_state(hipdrt_plan* p, const double* x, const double* rho, const double* s, const double* weights) {
+int hipdrt_plan_set_state(hipdrt_plan* p, const double* x, const double* rho, const double* s, const double* weights) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
@@ -1339,9 +1348,9 @@ int hipdrt_plan_set_state(hipdrt_plan* p, const double* x, const double* rho, co
     if (weights) HIPDRT_CHECK(hipMemcpyAsync(p->w.p, weights, B * m * sizeof(double), hipMemcpyHostToDevice, st));
     HIPDRT_CHECK(hipStreamSynchronize(st));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_set_state_dop(hipdrt_plan* p, const double* dop_rho) {
+int hipdrt_plan_set_state_dop(hipdrt_plan* p, const double* dop_rho) try {
     HIPDRT_REQUIRE(p && dop_rho, "NULL pointer");
     HIPDRT_REQUIRE(p->prepared && p->desc.dop_size > 0, "the plan has no distribution of phasances");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
@@ -1349,7 +1358,7 @@ int hipdrt_plan_set_state_dop(hipdrt_plan* p, const double* dop_rho) {
     HIPDRT_CHECK(hipMemcpyAsync(p->dop_rho.p, dop_rho, (size_t)p->B * 3 * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
     HIPDRT_CHECK(hipStreamSynchronize(p->ctx->stream));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 // QP arguments of the outer loop: one P per spectrum in the packed tile layout, the loop's constraint vector
 static QpArgs loop_qp_args(hipdrt_plan* p, const hipdrt_qp_opts& qpo) {
@@ -1373,7 +1382,7 @@ static QpArgs loop_qp_args(hipdrt_plan* p, const hipdrt_qp_opts& qpo) {
 // (1314-1318), the DOP pass runs as in the fit, and the vz_offset column is rewritten after every iteration from a matrix
 // whose offset column is FROZEN as this call found it (1295-1298, 1353-1357: the reference copies rm at entry, zeroing the
 // baseline columns only; the fit itself copied while the column was still zero).  The plan's scalar weight_factor is not used.
-int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double weight_factor, int min_iter) {
+int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double weight_factor, int min_iter) try {
     HIPDRT_REQUIRE(p && opts, "NULL pointer");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
     HIPDRT_REQUIRE(opts->max_iter >= 1 && min_iter >= 1, "max_iter, min_iter >= 1");
@@ -1456,14 +1465,14 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     HIPDRT_CHECK(hipStreamSynchronize(st));
     tm.collect(p->t_ms, p->launches);
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 // qphb.iterate_qphb (hybdrt/models/qphb.py:606-972) for every staged measurement of a prepared plan: the QP on
 // (weights, s_vectors, rho) as given, then the s / rho / DOP hyper-parameter pass, estimate_weights and is_converged
 // against x_in.  What _qphb_fit_core does around the call (xmx norms of the first iteration, data rescaling, the
 // vz_offset column; drt1d.py:903-979) is not part of it.
 int hipdrt_plan_iterate(hipdrt_plan* p, const hipdrt_iterate_state* in, int* converged, int* qp_status, int* qp_iters,
-                        double* primal_objective) {
+                        double* primal_objective) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->prepared, "hipdrt_plan_iterate works on prepared plans (the caller's rm, rv as iterate_qphb takes them)");
     HIPDRT_REQUIRE(p->B >= 1, "no measurements staged (call hipdrt_plan_upload_prepared)");
@@ -1520,18 +1529,18 @@ int hipdrt_plan_iterate(hipdrt_plan* p, const hipdrt_iterate_state* in, int* con
     if (converged) for (int b = 0; b < B; ++b) converged[b] = act[b] == 0;
     tm.collect(p->t_ms, p->launches);
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_timings(hipdrt_plan* p, float* t, int* launches) {
+int hipdrt_plan_timings(hipdrt_plan* p, float* t, int* launches) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     if (t) std::memcpy(t, p->t_ms, sizeof(p->t_ms));
     if (launches) std::memcpy(launches, p->launches, sizeof(p->launches));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_plan_download(hipdrt_plan* p, double* x, double* fit_x, double* r_inf, double* induc, double* weights,
                          double* coef_scale, double* rho, double* s_vectors, double* q_vector, int* outer_iters,
-                         int* qp_iters_total, int* status) {
+                         int* qp_iters_total, int* status) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "nothing fitted");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
@@ -1557,9 +1566,9 @@ int hipdrt_plan_download(hipdrt_plan* p, double* x, double* fit_x, double* r_inf
     if (qp_iters_total) HIPDRT_CHECK(hipMemcpy(qp_iters_total, p->qp_iters_total.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
     if (status) HIPDRT_CHECK(hipMemcpy(status, p->fit_status.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
+int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) try {
     HIPDRT_REQUIRE(p && out, "NULL pointer");
     HIPDRT_REQUIRE(b >= 0 && b < p->B, "spectrum index out of range");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
@@ -1573,7 +1582,7 @@ int hipdrt_plan_get_p_matrix(hipdrt_plan* p, int b, double* out) {
                    p->ldp, 0, nullptr);
     LAUNCH_OK();
     return copy_strided(out, p->Ptmp.d(), n, n, p->ldp, st);
-}
+} HIPDRT_CATCH
 
 // out[b][i] = rows_i' P_b^-1 rows_i * cs_b^2 for the fitted batch; rows[nrow][ncol] sits at columns col_offset.. of the
 // unknown vector (zero elsewhere)
@@ -1671,31 +1680,31 @@ static int plan_full_cov(hipdrt_plan* p, int b, const double* rows, int neval, i
     return HIPDRT_OK;
 }
 
-int hipdrt_plan_distribution_cov(hipdrt_plan* p, int b, const double* basis_eval, int neval, double* out, int* status) {
+int hipdrt_plan_distribution_cov(hipdrt_plan* p, int b, const double* basis_eval, int neval, double* out, int* status) try {
     HIPDRT_REQUIRE(p && basis_eval && out, "NULL pointer");
     return plan_full_cov(p, b, basis_eval, neval, p->ntau, p->ns, out, status);
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_param_cov(hipdrt_plan* p, int b, double* out, int* status) {
+int hipdrt_plan_param_cov(hipdrt_plan* p, int b, double* out, int* status) try {
     HIPDRT_REQUIRE(p && out, "NULL pointer");
     const int n = p->n;
     std::vector<double> eye((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) eye[(size_t)i * n + i] = 1.0;
     return plan_full_cov(p, b, eye.data(), n, n, 0, out, status);
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_distribution_var(hipdrt_plan* p, const double* basis_eval, int neval, double* out, int* status) {
+int hipdrt_plan_distribution_var(hipdrt_plan* p, const double* basis_eval, int neval, double* out, int* status) try {
     HIPDRT_REQUIRE(p && basis_eval && out, "NULL pointer");
     return plan_quadratic_forms(p, basis_eval, neval, p->ntau, p->ns, out, status);
-}
+} HIPDRT_CATCH
 
-int hipdrt_plan_param_var(hipdrt_plan* p, double* out, int* status) {
+int hipdrt_plan_param_var(hipdrt_plan* p, double* out, int* status) try {
     HIPDRT_REQUIRE(p && out, "NULL pointer");
     const int n = p->n;
     std::vector<double> eye((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) eye[(size_t)i * n + i] = 1.0;
     return plan_quadratic_forms(p, eye.data(), n, n, 0, out, status);
-}
+} HIPDRT_CATCH
 
 // history buffers for `rows` outer iterations (grown when a later call asks for more than the first one did)
 static int plan_hist_reserve(hipdrt_plan* p, int rows) {
@@ -1711,15 +1720,15 @@ static int plan_hist_reserve(hipdrt_plan* p, int rows) {
     return HIPDRT_OK;
 }
 
-int hipdrt_plan_record_history(hipdrt_plan* p, int b) {
+int hipdrt_plan_record_history(hipdrt_plan* p, int b) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     p->hist_b = b;
     return plan_hist_reserve(p, p->opts.max_iter);
-}
+} HIPDRT_CATCH
 
 int hipdrt_plan_get_history(hipdrt_plan* p, double* hist_x, double* hist_rho, double* hist_w, int* qp_iters,
-                            int max_rows, int* rows) {
+                            int max_rows, int* rows) try {
     HIPDRT_REQUIRE(p && rows, "NULL pointer");
     HIPDRT_REQUIRE(p->hist_b >= 0 && p->hist_cap > 0, "history recording was not enabled");
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
@@ -1732,14 +1741,14 @@ int hipdrt_plan_get_history(hipdrt_plan* p, double* hist_x, double* hist_rho, do
     if (hist_rho) HIPDRT_CHECK(hipMemcpy(hist_rho, p->hist_rho.p, (size_t)r * 3 * sizeof(double), hipMemcpyDeviceToHost));
     if (qp_iters) HIPDRT_CHECK(hipMemcpy(qp_iters, p->hist_qp.p, (size_t)(r + 1) * sizeof(int), hipMemcpyDeviceToHost));
     return HIPDRT_OK;
-}
+} HIPDRT_CATCH
 
 int hipdrt_fit_eis_batch(hipdrt_ctx* ctx, int B, const double* freq, int nf, const double* z_re, const double* z_im,
                          const double* tau, int ntau, double epsilon, int mode, int toeplitz_a, int toeplitz_m,
                          int ngrid, int ny, const double* wt_re, const double* wt_im, const double* log_wt_re,
                          const double* log_wt_im, const hipdrt_fit_opts* opts, double* x, double* fit_x, double* r_inf,
                          double* induc, double* weights, double* coef_scale, double* rho, double* q_vector,
-                         int* outer_iters, int* status) {
+                         int* outer_iters, int* status) try {
     hipdrt_plan* p = nullptr;
     TRY(hipdrt_plan_create(ctx, freq, nf, tau, ntau, epsilon, mode, toeplitz_a, toeplitz_m, ngrid, ny, wt_re, wt_im,
                            log_wt_re, log_wt_im, opts, B, &p));
@@ -1749,6 +1758,6 @@ int hipdrt_fit_eis_batch(hipdrt_ctx* ctx, int B, const double* freq, int nf, con
                                        outer_iters, nullptr, status);
     hipdrt_plan_destroy(p);
     return rc;
-}
+} HIPDRT_CATCH
 
 }  // extern "C"

@@ -1003,7 +1003,9 @@ __global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int 
             // fetch_add returns -- finds the bit, or somebody arrived meanwhile and the member looks again).  "All arrived,
             // not poisoned" can therefore not be seen by one member and missed by another; the late ones, whenever they
             // get a CU, find the bit and leave before they have touched anything but their own scratch.
-            int seen = __hip_atomic_fetch_add(&ops.gs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            // (release: the fetch_or of this member's XCC bit above is ordered before its count; the readers below acquire on
+            // the count, so "all G arrived" implies all G bits are visible -- two relaxed atomics on different words would not)
+            int seen = __hip_atomic_fetch_add(&ops.gs[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
             int spins = 0;
             while (!(seen & kNotResident) && seen < G) {
                 __builtin_amdgcn_s_sleep(2);
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void qp_kernel_group(QpArgs a, int NP, int 
                     seen = expected;                         // the count moved: judge the new value
                     continue;
                 }
-                seen = __hip_atomic_load(&ops.gs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                seen = __hip_atomic_load(&ops.gs[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             }
             // the XCC mask is complete once every member has arrived (a member ORs its bit in before it counts itself)
             xcc_mask = (seen & kNotResident) ? kNotResident

@@ -494,16 +494,30 @@ def _unpack_block(block):
     return obs_x, special, cols, ti, var, vok
 
 
-def _one_kernel(drt, members):
-    """pin (members = 0: one workgroup per problem, the batch kernel) or release (-1) the coneqp kernel choice of `drt` and its
-    sibling clones; plans made under the other choice are dropped (their scratch layout follows the kernel)"""
+def _one_kernel(drt, members, saved=None):
+    """pin (members = 0: one workgroup per problem, the batch kernel) the coneqp kernel choice of `drt` and its sibling clones,
+    or give back what each context held before (``saved`` = the list a pinning call returned).  Only plans made under ANOTHER
+    choice are dropped (their scratch layout follows the kernel); the contexts are the instances' own -- an instance on the
+    process-wide default context gets a private one first, so that no other DRT object or thread sees the switch."""
     from .. import _ffi
-    for d in [drt] + list(getattr(drt, '_sibling_clones', None) or []):
-        ctx = d._context if d._context is not None else _ffi.get_context(d.device)
-        ctx.debug_qp_group(members)
-        if getattr(d, '_plan', None) is not None:
-            d._plan.close()
-            d._plan = d._plan_key = None
+    held = []
+    for k, d in enumerate([drt] + list(getattr(drt, '_sibling_clones', None) or [])):
+        if d._context is None:                       # never switch the shared default context under other users' feet
+            d._context = _ffi.Context(d.device)
+            if getattr(d, '_plan', None) is not None:
+                d._plan.close()
+                d._plan = d._plan_key = None
+        ctx = d._context
+        before = getattr(ctx, '_qp_group_override', -1)
+        want = members if saved is None else saved[k]
+        held.append(before)
+        if want != before:
+            ctx.debug_qp_group(want)
+            ctx._qp_group_override = want
+            if getattr(d, '_plan', None) is not None:
+                d._plan.close()
+                d._plan = d._plan_key = None
+    return held
 
 
 def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world=None, tau_supergrid=None, scheme='interleave',
@@ -531,14 +545,16 @@ def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world
     its size (n <= 2048; small shares then fit slower, ~1.2 x for a single spectrum): the gathered map is then bit-identical
     for every world size, shard scheme and `inflight`."""
     from . import dist as hd
-    if reproducible and fit is fit_observations:
-        _one_kernel(drt, 0)
+    if reproducible:
+        if fit is not fit_observations:
+            raise ValueError("reproducible=True pins the device kernel of mapping.fit_observations; it cannot do that for another `fit`")
+        saved = _one_kernel(drt, 0)
         try:
             return fit_observations_sharded(drt, frequencies, z_obs, rank=rank, world=world, tau_supergrid=tau_supergrid,
                                             scheme=scheme, drt_var=drt_var, dst=dst, fit=fit, inflight=inflight,
                                             observations=observations, ignore_errors=ignore_errors, **fit_kw)
         finally:
-            _one_kernel(drt, -1)
+            _one_kernel(drt, 0, saved)
     if rank is None or world is None:
         import torch.distributed as tdist
         rank = tdist.get_rank() if tdist.is_initialized() else 0

@@ -917,3 +917,42 @@ def test_full_covariance_of_a_joint_fit_with_dop():
     dcov = drt.estimate_distribution_cov(ppd=10)
     var, _ = drt.estimate_distribution_var_batch(ppd=10)
     parity("dist_cov_diag", np.diag(dcov), var[0], default=1e-9, rel=True, floor=1e-9)
+
+
+def test_posterior_entry_points_after_a_warm_restart_with_row_factors():
+    """hipdrt_plan_continue on a prepared plan with chrono / eis row factors used to scale the weights in
+    place and leave w_eff -- what hipdrt_plan_get_p_matrix / _param_cov / _param_var build P from -- as the FIRST fit's scaled
+    weights (or uninitialised when the factors came with the restart).  Now the restart ends by refreshing it: P after a
+    restart is calculate_pq's construction on the restart's final state (last re-estimated weights x the factors its QPs saw,
+    last s / rho, the rewritten matrix), q_vector to match.  Checked against numpy on the downloaded state, with factors that
+    were set by the fit AND with factors first introduced by the restart."""
+    from hipdrt.models import DRT
+    from hipdrt import synth
+    meas = synth.hybrid_measurement(seed=0)
+    for fit_kw, cont_kw in ((dict(eis_weight_factor=2.0, chrono_weight_factor=0.5), dict()),
+                            (dict(), dict(eis_weight_factor=1.7, chrono_weight_factor=0.6))):
+        drt = DRT(warn=False)
+        drt.fit_hybrid(*meas, **fit_kw)
+        p_fit = drt.fit_parameters["p_matrix"].copy()
+        res = drt._continue_prepared(max_iter=3, weight_factor=1.3, **cont_kw)
+        plan, prep = drt._plan, drt._prep
+        nc, m, n = prep["num_chrono"], prep["m"], plan.n
+        cf = cont_kw.get("chrono_weight_factor", prep["chrono_weight_factor"])
+        ef = cont_kw.get("eis_weight_factor", prep["chrono_weight_factor"])      # (upstream's fallback: the CHRONO factor for both)
+        rows = np.concatenate([np.full(nc, cf), np.full(m - nc, ef)])
+        w_eff = res["weights"][0] * rows * 1.3
+        rm = plan.get("rzm")
+        rm = rm[0] if rm.ndim == 3 else rm
+        hyp = orc.get_default_hypers()
+        pen = [drt.qphb_params["penalty_matrices"][f"m{k}"] for k in range(3)]
+        ns = n - len(drt.basis_tau)
+        l2 = orc.calculate_qp_l2_matrix(hyp, res["rho"][0], pen, list(res["s_vectors"][0]), ns)
+        wrm = w_eff[:, None] * rm
+        p_ref = wrm.T @ wrm + l2
+        pm = plan.p_matrix(0)
+        assert np.abs(pm - p_ref).max() <= 1e-10 * np.abs(p_ref).max()
+        assert np.abs(pm - p_fit).max() > 1e-3 * np.abs(p_fit).max()            # (not the first fit's matrix any more)
+        q_ref = -wrm.T @ (w_eff * prep["rzv"] if "rzv" in prep else w_eff * drt.qphb_params["rv"])
+        assert np.abs(res["q_vector"][0] - q_ref).max() <= 1e-9 * np.abs(q_ref).max()
+        cov, ok = plan.param_cov(0)
+        assert ok and np.abs(cov - np.linalg.inv(p_ref)).max() <= 1e-7 * np.abs(np.linalg.inv(p_ref)).max()

@@ -95,6 +95,18 @@ SIGNATURES = {
     "hipdrt_debug_qp_group": [_vp, C.c_int],
     "hipdrt_debug_exact_zero_shortcuts": [_vp, C.c_int],
     "hipdrt_debug_qp_waves": [_vp, C.c_int],
+    "hipdrt_comm_unique_id": [C.c_char_p],
+    "hipdrt_comm_create": [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)],
+    "hipdrt_comm_destroy": [_vp],
+    "hipdrt_comm_info": [_vp, _ip, _ip, _ip],
+    "hipdrt_comm_broadcast_dev": [_vp, _vp, C.c_longlong, C.c_int],
+    "hipdrt_comm_gather_dev": [_vp, _vp, C.c_longlong, _vp, C.c_int],
+    "hipdrt_comm_broadcast": [_vp, _dp, C.c_longlong, C.c_int],
+    "hipdrt_comm_gather": [_vp, _dp, C.c_longlong, _dp, C.c_int],
+    "hipdrt_comm_allreduce_max": [_vp, _dp],
+    "hipdrt_comm_barrier": [_vp],
+    "hipdrt_device_alloc": [_vp, C.c_longlong, C.POINTER(_vp)],
+    "hipdrt_device_free": [_vp, _vp],
     "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

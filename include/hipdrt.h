@@ -38,6 +38,7 @@ extern "C" {
 
 typedef struct hipdrt_ctx hipdrt_ctx;
 typedef struct hipdrt_plan hipdrt_plan;
+typedef struct hipdrt_comm hipdrt_comm;
 
 /* ---- context -------------------------------------------------------------------------------------- */
 int hipdrt_create(int device, hipdrt_ctx** out);
@@ -398,6 +399,33 @@ int hipdrt_fit_eis_batch(hipdrt_ctx* ctx, int B, const double* freq, int nf, con
                          const hipdrt_fit_opts* opts, double* x, double* fit_x,
                          double* r_inf, double* induc, double* weights, double* coef_scale, double* rho,
                          double* q_vector, int* outer_iters, int* status);
+
+/* ---- one map over the GPUs of a node: RCCL behind the C ABI -------------------------------------------------------------
+ * The reference fits the observations of a map one after the other in ONE process (DRTMD.fit_observations,
+ * hybdrt/mapping/drtmd.py:303-319); they share only the lookup tables, the tau supergrid and cached matrices (245-301).  Here a
+ * map is sharded over one process per GPU; the two exchanges that needs are a broadcast of rank 0's lookup tables and ONE gather
+ * of the per-observation result rows.  librccl.so is loaded on first use.  Rendezvous: rank 0 calls hipdrt_comm_unique_id and
+ * gets its 128 bytes to the other ranks by any out-of-band channel (hybrid-drt_amd/mapping/dist.py: a file next to
+ * MASTER_PORT); every rank then calls hipdrt_comm_create with the same bytes (collective: returns when all `world` ranks did). */
+#define HIPDRT_COMM_ID_BYTES 128
+int hipdrt_comm_unique_id(char* id128);
+int hipdrt_comm_create(int device, int rank, int world, const char* id128, hipdrt_comm** out);
+int hipdrt_comm_destroy(hipdrt_comm* comm);
+int hipdrt_comm_info(hipdrt_comm* comm, int* rank, int* world, int* device);
+/* device buffers in, device buffers out.  broadcast: `count` doubles of `root` to everyone, in place.  gather: every rank
+ * sends `count` doubles, `root` receives world x count (rank r's block at r * count; dev_recv may be NULL elsewhere) -- a
+ * true gather, one ncclSend per rank and `world` ncclRecv on the root inside one group.  Both return when the data is there. */
+int hipdrt_comm_broadcast_dev(hipdrt_comm* comm, double* dev_buf, long long count, int root);
+int hipdrt_comm_gather_dev(hipdrt_comm* comm, const double* dev_send, long long count, double* dev_recv, int root);
+/* the same for host arrays (numpy in, numpy out), staged through the communicator's own device buffers */
+int hipdrt_comm_broadcast(hipdrt_comm* comm, double* host_buf, long long count, int root);
+int hipdrt_comm_gather(hipdrt_comm* comm, const double* host_send, long long count, double* host_recv, int root);
+/* max over the ranks of *value, in every rank (a benchmark's "slowest rank" time); value == NULL: a plain barrier */
+int hipdrt_comm_allreduce_max(hipdrt_comm* comm, double* value);
+int hipdrt_comm_barrier(hipdrt_comm* comm);
+/* device memory for callers that keep matrices resident (hipdrt_impedance_matrix_dev and the *_dev collectives take it) */
+int hipdrt_device_alloc(hipdrt_ctx* ctx, long long bytes, void** out);
+int hipdrt_device_free(hipdrt_ctx* ctx, void* ptr);
 
 #ifdef __cplusplus
 }

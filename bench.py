@@ -287,7 +287,8 @@ def main():
                          "nccl group exercises RCCL, the device binding and the staging on a one-GPU box)")
     ap.add_argument("--batch", type=int, default=1024, help="c3: spectra per GPU per step")
     ap.add_argument("--total", type=int, default=10000, help="c4: spectra of the whole map")
-    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' lets several "
+    ap.add_argument("--backend", default=None, help="collectives: rccl (default: RCCL behind the C ABI, no torch), nccl / gloo = "
+                                                    "torch.distributed's backends; 'gloo' lets several "
                                                     "ranks share one GPU for a functional check of the N > 1 path")
     ap.add_argument("--shard", choices=("block", "interleave", "lpt"), default="interleave", help="c4: shard scheme")
     ap.add_argument("--inflight", type=lambda v: v if v == "auto" else int(v), default=None,
@@ -335,18 +336,23 @@ def main():
         cpu = cpu_baseline(freq, tau, synth.zarc2_batch(freq, 64, first_seed=0), procs=args.cpu_procs)
 
     import threading
-    import torch
     from hipdrt import _ffi
     from hipdrt.mapping import dist as hd
     from hipdrt.mapping.drtmd import shard_indices
     from hipdrt.models import DRT
 
+    # (no torch in this process unless --backend nccl / gloo asks for torch.distributed: device memory, streams, events and the
+    # collectives all sit behind the C ABI -- include/hipdrt.h)
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if args.backend == "gloo":
-        local %= torch.cuda.device_count()               # functional check: ranks may share a GPU
-    torch.cuda.set_device(local)
+        ndev = next((i for i in range(64) if not _ffi.device_usable(i)), 64)
+        local %= max(ndev, 1)                            # functional check: ranks may share a GPU
+    if not _ffi.device_usable(local):
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    sync_ctx = _ffi.Context(local)
+
+    def device_sync():                                   # hipDeviceSynchronize: what torch.cuda.synchronize() is
+        sync_ctx.device_synchronize()
     try:
         # before any fit has touched the GPU: a backend that does not come up ends the run here, non-zero, nothing is restarted
         rank, world, _ = hd.init_from_env(backend=args.backend, device=local, force=args.force_dist)
@@ -432,7 +438,7 @@ def main():
             note(i)
 
     def sync_all():
-        torch.cuda.synchronize()
+        device_sync()
         for p_ in plans:
             p_.ctx.synchronize()
 
@@ -509,11 +515,11 @@ def main():
         for _ in range(max(1, args.warmup) if promote else 1):
             run4()                                                      # builds the sibling plans; warm-up map(s)
         hd.barrier()
-        torch.cuda.synchronize()
+        device_sync()
         t0 = time.perf_counter()
         for _ in range(maps4):
             got4 = run4()            # upload, fit, llh / rss, download on every rank + ONE gather: returns when rank 0 holds the map
-        torch.cuda.synchronize()
+        device_sync()
         hd.barrier()
         el4 = hd.max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
@@ -639,6 +645,9 @@ def main():
                 "note": "same K steps from ONE caller thread on ONE plan (one plan's memory): hipdrt_plan_fit cuts the staged batch "
                         "into ranges that run side by side on the plan's own streams (hipdrt_plan_set_subbatches, automatic)"},
             "scale_reference": scale_ref,
+            # how the ranks talk: 'rccl' = RCCL behind the C ABI (hipdrt_comm_*), 'nccl' / 'gloo' = torch.distributed; None = one
+            # rank, no group.  The native path never imports torch.
+            "collectives": {"backend": hd.backend(), "forced_one_rank_group": bool(hd.forced()), "torch_imported": "torch" in sys.modules},
             "with_transfers": None if transfer_elapsed is None else {
                 "value": world * B * c3_steps / transfer_elapsed, "ms_per_step": transfer_elapsed / c3_steps * 1e3,
                 "note": "same K steps with the upload of the spectra and the download of all results inside every step"},
@@ -648,13 +657,13 @@ def main():
             Bm = 512
             fb = np.sort(10 ** np.random.default_rng(0).uniform(-1, 6, size=(Bm, 256)), axis=1)[:, ::-1].copy()
             lk = drt.interpolate_lookups
-            dre = torch.empty((Bm, 256, 512), dtype=torch.float64, device=f"cuda:{local}")
-            dim = torch.empty_like(dre)
-            plan.ctx.impedance_matrix_timed(fb, tau, drt.tau_epsilon, dre.data_ptr(), dim.data_ptr(),
-                                            lookups=(lk["z_real"], lk["z_imag"]), repeat=1)
+            dre, dim = plan.ctx.device_alloc(Bm * 256 * 512 * 8), plan.ctx.device_alloc(Bm * 256 * 512 * 8)
+            plan.ctx.impedance_matrix_timed(fb, tau, drt.tau_epsilon, dre, dim, lookups=(lk["z_real"], lk["z_imag"]), repeat=1)
             reps = 10
-            ms = plan.ctx.impedance_matrix_timed(fb, tau, drt.tau_epsilon, dre.data_ptr(), dim.data_ptr(),
-                                                 lookups=(lk["z_real"], lk["z_imag"]), repeat=reps)
+            ms = plan.ctx.impedance_matrix_timed(fb, tau, drt.tau_epsilon, dre, dim, lookups=(lk["z_real"], lk["z_imag"]),
+                                                 repeat=reps)
+            plan.ctx.device_free(dre)
+            plan.ctx.device_free(dim)
             byts = Bm * 2 * 256 * 512 * 8
             gbs = byts * reps / (ms / 1e3) / 1e9
             out["matrix_build_roofline"] = {"bound": "hbm", "kernel": "impedance_interp_kernel",
@@ -768,9 +777,7 @@ def main():
     # the JSON line is the LAST thing this job writes to stdout: RCCL prints its banner through C stdio, which is block-buffered
     # on a pipe and would otherwise be flushed at exit, behind the line
     hd.barrier()
-    import torch.distributed as dist
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    hd.destroy()
     _flush_c_stdio()
     if rank == 0:
         print(json.dumps(out), flush=True)

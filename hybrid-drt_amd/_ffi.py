@@ -107,6 +107,7 @@ SIGNATURES = {
     "hipdrt_comm_barrier": [_vp],
     "hipdrt_device_alloc": [_vp, C.c_longlong, C.POINTER(_vp)],
     "hipdrt_device_free": [_vp, _vp],
+    "hipdrt_device_synchronize": [_vp],
     "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -385,6 +386,19 @@ class Context:
                                               _p(out["weights"]), _p(out["coefficient_scale"]), _p(out["rho"]),
                                               _p(out["q_vector"]), _pi(out["outer_iters"]), _pi(out["status"])))
         return out
+
+    def device_alloc(self, nbytes):
+        """device memory as an integer pointer (hipdrt_device_alloc): for the *_dev entry points; free with device_free"""
+        ptr = _vp()
+        _check(self._lib.hipdrt_device_alloc(self._h, int(nbytes), C.byref(ptr)))
+        return ptr.value
+
+    def device_free(self, ptr):
+        _check(self._lib.hipdrt_device_free(self._h, _vp(ptr)))
+
+    def device_synchronize(self):
+        """hipDeviceSynchronize on this context's device (every stream, every context of the process on that GPU)"""
+        _check(self._lib.hipdrt_device_synchronize(self._h))
 
     def debug_qp_group(self, members):
         """tests / diagnostics: force the workgroups per problem of this context's coneqp launches sized from now on
@@ -702,6 +716,71 @@ class PreparedPlan(Plan):
 
 
 _default_ctx = {}
+
+
+def device_usable(device: int = 0) -> bool:
+    """can this process open gfx950 device `device`? (no exception: mapping.dist picks its default backend with it)"""
+    try:
+        lib = load_library()
+    except HipDrtError:
+        return False
+    h = _vp()
+    if lib.hipdrt_create(int(device), C.byref(h)) != 0:
+        return False
+    lib.hipdrt_destroy(h)
+    return True
+
+
+def comm_unique_id() -> bytes:
+    """128 opaque bytes of a fresh RCCL communicator id (rank 0 makes them, every rank passes them to Comm)"""
+    buf = C.create_string_buffer(128)
+    _check(load_library().hipdrt_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (include/hipdrt.h: hipdrt_comm_*): one per process, numpy in / numpy out"""
+
+    def __init__(self, device, rank, world, unique_id):
+        self._lib = load_library()
+        self._h = _vp()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        if len(unique_id) != 128:
+            raise HipDrtError("a RCCL unique id has 128 bytes")
+        _check(self._lib.hipdrt_comm_create(self.device, self.rank, self.world, C.c_char_p(bytes(unique_id)), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.hipdrt_comm_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 (interpreter shutdown)
+            pass
+
+    def broadcast(self, array, root=0):
+        """`array` (contiguous float64) of `root` into every rank's `array`, in place"""
+        if not (isinstance(array, np.ndarray) and array.dtype == np.float64 and array.flags.c_contiguous):
+            raise HipDrtError("broadcast needs a C-contiguous float64 array (it is filled in place)")
+        _check(self._lib.hipdrt_comm_broadcast(self._h, _p(array), array.size, int(root)))
+        return array
+
+    def gather(self, block, root=0):
+        """every rank's `block` (same size everywhere) to `root`: returns (world, block.size) there, None elsewhere"""
+        block = _f64(block).ravel()
+        out = np.empty((self.world, block.size)) if self.rank == root else None
+        _check(self._lib.hipdrt_comm_gather(self._h, _p(block), block.size, _p(out), int(root)))
+        return out
+
+    def allreduce_max(self, value):
+        v = C.c_double(float(value))
+        _check(self._lib.hipdrt_comm_allreduce_max(self._h, C.byref(v)))
+        return v.value
+
+    def barrier(self):
+        _check(self._lib.hipdrt_comm_barrier(self._h))
 
 
 def get_context(device: int = 0) -> Context:

@@ -238,6 +238,14 @@ int hipdrt_device_alloc(hipdrt_ctx* ctx, long long bytes, void** out) try {
     return HIPDRT_OK;
 } COMM_CATCH
 
+// every stream of the context's device drained (hipDeviceSynchronize: what a benchmark brackets its timed region with)
+int hipdrt_device_synchronize(hipdrt_ctx* ctx) try {
+    HIPDRT_REQUIRE(ctx, "NULL pointer");
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
+    HIPDRT_CHECK(hipDeviceSynchronize());
+    return HIPDRT_OK;
+} COMM_CATCH
+
 int hipdrt_device_free(hipdrt_ctx* ctx, void* ptr) try {
     HIPDRT_REQUIRE(ctx, "NULL pointer");
     HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();

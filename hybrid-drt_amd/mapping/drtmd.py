@@ -556,9 +556,7 @@ def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world
         finally:
             _one_kernel(drt, 0, saved)
     if rank is None or world is None:
-        import torch.distributed as tdist
-        rank = tdist.get_rank() if tdist.is_initialized() else 0
-        world = tdist.get_world_size() if tdist.is_initialized() else 1
+        rank, world = hd.get_rank(), hd.get_world_size()
     general = observations is not None
     if general:
         num = len(observations)

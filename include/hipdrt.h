@@ -426,6 +426,8 @@ int hipdrt_comm_barrier(hipdrt_comm* comm);
 /* device memory for callers that keep matrices resident (hipdrt_impedance_matrix_dev and the *_dev collectives take it) */
 int hipdrt_device_alloc(hipdrt_ctx* ctx, long long bytes, void** out);
 int hipdrt_device_free(hipdrt_ctx* ctx, void* ptr);
+/* hipDeviceSynchronize on the context's device: every stream drained (a benchmark brackets its timed region with it)       */
+int hipdrt_device_synchronize(hipdrt_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -349,10 +349,9 @@ def main():
         local %= max(ndev, 1)                            # functional check: ranks may share a GPU
     if not _ffi.device_usable(local):
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    sync_ctx = _ffi.Context(local)
 
     def device_sync():                                   # hipDeviceSynchronize: what torch.cuda.synchronize() is
-        sync_ctx.device_synchronize()
+        plans[0].ctx.device_synchronize()                # (any context of the device will do; no context of its own: no extra stream)
     try:
         # before any fit has touched the GPU: a backend that does not come up ends the run here, non-zero, nothing is restarted
         rank, world, _ = hd.init_from_env(backend=args.backend, device=local, force=args.force_dist)

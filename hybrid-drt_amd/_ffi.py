@@ -108,6 +108,7 @@ SIGNATURES = {
     "hipdrt_device_alloc": [_vp, C.c_longlong, C.POINTER(_vp)],
     "hipdrt_device_free": [_vp, _vp],
     "hipdrt_device_synchronize": [_vp],
+    "hipdrt_device_probe": [C.c_int],
     "hipdrt_weighted_gram": [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp],
     "hipdrt_default_fit_opts": [C.POINTER(FitOpts)],
     "hipdrt_plan_create": [_vp, _dp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -155,6 +156,12 @@ def load_library():
     global _lib
     with _lock:
         if _lib is None:
+            # The HIP runtime deals streams onto 4 hardware queues by default; plans / ranges whose streams share a queue run one
+            # behind the other (four plans in flight: 2420 instead of 2620 fits/s when two of them meet on one queue, which depends
+            # on how many streams the process happened to create before -- profiles/r06_ab_bench_legs.txt).  The variable is read
+            # when the runtime starts, i.e. at the first HIP call of the process: set here, as a default the caller's environment
+            # overrides, it takes effect unless something else in the process has started HIP already.
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
             if not os.path.exists(LIB_PATH):
                 raise HipDrtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                                   f"g.build()'` (hipdrt has no CPU fallback)")
@@ -719,16 +726,13 @@ _default_ctx = {}
 
 
 def device_usable(device: int = 0) -> bool:
-    """can this process open gfx950 device `device`? (no exception: mapping.dist picks its default backend with it)"""
+    """can this process open gfx950 device `device`? (no exception, and nothing is created on the device -- not even a stream:
+    streams are dealt to the hardware queues in the order they are made; mapping.dist picks its default backend with this)"""
     try:
         lib = load_library()
     except HipDrtError:
         return False
-    h = _vp()
-    if lib.hipdrt_create(int(device), C.byref(h)) != 0:
-        return False
-    lib.hipdrt_destroy(h)
-    return True
+    return lib.hipdrt_device_probe(int(device)) == 0
 
 
 def comm_unique_id() -> bytes:

@@ -238,6 +238,15 @@ int hipdrt_device_alloc(hipdrt_ctx* ctx, long long bytes, void** out) try {
     return HIPDRT_OK;
 } COMM_CATCH
 
+// 0 when device `device` exists and is a gfx950 part; creates nothing on it (no context, no stream)
+int hipdrt_device_probe(int device) try {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { (void)hipGetLastError(); return HIPDRT_E_NODEVICE; }
+    hipDeviceProp_t prop;
+    HIPDRT_CHECK(hipGetDeviceProperties(&prop, device));
+    return std::string(prop.gcnArchName).rfind("gfx950", 0) == 0 ? HIPDRT_OK : HIPDRT_E_NODEVICE;
+} COMM_CATCH
+
 // every stream of the context's device drained (hipDeviceSynchronize: what a benchmark brackets its timed region with)
 int hipdrt_device_synchronize(hipdrt_ctx* ctx) try {
     HIPDRT_REQUIRE(ctx, "NULL pointer");

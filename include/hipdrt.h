@@ -428,6 +428,8 @@ int hipdrt_device_alloc(hipdrt_ctx* ctx, long long bytes, void** out);
 int hipdrt_device_free(hipdrt_ctx* ctx, void* ptr);
 /* hipDeviceSynchronize on the context's device: every stream drained (a benchmark brackets its timed region with it)       */
 int hipdrt_device_synchronize(hipdrt_ctx* ctx);
+/* 0 when device `device` exists and is a gfx950 part (HIPDRT_E_NODEVICE otherwise); creates nothing on the device                */
+int hipdrt_device_probe(int device);
 
 #ifdef __cplusplus
 }

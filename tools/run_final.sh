@@ -1,6 +1,6 @@
 # final measurement set of a round: tools/collect_profiles.sh + the c4 leg on one GPU + the two-rank gloo functional check (self-launched,
 # no torchrun) + single fits + SQ counters + the full-size fuzz + the GPU test suite + smoke
-cd $GRAFT_REPO_ROOT; O=gpurun_out; T=${1:-r05}
+cd $GRAFT_REPO_ROOT; O=gpurun_out; T=${1:-r06}
 bash tools/collect_profiles.sh $T
 timeout 900 python bench.py --config c4 --no-cpu-baseline --no-other-configs > $O/bench_${T}_c4.json 2> $O/bench_${T}_c4.err; tail -1 $O/bench_${T}_c4.json | cut -c1-300
 timeout 900 python bench.py --gpus 2 --backend gloo --config c4 --total 2000 --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > $O/bench_${T}_gloo2.json 2> $O/bench_${T}_gloo2.err; tail -1 $O/bench_${T}_gloo2.json | cut -c1-400

@@ -382,6 +382,63 @@ def main():
         B = len(mine)
         job_fits = total
 
+    # ---- BASELINE configs[3] on this N: the headline (`value`) with --config auto, `scale_reference` beside a c3 headline --------
+    # WHERE in the process this runs matters by 4 %: the HIP runtime deals every new stream to the least-used hardware queue, and a
+    # map whose three plans' streams wrap around the queue ring (created behind six others with 8 queues, behind two with 4)
+    # measures 2500 instead of 2605 fits/s (tools/probe_hw_queues.py, profiles/r06_hw_queue_placement.txt).  It is called behind
+    # the multi-plan configs[2] legs (four streams) and in front of the one-caller leg (two more).
+    def run_scale_reference():
+        scale_ref = None
+        if config == "c3" and not args.no_scale_reference:
+            from hipdrt.mapping.drtmd import auto_inflight, fit_observations_sharded
+            mine4 = shard_indices(args.total, world, rank, args.shard)
+            z4 = np.zeros((args.total, len(freq)), dtype=complex)          # every rank holds its own rows only
+            if len(mine4):
+                z4[mine4] = np.concatenate([synth.zarc2_batch(freq, 1, first_seed=int(i)) for i in mine4])
+            nfl4 = auto_inflight(len(mine4)) if args.inflight in (None, "auto") else args.inflight
+            d4 = DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local))
+            run4 = lambda: fit_observations_sharded(d4, freq, z4, rank=rank, world=world, scheme=args.shard, inflight=nfl4)  # noqa: E731
+            maps4 = args.steps if promote else args.scale_steps
+            for _ in range(max(1, args.warmup) if promote else 1):
+                run4()                                                      # builds the sibling plans; warm-up map(s)
+            hd.barrier()
+            d4._context.device_synchronize()
+            t0 = time.perf_counter()
+            for _ in range(maps4):
+                got4 = run4()            # upload, fit, llh / rss, download on every rank + ONE gather: returns when rank 0 holds the map
+            d4._context.device_synchronize()
+            hd.barrier()
+            el4 = hd.max_over_ranks(time.perf_counter() - t0)
+            if rank == 0:
+                # (a reference leg must not take the headline line down: what is wrong with the map is reported in its place)
+                ok4 = got4[0].shape == (args.total, len(tau)) and bool(np.isfinite(got4[0]).all()) and bool(got4[2]["obs_fit_status"].all())
+                scale_ref = {"value": args.total * maps4 / el4, "unit": "fits/s", "scaling": "strong",
+                             "seconds_per_map": el4 / maps4, "maps_timed": maps4, "n_gpus": world,
+                             "spectra_per_rank": [len(shard_indices(args.total, world, r, args.shard)) for r in range(world)],
+                             "batches_in_flight_per_gpu": nfl4,
+                             "workload": (f"BASELINE configs[3]: one map of {args.total} synthetic 2-ZARC spectra (256 x 512) sharded "
+                                          f"over {world} rank(s) ({args.shard} shards) by mapping.fit_observations_sharded: per map "
+                                          f"upload + full QPHB loop + llh / rss + download on every rank and one gather on rank 0, all "
+                                          f"timed (inputs start in HOST memory)")}
+                if not ok4:
+                    scale_ref["error"] = "the gathered map is incomplete (shape, non-finite coefficients or a failed fit)"
+            # plans, contexts and their streams go NOW (not whenever the collector gets to them): the configs[2] legs below then find
+            # every hardware queue unused, as a fresh process would
+            import gc
+            for d_ in [d4] + list(getattr(d4, "_sibling_clones", None) or []):
+                if getattr(d_, "_plan", None) is not None:
+                    d_._plan.close()
+                    d_._plan = d_._plan_key = None
+                if d_._context is not None:
+                    d_._context.close()
+            del d4, z4
+            gc.collect()
+
+
+        return scale_ref
+
+    scale_ref = None
+
     # one DRT + plan + HIP stream per in-flight batch
     if config == "c3":
         drts = [DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local)) for _ in range(nfl)]
@@ -481,6 +538,9 @@ def main():
         single_elapsed = timed_c3(1, worker_resident)               # one batch in flight: un-overlapped launches
         qp_ms, qp_launch = stats[0]["qp_ms"], stats[0]["qp_launch"]
         phase = dict(stats[0]["phase"])
+        # the configs[3] map: behind the four configs[2] plans' streams (queues 0..3: its three land on 4, 5, 6) and in front of
+        # the one-caller leg, whose ranges make two more streams
+        scale_ref = run_scale_reference() if not args.no_scale_reference else None
         if not args.no_single_caller:
             plans[0].set_subbatches(0)                              # one caller, one plan, the library cuts the batch into ranges
             one_caller_elapsed = timed_c3(1, worker_resident)
@@ -498,43 +558,6 @@ def main():
             obs_x, obs_special, res_all = gathered
             assert obs_x.shape == (args.total, len(tau)) and np.isfinite(obs_x).all() and res_all["obs_fit_status"].all()
             res = {k: res_all[k][mine] for k in ("outer_iters", "qp_iters_total", "status")}     # this rank's share
-
-    # ---- BASELINE configs[3] beside the headline, on every N (one workload per curve, and the other one visible) ----
-    scale_ref = None
-    if config == "c3" and not args.no_scale_reference:
-        from hipdrt.mapping.drtmd import auto_inflight, fit_observations_sharded
-        mine4 = shard_indices(args.total, world, rank, args.shard)
-        z4 = np.zeros((args.total, len(freq)), dtype=complex)          # every rank holds its own rows only
-        if len(mine4):
-            z4[mine4] = np.concatenate([synth.zarc2_batch(freq, 1, first_seed=int(i)) for i in mine4])
-        nfl4 = auto_inflight(len(mine4)) if args.inflight in (None, "auto") else args.inflight
-        d4 = DRT(fixed_basis_tau=tau, device=local, context=_ffi.Context(local))
-        run4 = lambda: fit_observations_sharded(d4, freq, z4, rank=rank, world=world, scheme=args.shard, inflight=nfl4)  # noqa: E731
-        maps4 = args.steps if promote else args.scale_steps
-        for _ in range(max(1, args.warmup) if promote else 1):
-            run4()                                                      # builds the sibling plans; warm-up map(s)
-        hd.barrier()
-        device_sync()
-        t0 = time.perf_counter()
-        for _ in range(maps4):
-            got4 = run4()            # upload, fit, llh / rss, download on every rank + ONE gather: returns when rank 0 holds the map
-        device_sync()
-        hd.barrier()
-        el4 = hd.max_over_ranks(time.perf_counter() - t0)
-        if rank == 0:
-            # (a reference leg must not take the headline line down: what is wrong with the map is reported in its place)
-            ok4 = got4[0].shape == (args.total, len(tau)) and bool(np.isfinite(got4[0]).all()) and bool(got4[2]["obs_fit_status"].all())
-            scale_ref = {"value": args.total * maps4 / el4, "unit": "fits/s", "scaling": "strong",
-                         "seconds_per_map": el4 / maps4, "maps_timed": maps4, "n_gpus": world,
-                         "spectra_per_rank": [len(shard_indices(args.total, world, r, args.shard)) for r in range(world)],
-                         "batches_in_flight_per_gpu": nfl4,
-                         "workload": (f"BASELINE configs[3]: one map of {args.total} synthetic 2-ZARC spectra (256 x 512) sharded "
-                                      f"over {world} rank(s) ({args.shard} shards) by mapping.fit_observations_sharded: per map "
-                                      f"upload + full QPHB loop + llh / rss + download on every rank and one gather on rank 0, all "
-                                      f"timed (inputs start in HOST memory)")}
-            if not ok4:
-                scale_ref["error"] = "the gathered map is incomplete (shape, non-finite coefficients or a failed fit)"
-        del d4, z4
 
     n, m = plan.n, plan.m
     out = None

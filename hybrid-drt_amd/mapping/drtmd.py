@@ -73,6 +73,9 @@ def drt_siblings(drt, count):
     return ([drt] + clones)[:count]
 
 
+_RANGES_PER_INFLIGHT_PLAN = 1      # (tools/probe_inflight_ranges.py sweeps it)
+
+
 def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid, drt_var, ignore_errors, llh_kw, rss_kw, fit_kw):
     """The observations in `inflight` contiguous chunks, each chunk one device batch on its own sibling plan, the host
     threads overlapping their device loops: spectra finish after 4 ... 50 outer iterations, so one batch alone leaves
@@ -92,7 +95,7 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
             sib._plan.set_subbatches(k)
 
     for sib in sibs:
-        pin(sib, 1)
+        pin(sib, _RANGES_PER_INFLIGHT_PLAN)
     outs, errs = [None] * len(chunks), [None] * len(chunks)
 
     def work(i):

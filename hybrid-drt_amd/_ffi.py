@@ -95,6 +95,7 @@ SIGNATURES = {
     "hipdrt_debug_qp_group": [_vp, C.c_int],
     "hipdrt_debug_exact_zero_shortcuts": [_vp, C.c_int],
     "hipdrt_debug_qp_waves": [_vp, C.c_int],
+    "hipdrt_debug_stream_pool": [_vp, C.c_int, C.POINTER(C.c_void_p), _ip, _ip, _ip],
     "hipdrt_comm_unique_id": [C.c_char_p],
     "hipdrt_comm_create": [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)],
     "hipdrt_comm_destroy": [_vp],
@@ -156,11 +157,12 @@ def load_library():
     global _lib
     with _lock:
         if _lib is None:
-            # The HIP runtime deals streams onto 4 hardware queues by default; plans / ranges whose streams share a queue run one
-            # behind the other (four plans in flight: 2420 instead of 2620 fits/s when two of them meet on one queue, which depends
-            # on how many streams the process happened to create before -- profiles/r06_ab_bench_legs.txt).  The variable is read
-            # when the runtime starts, i.e. at the first HIP call of the process: set here, as a default the caller's environment
-            # overrides, it takes effect unless something else in the process has started HIP already.
+            # The HIP runtime maps streams onto 4 hardware queues by default (one of them the null stream's).  libhipdrt creates
+            # its streams once per device, one per remaining queue, and deals them to contexts and to the ranges of a fit by
+            # activity and compute pipe (csrc/api.hip: StreamPool; profiles/r06_trace_queue_placement.txt) -- with 8 queues it has
+            # seven streams over the four pipes, enough for four ranges or four plans side by side on a pipe each; with 4 it
+            # has three.  The variable is read when the runtime starts, i.e. at the first HIP call of the process: set here, as
+            # a default the caller's environment overrides, it takes effect unless something else in the process has started HIP.
             os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
             if not os.path.exists(LIB_PATH):
                 raise HipDrtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
@@ -417,6 +419,16 @@ class Context:
         """tests / tools: 4 = this context's batch coneqp launches (n <= 528) use the fat four-wavefront kernel, 8 = the
         eight-wavefront one, -1 = the library's choice (hipdrt_debug_qp_waves, include/hipdrt_debug.h)"""
         _check(self._lib.hipdrt_debug_qp_waves(self._h, int(waves)))
+
+    def debug_stream_pool(self):
+        """tests: (streams, holders, running) of the library's own streams on this context's device
+        (hipdrt_debug_stream_pool, include/hipdrt_debug.h)"""
+        size = C.c_int(0)
+        _check(self._lib.hipdrt_debug_stream_pool(self._h, 0, None, None, None, C.byref(size)))
+        n = size.value
+        st, ho, ru = (C.c_void_p * n)(), (C.c_int * n)(), (C.c_int * n)()
+        _check(self._lib.hipdrt_debug_stream_pool(self._h, n, st, ho, ru, C.byref(size)))
+        return [st[i] for i in range(n)], [ho[i] for i in range(n)], [ru[i] for i in range(n)]
 
     def debug_exact_zero_shortcuts(self, on):
         """tests: with on = False this context's fits visit the penalty matrices' exact zeros as well (same bits, slower)

@@ -113,7 +113,7 @@ struct hipdrt_subfit {
     hipdrt_plan view;
     int rc = 0;
     std::string err;
-    ~hipdrt_subfit() { if (ctx.stream) (void)hipStreamDestroy(ctx.stream); }
+    // (ctx.stream is borrowed from the library's pool for the duration of one fit: hipdrt_plan_fit)
 };
 hipdrt_plan::~hipdrt_plan() = default;
 
@@ -138,6 +138,137 @@ static int plan_hist_reserve(hipdrt_plan* p, int rows);
 static int plan_toep_reach(hipdrt_plan* p);
 
 const char* hipdrt_last_error(void) { return g_err.c_str(); }
+
+// what the environment promises about the runtime's hardware-queue count (read when the runtime started; 4 when unset)
+static int hw_queues_hint() {
+    static const int q = [] { const char* e = std::getenv("GPU_MAX_HW_QUEUES"); const int v = e ? std::atoi(e) : 4; return v > 0 ? std::min(v, 32) : 4; }();
+    return q;
+}
+
+// ---- the library's own streams ------------------------------------------------------------------------------------------
+// The HIP runtime maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says otherwise), and two
+// launch sequences on ONE queue run one behind the other.  Its rule, read off rocprofv3's queue ids (tools/queue_map_probe.sh,
+// profiles/r06_queue_map.txt): queue 1 belongs to the null stream; a new stream gets a NEW queue while fewer than the maximum
+// exist, afterwards the LAST queue among those with the fewest streams -- counting idle streams like busy ones.  So the stream that
+// fills the pool and the one created right after it share a queue, and any two streams created one pool's length apart do:
+//   * four ranges of one plan behind three or five other (idle!) streams land on three queues, two of them back to back:
+//     1778 fits/s instead of 2304 (tools/trace_queue_placement.sh, profiles/r06_trace_queue_placement.txt);
+//   * two plans in flight whose contexts were created seven streams apart share queue 8: 1730 instead of 2266
+//     (profiles/r06_trace_plans_placement.txt);
+//   * the "wrapped" placements of profiles/r06_hw_queue_placement.txt (-4 %) and round 5's "three and four ranges flip between
+//     fast and slow".
+// The library therefore creates its streams ONCE per device -- as many as queues are left beside the null stream's, each on a
+// queue of its own when nothing else has created streams before -- and hands them out itself, by ACTIVITY: a context holds one
+// for its lifetime (the one with the fewest holders), the ranges of a fit borrow the ones with the fewest device loops running
+// for the duration of that fit.  Idle contexts and idle plans no longer push active ones onto shared queues.
+// HIPDRT_STREAM_POOL=<n> sets the count (1 ... 32).
+extern "C++" {
+namespace {
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> st;
+    std::vector<int> holders, running;
+};
+
+StreamPool* stream_pool(int device) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, StreamPool*>> pools;         // (never freed: the streams live as long as the process)
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& pr : pools) if (pr.first == device) return pr.second;
+    int n = std::max(2, hw_queues_hint() - 1);
+    if (const char* e = std::getenv("HIPDRT_STREAM_POOL")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) n = v; }
+    auto* pl = new StreamPool();
+    int before = 0;
+    (void)hipGetDevice(&before);
+    (void)hipSetDevice(device);
+    for (int i = 0; i < n; ++i) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        pl->st.push_back(st);
+    }
+    (void)hipSetDevice(before);
+    pl->holders.assign(pl->st.size(), 0);
+    pl->running.assign(pl->st.size(), 0);
+    pools.emplace_back(device, pl);
+    return pl;
+}
+
+// Streams whose queues sit on the same compute pipe of the command processor take turns at dispatching: queues are dealt to
+// the four pipes in creation order, so pool streams i and i + 4 are such a pair, and four ranges on queues of pipes 1, 2, 3, 1
+// measure 2205 fits/s where pipes 0 ... 3 measure 2300 (profiles/r06_trace_queue_placement.txt, second half: every placement the
+// trace shows as "four queues" but slow has two ranges one pipe apart).
+constexpr int kPipes = 4;
+
+// the stream for one more device loop: none running on it, the fewest loops running on its pipe, the fewest holders, the lowest index
+int pool_pick(const StreamPool& pl) {
+    int on_pipe[kPipes] = {0, 0, 0, 0};
+    for (int i = 0; i < (int)pl.st.size(); ++i) on_pipe[i % kPipes] += pl.running[i];
+    auto better = [&](int a, int b) {
+        if (pl.running[a] != pl.running[b]) return pl.running[a] < pl.running[b];
+        if (on_pipe[a % kPipes] != on_pipe[b % kPipes]) return on_pipe[a % kPipes] < on_pipe[b % kPipes];
+        return pl.holders[a] < pl.holders[b];
+    };
+    int best = 0;
+    for (int i = 1; i < (int)pl.st.size(); ++i) if (better(i, best)) best = i;
+    return best;
+}
+
+// a context's stream for its lifetime
+bool pool_hold(hipdrt_ctx* c) {
+    StreamPool* pl = stream_pool(c->device);
+    if (pl->st.empty()) return false;
+    std::lock_guard<std::mutex> lock(pl->mu);
+    int best = 0;
+    for (int i = 1; i < (int)pl->st.size(); ++i) if (pl->holders[i] < pl->holders[best]) best = i;
+    ++pl->holders[best];
+    c->stream = pl->st[best];
+    c->pool_idx = best;
+    return true;
+}
+void pool_drop(hipdrt_ctx* c) {
+    if (c->pool_idx < 0) return;
+    StreamPool* pl = stream_pool(c->device);
+    std::lock_guard<std::mutex> lock(pl->mu);
+    --pl->holders[c->pool_idx];
+    c->pool_idx = -1; c->stream = nullptr;
+}
+// a device loop starts / ends on stream `idx` (a fit on the context's own stream)
+void pool_running(int device, int idx, int delta) {
+    if (idx < 0) return;
+    StreamPool* pl = stream_pool(device);
+    std::lock_guard<std::mutex> lock(pl->mu);
+    pl->running[idx] += delta;
+}
+// k streams for the ranges of one fit, the least busy first (more ranges than streams: they repeat)
+void pool_borrow(int device, int k, int* idx, hipStream_t* st) {
+    StreamPool* pl = stream_pool(device);
+    std::lock_guard<std::mutex> lock(pl->mu);
+    for (int i = 0; i < k; ++i) {
+        idx[i] = pool_pick(*pl);
+        ++pl->running[idx[i]];
+        st[i] = pl->st[idx[i]];
+    }
+}
+int pool_size(int device) { return (int)stream_pool(device)->st.size(); }
+void pool_return(int device, int k, const int* idx) {
+    StreamPool* pl = stream_pool(device);
+    std::lock_guard<std::mutex> lock(pl->mu);
+    for (int i = 0; i < k; ++i) --pl->running[idx[i]];
+}
+struct LoopOnContextStream {       // RAII: "a device loop runs on this context's stream" for the ranges of other fits to avoid
+    hipdrt_ctx* c;
+    explicit LoopOnContextStream(hipdrt_ctx* c_) : c(c_) { pool_running(c->device, c->pool_idx, +1); }
+    ~LoopOnContextStream() { pool_running(c->device, c->pool_idx, -1); }
+};
+}  // namespace
+}
+
+extern "C++" {
+namespace hipdrt {
+// (comm.hip: a communicator made before the first context must not take one of the queues the pool would get)
+void ensure_stream_pool(int device) { (void)stream_pool(device); }
+}
+}
 
 int hipdrt_create(int device, hipdrt_ctx** out) try {
     HIPDRT_REQUIRE(out != nullptr, "out is NULL");
@@ -165,8 +296,7 @@ int hipdrt_create(int device, hipdrt_ctx** out) try {
         const int w = std::atoi(wv);
         if (w == 4 || w == 8) c->qp_waves = w;
     }
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; set_error(hipGetErrorString(e)); return HIPDRT_E_HIP; }
+    if (!pool_hold(c)) { delete c; set_error("no HIP stream could be created on device " + std::to_string(device)); return HIPDRT_E_HIP; }
     *out = c;
     return HIPDRT_OK;
 } HIPDRT_CATCH
@@ -175,7 +305,8 @@ static std::mutex g_life;          // context / plan creation and destruction (a
 
 static void free_ctx(hipdrt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);      // (the stream itself belongs to the library's pool)
+    pool_drop(ctx);
     delete ctx;
 }
 
@@ -538,6 +669,19 @@ int hipdrt_qp_batch(hipdrt_ctx* ctx, int B, int n, int p_batched, const double* 
 int hipdrt_debug_qp_group(hipdrt_ctx* ctx, int members) try {
     HIPDRT_REQUIRE(ctx, "NULL pointer");
     ctx->qp_force_group = members;
+    return HIPDRT_OK;
+} HIPDRT_CATCH
+
+int hipdrt_debug_stream_pool(hipdrt_ctx* ctx, int cap, void** streams, int* holders, int* running, int* size) try {
+    HIPDRT_REQUIRE(ctx && size && cap >= 0, "NULL pointer");
+    StreamPool* pl = stream_pool(ctx->device);
+    std::lock_guard<std::mutex> lock(pl->mu);
+    *size = (int)pl->st.size();
+    for (int i = 0; i < std::min(cap, *size); ++i) {
+        if (streams) streams[i] = pl->st[i];
+        if (holders) holders[i] = pl->holders[i];
+        if (running) running[i] = pl->running[i];
+    }
     return HIPDRT_OK;
 } HIPDRT_CATCH
 
@@ -1192,7 +1336,15 @@ static int subbatch_count(const hipdrt_plan* p) {
     // GPU_MAX_HW_QUEUES=8 in the process environment every range has its own queue and k = 2 / 3 / 4 measure 2285 / 2281 / 2330
     // at 1250 spectra (profiles/r05x_ab_hw_queues.txt) -- the library cannot set that for its host (it is read when the HIP
     // runtime starts), so it keeps the choice that is right with either setting.
-    int k = p->subbatches >= 1 ? std::min(p->subbatches, std::max(1, p->B / 64)) : (p->B >= 600 ? 2 : 1);
+    // Round 6: the ranges run on the library's own streams, picked per fit by activity and compute pipe (StreamPool above), so every
+    // range has a queue and a pipe to itself whatever else the process has created (profiles/r06_trace_queue_placement.txt: 2254 ...
+    // 2324 fits/s in all placements tried, against 1778 with two ranges on one queue and 2205 with two on one pipe), and FOUR ranges
+    // from 1000 spectra on are the best cut (profiles/r06_subbatch_sweep.txt, k = 1 / 2 / 3 / 4 / 6: 1024 spectra 2048 / 2262 / 2261 /
+    // 2320 / 2214, 1250: 2150 / 2368 / 2351 / 2422 / 2317, 2500: 2392 / 2556 / 2587 / 2600 / 2524; six lose: four pipes) -- as many
+    // as the pool has streams: three under the runtime's default of 4 hardware queues, four with GPU_MAX_HW_QUEUES >= 5 (the host
+    // layer's loader exports 8 unless its caller has set the variable).
+    const int k_auto = p->B >= 1000 ? std::min(4, pool_size(p->ctx->device)) : (p->B >= 600 ? 2 : 1);
+    int k = p->subbatches >= 1 ? std::min(p->subbatches, std::max(1, p->B / 64)) : k_auto;
     // the promise is "the bits of the un-split fit": the whole batch AND the smallest range must choose the batch coneqp kernel as
     // the views will see it (qp_layout runs qp_group_size on the view's own count with the context's current override, which may
     // have been set after the plan was allocated) -- otherwise fewer ranges, down to one
@@ -1204,10 +1356,7 @@ static int subbatch_count(const hipdrt_plan* p) {
 
 static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb) {
     hipdrt_plan& v = sf.view;
-    if (!sf.ctx.stream) {
-        sf.ctx.device = p->ctx->device; sf.ctx.num_cu = p->ctx->num_cu; sf.ctx.hbm_bytes = p->ctx->hbm_bytes; sf.ctx.arch = p->ctx->arch;
-        HIPDRT_CHECK(hipStreamCreateWithFlags(&sf.ctx.stream, hipStreamNonBlocking));
-    }
+    sf.ctx.device = p->ctx->device; sf.ctx.num_cu = p->ctx->num_cu; sf.ctx.hbm_bytes = p->ctx->hbm_bytes; sf.ctx.arch = p->ctx->arch;
     sf.ctx.qp_force_group = p->ctx->qp_force_group;
     sf.ctx.zero_shortcuts = p->ctx->zero_shortcuts;
     sf.ctx.qp_waves = p->ctx->qp_waves;
@@ -1254,7 +1403,10 @@ int hipdrt_plan_fit(hipdrt_plan* p) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(p->B >= 1, "no spectra staged (call hipdrt_plan_upload)");
     const int k = subbatch_count(p);
-    if (k <= 1) return plan_fit_one(p);
+    if (k <= 1) {
+        LoopOnContextStream busy(p->ctx);
+        return plan_fit_one(p);
+    }
     HIPDRT_CHECK(hipSetDevice(p->ctx->device)); (void)hipGetLastError();
     HIPDRT_CHECK(hipStreamSynchronize(p->ctx->stream));       // whatever staged the batch is done
     if (p->n_active_sub.bytes < (size_t)k * sizeof(int)) HIPDRT_CHECK(p->n_active_sub.alloc(16 * sizeof(int)));
@@ -1266,6 +1418,14 @@ int hipdrt_plan_fit(hipdrt_plan* p) try {
         const int b0 = (int)((long long)B * i / k), b1 = (int)((long long)B * (i + 1) / k);
         TRY(make_view(p, *p->subs[i], i, b0, b1 - b0));
     }
+    // the ranges' streams: borrowed from the library's pool for this fit, the least busy ones (the context's own may be among
+    // them: it is idle until the ranges are done)
+    struct Borrowed {
+        int device, k; int idx[16]; hipStream_t st[16];
+        Borrowed(int device_, int k_) : device(device_), k(k_) { pool_borrow(device, k, idx, st); }
+        ~Borrowed() { pool_return(device, k, idx); }
+    } streams(p->ctx->device, k);
+    for (int i = 0; i < k; ++i) p->subs[i]->ctx.stream = streams.st[i];
     const auto t0 = std::chrono::steady_clock::now();
     // no exception may cross the C ABI, and a joinable std::thread must not be destroyed: ranges whose worker thread cannot
     // be created (std::system_error) are fitted right here, on the caller's thread, after the started ones were joined
@@ -1386,6 +1546,7 @@ int hipdrt_plan_continue(hipdrt_plan* p, const hipdrt_fit_opts* opts, double wei
     HIPDRT_REQUIRE(p && opts, "NULL pointer");
     HIPDRT_REQUIRE(p->B >= 1, "no fitted batch in the plan");
     HIPDRT_REQUIRE(opts->max_iter >= 1 && min_iter >= 1, "max_iter, min_iter >= 1");
+    LoopOnContextStream busy(p->ctx);
     // rejected calls must leave the finished fit as it is: every check comes before the first write
     HIPDRT_REQUIRE(p->prepared || !p->has_weight_factors(),
                    "warm restarts take their weight_factor argument; clear the plan's weight factors");

@@ -110,6 +110,7 @@ int hipdrt_comm_create(int device, int rank, int world, const char* id128, hipdr
     HIPDRT_CHECK(hipSetDevice(device)); (void)hipGetLastError();
     auto* c = new hipdrt_comm();
     c->rank = rank; c->world = world; c->device = device;
+    hipdrt::ensure_stream_pool(device);            // the fits' streams get their hardware queues first
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; hipdrt::set_error(hipGetErrorString(e)); return HIPDRT_E_HIP; }
     ncclUniqueId id;

@@ -73,7 +73,8 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct hipdrt_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // one of the library's own streams (api.hip: StreamPool), held for the context's lifetime
+    int pool_idx = -1;
     int num_cu = 0;
     size_t hbm_bytes = 0;
     std::string arch;
@@ -94,6 +95,9 @@ struct hipdrt_ctx {
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ---------------------------------
 namespace hipdrt {
+
+// api.hip: the library's own streams (one per hardware queue) exist from here on
+void ensure_stream_pool(int device);
 
 // matrices.hip
 void launch_lookup(hipStream_t st, double eps, int ngrid, int ny, const double* wt_re, const double* wt_im,

@@ -49,12 +49,14 @@ _NOT_PER_OBS = ('basis_tau', 'timings_ms', 'launches', 'obs_tau_indices', 'obs_f
 
 
 def auto_inflight(num_obs):
-    """(Round 4: one plan cuts its batch into ranges itself -- hipdrt_plan_set_subbatches, same effect with one plan's
-    memory and one caller thread -- so inflight=1 is no longer the slow choice; this rule is kept for callers that ask for
-    'auto'.)  Batches in flight that served `num_obs` C2-size observations best on one MI355X (tools/probe_inflight.py, fits/s with
-    1 / 2 / 3 / 4 batches: 1250 obs. 1631 / 1814 / 1718 / 1473; 2500: 1792 / 1954 / 1971 / 1738; 10 000: 1994 / 2035 / 2053 /
-    1986): a batch should keep more than ~500 spectra, and more than three host threads get in each other's way."""
-    return 1 if num_obs < 512 else (2 if num_obs < 2000 else 3)
+    """Plans in flight that serve `num_obs` C2-size observations of ONE rank best.  Round 6: always ONE -- the plan cuts its batch
+    into ranges on its own streams (hipdrt_plan_set_subbatches, automatic: four from 1000 spectra on under the loader's
+    GPU_MAX_HW_QUEUES=8), which now beats every count of sibling plans with one plan's memory and one caller thread
+    (tools/probe_inflight_ranges.py, profiles/r06_inflight_ranges.txt, fits/s through fit_observations for 1 plan x 4 ranges /
+    2 plans / 3 plans: 1250 observations 2371 / 2326 / 2263, 2500: 2547 / 2515 / 2459, 10 000: 2651 / 2633 / 2616).  Rounds 3-5
+    answered 2 up to 2000 observations and 3 above (four hardware queues: profiles/r04_subbatch_sweep.txt); `inflight=k` is
+    still there for callers whose environment pins fewer queues."""
+    return 1
 
 
 def drt_siblings(drt, count):

@@ -44,7 +44,11 @@ typedef struct hipdrt_comm hipdrt_comm;
 int hipdrt_create(int device, hipdrt_ctx** out);
 int hipdrt_destroy(hipdrt_ctx* ctx);   /* with plans still alive on it the context is freed by the last hipdrt_plan_destroy */
 const char* hipdrt_last_error(void);
-/* HIP stream the ctx launches on (so callers can record events / order other work): returns hipStream_t */
+/* HIP stream the ctx launches on (so callers can record events / order other work): returns hipStream_t.
+ * The stream is one of the library's own (created once per device, one per hardware queue beside the null stream's:
+ * GPU_MAX_HW_QUEUES - 1, i.e. 3 by default and 7 under the host layer's default of 8; HIPDRT_STREAM_POOL=<n> overrides) and is
+ * held by the context for its lifetime; contexts beyond that count share streams (their work is then ordered with each other's,
+ * never wrong).  The ranges of a sub-batched hipdrt_plan_fit borrow the least busy of these streams for the duration of the call. */
 void* hipdrt_stream(hipdrt_ctx* ctx);
 int hipdrt_synchronize(hipdrt_ctx* ctx);
 /* name of the device architecture, e.g. "gfx950" */

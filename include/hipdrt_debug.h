@@ -35,6 +35,10 @@ int hipdrt_debug_qp_waves(hipdrt_ctx* ctx, int waves);
  * epilogue adds the L2 part to every tile and the hyper kernel's Toeplitz convolutions run over all columns instead of the
  * penalties' reach (csrc/gram.hip, csrc/hyper.hip).  The results are the same bits either way; tests/test_gpu_fit.py checks it. */
 int hipdrt_debug_exact_zero_shortcuts(hipdrt_ctx* ctx, int on);
+/* diagnostic (tests): the library's own streams on the context's device (hipdrt.h: hipdrt_stream) -- how many there are
+ * (return value through *size), and for the first min(*size, cap) of them the hipStream_t, the number of contexts holding it and
+ * the number of device loops running on it right now.  Any of the three arrays may be NULL.                               */
+int hipdrt_debug_stream_pool(hipdrt_ctx* ctx, int cap, void** streams, int* holders, int* running, int* size);
 
 #ifdef __cplusplus
 }

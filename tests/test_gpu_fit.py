@@ -594,6 +594,50 @@ def test_sub_batched_fit_is_bit_identical_to_the_one_range_fit():
     plan.set_subbatches(0)
 
 
+def test_contexts_and_ranges_run_on_the_librarys_own_streams():
+    """The library creates its streams once per device (one per hardware queue beside the null stream's: GPU_MAX_HW_QUEUES - 1,
+    7 under the loader's default of 8) and deals them out itself: a new context gets the stream with the fewest holders (the
+    first such one), a destroyed context gives its stream back, no device loop is marked as running once the fits have
+    returned, and a fit cut into more ranges than there are streams -- with idle contexts holding every stream -- still gives
+    the bits of the un-split fit."""
+    import os
+    from hipdrt import _ffi, synth
+    from hipdrt.models import DRT
+    base = _ffi.Context(0)
+    streams, holders, running = base.debug_stream_pool()
+    pool = len(streams)
+    assert pool == int(os.environ.get("HIPDRT_STREAM_POOL") or max(2, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) - 1))
+    assert len(set(streams)) == pool and all(streams) and base.stream in streams
+    ctxs = []
+    for _ in range(2 * pool):
+        _, holders, _ = base.debug_stream_pool()
+        expect = streams[int(np.argmin(holders))]                        # fewest holders, the first of them
+        ctxs.append(_ffi.Context(0))
+        assert ctxs[-1].stream == expect
+    _, holders, _ = base.debug_stream_pool()
+    assert min(holders) >= 2                                             # 2 * pool contexts over pool streams
+    gone, before = ctxs[3].stream, holders[streams.index(ctxs[3].stream)]
+    ctxs[3].close()
+    assert base.debug_stream_pool()[1][streams.index(gone)] == before - 1
+    c2 = synth.config_c2()
+    B = 640
+    z = synth.zarc2_batch(c2["freq"], B, first_seed=8000)
+    drt = DRT(fixed_basis_tau=c2["tau"], context=ctxs[0])
+    plan = drt.stage_batch(c2["freq"], z)
+    plan.set_subbatches(1)
+    drt.fit_staged()
+    ref = drt.collect_staged()
+    plan.set_subbatches(pool + 2)                                        # more ranges than streams: two streams carry two ranges
+    drt.fit_staged()
+    res = drt.collect_staged()
+    for key in ("x", "weights", "rho", "outer_iters", "qp_iters_total", "status"):
+        np.testing.assert_array_equal(res[key], ref[key], err_msg=key)
+    assert base.debug_stream_pool()[2] == [0] * pool                     # nothing is left marked as running
+    drt._plan.close()
+    for c in ctxs[1:3] + ctxs[4:]:
+        c.close()
+
+
 @pytest.mark.timeout(1200)
 def test_config4_ten_thousand_spectra_through_the_sharded_driver():
     """BASELINE configs[3] on one GPU: 10 000 spectra (256 x 512) through mapping.fit_observations_sharded (world 1), i.e.

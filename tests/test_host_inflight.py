@@ -90,9 +90,12 @@ def test_inflight_error_capture_and_reraising(monkeypatch):
 
 def test_auto_inflight_rule(monkeypatch):
     from hipdrt.mapping import drtmd
-    assert [drtmd.auto_inflight(n) for n in (1, 511, 512, 1999, 2000, 10000)] == [1, 1, 2, 2, 3, 3]
+    # round 6: one plan (which cuts its batch into ranges inside the library) at every size
+    assert [drtmd.auto_inflight(n) for n in (1, 511, 512, 1999, 2000, 10000)] == [1] * 6
     fakes = [_FakeDRT() for _ in range(3)]
     monkeypatch.setattr(drtmd, "drt_siblings", lambda drt, count: fakes[:count])
     freq = np.logspace(3, 0, 9)
     drtmd.fit_observations(fakes[0], freq, _data(600), inflight='auto')
-    assert [len(f.calls) for f in fakes] == [1, 1, 0] and [f.calls[0][1] for f in fakes[:2]] == [300, 300]
+    assert [len(f.calls) for f in fakes] == [1, 0, 0] and fakes[0].calls[0][1] == 600
+    drtmd.fit_observations(fakes[0], freq, _data(600), inflight=2)          # an explicit count still splits
+    assert [len(f.calls) for f in fakes] == [2, 1, 0] and [f.calls[-1][1] for f in fakes[:2]] == [300, 300]

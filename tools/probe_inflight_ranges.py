@@ -10,12 +10,17 @@ from hipdrt.mapping import drtmd
 from hipdrt.models import DRT
 
 c2 = synth.config_c2()
-totals = [int(a) for a in sys.argv[1:]] or [1250, 2500, 10000]
+GRID = ((1, 1), (1, 2), (1, 4), (1, 6), (2, 1), (2, 2), (2, 3), (3, 1), (3, 2), (4, 1), (4, 2))
+args = [a for a in sys.argv[1:] if not a.startswith("--grid=")]
+for a in sys.argv[1:]:
+    if a.startswith("--grid="):                      # e.g. --grid=1x1,1x4,2x1
+        GRID = tuple(tuple(int(v) for v in g.split("x")) for g in a[7:].split(","))
+totals = [int(a) for a in args] or [1250, 2500, 10000]
 print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"))
 for total in totals:
     z = synth.zarc2_batch(c2["freq"], total)
     drt = DRT(fixed_basis_tau=c2["tau"])
-    for plans, ranges in ((1, 1), (1, 2), (1, 4), (1, 6), (2, 1), (2, 2), (2, 3), (3, 1), (3, 2), (4, 1), (4, 2)):
+    for plans, ranges in GRID:
         if total // plans < 128:
             continue
         drtmd._RANGES_PER_INFLIGHT_PLAN = ranges

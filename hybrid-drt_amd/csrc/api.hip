@@ -304,9 +304,7 @@ int hipdrt_create(int device, hipdrt_ctx** out) try {
 static std::mutex g_life;          // context / plan creation and destruction (any thread, e.g. a garbage collector's)
 
 static void free_ctx(hipdrt_ctx* ctx) {
-    (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);      // (the stream itself belongs to the library's pool)
-    pool_drop(ctx);
+    pool_drop(ctx);                    // (the stream itself belongs to the library's pool and lives on)
     delete ctx;
 }
 

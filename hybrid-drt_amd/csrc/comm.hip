@@ -44,7 +44,11 @@ Rccl* rccl() {
             r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (r.lib) break;
         }
-        if (!r.lib) { r.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
+        if (!r.lib) {
+            const char* why = dlerror();           // (a second call would return NULL: dlerror clears its message)
+            r.err = std::string("librccl.so not found: ") + (why ? why : "");
+            return;
+        }
         auto sym = [&](const char* n) {
             void* p = dlsym(r.lib, n);
             if (!p && r.err.empty()) r.err = std::string("librccl.so lacks ") + n;

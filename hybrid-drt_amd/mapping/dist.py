@@ -79,15 +79,19 @@ def _exchange_unique_id(ffi, rank, world, timeout=180.0):
     if rank == 0:
         uid = ffi.comm_unique_id()
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
+        # /tmp is shared: never follow a link somebody else planted under the predictable name, never reuse an existing file
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
         os.replace(tmp, path)                                       # atomic: a reader never sees a partial file
         return uid, path
     t0 = time.time()
     while True:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
+            fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+            with os.fdopen(fd, "rb") as f:
+                mine = os.fstat(f.fileno()).st_uid == os.getuid()   # (only this user's rank 0 can have written it)
+                uid = f.read() if mine else b""
             if len(uid) == 128:
                 return uid, path
         except OSError:

@@ -12,8 +12,8 @@ min(K, 8) steps and are reported as `value_resident`, `value_streamed`, `single_
   c3  BASELINE configs[2]: `--batch` (1024) synthetic 2-ZARC spectra per GPU, shared 256-point frequency grid, 512-point
       tau grid.  A step = one full QPHB fit (DRT._qphb_fit_core: scaling, initial-weights QP, hyper-parameter loop to
       convergence, final q) of the batch, inputs resident in HBM when the timed region starts.  Weak scaling over ranks.
-  c4  BASELINE configs[3]: ONE map of `--total` (10 000) spectra sharded over the ranks (interleaved shards, every rank
-      splits its share over `--inflight` plans), a step = upload + fit + download on every rank + one gather of the
+  c4  BASELINE configs[3]: ONE map of `--total` (10 000) spectra sharded over the ranks (interleaved shards; every rank
+      fits its share on one plan that cuts it into side-by-side ranges, or on `--inflight` plans), a step = upload + fit + download on every rank + one gather of the
       results on rank 0, all inside the timed region.  Strong scaling.
 Rank 0 prints ONE JSON line.  `value` is always whole-job fits per second.
 """
@@ -293,8 +293,8 @@ def main():
     ap.add_argument("--shard", choices=("block", "interleave", "lpt"), default="interleave", help="c4: shard scheme")
     ap.add_argument("--inflight", type=lambda v: v if v == "auto" else int(v), default=None,
                     help="batches kept in flight per GPU (each on its own plan + HIP stream); c3 (default 4): steps are dealt "
-                         "round-robin to them; c4 (default auto = mapping.auto_inflight(share)): every rank's share is split "
-                         "over them")
+                         "round-robin to them; c4 (default auto = mapping.auto_inflight(share) = 1: one plan, which cuts the "
+                         "share into ranges inside the library): every rank's share is split over them")
     ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the all-cores CPU leg (0 = all cpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix-build", action="store_true")
@@ -383,10 +383,10 @@ def main():
         job_fits = total
 
     # ---- BASELINE configs[3] on this N: the headline (`value`) with --config auto, `scale_reference` beside a c3 headline --------
-    # WHERE in the process this runs matters by 4 %: the HIP runtime deals every new stream to the least-used hardware queue, and a
-    # map whose three plans' streams wrap around the queue ring (created behind six others with 8 queues, behind two with 4)
-    # measures 2500 instead of 2605 fits/s (tools/probe_hw_queues.py, profiles/r06_hw_queue_placement.txt).  It is called behind
-    # the multi-plan configs[2] legs (four streams) and in front of the one-caller leg (two more).
+    # (Until round 6 it mattered by 4 % WHERE in the process this ran -- the runtime's placement of the plans' streams on hardware
+    # queues, profiles/r06_hw_queue_placement.txt; the library now deals out its own streams by activity and compute pipe,
+    # csrc/api.hip: StreamPool, and the order of the legs no longer decides anything.  The map's default is ONE plan, which cuts
+    # every rank's share into ranges itself: mapping.auto_inflight.)
     def run_scale_reference():
         scale_ref = None
         if config == "c3" and not args.no_scale_reference:
@@ -422,8 +422,7 @@ def main():
                                           f"timed (inputs start in HOST memory)")}
                 if not ok4:
                     scale_ref["error"] = "the gathered map is incomplete (shape, non-finite coefficients or a failed fit)"
-            # plans, contexts and their streams go NOW (not whenever the collector gets to them): the configs[2] legs below then find
-            # every hardware queue unused, as a fresh process would
+            # plans and contexts go NOW (not whenever the collector gets to them): their memory is free for the legs below
             import gc
             for d_ in [d4] + list(getattr(d4, "_sibling_clones", None) or []):
                 if getattr(d_, "_plan", None) is not None:

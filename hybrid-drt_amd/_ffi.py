@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -163,7 +164,16 @@ def load_library():
             # seven streams over the four pipes, enough for four ranges or four plans side by side on a pipe each; with 4 it
             # has three.  The variable is read when the runtime starts, i.e. at the first HIP call of the process: set here, as
             # a default the caller's environment overrides, it takes effect unless something else in the process has started HIP.
-            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+            # (If torch is loaded and has started HIP already, the runtime runs with whatever it found then: exporting 8 now
+            # would only make libhipdrt size its stream pool for queues that do not exist.)
+            torch_mod = sys.modules.get("torch")
+            hip_started = False
+            try:
+                hip_started = bool(torch_mod is not None and torch_mod.cuda.is_initialized())
+            except Exception:                    # noqa: BLE001 (a torch build without the cuda module)
+                hip_started = False
+            if not hip_started:
+                os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
             if not os.path.exists(LIB_PATH):
                 raise HipDrtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                                   f"g.build()'` (hipdrt has no CPU fallback)")

@@ -9,6 +9,7 @@ cp gpurun_out/qp_traffic.json profiles/qp_traffic.json
 tail -1 gpurun_out/bench_${T}.json > profiles/${T}_bench.json
 tail -1 gpurun_out/bench_${T}_c4.json > profiles/${T}_bench_c4_1gpu.json
 tail -1 gpurun_out/bench_${T}_gloo2.json > profiles/${T}_bench_gloo2.json
+tail -1 gpurun_out/bench_${T}_c4_share1250.json > profiles/${T}_bench_c4_share1250.json
 grep '"metric"' gpurun_out/bench_${T}_force_dist.json | tail -1 > profiles/${T}_bench_force_dist.json
 mkdir -p /tmp/st_res
 ( cd hybrid-drt_amd/csrc && for f in api gram hyper matrices qp; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -I../../include -c $f.hip -o /tmp/st_res/$f.o --save-temps=obj 2>/dev/null; done )
@@ -26,7 +27,7 @@ print("single", round(d["single_stream"]["value"], 1), "single_caller", round(d[
       "matrix build", round(d["matrix_build_roofline"]["frac"], 3), "gram frac", round(d["roofline_gram"]["frac"], 3), "hyper ms", round(d["roofline_hyper"]["ms_per_step"], 1))
 print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["all_cores"]["value"])
 print({k: round(v["seconds"], 4) for k, v in d["other_configs"].items()})
-for f in (f"{T}_bench_c4_1gpu", f"{T}_bench_gloo2"):
+for f in (f"{T}_bench_c4_1gpu", f"{T}_bench_c4_share1250", f"{T}_bench_gloo2"):
     e = json.load(open(f"profiles/{f}.json")); print(f, round(e["value"], 1), round(e["ms_per_step"], 1), e["n_gpus"])
 for r_ in csv.DictReader(open(f"profiles/{T}_kernel_stats_inflight1.csv")):
     if "qp_kernel_resident" in r_["Name"]: print("rocprof one-plan run: qp_kernel_resident calls", r_["Calls"], "avg ms %.3f" % (float(r_["AverageNs"]) / 1e6))

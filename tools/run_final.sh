@@ -3,6 +3,7 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out; T=${1:-r06}
 bash tools/collect_profiles.sh $T
 timeout 900 python bench.py --config c4 --no-cpu-baseline --no-other-configs > $O/bench_${T}_c4.json 2> $O/bench_${T}_c4.err; tail -1 $O/bench_${T}_c4.json | cut -c1-300
+timeout 600 python bench.py --config c4 --total 1250 --no-cpu-baseline --no-other-configs > $O/bench_${T}_c4_share1250.json 2> $O/bench_${T}_c4_share1250.err; tail -1 $O/bench_${T}_c4_share1250.json | cut -c1-200
 timeout 900 python bench.py --gpus 2 --backend gloo --config c4 --total 2000 --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > $O/bench_${T}_gloo2.json 2> $O/bench_${T}_gloo2.err; tail -1 $O/bench_${T}_gloo2.json | cut -c1-400
 timeout 600 python bench.py --force-dist --steps 4 --no-cpu-baseline --no-other-configs --no-matrix-build > $O/bench_${T}_force_dist.json 2> $O/bench_${T}_force_dist.err; tail -1 $O/bench_${T}_force_dist.json | cut -c1-300
 timeout 600 python tools/probe_single.py 0 -1 2>&1 | grep -v "Extension modules" > $O/${T}_single.txt; cat $O/${T}_single.txt

@@ -158,10 +158,11 @@ def _supergrid_slots(tau_supergrid, basis_tau):
     return left, right
 
 
-def observation_groups(observations):
+def observation_groups(observations, tags=None):
     """Observations that can share one device plan: same data type (EIS / chrono / joint), same frequency grid, same sample
-    times and current signal -- hence the same matrices and the same slice of the tau supergrid.  Returns a list of
-    (kind, [observation indices]) in order of first appearance."""
+    times and current signal -- hence the same matrices and the same slice of the tau supergrid (and the same `tags[k]`, when
+    tags are given: what else must agree inside a group).  Returns a list of (kind, [observation indices]) in order of first
+    appearance."""
     groups, order = {}, []
     for k, (chrono, eis) in enumerate(observations):
         has_c = chrono is not None and chrono[0] is not None
@@ -173,11 +174,59 @@ def observation_groups(observations):
             key += (np.asarray(chrono[0], dtype=float).tobytes(), np.asarray(chrono[1], dtype=float).tobytes())
         if has_e:
             key += (np.asarray(eis[0], dtype=float).tobytes(),)
+        if tags is not None:
+            key += (tags[k],)
         if key not in groups:
             groups[key] = []
             order.append(key)
         groups[key].append(k)
     return [(key[0], groups[key]) for key in order]
+
+
+_FILTER_KW = ('remove_extremes', 'extreme_kw', 'remove_outliers', 'outlier_thresh')
+
+
+def _as_measurement(observation):
+    chrono, eis = observation
+    chrono = chrono if (chrono is not None and chrono[0] is not None) else (None, None, None)
+    eis = eis if (eis is not None and eis[0] is not None) else (None, None)
+    return chrono[0], chrono[1], chrono[2], eis[0], eis[1]
+
+
+def _as_observation(meas):
+    return (None if meas[0] is None else (meas[0], meas[1], meas[2])), (None if meas[3] is None else (meas[3], meas[4]))
+
+
+def prefilter_observations(drt, observations, fit_kw):
+    """``remove_extremes`` / ``remove_outliers`` among the fit keywords (drt1d.py:187-302) for a LIST of observations.  Both
+    change the SIZE of an observation's data, so they run before the batches are formed: the quantile-range pre-filter per
+    observation on the host, then the outlier detection -- an initialize_weights-only pass with the outlier-aware weights -- as
+    one device batch per group of like observations; every observation loses its own flagged points and the fit keywords come
+    back without the two switches (and without outlier_p, as upstream's refit).  Returns (observations, fit_kw, tags, step_times):
+    tags[k] = (detection group, which points were dropped) keeps observations apart that must not share a plan, step_times[k] =
+    the step times the detection pass found before the removal (drt1d.py:283-302; None without chrono data)."""
+    fit_kw = dict(fit_kw)
+    num = len(observations)
+    tags, step_times = None, [None] * num
+    meas = [_as_measurement(o) for o in observations]
+    if fit_kw.get('remove_extremes'):
+        meas = [drt._drop_extremes(m, fit_kw.get('extreme_kw')) for m in meas]
+    if fit_kw.get('remove_outliers'):
+        if fit_kw.get('outlier_p') is None:
+            raise ValueError('If remove_outliers is True, the prior probability of outlier presence, outlier_p, '
+                             'must be specified. A good starting value might be 0.01-0.05')           # drt1d.py:215-218
+        pass_kw = dict(fit_kw, remove_extremes=False)
+        ckw, _ = drt._split_kwargs(pass_kw)
+        tags = [None] * num
+        for g, (_, idx) in enumerate(observation_groups([_as_observation(m) for m in meas])):
+            cleaned, st, masks = drt._remove_outliers_batch([meas[k] for k in idx], pass_kw, ckw)
+            for k, c, (cm, em) in zip(idx, cleaned, masks):
+                meas[k], step_times[k] = c, st
+                tags[k] = (g, b'' if cm is None else np.packbits(cm).tobytes(), b'' if em is None else np.packbits(em).tobytes())
+        fit_kw['outlier_p'] = None
+    for key in _FILTER_KW:
+        fit_kw.pop(key, None)
+    return [_as_observation(m) for m in meas], fit_kw, tags, step_times
 
 
 def fit_observation_list(drt, observations, tau_supergrid, drt_var=False, ignore_errors=False, llh_kw=None, rss_kw=None,
@@ -200,19 +249,21 @@ def fit_observation_list(drt, observations, tau_supergrid, drt_var=False, ignore
     if drt_var:
         res['obs_drt_var'] = np.zeros((num, len(tau_supergrid)))
         res['obs_drt_var_ok'] = np.zeros(num, dtype=bool)
-    for g, (kind, idx) in enumerate(observation_groups(observations)):
+    tags, step_times = None, [None] * num
+    if fit_kw.get('remove_extremes') or fit_kw.get('remove_outliers'):
+        observations, fit_kw, tags, step_times = prefilter_observations(drt, observations, fit_kw)
+    for g, (kind, idx) in enumerate(observation_groups(observations, tags)):
         idx = np.asarray(idx)
         if kind == 'eis':
             freq = np.asarray(observations[idx[0]][1][0], dtype=float)
             out = drt.fit_eis_batch(freq, np.array([observations[k][1][1] for k in idx]), **fit_kw)
             special_keys = [key for key in ('R_inf', 'inductance') if key in out]
         else:
-            meas = []
-            for k in idx:
-                chrono, eis = observations[k]
-                eis = eis if (eis is not None and eis[0] is not None) else (None, None)
-                meas.append((chrono[0], chrono[1], chrono[2], eis[0], eis[1]))
-            out = drt._fit_prepared_batch(meas, fit_kw)
+            meas = [_as_measurement(observations[k]) for k in idx]
+            group_kw = fit_kw
+            if step_times[idx[0]] is not None:          # found before the outliers were removed (drt1d.py:283-302)
+                group_kw = dict(fit_kw, step_times=step_times[idx[0]], step_sizes=None)
+            out = drt._fit_prepared_batch(meas, group_kw)
             special_keys = [key for key in drt.special_qp_params if key in out]
         basis_tau = out['basis_tau']
         left, right = _supergrid_slots(tau_supergrid, basis_tau)

@@ -154,8 +154,8 @@ def resolve_group(obs_drt_list, obs_tau_indices, nonneg, num_tau_super, batch_si
                   lambda_psi=1, tau_filter_sigma=0, special_filter_sigma=0, device=0):
     """DRTMD.resolve_group (hybdrt/mapping/drtmd.py:486-559) for observations already sorted along psi: overlapping batches
     of `batch_size` observations are re-optimised coherently (resolve_observations each) and the overlaps averaged with
-    weights growing with the distance from the batch edge.  The batches are independent QPs of one size, so they go to the
-    device as ONE batched launch.  Returns (obs_x_resolved (num_obs, num_tau_super), obs_special_resolved dict)."""
+    weights growing with the distance from the batch edge.  The batches are independent QPs: all of one size go to the device as
+    ONE batched launch (one size when every observation was fitted on the same tau range).  Returns (obs_x_resolved (num_obs, num_tau_super), obs_special_resolved dict)."""
     num_obs = len(obs_drt_list)
     batch_size = min(batch_size, num_obs)
     stride = max(batch_size - overlap, 1)
@@ -172,23 +172,34 @@ def resolve_group(obs_drt_list, obs_tau_indices, nonneg, num_tau_super, batch_si
     probs = [resolve_observations(obs_drt_list[a:a + batch_size], obs_tau_indices[a:a + batch_size], nonneg,
                                   truncate=truncate, sigma=sigma, lambda_psi=lambda_psi, tau_filter_sigma=tau_filter_sigma,
                                   special_filter_sigma=special_filter_sigma, _assemble_only=True) for a in starts]
-    sizes = {pr[0].shape for pr in probs}
-    if len(sizes) != 1:
-        raise NotImplementedError("batches whose common tau ranges differ in length would need separate launches")
-    res = _ffi.get_context(device).qp_batch(np.stack([pr[0] for pr in probs]), np.stack([pr[1] for pr in probs]),
-                                            np.stack([pr[2] for pr in probs]))
-    if np.any(res['status'] < 0):
-        raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
-    resolve_group.last_qp = dict(iterations=res['iterations'].tolist())
+    # batches whose common tau ranges have the same length are QPs of one size: one batched launch per size (observations
+    # fitted on different slices of the supergrid give batches of different sizes, drtmd.py:513-528 + resolve.py:219-232)
+    by_size = {}
+    for i, pr in enumerate(probs):
+        by_size.setdefault(pr[0].shape, []).append(i)
+    x_sol, iterations = [None] * len(probs), [0] * len(probs)
+    for members in by_size.values():
+        res = _ffi.get_context(device).qp_batch(np.stack([probs[i][0] for i in members]), np.stack([probs[i][1] for i in members]),
+                                                np.stack([probs[i][2] for i in members]))
+        if np.any(res['status'] < 0):
+            raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+        for j, i in enumerate(members):
+            x_sol[i], iterations[i] = res['x'][j], int(res['iterations'][j])
+    resolve_group.last_qp = dict(iterations=iterations, launches=len(by_size))
     special = probs[0][3]
     x_batch = np.zeros((len(starts), num_obs, num_tau_super))
     sp_batch = {k: np.zeros((len(starts), num_obs) + ((v.get('size', 1),) if v.get('size', 1) > 1 else ()))
                 for k, v in special.items()}
     margins = -np.ones((len(starts), num_obs))
+    # The reference runs the batches one after the other on ONE array: a batch overwrites its observations' rows inside its own
+    # common tau range only (drtmd.py:476) and then records a copy of those rows (drtmd.py:531) -- where a later batch's range is
+    # shorter, the copy still holds what the earlier batch wrote outside it.  Same here, on the solutions of the batched launch.
+    rows = np.zeros((num_obs, num_tau_super))
     for i, (a, pr) in enumerate(zip(starts, probs)):
         _, _, _, sp_, match, nr, nc = pr
-        x_drt, x_special = unpack_resolved_x(res['x'][i].reshape(nr, nc), obs_drt_list[a:a + batch_size], sp_)
-        x_batch[i, a:a + batch_size, match[0]:match[1]] = x_drt
+        x_drt, x_special = unpack_resolved_x(x_sol[i].reshape(nr, nc), obs_drt_list[a:a + batch_size], sp_)
+        rows[a:a + batch_size, match[0]:match[1]] = x_drt
+        x_batch[i, a:a + batch_size] = rows[a:a + batch_size]
         for k, v in x_special.items():
             sp_batch[k][i, a:a + batch_size] = v
         margins[i, a:a + batch_size] = np.minimum(np.arange(batch_size), np.arange(batch_size)[::-1])

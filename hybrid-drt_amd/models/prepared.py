@@ -434,38 +434,72 @@ class PreparedFitMixin:
                             'hybrid_weight_factor_method', 'weight_factor', 'xtol', 'max_iter', 'iw_l1_lambda_0',
                             'iw_l2_lambda_0', 'remove_outliers', 'outlier_thresh', 'step_sizes')
 
+    def _drop_extremes(self, meas, extreme_kw=None):
+        """drt1d.py:187-212: points whose value lies far outside the central quantile range of the raw signal are removed
+        (a chrono sample if the current or the voltage is extreme, an impedance point if either part is)."""
+        ekw = extreme_kw if extreme_kw is not None else {'qr_size': 0.8, 'qr_thresh': 1.5}
+        times, i_signal, v_signal, frequencies, z = meas
+        if times is not None:
+            times, i_signal, v_signal = (np.asarray(a) for a in (times, i_signal, v_signal))
+            flag = pp.identify_extreme_values(i_signal, **ekw) | pp.identify_extreme_values(v_signal, **ekw)
+            if np.any(flag):
+                if self.warn:
+                    warnings.warn('Identified extreme values in chrono data at the following '
+                                  f'indices: {np.where(flag)[0].tolist()}. These data points will be removed before fitting')
+                times, i_signal, v_signal = times[~flag], i_signal[~flag], v_signal[~flag]
+        if frequencies is not None:
+            frequencies, z = np.asarray(frequencies), np.asarray(z)
+            flag = pp.identify_extreme_values(z.real, **ekw) | pp.identify_extreme_values(z.imag, **ekw)
+            if np.any(flag):
+                if self.warn:
+                    warnings.warn('Identified extreme values in EIS data at the following '
+                                  f'indices: {np.where(flag)[0].tolist()}. These data points will be removed before fitting')
+                frequencies, z = frequencies[~flag], z[~flag]
+        return times, i_signal, v_signal, frequencies, z
+
     def _remove_outliers(self, meas, fit_kw, ckw):
         """drt1d.py:214-302: an initialize_weights-only pass with the outlier-aware weights (device: max_iter = 0) gives
         outlier_t; points with 1 - outlier_t above the threshold are dropped (an impedance point if either part is),
         the step times found before the removal are kept."""
-        times, i_signal, v_signal, frequencies, z = meas
+        cleaned, step_times, masks = self._remove_outliers_batch([meas], fit_kw, ckw)
+        self.chrono_outlier_index, self.eis_outlier_index = masks[0]
+        return cleaned[0], step_times
+
+    def _remove_outliers_batch(self, measurements, fit_kw, ckw):
+        """the detection pass of _remove_outliers for measurements of ONE protocol as one device batch (mapping.fit_observations):
+        returns (cleaned measurements, the protocol's step times, [(chrono mask | None, eis mask | None)])"""
         pass_kw = {k: v for k, v in fit_kw.items() if k not in self._NOT_IN_OUTLIER_PASS}
-        preps, plan = self._fit_prepared([meas], dict(pass_kw, max_iter=0), _init_only=True)
-        nc = preps[0]['num_chrono']
-        flagged = (1 - plan.get('outlier_t')[0]) > ckw['outlier_thresh']
-        chrono_idx = flagged[:nc] if times is not None else None
-        eis_idx = None
-        if frequencies is not None:
-            nf = len(frequencies)
-            eis_idx = flagged[nc:nc + nf] | flagged[nc + nf:]
-        self.chrono_outlier_index, self.eis_outlier_index = chrono_idx, eis_idx
-        self.chrono_outliers = self.eis_outliers = None
+        preps, plan = self._fit_prepared(list(measurements), dict(pass_kw, max_iter=0), _init_only=True)
+        outlier_t = plan.get('outlier_t')
         step_times = preps[0].get('step_times')
-        if times is not None and np.any(chrono_idx):
-            if self.warn:
-                warnings.warn('Found outliers in chrono data at the following '
-                              f'indices: {np.where(chrono_idx)[0].tolist()}. These data points will be removed before fitting')
-            times, i_signal, v_signal = (np.asarray(a) for a in (times, i_signal, v_signal))
-            self.chrono_outliers = (times[chrono_idx], i_signal[chrono_idx], v_signal[chrono_idx])
-            times, i_signal, v_signal = times[~chrono_idx], i_signal[~chrono_idx], v_signal[~chrono_idx]
-        if frequencies is not None and np.any(eis_idx):
-            if self.warn:
-                warnings.warn('Found outliers in EIS data at the following '
-                              f'indices: {np.where(eis_idx)[0].tolist()}. These data points will be removed before fitting')
-            frequencies, z = np.asarray(frequencies), np.asarray(z)
-            self.eis_outliers = (frequencies[eis_idx], z[eis_idx])
-            frequencies, z = frequencies[~eis_idx], z[~eis_idx]
-        return (times, i_signal, v_signal, frequencies, z), step_times
+        cleaned, masks = [], []
+        self.chrono_outliers = self.eis_outliers = None
+        for b, (meas, pr) in enumerate(zip(measurements, preps)):
+            times, i_signal, v_signal, frequencies, z = meas
+            nc = pr['num_chrono']
+            flagged = (1 - outlier_t[b]) > ckw['outlier_thresh']
+            chrono_idx = flagged[:nc] if times is not None else None
+            eis_idx = None
+            if frequencies is not None:
+                nf = len(frequencies)
+                eis_idx = flagged[nc:nc + nf] | flagged[nc + nf:]
+            if times is not None and np.any(chrono_idx):
+                if self.warn:
+                    warnings.warn('Found outliers in chrono data at the following '
+                                  f'indices: {np.where(chrono_idx)[0].tolist()}. These data points will be removed before fitting')
+                times, i_signal, v_signal = (np.asarray(a) for a in (times, i_signal, v_signal))
+                self.chrono_outliers = (times[chrono_idx], i_signal[chrono_idx], v_signal[chrono_idx])
+                times, i_signal, v_signal = times[~chrono_idx], i_signal[~chrono_idx], v_signal[~chrono_idx]
+            if frequencies is not None and np.any(eis_idx):
+                if self.warn:
+                    warnings.warn('Found outliers in EIS data at the following '
+                                  f'indices: {np.where(eis_idx)[0].tolist()}. These data points will be removed before fitting')
+                frequencies, z = np.asarray(frequencies), np.asarray(z)
+                self.eis_outliers = (frequencies[eis_idx], z[eis_idx])
+                frequencies, z = frequencies[~eis_idx], z[~eis_idx]
+            cleaned.append((times, i_signal, v_signal, frequencies, z))
+            masks.append((chrono_idx, eis_idx))
+        return cleaned, step_times, masks
 
     def _fit_prepared(self, measurements, fit_kw, history_of=-1, _init_only=False):
         """measurements: list of (times, i_signal, v_signal, frequencies, z) of identical shapes (one protocol)."""
@@ -487,26 +521,9 @@ class PreparedFitMixin:
         if ckw['remove_extremes']:
             # drt1d.py:187-212: rough pre-filter on the raw signals (quantile-range rule), before anything else
             if len(measurements) != 1:
-                raise NotImplementedError("remove_extremes changes the data size per measurement: single fits only")
-            ekw = ckw['extreme_kw'] if ckw['extreme_kw'] is not None else {'qr_size': 0.8, 'qr_thresh': 1.5}
-            times, i_signal, v_signal, frequencies, z = measurements[0]
-            if times is not None:
-                times, i_signal, v_signal = (np.asarray(a) for a in (times, i_signal, v_signal))
-                flag = pp.identify_extreme_values(i_signal, **ekw) | pp.identify_extreme_values(v_signal, **ekw)
-                if np.any(flag):
-                    if self.warn:
-                        warnings.warn('Identified extreme values in chrono data at the following '
-                                      f'indices: {np.where(flag)[0].tolist()}. These data points will be removed before fitting')
-                    times, i_signal, v_signal = times[~flag], i_signal[~flag], v_signal[~flag]
-            if frequencies is not None:
-                frequencies, z = np.asarray(frequencies), np.asarray(z)
-                flag = pp.identify_extreme_values(z.real, **ekw) | pp.identify_extreme_values(z.imag, **ekw)
-                if np.any(flag):
-                    if self.warn:
-                        warnings.warn('Identified extreme values in EIS data at the following '
-                                      f'indices: {np.where(flag)[0].tolist()}. These data points will be removed before fitting')
-                    frequencies, z = frequencies[~flag], z[~flag]
-            measurements = [(times, i_signal, v_signal, frequencies, z)]
+                raise NotImplementedError("remove_extremes changes the data size per measurement: single fits only "
+                                          "(mapping.fit_observations filters every observation before it forms batches)")
+            measurements = [self._drop_extremes(measurements[0], ckw['extreme_kw'])]
             fit_kw = dict(fit_kw, remove_extremes=False)
             ckw, rest = self._split_kwargs(fit_kw)
         if ckw['remove_outliers']:
@@ -514,7 +531,8 @@ class PreparedFitMixin:
                 raise ValueError('If remove_outliers is True, the prior probability of outlier presence, outlier_p, '
                                  'must be specified. A good starting value might be 0.01-0.05')
             if len(measurements) != 1:
-                raise NotImplementedError("remove_outliers changes the data size per measurement: single fits only")
+                raise NotImplementedError("remove_outliers changes the data size per measurement: single fits only "
+                                          "(mapping.fit_observations runs the detection pass per group and forms new batches)")
             meas, step_times = self._remove_outliers(measurements[0], fit_kw, ckw)
             measurements = [meas]
             fit_kw = dict(fit_kw, remove_outliers=False, outlier_p=None)

@@ -477,8 +477,9 @@ def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7, basis_tau=None, store_p=Tru
                special_index=np.array([v["index"] for v in sp.values()]),
                special_size=np.array([v.get("size", 1) for v in sp.values()]),
                special_nonneg=np.array([v["nonneg"] for v in sp.values()]),
-               p_matrix=np.array([d.fit_parameters["p_matrix"] for d in drts]),
-               q_vector=np.array([d.fit_parameters["q_vector"] for d in drts]),
+               p_matrix=_pad_stack([d.fit_parameters["p_matrix"] for d in drts]),
+               q_vector=_pad_stack([d.fit_parameters["q_vector"] for d in drts]),
+               n_params=np.array([len(d.fit_parameters["q_vector"]) for d in drts]),
                v_baseline=np.array([d.fit_parameters["v_baseline"] for d in drts]),
                vz_offset=np.array([d.fit_parameters["vz_offset"] for d in drts]),
                R_inf=np.array([d.fit_parameters["R_inf"] for d in drts]),
@@ -503,7 +504,17 @@ def run_resolve(DRT, cvxopt, name, fit_dop, n_obs=7, basis_tau=None, store_p=Tru
     print(f"resolve_{name}: {n_obs} obs x {x_opt.shape[1]} params, qp iterations {out['qp_iterations'].tolist()}")
 
 
-def run_resolve_group(cvxopt, name, n_obs=16, batch_size=7, overlap=2):
+def _pad_stack(arrays):
+    """arrays of one rank and different sizes -> one zero-padded stack (the sizes are stored beside it)"""
+    arrays = [np.asarray(a) for a in arrays]
+    shape = tuple(max(a.shape[d] for a in arrays) for d in range(arrays[0].ndim))
+    out = np.zeros((len(arrays),) + shape)
+    for i, a in enumerate(arrays):
+        out[(i,) + tuple(slice(0, n) for n in a.shape)] = a
+    return out
+
+
+def run_resolve_group(cvxopt, name, n_obs=16, batch_size=7, overlap=2, t_hi_of=None):
     """the reference's own DRTMD (mapping/drtmd.py:186-329, 432-559) driven with array data: n_obs joint fits along one psi
     axis, then resolve_group -- overlapping batches of coupled QPs, margin-weighted average of the overlaps."""
     from hipdrt import synth
@@ -512,7 +523,10 @@ def run_resolve_group(cvxopt, name, n_obs=16, batch_size=7, overlap=2):
     with _quiet():
         dmd = DRTMD(tau_supergrid=sup, psi_dim_names=['T'], print_progress=False, warn=False)
         for k in range(n_obs):
-            m = synth.hybrid_measurement(seed=100 + k, jitter=True, n_post=100, nf=31)
+            # t_hi_of: observations with a shorter record are fitted on a shorter slice of the supergrid -- batches whose common
+            # tau ranges differ in length
+            extra = {} if t_hi_of is None else dict(t_hi=t_hi_of(k))
+            m = synth.hybrid_measurement(seed=100 + k, jitter=True, n_post=100, nf=31, **extra)
             dmd.add_observation(np.array([float(k)]), (m[0], m[1], m[2]), (m[3], m[4]), group_id='g')
         dmd.fit_all()
     log = []
@@ -523,12 +537,14 @@ def run_resolve_group(cvxopt, name, n_obs=16, batch_size=7, overlap=2):
     drts = [dmd.get_fit(i) for i in range(n_obs)]
     sp = drts[0].special_qp_params
     out = dict(n_obs=n_obs, batch_size=batch_size, overlap=overlap, n_super=len(sup),
+               t_hi=np.array([50.0 if t_hi_of is None else t_hi_of(k) for k in range(n_obs)]),
                obs_tau_indices=np.array(dmd.obs_tau_indices), special_names=np.array(list(sp.keys())),
                special_index=np.array([v["index"] for v in sp.values()]),
                special_size=np.array([v.get("size", 1) for v in sp.values()]),
                special_nonneg=np.array([v["nonneg"] for v in sp.values()]),
-               p_matrix=np.array([d.fit_parameters["p_matrix"] for d in drts]),
-               q_vector=np.array([d.fit_parameters["q_vector"] for d in drts]),
+               p_matrix=_pad_stack([d.fit_parameters["p_matrix"] for d in drts]),
+               q_vector=_pad_stack([d.fit_parameters["q_vector"] for d in drts]),
+               n_params=np.array([len(d.fit_parameters["q_vector"]) for d in drts]),
                v_baseline=np.array([d.fit_parameters["v_baseline"] for d in drts]),
                vz_offset=np.array([d.fit_parameters["vz_offset"] for d in drts]),
                R_inf=np.array([d.fit_parameters["R_inf"] for d in drts]),
@@ -560,6 +576,55 @@ def mixed_map_observations(n_obs=16):
             f = fa if k % 3 == 1 else fb
             obs.append((None, (f, synth.zarc2_spectrum(f, 300 + k, jitter=True))))
     return obs
+
+
+def outlier_map_observations(n_obs=9):
+    """the first observations of the mixed map with gross errors planted in some of them (tests/test_gpu_mapping.py holds the
+    same recipe): what DRTMD(fit_kw=dict(remove_outliers=True, outlier_p=0.05)) has to find and drop per observation"""
+    obs = mixed_map_observations(n_obs)
+    plant = {0: dict(v={100: 5e-5}, z={10: 0.3}), 1: dict(z={10: 0.3}), 4: dict(z={10: 0.3, 25: -0.25j}), 5: dict(z={20: -0.25j}),
+             6: dict(v={110: -8e-5})}
+    out = []
+    for k, (chrono, eis) in enumerate(obs):
+        p_ = plant.get(k, {})
+        if chrono is not None and "v" in p_:
+            v = np.array(chrono[2], dtype=float)
+            for i, dv in p_["v"].items():
+                v[i] += dv
+            chrono = (chrono[0], chrono[1], v)
+        if "z" in p_:
+            z = np.array(eis[1], dtype=complex)
+            for i, dz in p_["z"].items():
+                z[i] += dz
+            eis = (eis[0], z)
+        out.append((chrono, eis))
+    return out
+
+
+def run_drtmd_outliers(n_obs=9):
+    """the reference's own DRTMD with remove_outliers among its fit keywords (every observation through the detection pass and
+    the refit of drt1d.py:214-302) on the map above: obs_x, specials, llh / rss, tau slices"""
+    from hybdrt.mapping.drtmd import DRTMD
+    sup = np.logspace(-8, 4, 121)
+    obs = outlier_map_observations(n_obs)
+    removed = []
+    with _quiet():
+        dmd = DRTMD(tau_supergrid=sup, psi_dim_names=['T'], print_progress=False, warn=False,
+                    fit_kw=dict(nonneg=True, remove_outliers=True, outlier_p=0.05))
+        for k, (chrono, eis) in enumerate(obs):
+            dmd.add_observation(np.array([float(k)]), chrono, eis, group_id='g')
+            dmd.fit_observation(k)
+            d = dmd.drt1d
+            removed.append((0 if d.chrono_outlier_index is None else int(np.sum(d.chrono_outlier_index)),
+                            0 if d.eis_outlier_index is None else int(np.sum(d.eis_outlier_index))))
+    assert dmd.obs_fit_status.all()
+    out = dict(n_obs=n_obs, tau_supergrid=sup, obs_x=dmd.obs_x, obs_llh=dmd.obs_llh, obs_rss=dmd.obs_rss,
+               obs_tau_indices=np.array(dmd.obs_tau_indices), removed=np.array(removed),
+               special_names=np.array(list(dmd.obs_special.keys())))
+    for key, val in dmd.obs_special.items():
+        out["special_" + key] = np.asarray(val)
+    np.savez_compressed(os.path.join(OUT, "refrun_drtmd_outliers9.npz"), **out)
+    print(f"drtmd_outliers9: removed (chrono, eis) per observation {removed}")
 
 
 def run_drtmd_mixed(n_obs=16):
@@ -717,11 +782,20 @@ def main():
         run_resolve(DRT, cvxopt, "hybrid7_dop", True)
         run_resolve_group(cvxopt, "hybrid16")
         return
+    if "--only-resolve-ranges" in sys.argv:
+        # observations 9..15 have a ten times shorter record: three batches with common tau ranges of two lengths
+        _, cvxopt = _boot_reference()
+        run_resolve_group(cvxopt, "hybrid16_ranges", t_hi_of=lambda k: 50.0 if k < 9 else 5.0)
+        return
     if "--only-resolve-c2grid" in sys.argv:
         # 7 joint fits on the 512-point tau grid of BASELINE configs[2]: a coupled QP of 7 x 514 = 3598 unknowns
         from hipdrt import synth
         DRT, cvxopt = _boot_reference()
         run_resolve(DRT, cvxopt, "c2grid", False, basis_tau=synth.config_c2()["tau"], store_p=False)
+        return
+    if "--only-drtmd-outliers" in sys.argv:
+        _boot_reference()
+        run_drtmd_outliers()
         return
     if "--only-drtmd-pfrt" in sys.argv:
         _boot_reference()
@@ -826,7 +900,9 @@ def main():
     run_resolve(DRT, cvxopt, "hybrid7", False)
     run_resolve(DRT, cvxopt, "hybrid7_dop", True)
     run_resolve_group(cvxopt, "hybrid16")
+    run_resolve_group(cvxopt, "hybrid16_ranges", t_hi_of=lambda k: 50.0 if k < 9 else 5.0)
     run_drtmd_mixed()
+    run_drtmd_outliers()
     # (12) evaluation of fitted models
     # (13) Kramers-Kronig test
     # (14) progressive decimation of raw chrono records

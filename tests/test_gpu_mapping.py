@@ -60,6 +60,67 @@ def test_mixed_map_matches_the_reference_drtmd():
     _check_against_reference(g, obs_x, obs_special, res, drt_var=True)
 
 
+def outlier_map_observations(n_obs=9):
+    """as oracle/make_golden.py: outlier_map_observations (gross errors planted in some observations of the mixed map)"""
+    obs = mixed_map_observations(n_obs)
+    plant = {0: dict(v={100: 5e-5}, z={10: 0.3}), 1: dict(z={10: 0.3}), 4: dict(z={10: 0.3, 25: -0.25j}), 5: dict(z={20: -0.25j}),
+             6: dict(v={110: -8e-5})}
+    out = []
+    for k, (chrono, eis) in enumerate(obs):
+        p_ = plant.get(k, {})
+        if chrono is not None and "v" in p_:
+            v = np.array(chrono[2], dtype=float)
+            for i, dv in p_["v"].items():
+                v[i] += dv
+            chrono = (chrono[0], chrono[1], v)
+        if "z" in p_:
+            z = np.array(eis[1], dtype=complex)
+            for i, dz in p_["z"].items():
+                z[i] += dz
+            eis = (eis[0], z)
+        out.append((chrono, eis))
+    return out
+
+
+def test_remove_outliers_in_a_map_matches_the_reference_drtmd():
+    """remove_outliers=True among a map's fit keywords (drt1d.py:214-302 per observation in the reference's DRTMD loop): the
+    detection pass runs as one device batch per group of like observations, every observation loses its own flagged points, and
+    the refits are batched over observations that lost the same points -- against the reference's own DRTMD run with the same
+    keywords (nine observations, gross errors planted in five; it removes between 0 and 5 points per observation)."""
+    from hipdrt.mapping import fit_observations
+    from hipdrt.mapping.drtmd import observation_groups, prefilter_observations
+    from hipdrt.models import DRT
+    g = np.load(os.path.join(GOLDEN, "refrun_drtmd_outliers9.npz"))
+    obs = outlier_map_observations(int(g["n_obs"]))
+    sup = g["tau_supergrid"]
+    drt = DRT(tau_supergrid=sup, warn=False)
+    kw = dict(nonneg=True, remove_outliers=True, outlier_p=0.05)
+    cleaned, kw2, tags, step_times = prefilter_observations(drt, obs, kw)
+    lost = [((0 if o[0] is None else len(o[0][0])) - (0 if c[0] is None else len(c[0][0])), len(o[1][0]) - len(c[1][0]))
+            for o, c in zip(obs, cleaned)]
+    assert lost == [tuple(r) for r in g["removed"].tolist()]                 # the same number of points per observation
+    assert "remove_outliers" not in kw2 and kw2["outlier_p"] is None
+    groups = observation_groups(cleaned, tags)
+    assert 3 < len(groups) < len(obs)                                        # new batches: neither the three old groups nor singles
+    obs_x, obs_special, res = fit_observations(drt, observations=obs, tau_supergrid=sup, **kw)
+    assert res["obs_fit_status"].all() and len(res["groups"]) == len(groups)
+    peak = np.abs(g["obs_x"]).max(axis=1, keepdims=True)
+    parity_close("outlier_map.obs_x", obs_x / peak, g["obs_x"] / peak, 1e-9, scale=1.0)
+    assert [tuple(t) for t in res["obs_tau_indices"]] == [tuple(t) for t in g["obs_tau_indices"].tolist()]
+    for key in obs_special:
+        ref = g["special_" + key].reshape(len(obs_x), -1)[:, 0]
+        parity_close("outlier_map.special_" + key, np.asarray(obs_special[key]).reshape(len(obs_x), -1)[:, 0], ref, 1e-8)
+    parity_close("outlier_map.obs_llh", res["obs_llh"] / g["obs_llh"], np.ones(len(obs_x)), 1e-8, scale=1.0)
+    parity_close("outlier_map.obs_rss", res["obs_rss"] / g["obs_rss"], np.ones(len(obs_x)), 1e-8, scale=1.0)
+    # remove_extremes: per observation on the host, then batches as usual (same values as the single fit with the keyword)
+    ext = [(c, (e[0], np.where(np.arange(len(e[0])) == 7, e[1] + (5.0 if k == 1 else 0.0), e[1]))) for k, (c, e) in enumerate(obs[:3])]
+    ox, _, rs = fit_observations(DRT(tau_supergrid=sup, warn=False), observations=ext, tau_supergrid=sup, nonneg=True, remove_extremes=True)
+    single = DRT(tau_supergrid=sup, warn=False)
+    single.fit_eis(ext[1][1][0], ext[1][1][1], nonneg=True, remove_extremes=True)
+    l, r = rs["obs_tau_indices"][1]
+    np.testing.assert_allclose(ox[1, l:r], single.fit_parameters["x"], rtol=0, atol=1e-9 * np.abs(ox[1]).max())
+
+
 def test_mixed_map_through_the_sharded_driver():
     """the same map through fit_observations_sharded (world 1 = what every rank of a node runs on its shard): identical to
     the direct call"""

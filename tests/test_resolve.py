@@ -146,6 +146,36 @@ def test_resolve_group_matches_reference_drtmd():
 
 
 @pytest.mark.gpu
+def test_resolve_group_with_batches_of_different_sizes():
+    """observations 9..15 have a ten times shorter record and were fitted on a shorter slice of the supergrid ((12, 98) against
+    (12, 108)): the three overlapping batches are coupled QPs of different sizes -- one launch per size -- against the reference's
+    own DRTMD.resolve_group on the same 16 joint fits (same iteration counts, same margin-weighted averages)"""
+    from hipdrt.mapping import resolve
+    g = np.load(os.path.join(GOLDEN, "refrun_resolve_group_hybrid16_ranges.npz"))
+    special = {str(k): dict(index=int(i), size=int(s), nonneg=bool(nn))
+               for k, i, s, nn in zip(g["special_names"], g["special_index"], g["special_size"], g["special_nonneg"])}
+    obs = []
+    for i in range(int(g["n_obs"])):
+        n = int(g["n_params"][i])                                   # (the stacks are zero-padded to the largest observation)
+        o = {k: g[k][i] for k in KEYS}
+        o["p_matrix"], o["q_vector"] = g["p_matrix"][i][:n, :n], g["q_vector"][i][:n]
+        obs.append(o)
+    drts = [as_drt(o, special) for o in obs]
+    for d, ls in zip(drts, g["inductance_scale"]):
+        d.inductance_scale = float(ls)
+    tau_idx = [tuple(int(v) for v in t) for t in g["obs_tau_indices"]]
+    assert len(set(tau_idx)) == 2
+    x_res, sp_res = resolve.resolve_group(drts, tau_idx, True, int(g["n_super"]), batch_size=int(g["batch_size"]),
+                                          overlap=int(g["overlap"]))
+    assert resolve.resolve_group.last_qp["iterations"] == g["qp_iterations"].tolist()
+    assert resolve.resolve_group.last_qp["launches"] >= 2
+    scale = np.abs(g["obs_x_resolved"]).max()
+    parity("x_res", x_res, g["obs_x_resolved"], default=1e-7, scale=scale)
+    parity("R_inf", sp_res["R_inf"], g["R_inf_resolved"], default=1e-6, rel=True)
+    parity("inductance", sp_res["inductance"], g["inductance_resolved"], default=1e-5, rel=True)
+
+
+@pytest.mark.gpu
 def test_batch_fits_feed_resolve_like_single_fits():
     """fit_hybrid_batch + DRT.batch_fits() -> resolve_observations gives what seven single fits give"""
     from hipdrt.models import DRT

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HIPDRT_LIB", os.path.join(_HERE, "libhipdrt.so"))
 
 MODE_INTERP, MODE_TRAPZ = 0, 1
+RESPONSE_POT, RESPONSE_EXPDECAY = 0, 1
 QP_OPTIMAL, QP_MAXITER, QP_SINGULAR_LATE, QP_SINGULAR, QP_ABORTED = 0, 1, 2, -1, -2
 
 
@@ -86,6 +87,8 @@ SIGNATURES = {
     "hipdrt_response_lookup": [_vp, C.c_double, C.c_int, C.c_int, _dp, _dp],
     "hipdrt_response_matrix": [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp,
                                C.c_int, _dp, _dp],
+    "hipdrt_response_matrix_variant": [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                                       _dp, _dp],
     "hipdrt_nonuniform_gaussian_filter1d": [_vp, _dp, C.c_int, _dp, _ip, C.c_int, _ip, _dp, C.c_int, _dp, _dp, C.c_longlong,
                                             _ip, _ip, _dp],
     "hipdrt_penalty_matrices": [_vp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp],
@@ -340,6 +343,24 @@ class Context:
         _check(self._lib.hipdrt_response_matrix(self._h, _p(times), times.size, _p(tau), tau.size, _p(st), _p(sa), st.size,
                                                 int(mode), float(epsilon), ng, plt, pv, int(ny), _p(a),
                                                 _p(lay) if layered else None))
+        return a, lay
+
+    def response_matrix_variant(self, times, tau, step_times, step_sizes, variant, tau_rise=None, epsilon=1.0, ny=1000,
+                                layered=True):
+        """the potentiostatic (RESPONSE_POT) and the expdecay-step (RESPONSE_EXPDECAY, trapz) forms of construct_response_matrix"""
+        times, tau, st, sa = _f64(times), _f64(tau), _f64(step_times), _f64(step_sizes)
+        if st.size != sa.size:
+            raise ValueError("step_times and step_sizes must have the same length")
+        tr = None
+        if tau_rise is not None:
+            tr = _f64(tau_rise)
+            if tr.size != st.size:
+                raise ValueError("tau_rise needs one entry per step")
+        a = np.empty((times.size, tau.size))
+        lay = np.empty((st.size, times.size, tau.size)) if layered else None
+        _check(self._lib.hipdrt_response_matrix_variant(self._h, _p(times), times.size, _p(tau), tau.size, _p(st), _p(sa),
+                                                        _p(tr) if tr is not None else None, st.size, int(variant), float(epsilon),
+                                                        int(ny), _p(a), _p(lay) if layered else None))
         return a, lay
 
     def nonuniform_gaussian_filter1d(self, y, sigma, seg, filtered, nodes, node_delta, weights, woff, radius):

@@ -464,6 +464,36 @@ int hipdrt_response_matrix(hipdrt_ctx* ctx, const double* times, int nt, const d
     return HIPDRT_OK;
 } HIPDRT_CATCH
 
+int hipdrt_response_matrix_variant(hipdrt_ctx* ctx, const double* times, int nt, const double* tau, int ntau,
+                                   const double* step_times, const double* step_sizes, const double* tau_rise, int nsteps,
+                                   int variant, double epsilon, int ny, double* a, double* layered) try {
+    HIPDRT_REQUIRE(ctx && times && tau && step_times && step_sizes && a, "NULL pointer");
+    HIPDRT_REQUIRE(nt >= 1 && ntau >= 1 && nsteps >= 1, "nt, ntau, nsteps >= 1");
+    HIPDRT_REQUIRE(variant == HIPDRT_RESPONSE_POT || variant == HIPDRT_RESPONSE_EXPDECAY, "variant must be POT or EXPDECAY");
+    if (variant == HIPDRT_RESPONSE_EXPDECAY) {
+        HIPDRT_REQUIRE(tau_rise, "the expdecay step model needs tau_rise");
+        HIPDRT_REQUIRE(ny >= 2 && ny <= 6000, "2 <= ny <= 6000");
+    }
+    HIPDRT_CHECK(hipSetDevice(ctx->device)); (void)hipGetLastError();
+    hipStream_t st = ctx->stream;
+    DevBuf dt, dtau, dst, dsa, dtr, da, dl;
+    TRY(upload(dt, times, (size_t)nt * sizeof(double), st));
+    TRY(upload(dtau, tau, (size_t)ntau * sizeof(double), st));
+    TRY(upload(dst, step_times, (size_t)nsteps * sizeof(double), st));
+    TRY(upload(dsa, step_sizes, (size_t)nsteps * sizeof(double), st));
+    if (variant == HIPDRT_RESPONSE_EXPDECAY) TRY(upload(dtr, tau_rise, (size_t)nsteps * sizeof(double), st));
+    const size_t ab = (size_t)nt * ntau * sizeof(double);
+    HIPDRT_CHECK(da.alloc(ab));
+    if (layered) HIPDRT_CHECK(dl.alloc(ab * nsteps));
+    launch_response_variant(st, dt.d(), nt, dtau.d(), ntau, dst.d(), dsa.d(), dtr.d(), nsteps, variant, epsilon, ny, da.d(),
+                            layered ? dl.d() : nullptr);
+    LAUNCH_OK();
+    HIPDRT_CHECK(hipMemcpyAsync(a, da.p, ab, hipMemcpyDeviceToHost, st));
+    if (layered) HIPDRT_CHECK(hipMemcpyAsync(layered, dl.p, ab * nsteps, hipMemcpyDeviceToHost, st));
+    HIPDRT_CHECK(hipStreamSynchronize(st));
+    return HIPDRT_OK;
+} HIPDRT_CATCH
+
 // lut6 = {log_wt_re, z_re, slope_re, log_wt_im, z_im, slope_im}
 static int build_lut6(hipStream_t st, DevBuf& lut6, int ngrid, const double* log_wt_re, const double* z_re,
                       const double* log_wt_im, const double* z_im, bool z_on_device) {

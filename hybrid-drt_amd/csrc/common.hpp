@@ -117,6 +117,9 @@ void launch_response_lookup(hipStream_t st, double eps, int ngrid, int ny, const
 void launch_response_matrix(hipStream_t st, const double* times, int nt, const double* tau, int ntau,
                             const double* step_times, const double* step_sizes, int nsteps, int mode, double eps,
                             int ngrid, const double* lut3, int ny, double* a, double* layered);
+void launch_response_variant(hipStream_t st, const double* times, int nt, const double* tau, int ntau,
+                             const double* step_times, const double* step_sizes, const double* tau_rise, int nsteps,
+                             int variant, double eps, int ny, double* a, double* layered);
 void launch_nonuniform_gauss(hipStream_t st, const double* y, int n, const double* sigma, const int* seg_of, const int* seg,
                              const double* nodes, int K, const double* node_delta, const double* weights, const int* woff,
                              const int* radius, double* out);

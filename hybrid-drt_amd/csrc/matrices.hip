@@ -436,6 +436,77 @@ __global__ __launch_bounds__(256) void response_trapz_kernel(const double* __res
     }
 }
 
+
+// ---- the non-default forms of construct_response_matrix (mat1d.py:96-118) --------------------------------------------------
+// expdecay step model (basis.py:619-637): the current rises as 1 - exp(-t / tau_rise); integrand
+//   phi(y) * (1 - e^{-t/T} + tau_rise / (tau_rise - T) * (e^{-t/T} - e^{-t/tau_rise})),  T = e^y tau
+__device__ __forceinline__ double trapz_response_expdecay(const double* ys, const double* phis, const double* eys, int ny,
+                                                          double tau, double t, double tr, int lane) {
+    const double etr = exp(-t / tr);
+    auto f = [&](int j) {
+        const double T = eys[j] * tau;
+        const double eT = exp(-t / T);
+        return phis[j] * ((1.0 - eT) + (tr / (tr - T)) * (eT - etr));
+    };
+    double s = 0.0;
+    for (int j = lane; j < ny - 1; j += 64) {
+        const double d = ys[j + 1] - ys[j];
+        s += d * (f(j + 1) + f(j)) / 2.0;
+    }
+    return wave_sum(s);
+}
+
+// variant 1 (expdecay, trapz): one wavefront per entry like response_trapz_kernel, tau_rise[k] per step
+__global__ __launch_bounds__(256) void response_expdecay_kernel(const double* __restrict__ times, int nt,
+                                                                const double* __restrict__ tau, int ntau,
+                                                                const double* __restrict__ step_times,
+                                                                const double* __restrict__ step_sizes,
+                                                                const double* __restrict__ tau_rise, int nsteps,
+                                                                double eps, int ny, double* __restrict__ a,
+                                                                double* __restrict__ layered) {
+    extern __shared__ double sm[];
+    double* ys = sm; double* phis = sm + ny; double* eys = sm + 2 * ny;
+    fill_y_tables(ys, phis, eys, ny, eps);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.y;
+    const double t = times[r];
+    for (int q = 0; q < 4; ++q) {
+        const int c = blockIdx.x * 16 + q * 4 + wv;
+        if (c >= ntau) continue;
+        double acc = 0.0;
+        for (int k = 0; k < nsteps; ++k) {
+            const double st = step_times[k];
+            double val = 0.0;
+            if (t > st) val = trapz_response_expdecay(ys, phis, eys, ny, tau[c], t - st, tau_rise[k], lane) * step_sizes[k];
+            if (layered && lane == 0) layered[((size_t)k * nt + r) * ntau + c] = val;
+            acc += val;
+        }
+        if (lane == 0) a[(size_t)r * ntau + c] = acc;
+    }
+}
+
+// variant 0 (potentiostatic, mat1d.py:114-118): the basis is a delta function, the current after a voltage step decays as
+// exp(-(t - t_k) / tau) from the step on (unit_step: t >= t_k); rows before the step are 0 (the reference's nan_to_num)
+__global__ __launch_bounds__(256) void response_pot_kernel(const double* __restrict__ times, int nt,
+                                                           const double* __restrict__ tau, int ntau,
+                                                           const double* __restrict__ step_times,
+                                                           const double* __restrict__ step_sizes, int nsteps,
+                                                           double* __restrict__ a, double* __restrict__ layered) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= ntau) return;
+    const double t = times[r], tc = tau[c];
+    double acc = 0.0;
+    for (int k = 0; k < nsteps; ++k) {
+        const double st = step_times[k];
+        double val = 0.0;
+        if (t >= st) val = exp(-(t - st) / tc) * step_sizes[k];
+        if (layered) layered[((size_t)k * nt + r) * ntau + c] = val;
+        acc += val;
+    }
+    a[(size_t)r * ntau + c] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // EIS variance-estimation matrix: one 256-thread block per row of the (2nf x 2nf) matrix
 // ---------------------------------------------------------------------------------------------------------
@@ -654,6 +725,17 @@ void launch_response_matrix(hipStream_t st, const double* times, int nt, const d
         hipLaunchKernelGGL(response_trapz_kernel, dim3((ntau + 15) / 16, nt), dim3(256), 3 * ny * sizeof(double), st,
                            times, nt, tau, ntau, step_times, step_sizes, nsteps, eps, ny, a, layered);
     }
+}
+
+void launch_response_variant(hipStream_t st, const double* times, int nt, const double* tau, int ntau,
+                             const double* step_times, const double* step_sizes, const double* tau_rise, int nsteps,
+                             int variant, double eps, int ny, double* a, double* layered) {
+    if (variant == HIPDRT_RESPONSE_POT)
+        hipLaunchKernelGGL(response_pot_kernel, dim3((ntau + 255) / 256, nt), dim3(256), 0, st, times, nt, tau, ntau,
+                           step_times, step_sizes, nsteps, a, layered);
+    else
+        hipLaunchKernelGGL(response_expdecay_kernel, dim3((ntau + 15) / 16, nt), dim3(256), 3 * ny * sizeof(double), st,
+                           times, nt, tau, ntau, step_times, step_sizes, tau_rise, nsteps, eps, ny, a, layered);
 }
 
 void launch_penalty(hipStream_t st, const double* ln_tau, int n, double eps, int toeplitz, double* m0, double* m1,

@@ -83,15 +83,26 @@ def construct_response_matrix(basis_tau, times, step_model, step_times, step_siz
                               integrate_points=1000, zga_params=None, interpolate_grids=None, device=0):
     """mat1d.construct_response_matrix (hybdrt/matrices/mat1d.py:16-122): returns (A, A_layered) with
     ``A @ x`` the time response to the current steps; ``A_layered[k]`` is the contribution of step k.
-    Built for the fit defaults (gaussian basis, galvanostatic, ideal step); 'interp' needs ``interpolate_grids``
-    = (log_td_grid, response_grid) from ``basis.generate_response_lookup``."""
+    Gaussian basis; galvanostatic with ideal steps ('interp' needs ``interpolate_grids`` = (log_td_grid, response_grid) from
+    ``basis.generate_response_lookup``; 'trapz') or with exponentially rising steps (``step_model='expdecay'``, ``tau_rise`` per step,
+    'trapz'), and the potentiostatic delta-function response (``op_mode='pot'``).  'quad' is not built."""
     if step_model not in ('ideal', 'expdecay'):
         raise ValueError(f'Invalid step_model {step_model}. Options: ideal, expdecay')
     if op_mode not in ('galv', 'pot'):
         raise ValueError(f'Invalid op_mode {op_mode}. Options: galv, pot')
-    if basis_type != 'gaussian' or op_mode != 'galv' or step_model != 'ideal':
-        raise NotImplementedError("only gaussian basis / galvanostatic / ideal step are on the hot path")
+    if basis_type != 'gaussian':
+        raise NotImplementedError("only the gaussian basis is built")
+    step_times = np.asarray(step_times, dtype=float)
+    step_sizes = np.asarray(step_sizes, dtype=float)
+    times = np.asarray(times, dtype=float)
+    basis_tau = np.asarray(basis_tau, dtype=float)
+    if step_times.size == 0:
+        return np.zeros((times.size, basis_tau.size)), np.zeros((0, times.size, basis_tau.size))
+    if op_mode == 'pot':
+        # mat1d.py:114-118: the basis is a delta function whatever basis_type / step_model / integrate_method say
+        return _ffi.get_context(device).response_matrix_variant(times, basis_tau, step_times, step_sizes, _ffi.RESPONSE_POT)
     if integrate_method == 'interp':
+        # (the lookup holds the ideal step's response; the reference interpolates it for either step model, mat1d.py:108-112)
         if interpolate_grids is None:
             raise ValueError("interpolate_grids must be provided for integrate_method 'interp'")
         mode = _ffi.MODE_INTERP
@@ -99,12 +110,11 @@ def construct_response_matrix(basis_tau, times, step_model, step_times, step_siz
         mode = _ffi.MODE_TRAPZ
     else:
         raise NotImplementedError("integrate_method 'quad' is not built (scipy.integrate.quad on the host in the reference)")
-    step_times = np.asarray(step_times, dtype=float)
-    step_sizes = np.asarray(step_sizes, dtype=float)
-    times = np.asarray(times, dtype=float)
-    basis_tau = np.asarray(basis_tau, dtype=float)
-    if step_times.size == 0:
-        return np.zeros((times.size, basis_tau.size)), np.zeros((0, times.size, basis_tau.size))
+    if step_model == 'expdecay' and mode == _ffi.MODE_TRAPZ:
+        if tau_rise is None:            # mat1d.py:44-45: zeros -- the integrand's tau_rise / (tau_rise - T) factor is 0 / (-T) then
+            tau_rise = np.zeros(step_times.size)
+        return _ffi.get_context(device).response_matrix_variant(times, basis_tau, step_times, step_sizes, _ffi.RESPONSE_EXPDECAY,
+                                                                tau_rise=tau_rise, epsilon=epsilon, ny=integrate_points)
     return _ffi.get_context(device).response_matrix(times, basis_tau, step_times, step_sizes, epsilon, mode=mode,
                                                     lookup=interpolate_grids, ny=integrate_points, layered=True)
 
@@ -136,10 +146,19 @@ def construct_ohmic_response_vector(times, step_model, step_times, step_sizes, t
 
 
 def construct_inductance_response_vector(times, step_model, step_times, step_sizes, tau_rise, op_mode='galv'):
-    """mat1d.construct_inductance_response_vector (mat1d.py:377-395): zero for ideal steps."""
-    if step_model != 'ideal':
-        raise NotImplementedError("only the ideal step model is built")
-    return np.zeros(len(times))
+    """mat1d.construct_inductance_response_vector (mat1d.py:377-395): zero for ideal steps; an exponentially rising current
+    induces (step / tau_rise) exp(-(t - t_step) / tau_rise) after every step."""
+    if step_model not in ('ideal', 'expdecay'):
+        raise ValueError(f'Invalid step_model {step_model}. Options: ideal, expdecay')
+    times = np.asarray(times, dtype=float)
+    irv = np.zeros(len(times))
+    if step_model == 'expdecay':
+        if op_mode != 'galv':
+            raise ValueError('Inductance response vector not implemented for potentiostatic mode')
+        for st, sa, tr in zip(step_times, step_sizes, tau_rise):
+            after = times >= st
+            irv[after] += (sa / tr) * np.exp(-(times[after] - st) / tr)
+    return irv
 
 
 def construct_capacitance_response_vector(times, step_model, step_times, step_sizes, tau_rise, op_mode='galv'):

@@ -114,6 +114,18 @@ int hipdrt_response_matrix(hipdrt_ctx* ctx, const double* times, int nt, const d
                            double epsilon, int ngrid, const double* log_td, const double* v, int ny,
                            double* a, double* layered);
 
+/* The non-default forms of mat1d.construct_response_matrix (hybdrt/matrices/mat1d.py:96-118), Gaussian basis:
+ *   HIPDRT_RESPONSE_POT       op_mode='pot' (mat1d.py:114-118): exp(-(t - t_k) / tau) * unit_step(t, t_k) * size_k, rows before a
+ *                             step 0 (tau_rise, epsilon, ny unused)
+ *   HIPDRT_RESPONSE_EXPDECAY  op_mode='galv', step_model='expdecay', integrate_method='trapz' (integrand basis.py:619-637):
+ *                             tau_rise[nsteps] = rise time of every step, ny-point trapezoid over y = linspace(-20, 20, ny)
+ * same outputs as hipdrt_response_matrix                                                                    */
+#define HIPDRT_RESPONSE_POT 0
+#define HIPDRT_RESPONSE_EXPDECAY 1
+int hipdrt_response_matrix_variant(hipdrt_ctx* ctx, const double* times, int nt, const double* tau, int ntau,
+                                   const double* step_times, const double* step_sizes, const double* tau_rise, int nsteps,
+                                   int variant, double epsilon, int ny, double* a, double* layered);
+
 /* filters.nonuniform_gaussian_filter1d (hybdrt/filters/_filters.py:261-343; order 0, mode 'reflect', empty=False) applied
  * segment by segment: the anti-aliasing filter of the chrono down-sampling (preprocessing.filter_chrono_signal, 507-572,
  * called by downsample_data, 423-432).  y[n], sigma[n] (per-sample filter widths in samples, already capped);

@@ -156,6 +156,14 @@ def run_response_matrices():
                                              op_mode='galv', integrate_method='trapz', integrate_points=1000)
     out.update(trapz_tau=tau_s, trapz_times=times_s, trapz_epsilon=eps_s, trapz_step_times=st, trapz_step_sizes=sa,
                trapz_A=a, trapz_layered=lay)
+    # the non-default forms (mat1d.py:96-118): potentiostatic delta response; expdecay step model (trapz) + its inductance vector
+    a, lay = mat1d.construct_response_matrix(tau_s, times_s, 'ideal', st, sa, basis_type='gaussian', epsilon=eps_s, op_mode='pot')
+    out.update(pot_A=a, pot_layered=lay)
+    tr = np.array([2e-4, 5e-3])
+    a, lay = mat1d.construct_response_matrix(tau_s, times_s, 'expdecay', st, sa, basis_type='gaussian', epsilon=eps_s, tau_rise=tr,
+                                             op_mode='galv', integrate_method='trapz', integrate_points=1000)
+    out.update(expdecay_tau_rise=tr, expdecay_A=a, expdecay_layered=lay,
+               expdecay_inductance_rv=mat1d.construct_inductance_response_vector(times_s, 'expdecay', st, sa, tr))
     # chrono variance-estimation matrices (survey row a5, mat1d.py:457-490): flexible and uniform error structure
     for name in ("one_step", "three_steps"):
         st = cases[name][0]

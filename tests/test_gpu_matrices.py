@@ -203,6 +203,36 @@ def test_response_matrix_trapz_vs_reference_fixture(ctx):
     np.testing.assert_allclose(a, g["trapz_A"], rtol=RTOL, atol=4e-18)
 
 
+def test_response_matrix_potentiostatic_and_expdecay_vs_reference_fixture(ctx):
+    """the non-default forms of construct_response_matrix (mat1d.py:96-118) against the reference's own output: the potentiostatic
+    delta-function response (rows before a step exactly zero, the step's own row included from t >= t_step on), the expdecay step
+    model's trapezoid integrals with one rise time per step, and the inductance response vector that goes with it"""
+    from hipdrt.matrices import mat1d
+    g = load("refrun_response.npz")
+    tau, times, st, sa = g["trapz_tau"], g["trapz_times"], g["trapz_step_times"], g["trapz_step_sizes"]
+    a, lay = mat1d.construct_response_matrix(tau, times, 'ideal', st, sa, epsilon=float(g["trapz_epsilon"]), op_mode='pot')
+    np.testing.assert_array_equal(lay == 0.0, g["pot_layered"] == 0.0)
+    np.testing.assert_allclose(lay, g["pot_layered"], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(a, g["pot_A"], rtol=1e-13, atol=1e-18)
+    tr = g["expdecay_tau_rise"]
+    a, lay = mat1d.construct_response_matrix(tau, times, 'expdecay', st, sa, epsilon=float(g["trapz_epsilon"]), tau_rise=tr,
+                                             integrate_method='trapz', integrate_points=1000)
+    np.testing.assert_array_equal(lay == 0.0, g["expdecay_layered"] == 0.0)
+    # (the integrand subtracts exponentials of nearly equal size where e^y tau passes tau_rise: absolute floor as for 'trapz')
+    np.testing.assert_allclose(lay, g["expdecay_layered"], rtol=1e-10, atol=1e-17)
+    np.testing.assert_allclose(a, g["expdecay_A"], rtol=1e-10, atol=1e-17)
+    assert np.abs(a - g["trapz_A"]).max() > 1e-3 * np.abs(a).max()            # not the ideal step's matrix
+    # tau_rise -> 0 is the ideal step
+    a0, _ = mat1d.construct_response_matrix(tau, times, 'expdecay', st, sa, epsilon=float(g["trapz_epsilon"]),
+                                            integrate_method='trapz', integrate_points=1000)
+    np.testing.assert_allclose(a0, g["trapz_A"], rtol=RTOL, atol=4e-18)
+    irv = mat1d.construct_inductance_response_vector(times, 'expdecay', st, sa, tr)
+    np.testing.assert_allclose(irv, g["expdecay_inductance_rv"], rtol=1e-14, atol=0)
+    assert not mat1d.construct_inductance_response_vector(times, 'ideal', st, sa, None).any()
+    with pytest.raises(NotImplementedError):
+        mat1d.construct_response_matrix(tau, times, 'ideal', st, sa, integrate_method='quad')
+
+
 def test_response_matrix_c5_size_vs_oracle(ctx):
     """C5-sized chrono grid (4096 samples x 1024 tau, one step): HIP vs the CPU restatement on a row subset, and
     size-independent properties: linearity in the step size, zero rows before the step, monotone saturation."""
@@ -235,7 +265,9 @@ def test_response_matrix_rejects_unbuilt_branches(ctx):
     with pytest.raises(ValueError):
         mat1d.construct_response_matrix([1.0], [1.0], 'bogus', [0.0], [1.0])
     with pytest.raises(NotImplementedError):
-        mat1d.construct_response_matrix([1.0], [1.0], 'ideal', [0.0], [1.0], op_mode='pot')
+        mat1d.construct_response_matrix([1.0], [1.0], 'ideal', [0.0], [1.0], integrate_method='quad')
+    with pytest.raises(NotImplementedError):
+        mat1d.construct_response_matrix([1.0], [1.0], 'ideal', [0.0], [1.0], basis_type='Cole-Cole')
 
 
 @pytest.mark.parametrize("case", ["one_step", "three_steps"])

@@ -55,7 +55,11 @@ def get_step_info(times, y, allow_consecutive=True, offset_step_times=False, off
 def process_input_signal(times, input_signal, step_model, offset_steps, offset_size=None, rthresh=50):
     """preprocessing.process_input_signal (136-158) for step_model='ideal'."""
     if step_model != 'ideal':
-        raise NotImplementedError("only the ideal step model is built (expdecay fits the input signal on the host)")
+        # (the matrix level of the expdecay model IS built -- mat1d.construct_response_matrix / construct_inductance_response_vector;
+        # a FIT with it does not exist upstream either: _prep_chrono_fit_matrix calls construct_capacitance_response_vector
+        # unconditionally, drt1d.py:5581, which raises 'Capacitance response not implemented for non-ideal steps', mat1d.py:440)
+        raise NotImplementedError("only the ideal step model can be fitted (upstream's own expdecay fit stops in "
+                                  "construct_capacitance_response_vector)")
     step_times, step_sizes = get_step_info(times, input_signal, True, offset_steps, offset_size, rthresh)
     return step_times, step_sizes, None
 

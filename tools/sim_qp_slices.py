@@ -30,7 +30,7 @@ def one(i):
     return [l["iterations"] for l in od.qp_log]
 
 
-F_MS, SLOTS, ROUND_MS, GRAM_MS = 0.42, 512, 0.9, 0.00306     # factorisation under load, 2 workgroups x 256 CUs, per round, per spectrum
+F_MS, SLOTS, ROUND_MS, GRAM_MS = 0.44, 256, 0.9, 0.00306     # factorisation under load (profiles/r06_qp_saturation.txt), one workgroup per CU, per round, per spectrum
 
 
 def play(logs, B, K):

@@ -99,3 +99,27 @@ def test_auto_inflight_rule(monkeypatch):
     assert [len(f.calls) for f in fakes] == [1, 0, 0] and fakes[0].calls[0][1] == 600
     drtmd.fit_observations(fakes[0], freq, _data(600), inflight=2)          # an explicit count still splits
     assert [len(f.calls) for f in fakes] == [2, 1, 0] and [f.calls[-1][1] for f in fakes[:2]] == [300, 300]
+
+
+def test_extremes_are_dropped_per_observation_before_batches_are_formed():
+    """remove_extremes among a map's fit keywords (host logic only): the quantile-range filter runs per observation, observations that
+    lose different points no longer share a group, the switches leave the fit keywords; tags keep like-looking observations apart"""
+    import types
+    from hipdrt.mapping import drtmd
+    from hipdrt.models.prepared import PreparedFitMixin
+    stub = types.SimpleNamespace(warn=False)
+    stub._drop_extremes = lambda meas, ekw=None: PreparedFitMixin._drop_extremes(stub, meas, ekw)
+    freq = np.logspace(4, 0, 30)
+    z = (1.0 / (1.0 + 1j * freq / 50.0)).astype(complex)
+    z_bad = z.copy()
+    z_bad[7] += 40.0
+    obs = [(None, (freq, z)), (None, (freq, z_bad)), (None, (freq, z * 1.01))]
+    assert [len(i) for _, i in drtmd.observation_groups(obs)] == [3]
+    cleaned, kw, tags, step_times = drtmd.prefilter_observations(stub, obs, dict(nonneg=True, remove_extremes=True, extreme_kw=None))
+    assert kw == dict(nonneg=True) and tags is None and step_times == [None] * 3
+    assert [len(o[1][0]) for o in cleaned] == [30, 29, 30] and 7 not in np.searchsorted(-freq, -cleaned[1][1][0])
+    groups = drtmd.observation_groups(cleaned)
+    assert [idx for _, idx in groups] == [[0, 2], [1]]                      # the filtered one has its own frequency grid now
+    assert [idx for _, idx in drtmd.observation_groups(obs, tags=["a", "b", "a"])] == [[0, 2], [1]]
+    with pytest.raises(ValueError, match="outlier_p"):
+        drtmd.prefilter_observations(stub, obs, dict(remove_outliers=True))

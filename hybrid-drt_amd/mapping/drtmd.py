@@ -98,6 +98,7 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
 
     for sib in sibs:
         pin(sib, _RANGES_PER_INFLIGHT_PLAN)
+        sib.collect_fields = getattr(drt, 'collect_fields', None)
     outs, errs = [None] * len(chunks), [None] * len(chunks)
 
     def work(i):
@@ -635,7 +636,16 @@ def fit_observations_sharded(drt, frequencies=None, z_obs=None, rank=None, world
             obs_x, obs_special, res = fit(drt, tau_supergrid=tau_supergrid, drt_var=drt_var,
                                           observations=[observations[k] for k in mine], **kw)
         else:
-            obs_x, obs_special, res = fit(drt, frequencies, z_obs[mine], tau_supergrid=tau_supergrid, drt_var=drt_var, **kw)
+            # the gather below carries obs_x, the special parameters, llh / rss and the counts: nothing else is downloaded
+            lean = fit is fit_observations
+            before = getattr(drt, 'collect_fields', None)
+            if lean:
+                drt.collect_fields = 'map'
+            try:
+                obs_x, obs_special, res = fit(drt, frequencies, z_obs[mine], tau_supergrid=tau_supergrid, drt_var=drt_var, **kw)
+            finally:
+                if lean:
+                    drt.collect_fields = before
         packed = _pack_rows(obs_x, obs_special, res, drt_var)
     else:
         packed = None

@@ -286,10 +286,15 @@ class DRT(PreparedFitMixin):
     def collect_staged(self):
         plan = self._plan
         frequencies = self.f_fit
-        res = plan.download(s_vectors=True)
-        nf = len(frequencies)
-        sigma = 1.0 / res['weights']
-        res['z_sigma_tot'] = (sigma[:, :nf] + 1j * sigma[:, nf:]) * res['coefficient_scale'][:, None]
+        if getattr(self, 'collect_fields', None) == 'map':
+            # a map keeps, per observation, the distribution, the special parameters, llh / rss and the counts (drtmd.py:245-301):
+            # the solution in scaled units, weights, rho, s vectors and q stay on the device (mapping.fit_observations_sharded)
+            res = plan.download(lean=True)
+        else:
+            res = plan.download(s_vectors=True)
+            nf = len(frequencies)
+            sigma = 1.0 / res['weights']
+            res['z_sigma_tot'] = (sigma[:, :nf] + 1j * sigma[:, nf:]) * res['coefficient_scale'][:, None]
         res['basis_tau'] = self.basis_tau
         res['timings_ms'], res['launches'] = plan.timings()
         return res

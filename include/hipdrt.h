@@ -243,10 +243,14 @@ int hipdrt_plan_fit(hipdrt_plan* plan);
 /* How many contiguous ranges ("sub-batches") hipdrt_plan_fit cuts the staged spectra into: every range runs the same device
  * loop on a stream of its own, side by side, inside the one call and the plan's own buffers -- what DRTMD's serial loop over
  * observations (hybdrt/mapping/drtmd.py:303-319) becomes when the tail of one range's launches is filled by the others'.
- * k = 0 (default): chosen from the batch size (1 below 600 spectra, 2 from 600 on: profiles/r04_subbatch_sweep.txt,
- * r05h_subbatch_sweep.txt -- three or four ranges win or lose ~20 % depending on how their launches interleave); k >= 1: that many (capped so that a range keeps >= 64 spectra).  A caller that keeps SEVERAL plans fitting at
- * the same time (own contexts, own threads) should set k = 1 on each: the plans already fill each other's tails, and ranges inside
- * them only add launch waves (4 plans x 2 ranges: 2101 fits/s against 2326 for 4 x 1).  Plans with prepared matrices, a recorded history, weight factors or outlier_p fit in one range.
+ * k = 0 (default): chosen from the batch size -- 1 below 600 spectra, 2 from 600 on, 4 from 1000 on (capped at the number of the
+ * library's own streams, see hipdrt_stream: 3 under the runtime's default of 4 hardware queues; profiles/r06_subbatch_sweep.txt); the
+ * ranges run on those streams, picked per fit by activity and compute pipe, so the choice no longer depends on what else the process
+ * has created (profiles/r06_trace_queue_placement.txt).  k >= 1: that many (capped so that a range keeps >= 64 spectra).  A caller
+ * that keeps four or more plans fitting at the same time (own contexts, own threads) should set k = 1 on each: the command processor
+ * has four compute pipes, and launch sequences beyond four take turns (4 plans x 2 ranges: 1900 fits/s against 2372 for 4 x 1 at
+ * 1250 spectra, profiles/r06_inflight_ranges.txt).  Plans with prepared matrices, a recorded history, weight factors or outlier_p
+ * fit in one range.
  * Per-spectrum results do not depend on k (every kernel of the loop works per spectrum).                                    */
 int hipdrt_plan_set_subbatches(hipdrt_plan* plan, int k);
 /* results for the B staged spectra (any pointer may be NULL):

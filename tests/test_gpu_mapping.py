@@ -121,6 +121,31 @@ def test_remove_outliers_in_a_map_matches_the_reference_drtmd():
     np.testing.assert_allclose(ox[1, l:r], single.fit_parameters["x"], rtol=0, atol=1e-9 * np.abs(ox[1]).max())
 
 
+def test_sharded_map_downloads_only_what_a_map_records():
+    """fit_observations_sharded on a shared grid collects the lean set (distribution, special parameters, counts, status -- the
+    solution in scaled units, weights, rho, s vectors and q stay on the device): the same bits as the direct call returns for
+    those fields, the DRT object's own setting is restored, and a later plain batch fit on it is complete again"""
+    from hipdrt import synth
+    from hipdrt.mapping import fit_observations, fit_observations_sharded
+    from hipdrt.models import DRT
+    c1 = synth.config_c1()
+    z = synth.zarc2_batch(c1["freq"], 40, first_seed=900)
+    direct = fit_observations(DRT(fixed_basis_tau=c1["tau"]), c1["freq"], z, drt_var=True)
+    drt = DRT(fixed_basis_tau=c1["tau"])
+    obs_x, obs_special, res = fit_observations_sharded(drt, c1["freq"], z, rank=0, world=1, drt_var=True)
+    np.testing.assert_array_equal(obs_x, direct[0])
+    for key in ("R_inf", "inductance"):
+        np.testing.assert_array_equal(obs_special[key], direct[1][key], err_msg=key)
+    for key in ("obs_llh", "obs_rss", "outer_iters", "qp_iters_total", "status", "obs_drt_var"):
+        np.testing.assert_array_equal(res[key], direct[2][key], err_msg=key)
+    assert getattr(drt, "collect_fields", None) is None
+    full = drt.fit_eis_batch(c1["freq"], z[:4])
+    assert {"x", "weights", "rho", "s_vectors", "q_vector", "z_sigma_tot"} <= set(full)
+    lean = drt._plan.download(lean=True)
+    assert "weights" not in lean and "x" not in lean
+    np.testing.assert_array_equal(lean["fit_x"], full["fit_x"])
+
+
 def test_mixed_map_through_the_sharded_driver():
     """the same map through fit_observations_sharded (world 1 = what every rank of a node runs on its shard): identical to
     the direct call"""

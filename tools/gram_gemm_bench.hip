@@ -12,9 +12,11 @@ constexpr int TM = 128, TN = 128, SK = 16, LD = 144;     // LD: k rows land 32 b
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // Kp: [mblk][k][TM] (a slab of 16 k rows of one M block is 16 kB contiguous), W2: [k][N], P: [n][M]
-template <bool XCD, bool STORE>
+template <bool XCD, bool STORE, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const double* __restrict__ Kp, const double* __restrict__ W2,
-                                                      double* __restrict__ P, int M, int N, int KD, int nblk_n) {
+                                                      double* __restrict__ P, int M, int N, int KD, int nblk_n,
+                                                      unsigned long long* __restrict__ clk) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     __shared__ double sA[2][SK * LD];
     __shared__ double sB[2][SK * LD];
     int mb, nb;
@@ -53,6 +55,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const double* __restrict__
     int buf = 0;
     for (int k0 = 0; k0 < KD; k0 += SK) {
         if (k0 + SK < KD) fetch(k0 + SK);
+        if (PIPE) {
+            // operands of k step kk + 4 requested in front of the sixteen matrix instructions of step kk
+            double a[2][4], b[2][4];
+            auto ld = [&](int slot, int kk) {
+                const int kr = kk + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a[slot][i] = sA[buf][kr * LD + wm + 16 * i + (lane & 15)]; b[slot][i] = sB[buf][kr * LD + wn + 16 * i + (lane & 15)]; }
+            };
+            ld(0, 0);
+#pragma unroll
+            for (int q = 0; q < SK / 4; ++q) {
+                if (q + 1 < SK / 4) ld((q + 1) & 1, 4 * (q + 1));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[q & 1][j], a[q & 1][i], acc[i][j], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < SK; kk += 4) {
             const int kr = kk + (lane >> 4);
@@ -64,9 +84,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const double* __restrict__
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0);
         }
+        }
         if (k0 + SK < KD) { stash(buf ^ 1); }
         __syncthreads();
         buf ^= 1;
+    }
+    if (threadIdx.x == 0 && clk && blockIdx.x == gridDim.x / 2) {     // shader clock over this workgroup's life: ticks per 100 MHz tick
+        clk[0] = __builtin_amdgcn_s_memtime() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
     // acc[i][j], lane l, register r = element (m = wm + 16 i + (l & 15), n = wn + 16 j + (l >> 4) + 4 r): 16 consecutive m per n
 #pragma unroll
@@ -90,19 +114,24 @@ int main(int argc, char** argv) {
     double *dK, *dW, *dP;
     CK(hipMalloc(&dK, hK.size() * 8)); CK(hipMalloc(&dW, hW.size() * 8)); CK(hipMalloc(&dP, (size_t)N * M * 8));
     CK(hipMemcpy(dK, hK.data(), hK.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), hW.size() * 8, hipMemcpyHostToDevice));
+    unsigned long long* dC; CK(hipMalloc(&dC, 16)); CK(hipMemset(dC, 0, 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int xcd = 0; xcd < 3; ++xcd) {
+    for (int xcd = 0; xcd < 5; ++xcd) {
         const int grid = ((nbm + 7) / 8) * 8 * nbn;
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
-            if (xcd == 1) hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn);
-            else if (xcd == 2) hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn);
-            else hipLaunchKernelGGL((gemm_kernel<false, true>), dim3(nbm * nbn), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn);
+            if (xcd == 1) hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
+            else if (xcd == 2) hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
+            else if (xcd == 3) hipLaunchKernelGGL((gemm_kernel<true, false, true>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
+            else if (xcd == 4) hipLaunchKernelGGL((gemm_kernel<true, true, true>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
+            else hipLaunchKernelGGL((gemm_kernel<false, true>), dim3(nbm * nbn), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             const double fl = 2.0 * M * (double)N * KD;
+            unsigned long long hc[2]; CK(hipMemcpy(hc, dC, 16, hipMemcpyDeviceToHost));
+            if (rep == 2 && hc[1]) printf("   shader clock while a mid-grid workgroup ran: %.2f GHz (%llu shader ticks over %llu ticks of 100 MHz)\n", hc[0] / (double)hc[1] * 0.1, hc[0], hc[1]);
             if (rep == 2) printf("N = %d spectra, %s block order: %.3f ms, %.1f TFLOP/s = %.3f of 78.6; P written %.2f GB -> %.2f TB/s of stores\n", N,
-                                 xcd == 2 ? "XCD-grouped, NO STORES (K loop only)" : xcd ? "XCD-grouped" : "row-major", ms, fl / ms / 1e9, fl / ms / 1e9 / 78.6, (double)N * M * 8 / 1e9, (double)N * M * 8 / ms / 1e9);
+                                 xcd == 4 ? "XCD-grouped, operands one k step ahead" : xcd == 3 ? "XCD-grouped, operands one k step ahead, NO STORES" : xcd == 2 ? "XCD-grouped, NO STORES (K loop only)" : xcd ? "XCD-grouped" : "row-major", ms, fl / ms / 1e9, fl / ms / 1e9 / 78.6, (double)N * M * 8 / 1e9, (double)N * M * 8 / ms / 1e9);
         }
     }
     // spot check

@@ -12,7 +12,7 @@ constexpr int TM = 128, TN = 128, SK = 16, LD = 144;     // LD: k rows land 32 b
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // Kp: [mblk][k][TM] (a slab of 16 k rows of one M block is 16 kB contiguous), W2: [k][N], P: [n][M]
-template <bool XCD, bool STORE, bool PIPE = false>
+template <bool XCD, bool STORE, bool PIPE = false, int MODE = 0>      // MODE 1: no global fetch / LDS refill inside the loop; 2: no LDS reads either
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const double* __restrict__ Kp, const double* __restrict__ W2,
                                                       double* __restrict__ P, int M, int N, int KD, int nblk_n,
                                                       unsigned long long* __restrict__ clk) {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const double* __restrict__
     __syncthreads();
     int buf = 0;
     for (int k0 = 0; k0 < KD; k0 += SK) {
-        if (k0 + SK < KD) fetch(k0 + SK);
+        if (MODE == 0 && k0 + SK < KD) fetch(k0 + SK);
         if (PIPE) {
             // operands of k step kk + 4 requested in front of the sixteen matrix instructions of step kk
             double a[2][4], b[2][4];
@@ -78,16 +78,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const double* __restrict__
             const int kr = kk + (lane >> 4);
             double a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = sA[buf][kr * LD + wm + 16 * i + (lane & 15)]; b[i] = sB[buf][kr * LD + wn + 16 * i + (lane & 15)]; }
+            for (int i = 0; i < 4; ++i) {
+                if (MODE == 2) { a[i] = 1.0 + kr + i + k0; b[i] = 2.0 + kr - i + k0; }
+                else { a[i] = sA[buf][kr * LD + wm + 16 * i + (lane & 15)]; b[i] = sB[buf][kr * LD + wn + 16 * i + (lane & 15)]; }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         }
-        if (k0 + SK < KD) { stash(buf ^ 1); }
-        __syncthreads();
-        buf ^= 1;
+        if (MODE == 0 || MODE == 4) {             // MODE 4: LDS refill + barrier, but from registers fetched once (no global loads in the loop)
+            if (k0 + SK < KD) { stash(buf ^ 1); }
+            __syncthreads();
+            buf ^= 1;
+        } else if (MODE == 3) {                   // MODE 3: the barrier alone
+            __syncthreads();
+            buf ^= 1;
+        }
     }
     if (threadIdx.x == 0 && clk && blockIdx.x == gridDim.x / 2) {     // shader clock over this workgroup's life: ticks per 100 MHz tick
         clk[0] = __builtin_amdgcn_s_memtime() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
@@ -116,7 +124,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dK, hK.data(), hK.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), hW.size() * 8, hipMemcpyHostToDevice));
     unsigned long long* dC; CK(hipMalloc(&dC, 16)); CK(hipMemset(dC, 0, 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int xcd = 0; xcd < 5; ++xcd) {
+    for (int xcd = 0; xcd < 9; ++xcd) {
         const int grid = ((nbm + 7) / 8) * 8 * nbn;
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
@@ -124,6 +132,10 @@ int main(int argc, char** argv) {
             else if (xcd == 2) hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
             else if (xcd == 3) hipLaunchKernelGGL((gemm_kernel<true, false, true>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
             else if (xcd == 4) hipLaunchKernelGGL((gemm_kernel<true, true, true>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
+            else if (xcd == 5) hipLaunchKernelGGL((gemm_kernel<true, false, false, 1>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
+            else if (xcd == 6) hipLaunchKernelGGL((gemm_kernel<true, false, false, 2>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
+            else if (xcd == 7) hipLaunchKernelGGL((gemm_kernel<true, false, false, 3>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
+            else if (xcd == 8) hipLaunchKernelGGL((gemm_kernel<true, false, false, 4>), dim3(grid), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
             else hipLaunchKernelGGL((gemm_kernel<false, true>), dim3(nbm * nbn), dim3(256), 0, 0, dK, dW, dP, M, N, KD, nbn, dC);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -131,7 +143,7 @@ int main(int argc, char** argv) {
             unsigned long long hc[2]; CK(hipMemcpy(hc, dC, 16, hipMemcpyDeviceToHost));
             if (rep == 2 && hc[1]) printf("   shader clock while a mid-grid workgroup ran: %.2f GHz (%llu shader ticks over %llu ticks of 100 MHz)\n", hc[0] / (double)hc[1] * 0.1, hc[0], hc[1]);
             if (rep == 2) printf("N = %d spectra, %s block order: %.3f ms, %.1f TFLOP/s = %.3f of 78.6; P written %.2f GB -> %.2f TB/s of stores\n", N,
-                                 xcd == 4 ? "XCD-grouped, operands one k step ahead" : xcd == 3 ? "XCD-grouped, operands one k step ahead, NO STORES" : xcd == 2 ? "XCD-grouped, NO STORES (K loop only)" : xcd ? "XCD-grouped" : "row-major", ms, fl / ms / 1e9, fl / ms / 1e9 / 78.6, (double)N * M * 8 / 1e9, (double)N * M * 8 / ms / 1e9);
+                                 xcd == 8 ? "NO STORES, LDS refill + barrier per slab, no global loads in the loop" : xcd == 7 ? "NO STORES, barrier per slab only" : xcd == 6 ? "NO STORES, no global fetch, no LDS reads (registers only)" : xcd == 5 ? "NO STORES, no global fetch / LDS refill / barrier in the loop (LDS reads only)" : xcd == 4 ? "XCD-grouped, operands one k step ahead" : xcd == 3 ? "XCD-grouped, operands one k step ahead, NO STORES" : xcd == 2 ? "XCD-grouped, NO STORES (K loop only)" : xcd ? "XCD-grouped" : "row-major", ms, fl / ms / 1e9, fl / ms / 1e9 / 78.6, (double)N * M * 8 / 1e9, (double)N * M * 8 / ms / 1e9);
         }
     }
     // spot check

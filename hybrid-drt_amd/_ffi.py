@@ -87,6 +87,7 @@ SIGNATURES = {
     "hipdrt_response_lookup": [_vp, C.c_double, C.c_int, C.c_int, _dp, _dp],
     "hipdrt_response_matrix": [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp,
                                C.c_int, _dp, _dp],
+    "hipdrt_plan_bytes_per_spectrum": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)],
     "hipdrt_response_matrix_variant": [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
                                        _dp, _dp],
     "hipdrt_nonuniform_gaussian_filter1d": [_vp, _dp, C.c_int, _dp, _ip, C.c_int, _ip, _dp, C.c_int, _dp, _dp, C.c_longlong,
@@ -245,6 +246,12 @@ class Context:
 
     def synchronize(self):
         _check(self._lib.hipdrt_synchronize(self._h))
+
+    def plan_bytes_per_spectrum(self, nf, ntau, ns):
+        """device bytes one staged spectrum costs an EIS plan of this shape (hipdrt_plan_bytes_per_spectrum)"""
+        out = C.c_longlong(0)
+        _check(self._lib.hipdrt_plan_bytes_per_spectrum(int(nf), int(ntau), int(ns), C.byref(out)))
+        return out.value
 
     def device_info(self):
         buf = C.create_string_buffer(64)

@@ -1420,6 +1420,21 @@ static int make_view(hipdrt_plan* p, hipdrt_subfit& sf, int idx, int b0, int nb)
     return HIPDRT_OK;
 }
 
+// device bytes one more staged spectrum costs an EIS plan (the per-spectrum buffers plan_alloc and hipdrt_plan_fit size by the
+// capacity): what a map driver divides the device's memory by before it forms its batches
+int hipdrt_plan_bytes_per_spectrum(int nf, int ntau, int ns, long long* bytes) try {
+    HIPDRT_REQUIRE(bytes && nf >= 1 && ntau >= 1 && ns >= 0, "arguments");
+    const size_t n = (size_t)ntau + ns, m = 2 * (size_t)nf, D = sizeof(double), I = sizeof(int);
+    size_t b = 0;
+    b += 2 * (size_t)nf * D;                           // z_re, z_im
+    b += 3 * m * D + 3 * m * D;                        // rv, w, est_w; the three batched products of the hyper phase
+    b += 3 * n * D + 3 * n * D;                        // x, x_in, q; s
+    b += (3 + 3 + 1 + 1 + 1) * D + 8 * I;              // rho, xmx, scales, cost; flags and counters
+    b += (qp_scratch_doubles((int)n, 0) + qp_state_doubles((int)n) + qp_ppk_doubles((int)n)) * D + qp_gsync_ints() * I;
+    *bytes = (long long)b;
+    return HIPDRT_OK;
+} HIPDRT_CATCH
+
 int hipdrt_plan_set_subbatches(hipdrt_plan* p, int k) try {
     HIPDRT_REQUIRE(p, "plan is NULL");
     HIPDRT_REQUIRE(k >= 0 && k <= 16, "0 (automatic) <= k <= 16");

@@ -120,6 +120,11 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
     for exc in errs:
         if exc is not None:
             raise exc
+    return _merge_chunk_results(outs, chunks, ignore_errors)
+
+
+def _merge_chunk_results(outs, chunks, ignore_errors):
+    """results of fit_observations on consecutive chunks of one map -> the result for the whole map"""
     obs_x = np.concatenate([o[0] for o in outs])
     obs_special = {k: np.concatenate([o[1][k] for o in outs]) for k in outs[0][1]}
     res = {}
@@ -133,6 +138,26 @@ def _fit_observations_inflight(drt, frequencies, z_obs, inflight, tau_supergrid,
     res['obs_fit_errors'] = [e for o in outs for e in o[2]['obs_fit_errors']]
     _raise_first_error(res, ignore_errors)
     return obs_x, obs_special, res
+
+
+def max_batch_for(drt, frequencies):
+    """How many spectra of this shape ONE device batch may hold: 80 % of the device's memory over what a staged spectrum costs the
+    plan (hipdrt_plan_bytes_per_spectrum: 4.9 MB at 256 x 512, i.e. about 47 000 spectra on 288 GB).  None when the DRT object
+    cannot say (stand-ins in the CPU tests)."""
+    try:
+        from .. import _ffi
+        ctx = drt._context if getattr(drt, '_context', None) is not None else _ffi.get_context(drt.device)
+        if drt.fixed_basis_tau is not None:
+            tau = drt.fixed_basis_tau
+        else:
+            from .. import preprocessing as pp
+            tau = pp.get_basis_tau(np.asarray(frequencies, dtype=float), None, None, tau_grid=drt.tau_supergrid,
+                                   extend_decades=drt.extend_basis_decades)
+        ns = int(bool(drt.fit_ohmic)) + int(bool(drt.fit_inductance))
+        per = ctx.plan_bytes_per_spectrum(len(frequencies), len(tau), ns)
+        return max(1, int(0.8 * ctx.device_info()['hbm_bytes'] / per))
+    except (AttributeError, TypeError):
+        return None
 
 
 def _raise_first_error(res, ignore_errors):
@@ -391,7 +416,7 @@ def fit_observations_pfrt(drt, observations, tau_supergrid, pfrt_factors=None, d
 
 
 def fit_observations(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_var=False, ignore_errors=False, llh_kw=None,
-                     rss_kw=None, inflight=1, observations=None, fit_type='drt', pfrt_factors=None, **fit_kw):
+                     rss_kw=None, inflight=1, observations=None, fit_type='drt', pfrt_factors=None, max_batch=None, **fit_kw):
     """Fit every observation and scatter the coefficients into supergrid slots like DRTMD.fit_observation does
     (drtmd.py:245-301): returns obs_x (B, len(supergrid)), obs_special dict, and the raw result dict, which also
     carries what the reference keeps per observation:
@@ -408,7 +433,10 @@ def fit_observations(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_
     ``observations=[(chrono_data, eis_data), ...]`` = any mix of data types and grids (fit_observation_list; needs
     `tau_supergrid`).  ``inflight`` > 1 (shared-grid form) fits the observations as that many batches side by side
     (sibling plans of `drt`, one host thread each): same results, in the same order, at the throughput of several batches
-    in flight; 'auto' = auto_inflight(number of observations).  (Afterwards `drt` itself holds the first batch only.)"""
+    in flight; 'auto' = auto_inflight(number of observations).  (Afterwards `drt` itself holds the first batch only.)
+    A shared-grid map that does not fit the device at once is fitted as consecutive batches of nearly equal size through the same
+    plan (``max_batch`` spectra at most; default max_batch_for(drt, frequencies): 80 % of the device's memory, about 47 000 spectra
+    of 256 x 512 on 288 GB) -- same results, same order."""
     if fit_type not in ('drt', 'pfrt'):
         raise ValueError(f"Invalid fit_type {fit_type}. Options: ['drt', 'pfrt']")          # drtmd.py:1479-1482
     if fit_type == 'pfrt':
@@ -432,6 +460,14 @@ def fit_observations(drt, frequencies=None, z_obs=None, tau_supergrid=None, drt_
     if inflight > 1 and z_obs.shape[0] >= 2 * inflight:
         return _fit_observations_inflight(drt, frequencies, z_obs, int(inflight), tau_supergrid, drt_var, ignore_errors,
                                           llh_kw, rss_kw, fit_kw)
+    limit = max_batch if max_batch is not None else max_batch_for(drt, frequencies)
+    if limit is not None and z_obs.shape[0] > limit:
+        # a map that does not fit the device at once: consecutive batches of (nearly) equal size through the same plan
+        parts = -(-z_obs.shape[0] // limit)
+        chunks = [c for c in np.array_split(np.arange(z_obs.shape[0]), parts) if len(c)]
+        outs = [fit_observations(drt, frequencies, z_obs[c], tau_supergrid=tau_supergrid, drt_var=drt_var, ignore_errors=True,
+                                 llh_kw=llh_kw, rss_kw=rss_kw, inflight=1, max_batch=limit, **fit_kw) for c in chunks]
+        return _merge_chunk_results(outs, chunks, ignore_errors)
     llh_kw, rss_kw = _metric_kw(llh_kw, rss_kw)
     res = drt.fit_eis_batch(frequencies, z_obs, **fit_kw)
     num = z_obs.shape[0]

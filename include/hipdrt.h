@@ -253,6 +253,10 @@ int hipdrt_plan_fit(hipdrt_plan* plan);
  * fit in one range.
  * Per-spectrum results do not depend on k (every kernel of the loop works per spectrum).                                    */
 int hipdrt_plan_set_subbatches(hipdrt_plan* plan, int k);
+/* device bytes ONE staged spectrum costs an EIS plan of this shape (nf frequencies, ntau basis points, ns special parameters):
+ * 4.9 MB at 256 x 512 -- the factor and P in tile order are the bulk.  A map driver sizes its batches with it
+ * (mapping.fit_observations cuts a map that would not fit 80 % of the device's memory into consecutive batches).             */
+int hipdrt_plan_bytes_per_spectrum(int nf, int ntau, int ns, long long* bytes);
 /* results for the B staged spectra (any pointer may be NULL):
  * x[B][n] QP solution in scaled units, fit_x[B][ntau] / r_inf[B] / induc[B] rescaled like
  * extract_qphb_parameters (drt1d.py:6228-6289), weights[B][m] (1/sigma, scaled units),

@@ -146,6 +146,33 @@ def test_sharded_map_downloads_only_what_a_map_records():
     np.testing.assert_array_equal(lean["fit_x"], full["fit_x"])
 
 
+def test_map_cut_into_consecutive_batches_gives_the_same_bits():
+    """a map that does not fit the device at once (here: max_batch = 20 of 60 spectra) runs as consecutive batches through the same
+    plan -- identical to the one-batch result; and the library's estimate of what a staged spectrum costs (4.9 MB at 256 x 512)
+    is what the default limit is made of"""
+    from hipdrt import _ffi, synth
+    from hipdrt.mapping import fit_observations
+    from hipdrt.mapping.drtmd import max_batch_for
+    from hipdrt.models import DRT
+    c1 = synth.config_c1()
+    z = synth.zarc2_batch(c1["freq"], 60, first_seed=1200)
+    whole = fit_observations(DRT(fixed_basis_tau=c1["tau"]), c1["freq"], z, drt_var=True)
+    drt = DRT(fixed_basis_tau=c1["tau"])
+    cut = fit_observations(drt, c1["freq"], z, drt_var=True, max_batch=20)
+    assert drt._plan.B == 20                                               # the last of three batches
+    np.testing.assert_array_equal(cut[0], whole[0])
+    for key in whole[1]:
+        np.testing.assert_array_equal(cut[1][key], whole[1][key], err_msg=key)
+    for key in ("obs_llh", "obs_rss", "outer_iters", "qp_iters_total", "status", "obs_drt_var", "fit_x", "weights"):
+        np.testing.assert_array_equal(cut[2][key], whole[2][key], err_msg=key)
+    c2 = synth.config_c2()
+    ctx = _ffi.get_context(0)
+    per = ctx.plan_bytes_per_spectrum(len(c2["freq"]), len(c2["tau"]), 2)
+    assert 4.7e6 < per < 5.1e6                                             # measured 4.88 MB (tools/probe_plan_memory.py)
+    limit = max_batch_for(DRT(fixed_basis_tau=c2["tau"]), c2["freq"])
+    assert limit == int(0.8 * ctx.device_info()["hbm_bytes"] / per) and 30000 < limit < 80000
+
+
 def test_mixed_map_through_the_sharded_driver():
     """the same map through fit_observations_sharded (world 1 = what every rank of a node runs on its shard): identical to
     the direct call"""

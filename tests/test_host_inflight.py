@@ -123,3 +123,23 @@ def test_extremes_are_dropped_per_observation_before_batches_are_formed():
     assert [idx for _, idx in drtmd.observation_groups(obs, tags=["a", "b", "a"])] == [[0, 2], [1]]
     with pytest.raises(ValueError, match="outlier_p"):
         drtmd.prefilter_observations(stub, obs, dict(remove_outliers=True))
+
+
+def test_a_map_larger_than_one_batch_is_fitted_in_consecutive_batches():
+    """max_batch: the shared-grid form cuts a map that does not fit the device at once into consecutive batches of nearly equal
+    size on the same plan; results come back in the original order (host logic with a stand-in DRT)"""
+    from hipdrt.mapping import drtmd
+    fake = _FakeDRT()
+    freq = np.logspace(3, 0, 9)
+    z = _data(25)
+    obs_x, obs_special, res = drtmd.fit_observations(fake, freq, z, max_batch=10)
+    assert [c[1] for c in fake.calls] == [9, 8, 8]                      # three batches, not 10 + 10 + 5
+    whole = _FakeDRT()
+    ref_x, ref_special, ref = drtmd.fit_observations(whole, freq, z)
+    assert [c[1] for c in whole.calls] == [25]                          # (a stand-in cannot say what fits: one batch)
+    np.testing.assert_array_equal(obs_x, ref_x)
+    for key in ref_special:
+        np.testing.assert_array_equal(obs_special[key], ref_special[key])
+    np.testing.assert_array_equal(res["obs_llh"], ref["obs_llh"])
+    assert len(res["obs_fit_errors"]) == 25 and res["obs_fit_status"].all()
+    assert drtmd.max_batch_for(fake, freq) is None

@@ -716,7 +716,9 @@ def main():
                 "unknowns": int(d5.qphb_params["rm"].shape[1]), "outer_iterations": it5,
                 "note": "2 uV of voltage noise: the reference's own outer loop is not contractive on this workload -- the answer is "
                         "not reproducible beyond outer iteration 6 in any implementation (tests/golden/refrun_config5_2uV pins those "
-                        "six); the timing is of the full 50 iterations"}
+                        "six); the timing is of the full 50 iterations.  The call before it fitted the same protocol on the same object: "
+                        "the penalty / variance / impedance blocks are kept from it, as upstream keeps its fit matrices while the "
+                        "sampling does not change -- the first fit of a protocol takes about 0.08 s longer"}
             # the same fit on the CONTRACTIVE workload (20 uV of voltage noise; tests/golden/refrun_config5_full pins its first
             # twelve outer iterations against the reference's own run at 4.8e-10 of the peak)
             meas20 = synth.hybrid_measurement(seed=0, n_pre=96, n_post=4000, nf=512, v_noise=2e-5)

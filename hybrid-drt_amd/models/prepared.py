@@ -82,11 +82,15 @@ class PreparedFitMixin:
         return self._luts
 
     def _memo(self, name, fn, *args):
-        """members of a batch share grids: identical device builds (same inputs, byte for byte) are done once per fit call"""
+        """Members of a batch share grids: identical device builds (same inputs, byte for byte) are done once per fit call -- and,
+        as upstream keeps its fit matrices while the sampling does not change (the `_recalc_*` flags of drt1d.py:5540-5660), what a
+        call used is still there for the NEXT call on this object: a map's loop over observations of one protocol builds its
+        penalty / variance / impedance blocks once.  Only what the last call used is kept (one protocol's matrices)."""
         key = (name,) + tuple(a.tobytes() if isinstance(a, np.ndarray) else a for a in args)
         memo = self.__dict__.setdefault('_build_memo', {})
         if key not in memo:
-            memo[key] = fn()
+            kept = self.__dict__.get('_build_memo_kept', {})
+            memo[key] = kept[key] if key in kept else fn()
         return memo[key]
 
     def _vz_strength(self, sample_times, frequencies, step_times, vz_offset_eps):
@@ -242,7 +246,9 @@ class PreparedFitMixin:
             # independent of the measured values: one build per batch
             blocks.append(self._memo('eis_block', build_eis_block, frequencies, basis_tau, eps, integrate_mode, n,
                                      float(kw['inductance_scale']), float(kw['capacitance_scale']), series_neg,
-                                     dop_scale if dop_scale is not None else 0))
+                                     dop_scale if dop_scale is not None else 0, str(sorted(sp.items())),
+                                     self.basis_nu if self.fit_dop else 0, float(self.nu_epsilon) if self.fit_dop else 0.0,
+                                     int(self.frequency_precision)))
             z_scaled = z / impedance_scale
             rows.append(np.concatenate([z_scaled.real, z_scaled.imag]))
         rzm = blocks[0] if len(blocks) == 1 else np.vstack(blocks)
@@ -543,7 +549,7 @@ class PreparedFitMixin:
         ctx = self._context if self._context is not None else _ffi.get_context(self.device)
         self._build_memo = {}
         preps = [self._prepare_measurement(ctx, *meas, kw, ckw, hypers) for meas in measurements]
-        self._build_memo = {}
+        self._build_memo_kept, self._build_memo = self._build_memo, {}        # (what this call used, for the next one)
         for pr in preps:        # the loop's inputs before any host- or device-side rescale (diagnostics, tests)
             pr['rzv_initial'], pr['rzm_initial'] = pr['rzv'], pr['rzm']
         if ckw['solve_rp'] and kw['scale_data']:

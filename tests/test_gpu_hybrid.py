@@ -956,3 +956,29 @@ def test_posterior_entry_points_after_a_warm_restart_with_row_factors():
         assert np.abs(res["q_vector"][0] - q_ref).max() <= 1e-9 * np.abs(q_ref).max()
         cov, ok = plan.param_cov(0)
         assert ok and np.abs(cov - np.linalg.inv(p_ref)).max() <= 1e-7 * np.abs(np.linalg.inv(p_ref)).max()
+
+
+def test_protocol_matrices_are_kept_between_calls_and_rebuilt_when_the_sampling_changes():
+    """the penalty / variance / impedance blocks of a protocol are built once per DRT object (upstream: the _recalc flags): a second
+    fit of the same sampling reuses the SAME arrays and gives the same bits as a fresh object; another frequency grid rebuilds them"""
+    from hipdrt import synth
+    from hipdrt.models import DRT
+    m = synth.hybrid_measurement(seed=11, n_post=80, nf=25)
+    m2 = synth.hybrid_measurement(seed=12, n_post=80, nf=25)
+    d = DRT(warn=False)
+    d.fit_hybrid(*m)
+    vmm1, pen1 = d.qphb_params["vmm"], d.qphb_params["penalty_matrices"]["m1"]
+    d.fit_hybrid(*m2)
+    assert d.qphb_params["vmm"] is vmm1                                  # kept
+    fresh = DRT(warn=False)
+    fresh.fit_hybrid(*m2)
+    np.testing.assert_array_equal(d.fit_parameters["x"], fresh.fit_parameters["x"])
+    np.testing.assert_array_equal(d.qphb_params["vmm"], fresh.qphb_params["vmm"])
+    np.testing.assert_array_equal(d.qphb_params["penalty_matrices"]["m1"], pen1)
+    m3 = synth.hybrid_measurement(seed=12, n_post=80, nf=31)             # another frequency grid: everything is rebuilt
+    d.fit_hybrid(*m3)
+    assert d.qphb_params["vmm"] is not vmm1 and d.qphb_params["vmm"].shape != vmm1.shape
+    fresh3 = DRT(warn=False)
+    fresh3.fit_hybrid(*m3)
+    np.testing.assert_array_equal(d.fit_parameters["x"], fresh3.fit_parameters["x"])
+    assert len(d._build_memo_kept) <= 6                                  # one protocol's builds, not a growing cache

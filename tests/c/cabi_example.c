@@ -35,6 +35,15 @@ int main(void) {
                                   NULL, 1000, &are[0][0], &aim[0][0]));
     for (int r = 0; r < 4; ++r)
         for (int c = 0; c < 6; ++c) printf("a %d %d %.17g %.17g\n", r, c, are[r][c], aim[r][c]);
+    /* round 6: the potentiostatic delta response (two voltage steps, 3 samples x 2 time constants) and what a staged
+     * 256 x 512 spectrum costs a plan */
+    const double times[3] = {0.5, 1.5, 3.0}, ptau[2] = {0.5, 2.0}, st[2] = {1.0, 2.0}, sa[2] = {1e-3, -2e-3};
+    double pa[3][2];
+    CHECK(hipdrt_response_matrix_variant(ctx, times, 3, ptau, 2, st, sa, NULL, 2, HIPDRT_RESPONSE_POT, 0.0, 0, &pa[0][0], NULL));
+    for (int r = 0; r < 3; ++r) printf("pot %d %.17g %.17g\n", r, pa[r][0], pa[r][1]);
+    long long per = 0;
+    CHECK(hipdrt_plan_bytes_per_spectrum(256, 512, 2, &per));
+    printf("bytes_per_spectrum %lld\n", per);
     CHECK(hipdrt_destroy(ctx));
     return 0;
 }

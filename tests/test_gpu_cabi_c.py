@@ -47,3 +47,10 @@ def test_c_example_runs_and_matches_the_checker(tmp_path):
     got = np.array([[float(v) for v in line.split()[3:5]] for line in out[3:27]]).reshape(4, 6, 2)
     np.testing.assert_allclose(got[..., 0], a_re, rtol=1e-12, atol=1e-300)
     np.testing.assert_allclose(got[..., 1], a_im, rtol=1e-12, atol=1e-300)
+    # potentiostatic response (mat1d.py:114-118): exp(-(t - t_k) / tau) * unit_step(t, t_k) * size_k summed over the steps
+    times, ptau, st, sa = np.array([0.5, 1.5, 3.0]), np.array([0.5, 2.0]), (1.0, 2.0), (1e-3, -2e-3)
+    want = sum(np.where(times[:, None] >= t_k, np.exp(-(times[:, None] - t_k) / ptau[None, :]) * s_k, 0.0) for t_k, s_k in zip(st, sa))
+    pot = np.array([[float(v) for v in line.split()[2:4]] for line in out[27:30]])
+    assert not pot[0].any()
+    np.testing.assert_allclose(pot, want, rtol=1e-13, atol=0)
+    assert out[30].split()[0] == "bytes_per_spectrum" and 4.7e6 < int(out[30].split()[1]) < 5.1e6
